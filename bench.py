@@ -1,0 +1,296 @@
+#!/usr/bin/env python
+"""Benchmark of the reranker scoring hot path on MI355X (BASELINE.json metric:
+query-doc pairs scored/sec at 1/2/4/8 GPUs).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic candidate lists already
+resident in HBM: by default BASELINE.json configs[1] — KNRM inference, qlen 4, dlen 800,
+GloVe-shaped 400,001 x 300 fp32 table, 1000 docs/query, 64 queries per step per GPU
+(SURVEY.md §8d "Config 2").  Multi-GPU: queries are sharded over ranks (weak scaling: every
+rank scores its own 64 queries per step) and each step ends with one RCCL all-gather of the
+score vectors.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides: MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def algorithmic_bytes_per_pair(model, Q, L, D):
+    """ids int64 + one fp32 embedding row per term + fp32 score (+ idf for DRMM)."""
+    b = L * (8 + 4 * D) + Q * (8 + 4 * D) + 4
+    return b + (4 * Q if model == "drmm" else 0)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="knrm", choices=["knrm", "drmm"])
+    ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU")
+    ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
+    ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
+    ap.add_argument("--vocab", type=int, default=400001)
+    ap.add_argument("--dim", type=int, default=300)
+    ap.add_argument("--uniform-ids", action="store_true", help="uniform instead of Zipf(1.1) term ids (HBM-bound case)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from types import SimpleNamespace
+
+    from capreolus_amd import engine, synthetic
+    from capreolus_amd.reranker import DRMM, KNRM
+
+    Q, L, V, D = 4, 800, args.vocab, args.dim
+    n_pairs = args.queries * args.docs
+    # table: seeded the same on every rank (replicated); data: seeded per rank
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    emb = torch.randn((V, D), generator=g, device=dev) * 0.4
+    emb[0] = 0
+    batch = synthetic.make_candidate_list_torch(args.queries, args.docs, V, dev, seed=1 + rank, maxqlen=Q, maxdoclen=L,
+                                                uniform_ids=args.uniform_ids)
+    if args.model == "drmm":
+        batch["query"] = batch["query"].clamp(min=0)
+
+    torch.manual_seed(0)
+    stub = SimpleNamespace(embeddings=np.zeros((2, D), dtype=np.float32))
+    rr = (KNRM if args.model == "knrm" else DRMM)({}, stub)
+    m = rr.build_model().to(dev).eval()
+    m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
+    w = m.embedding.weight
+    packed = m._packed.get(w)
+    out = torch.empty(n_pairs, dtype=torch.float32, device=dev)
+    gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if world > 1 else None
+
+    launch = args.launch_docs or n_pairs
+    slices = [(i, min(i + launch, n_pairs)) for i in range(0, n_pairs, launch)]
+    q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
+
+    if args.model == "knrm":
+        mu, sigma = m.kernels.stacked()
+        w1, b1 = m.combine[0].weight.detach().contiguous(), m.combine[0].bias.detach()
+
+        def launch_one(lo, hi):
+            engine.knrm_forward(q_all[lo:hi], d_all[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+    else:
+        edges = m._bin_edges(dev)
+        gw = m.gates.weight.detach().contiguous().view(-1)
+        f0w, f0b = m.ffw[0].weight.detach().contiguous(), m.ffw[0].bias.detach()
+        f2w, f2b = m.ffw[2].weight.detach().contiguous().view(-1), m.ffw[2].bias.detach()
+        ow, ob = m.output_layer.weight.detach().view(-1), m.output_layer.bias.detach()
+
+        def launch_one(lo, hi):
+            engine.drmm_forward(q_all[lo:hi], d_all[lo:hi], idf_all[lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
+                                f2w, f2b, ow, ob, out=out[lo:hi], check=False)
+
+    def step():
+        for lo, hi in slices:
+            launch_one(lo, hi)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    engine.status_word(dev).raise_if_set()
+    assert torch.isfinite(out).all()
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream around each launch --
+    evs = []
+    for _ in range(max(3, min(args.steps, 10))):
+        for lo, hi in slices:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch_one(lo, hi)
+            e1.record()
+            evs.append((e0, e1, hi - lo))
+    torch.cuda.synchronize()
+    kern_s = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) * 1e-3 / len(evs)
+    kern_pairs = sum(n for _, _, n in evs) / len(evs)
+    abytes = algorithmic_bytes_per_pair(args.model, Q, L, D)
+    achieved = kern_pairs * abytes / kern_s / 1e9
+    nonpad = float((d_all > 0).sum().item()) / n_pairs
+    real_bytes = (L * 8 + (nonpad + Q) * (4 * (packed.numel() // V)) + 4) * kern_pairs
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", f"{args.model}_hbm_traffic.json")
+    if os.path.exists(tfile) and not args.uniform_ids and args.launch_docs == 0 and args.queries == 64:
+        with open(tfile) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    rec = {
+        "metric": "query-doc pairs scored/sec",
+        "value": n_pairs * world * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.model.upper()} inference (BASELINE.json configs[{1 if args.model == 'knrm' else 2}]): qlen={Q} dlen={L} "
+                        f"embed={D} vocab={V}, {args.docs} docs/query x {args.queries} queries per step per GPU, "
+                        f"{'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, lognormal doc lengths, "
+                        f"{len(slices)} launch(es) per step",
+            "pairs_per_step_per_gpu": n_pairs,
+            "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"{args.model}_forward_kernel<5>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_pair": abytes,
+            "pairs_per_launch": kern_pairs,
+            "kernel_ms": kern_s * 1e3,
+            "note": "achieved = SURVEY §8(d) bytes (all L positions x fp32 row) / event-timed kernel duration; pads and OOV "
+                    "terms are scored in closed form without a gather, so bytes actually requested are achieved_gathered",
+            "achieved_gathered": real_bytes / kern_s / 1e9,
+            "mean_nonpad_terms_per_doc": nonpad,
+        },
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        rec["cpu_baseline"] = cpu_baseline(args, m, batch, emb, Q, L, D)
+    print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, m, batch, emb, Q, L, D):
+    """The CPU oracle (oracle/interaction_oracle.c, OpenMP over pairs) timed on this box's host cores on a
+    bounded sample of the same workload; also the ATen op-sequence port for reference."""
+    from oracle import cpu as oracle
+    from oracle import torch_port
+
+    cores = os.cpu_count() or 1
+    n = args.cpu_pairs or min(batch["query"].shape[0], 2000 * max(1, cores // 4))
+    q = batch["query"][:n].cpu().numpy()
+    d = batch["posdoc"][:n].cpu().numpy()
+    idf = batch["query_idf"][:n].cpu().numpy()
+    emb_h = emb.cpu().numpy()
+    packed = oracle.pack(emb_h)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    if args.model == "knrm":
+        mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+
+        def run():
+            return oracle.knrm(q, d, packed, D, mu, sigma, sd["combine.0.weight"], sd["combine.0.bias"])[0]
+    else:
+        edges = torch.linspace(-1, 1, 30)[1:].numpy()
+
+        def run():
+            return oracle.drmm(q, d, idf, packed, D, edges, "LCH", "IDF", sd["gates.weight"], emb_h, sd["ffw.0.weight"],
+                               sd["ffw.0.bias"], sd["ffw.2.weight"], sd["ffw.2.bias"], sd["output_layer.weight"],
+                               sd["output_layer.bias"])[0]
+
+    run()  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        run()
+        reps += 1
+        if time.perf_counter() - t0 > 8.0 or reps >= 5:
+            break
+    c_rate = n * reps / (time.perf_counter() - t0)
+
+    # ATen port (what the reference executes on CPU): batches of 1000 pairs
+    te = torch.as_tensor(emb_h)
+    tq, td, tidf = torch.as_tensor(q), torch.as_tensor(d), torch.as_tensor(idf)
+    torch.set_num_threads(cores)
+    nb = min(n, 4000)
+    with torch.no_grad():
+        if args.model == "knrm":
+            tmu, tsig = torch.as_tensor(mu), torch.as_tensor(sigma)
+            tw, tb = torch.as_tensor(sd["combine.0.weight"]), torch.as_tensor(sd["combine.0.bias"])
+
+            def trun(lo, hi):
+                return torch_port.knrm(te, tq[lo:hi], td[lo:hi], tmu, tsig, tw, tb)
+        else:
+            ts = {k: torch.as_tensor(v) for k, v in sd.items()}
+
+            def trun(lo, hi):
+                return torch_port.drmm(te, tq[lo:hi], td[lo:hi], tidf[lo:hi], 29, "LCH", "IDF", ts["gates.weight"],
+                                       ts["ffw.0.weight"], ts["ffw.0.bias"], ts["ffw.2.weight"], ts["ffw.2.bias"],
+                                       ts["output_layer.weight"], ts["output_layer.bias"])
+        trun(0, min(256, nb))
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 8.0:
+            for lo in range(0, nb, 1000):
+                trun(lo, min(lo + 1000, nb))
+                done += min(lo + 1000, nb) - lo
+                if time.perf_counter() - t0 > 8.0:
+                    break
+    t_rate = done / (time.perf_counter() - t0)
+    return {
+        "value": c_rate,
+        "unit": "pairs/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n} pairs of the step's batch, oracle/interaction_oracle.c with OpenMP over pairs ({reps} repetitions)",
+        "aten_port_value": t_rate,
+        "aten_port_note": f"oracle/torch_port.py (the reference's ATen op sequence) on {cores} threads, batches of 1000 pairs",
+    }
+
+
+if __name__ == "__main__":
+    main()

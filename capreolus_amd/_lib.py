@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI library (include/capreolus_amd.h).
+
+There is no fallback: if csrc/libcapreolus_amd.so is missing or does not export every declared
+symbol the import of the scoring engine fails loudly (the reference's prediction path also fails
+loudly, capreolus/sampler/__init__.py:230-233).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcapreolus_amd.so")
+
+OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
+STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV = 1, 2, 4
+
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/capreolus_amd.h declares
+SIGNATURES = {
+    "capamd_version": (_i, []),
+    "capamd_arch": (ctypes.c_char_p, []),
+    "capamd_packed_row_stride": (_i64, [_i]),
+    "capamd_packed_table_bytes": (_i64, [_i64, _i]),
+    "capamd_pack_embeddings": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),
+    "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
+    "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "capamd_drmm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a non-zero CAPAMD_ERR_* code."""
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP scoring library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or capreolus_amd/csrc/build.py). "
+            "There is no CPU fallback for the scoring path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+_ERR_NAMES = {ERR_ARG: "CAPAMD_ERR_ARG", ERR_ALIGN: "CAPAMD_ERR_ALIGN", ERR_LAUNCH: "CAPAMD_ERR_LAUNCH",
+              ERR_WORKSPACE: "CAPAMD_ERR_WORKSPACE"}
+
+
+def check(rc, what):
+    if rc != OK:
+        raise EngineError(f"{what} failed with {_ERR_NAMES.get(rc, rc)}")

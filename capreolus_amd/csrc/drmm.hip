@@ -1,0 +1,233 @@
+// Fused DRMM forward for gfx950: gather -> cosine interaction -> matching histogram (integer
+// bin counts in LDS) -> CH/NH/LCH -> per-term feed-forward net -> IDF/TV term gate -> score.
+//
+// Reference semantics: DRMM_class._hist_map / _term_gate / forward
+// (capreolus/reranker/DRMM.py:41-81, :83-99, :101-116) on SimilarityMatrix (common.py:143-182).
+//
+// Same work layout as knrm.hip (one workgroup per pair, 16 lanes per document term, real terms
+// compacted in LDS).  What differs is the back end:
+//   * bin(sim) = first i with sim < edge_i, else none (DRMM.py:62-69 builds this as differences of
+//     cumulative counts); an arithmetic guess is corrected against the fp32 edge table so the
+//     comparisons are exactly the reference's `sim < edge`; the exact-match bin counts
+//     0.999 < sim < 1.001 (DRMM.py:66).  Counts are integers accumulated with LDS atomics, so the
+//     result does not depend on the order terms are visited.
+//   * pad document positions carry +1e7 in the reference (DRMM.py:57) -> they fall in no bin and
+//     are skipped; OOV document terms (id < 0) have sim exactly 0 -> added to bin(0) in closed form.
+#include "capreolus_amd.h"
+#include "interaction.cuh"
+
+using namespace capamd;
+
+namespace {
+
+constexpr int kMaxBins = 64;   // nbins + 1 <= 64
+constexpr int kMaxNodes = 64;
+constexpr int kMaxQ = 32;
+
+struct DrmmArgs {
+  const int64_t* q_ids;
+  const int64_t* d_ids;
+  const float* idf;
+  int B, Q, L;
+  const float* packed;
+  int64_t V;
+  int D;
+  const float* edges;
+  int nbins, hist_type, gate_type;
+  const float* gate_w;
+  const float* emb_raw;
+  int64_t ld;
+  const float* w1;
+  const float* b1;
+  int nodes;
+  const float* w2;
+  const float* b2;
+  const float* out_w;
+  const float* out_b;
+  float* out;
+  int32_t* counts_out;
+  int* status;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
+  int bi = (int)floorf((x + 1.f) * (0.5f * (float)nbins));
+  bi = bi < 0 ? 0 : (bi > nbins ? nbins : bi);
+  while (bi > 0 && x < edges[bi - 1]) --bi;
+  while (bi < nbins && !(x < edges[bi])) ++bi;
+  return bi;  // == nbins: at or above the last edge (1.0): no regular bin
+}
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void drmm_forward_kernel(DrmmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  const int tok_cap = (a.L + 3) & ~3;
+  int* hist = tok + tok_cap;                                   // [kQT][kMaxBins]
+  float* edges = reinterpret_cast<float*>(hist + kQT * kMaxBins);  // [kMaxBins]
+  float* zlds = edges + kMaxBins;                              // [kMaxQ]
+  float* glds = zlds + kMaxQ;                                  // [kMaxQ]
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [8]: 0..3 real counts, 4..7 oov counts
+
+  const int tid = threadIdx.x;
+  const int lane16 = tid & 15;
+  const int g = tid >> 4;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int b = blockIdx.x;
+  const int NB = a.nbins + 1;
+  const int64_t* qrow = a.q_ids + (int64_t)b * a.Q;
+  const int64_t* drow = a.d_ids + (int64_t)b * a.L;
+
+  if (tid < a.nbins) edges[tid] = a.edges[tid];
+
+  // ---- compact real document terms; count OOV terms --------------------------------------
+  int n_real = 0, n_oov = 0;
+  for (int base = 0; base < a.L; base += kThreads) {
+    const int j = base + tid;
+    int64_t did = (j < a.L) ? drow[j] : 0;
+    if (did >= a.V) {
+      atomicOr(a.status, kErrDocIdRange);
+      did = 0;
+    }
+    const bool real = did > 0;
+    const unsigned long long m = __ballot(real);
+    const unsigned long long mo = __ballot(did < 0);
+    if (lane == 0) {
+      wave_cnt[wave] = __popcll(m);
+      wave_cnt[4 + wave] = __popcll(mo);
+    }
+    __syncthreads();
+    int off = n_real;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (real) tok[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)did;
+    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+    __syncthreads();
+  }
+
+  for (int q0 = 0; q0 < a.Q; q0 += kQT) {
+    // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
+    if (tid < kQT && q0 + tid < a.Q && qrow[q0 + tid] < 0) atomicOr(a.status, kErrQueryOOV);
+    QueryPass<NV> qp;
+    load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+    if (qp.id_my < 0) qp.id_my = 0;
+    for (int i = tid; i < kQT * kMaxBins; i += kThreads) hist[i] = 0;
+    __syncthreads();
+
+    for (int t0 = g; t0 < n_real; t0 += 2 * kGroupsPerWG) {
+      const int t1 = t0 + kGroupsPerWG;
+      const bool has1 = t1 < n_real;
+      RowRegs<NV> d0, d1;
+      load_row<NV>(a.packed, tok[t0], lane16, d0);
+      load_row<NV>(a.packed, has1 ? tok[t1] : 0, lane16, d1);
+      const float x0 = row_sim_my<NV>(d0, qp, lane16);
+      const float x1 = row_sim_my<NV>(d1, qp, lane16);
+      if (lane16 < kQT) {
+        int* h = hist + lane16 * kMaxBins;
+        const int b0 = bin_of(x0, edges, a.nbins);
+        if (b0 < a.nbins) atomicAdd(&h[b0], 1);
+        if (x0 > 0.999f && x0 < 1.001f) atomicAdd(&h[a.nbins], 1);
+        if (has1) {
+          const int b1 = bin_of(x1, edges, a.nbins);
+          if (b1 < a.nbins) atomicAdd(&h[b1], 1);
+          if (x1 > 0.999f && x1 < 1.001f) atomicAdd(&h[a.nbins], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < kQT && n_oov > 0) {  // OOV document terms: sim == 0 exactly
+      const int bz = bin_of(0.f, edges, a.nbins);
+      if (bz < a.nbins) hist[tid * kMaxBins + bz] += n_oov;
+    }
+    __syncthreads();
+
+    // ---- per query term (one wave each): histogram transform + feed-forward net ------------
+    const int q = q0 + wave;
+    if (q < a.Q) {
+      const int* h = hist + wave * kMaxBins;
+      if (a.counts_out && lane < NB) a.counts_out[((int64_t)b * a.Q + q) * NB + lane] = h[lane];
+      float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;  // DRMM.py:71
+      if (a.hist_type == 1) {                              // NH (DRMM.py:72-74)
+        const float hs = wave_sum(hv);
+        hv = hv / hs;
+      } else if (a.hist_type == 2) {                       // LCH (DRMM.py:75-76)
+        hv = lane < NB ? logf(hv) : 0.f;
+      }
+      // ffw (DRMM.py:25): lane n holds node n
+      float acc = lane < a.nodes ? a.b1[lane] : 0.f;
+      for (int i = 0; i < NB; ++i) {
+        const float hi = __shfl(hv, i, 64);
+        if (lane < a.nodes) acc = __builtin_fmaf(a.w1[lane * NB + i], hi, acc);
+      }
+      const float contrib = lane < a.nodes ? a.w2[lane] * tanhf(acc) : 0.f;
+      const float o = wave_sum(contrib) + a.b2[0];
+      // term gate logit (DRMM.py:83-95)
+      float gl;
+      const int64_t qid = qrow[q];
+      if (a.gate_type == 0) {
+        gl = a.gate_w[0] * a.idf[(int64_t)b * a.Q + q];
+      } else {
+        const float* e = a.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * a.ld;
+        float p = 0.f;
+        for (int c = lane; c < a.D; c += 64) p = __builtin_fmaf(a.gate_w[c], e[c], p);
+        gl = wave_sum(p);
+      }
+      if (qid == 0) gl += -1e7f;
+      if (lane == 0) {
+        zlds[q] = tanhf(o);
+        glds[q] = gl;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (tid == 0) {  // softmax gate + output layer (DRMM.py:97-98, :112-114)
+    float m = glds[0];
+    for (int q = 1; q < a.Q; ++q) m = fmaxf(m, glds[q]);
+    float den = 0.f, num = 0.f;
+    for (int q = 0; q < a.Q; ++q) {
+      const float e = expf(glds[q] - m);
+      den += e;
+      num = __builtin_fmaf(e, zlds[q], num);
+    }
+    a.out[b] = __builtin_fmaf(a.out_w[0], num / den, a.out_b[0]);
+  }
+}
+
+}  // namespace
+
+extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
+                                   const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type,
+                                   int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
+                                   const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
+                                   const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+  if (!q_ids || !d_ids || !idf || !packed || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out ||
+      !status)
+    return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (nbins < 1 || nbins + 1 > kMaxBins || nodes < 1 || nodes > kMaxNodes) return CAPAMD_ERR_ARG;
+  if (hist_type < 0 || hist_type > 2 || gate_type < 0 || gate_type > 1) return CAPAMD_ERR_ARG;
+  if (gate_type == 1 && (!emb_raw || ld < D)) return CAPAMD_ERR_ARG;
+  if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  if (B == 0) return CAPAMD_OK;
+  DrmmArgs a{q_ids, d_ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
+             w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(NV_) hipLaunchKernelGGL(drmm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(5); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}

@@ -1,0 +1,138 @@
+// Shared front end of the KNRM / DRMM hot path for gfx950 (MI355X, wave64).
+//
+// What it computes is the reference's SimilarityMatrix (capreolus/reranker/common.py:143-182):
+//   sim[q][j] = exact(q,j) + cos(q,j)
+//   cos  = <E[q], E[d_j]> / ((|E[q]|+1e-9) * (|E[d_j]|+1e-9)),   0 where q<=0 or d_j<=0   (common.py:160-167)
+//   exact= 1 where q == d_j < 0 (OOV ids are negative),           0 elsewhere               (common.py:155-158,179)
+//
+// How it computes it (the documented arithmetic order; oracle/interaction_oracle.c restates it
+// bit for bit):
+//   * the embedding table is re-laid out once ("packed"): row stride RS = 64*NV floats with
+//     NV = ceil((D+1)/64); floats [D, RS-1) are 0 and float RS-1 holds den = |row|_2 + 1e-9f.
+//     A row is then NV*4 aligned 64-byte pieces -> one 16-lane group fetches it with NV float4
+//     loads per lane, 256 contiguous bytes per group per load (row start is 256-B aligned).
+//   * a doc term is owned by one 16-lane group (a DPP "row").  Lane l holds floats
+//     {(i*16+l)*4 .. +3 : i < NV} of the row and of each of the (up to) 4 query rows.
+//     per-lane partial:  p = fma(d.x,q.x,p); p = fma(d.y,q.y,p); p = fma(d.z,q.z,p); p = fma(d.w,q.w,p)
+//                        for i = 0..NV-1 in that order, starting from p = 0
+//     group all-reduce:  p += p[l^1]; p += p[l^2]; p += p[half-mirror]; p += p[mirror]
+//                        (== the balanced tree ((p0+p1)+(p2+p3)) + ... over the 16 lane partials;
+//                         every lane ends with the same bits because fp add is commutative)
+//     sim = p / (qden * dden)     IEEE fp32 multiply then correctly-rounded divide
+//   * pads / OOV doc terms are never gathered: their sim is exactly 0 (or 1 for an OOV exact
+//     match) and callers add their contribution in closed form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace capamd {
+
+constexpr int kGroup = 16;        // lanes per doc term (one DPP row)
+constexpr int kThreads = 256;     // 4 waves per workgroup
+constexpr int kGroupsPerWG = kThreads / kGroup;
+constexpr int kQT = 4;            // query terms held in registers per pass
+constexpr int kMaxNV = 5;         // D <= 319
+
+// status word bits (device int32 the caller zeroes and reads back)
+constexpr int kErrDocIdRange = 1;    // doc id >= V
+constexpr int kErrQueryIdRange = 2;  // query id >= V
+constexpr int kErrQueryOOV = 4;      // negative query id where the reference model cannot take one (DRMM.py:109)
+
+__host__ __device__ inline int nv_for_dim(int D) { return (D + 1 + 63) / 64; }
+__host__ __device__ inline int row_stride_for_dim(int D) { return 64 * nv_for_dim(D); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce over the 16 lanes of a DPP row; order documented in the header comment.
+__device__ __forceinline__ float group_allreduce(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]  : lane ^ 1
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]  : lane ^ 2
+  v += dpp_mov<0x141>(v);  // row_half_mirror      : other quad of the 8-lane half
+  v += dpp_mov<0x140>(v);  // row_mirror           : other half of the row
+  return v;
+}
+
+template <int NV>
+struct RowRegs {
+  float4 v[NV];
+};
+
+// Loads this lane's slice of packed row `row` (row must be in [0, V)).
+template <int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ packed, int64_t row, int lane16, RowRegs<NV>& r) {
+  const float4* p = reinterpret_cast<const float4*>(packed + row * (int64_t)(64 * NV)) + lane16;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r.v[i] = p[i * 16];
+}
+
+// den of a row lives in the last float of the row = lane 15's last float4 .w
+template <int NV>
+__device__ __forceinline__ float row_den(const RowRegs<NV>& r) {
+  return __shfl(r.v[NV - 1].w, 15, 16);
+}
+
+template <int NV>
+__device__ __forceinline__ float lane_dot(const RowRegs<NV>& d, const RowRegs<NV>& q) {
+  float p = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    p = __builtin_fmaf(d.v[i].x, q.v[i].x, p);
+    p = __builtin_fmaf(d.v[i].y, q.v[i].y, p);
+    p = __builtin_fmaf(d.v[i].z, q.v[i].z, p);
+    p = __builtin_fmaf(d.v[i].w, q.v[i].w, p);
+  }
+  return p;
+}
+
+// Query side of one pass: up to kQT query terms, each lane holding its slice of every row.
+// Lane l of a group "owns" query term (l & 3) of the pass: it finishes that term's similarity.
+template <int NV>
+struct QueryPass {
+  RowRegs<NV> row[kQT];
+  int id[kQT];     // original ids (0 = pad, <0 = OOV); terms beyond Q are 0
+  float den_my;    // |E[q]|+1e-9 of the term this lane owns
+  int id_my;       // id of the term this lane owns
+};
+
+template <int NV>
+__device__ __forceinline__ void load_query_pass(const float* __restrict__ packed, const int64_t* __restrict__ qids,
+                                                int Q, int q0, int64_t V, int lane16, QueryPass<NV>& qp, int* status) {
+  const int myq = lane16 & 3;
+  qp.den_my = 1e-9f;
+  qp.id_my = 0;
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    int64_t id = (q0 + t < Q) ? qids[q0 + t] : 0;
+    if (id >= V) {
+      if (status) atomicOr(status, kErrQueryIdRange);
+      id = 0;
+    }
+    qp.id[t] = (int)id;
+    load_row<NV>(packed, id > 0 ? id : 0, lane16, qp.row[t]);
+    const float den = row_den<NV>(qp.row[t]);
+    if (myq == t) {
+      qp.den_my = den;
+      qp.id_my = (int)id;
+    }
+    if (lane16 == 15) qp.row[t].v[NV - 1].w = 0.f;  // keep the den slot out of the dot product
+  }
+}
+
+// Similarity of one gathered doc row (id > 0) against the query term this lane owns.  Lanes
+// l, l+4, l+8, l+12 of a group return the same bits.
+template <int NV>
+__device__ __forceinline__ float row_sim_my(const RowRegs<NV>& d, const QueryPass<NV>& qp, int lane16) {
+  const float dden = row_den<NV>(d);
+  float p[kQT];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) p[t] = group_allreduce(lane_dot<NV>(d, qp.row[t]));
+  const int myq = lane16 & 3;
+  const float pm = myq == 0 ? p[0] : myq == 1 ? p[1] : myq == 2 ? p[2] : p[3];
+  const float s = pm / (qp.den_my * dden);
+  return qp.id_my > 0 ? s : 0.f;
+}
+
+}  // namespace capamd

@@ -1,0 +1,232 @@
+// Fused KNRM forward for gfx950: gather -> cosine/exact-match interaction -> RBF kernel bank ->
+// sum over document -> masked log -> sum over query -> combine MLP, one workgroup per
+// (query, document) pair, nothing but the score written back.
+//
+// Reference semantics: KNRM_class.forward (capreolus/reranker/KNRM.py:39-55) on top of
+// SimilarityMatrix (common.py:143-182) and RbfKernelBank (common.py:224-250).
+//
+// Layout of the work
+//   workgroup  = 256 threads = 4 waves = 16 groups of 16 lanes; one pair per workgroup.
+//   phase 1    = the 800 document ids are read once (coalesced int64), real terms (id > 0) are
+//                compacted in document order into LDS; pads (id == 0) and OOV terms (id < 0)
+//                are only counted: their similarity is exactly 0 (or exactly 1 for an OOV exact
+//                match, common.py:155-158) so their kernel-pooling contribution is added in
+//                closed form  n0[q]*K_k(0) + n1[q]*K_k(1)   (KNRM.py:50 sums over ALL positions).
+//   phase 2    = group g walks compacted terms g, g+16, ...; each lane fetches its 16-byte
+//                pieces of the packed row (5 x float4 for D=300), 4 query rows stay in registers;
+//                16-lane DPP all-reduce gives the 4 dot products; lane l then owns query term
+//                l&3 and kernels (l>>2), (l>>2)+4, (l>>2)+8 -> 3 exp per lane per term.
+//   phase 3    = cross-group reduction through LDS in fixed order, log/mask/sum, combine.
+// HBM/L2 traffic per pair: L*8 B of ids + one packed row per real term; the [B,Q,L] similarity
+// and [B,K,Q,L] kernel tensors of the reference are never materialised.
+#include "capreolus_amd.h"
+#include "interaction.cuh"
+
+using namespace capamd;
+
+namespace {
+
+constexpr int kMaxK = 12;      // 3 kernel slots x 4 lane-rows
+constexpr int kMaxHidden = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct KnrmArgs {
+  const int64_t* q_ids;
+  const int64_t* d_ids;
+  int B, Q, L;
+  const float* packed;
+  int64_t V;
+  const float* mu;
+  const float* sigma;
+  int K;
+  const float* w1;
+  const float* b1;
+  int hidden;
+  const float* w2;
+  const float* b2;
+  int scoretanh;
+  float* out;
+  int* status;
+};
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void knrm_forward_kernel(KnrmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // carve: tok[L] | partial[16][16][4] | S/aux
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  const int tok_cap = (a.L + 3) & ~3;
+  float* partial = reinterpret_cast<float*>(tok + tok_cap);      // 1024 floats
+  float* Rlds = partial + kGroupsPerWG * kGroup * 4;             // 48
+  float* Flds = Rlds + 48;                                       // kMaxK (+pad to 16)
+  float* Hlds = Flds + 16;                                       // kMaxHidden
+  int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // 4 (+4 spare)
+  int* n_one = wave_cnt + 8;                                     // kQT per pass
+
+  const int tid = threadIdx.x;
+  const int lane16 = tid & 15;
+  const int g = tid >> 4;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int b = blockIdx.x;
+  const int64_t* qrow = a.q_ids + (int64_t)b * a.Q;
+  const int64_t* drow = a.d_ids + (int64_t)b * a.L;
+
+  // ---- phase 1: compact real document terms in order --------------------------------------
+  int n_real = 0;
+  for (int base = 0; base < a.L; base += kThreads) {
+    const int j = base + tid;
+    int64_t did = (j < a.L) ? drow[j] : 0;
+    if (did >= a.V) {
+      atomicOr(a.status, kErrDocIdRange);
+      did = 0;
+    }
+    const bool real = did > 0;
+    const unsigned long long m = __ballot(real);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_real;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (real) tok[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)did;
+    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int n_nonreal = a.L - n_real;
+
+  // per-lane kernel constants: lane owns query term (lane16 & 3), kernels krow + 4*s
+  const int krow = lane16 >> 2;
+  float mu_s[3], c_s[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int k = krow + 4 * s;
+    const float sg = k < a.K ? a.sigma[k] : 1.f;
+    mu_s[s] = k < a.K ? a.mu[k] : 0.f;
+    c_s[s] = k < a.K ? (-0.5f * kLog2e) / (sg * sg) : 0.f;
+  }
+  if (tid < 16) Flds[tid] = 0.f;
+
+  for (int q0 = 0; q0 < a.Q; q0 += kQT) {
+    QueryPass<NV> qp;
+    load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+    if (tid < kQT) n_one[tid] = 0;
+    __syncthreads();
+    // OOV exact matches (negative ids equal): rare, counted from the raw id row
+    {
+      bool any_oov_q = false;
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) any_oov_q |= qp.id[t] < 0;
+      if (any_oov_q) {
+        for (int j = tid; j < a.L; j += kThreads) {
+          const int64_t did = drow[j];
+          if (did < 0) {
+#pragma unroll
+            for (int t = 0; t < kQT; ++t)
+              if (qp.id[t] == (int)did && did > -2147483648LL) atomicAdd(&n_one[t], 1);
+          }
+        }
+      }
+    }
+
+    float acc[3] = {0.f, 0.f, 0.f};
+    float rowsum = 0.f;
+    for (int t0 = g; t0 < n_real; t0 += 2 * kGroupsPerWG) {
+      const int t1 = t0 + kGroupsPerWG;
+      const bool has1 = t1 < n_real;
+      RowRegs<NV> d0, d1;
+      load_row<NV>(a.packed, tok[t0], lane16, d0);
+      load_row<NV>(a.packed, has1 ? tok[t1] : 0, lane16, d1);
+      const float x0 = row_sim_my<NV>(d0, qp, lane16);
+      const float x1 = row_sim_my<NV>(d1, qp, lane16);
+      rowsum += x0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const float adj = x0 - mu_s[s];
+        acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+      }
+      if (has1) {
+        rowsum += x1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const float adj = x1 - mu_s[s];
+          acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+        }
+      }
+    }
+
+    // ---- phase 3: fixed-order cross-group reduction ---------------------------------------
+    *reinterpret_cast<float4*>(partial + (g * kGroup + lane16) * 4) = make_float4(acc[0], acc[1], acc[2], rowsum);
+    __syncthreads();
+    if (tid < 48) {
+      const int q = tid & 3, kk = tid >> 2;
+      const int src_lane = (kk & 3) * 4 + q, slot = kk >> 2;
+      float s = 0.f, rs = 0.f;
+      for (int gg = 0; gg < kGroupsPerWG; ++gg) {
+        s += partial[(gg * kGroup + src_lane) * 4 + slot];
+        rs += partial[(gg * kGroup + q) * 4 + 3];
+      }
+      float R = 0.f;
+      if (kk < a.K) {
+        const float mk = a.mu[kk], sg = a.sigma[kk];
+        const float ck = (-0.5f * kLog2e) / (sg * sg);
+        const int no = n_one[q];
+        const int nz = n_nonreal - no;
+        s += (float)nz * __builtin_amdgcn_exp2f(mk * mk * ck);
+        s += (float)no * __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * ck);
+        rs += (float)no;
+        // KNRM.py:51-52: mask = (sum_j sim != 0); where(mask, log(result + 1e-6), 0)
+        R = (rs != 0.f) ? logf(s + 1e-6f) : 0.f;
+      }
+      Rlds[tid] = R;
+    }
+    __syncthreads();
+    if (tid < kMaxK) Flds[tid] += ((Rlds[tid * 4 + 0] + Rlds[tid * 4 + 1]) + Rlds[tid * 4 + 2]) + Rlds[tid * 4 + 3];
+    __syncthreads();
+  }
+
+  // ---- combine (KNRM.py:27-34, :54) ----------------------------------------------------------
+  if (a.hidden > 0) {
+    if (tid < a.hidden) {
+      float h = a.b1[tid];
+      for (int k = 0; k < a.K; ++k) h = __builtin_fmaf(a.w1[tid * a.K + k], Flds[k], h);
+      Hlds[tid] = tanhf(h);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float sc;
+    if (a.hidden > 0) {
+      sc = a.b2[0];
+      for (int j = 0; j < a.hidden; ++j) sc = __builtin_fmaf(a.w2[j], Hlds[j], sc);
+    } else {
+      sc = a.b1[0];
+      for (int k = 0; k < a.K; ++k) sc = __builtin_fmaf(a.w1[k], Flds[k], sc);
+    }
+    if (a.scoretanh) sc = tanhf(sc);
+    a.out[b] = sc;
+  }
+}
+
+}  // namespace
+
+extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed,
+                                   int64_t V, int D, const float* mu, const float* sigma, int K, const float* w1,
+                                   const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
+                                   float* out, int* status, void* stream) {
+  if (!q_ids || !d_ids || !packed || !mu || !sigma || !w1 || !b1 || !out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || L < 1 || V < 1 || K < 1 || K > kMaxK || hidden < 0 || hidden > kMaxHidden) return CAPAMD_ERR_ARG;
+  if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
+  if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (B == 0) return CAPAMD_OK;
+  KnrmArgs a{q_ids, d_ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(NV_) hipLaunchKernelGGL(knrm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(5); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}

@@ -1,0 +1,155 @@
+"""Thin PyTorch plumbing over the C-ABI library: device memory, streams, error surfacing.
+
+PyTorch is used for exactly three things here: owning device buffers (caching allocator),
+naming the current HIP stream, and holding the model parameters.  All arithmetic of the
+scoring path happens inside libcapreolus_amd.so (capreolus_amd/csrc/*.hip).  There is no CPU
+or eager-PyTorch fallback: inputs that are not on a HIP device raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+HIST_TYPES = {"CH": 0, "NH": 1, "LCH": 2}
+GATE_TYPES = {"IDF": 0, "TV": 1}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "capreolus_amd scores on an MI355X only: got a tensor on %s. There is no CPU fallback; "
+                "move the batch and the model to 'cuda' (PytorchTrainer.predict does)." % t.device
+            )
+
+
+def _i64(t):
+    return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.to(torch.int64).contiguous()
+
+
+def _f32(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+class StatusWord:
+    """The device int32 the kernels OR data-dependent error bits into (include/capreolus_amd.h)."""
+
+    def __init__(self, device):
+        self.t = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def raise_if_set(self):
+        bits = int(self.t.item())  # synchronises, like the reference's .cpu() (trainer/pytorch.py:345)
+        if bits:
+            self.t.zero_()
+            msgs = []
+            if bits & _lib.STATUS_DOC_ID_RANGE:
+                msgs.append("a document term id is >= the embedding table size")
+            if bits & _lib.STATUS_QUERY_ID_RANGE:
+                msgs.append("a query term id is >= the embedding table size")
+            if bits & _lib.STATUS_QUERY_OOV:
+                msgs.append("DRMM cannot score an OOV (negative) query term id (reference DRMM.py:109 raises IndexError)")
+            raise IndexError("index out of range in self: " + "; ".join(msgs))
+
+
+_status_words = {}
+
+
+def status_word(device):
+    key = (device.type, device.index)
+    if key not in _status_words:
+        _status_words[key] = StatusWord(device)
+    return _status_words[key]
+
+
+class PackedEmbedding:
+    """The embedding table re-laid out for the gather kernels (capamd_pack_embeddings).
+
+    Re-packed whenever the source weight changes (tracked with the tensor's version counter and
+    storage pointer), so `load_weights` / fine-tuning never score against stale rows.
+    """
+
+    def __init__(self):
+        self._key = None
+        self.packed = None
+        self.V = self.D = 0
+
+    def get(self, weight):
+        _need_gpu(weight)
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index)
+        if key != self._key:
+            lib = _lib.load()
+            w = _f32(weight.detach())
+            V, D = w.shape
+            nbytes = lib.capamd_packed_table_bytes(V, D)
+            if nbytes < 0:
+                raise ValueError(f"embedding dimension {D} is not supported by the packed layout (D <= 319)")
+            packed = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.check(lib.capamd_pack_embeddings(_ptr(w), V, D, w.stride(0), _ptr(packed), _stream()), "capamd_pack_embeddings")
+            self.packed, self.V, self.D, self._key = packed, V, D, key
+        return self.packed
+
+
+def similarity_matrix(query, doc, packed, V, D, check=True):
+    """SimilarityMatrix.forward (reference common.py:170-182): fp32 [B, Q, L]."""
+    _need_gpu(query, doc, packed)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L = d.shape[1]
+    out = torch.empty((B, Q, L), dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    rc = _lib.load().capamd_similarity_matrix(_ptr(q), _ptr(d), B, Q, L, _ptr(packed), V, D, _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_similarity_matrix")
+    if check:
+        st.raise_if_set()
+    return out
+
+
+def knrm_forward(query, doc, packed, V, D, mu, sigma, w1, b1, w2=None, b2=None, scoretanh=False, out=None, check=True):
+    """KNRM_class.forward (reference KNRM.py:39-55): fp32 [B]."""
+    _need_gpu(query, doc, packed, mu, sigma, w1, b1, w2, b2)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L = d.shape[1]
+    if d.shape[0] != B:
+        raise AssertionError("query and document batch sizes differ")  # common.py:172
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    hidden = 0 if w2 is None else w1.shape[0]
+    st = status_word(q.device)
+    rc = _lib.load().capamd_knrm_forward(
+        _ptr(q), _ptr(d), B, Q, L, _ptr(packed), V, D, _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), hidden,
+        _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_knrm_forward")
+    if check:
+        st.raise_if_set()
+    return out
+
+
+def drmm_forward(query, doc, idf, packed, V, D, edges, hist_type, gate_type, gate_w, emb_raw, w1, b1, w2, b2, out_w, out_b,
+                 out=None, counts_out=None, check=True):
+    """DRMM_class.forward (reference DRMM.py:101-116): fp32 [B]."""
+    _need_gpu(query, doc, idf, packed, edges, gate_w, w1, b1, w2, b2, out_w, out_b)
+    q, d, idf = _i64(query), _i64(doc), _f32(idf)
+    B, Q = q.shape
+    L = d.shape[1]
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    ld = emb_raw.stride(0) if emb_raw is not None else 0
+    rc = _lib.load().capamd_drmm_forward(
+        _ptr(q), _ptr(d), _ptr(idf), B, Q, L, _ptr(packed), V, D, _ptr(edges), edges.numel(), HIST_TYPES[hist_type],
+        GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0], _ptr(w2), _ptr(b2),
+        _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(counts_out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmm_forward")
+    if check:
+        st.raise_if_set()
+    return out

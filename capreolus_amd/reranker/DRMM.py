@@ -1,0 +1,81 @@
+"""DRMM behind the reference plugin surface (capreolus/reranker/DRMM.py:119-155), scored by the
+fused gfx950 kernel (capreolus_amd/csrc/drmm.hip) through the C ABI.
+
+Parameter names follow the reference state_dict (``ffw.{0,2}.*``, ``gates.weight``,
+``output_layer.*``, ``embedding.weight``).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from . import Reranker
+
+
+class DRMM_class(nn.Module):
+    def __init__(self, extractor, config):
+        super().__init__()
+        self.nbins = config["nbins"]
+        self.nodes = config["nodes"]
+        self.hist_type = config["histType"]
+        self.gate_type = config["gateType"]
+        if self.hist_type not in engine.HIST_TYPES:
+            raise ValueError("Invalid value for histType: histType should be 'CH', 'NH', or 'LCH'")
+        weights = torch.as_tensor(np.asarray(extractor.embeddings, dtype=np.float32))
+        self.embedding = nn.Embedding(*weights.shape)
+        self.embedding.weight.data.copy_(weights)
+        self.embedding.weight.requires_grad = False
+        self.ffw = nn.Sequential(nn.Linear(self.nbins + 1, self.nodes), nn.Tanh(), nn.Linear(self.nodes, 1), nn.Tanh())
+        if self.gate_type == "IDF":
+            self.gates = nn.Linear(1, 1, bias=False)
+        elif self.gate_type == "TV":
+            self.gates = nn.Linear(weights.shape[1], 1, bias=False)
+        else:
+            raise ValueError("Invalid value for gateType: gateType should be either IDF or TV")
+        self.output_layer = nn.Linear(1, 1)
+        # MatchZoo-style initialisation, as the reference (DRMM.py:36-39)
+        nn.init.uniform_(self.ffw[0].weight, -0.1, 0.1)
+        nn.init.uniform_(self.ffw[2].weight, -0.1, 0.1)
+        nn.init.uniform_(self.gates.weight, -0.01, 0.01)
+        self._packed = engine.PackedEmbedding()
+        self._edges = None
+
+    def _bin_edges(self, device):
+        # same values the reference computes on the host: torch.linspace(-1, 1, nbins+1)[1:] (DRMM.py:63)
+        if self._edges is None or self._edges.device != device or self._edges.numel() != self.nbins:
+            self._edges = torch.linspace(-1, 1, self.nbins + 1)[1:].contiguous().to(device)
+        return self._edges
+
+    def forward(self, sentence, query_sentence, query_idf, counts_out=None):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError(
+                "capreolus_amd scores with hand-written inference kernels; the training step is not part of this "
+                "engine yet. Call under model.eval() / torch.no_grad() as PytorchTrainer.predict does."
+            )
+        w = self.embedding.weight
+        packed = self._packed.get(w)
+        out = engine.drmm_forward(
+            query_sentence, sentence, query_idf, packed, w.shape[0], w.shape[1], self._bin_edges(w.device), self.hist_type,
+            self.gate_type, self.gates.weight.detach().contiguous().view(-1), w.detach(), self.ffw[0].weight.detach().contiguous(),
+            self.ffw[0].bias.detach(), self.ffw[2].weight.detach().contiguous().view(-1), self.ffw[2].bias.detach(),
+            self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), counts_out=counts_out)
+        return out.view(-1, 1)
+
+
+class DRMM(Reranker):
+    """Guo et al., A Deep Relevance Matching Model for Ad-hoc Retrieval, CIKM'16 (reference DRMM.py:119-133)."""
+
+    module_name = "DRMM"
+    config_spec = {"nbins": 29, "nodes": 5, "histType": "LCH", "gateType": "IDF"}
+
+    def build_model(self):
+        if not hasattr(self, "model"):
+            self.model = DRMM_class(self.extractor, self.config)
+        return self.model
+
+    def score(self, d):
+        q, idf = d["query"], d["query_idf"]
+        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+
+    def test(self, d):
+        return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

@@ -1,0 +1,94 @@
+"""KNRM behind the reference plugin surface (capreolus/reranker/KNRM.py:58-101), scored by the
+fused gfx950 kernel (capreolus_amd/csrc/knrm.hip) through the C ABI.
+
+The nn.Module only *holds* parameters, under the reference's state_dict names
+(``kernels.kernels.{k}.mu|sigma``, ``embedding.weight``, ``combine.{0,2}.weight|bias`` —
+SURVEY.md §8b) so checkpoints interchange; its forward is one C-ABI call.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from . import Reranker
+
+_MUS = [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9, 1.0]  # reference KNRM.py:20
+_SIGMAS = [0.1] * 10 + [0.001]                                        # reference KNRM.py:21
+
+
+class _Rbf(nn.Module):
+    def __init__(self, mu, sigma, requires_grad):
+        super().__init__()
+        self.mu = nn.Parameter(torch.tensor(mu), requires_grad=requires_grad)
+        self.sigma = nn.Parameter(torch.tensor(sigma), requires_grad=requires_grad)
+
+
+class _RbfBank(nn.Module):
+    def __init__(self, mus, sigmas, requires_grad):
+        super().__init__()
+        self.kernels = nn.ModuleList([_Rbf(m, s, requires_grad) for m, s in zip(mus, sigmas)])
+
+    def count(self):
+        return len(self.kernels)
+
+    def stacked(self):
+        """(mu[K], sigma[K]) as contiguous device vectors, re-read from the live parameters."""
+        mu = torch.stack([k.mu.detach() for k in self.kernels]).float()
+        sigma = torch.stack([k.sigma.detach() for k in self.kernels]).float()
+        return mu, sigma
+
+
+class KNRM_class(nn.Module):
+    def __init__(self, extractor, config):
+        super().__init__()
+        self.p = config
+        self.kernels = _RbfBank(_MUS, _SIGMAS, requires_grad=config["gradkernels"])
+        weights = torch.as_tensor(np.asarray(extractor.embeddings, dtype=np.float32))
+        self.embedding = nn.Embedding(*weights.shape)
+        self.embedding.weight.data.copy_(weights)
+        self.embedding.weight.requires_grad = bool(config["finetune"])
+        K = self.kernels.count()
+        steps = [nn.Linear(K, 1)] if config["singlefc"] else [nn.Linear(K, 30), nn.Tanh(), nn.Linear(30, 1)]
+        if config["scoretanh"]:
+            steps.append(nn.Tanh())
+        self.combine = nn.Sequential(*steps)
+        self._packed = engine.PackedEmbedding()
+
+    def forward(self, doctoks, querytoks, query_idf=None):
+        """[B, 1] scores.  query_idf is accepted and ignored, as in the reference (KNRM.py:39)."""
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError(
+                "capreolus_amd scores with hand-written inference kernels; the training step (forward+backward) "
+                "is not part of this engine yet. Call under model.eval() / torch.no_grad() as PytorchTrainer.predict does."
+            )
+        w = self.embedding.weight
+        packed = self._packed.get(w)
+        mu, sigma = self.kernels.stacked()
+        lin1 = self.combine[0]
+        if self.p["singlefc"]:
+            w2 = b2 = None
+        else:
+            w2, b2 = self.combine[2].weight.detach(), self.combine[2].bias.detach()
+        out = engine.knrm_forward(
+            querytoks, doctoks, packed, w.shape[0], w.shape[1], mu, sigma, lin1.weight.detach().contiguous(),
+            lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"])
+        return out.view(-1, 1)
+
+
+class KNRM(Reranker):
+    """Xiong et al., End-to-End Neural Ad-hoc Ranking with Kernel Pooling, SIGIR'17 (reference KNRM.py:58-69)."""
+
+    module_name = "KNRM"
+    config_spec = {"gradkernels": True, "scoretanh": False, "singlefc": True, "finetune": False}
+
+    def build_model(self):
+        if not hasattr(self, "model"):
+            self.model = KNRM_class(self.extractor, self.config)
+        return self.model
+
+    def score(self, d):
+        q, idf = d["query"], d["query_idf"]
+        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+
+    def test(self, d):
+        return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

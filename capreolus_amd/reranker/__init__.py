@@ -1,0 +1,70 @@
+"""Reranker plugin surface, mirroring capreolus.reranker.Reranker (reference
+capreolus/reranker/__init__.py:7-55): ``build_model``, ``score(d)``, ``test(d)``,
+``save_weights`` / ``load_weights`` with the same checkpoint format (pickled state_dict minus
+``embedding.weight`` / ``_nosave_`` keys + ``<fn>.optimizer``), so weights trained with the
+reference load here and vice versa.
+
+profane (the reference's module-graph library) is not a dependency: a reranker is constructed
+directly from a config dict and an extractor-like object (anything with the attributes the model
+reads: ``embeddings`` for KNRM/DRMM, ``config`` for BERT-MaxP).
+"""
+import os
+import pickle
+
+
+class Reranker:
+    module_type = "reranker"
+    module_name = None
+    config_spec = {}  # key -> default (the reference's ConfigOption defaults)
+
+    def __init__(self, config=None, extractor=None, trainer=None):
+        cfg = dict(self.config_spec)
+        unknown = set(config or {}) - set(cfg)
+        if unknown:
+            raise ValueError(f"unknown config options for {self.module_name}: {sorted(unknown)}")
+        cfg.update(config or {})
+        self.config = cfg
+        self.extractor = extractor
+        self.trainer = trainer
+
+    def build_model(self):
+        raise NotImplementedError
+
+    def score(self, d):
+        raise NotImplementedError
+
+    def test(self, d):
+        raise NotImplementedError
+
+    def add_summary(self, summary_writer, niter):
+        for name, weight in self.model.named_parameters():
+            summary_writer.add_histogram(name, weight.data.cpu(), niter)
+
+    @staticmethod
+    def _saved_keys(state_dict):
+        return {k: v for k, v in state_dict.items() if "embedding.weight" not in k and "_nosave_" not in k}
+
+    def save_weights(self, weights_fn, optimizer):
+        weights_fn = os.fspath(weights_fn)
+        os.makedirs(os.path.dirname(weights_fn) or ".", exist_ok=True)
+        with open(weights_fn, "wb") as outf:
+            pickle.dump(self._saved_keys(self.model.state_dict()), outf, protocol=-1)
+        with open(weights_fn + ".optimizer", "wb") as outf:
+            pickle.dump(optimizer.state_dict(), outf, protocol=-1)
+
+    def load_weights(self, weights_fn, optimizer):
+        weights_fn = os.fspath(weights_fn)
+        with open(weights_fn, "rb") as f:
+            d = pickle.load(f)
+        missing = set(self._saved_keys(self.model.state_dict())) - set(d)
+        if missing:
+            raise RuntimeError("loading state_dict with keys that do not match current model: %s" % missing)
+        self.model.load_state_dict(d, strict=False)
+        with open(weights_fn + ".optimizer", "rb") as f:
+            optimizer.load_state_dict(pickle.load(f))
+
+
+from .KNRM import KNRM, KNRM_class  # noqa: E402,F401
+from .DRMM import DRMM, DRMM_class  # noqa: E402,F401
+
+registry = {"KNRM": KNRM, "DRMM": DRMM}

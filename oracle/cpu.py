@@ -1,0 +1,100 @@
+"""ctypes front end of oracle/liboracle.so (the C restatement in interaction_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  All arrays are host numpy arrays.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+HIST_TYPES = {"CH": 0, "NH": 1, "LCH": 2}
+GATE_TYPES = {"IDF": 0, "TV": 1}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "interaction_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.oracle_row_stride.restype = ctypes.c_int64
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def row_stride(D):
+    return int(lib().oracle_row_stride(ctypes.c_int(D)))
+
+
+def pack(emb):
+    emb = _f32(emb)
+    V, D = emb.shape
+    packed = np.empty((V, row_stride(D)), dtype=np.float32)
+    lib().oracle_pack(_p(emb), ctypes.c_int64(V), ctypes.c_int(D), ctypes.c_int64(D), _p(packed))
+    return packed
+
+
+def simmat(q_ids, d_ids, packed, D):
+    q_ids, d_ids = _i64(q_ids), _i64(d_ids)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    out = np.empty((B, Q, L), dtype=np.float32)
+    err = lib().oracle_simmat(_p(q_ids), _p(d_ids), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D, _p(out))
+    return out, err
+
+
+def knrm(q_ids, d_ids, packed, D, mu, sigma, w1, b1, w2=None, b2=None, scoretanh=False):
+    """w1 [1,K] & w2 None -> singlefc;  w1 [H,K], w2 [1,H] -> two layers (KNRM.py:27-34)."""
+    q_ids, d_ids = _i64(q_ids), _i64(d_ids)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    mu, sigma, w1, b1 = _f32(mu), _f32(sigma), _f32(w1), _f32(b1)
+    K = mu.shape[0]
+    hidden = 0
+    if w2 is not None:
+        w2, b2 = _f32(w2), _f32(b2)
+        hidden = w1.shape[0]
+    out = np.empty(B, dtype=np.float32)
+    err = lib().oracle_knrm(_p(q_ids), _p(d_ids), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D, _p(mu),
+                            _p(sigma), K, _p(w1), _p(b1), hidden, _p(w2), _p(b2), int(bool(scoretanh)), _p(out))
+    return out, err
+
+
+def drmm(q_ids, d_ids, idf, packed, D, edges, hist_type, gate_type, gate_w, emb_raw, w1, b1, w2, b2, out_w, out_b):
+    q_ids, d_ids, idf = _i64(q_ids), _i64(d_ids), _f32(idf)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    edges = _f32(edges)
+    nbins = edges.shape[0]
+    w1, b1, w2, b2 = _f32(w1), _f32(b1), _f32(w2).reshape(-1), _f32(b2).reshape(-1)
+    nodes = w1.shape[0]
+    gate_w, out_w, out_b = _f32(gate_w).reshape(-1), _f32(out_w).reshape(-1), _f32(out_b).reshape(-1)
+    emb_raw = None if emb_raw is None else _f32(emb_raw)
+    out = np.empty(B, dtype=np.float32)
+    counts = np.empty((B, Q, nbins + 1), dtype=np.int32)
+    err = lib().oracle_drmm(_p(q_ids), _p(d_ids), _p(idf), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D,
+                            _p(edges), nbins, HIST_TYPES[hist_type], GATE_TYPES[gate_type], _p(gate_w), _p(emb_raw),
+                            ctypes.c_int64(D), _p(w1), _p(b1), nodes, _p(w2), _p(b2), _p(out_w), _p(out_b), _p(out),
+                            _p(counts))
+    return out, counts, err

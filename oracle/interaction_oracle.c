@@ -1,0 +1,233 @@
+/*
+ * oracle/interaction_oracle.c — CPU restatement of the KNRM / DRMM scoring path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under capreolus_amd/ imports, links or executes this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as the
+ * checker / the timed CPU baseline.  The product path is the HIP library and fails loudly
+ * without it.
+ *
+ * Parity pinning: this restatement is checked against golden vectors produced by running the
+ * reference nn.Modules themselves (tests/golden/make_golden.py imports them from the reference
+ * tree in the build container); see tests/test_oracle_golden.py.  The reference's own test
+ * suite holds no known-answer vectors for this path.
+ *
+ * Each function cites the reference lines (under capreolus/) it restates.
+ *
+ * Arithmetic order.  The similarity front end (pack, dot, cosine) reproduces, operation for
+ * operation, the order documented in capreolus_amd/csrc/interaction.cuh — 16 "lane" partial
+ * fma chains combined by a balanced tree — so that GPU and oracle agree BIT FOR BIT on every
+ * similarity and therefore exactly on DRMM's integer bin counts.  Everything downstream of the
+ * similarities (kernel pooling sums, logs, MLPs) is done here in double precision with libm,
+ * i.e. more accurately than either the reference or the GPU; those are compared with a
+ * tolerance.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GROUP 16
+
+static int nv_for_dim(int D) { return (D + 1 + 63) / 64; }
+int64_t oracle_row_stride(int D) { return 64 * nv_for_dim(D); }
+
+/* balanced tree over 16 lane partials: ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... */
+static float tree16(const float* p) {
+  float q[4];
+  for (int j = 0; j < 4; ++j) q[j] = (p[4 * j] + p[4 * j + 1]) + (p[4 * j + 2] + p[4 * j + 3]);
+  return (q[0] + q[1]) + (q[2] + q[3]);
+}
+
+/* create_emb_layer + the norm half of cosine_similarity_matrix (reranker/common.py:279-288, :162-163):
+ * packed row = [row, 0..., |row|_2 + 1e-9]. */
+void oracle_pack(const float* emb, int64_t V, int D, int64_t ld, float* packed) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < V; ++r) {
+    const float* src = emb + r * ld;
+    float* dst = packed + r * RS;
+    memset(dst, 0, sizeof(float) * (size_t)RS);
+    memcpy(dst, src, sizeof(float) * (size_t)D);
+    float part[GROUP];
+    for (int l = 0; l < GROUP; ++l) {
+      float s = 0.f;
+      for (int i = 0; i < NV; ++i)
+        for (int c = 0; c < 4; ++c) {
+          const int f = (i * 16 + l) * 4 + c;
+          const float v = f < D ? src[f] : 0.f;
+          s = fmaf(v, v, s);
+        }
+      part[l] = s;
+    }
+    dst[RS - 1] = sqrtf(tree16(part)) + 1e-9f;
+  }
+}
+
+/* <E[q], E[d]> in the documented lane order; the den slot (last float) is excluded. */
+static float dot_rows(const float* q, const float* d, int NV) {
+  float part[GROUP];
+  const int last = 64 * NV - 1;
+  for (int l = 0; l < GROUP; ++l) {
+    float p = 0.f;
+    for (int i = 0; i < NV; ++i)
+      for (int c = 0; c < 4; ++c) {
+        const int f = (i * 16 + l) * 4 + c;
+        const float qv = f == last ? 0.f : q[f];
+        p = fmaf(d[f], qv, p);
+      }
+    part[l] = p;
+  }
+  return tree16(part);
+}
+
+/* SimilarityMatrix.forward (reranker/common.py:170-182): exact_match_matrix (:155-158) on
+ * clamp(max=0) ids + cosine_similarity_matrix (:160-167) on clamp(min=0) ids, padding removed
+ * (:149-153).  Returns 0 or a bitmask of {1: doc id >= V, 2: query id >= V}. */
+static float sim_one(int64_t qid, int64_t did, const float* packed, int64_t RS, int NV) {
+  if (did > 0) {
+    if (qid <= 0) return 0.f;
+    const float* qr = packed + qid * RS;
+    const float* dr = packed + did * RS;
+    return dot_rows(qr, dr, NV) / (qr[RS - 1] * dr[RS - 1]);
+  }
+  return (did < 0 && qid == did) ? 1.f : 0.f;
+}
+
+int oracle_simmat(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V, int D,
+                  float* sim_out) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      for (int j = 0; j < L; ++j) {
+        int64_t did = d_ids[(int64_t)b * L + j];
+        if (did >= V) { err |= 1; did = 0; }
+        sim_out[((int64_t)b * Q + q) * L + j] = sim_one(qid, did, packed, RS, NV);
+      }
+    }
+  return err;
+}
+
+/* KNRM_class.forward (reranker/KNRM.py:39-55) with RbfKernel.forward (reranker/common.py:232-234):
+ *   K_k = exp(-0.5*(sim-mu_k)*(sim-mu_k)/sigma_k/sigma_k); sum over ALL L positions (KNRM.py:50);
+ *   mask = (sum_j sim != 0) (KNRM.py:51); where(mask, log(sum + 1e-6), 0) summed over q (:52-53);
+ *   combine (KNRM.py:27-34): hidden == 0 -> Linear(K,1); else Linear(K,hidden),Tanh,Linear(hidden,1); optional Tanh. */
+int oracle_knrm(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V, int D,
+                const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden, const float* w2,
+                const float* b2, int scoretanh, float* out) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b) {
+    double F[64];
+    for (int k = 0; k < K; ++k) F[k] = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      double S[64], rowsum = 0.0;
+      for (int k = 0; k < K; ++k) S[k] = 0.0;
+      for (int j = 0; j < L; ++j) {
+        int64_t did = d_ids[(int64_t)b * L + j];
+        if (did >= V) { err |= 1; did = 0; }
+        const float sim = sim_one(qid, did, packed, RS, NV);
+        rowsum += sim;
+        for (int k = 0; k < K; ++k) {
+          const double adj = (double)sim - (double)mu[k];
+          S[k] += exp(-0.5 * adj * adj / (double)sigma[k] / (double)sigma[k]);
+        }
+      }
+      if (rowsum != 0.0)
+        for (int k = 0; k < K; ++k) F[k] += log(S[k] + 1e-6);
+    }
+    double sc;
+    if (hidden > 0) {
+      sc = b2[0];
+      for (int h = 0; h < hidden; ++h) {
+        double a = b1[h];
+        for (int k = 0; k < K; ++k) a += (double)w1[h * K + k] * F[k];
+        sc += (double)w2[h] * tanh(a);
+      }
+    } else {
+      sc = b1[0];
+      for (int k = 0; k < K; ++k) sc += (double)w1[k] * F[k];
+    }
+    if (scoretanh) sc = tanh(sc);
+    out[b] = (float)sc;
+  }
+  return err;
+}
+
+/* DRMM_class.forward (reranker/DRMM.py:101-116):
+ *   _hist_map (:41-81): sim += 1e7 on pad doc positions (:57); cum_i = #(sim < edge_i) (:62-65);
+ *     hist_nbins = #(0.999 < sim < 1.001) (:66); adjacent differences (:68-69); +1 (:71);
+ *     NH / LCH / CH (:72-79).
+ *   ffw (:25): tanh(w2 . tanh(W1 h + b1) + b2) per query term.
+ *   _term_gate (:83-99): softmax_q( gate(q) + (1-qmask)*-1e7 ), gate = w*idf (IDF) or w.E[q] (TV).
+ *   output_layer (:34, :114).
+ * hist_type 0 CH, 1 NH, 2 LCH; gate_type 0 IDF, 1 TV.  A negative query id returns error bit 4
+ * (the reference raises IndexError at DRMM.py:109). */
+int oracle_drmm(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed,
+                int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type, const float* gate_w,
+                const float* emb_raw, int64_t ld, const float* w1, const float* b1, int nodes, const float* w2,
+                const float* b2, const float* out_w, const float* out_b, float* out, int32_t* counts_out) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+  const int NB = nbins + 1;
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b) {
+    double z[64], glogit[64];
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      if (qid < 0) { err |= 4; qid = 0; }
+      int32_t cnt[128];
+      for (int i = 0; i < NB; ++i) cnt[i] = 0;
+      for (int j = 0; j < L; ++j) {
+        int64_t did = d_ids[(int64_t)b * L + j];
+        if (did >= V) { err |= 1; did = 0; }
+        if (did == 0) continue; /* +1e7: below no edge, outside (0.999, 1.001) */
+        const float sim = sim_one(qid, did, packed, RS, NV);
+        int bin = 0;
+        while (bin < nbins && !(sim < edges[bin])) ++bin; /* first edge with sim < edge */
+        if (bin < nbins) cnt[bin] += 1;
+        if (sim > 0.999f && sim < 1.001f) cnt[nbins] += 1;
+      }
+      if (counts_out)
+        for (int i = 0; i < NB; ++i) counts_out[((int64_t)b * Q + q) * NB + i] = cnt[i];
+      double h[128], hs = 0.0;
+      for (int i = 0; i < NB; ++i) { h[i] = (double)cnt[i] + 1.0; hs += h[i]; }
+      if (hist_type == 1) for (int i = 0; i < NB; ++i) h[i] /= hs;
+      else if (hist_type == 2) for (int i = 0; i < NB; ++i) h[i] = log(h[i]);
+      double o = b2[0];
+      for (int n = 0; n < nodes; ++n) {
+        double a = b1[n];
+        for (int i = 0; i < NB; ++i) a += (double)w1[n * NB + i] * h[i];
+        o += (double)w2[n] * tanh(a);
+      }
+      z[q] = tanh(o);
+      double gl;
+      if (gate_type == 0) gl = (double)gate_w[0] * (double)idf[(int64_t)b * Q + q];
+      else {
+        gl = 0.0;
+        const float* e = emb_raw + qid * ld; /* un-normalised query embedding (DRMM.py:109) */
+        for (int c = 0; c < D; ++c) gl += (double)gate_w[c] * (double)e[c];
+      }
+      if (qid == 0) gl += -1e7;
+      /* the reference adds in fp32: w*idf + (-1e7) rounds to exactly -1e7 for |w*idf| < 0.5 */
+      glogit[q] = (double)(float)gl;
+    }
+    double m = glogit[0];
+    for (int q = 1; q < Q; ++q) if (glogit[q] > m) m = glogit[q];
+    double den = 0.0, num = 0.0;
+    for (int q = 0; q < Q; ++q) { const double e = exp(glogit[q] - m); den += e; num += e * z[q]; }
+    out[b] = (float)((double)out_w[0] * (num / den) + (double)out_b[0]);
+  }
+  return err;
+}

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (fixture loading, tolerances)."""
+import os
+
+import numpy as np
+
+from capreolus_amd import synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist"]
+DRMM_CASES = ["default", "zero_idf", "tv_nh", "ch", "ranklist"]
+
+# BASELINE.json north_star: "within 1e-3 relative (fp) and rank-order exactly"
+REL_TOL = 1e-3
+
+
+def load_case(kind, name):
+    z = np.load(os.path.join(GOLDEN, f"{kind}_{name}.npz"))
+    c = {k: z[k] for k in z.files}
+    c["emb"] = synthetic.make_embeddings(int(c["V"]), int(c["D"]), seed=int(c["emb_seed"]))
+    c["query"] = c["query"].astype(np.int64)
+    c["posdoc"] = c["posdoc"].astype(np.int64)
+    return c
+
+
+def knrm_weights(c):
+    """(mu, sigma, w1, b1, w2, b2) from the reference state_dict keys."""
+    K = sum(1 for k in c if k.startswith("sd.kernels.kernels.") and k.endswith(".mu"))
+    mu = np.array([c[f"sd.kernels.kernels.{k}.mu"] for k in range(K)], dtype=np.float32)
+    sigma = np.array([c[f"sd.kernels.kernels.{k}.sigma"] for k in range(K)], dtype=np.float32)
+    w1, b1 = c["sd.combine.0.weight"], c["sd.combine.0.bias"]
+    w2 = c.get("sd.combine.2.weight")
+    b2 = c.get("sd.combine.2.bias")
+    return mu, sigma, w1, b1, w2, b2
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want) / np.maximum(np.abs(want), 1e-6)
+
+
+def rank_order(scores_f16):
+    """Ranking the trainer/searcher produce: scores rounded to fp16 (trainer/pytorch.py:346-348),
+    sorted by score descending; ties keep first-stage order (stable)."""
+    s = np.asarray(scores_f16, dtype=np.float16).astype(np.float64)
+    return np.argsort(-s, kind="stable")

@@ -1,0 +1,250 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference golden
+vectors.  Needs an MI355X: `pytest -m gpu`."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from capreolus_amd import engine, synthetic
+from capreolus_amd.reranker import DRMM, KNRM
+from oracle import cpu as oracle
+from tests.helpers import DRMM_CASES, KNRM_CASES, REL_TOL, knrm_weights, load_case, rank_order, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# GPU vs oracle on the continuous part (exp/log/tanh after bit-identical similarities): the two
+# differ only by fp32 rounding of ~800-term sums and libm-vs-hardware transcendentals.
+ORACLE_TOL = 2e-5
+
+
+def _t(a):
+    return torch.as_tensor(a).to(DEV)
+
+
+def _knrm_model(c):
+    cfg = {"singlefc": bool(c["singlefc"]), "scoretanh": bool(c["scoretanh"])}
+    r = KNRM(cfg, SimpleNamespace(embeddings=c["emb"]))
+    m = r.build_model()
+    sd = {k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=False)  # the reference checkpoint format: everything but the embedding
+    m.to(DEV).eval()
+    return r
+
+
+def _drmm_model(c):
+    cfg = {"nbins": int(c["nbins"]), "nodes": int(c["nodes"]), "histType": str(c["histType"]), "gateType": str(c["gateType"])}
+    r = DRMM(cfg, SimpleNamespace(embeddings=c["emb"]))
+    m = r.build_model()
+    sd = {k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=False)
+    m.to(DEV).eval()
+    return r
+
+
+def _batch(c):
+    return {"query": _t(c["query"]), "posdoc": _t(c["posdoc"]), "query_idf": _t(c["query_idf"])}
+
+
+@pytest.mark.parametrize("V,D", [(257, 300), (100, 50), (64, 63), (33, 64), (50, 319), (40, 1), (77, 128)])
+def test_pack_bit_exact(V, D):
+    emb = synthetic.make_embeddings(V, D, seed=V + D)
+    pe = engine.PackedEmbedding()
+    got = pe.get(_t(emb)).cpu().numpy().reshape(V, -1)
+    want = oracle.pack(emb)
+    assert got.shape == want.shape
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name", KNRM_CASES)
+def test_similarity_matrix_bit_exact(name):
+    c = load_case("knrm", name)
+    pe = engine.PackedEmbedding()
+    packed = pe.get(_t(c["emb"]))
+    got = engine.similarity_matrix(_t(c["query"]), _t(c["posdoc"]), packed, int(c["V"]), int(c["D"])).cpu().numpy()
+    want, err = oracle.simmat(c["query"], c["posdoc"], oracle.pack(c["emb"]), int(c["D"]))
+    assert err == 0
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), np.abs(got - want).max()
+    np.testing.assert_allclose(got.sum(axis=2, dtype=np.float64), c["ref_sim_rowsum"], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", KNRM_CASES)
+def test_knrm_scores(name):
+    c = load_case("knrm", name)
+    r = _knrm_model(c)
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy()
+    assert got.shape == c["ref_scores"].shape
+    mu, sigma, w1, b1, w2, b2 = knrm_weights(c)
+    want, _ = oracle.knrm(c["query"], c["posdoc"], oracle.pack(c["emb"]), int(c["D"]), mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, rel_err(got, c["ref_scores"]).max()
+
+
+def test_knrm_rank_order():
+    c = load_case("knrm", "ranklist")
+    r = _knrm_model(c)
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy().astype(np.float16)  # trainer/pytorch.py:346-348
+    same = got == c["ref_scores_f16"]
+    assert same.mean() > 0.98
+    if same.all():
+        assert (rank_order(got) == rank_order(c["ref_scores_f16"])).all()
+    else:  # an fp16 rounding boundary was crossed by a <1e-3 difference: order must agree away from those docs
+        keep = np.nonzero(same)[0]
+        assert (keep[rank_order(got[keep])] == keep[rank_order(c["ref_scores_f16"][keep])]).all()
+
+
+def test_knrm_score_pair_interface():
+    c = load_case("knrm", "default")
+    r = _knrm_model(c)
+    d = _batch(c)
+    d["negdoc"] = torch.zeros_like(d["posdoc"])  # embedtext.py:151
+    with torch.no_grad():
+        pos, neg = r.score(d)
+        ref = r.test(d)
+    assert torch.equal(pos, ref)
+    assert neg.shape == pos.shape and torch.isfinite(neg).all()
+
+
+@pytest.mark.parametrize("name", DRMM_CASES)
+def test_drmm_counts_and_scores(name):
+    c = load_case("drmm", name)
+    r = _drmm_model(c)
+    B, Q = c["query"].shape
+    counts = torch.empty((B, Q, int(c["nbins"]) + 1), dtype=torch.int32, device=DEV)
+    b = _batch(c)
+    with torch.no_grad():
+        got = r.model(b["posdoc"], b["query"], b["query_idf"], counts_out=counts).view(-1).cpu().numpy()
+        got2 = r.test(b).cpu().numpy()
+    assert (got == got2).all()
+    want, wcounts, err = oracle.drmm(
+        c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), c["edges"], str(c["histType"]),
+        str(c["gateType"]), c["sd.gates.weight"], c["emb"], c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.ffw.2.weight"],
+        c["sd.ffw.2.bias"], c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+    assert err == 0
+    assert (counts.cpu().numpy() == wcounts).all()  # integer work: bit exact
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    # against the reference itself: exact counts / 1e-3 scores wherever no similarity is within 4 ulp
+    # of a bin edge; elsewhere only the last regular bin may move (see tests/test_oracle_golden.py)
+    d = counts.cpu().numpy().astype(np.int64) - c["ref_counts"].astype(np.int64)
+    diff = np.abs(d).sum(axis=(1, 2))
+    assert (diff[c["n_ambiguous"] == 0] == 0).all()
+    assert (diff <= c["n_ambiguous"]).all()
+    assert set(np.nonzero(np.abs(d).sum(axis=(0, 1)))[0].tolist()) <= {int(c["nbins"]) - 1}
+    assert rel_err(got, c["ref_scores"])[diff == 0].max() <= REL_TOL
+
+
+def test_errors_surface_as_exceptions():
+    c = load_case("drmm", "default")
+    r = _drmm_model(c)
+    b = _batch(c)
+    b["query"] = b["query"].clone()
+    b["query"][0, 0] = -3
+    with torch.no_grad(), pytest.raises(IndexError):
+        r.test(b)
+    c = load_case("knrm", "default")
+    r = _knrm_model(c)
+    b = _batch(c)
+    b["posdoc"] = b["posdoc"].clone()
+    b["posdoc"][1, 2] = int(c["V"])  # one past the table
+    with torch.no_grad(), pytest.raises(IndexError):
+        r.test(b)
+    with torch.no_grad():  # and the engine is usable afterwards
+        assert torch.isfinite(r.test(_batch(c))).all()
+    with pytest.raises(RuntimeError):
+        r.test({k: v.cpu() for k, v in _batch(c).items()})  # no CPU fallback
+    r.model.train()
+    with pytest.raises(NotImplementedError):
+        r.score({**_batch(c), "negdoc": _batch(c)["posdoc"]})
+
+
+def test_empty_batch_and_weight_reload():
+    c = load_case("knrm", "default")
+    r = _knrm_model(c)
+    b = _batch(c)
+    with torch.no_grad():
+        e = r.test({k: v[:0] for k, v in b.items()})
+        assert e.shape == (0,)
+        s0 = r.test(b).clone()
+        r.model.combine[0].bias.add_(1.0)  # weights are read from the live module on every call
+        s1 = r.test(b)
+        assert torch.allclose(s1, s0 + 1.0, atol=1e-5)
+        r.model.embedding.weight[5:].mul_(-1.0)  # in-place edit bumps the version -> re-pack
+        s2 = r.test(b)
+        assert torch.isfinite(s2).all()
+
+
+# ---- BASELINE.json full sizes: size-independent properties + oracle on a sample -----------------
+@pytest.fixture(scope="module")
+def full():
+    V, D = 400001, 300
+    g = torch.Generator(device=DEV)
+    g.manual_seed(0)
+    emb = torch.randn((V, D), generator=g, device=DEV) * 0.4
+    emb[0] = 0
+    batch = synthetic.make_candidate_list_torch(2, 1000, V, DEV, seed=1)
+    return emb, batch
+
+
+def test_full_size_knrm_properties(full):
+    emb, batch = full
+    r = KNRM({}, SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32)))
+    m = r.build_model().to(DEV).eval()
+    m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        s = r.test(batch)
+        assert s.shape == (2000,) and torch.isfinite(s).all()
+        # (a) pairs are independent: any permutation of the batch permutes the scores bit for bit
+        perm = torch.randperm(2000, device=DEV)
+        sp = r.test({k: v[perm] for k, v in batch.items()})
+        assert torch.equal(sp, s[perm])
+        # (b) chunked calls == one call (evalbatch does not matter)
+        sc = torch.cat([r.test({k: v[i:i + 333] for k, v in batch.items()}) for i in range(0, 2000, 333)])
+        assert torch.equal(sc, s)
+        # (c) order of terms inside a document only changes fp32 summation order
+        doc = batch["posdoc"].clone()
+        L = doc.shape[1]
+        doc = doc[:, torch.randperm(L, device=DEV)]
+        s3 = r.test({**batch, "posdoc": doc})
+        assert (s3 - s).abs().max() <= 2e-5 * s.abs().max()
+    # (d) a sample of pairs against the oracle
+    idx = np.arange(0, 2000, 63)
+    q, d = batch["query"][idx].cpu().numpy(), batch["posdoc"][idx].cpu().numpy()
+    used = np.unique(np.concatenate([q.ravel(), d.ravel()]))
+    used = used[used > 0]
+    remap = np.zeros(400001, dtype=np.int64)
+    remap[used] = np.arange(1, len(used) + 1)
+    small = np.concatenate([np.zeros((1, 300), np.float32), emb[torch.as_tensor(used, device=DEV)].cpu().numpy()])
+    rq, rd = np.where(q > 0, remap[np.maximum(q, 0)], q), np.where(d > 0, remap[np.maximum(d, 0)], d)
+    mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+    want, _ = oracle.knrm(rq, rd, oracle.pack(small), 300, mu, sigma, m.combine[0].weight.detach().cpu().numpy(),
+                          m.combine[0].bias.detach().cpu().numpy())
+    assert rel_err(s[idx].cpu().numpy(), want).max() <= ORACLE_TOL
+
+
+def test_full_size_drmm_properties(full):
+    emb, batch = full
+    r = DRMM({}, SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32)))
+    m = r.build_model().to(DEV).eval()
+    m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
+    b = {k: v for k, v in batch.items()}
+    b["query"] = b["query"].clamp(min=0)
+    with torch.no_grad():
+        c0 = torch.empty((2000, 4, 30), dtype=torch.int32, device=DEV)
+        s = m(b["posdoc"], b["query"], b["query_idf"], counts_out=c0).view(-1)
+        assert torch.isfinite(s).all()
+        # every non-pad term falls in at most one regular bin
+        nonpad = (b["posdoc"] != 0).sum(1)
+        assert (c0[:, :, :29].sum(-1) <= nonpad[:, None]).all()
+        # (a) term order inside the document: integer counts are order independent -> bit-identical scores
+        doc = b["posdoc"][:, torch.randperm(800, device=DEV)]
+        c1 = torch.empty_like(c0)
+        s1 = m(doc, b["query"], b["query_idf"], counts_out=c1).view(-1)
+        assert torch.equal(c0, c1) and torch.equal(s, s1)
+        # (b) extra pad positions change nothing (DRMM.py:57 pushes pads out of every bin)
+        wide = torch.cat([b["posdoc"], torch.zeros((2000, 133), dtype=torch.int64, device=DEV)], 1)
+        s2 = m(wide, b["query"], b["query_idf"]).view(-1)
+        assert torch.equal(s, s2)

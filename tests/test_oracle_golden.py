@@ -1,0 +1,108 @@
+"""Pins the CPU oracle (oracle/interaction_oracle.c) against golden vectors produced by the
+REFERENCE nn.Modules (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import cpu as oracle
+from tests.helpers import DRMM_CASES, KNRM_CASES, REL_TOL, knrm_weights, load_case, rank_order, rel_err
+
+
+@pytest.mark.parametrize("name", KNRM_CASES)
+def test_knrm_oracle_matches_reference(name):
+    c = load_case("knrm", name)
+    packed = oracle.pack(c["emb"])
+    mu, sigma, w1, b1, w2, b2 = knrm_weights(c)
+    got, err = oracle.knrm(c["query"], c["posdoc"], packed, int(c["D"]), mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
+    assert err == 0
+    e = rel_err(got, c["ref_scores"])
+    assert e.max() <= REL_TOL, (name, e.max(), int(e.argmax()))
+    # the interaction matrix itself: row sums of the reference's simmat
+    sim, err = oracle.simmat(c["query"], c["posdoc"], packed, int(c["D"]))
+    assert err == 0
+    np.testing.assert_allclose(sim.sum(axis=2, dtype=np.float64), c["ref_sim_rowsum"], rtol=1e-4, atol=2e-4)
+
+
+def test_knrm_oracle_rank_order_matches_reference():
+    c = load_case("knrm", "ranklist")
+    packed = oracle.pack(c["emb"])
+    mu, sigma, w1, b1, w2, b2 = knrm_weights(c)
+    got, _ = oracle.knrm(c["query"], c["posdoc"], packed, int(c["D"]), mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
+    assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98  # fp16 rounding boundary flips only
+    ours, ref = rank_order(got.astype(np.float16)), rank_order(c["ref_scores_f16"])
+    same = got.astype(np.float16) == c["ref_scores_f16"]
+    if same.all():
+        assert (ours == ref).all()
+
+
+def _drmm_run(c):
+    packed = oracle.pack(c["emb"])
+    return oracle.drmm(
+        c["query"], c["posdoc"], c["query_idf"], packed, int(c["D"]), c["edges"], str(c["histType"]), str(c["gateType"]),
+        c["sd.gates.weight"], c["emb"], c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.ffw.2.weight"], c["sd.ffw.2.bias"],
+        c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+
+
+@pytest.mark.parametrize("name", DRMM_CASES)
+def test_drmm_oracle_matches_reference(name):
+    c = load_case("drmm", name)
+    got, counts, err = _drmm_run(c)
+    assert err == 0
+    amb = c["n_ambiguous"]
+    nb = int(c["nbins"])
+    d = counts.astype(np.int64) - c["ref_counts"].astype(np.int64)
+    diff = np.abs(d).sum(axis=(1, 2))
+    # (1) histogram counts: identical wherever no similarity sits within 4 ulp of a bin edge.  Where
+    # some do -- SURVEY.md §7: identical in-vocab terms give cos in {1-ulp, 1, 1+ulp} depending on
+    # the BLAS summation order, so the reference itself flips a coin on "cos < 1.0" -- at most that
+    # many counts may move, and only in the last regular bin [edge_{nbins-2}, 1.0).
+    assert (diff[amb == 0] == 0).all(), (name, np.nonzero((diff > 0) & (amb == 0))[0])
+    assert (diff <= amb).all(), (name, diff, amb)
+    moved = np.nonzero(np.abs(d).sum(axis=(0, 1)))[0]
+    assert set(moved.tolist()) <= {nb - 1}, (name, moved)
+    # (2) scores: within 1e-3 wherever the counts agree (that covers every unambiguous pair)
+    e = rel_err(got, c["ref_scores"])
+    clean = diff == 0
+    assert clean.sum() >= 0.3 * len(clean), name
+    assert e[clean].max() <= REL_TOL, (name, e[clean].max())
+    # (3) where counts moved the score moves with them and nothing else: bounded by what the moved
+    # counts can do through log(count+1) and the tanh MLP (loose bound, reported in DESIGN.md)
+    assert e.max() <= 0.05, (name, e.max())
+
+
+def test_drmm_oracle_rejects_oov_query():
+    c = load_case("drmm", "default")
+    c["query"] = c["query"].copy()
+    c["query"][0, 0] = -3
+    _, _, err = _drmm_run(c)
+    assert err & 4  # reference: IndexError at DRMM.py:109
+
+
+@pytest.mark.parametrize("name", KNRM_CASES)
+def test_knrm_torch_port_matches_reference(name):
+    import torch
+
+    from oracle import torch_port
+
+    c = load_case("knrm", name)
+    mu, sigma, w1, b1, w2, b2 = (None if x is None else torch.as_tensor(x) for x in knrm_weights(c))
+    with torch.no_grad():
+        got = torch_port.knrm(torch.as_tensor(c["emb"]), torch.as_tensor(c["query"]), torch.as_tensor(c["posdoc"]), mu, sigma,
+                              w1, b1, w2, b2, bool(c["scoretanh"])).numpy()
+    assert rel_err(got, c["ref_scores"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", DRMM_CASES)
+def test_drmm_torch_port_matches_reference(name):
+    import torch
+
+    from oracle import torch_port
+
+    c = load_case("drmm", name)
+    t = lambda k: torch.as_tensor(c[k])  # noqa: E731
+    with torch.no_grad():
+        got = torch_port.drmm(t("emb"), t("query"), t("posdoc"), t("query_idf"), int(c["nbins"]), str(c["histType"]),
+                              str(c["gateType"]), t("sd.gates.weight"), t("sd.ffw.0.weight"), t("sd.ffw.0.bias"),
+                              t("sd.ffw.2.weight"), t("sd.ffw.2.bias"), t("sd.output_layer.weight"),
+                              t("sd.output_layer.bias")).numpy()
+    # same ATen ops in the same order as the reference -> same coin flips on cos(a,a) < 1
+    assert rel_err(got, c["ref_scores"]).max() <= 1e-5
