@@ -7,6 +7,11 @@ loudly, capreolus/sampler/__init__.py:230-233).
 import ctypes
 import os
 
+# Load PyTorch's HIP runtime FIRST.  The ROCm wheels bundle their own libamdhip64.so.7 (same SONAME
+# as /opt/rocm's); if this library were dlopen'ed before torch, the process would end up with two HIP
+# runtimes and kernels registered with one could not be launched on streams created by the other.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcapreolus_amd.so")
 

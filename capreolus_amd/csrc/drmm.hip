@@ -207,6 +207,7 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
                                    int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
                                    const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
                                    const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
   if (!q_ids || !d_ids || !idf || !packed || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out ||
       !status)
     return CAPAMD_ERR_ARG;
@@ -220,6 +221,7 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4;
   hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL(drmm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;

@@ -211,6 +211,7 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
                                    int64_t V, int D, const float* mu, const float* sigma, int K, const float* w1,
                                    const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
                                    float* out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
   if (!q_ids || !d_ids || !packed || !mu || !sigma || !w1 || !b1 || !out || !status) return CAPAMD_ERR_ARG;
   if (B < 0 || Q < 1 || L < 1 || V < 1 || K < 1 || K > kMaxK || hidden < 0 || hidden > kMaxHidden) return CAPAMD_ERR_ARG;
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
@@ -219,6 +220,7 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
   KnrmArgs a{q_ids, d_ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4;
   hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL(knrm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;

@@ -86,16 +86,19 @@ int capamd_pack_embeddings(const float* emb, int64_t V, int D, int64_t ld, float
   if ((reinterpret_cast<uintptr_t>(packed) & 255) != 0) return CAPAMD_ERR_ALIGN;
   const int64_t blocks = (V + kGroupsPerWG - 1) / kGroupsPerWG;
   if (blocks > 0x7fffffff) return CAPAMD_ERR_ARG;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, emb, V, D, ld, packed);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 int capamd_similarity_matrix(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed,
                              int64_t V, int D, float* sim_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
   if (!q_ids || !d_ids || !packed || !sim_out || !status || B < 0 || Q < 1 || L < 1 || V < 1) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if (B == 0) return CAPAMD_OK;
   hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
 #define LAUNCH(NV_)                                                                                              \
   hipLaunchKernelGGL(simmat_kernel<NV_>, dim3(B), dim3(kThreads), 0, s, q_ids, d_ids, Q, L, packed, V, sim_out, \
                      status)
