@@ -1,0 +1,177 @@
+"""Prediction loop behind the reference trainer surface (capreolus/trainer/pytorch.py:310-377),
+with the one thing the reference lacks: sharding of the candidate lists over the GPUs of a node.
+
+Single process: identical control flow to the reference `PytorchTrainer.predict` — DataLoader over
+the prediction sampler, last incomplete batch filled by repetition (:355-377), ``reranker.test``
+per batch, scores rounded through float16 (:346-348), TREC run written with the reference's
+ordering (searcher/__init__.py:48-58).
+
+One process per GPU (``torch.distributed`` initialised, backend "nccl" = RCCL): every rank scores
+a contiguous block of *queries* (a query's candidates stay on one GPU) and the fp32 score vectors
+are exchanged with a single all_gather at the end.  No other collective is on the
+path.
+"""
+import copy
+import itertools
+import math
+import os
+
+import numpy as np
+import torch
+
+from ..run_io import write_trec_run
+
+
+def shard_bounds(sizes, world):
+    """Contiguous split of items with the given sizes into `world` blocks of near-equal total size.
+    Returns world+1 boundaries (indices into the item list)."""
+    total = sum(sizes)
+    bounds, acc, nxt = [0], 0, 1
+    for i, s in enumerate(sizes):
+        # close block nxt-1 before item i if that gets closer to its ideal end
+        while nxt < world and acc + s / 2.0 > total * nxt / world:
+            bounds.append(i)
+            nxt += 1
+        acc += s
+    while len(bounds) < world:
+        bounds.append(len(sizes))
+    bounds.append(len(sizes))
+    return bounds
+
+
+def shard_pred_data(pred_data, rank, world):
+    """The part of a prediction sampler this rank scores, plus (offset, count, total) in samples.
+
+    Samplers that expose ``qid_to_docids`` (the reference PredSampler, sampler/__init__.py:207-264)
+    are split by query; anything else is split into contiguous sample ranges.
+    """
+    if world == 1:
+        n = len(pred_data)
+        return pred_data, 0, n, n
+    q2d = getattr(pred_data, "qid_to_docids", None)
+    if q2d is not None:
+        qids = list(q2d.keys())
+        sizes = [len(q2d[q]) for q in qids]
+        b = shard_bounds(sizes, world)
+        mine = qids[b[rank]:b[rank + 1]]
+        part = copy.copy(pred_data)
+        part.qid_to_docids = {q: q2d[q] for q in mine}
+        offset = sum(sizes[: b[rank]])
+        return part, offset, sum(sizes[b[rank]:b[rank + 1]]), sum(sizes)
+    n = len(pred_data)
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+
+    class _Slice(torch.utils.data.IterableDataset):
+        def __iter__(self_inner):
+            return itertools.islice(iter(pred_data), lo, hi)
+
+        def __len__(self_inner):
+            return hi - lo
+
+    return _Slice(), lo, hi - lo, n
+
+
+class PytorchTrainer:
+    module_name = "pytorch"
+    config_spec = {  # reference defaults, trainer/pytorch.py:24-44
+        "batch": 32, "evalbatch": 0, "niters": 20, "itersize": 512, "gradacc": 1, "lr": 0.001, "softmaxloss": False,
+        "fastforward": False, "validatefreq": 1, "multithread": False, "boardname": "default", "warmupiters": 0,
+        "decay": 0.0, "decayiters": 3, "decaytype": None, "amp": None, "seed": 123,
+    }
+
+    def __init__(self, config=None):
+        cfg = dict(self.config_spec)
+        unknown = set(config or {}) - set(cfg)
+        if unknown:
+            raise ValueError(f"unknown config options for trainer: {sorted(unknown)}")
+        cfg.update(config or {})
+        self.config = cfg
+        self.build()
+
+    def build(self):
+        c = self.config
+        if c["batch"] < 1:
+            raise ValueError("batch must be >= 1")
+        if c["evalbatch"] < 0:
+            raise ValueError("evalbatch must be 0 (to use the training batch size) or  >= 1")
+        if c["amp"] not in (None, "train", "pred", "both"):
+            raise ValueError("amp must be one of: None, train, pred, both")
+
+    def fill_incomplete_batch(self, batch, batch_size=None):
+        """Repeat-pad a short final batch (reference trainer/pytorch.py:355-377)."""
+        batch_size = batch_size or self.config["batch"]
+        n = len(batch["qid"])
+        reps, diff = math.ceil(batch_size / n), batch_size - n
+
+        def pad(v):
+            if isinstance(v, np.ndarray) or torch.is_tensor(v):
+                v = v.repeat((reps,) + (1,) * (len(v.shape) - 1))
+            else:
+                v = v + [v[0]] * diff
+            return v[:batch_size]
+
+        return {k: pad(v) for k, v in batch.items()}
+
+    def predict(self, reranker, pred_data, pred_fn=None):
+        """Scores every (qid, docid) of `pred_data`; returns {qid: {docid: score}} on every rank and
+        writes the TREC run to `pred_fn` (rank 0)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        if torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.device = torch.device("cpu")
+        model = reranker.model.to(self.device)
+        model.eval()
+
+        part, offset, count, total = shard_pred_data(pred_data, rank, world)
+        evalbatch = self.config["evalbatch"] if self.config["evalbatch"] > 0 else self.config["batch"]
+        workers = 1 if self.config["multithread"] else 0
+        keys, chunks = [], []
+        if count > 0:
+            loader = torch.utils.data.DataLoader(part, batch_size=evalbatch, pin_memory=self.device.type == "cuda",
+                                                 num_workers=workers)
+            with torch.no_grad():
+                for batch in loader:
+                    n = len(batch["qid"])
+                    if n != evalbatch:
+                        batch = self.fill_incomplete_batch(batch, batch_size=evalbatch)
+                    dbatch = {k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in batch.items()}
+                    scores = reranker.test(dbatch).view(-1)[:n]
+                    chunks.append(scores.float())      # stays on the device: no per-batch sync
+                    keys.extend(zip(batch["qid"][:n], batch["posdocid"][:n]))
+        local = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
+        if local.numel() != count:
+            raise RuntimeError(f"rank {rank} scored {local.numel()} pairs, expected {count}")
+
+        if world > 1:
+            # every rank can derive every rank's (offset, count) from the sampler; only scores travel
+            plan = [shard_pred_data(pred_data, r, world)[1:3] for r in range(world)]
+            width = max(c for _, c in plan)
+            padded = torch.zeros(width, dtype=torch.float32, device=self.device)
+            padded[:count] = local
+            gathered = torch.empty(width * world, dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(gathered, padded)   # the one collective of the path (RCCL over xGMI)
+            gathered = gathered.cpu().numpy().reshape(world, width)
+            allscores = np.concatenate([gathered[r, :c] for r, (_, c) in enumerate(plan)])
+            if hasattr(pred_data, "get_qid_docid_pairs"):   # reference PredSampler, sampler/__init__.py:257-264
+                allkeys = list(pred_data.get_qid_docid_pairs())
+            else:                                            # opaque sampler: ids are only known where they were read
+                parts = [None] * world
+                dist.all_gather_object(parts, keys)
+                allkeys = [k for ks in parts for k in ks]
+            if len(allkeys) != len(allscores):
+                raise RuntimeError(f"gathered {len(allscores)} scores for {len(allkeys)} (qid, docid) pairs")
+        else:
+            allkeys, allscores = keys, local.cpu().numpy()
+
+        preds = {}
+        for (qid, docid), score in zip(allkeys, allscores):
+            # float16: what the reference hands to pytrec_eval (trainer/pytorch.py:346-348)
+            preds.setdefault(qid, {})[docid] = score.astype(np.float16).item()
+        if pred_fn is not None and rank == 0:
+            os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
+            write_trec_run(preds, pred_fn)
+        return preds

@@ -1,0 +1,175 @@
+"""Host logic on CPU: trainer mirror (batch filling, fp16 rounding, run writing), query sharding and the
+world_size-2 gather over gloo, run IO and nDCG@20."""
+import os
+import socket
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from capreolus_amd import run_io
+from capreolus_amd.trainer.pytorch import PytorchTrainer, shard_bounds, shard_pred_data
+
+
+class FakeSampler(torch.utils.data.IterableDataset):
+    """Stands in for the reference PredSampler (sampler/__init__.py:207-264): same attributes the trainer uses."""
+
+    def __init__(self, n_queries=7, seed=0):
+        rs = np.random.RandomState(seed)
+        self.qid_to_docids = {str(300 + q): [f"d{q}_{i}" for i in range(rs.randint(1, 40))] for q in range(n_queries)}
+
+    def _vec(self, qid, docid):
+        h = (zlib.crc32(f"{qid}/{docid}".encode()) % 1000) / 7.0
+        return {"qid": qid, "posdocid": docid, "query": np.full(4, int(qid), dtype=np.int64),
+                "posdoc": np.full(16, len(docid), dtype=np.int64), "query_idf": np.full(4, h, dtype=np.float32)}
+
+    def __iter__(self):
+        for qid, docids in self.qid_to_docids.items():
+            for d in docids:
+                yield self._vec(qid, d)
+
+    def __len__(self):
+        return sum(len(v) for v in self.qid_to_docids.values())
+
+    def get_qid_docid_pairs(self):
+        for qid, docids in self.qid_to_docids.items():
+            for d in docids:
+                yield qid, d
+
+
+class FakeReranker:
+    """A scorer that is a pure function of the batch tensors (no HIP needed): exercises only the host logic."""
+
+    def __init__(self):
+        self.model = torch.nn.Linear(1, 1)
+        self.calls = []
+
+    def test(self, d):
+        self.calls.append(len(d["qid"]))
+        return d["query_idf"][:, 0] * 1.0009765625 + d["posdoc"][:, 0].float()
+
+
+def _expected(s):
+    out = {}
+    for qid, docid in s.get_qid_docid_pairs():
+        v = s._vec(qid, docid)
+        sc = np.float32(v["query_idf"][0]) * np.float32(1.0009765625) + np.float32(v["posdoc"][0])
+        out.setdefault(qid, {})[docid] = np.float32(sc).astype(np.float16).item()
+    return out
+
+
+def test_predict_single_process(tmp_path):
+    s, r = FakeSampler(), FakeReranker()
+    t = PytorchTrainer({"batch": 8})
+    preds = t.predict(r, s, tmp_path / "sub" / "run.txt")
+    assert preds == _expected(s)
+    assert set(r.calls) == {8}  # the short last batch is filled by repetition (reference :339-340)
+    run = run_io.load_trec_run(tmp_path / "sub" / "run.txt")
+    assert list(run.keys()) == sorted(preds.keys(), key=int)
+    for qid in run:
+        sc = list(run[qid].values())
+        assert sc == sorted(sc, reverse=True)
+        assert run[qid] == pytest.approx(preds[qid])
+
+
+def test_fill_incomplete_batch():
+    t = PytorchTrainer({"batch": 5})
+    b = {"qid": ["1", "2"], "x": torch.arange(4).view(2, 2), "y": np.arange(2)}
+    f = t.fill_incomplete_batch(b)
+    assert f["qid"] == ["1", "2", "1", "1", "1"]
+    assert f["x"].tolist() == [[0, 1], [2, 3], [0, 1], [2, 3], [0, 1]]
+    assert f["y"].tolist() == [0, 0, 0, 1, 1]  # numpy repeat is element-wise: the reference quirk is kept
+
+
+def test_bad_config():
+    with pytest.raises(ValueError):
+        PytorchTrainer({"batch": 0})
+    with pytest.raises(ValueError):
+        PytorchTrainer({"amp": "yes"})
+    with pytest.raises(ValueError):
+        PytorchTrainer({"nonsense": 1})
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_bounds_cover_everything(world):
+    rs = np.random.RandomState(world)
+    for _ in range(20):
+        sizes = rs.randint(1, 1000, size=rs.randint(1, 30)).tolist()
+        b = shard_bounds(sizes, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == len(sizes)
+        assert all(b[i] <= b[i + 1] for i in range(world))
+    s = FakeSampler(11)
+    seen = []
+    for r in range(world):
+        part, off, cnt, tot = shard_pred_data(s, r, world)
+        assert tot == len(s) and off == len(seen)
+        got = [(v["qid"], v["posdocid"]) for v in part]
+        assert len(got) == cnt
+        seen.extend(got)
+    assert seen == list(s.get_qid_docid_pairs())
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, r = FakeSampler(9, seed=3), FakeReranker()
+    preds = PytorchTrainer({"batch": 4}).predict(r, s, os.path.join(out_dir, "run.txt"))
+    ok = preds == _expected(s)
+    # each rank scored only its own block of queries
+    n_local = shard_pred_data(s, rank, world)[2]
+    ok = ok and sum(r.calls) >= n_local and sum(r.calls) < n_local + 4
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_predict_sharded_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"ok{r}").read() == "True"
+    run = run_io.load_trec_run(tmp_path / "run.txt")
+    assert sum(len(v) for v in run.values()) == len(FakeSampler(9, seed=3))
+
+
+def test_ndcg_cut_hand_computed():
+    qrels = {"1": {"a": 2, "b": 0, "c": 1, "d": 1}, "2": {"x": 1}}
+    run = {"1": {"a": 0.5, "b": 0.9, "c": 0.5, "zz": 0.7, "d": 0.1}, "2": {"y": 1.0}, "3": {"q": 1.0}}
+    # query 1 ranking: b(0) zz(unjudged 0) then the 0.5 tie broken by docid descending: c(1) a(2), then d(1)
+    dcg = 0 / np.log2(2) + 0 / np.log2(3) + 1 / np.log2(4) + 2 / np.log2(5) + 1 / np.log2(6)
+    idcg = 2 / np.log2(2) + 1 / np.log2(3) + 1 / np.log2(4)
+    got = run_io.ndcg_cut(qrels, run, k=20)
+    assert got["1"] == pytest.approx(dcg / idcg, abs=1e-12)
+    assert got["2"] == 0.0 and "3" not in got
+    assert run_io.ndcg_cut(qrels, run, k=2)["1"] == 0.0
+    assert run_io.mean_ndcg_cut(qrels, run) == pytest.approx((dcg / idcg) / 2)
+
+
+def test_abi_header_and_library_agree():
+    """Every function include/capreolus_amd.h declares is exported by the built library, and the
+    ctypes table binds exactly that set (no compute calls: there is no GPU here)."""
+    import re
+
+    from capreolus_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "capreolus_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(capamd_\w+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.capamd_version() == int(re.search(r"#define CAPAMD_VERSION (\d+)", hdr).group(1))
+    assert lib.capamd_arch() == b"gfx950"
+    assert lib.capamd_packed_row_stride(300) == 320 and lib.capamd_packed_row_stride(63) == 64
+    assert lib.capamd_packed_row_stride(64) == 128 and lib.capamd_packed_row_stride(320) == -1
+    assert lib.capamd_packed_table_bytes(400001, 300) == 400001 * 320 * 4
