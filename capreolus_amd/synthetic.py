@@ -147,9 +147,10 @@ def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, em
     mask = np.zeros((B, P, S), dtype=np.int64)
     seg = np.zeros((B, P, S), dtype=np.int64)
     qmax = max(1, min(12, S // 4))
-    q_shared = rs.randint(1000, vocab, size=rs.randint(min(3, qmax), qmax + 1))
+    tlo = min(1000, vocab // 4)  # BERT's first ~1000 ids are special/unused tokens
+    q_shared = rs.randint(tlo, vocab, size=rs.randint(min(3, qmax), qmax + 1))
     for b in range(B):
-        q = q_shared if same_query else rs.randint(1000, vocab, size=rs.randint(min(3, qmax), qmax + 1))
+        q = q_shared if same_query else rs.randint(tlo, vocab, size=rs.randint(min(3, qmax), qmax + 1))
         nq = len(q)
         for p in range(P):
             head = [CLS] + list(q) + [SEP]
@@ -158,7 +159,7 @@ def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, em
                 body = [PAD]
             else:
                 plo, phi = min(40, room), min(240, room)
-                body = list(rs.randint(1000, vocab, size=rs.randint(plo, phi + 1)))
+                body = list(rs.randint(tlo, vocab, size=rs.randint(plo, phi + 1)))
             toks = head + body + [SEP]
             n = len(toks)
             inp[b, p, :n] = toks

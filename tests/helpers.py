@@ -44,3 +44,20 @@ def rank_order(scores_f16):
     sorted by score descending; ties keep first-stage order (stable)."""
     s = np.asarray(scores_f16, dtype=np.float16).astype(np.float64)
     return np.argsort(-s, kind="stable")
+
+BERT_CASES = ["mini", "mini_s128", "base"]
+
+
+def load_bert_case(name):
+    import torch
+
+    from oracle import bert_port
+
+    z = np.load(os.path.join(GOLDEN, f"bert_{name}.npz"))
+    c = {k: z[k] for k in z.files}
+    hidden, layers, heads, ffn, vocab, max_pos = (int(x) for x in c["dims"])
+    c.update(hidden=hidden, layers=layers, heads=heads, ffn=ffn, vocab=vocab, max_pos=max_pos)
+    c["weights"] = bert_port.random_weights(hidden, layers, heads, ffn, vocab, max_pos, seed=int(c["weight_seed"]))
+    for k in ("pos_bert_input", "pos_mask", "pos_seg"):
+        c[k] = torch.from_numpy(c[k].astype(np.int64))
+    return c
