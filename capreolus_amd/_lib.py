@@ -20,6 +20,18 @@ STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV = 1, 2, 4
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
+
+
+class BertModel(ctypes.Structure):
+    """capamd_bert_model (include/capreolus_amd.h)."""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("hidden", "layers", "heads", "ffn", "vocab", "max_pos", "type_vocab")] + [
+        (n, ctypes.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "pooler_w", "pooler_b",
+                                       "cls_w", "cls_b", "blob", "layer_f32")]
+
+
+_mp = ctypes.POINTER(BertModel)
+
 # name -> (restype, argtypes); must list every symbol include/capreolus_amd.h declares
 SIGNATURES = {
     "capamd_version": (_i, []),
@@ -31,6 +43,13 @@ SIGNATURES = {
     "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capamd_drmm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "capamd_bert_blob_bytes": (_i64, [_mp]),
+    "capamd_bert_layer_f32_floats": (_i64, [_mp]),
+    "capamd_bert_pack_layer": (_i, [_mp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    "capamd_bert_workspace_bytes": (_i64, [_mp, _i, _i64, _i64]),
+    "capamd_bert_maxp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

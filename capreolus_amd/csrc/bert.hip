@@ -1,0 +1,373 @@
+// BERT-MaxP passage scoring for gfx950: PTBERTMaxP_Class.predict_step (reference
+// capreolus/reranker/ptBERTMaxP.py:67-96) with the transformers BertForSequenceClassification it
+// calls at :82 re-built as hand-written kernels: embedding sum + LayerNorm, bf16 MFMA GEMMs with
+// fused bias / GELU / residual epilogues (bert_gemm.cuh), fused exact-softmax attention
+// (bert_attn.cuh), LayerNorm, pooler + classifier, passage pooling.
+//
+// Precision: GEMM/attention operands bf16, accumulation fp32; the residual stream, LayerNorm
+// statistics, softmax and the pooler/classifier are fp32.
+#include "bert_attn.cuh"
+#include "bert_gemm.cuh"
+#include "capreolus_amd.h"
+
+using namespace capamd;
+
+namespace {
+
+constexpr float kLnEps = 1e-12f;  // BertConfig.layer_norm_eps
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- fp32 -> bf16 weight conversion (row-major copy into the blob) ----------------------------
+__global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (__bf16)src[i];
+}
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// One wave per token: v = LayerNorm(x) over H (H % 256 == 0 is NOT required; H % 4 == 0, H <= 1024).
+// MODE 0: x = word[id] + pos[s] + type[seg]  (embeddings);  MODE 1: x = pre[token]
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ pre, const int64_t* __restrict__ ids,
+                                                 const int64_t* __restrict__ seg, const float* __restrict__ word,
+                                                 const float* __restrict__ pos, const float* __restrict__ type, int vocab,
+                                                 int type_vocab, int S, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, int64_t M, int H, float* __restrict__ xf,
+                                                 __bf16* __restrict__ xb, int* status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= M) return;
+  const int nchunk = H >> 2;  // float4 chunks per row
+  float4 v[4];
+  const float* r0 = nullptr;
+  const float* r1 = nullptr;
+  const float* r2 = nullptr;
+  if (MODE == 0) {
+    int64_t id = ids[tok], sg = seg[tok];
+    if (id < 0 || id >= vocab || sg < 0 || sg >= type_vocab) {
+      if (lane == 0) atomicOr(status, 1);
+      id = 0;
+      sg = 0;
+    }
+    r0 = word + id * H;
+    r1 = pos + (tok % S) * H;
+    r2 = type + sg * H;
+  } else {
+    r0 = pre + tok * H;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float4 x = reinterpret_cast<const float4*>(r0)[c];
+      if (MODE == 0) {
+        const float4 y = reinterpret_cast<const float4*>(r1)[c], z = reinterpret_cast<const float4*>(r2)[c];
+        x.x += y.x + z.x; x.y += y.y + z.y; x.z += y.z + z.z; x.w += y.w + z.w;
+      }
+      v[i] = x;
+      s += (x.x + x.y) + (x.z + x.w);
+    }
+  }
+  const float mean = wave_sum64(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (lane + 64 * i < nchunk) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  const float rstd = rsqrtf(wave_sum64(q) / (float)H + kLnEps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      reinterpret_cast<float4*>(xf + tok * H)[c] = o;
+      bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+      reinterpret_cast<bf16x4*>(xb + tok * H)[c] = ob;
+    }
+  }
+}
+
+// pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]); one block per passage.
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xf, int S, int H, const float* __restrict__ pw,
+                                                   const float* __restrict__ pb, const float* __restrict__ cw,
+                                                   const float* __restrict__ cb, float* __restrict__ logits) {
+  __shared__ float cls[1024];
+  __shared__ float part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* h = xf + (int64_t)blockIdx.x * S * H;  // token 0 of the passage
+  for (int i = tid; i < H; i += 256) cls[i] = h[i];
+  __syncthreads();
+  float acc = 0.f;  // this wave's share of sum_j cw[1][j] * tanh(pooler_j)
+  for (int j = wave; j < H; j += 4) {
+    const float* w = pw + (int64_t)j * H;
+    float p = 0.f;
+    for (int i = lane; i < H; i += 64) p = __builtin_fmaf(w[i], cls[i], p);
+    p = wave_sum64(p);
+    acc = __builtin_fmaf(cw[H + j], tanhf(p + pb[j]), acc);
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (tid == 0) logits[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) + cb[1];
+}
+
+// passage pooling (ptBERTMaxP.py:75-94); one wave per document.  agg: 0 max, 1 first, 2 sum, 3 avg
+__global__ __launch_bounds__(64) void pool_kernel(const float* __restrict__ logits, const int64_t* __restrict__ mask,
+                                                  const int64_t* __restrict__ seg, int P, int S, int agg, float* __restrict__ out,
+                                                  int* __restrict__ total_cnt) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float best = -INFINITY, sum = 0.f;
+  int cnt = 0;
+  for (int p = 0; p < P; ++p) {
+    const float s = logits[(int64_t)b * P + p];
+    best = fmaxf(best, s);
+    if (agg >= 2) {
+      const int64_t* m = mask + ((int64_t)b * P + p) * S;
+      const int64_t* g = seg + ((int64_t)b * P + p) * S;
+      float pos = 0.f;
+      for (int i = lane; i < S; i += 64) pos += (float)(m[i] * g[i]);
+      pos = wave_sum64(pos);
+      if (pos > 5.f) {  // passage_mask = (sum(mask*seg) > 5)
+        sum += s;
+        cnt += 1;
+      }
+    }
+  }
+  if (lane == 0) {
+    out[b] = agg == 0 ? best : agg == 1 ? logits[(int64_t)b * P] : sum;
+    if (agg == 3) atomicAdd(total_cnt, cnt);
+  }
+}
+__global__ void avg_div_kernel(float* out, int B, const int* total_cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = out[i] / (float)(*total_cnt);  // batch-wide denominator, as the reference (:92)
+}
+
+struct Dims {
+  int H, layers, heads, F, vocab, max_pos, type_vocab;
+};
+
+bool dims_ok(const capamd_bert_model* m) {
+  return m && m->hidden >= 64 && m->hidden <= 1024 && m->hidden % 64 == 0 && m->heads * 64 == m->hidden && m->layers >= 1 &&
+         m->ffn >= 64 && m->ffn % 64 == 0 && m->vocab >= 1 && m->max_pos >= 1 && m->type_vocab >= 1;
+}
+
+int64_t layer_blob_elems(int H, int F) { return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H; }
+int64_t layer_f32_floats(int H, int F) { return (int64_t)3 * H + H + H + H + F + H + H + H; }
+
+template <int EPI>
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+  if (g.M % 256 == 0 && g.N % 256 == 0) {
+    using G = GemmKernel<256, 256, 4, 2, EPI>;
+    auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(g.N / 256, g.M / 256), dim3(G::kThreads), G::kLdsBytes, s, g);
+  } else {
+    using G = GemmKernel<64, 64, 2, 2, EPI>;
+    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3(g.N / 64, g.M / 64), dim3(G::kThreads), G::kLdsBytes, s, g);
+  }
+  return hipGetLastError();
+}
+
+struct Workspace {
+  float* xf;      // [M, H] residual stream
+  __bf16* xb;     // [M, H] bf16 copy (GEMM operand)
+  __bf16* q;      // [M, H]
+  __bf16* k;      // [M, H]
+  __bf16* vt;     // [M/S*heads, 64, S]
+  __bf16* ctx;    // [M, H]
+  float* pre;     // [M, H] pre-LayerNorm sums
+  __bf16* mid;    // [M, F]
+  float* logits;  // [B*P] (whole call)
+  int* cnt;       // avg denominator
+};
+
+size_t ws_bytes_for(int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_total) {
+  const int64_t M = n_psg_mb * S;
+  size_t b = 0;
+  auto add = [&](size_t x) { b += (x + 255) & ~(size_t)255; };
+  add((size_t)M * H * 4); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2);
+  add((size_t)M * H * 2); add((size_t)M * H * 4); add((size_t)M * F * 2); add((size_t)n_psg_total * 4); add(256);
+  return b;
+}
+
+Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_total) {
+  const int64_t M = n_psg_mb * S;
+  Workspace w;
+  auto take = [&](size_t x) { char* r = p; p += (x + 255) & ~(size_t)255; return r; };
+  w.xf = (float*)take((size_t)M * H * 4);
+  w.xb = (__bf16*)take((size_t)M * H * 2);
+  w.q = (__bf16*)take((size_t)M * H * 2);
+  w.k = (__bf16*)take((size_t)M * H * 2);
+  w.vt = (__bf16*)take((size_t)M * H * 2);
+  w.ctx = (__bf16*)take((size_t)M * H * 2);
+  w.pre = (float*)take((size_t)M * H * 4);
+  w.mid = (__bf16*)take((size_t)M * F * 2);
+  w.logits = (float*)take((size_t)n_psg_total * 4);
+  w.cnt = (int*)take(256);
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t capamd_bert_blob_bytes(const capamd_bert_model* m) {
+  return dims_ok(m) ? (int64_t)m->layers * layer_blob_elems(m->hidden, m->ffn) * 2 : -1;
+}
+int64_t capamd_bert_layer_f32_floats(const capamd_bert_model* m) { return dims_ok(m) ? layer_f32_floats(m->hidden, m->ffn) : -1; }
+
+int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* const* t /* 16 device pointers, host array */,
+                           void* blob, float* layer_f32, void* stream) {
+  if (!dims_ok(m) || !t || !blob || !layer_f32 || layer < 0 || layer >= m->layers) return CAPAMD_ERR_ARG;
+  for (int i = 0; i < 16; ++i)
+    if (!t[i]) return CAPAMD_ERR_ARG;
+  const int64_t H = m->hidden, F = m->ffn;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  __bf16* wb = (__bf16*)blob + (int64_t)layer * layer_blob_elems(H, F);
+  float* fb = layer_f32 + (int64_t)layer * layer_f32_floats(H, F);
+  // order of t: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b ffn1.w ffn1.b ffn2.w ffn2.b ln2.g ln2.b
+  struct { int src; int64_t off, n; } wcp[] = {{0, 0, H * H}, {2, H * H, H * H}, {4, 2 * H * H, H * H}, {6, 3 * H * H, H * H},
+                                               {10, 4 * H * H, F * H}, {12, 4 * H * H + F * H, H * F}};
+  for (auto& c : wcp) hipLaunchKernelGGL(cvt_bf16_kernel, dim3(512), dim3(256), 0, s, t[c.src], wb + c.off, c.n);
+  struct { int src; int64_t off, n; } fcp[] = {{1, 0, H}, {3, H, H}, {5, 2 * H, H}, {7, 3 * H, H}, {8, 4 * H, H}, {9, 5 * H, H},
+                                               {11, 6 * H, F}, {13, 6 * H + F, H}, {14, 7 * H + F, H}, {15, 8 * H + F, H}};
+  for (auto& c : fcp) hipLaunchKernelGGL(copy_f32_kernel, dim3(8), dim3(256), 0, s, t[c.src], fb + c.off, c.n);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+int64_t capamd_bert_workspace_bytes(const capamd_bert_model* m, int S, int64_t passages_per_microbatch, int64_t total_passages) {
+  if (!dims_ok(m) || S < 1 || passages_per_microbatch < 1 || total_passages < 1) return -1;
+  return (int64_t)ws_bytes_for(m->hidden, m->ffn, S, passages_per_microbatch, total_passages);
+}
+
+int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
+                             const capamd_bert_model* m, int aggregation, int64_t passages_per_microbatch, void* workspace,
+                             int64_t workspace_bytes, float* out, float* passage_logits_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !out || !status || B < 0 || P < 1) return CAPAMD_ERR_ARG;
+  if (!(S == 64 || S == 128 || S == 256) || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
+  if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->pooler_w || !m->pooler_b || !m->cls_w ||
+      !m->cls_b || !m->blob || !m->layer_f32)
+    return CAPAMD_ERR_ARG;
+  const int H = m->hidden, F = m->ffn;
+  const int64_t NP = (int64_t)B * P;
+  int64_t mb = passages_per_microbatch < NP ? passages_per_microbatch : NP;
+  if (mb < 1) return CAPAMD_ERR_ARG;
+  if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  Workspace w = carve((char*)workspace, H, F, S, mb, NP);
+  const __bf16* blob = (const __bf16*)m->blob;
+  hipError_t e = hipSuccess;
+
+  for (int64_t p0 = 0; p0 < NP && e == hipSuccess; p0 += mb) {
+    const int64_t np = (NP - p0 < mb) ? NP - p0 : mb;
+    const int64_t M = np * S;
+    const int64_t* ids_mb = ids + p0 * S;
+    const int64_t* mask_mb = mask + p0 * S;
+    const int64_t* seg_mb = seg + p0 * S;
+    hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, w.xf, w.xb, status);
+    for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
+      const __bf16* wl = blob + (int64_t)l * layer_blob_elems(H, F);
+      const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
+      const __bf16 *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
+      const float *bqkv = fl, *bo = fl + 3 * H, *ln1g = fl + 4 * H, *ln1b = fl + 5 * H, *b1 = fl + 6 * H, *b2 = fl + 6 * H + F,
+                  *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
+      GemmArgs g{};
+      g.H = H; g.S = S; g.heads = m->heads;
+      // QKV projection (+bias, Q/8, V transposed per head)
+      g.A = w.xb; g.W = wqkv; g.bias = bqkv; g.M = (int)M; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
+      e = launch_gemm<kEpiQkv>(g, s);
+      if (e != hipSuccess) break;
+      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
+      const unsigned nblk = (unsigned)(np * m->heads);
+      if (S == 256) hipLaunchKernelGGL(attention_kernel<256>, dim3(nblk), dim3(512), 0, s, at);
+      else if (S == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3(nblk), dim3(256), 0, s, at);
+      else hipLaunchKernelGGL(attention_kernel<64>, dim3(nblk), dim3(128), 0, s, at);
+      // attention output projection + residual -> LayerNorm
+      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid = w.xf; g.out_f32 = w.pre;
+      e = launch_gemm<kEpiBiasResidF32>(g, s);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         0, 0, S, ln1g, ln1b, M, H, w.xf, w.xb, status);
+      // feed-forward: 768 -> 3072 (GELU) -> 768 + residual -> LayerNorm
+      g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
+      e = launch_gemm<kEpiBiasGeluBf16>(g, s);
+      if (e != hipSuccess) break;
+      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid = w.xf; g.out_f32 = w.pre;
+      e = launch_gemm<kEpiBiasResidF32>(g, s);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         0, 0, S, ln2g, ln2b, M, H, w.xf, w.xb, status);
+    }
+    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)np), dim3(256), 0, s, w.xf, S, H, m->pooler_w, m->pooler_b, m->cls_w, m->cls_b,
+                       w.logits + p0);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
+  if (aggregation == 3) (void)hipMemsetAsync(w.cnt, 0, 4, s);
+  hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(64), 0, s, w.logits, mask, seg, P, S, aggregation, out, w.cnt);
+  if (aggregation == 3) hipLaunchKernelGGL(avg_div_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out, B, w.cnt);
+  if (passage_logits_out) (void)hipMemcpyAsync(passage_logits_out, w.logits, (size_t)NP * 4, hipMemcpyDeviceToDevice, s);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+/* building blocks, exported for unit tests and for callers that want the encoder pieces */
+int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const float* resid,
+                     void* out, void* stream) {
+  if (!A || !W || !bias || !out || M < 64 || N < 64 || K < 64 || M % 64 || N % 64 || K % 64) return CAPAMD_ERR_ARG;
+  (void)hipGetLastError();
+  GemmArgs g{};
+  g.A = (const __bf16*)A; g.W = (const __bf16*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  hipError_t e;
+  if (epilogue == kEpiBiasBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasBf16>(g, (hipStream_t)stream); }
+  else if (epilogue == kEpiBiasGeluBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasGeluBf16>(g, (hipStream_t)stream); }
+  else if (epilogue == kEpiBiasResidF32) {
+    if (!resid) return CAPAMD_ERR_ARG;
+    g.resid = resid; g.out_f32 = (float*)out; e = launch_gemm<kEpiBiasResidF32>(g, (hipStream_t)stream);
+  } else return CAPAMD_ERR_ARG;
+  return e == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,
+                              int hidden, int heads, void* q, void* k, void* vt, void* ctx, void* stream) {
+  if (!x || !wqkv || !bqkv || !mask || !q || !k || !vt || !ctx || n_passages < 1 || heads * 64 != hidden) return CAPAMD_ERR_ARG;
+  if (!(S == 64 || S == 128 || S == 256)) return CAPAMD_ERR_ARG;
+  (void)hipGetLastError();
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{};
+  g.H = hidden; g.S = S; g.heads = heads;
+  g.A = (const __bf16*)x; g.W = (const __bf16*)wqkv; g.bias = bqkv; g.M = n_passages * S; g.N = 3 * hidden; g.K = hidden;
+  g.out_bf16 = (__bf16*)q; g.out_k = (__bf16*)k; g.out_vt = (__bf16*)vt;
+  if (launch_gemm<kEpiQkv>(g, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
+  AttnArgs at{(const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, mask, (__bf16*)ctx, hidden, heads};
+  const unsigned nblk = (unsigned)(n_passages * heads);
+  if (S == 256) hipLaunchKernelGGL(attention_kernel<256>, dim3(nblk), dim3(512), 0, s, at);
+  else if (S == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3(nblk), dim3(256), 0, s, at);
+  else hipLaunchKernelGGL(attention_kernel<64>, dim3(nblk), dim3(128), 0, s, at);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+}  // extern "C"

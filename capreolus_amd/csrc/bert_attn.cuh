@@ -1,0 +1,149 @@
+// Fused multi-head self-attention for the BERT passage encoder on gfx950 (head_dim 64, S in {64,128,256}).
+//
+// One workgroup per (passage, head); S/32 waves, each owning 32 query rows and ALL S keys, so the
+// softmax is exact (no online rescaling): the S/32 score tiles of a wave (16 fp32 registers per
+// 32x32 tile) stay in registers from QK^T to PV.
+//
+//   scores^T = K · Q^T     (v_mfma_f32_32x32x16_bf16, K rows as the A operand, so a lane holds
+//                           ONE query (lane&31) and S/2 keys -> row max/sum are in-lane reductions
+//                           plus one exchange with lane^32)
+//   P = softmax(scores + additive pad mask)      (Q was pre-scaled by 1/8 in the QKV epilogue)
+//   ctx^T = V^T · P^T      (A operand = V^T fragment read from a [64 d][S keys] LDS image, B operand =
+//                           the P registers as they are: the MFMA k index is only a summation index,
+//                           so the key order the QK^T layout leaves in a lane is used for V as well)
+// K is staged with global_load_lds into the same swizzled [rows][64] image the GEMM uses; V^T comes
+// from the QKV GEMM already transposed per head and is staged through registers into rows padded
+// by 8 bytes (conflict-free ds_read_b64 for 32 lanes reading 32 different d rows).
+#pragma once
+#include "bert_gemm.cuh"
+
+namespace capamd {
+
+struct AttnArgs {
+  const __bf16* Q;       // [M, H] (pre-scaled by 1/8)
+  const __bf16* K;       // [M, H]
+  const __bf16* Vt;      // [M/S * heads][64][S]
+  const int64_t* mask;   // [M/S, S] attention mask (1 = attend), rows of the current micro-batch
+  __bf16* ctx;           // [M, H]
+  int H, heads;
+};
+
+template <int S>
+__global__ __launch_bounds__(2 * S) void attention_kernel(AttnArgs a) {
+  constexpr int NT = S / 32;            // key tiles == waves
+  constexpr int VROW = S * 2 + 8;       // bytes per V^T row in LDS
+  __shared__ __attribute__((aligned(16))) char lds[S * 128 + 64 * VROW + S * 4];
+  char* Ks = lds;
+  char* Vs = lds + S * 128;
+  float* madd = reinterpret_cast<float*>(lds + S * 128 + 64 * VROW);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int psg = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
+  const int64_t tok0 = (int64_t)psg * S;
+
+  // ---- stage K (swizzled, via LDS-DMA), V^T (padded rows, via registers), additive mask ----
+  {
+    const int r8 = lane >> 3, p = lane & 7;
+    constexpr int INSTR = S * 8 / 64 / NT;  // = 4
+#pragma unroll
+    for (int t = 0; t < INSTR; ++t) {
+      const int row = (wave * INSTR + t) * 8 + r8;
+      const __bf16* src = a.K + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * INSTR + t) * 1024), 16, 0, 0);
+    }
+    const __bf16* vsrc = a.Vt + (int64_t)blockIdx.x * 64 * S;
+    for (int c = tid; c < 64 * S / 8; c += 2 * S) {
+      const int d = c / (S / 8), k8 = c % (S / 8);
+      const uint4 x = *reinterpret_cast<const uint4*>(vsrc + d * S + k8 * 8);
+      *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16) = make_uint2(x.x, x.y);
+      *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16 + 8) = make_uint2(x.z, x.w);
+    }
+    for (int k = tid; k < S; k += 2 * S)
+      madd[k] = a.mask[(int64_t)psg * S + k] != 0 ? 0.f : -3.4028234663852886e38f;  // HF: (1-mask) * finfo.min
+  }
+  // this wave's Q fragments (B operand): query = wave*32 + l31, d = (2*ks+half)*8 ..+7
+  bf16x8 qf[4];
+  {
+    const __bf16* qrow = a.Q + (tok0 + wave * 32 + l31) * a.H + head * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+  }
+  __syncthreads();
+
+  // ---- scores^T tiles: lane <- query l31, keys 32t + 8*(r>>2) + 4*half + (r&3) ----
+  f32x16 sc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int row = t * 32 + l31;
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
+      sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+    }
+  }
+  // ---- exact softmax over the S keys of this lane's query ----
+  float mx = -3.4028234663852886e38f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 ma = *reinterpret_cast<const float4*>(madd + t * 32 + 8 * g4 + 4 * half);
+      sc[t][g4 * 4 + 0] += ma.x;
+      sc[t][g4 * 4 + 1] += ma.y;
+      sc[t][g4 * 4 + 2] += ma.z;
+      sc[t][g4 * 4 + 3] += ma.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sc[t][g4 * 4 + e]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f((sc[t][r] - mx) * 1.4426950408889634f);
+      sc[t][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+
+  // ---- ctx^T = V^T · P^T : out[dt] lane <- query l31, d = 32dt + 8*(r>>2) + 4*half + (r&3) ----
+  f32x16 out[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[t][8 * s2 + e];
+      const int kb = (32 * t + 16 * s2 + 4 * half) * 2;  // byte offset of keys {kb/2 .. +3}; second group +8 keys
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* vr = Vs + (dt * 32 + l31) * VROW + kb;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+        const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, raw);
+        out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, out[dt], 0, 0, 0);
+      }
+    }
+  __bf16* crow = a.ctx + (tok0 + wave * 32 + l31) * a.H + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o = {(__bf16)(out[dt][g4 * 4 + 0] * inv), (__bf16)(out[dt][g4 * 4 + 1] * inv),
+                  (__bf16)(out[dt][g4 * 4 + 2] * inv), (__bf16)(out[dt][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+    }
+}
+
+}  // namespace capamd

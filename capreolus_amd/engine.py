@@ -153,3 +153,97 @@ def drmm_forward(query, doc, idf, packed, V, D, edges, hist_type, gate_type, gat
     if check:
         st.raise_if_set()
     return out
+
+
+AGGREGATIONS = {"max": 0, "first": 1, "sum": 2, "avg": 3}
+
+_LAYER_TENSORS = (
+    "attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+    "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight", "attention.output.dense.bias",
+    "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+    "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias",
+)
+
+
+class BertEngine:
+    """Device-side state of one BERT sequence classifier for capamd_bert_maxp_forward.
+
+    `params` maps the HF state_dict names (``bert.embeddings...``, ``bert.encoder.layer.N...``,
+    ``bert.pooler.dense...``, ``classifier...``) to live fp32 parameters on the device.  The bf16
+    weight blob is rebuilt whenever any parameter's version counter or storage changes.
+    """
+
+    def __init__(self, params, heads, microbatch=256):
+        self.params = params
+        self.heads = heads
+        self.microbatch = microbatch
+        self._key = None
+        self._blob = self._lf32 = self._ws = None
+        self._model = None
+        self._keep = None
+
+    def _dims(self):
+        p = self.params
+        hidden = p["bert.embeddings.word_embeddings.weight"].shape[1]
+        layers = 1 + max(int(k.split(".")[3]) for k in p if k.startswith("bert.encoder.layer."))
+        m = _lib.BertModel()
+        m.hidden, m.layers, m.heads = hidden, layers, self.heads
+        m.ffn = p["bert.encoder.layer.0.intermediate.dense.weight"].shape[0]
+        m.vocab = p["bert.embeddings.word_embeddings.weight"].shape[0]
+        m.max_pos = p["bert.embeddings.position_embeddings.weight"].shape[0]
+        m.type_vocab = p["bert.embeddings.token_type_embeddings.weight"].shape[0]
+        return m
+
+    def model(self):
+        p = self.params
+        key = tuple((t.data_ptr(), t._version) for t in p.values())
+        if key == self._key:
+            return self._model
+        lib = _lib.load()
+        some = p["classifier.weight"]
+        _need_gpu(*p.values())
+        m = self._dims()
+        nblob, nf = lib.capamd_bert_blob_bytes(ctypes.byref(m)), lib.capamd_bert_layer_f32_floats(ctypes.byref(m))
+        if nblob < 0:
+            raise ValueError("unsupported BERT geometry: need hidden == 64*heads, hidden % 64 == 0 (<= 1024), ffn % 64 == 0")
+        blob = torch.empty(nblob, dtype=torch.uint8, device=some.device)
+        lf32 = torch.empty(nf * m.layers, dtype=torch.float32, device=some.device)
+        keep = {k: _f32(v.detach()) for k, v in p.items()}
+        for layer in range(m.layers):
+            arr = (ctypes.c_void_p * 16)(*[keep[f"bert.encoder.layer.{layer}.{n}"].data_ptr() for n in _LAYER_TENSORS])
+            _lib.check(lib.capamd_bert_pack_layer(ctypes.byref(m), layer, arr, _ptr(blob), _ptr(lf32), _stream()), "capamd_bert_pack_layer")
+        for field, name in (("word_emb", "bert.embeddings.word_embeddings.weight"), ("pos_emb", "bert.embeddings.position_embeddings.weight"),
+                            ("type_emb", "bert.embeddings.token_type_embeddings.weight"), ("emb_ln_g", "bert.embeddings.LayerNorm.weight"),
+                            ("emb_ln_b", "bert.embeddings.LayerNorm.bias"), ("pooler_w", "bert.pooler.dense.weight"),
+                            ("pooler_b", "bert.pooler.dense.bias"), ("cls_w", "classifier.weight"), ("cls_b", "classifier.bias")):
+            setattr(m, field, keep[name].data_ptr())
+        m.blob, m.layer_f32 = blob.data_ptr(), lf32.data_ptr()
+        self._blob, self._lf32, self._keep, self._model, self._key = blob, lf32, keep, m, key
+        return m
+
+    def forward(self, doc_input, doc_mask, doc_seg, aggregation="max", return_passage_logits=False, check=True):
+        """PTBERTMaxP_Class.predict_step (reference ptBERTMaxP.py:67-96): int64 [B,P,S] x3 -> fp32 [B]."""
+        _need_gpu(doc_input, doc_mask, doc_seg)
+        if aggregation not in AGGREGATIONS:
+            raise ValueError("Unknown aggregation method: {}".format(aggregation))
+        ids, mask, seg = _i64(doc_input), _i64(doc_mask), _i64(doc_seg)
+        B, P, S = ids.shape
+        out = torch.empty(B, dtype=torch.float32, device=ids.device)
+        if B == 0:
+            return (out, torch.empty(0, device=ids.device)) if return_passage_logits else out
+        m = self.model()
+        lib = _lib.load()
+        mb = min(self.microbatch, B * P)
+        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
+        if need < 0:
+            raise ValueError(f"unsupported passage length {S} (supported: 64, 128, 256)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
+        st = status_word(ids.device)
+        rc = lib.capamd_bert_maxp_forward(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), AGGREGATIONS[aggregation], mb,
+                                          _ptr(self._ws), self._ws.numel(), _ptr(out), _ptr(plog), _ptr(st.t), _stream())
+        _lib.check(rc, "capamd_bert_maxp_forward")
+        if check:
+            st.raise_if_set()
+        return (out, plog) if return_passage_logits else out

@@ -67,4 +67,6 @@ class Reranker:
 from .KNRM import KNRM, KNRM_class  # noqa: E402,F401
 from .DRMM import DRMM, DRMM_class  # noqa: E402,F401
 
-registry = {"KNRM": KNRM, "DRMM": DRMM}
+from .ptBERTMaxP import PTBERTMaxP, PTBERTMaxP_Class  # noqa: E402,F401
+
+registry = {"KNRM": KNRM, "DRMM": DRMM, "ptBERTMaxP": PTBERTMaxP}

@@ -1,0 +1,119 @@
+"""BERT-MaxP behind the reference plugin surface (capreolus/reranker/ptBERTMaxP.py:99-135), scored by the
+gfx950 kernels in capreolus_amd/csrc/bert*.{hip,cuh} through the C ABI.
+
+The reference keeps a transformers `AutoModelForSequenceClassification` in ``self.bert``; here a bare
+parameter container with the same attribute tree (and therefore the same state_dict names:
+``bert.bert.embeddings.*``, ``bert.bert.encoder.layer.N.*``, ``bert.bert.pooler.dense.*``,
+``bert.classifier.*``) holds the weights, so reference checkpoints load unchanged.  Only BERT-architecture
+checkpoints are supported (bert-base-uncased, Capreolus/bert-base-msmarco, ...).
+"""
+import torch
+from torch import nn
+
+from .. import engine
+from . import Reranker
+
+
+class _Box(nn.Module):
+    """A named bag of sub-modules (gives the HF attribute paths without any HF code)."""
+
+    def __init__(box, **mods):  # noqa: N805  ("self" is one of the HF attribute names)
+        super().__init__()
+        for k, v in mods.items():
+            setattr(box, k, v)
+
+
+def _encoder_layer(H, F):
+    return _Box(
+        attention=_Box(self=_Box(query=nn.Linear(H, H), key=nn.Linear(H, H), value=nn.Linear(H, H)),
+                       output=_Box(dense=nn.Linear(H, H), LayerNorm=nn.LayerNorm(H, eps=1e-12))),
+        intermediate=_Box(dense=nn.Linear(H, F)),
+        output=_Box(dense=nn.Linear(F, H), LayerNorm=nn.LayerNorm(H, eps=1e-12)),
+    )
+
+
+def bert_container(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2):
+    """Parameter tree of BertForSequenceClassification(num_labels=2) (state_dict names as HF)."""
+    body = _Box(
+        embeddings=_Box(word_embeddings=nn.Embedding(vocab, hidden, padding_idx=0), position_embeddings=nn.Embedding(max_pos, hidden),
+                        token_type_embeddings=nn.Embedding(type_vocab, hidden), LayerNorm=nn.LayerNorm(hidden, eps=1e-12)),
+        encoder=_Box(layer=nn.ModuleList([_encoder_layer(hidden, ffn) for _ in range(layers)])),
+        pooler=_Box(dense=nn.Linear(hidden, hidden)),
+    )
+    box = _Box(bert=body, classifier=nn.Linear(hidden, 2))
+    box.num_attention_heads = heads
+    return box
+
+
+class PTBERTMaxP_Class(nn.Module):
+    def __init__(self, extractor, config):
+        super().__init__()
+        self.extractor = extractor
+        self.config = config
+        pre = config["pretrained"]
+        if isinstance(pre, dict):            # explicit geometry, weights loaded later with load_state_dict
+            self.bert = bert_container(**pre)
+        elif isinstance(pre, str) and ("electra" in pre or "roberta" in pre):
+            raise NotImplementedError(f"{pre}: only BERT-architecture sequence classifiers are scored by the MI355X engine")
+        else:
+            self.bert = self._from_hf(pre, config["hidden_dropout_prob"])
+        self._engine = None
+
+    @staticmethod
+    def _from_hf(name, hidden_dropout_prob):
+        """Reads a local/cached HF checkpoint (no network here) and copies its tensors into the container."""
+        from transformers import AutoModelForSequenceClassification
+
+        if name == "bert-base-msmarco":
+            name = "Capreolus/bert-base-msmarco"
+        hf = AutoModelForSequenceClassification.from_pretrained(name, hidden_dropout_prob=hidden_dropout_prob)
+        c = hf.config
+        if c.model_type != "bert" or c.hidden_act != "gelu" or c.num_labels != 2:
+            raise NotImplementedError(f"{name}: unsupported architecture {c.model_type}/{c.hidden_act}/{c.num_labels} labels")
+        box = bert_container(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size, c.vocab_size,
+                             c.max_position_embeddings, c.type_vocab_size)
+        missing = box.load_state_dict(hf.state_dict(), strict=False)
+        if missing.missing_keys:
+            raise RuntimeError(f"checkpoint lacks {missing.missing_keys}")
+        return box
+
+    def _params(self):
+        return {k: v for k, v in self.bert.state_dict(keep_vars=True).items()}
+
+    def forward(self, doc_input, doc_mask, doc_seg):
+        if self.training:
+            raise NotImplementedError(
+                "capreolus_amd scores with hand-written inference kernels; fine-tuning (ptBERTMaxP.py:60-61) is not part of "
+                "this engine. Call under model.eval() as PytorchTrainer.predict does."
+            )
+        return self.predict_step(doc_input, doc_mask, doc_seg)
+
+    def predict_step(self, doc_input, doc_mask, doc_seg):
+        P, S = self.extractor.config["numpassages"], self.extractor.config["maxseqlen"]
+        B = doc_input.shape[0]
+        if self._engine is None:
+            self._engine = engine.BertEngine(self._params(), self.bert.num_attention_heads,
+                                             microbatch=int(self.config.get("microbatch", 256)))
+        else:
+            self._engine.params = self._params()
+        shape = (B, P, S)
+        return self._engine.forward(doc_input.reshape(shape), doc_mask.reshape(shape), doc_seg.reshape(shape), self.config["aggregation"])
+
+
+class PTBERTMaxP(Reranker):
+    """Dai & Callan, Deeper Text Understanding for IR with Contextual Neural Language Modeling, SIGIR'19
+    (reference ptBERTMaxP.py:99-122)."""
+
+    module_name = "ptBERTMaxP"
+    config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256}
+
+    def build_model(self):
+        self.model = PTBERTMaxP_Class(self.extractor, self.config)
+        return self.model
+
+    def score(self, d):
+        return [self.model(d["pos_bert_input"], d["pos_mask"], d["pos_seg"]).view(-1),
+                self.model(d["neg_bert_input"], d["neg_mask"], d["neg_seg"]).view(-1)]
+
+    def test(self, d):
+        return self.model(d["pos_bert_input"], d["pos_mask"], d["pos_seg"]).view(-1)

@@ -85,6 +85,61 @@ int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float*
                         const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
                         const float* out_b, float* out, int32_t* counts_out, int* status, void* stream);
 
+/* ---- PTBERTMaxP_Class.predict_step (capreolus/reranker/ptBERTMaxP.py:67-96) behind PTBERTMaxP.test
+ * (ptBERTMaxP.py:134-135), including the transformers.BertForSequenceClassification forward it calls
+ * at :82 (embeddings, 12 post-LN encoder layers, pooler, classifier, logit 1).
+ *
+ * The model is described by plain pointers.  fp32 tensors are read in place from the live
+ * nn.Module parameters; the GEMM weights are converted once to bf16 into a caller-owned `blob`
+ * (capamd_bert_pack_layer; re-run it after load_weights / an optimizer step), the per-layer
+ * biases and LayerNorm vectors are gathered into `layer_f32`.
+ * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S in {64, 128, 256}. */
+typedef struct capamd_bert_model {
+  int hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+  const float* word_emb;  /* [vocab, hidden]      bert.embeddings.word_embeddings.weight */
+  const float* pos_emb;   /* [max_pos, hidden]    bert.embeddings.position_embeddings.weight */
+  const float* type_emb;  /* [type_vocab, hidden] bert.embeddings.token_type_embeddings.weight */
+  const float* emb_ln_g;  /* [hidden]             bert.embeddings.LayerNorm.weight */
+  const float* emb_ln_b;  /* [hidden]             bert.embeddings.LayerNorm.bias */
+  const float* pooler_w;  /* [hidden, hidden]     bert.pooler.dense.weight */
+  const float* pooler_b;  /* [hidden] */
+  const float* cls_w;     /* [2, hidden]          classifier.weight */
+  const float* cls_b;     /* [2] */
+  const void* blob;       /* capamd_bert_blob_bytes(): per layer Wqkv[3H,H] | Wo[H,H] | W1[F,H] | W2[H,F], bf16 */
+  const float* layer_f32; /* layers * capamd_bert_layer_f32_floats(): bqkv | bo | ln1.g | ln1.b | b1 | b2 | ln2.g | ln2.b */
+} capamd_bert_model;
+
+int64_t capamd_bert_blob_bytes(const capamd_bert_model* m);        /* only the int fields are read */
+int64_t capamd_bert_layer_f32_floats(const capamd_bert_model* m);  /* floats per layer */
+/* tensors_host: HOST array of 16 DEVICE pointers for encoder layer `layer`, in this order:
+ * attention.self.query.{weight,bias}, .key.{weight,bias}, .value.{weight,bias}, attention.output.dense.{weight,bias},
+ * attention.output.LayerNorm.{weight,bias}, intermediate.dense.{weight,bias}, output.dense.{weight,bias},
+ * output.LayerNorm.{weight,bias} */
+int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* const* tensors_host, void* blob,
+                           float* layer_f32, void* stream);
+/* workspace for scoring `total_passages` = B*P passages in micro-batches of `passages_per_microbatch` */
+int64_t capamd_bert_workspace_bytes(const capamd_bert_model* m, int S, int64_t passages_per_microbatch,
+                                    int64_t total_passages);
+/* ids/mask/seg int64 [B, P, S] (bertpassage.py:313-325); aggregation 0 max, 1 first, 2 sum, 3 avg
+ * (ptBERTMaxP.py:85-94; avg divides by the batch-wide passage count as the reference does);
+ * out fp32 [B]; passage_logits_out optional fp32 [B*P]; workspace 256-byte aligned. */
+int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
+                             const capamd_bert_model* m, int aggregation, int64_t passages_per_microbatch,
+                             void* workspace, int64_t workspace_bytes, float* out, float* passage_logits_out,
+                             int* status, void* stream);
+
+/* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
+ * the reference calls at ptBERTMaxP.py:82).  bf16 operands, fp32 accumulation.
+ * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;
+ * 2: + resid[M,N] (fp32), fp32 out.  M, N, K multiples of 64. */
+int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
+                     const float* resid, void* out, void* stream);
+/* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.
+ * q, k: bf16 [n_passages*S, hidden]; vt: bf16 [n_passages*heads, 64, S]; ctx: bf16 [n_passages*S, hidden];
+ * mask int64 [n_passages, S]. */
+int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
+                              int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
