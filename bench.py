@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="knrm", choices=["knrm", "drmm"])
+    ap.add_argument("--model", default="knrm", choices=["knrm", "drmm", "bert"])
     ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU")
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
@@ -66,6 +66,9 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.model == "bert":
+        return bench_bert(args, world, rank, dev)
 
     from types import SimpleNamespace
 
@@ -210,6 +213,127 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(args, m, batch, emb, Q, L, D)
+    print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA")
+
+
+def bert_flops_per_passage(S=256, H=768, F=3072, layers=12):
+    """QKVO 4*2*S*H^2 + attention 2*2*S^2*H + FFN 2*2*S*H*F per layer."""
+    return layers * (8 * S * H * H + 4 * S * S * H + 4 * S * H * F)
+
+
+def bench_bert(args, world, rank, dev):
+    """BASELINE.json configs[3]: BERT-base MaxP, 4 passages x 256 tokens per document, 1000 docs/query."""
+    import ctypes
+    from types import SimpleNamespace
+
+    from capreolus_amd import _lib, engine, synthetic
+    from capreolus_amd.reranker import PTBERTMaxP
+    from oracle import bert_port
+
+    if world > 1:
+        import torch.distributed as dist
+    P, S, H, F, LAYERS, HEADS, VOCAB = 4, 256, 768, 3072, 12, 12, 30522
+    docs = args.docs * (args.queries if args.queries != 64 else 1)   # default: one query's 1000 candidates per step
+    rs = np.random.RandomState(1000 + rank)
+    host = synthetic.make_bert_passages(rs, min(docs, 64), P, S, vocab=VOCAB)
+    reps = (docs + host["pos_bert_input"].shape[0] - 1) // host["pos_bert_input"].shape[0]
+    d = {k: torch.as_tensor(np.tile(v, (reps, 1, 1))[:docs]).to(dev) for k, v in host.items()}
+    # vary the tiled copies so that no two documents are identical
+    d["pos_bert_input"] = torch.where((d["pos_mask"] == 1) & (d["pos_bert_input"] > 999),
+                                      (d["pos_bert_input"] + torch.arange(docs, device=dev)[:, None, None] * 7) % (VOCAB - 1000) + 1000,
+                                      d["pos_bert_input"])
+    weights = bert_port.random_weights(H, LAYERS, HEADS, F, VOCAB, 512, seed=0)
+    rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": 256},
+                    SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
+    m = rr.build_model()
+    m.bert.load_state_dict(weights, strict=True)
+    m.to(dev).eval()
+    with torch.no_grad():
+        rr.test({k: v[:8] for k, v in d.items()})   # builds the bf16 blob
+    eng = m._engine
+    gathered = torch.empty(docs * world, dtype=torch.float32, device=dev) if world > 1 else None
+    out = [None]
+
+    def step():
+        out[0] = eng.forward(d["pos_bert_input"], d["pos_mask"], d["pos_seg"], "max", check=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out[0])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    engine.status_word(dev).raise_if_set()
+    assert torch.isfinite(out[0]).all()
+
+    # dominant kernel: the FFN1 GEMM (M = 256 passages x 256 tokens, N = 3072, K = 768, bias+GELU epilogue)
+    Mg, Ng, Kg = 256 * S, F, H
+    A = torch.randn((Mg, Kg), device=dev).bfloat16()
+    W = (torch.randn((Ng, Kg), device=dev) * 0.05).bfloat16()
+    bias = torch.randn(Ng, device=dev)
+    o = torch.empty((Mg, Ng), dtype=torch.bfloat16, device=dev)
+    lib = _lib.load()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    evs = []
+    for i in range(13):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), Mg, Ng, Kg, 1, None, vp(o), st) == 0
+        e1.record()
+        if i >= 3:
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    gemm_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+    gemm_tf = 2.0 * Mg * Ng * Kg / gemm_s / 1e12
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    psg_per_s = docs * P * world * args.steps / elapsed
+    step_tf = psg_per_s / world * bert_flops_per_passage() / 1e12
+    rec = {
+        "metric": "query-doc pairs scored/sec", "value": docs * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BERT-base MaxP inference (BASELINE.json configs[3]): {P} passages x {S} tokens per doc, {docs} docs per step "
+                               f"per GPU, seeded random-init weights, bf16 MFMA with fp32 accumulate/residual/LayerNorm/softmax",
+                   "passages_per_s": psg_per_s, "parallelism": f"document-sharded x{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256,4,2,bias+GELU> (FFN1, M=65536 N=3072 K=768)",
+                     "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
+                     "traffic": None, "kernel_ms": gemm_s * 1e3,
+                     "whole_step_achieved": step_tf, "whole_step_frac": step_tf / MFMA_BF16_PEAK_TFLOPS,
+                     "algorithmic_flops_per_passage": bert_flops_per_passage()},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        n = args.cpu_pairs or 4
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        hd = {k: v[:n].cpu() for k, v in d.items()}
+        t0 = time.perf_counter()
+        bert_port.maxp(weights, hd["pos_bert_input"], hd["pos_mask"], hd["pos_seg"], HEADS, LAYERS, "max", chunk=16)
+        dt = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} documents ({n * P} passages) through oracle/bert_port.py (fp32 ATen ops, {cores} threads)"}
     print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()
