@@ -4,11 +4,14 @@
 // fused bias / GELU / residual epilogues (bert_gemm.cuh), fused exact-softmax attention
 // (bert_attn.cuh), LayerNorm, pooler + classifier, passage pooling.
 //
-// Precision: GEMM/attention operands bf16, accumulation fp32; the residual stream, LayerNorm
-// statistics, softmax and the pooler/classifier are fp32.
+// Precision: the activation stream (incl. the residual path) is bf16 end to end; every accumulation, the
+// pre-LayerNorm sum (one rounding), LayerNorm statistics, softmax and the pooler/classifier are fp32.
+// (A fp32 residual stream was measured to give the same 6e-3 logit error: the error is set by the bf16
+// GEMM operands, not by the residual precision.)
 #include "bert_attn.cuh"
 #include "bert_gemm.cuh"
 #include "capreolus_amd.h"
+#include <stdlib.h>
 
 using namespace capamd;
 
@@ -31,13 +34,14 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 }
 
 // One wave per token: v = LayerNorm(x) over H (H % 256 == 0 is NOT required; H % 4 == 0, H <= 1024).
-// MODE 0: x = word[id] + pos[s] + type[seg]  (embeddings);  MODE 1: x = pre[token]
+// MODE 0: x = word[id] + pos[s] + type[seg]  (fp32 embedding tables);  MODE 1: x = pre[token] (bf16 pre-LN sum).
+// Output: bf16 (the activation stream is bf16 end to end; statistics and the affine are fp32).
 template <int MODE>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ pre, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void ln_kernel(const __bf16* __restrict__ pre, const int64_t* __restrict__ ids,
                                                  const int64_t* __restrict__ seg, const float* __restrict__ word,
                                                  const float* __restrict__ pos, const float* __restrict__ type, int vocab,
                                                  int type_vocab, int S, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, int64_t M, int H, float* __restrict__ xf,
+                                                 const float* __restrict__ beta, int64_t M, int H,
                                                  __bf16* __restrict__ xb, int* status) {
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,15 +61,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ pre, 
     r0 = word + id * H;
     r1 = pos + (tok % S) * H;
     r2 = type + sg * H;
-  } else {
-    r0 = pre + tok * H;
   }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
-      float4 x = reinterpret_cast<const float4*>(r0)[c];
+      float4 x;
+      if (MODE == 1) {
+        const bf16x4 b = reinterpret_cast<const bf16x4*>(pre + tok * H)[c];
+        x = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+      } else {
+        x = reinterpret_cast<const float4*>(r0)[c];
+      }
       if (MODE == 0) {
         const float4 y = reinterpret_cast<const float4*>(r1)[c], z = reinterpret_cast<const float4*>(r2)[c];
         x.x += y.x + z.x; x.y += y.y + z.y; x.z += y.z + z.z; x.w += y.w + z.w;
@@ -93,34 +101,56 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ pre, 
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      reinterpret_cast<float4*>(xf + tok * H)[c] = o;
       bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
       reinterpret_cast<bf16x4*>(xb + tok * H)[c] = ob;
     }
   }
 }
 
-// pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]); one block per passage.
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xf, int S, int H, const float* __restrict__ pw,
-                                                   const float* __restrict__ pb, const float* __restrict__ cw,
-                                                   const float* __restrict__ cb, float* __restrict__ logits) {
-  __shared__ float cls[1024];
-  __shared__ float part[4];
+// pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]).  One block per kHeadPsg
+// passages: every pooler row is fetched once per block and reused for the block's passages from registers.
+constexpr int kHeadPsg = 2;
+__global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf, int64_t n_psg, int S, int H,
+                                                   const float* __restrict__ pw, const float* __restrict__ pb,
+                                                   const float* __restrict__ cw, const float* __restrict__ cb,
+                                                   float* __restrict__ logits) {
+  __shared__ float cls[kHeadPsg][1024];
+  __shared__ float part[4][kHeadPsg];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* h = xf + (int64_t)blockIdx.x * S * H;  // token 0 of the passage
-  for (int i = tid; i < H; i += 256) cls[i] = h[i];
+  const int64_t p0 = (int64_t)blockIdx.x * kHeadPsg;
+#pragma unroll
+  for (int q = 0; q < kHeadPsg; ++q) {
+    const int64_t psg = p0 + q < n_psg ? p0 + q : n_psg - 1;
+    const __bf16* h = xf + psg * S * H;  // token 0 ([CLS]) of the passage
+    for (int i = tid; i < H; i += 256) cls[q][i] = (float)h[i];
+  }
   __syncthreads();
-  float acc = 0.f;  // this wave's share of sum_j cw[1][j] * tanh(pooler_j)
+  float acc[kHeadPsg];
+#pragma unroll
+  for (int q = 0; q < kHeadPsg; ++q) acc[q] = 0.f;
+  const int nc = (H + 63) >> 6;  // <= 16
   for (int j = wave; j < H; j += 4) {
     const float* w = pw + (int64_t)j * H;
-    float p = 0.f;
-    for (int i = lane; i < H; i += 64) p = __builtin_fmaf(w[i], cls[i], p);
-    p = wave_sum64(p);
-    acc = __builtin_fmaf(cw[H + j], tanhf(p + pb[j]), acc);
+    float wr[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) wr[c] = (c < nc && lane + 64 * c < H) ? w[lane + 64 * c] : 0.f;
+    const float bj = pb[j], cj = cw[H + j];
+#pragma unroll
+    for (int q = 0; q < kHeadPsg; ++q) {
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < nc) p = __builtin_fmaf(wr[c], cls[q][(lane + 64 * c) & 1023], p);
+      p = wave_sum64(p);
+      acc[q] = __builtin_fmaf(cj, tanhf(p + bj), acc[q]);
+    }
   }
-  if (lane == 0) part[wave] = acc;
+  if (lane == 0)
+#pragma unroll
+    for (int q = 0; q < kHeadPsg; ++q) part[wave][q] = acc[q];
   __syncthreads();
-  if (tid == 0) logits[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) + cb[1];
+  if (tid < kHeadPsg && p0 + tid < n_psg)
+    logits[p0 + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + cb[1];
 }
 
 // passage pooling (ptBERTMaxP.py:75-94); one wave per document.  agg: 0 max, 1 first, 2 sum, 3 avg
@@ -178,22 +208,21 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(g.N / 256, g.M / 256), dim3(G::kThreads), G::kLdsBytes, s, g);
+    hipLaunchKernelGGL(k, dim3((g.N / 256) * (g.M / 256)), dim3(G::kThreads), G::kLdsBytes, s, g);
   } else {
     using G = GemmKernel<64, 64, 2, 2, EPI>;
-    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3(g.N / 64, g.M / 64), dim3(G::kThreads), G::kLdsBytes, s, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3((g.N / 64) * (g.M / 64)), dim3(G::kThreads), G::kLdsBytes, s, g);
   }
   return hipGetLastError();
 }
 
 struct Workspace {
-  float* xf;      // [M, H] residual stream
-  __bf16* xb;     // [M, H] bf16 copy (GEMM operand)
+  __bf16* xb;     // [M, H] activation / residual stream
   __bf16* q;      // [M, H]
   __bf16* k;      // [M, H]
   __bf16* vt;     // [M/S*heads, 64, S]
   __bf16* ctx;    // [M, H]
-  float* pre;     // [M, H] pre-LayerNorm sums
+  __bf16* pre;    // [M, H] pre-LayerNorm sums
   __bf16* mid;    // [M, F]
   float* logits;  // [B*P] (whole call)
   int* cnt;       // avg denominator
@@ -203,8 +232,8 @@ size_t ws_bytes_for(int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_total) 
   const int64_t M = n_psg_mb * S;
   size_t b = 0;
   auto add = [&](size_t x) { b += (x + 255) & ~(size_t)255; };
-  add((size_t)M * H * 4); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2);
-  add((size_t)M * H * 2); add((size_t)M * H * 4); add((size_t)M * F * 2); add((size_t)n_psg_total * 4); add(256);
+  add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2);
+  add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * F * 2); add((size_t)n_psg_total * 4); add(256);
   return b;
 }
 
@@ -212,13 +241,12 @@ Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_to
   const int64_t M = n_psg_mb * S;
   Workspace w;
   auto take = [&](size_t x) { char* r = p; p += (x + 255) & ~(size_t)255; return r; };
-  w.xf = (float*)take((size_t)M * H * 4);
   w.xb = (__bf16*)take((size_t)M * H * 2);
   w.q = (__bf16*)take((size_t)M * H * 2);
   w.k = (__bf16*)take((size_t)M * H * 2);
   w.vt = (__bf16*)take((size_t)M * H * 2);
   w.ctx = (__bf16*)take((size_t)M * H * 2);
-  w.pre = (float*)take((size_t)M * H * 4);
+  w.pre = (__bf16*)take((size_t)M * H * 2);
   w.mid = (__bf16*)take((size_t)M * F * 2);
   w.logits = (float*)take((size_t)n_psg_total * 4);
   w.cnt = (int*)take(256);
@@ -287,7 +315,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
     const int64_t* mask_mb = mask + p0 * S;
     const int64_t* seg_mb = seg + p0 * S;
     hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, w.xf, w.xb, status);
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, w.xb, status);
     for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
       const __bf16* wl = blob + (int64_t)l * layer_blob_elems(H, F);
       const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
@@ -306,24 +334,24 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
       else if (S == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3(nblk), dim3(256), 0, s, at);
       else hipLaunchKernelGGL(attention_kernel<64>, dim3(nblk), dim3(128), 0, s, at);
       // attention output projection + residual -> LayerNorm
-      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid = w.xf; g.out_f32 = w.pre;
-      e = launch_gemm<kEpiBiasResidF32>(g, s);
+      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasResidBf16>(g, s);
       if (e != hipSuccess) break;
       hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln1g, ln1b, M, H, w.xf, w.xb, status);
+                         0, 0, S, ln1g, ln1b, M, H, w.xb, status);
       // feed-forward: 768 -> 3072 (GELU) -> 768 + residual -> LayerNorm
       g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
       e = launch_gemm<kEpiBiasGeluBf16>(g, s);
       if (e != hipSuccess) break;
-      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid = w.xf; g.out_f32 = w.pre;
-      e = launch_gemm<kEpiBiasResidF32>(g, s);
+      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasResidBf16>(g, s);
       if (e != hipSuccess) break;
       hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln2g, ln2b, M, H, w.xf, w.xb, status);
+                         0, 0, S, ln2g, ln2b, M, H, w.xb, status);
     }
     if (e != hipSuccess) break;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)np), dim3(256), 0, s, w.xf, S, H, m->pooler_w, m->pooler_b, m->cls_w, m->cls_b,
-                       w.logits + p0);
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg)), dim3(256), 0, s, w.xb, np, S, H, m->pooler_w,
+                       m->pooler_b, m->cls_w, m->cls_b, w.logits + p0);
     e = hipGetLastError();
   }
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
@@ -335,18 +363,25 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 }
 
 /* building blocks, exported for unit tests and for callers that want the encoder pieces */
-int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const float* resid,
+static unsigned long long* g_gemm_dbg = nullptr;
+void capamd_debug_set_gemm_stamps(void* p) { g_gemm_dbg = (unsigned long long*)p; }  /* profiling hook (scripts/gemm_timeline.py) */
+
+int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const void* resid,
                      void* out, void* stream) {
   if (!A || !W || !bias || !out || M < 64 || N < 64 || K < 64 || M % 64 || N % 64 || K % 64) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   GemmArgs g{};
   g.A = (const __bf16*)A; g.W = (const __bf16*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.dbg = g_gemm_dbg;
   hipError_t e;
   if (epilogue == kEpiBiasBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasBf16>(g, (hipStream_t)stream); }
   else if (epilogue == kEpiBiasGeluBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasGeluBf16>(g, (hipStream_t)stream); }
   else if (epilogue == kEpiBiasResidF32) {
     if (!resid) return CAPAMD_ERR_ARG;
-    g.resid = resid; g.out_f32 = (float*)out; e = launch_gemm<kEpiBiasResidF32>(g, (hipStream_t)stream);
+    g.resid = (const float*)resid; g.out_f32 = (float*)out; e = launch_gemm<kEpiBiasResidF32>(g, (hipStream_t)stream);
+  } else if (epilogue == kEpiBiasResidBf16) {
+    if (!resid) return CAPAMD_ERR_ARG;
+    g.resid_bf16 = (const __bf16*)resid; g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasResidBf16>(g, (hipStream_t)stream);
   } else return CAPAMD_ERR_ARG;
   return e == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }

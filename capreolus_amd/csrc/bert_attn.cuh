@@ -69,6 +69,7 @@ __global__ __launch_bounds__(2 * S) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of K: hipcc does not wait for it at the barrier by itself
   __syncthreads();
 
   // ---- scores^T tiles: lane <- query l31, keys 32t + 8*(r>>2) + 4*half + (r&3) ----

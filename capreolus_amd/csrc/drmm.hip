@@ -63,8 +63,8 @@ __device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
   return bi;  // == nbins: at or above the last edge (1.0): no regular bin
 }
 
-template <int NV>
-__global__ __launch_bounds__(kThreads) void drmm_forward_kernel(DrmmArgs a) {
+template <int NV, int U, bool QLDS, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* tok = reinterpret_cast<int*>(smem_raw);
   const int tok_cap = (a.L + 3) & ~3;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kThreads) void drmm_forward_kernel(DrmmArgs a) {
   float* zlds = edges + kMaxBins;                              // [kMaxQ]
   float* glds = zlds + kMaxQ;                                  // [kMaxQ]
   int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [8]: 0..3 real counts, 4..7 oov counts
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);      // QLDS: [kQT][NV*16] float4
 
   const int tid = threadIdx.x;
   const int lane16 = tid & 15;
@@ -115,29 +116,36 @@ __global__ __launch_bounds__(kThreads) void drmm_forward_kernel(DrmmArgs a) {
     // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
     if (tid < kQT && q0 + tid < a.Q && qrow[q0 + tid] < 0) atomicOr(a.status, kErrQueryOOV);
     QueryPass<NV> qp;
-    load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+    if (QLDS)
+      load_query_pass_lds<NV>(a.packed, qrow, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+    else
+      load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
     if (qp.id_my < 0) qp.id_my = 0;
     for (int i = tid; i < kQT * kMaxBins; i += kThreads) hist[i] = 0;
     __syncthreads();
 
-    for (int t0 = g; t0 < n_real; t0 += 2 * kGroupsPerWG) {
-      const int t1 = t0 + kGroupsPerWG;
-      const bool has1 = t1 < n_real;
-      RowRegs<NV> d0, d1;
-      load_row<NV>(a.packed, tok[t0], lane16, d0);
-      load_row<NV>(a.packed, has1 ? tok[t1] : 0, lane16, d1);
-      const float x0 = row_sim_my<NV>(d0, qp, lane16);
-      const float x1 = row_sim_my<NV>(d1, qp, lane16);
+    for (int t0 = g; t0 < n_real; t0 += U * kGroupsPerWG) {
+      RowRegs<NV> d[U];
+      bool has[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tu = t0 + u * kGroupsPerWG;
+        has[u] = tu < n_real;
+        load_row<NV>(a.packed, has[u] ? tok[tu] : 0, lane16, d[u]);
+      }
+      float x[U];
+      int qoff = 0;
+      if (QLDS) asm volatile("" : "+v"(qoff));
+      rows_sim_my<NV, U, QLDS>(d, qp, qlds + qoff, lane16, x);
       if (lane16 < kQT) {
         int* h = hist + lane16 * kMaxBins;
-        const int b0 = bin_of(x0, edges, a.nbins);
-        if (b0 < a.nbins) atomicAdd(&h[b0], 1);
-        if (x0 > 0.999f && x0 < 1.001f) atomicAdd(&h[a.nbins], 1);
-        if (has1) {
-          const int b1 = bin_of(x1, edges, a.nbins);
-          if (b1 < a.nbins) atomicAdd(&h[b1], 1);
-          if (x1 > 0.999f && x1 < 1.001f) atomicAdd(&h[a.nbins], 1);
-        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (has[u]) {
+            const int bu = bin_of(x[u], edges, a.nbins);
+            if (bu < a.nbins) atomicAdd(&h[bu], 1);
+            if (x[u] > 0.999f && x[u] < 1.001f) atomicAdd(&h[a.nbins], 1);
+          }
       }
     }
     __syncthreads();
@@ -219,16 +227,16 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
   if (B == 0) return CAPAMD_OK;
   DrmmArgs a{q_ids, d_ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4;
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_) hipLaunchKernelGGL(drmm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
   switch (nv_for_dim(D)) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
-    default: LAUNCH(5); break;
+    case 1: LAUNCH(1, 2, false, 3); break;
+    case 2: LAUNCH(2, 2, false, 3); break;
+    case 3: LAUNCH(3, 2, false, 3); break;
+    case 4: LAUNCH(4, 2, false, 3); break;
+    default: LAUNCH(5, 1, true, 6); break;  // same choice as knrm.hip (measured there)
   }
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;

@@ -135,4 +135,79 @@ __device__ __forceinline__ float row_sim_my(const RowRegs<NV>& d, const QueryPas
   return qp.id_my > 0 ? s : 0.f;
 }
 
+// ---- multi-term form used by the scoring kernels -------------------------------------------------
+// U document rows are gathered per group per iteration (U*NV float4 loads in flight per lane).  The
+// query rows come either from registers (QueryPass) or, when QLDS, from an LDS copy shared by the
+// workgroup ([kQT][NV*16] float4, den slot zeroed) which frees 16*NV VGPRs per wave for more rows in
+// flight; each query chunk read from LDS is reused for all U rows.  The fma order per (row, query
+// term) is unchanged (i ascending; x, y, z, w), so results are bit-identical across variants.
+template <int NV, int U, bool QLDS>
+__device__ __forceinline__ void rows_sim_my(const RowRegs<NV> (&d)[U], const QueryPass<NV>& qp, const float4* qlds, int lane16,
+                                            float (&sim)[U]) {
+  float p[U][kQT];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) p[u][t] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) {
+      const float4 q = QLDS ? qlds[(t * NV + i) * 16 + lane16] : qp.row[t].v[i];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float a = p[u][t];
+        a = __builtin_fmaf(d[u].v[i].x, q.x, a);
+        a = __builtin_fmaf(d[u].v[i].y, q.y, a);
+        a = __builtin_fmaf(d[u].v[i].z, q.z, a);
+        a = __builtin_fmaf(d[u].v[i].w, q.w, a);
+        p[u][t] = a;
+      }
+      // keep at most one query chunk in flight ahead of its use: otherwise the scheduler front-loads all
+      // kQT*NV LDS reads and the 16*NV VGPRs the LDS copy was meant to free are back
+      if (QLDS && (t & 1)) __builtin_amdgcn_sched_barrier(0);
+    }
+  const int myq = lane16 & 3;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float dden = row_den<NV>(d[u]);
+    float r[kQT];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) r[t] = group_allreduce(p[u][t]);
+    const float pm = myq == 0 ? r[0] : myq == 1 ? r[1] : myq == 2 ? r[2] : r[3];
+    const float s = pm / (qp.den_my * dden);
+    sim[u] = qp.id_my > 0 ? s : 0.f;
+  }
+}
+
+// query pass whose rows live in LDS: only ids / den of the owned term stay in registers
+template <int NV>
+__device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ packed, const int64_t* __restrict__ qids, int Q,
+                                                    int q0, int64_t V, int tid, int nthreads, int lane16, float4* qlds,
+                                                    QueryPass<NV>& qp, int* status) {
+  const int myq = lane16 & 3;
+  qp.den_my = 1e-9f;
+  qp.id_my = 0;
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    int64_t id = (q0 + t < Q) ? qids[q0 + t] : 0;
+    if (id >= V) {
+      if (status) atomicOr(status, kErrQueryIdRange);
+      id = 0;
+    }
+    qp.id[t] = (int)id;
+    const float* row = packed + (id > 0 ? id : 0) * (int64_t)(64 * NV);
+    const float den = row[64 * NV - 1];
+    if (myq == t) {
+      qp.den_my = den;
+      qp.id_my = (int)id;
+    }
+    for (int c = tid; c < NV * 16; c += nthreads) {
+      float4 v = reinterpret_cast<const float4*>(row)[c];
+      if (c == NV * 16 - 1) v.w = 0.f;  // keep the den slot out of the dot product
+      qlds[t * NV * 16 + c] = v;
+    }
+  }
+}
+
 }  // namespace capamd

@@ -21,6 +21,7 @@
 // and [B,K,Q,L] kernel tensors of the reference are never materialised.
 #include "capreolus_amd.h"
 #include "interaction.cuh"
+#include <stdlib.h>
 
 using namespace capamd;
 
@@ -49,8 +50,8 @@ struct KnrmArgs {
   int* status;
 };
 
-template <int NV>
-__global__ __launch_bounds__(kThreads) void knrm_forward_kernel(KnrmArgs a) {
+template <int NV, int U, bool QLDS, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // carve: tok[L] | partial[16][16][4] | S/aux
   int* tok = reinterpret_cast<int*>(smem_raw);
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(kThreads) void knrm_forward_kernel(KnrmArgs a) {
   float* Flds = Rlds + 48;                                       // kMaxK (+pad to 16)
   float* Hlds = Flds + 16;                                       // kMaxHidden
   int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // 4 (+4 spare)
-  int* n_one = wave_cnt + 8;                                     // kQT per pass
+  int* n_one = wave_cnt + 8;                                     // kQT per pass (+4 spare)
+  float4* qlds = reinterpret_cast<float4*>(n_one + 8);           // QLDS: [kQT][NV*16] float4
 
   const int tid = threadIdx.x;
   const int lane16 = tid & 15;
@@ -106,7 +108,10 @@ __global__ __launch_bounds__(kThreads) void knrm_forward_kernel(KnrmArgs a) {
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     QueryPass<NV> qp;
-    load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+    if (QLDS)
+      load_query_pass_lds<NV>(a.packed, qrow, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+    else
+      load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
     if (tid < kQT) n_one[tid] = 0;
     __syncthreads();
     // OOV exact matches (negative ids equal): rare, counted from the raw id row
@@ -128,28 +133,29 @@ __global__ __launch_bounds__(kThreads) void knrm_forward_kernel(KnrmArgs a) {
 
     float acc[3] = {0.f, 0.f, 0.f};
     float rowsum = 0.f;
-    for (int t0 = g; t0 < n_real; t0 += 2 * kGroupsPerWG) {
-      const int t1 = t0 + kGroupsPerWG;
-      const bool has1 = t1 < n_real;
-      RowRegs<NV> d0, d1;
-      load_row<NV>(a.packed, tok[t0], lane16, d0);
-      load_row<NV>(a.packed, has1 ? tok[t1] : 0, lane16, d1);
-      const float x0 = row_sim_my<NV>(d0, qp, lane16);
-      const float x1 = row_sim_my<NV>(d1, qp, lane16);
-      rowsum += x0;
+    for (int t0 = g; t0 < n_real; t0 += U * kGroupsPerWG) {
+      RowRegs<NV> d[U];
+      bool has[U];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const float adj = x0 - mu_s[s];
-        acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+      for (int u = 0; u < U; ++u) {
+        const int tu = t0 + u * kGroupsPerWG;
+        has[u] = tu < n_real;
+        load_row<NV>(a.packed, has[u] ? tok[tu] : 0, lane16, d[u]);
       }
-      if (has1) {
-        rowsum += x1;
+      float x[U];
+      int qoff = 0;
+      if (QLDS) asm volatile("" : "+v"(qoff));  // opaque per iteration: keeps the LDS query reads inside the loop (no LICM into 80 VGPRs)
+      rows_sim_my<NV, U, QLDS>(d, qp, qlds + qoff, lane16, x);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const float adj = x1 - mu_s[s];
-          acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+      for (int u = 0; u < U; ++u)
+        if (has[u]) {
+          rowsum += x[u];
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const float adj = x[u] - mu_s[s];
+            acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+          }
         }
-      }
     }
 
     // ---- phase 3: fixed-order cross-group reduction ---------------------------------------
@@ -218,17 +224,45 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   if (B == 0) return CAPAMD_OK;
   KnrmArgs a{q_ids, d_ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4;
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_) hipLaunchKernelGGL(knrm_forward_kernel<NV_>, dim3(B), dim3(kThreads), smem, s, a)
-  switch (nv_for_dim(D)) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
-    default: LAUNCH(5); break;
+  // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
+  // shared LDS copy) and the occupancy target.  Measured on MI355X: U=1 + LDS query rows + 6
+  // waves/SIMD (80 VGPRs) is fastest (36.7 M pairs/s vs 29.5 M for U=2/registers/3 waves); deeper unrolls at lower
+  // occupancy and any variant that spills are slower.  CAPAMD_KNRM_VARIANT selects the others for profiling.
+  static const int variant = [] {
+    const char* e = getenv("CAPAMD_KNRM_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH_V(NV_)                          \
+  switch (variant) {                           \
+    case 1: LAUNCH(NV_, 4, false, 2); break;   \
+    case 2: LAUNCH(NV_, 2, true, 4); break;    \
+    case 3: LAUNCH(NV_, 4, true, 4); break;    \
+    case 4: LAUNCH(NV_, 1, true, 8); break;    \
+    case 5: LAUNCH(NV_, 3, true, 4); break;    \
+    case 6: LAUNCH(NV_, 6, true, 2); break;    \
+    case 7: LAUNCH(NV_, 2, true, 6); break;    \
+    case 8: LAUNCH(NV_, 1, true, 7); break;    \
+    case 9: LAUNCH(NV_, 1, true, 6); break;    \
+    case 10: LAUNCH(NV_, 2, true, 5); break;   \
+    case 11: LAUNCH(NV_, 1, false, 4); break;  \
+    case 12: LAUNCH(NV_, 1, false, 3); break;  \
+    case 13: LAUNCH(NV_, 2, true, 3); break;   \
+    case 14: LAUNCH(NV_, 1, true, 5); break;   \
+    case 15: LAUNCH(NV_, 2, false, 3); break;  \
+    default: LAUNCH(NV_, 1, true, 6); break;   \
   }
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1, 2, false, 3); break;
+    case 2: LAUNCH(2, 2, false, 3); break;
+    case 3: LAUNCH(3, 2, false, 3); break;
+    case 4: LAUNCH(4, 2, false, 3); break;
+    default: LAUNCH_V(5); break;
+  }
+#undef LAUNCH_V
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }

@@ -131,12 +131,15 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 /* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
  * the reference calls at ptBERTMaxP.py:82).  bf16 operands, fp32 accumulation.
  * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;
- * 2: + resid[M,N] (fp32), fp32 out.  M, N, K multiples of 64. */
+ * 2: + resid[M,N] (fp32), fp32 out; 4: + resid[M,N] (bf16), bf16 out (one rounding).  M, N, K multiples of 64. */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
-                     const float* resid, void* out, void* stream);
+                     const void* resid, void* out, void* stream);
 /* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.
  * q, k: bf16 [n_passages*S, hidden]; vt: bf16 [n_passages*heads, 64, S]; ctx: bf16 [n_passages*S, hidden];
  * mask int64 [n_passages, S]. */
+/* Profiling hook: when non-NULL, capamd_bert_gemm blocks write up to 32 s_memtime stamps each into
+ * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off (the default). */
+void capamd_debug_set_gemm_stamps(void* stamps);
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
                               int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, void* stream);
 
