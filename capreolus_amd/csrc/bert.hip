@@ -197,6 +197,18 @@ bool dims_ok(const capamd_bert_model* m) {
 int64_t layer_blob_elems(int H, int F) { return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H; }
 int64_t layer_f32_floats(int H, int F) { return (int64_t)3 * H + H + H + H + F + H + H + H; }
 
+int num_cus() {
+  static int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t p;
+      if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+    }
+    return cus;
+  }();
+  return n;
+}
+
 template <int EPI>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.M % 256 == 0 && g.N % 256 == 0) {
@@ -208,10 +220,12 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       if (e != hipSuccess) return e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3((g.N / 256) * (g.M / 256)), dim3(G::kThreads), G::kLdsBytes, s, g);
+    const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+    hipLaunchKernelGGL(k, dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
   } else {
     using G = GemmKernel<64, 64, 2, 2, EPI>;
-    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3((g.N / 64) * (g.M / 64)), dim3(G::kThreads), G::kLdsBytes, s, g);
+    const int tiles = (g.N / 64) * (g.M / 64), cap = 4 * num_cus(), grid = tiles < cap ? tiles : cap;
+    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
   }
   return hipGetLastError();
 }
@@ -376,10 +390,7 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   hipError_t e;
   if (epilogue == kEpiBiasBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasBf16>(g, (hipStream_t)stream); }
   else if (epilogue == kEpiBiasGeluBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasGeluBf16>(g, (hipStream_t)stream); }
-  else if (epilogue == kEpiBiasResidF32) {
-    if (!resid) return CAPAMD_ERR_ARG;
-    g.resid = (const float*)resid; g.out_f32 = (float*)out; e = launch_gemm<kEpiBiasResidF32>(g, (hipStream_t)stream);
-  } else if (epilogue == kEpiBiasResidBf16) {
+  else if (epilogue == kEpiBiasResidBf16) {
     if (!resid) return CAPAMD_ERR_ARG;
     g.resid_bf16 = (const __bf16*)resid; g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasResidBf16>(g, (hipStream_t)stream);
   } else return CAPAMD_ERR_ARG;

@@ -21,9 +21,16 @@
 // on the ds_read_b128 side: conflict-free for the b128 lane groups (linear DMA destination + swizzled
 // source + swizzled read).  MFMA fragments are double-buffered in registers one 16-deep slice ahead.
 //
-// Epilogue: accumulators (+bias, x0.125 for Q, GELU, ...) are staged through the now idle LDS as a
-// row-major tile and written out with 16-byte stores, whole 512-byte row segments per wave-instruction
-// (an MFMA-layout store would issue 2-8 byte pieces scattered over 32 rows).
+// Persistent blocks: one workgroup per CU walks its tiles (XCD-aware order); the four half-bursts of the NEXT
+// tile are issued before the epilogue of the current one, so the ~7k-cycle fill latency of a tile start is
+// hidden behind the epilogue instead of being paid per tile.
+//
+// Epilogue: no block barrier and none of the operand regions (it must not disturb the prefetch): every wave
+// transposes its own sub-tile through a private 4 KiB LDS buffer, 32 rows x 128 bytes at a time (16-byte chunks
+// XOR-swizzled by row), and writes/reads it back as whole 128-byte row segments -> 16-byte stores, 8 rows x 128
+// contiguous bytes per wave-instruction.  (Storing the MFMA layout directly, 32 rows x 32 bytes per instruction,
+// measured 15.8k cycles per tile against ~6k.)  Bias, x1/8 for Q, erf-GELU and the residual add are fused; the
+// residual is fetched in the copy-out shape before the prefetch is issued and added in fp32 (one rounding).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,7 +46,6 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 enum GemmEpilogue {
   kEpiBiasBf16 = 0,      // out_bf16[m][n] = acc + bias[n]
   kEpiBiasGeluBf16 = 1,  // out_bf16[m][n] = gelu(acc + bias[n])                      (erf GELU)
-  kEpiBiasResidF32 = 2,  // out_f32[m][n]  = acc + bias[n] + resid[m][n]              (pre-LayerNorm sum)
   kEpiQkv = 3,           // n < H: Q[m][n] = (acc+bias)/8 ; n < 2H: K[m][n-H] ; else V^T[(psg,head)][d][key]
   kEpiBiasResidBf16 = 4, // out_bf16[m][n] = acc + bias[n] + resid_bf16[m][n]         (pre-LayerNorm sum, bf16 stream)
 };
@@ -52,9 +58,7 @@ struct GemmArgs {
   __bf16* out_bf16;     // kEpiBias*: [M, N];  kEpiQkv: Q [M, H]
   __bf16* out_k;        // kEpiQkv: K [M, H]
   __bf16* out_vt;       // kEpiQkv: V^T [M/S * heads][64][S]
-  const float* resid;   // kEpiBiasResidF32: [M, N]
   const __bf16* resid_bf16;  // kEpiBiasResidBf16: [M, N]
-  float* out_f32;       // kEpiBiasResidF32: [M, N]
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };
@@ -99,15 +103,14 @@ struct GemmKernel {
   static constexpr int kStageBytes = (BM + BN) * BK * 2;        // one K step of both operands
   static constexpr int kHalfBytes = kStageBytes / 2;            // one k-half (32 of the 64 k) of both operands
   static constexpr int kBurst = (BM + BN) * 64 / 1024 / kWaves; // global_load_lds instructions per wave per half-burst
-  static constexpr int kEpiElem = (EPI == kEpiBiasResidF32 || EPI == kEpiBiasResidBf16) ? 4 : 2;  // staged element size
-  // epilogue staging: rows of BN (or BM when transposed; BM == BN required for kEpiQkv) elements + 16 B pad
-  static constexpr int kEpiRowBytes = BN * kEpiElem + 16;
-  static constexpr int kEpiPasses = (kEpiElem == 4 && BM * kEpiRowBytes > 140000) ? 2 : 1;
-  static constexpr int kEpiBytes = (BM / kEpiPasses) * kEpiRowBytes;
-  static constexpr int kLdsBytes = (2 * kStageBytes > kEpiBytes) ? 2 * kStageBytes : kEpiBytes;
+  static constexpr bool kResid = (EPI == kEpiBiasResidBf16);
+  // epilogue rounds: one 32-row x 128-byte block per round = two 32x32 tiles in bf16, one in fp32 (residual sum)
+  static constexpr int kStores = kResid ? TN * TM * 4 : TN * TM * 2;  // global store instructions per wave per tile
+  static constexpr int kEpiLds = 4096;                                // wave-private staging bytes
+  static constexpr int kLdsBytes = 2 * kStageBytes + kWaves * kEpiLds;
   static_assert(WMT % 32 == 0 && WNT % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert(EPI != kEpiQkv || BM == BN, "QKV epilogue stages a transposed tile: needs BM == BN");
   static_assert((BM * 4) % (64 * kWaves) == 0 && (BN * 4) % (64 * kWaves) == 0, "stage loop must divide evenly");
+  static_assert(3 * kBurst + kStores <= 63, "vmcnt immediate");
 
   // issue the global->LDS copies of k-half `h` of K step `kt` into its region (kt & 1, h)
   static __device__ __forceinline__ void stage_half(const GemmArgs& a, char* lds, int kt, int h, int m0, int n0, int wave, int lane) {
@@ -131,30 +134,37 @@ struct GemmKernel {
     }
   }
 
+  static __device__ __forceinline__ void issue_prologue(const GemmArgs& a, char* lds, int m0, int n0, int wave, int lane) {
+    stage_half(a, lds, 0, 0, m0, n0, wave, lane);
+    stage_half(a, lds, 0, 1, m0, n0, wave, lane);
+    if (a.K > BK) {
+      stage_half(a, lds, 1, 0, m0, n0, wave, lane);
+      stage_half(a, lds, 1, 1, m0, n0, wave, lane);
+    }
+  }
+
   // fragment of 16-deep slice `s2` (0/1) of a half region: row, k = s2*16 + half*8 .. +7
   static __device__ __forceinline__ bf16x8 frag(const char* tile, int row, int s2, int half) {
     return *reinterpret_cast<const bf16x8*>(tile + row * 64 + swz_chunk4(row, 2 * s2 + half) * 16);
   }
 
+  struct Lane {
+    int tid, lane, wave, wm, wn, l31, half;
+  };
+
+  // ---- K loop of one tile; the tile's prologue bursts have been issued (pending_stores 16-byte stores of the
+  // previous tile's epilogue were issued after them) ----------------------------------------------------------
   template <bool TRANS>
-  static __device__ __forceinline__ void run(const GemmArgs& a, char* lds, int m0, int n0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    const int l31 = lane & 31, half = lane >> 5;
-    f32x16 acc[TN][TM];
+  static __device__ __forceinline__ void k_loop(const GemmArgs& a, char* lds, int m0, int n0, const Lane& L, bool pending_stores,
+                                                bool chain, int m1, int n1, f32x16 (&acc)[TN][TM]) {
+    const int KT = a.K / BK;
+    const int wave = L.wave, lane = L.lane, wm = L.wm, wn = L.wn, l31 = L.l31, half = L.half;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int KT = a.K / BK;
-    unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
-    int dbg_i = 0;
-#define CAPAMD_STAMP() do { if (dbg && tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
-    CAPAMD_STAMP();
-    // ---- main loop (see the header comment for the schedule) --------------------------------------------
     // slice ks of step kt lives in region (kt&1, ks>>1).  Per step, two barriers:
     //   B1 (entering slice 1): half 0 of this step has been read by everyone -> re-stage it with step kt+2;
     //                          half 1 of this step must have landed (its reads start now).
@@ -170,38 +180,40 @@ struct GemmKernel {
 #pragma unroll
       for (int i = 0; i < TN; ++i) fw[slot][i] = frag(wt, wn * WNT + i * 32 + l31, ks & 1, half);
     };
-    auto publish = [&](int newer) {  // wait for the oldest outstanding burst (newer = bursts issued after it), then barrier
-      if (newer >= 2) wait_vmcnt<2 * kBurst>();
+    // wait for the oldest outstanding burst (newer = bursts issued after it; with_stores: the previous tile's epilogue
+    // stores were also issued after it and need not have drained yet), then barrier
+    auto publish = [&](int newer, bool with_stores) {
+      if (with_stores && newer >= 2) wait_vmcnt<2 * kBurst + kStores>();
+      else if (newer >= 2) wait_vmcnt<2 * kBurst>();
       else if (newer == 1) wait_vmcnt<kBurst>();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my fragment reads of the region about to be re-staged are done
       __builtin_amdgcn_s_barrier();
     };
-    stage_half(a, lds, 0, 0, m0, n0, wave, lane);
-    stage_half(a, lds, 0, 1, m0, n0, wave, lane);
+    // first half-burst landed?  newer ops: the other prologue bursts (+ the previous tile's stores, issued later)
     if (KT > 1) {
-      stage_half(a, lds, 1, 0, m0, n0, wave, lane);
-      stage_half(a, lds, 1, 1, m0, n0, wave, lane);
-      wait_vmcnt<3 * kBurst>();
+      if (pending_stores) wait_vmcnt<3 * kBurst + kStores>();
+      else wait_vmcnt<3 * kBurst>();
     } else {
-      wait_vmcnt<kBurst>();
+      if (pending_stores) wait_vmcnt<kBurst + kStores>();
+      else wait_vmcnt<kBurst>();
     }
     __builtin_amdgcn_s_barrier();
-    CAPAMD_STAMP();
     load_frags(0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
-      if (kt < 13) CAPAMD_STAMP();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
         if (ks == 1) {
           // need (kt, half 1); newer bursts: (kt+1, 0), (kt+1, 1) when step kt+1 exists
-          publish(kt + 1 < KT ? 2 : 0);
+          publish((kt + 1 < KT || chain) ? 2 : 0, pending_stores && kt <= 1 && KT > 2);
           if (kt + 2 < KT) stage_half(a, lds, kt + 2, 0, m0, n0, wave, lane);
+          else if (chain) stage_half(a, lds, kt + 2 - KT, 0, m1, n1, wave, lane);  // the fill stream runs on into the next tile
         } else if (ks == 3) {
           // need (kt+1, half 0); newer: (kt+1, 1), (kt+2, 0) when step kt+2 exists
-          publish(kt + 2 < KT ? 2 : 1);
+          publish((kt + 2 < KT || chain) ? 2 : 1, pending_stores && kt == 0 && KT > 2);
           if (kt + 2 < KT) stage_half(a, lds, kt + 2, 1, m0, n0, wave, lane);
+          else if (chain) stage_half(a, lds, kt + 2 - KT, 1, m1, n1, wave, lane);
         }
         if (ks < 3) load_frags(kt, ks + 1, nxt);
         else if (kt + 1 < KT) load_frags(kt + 1, 0, nxt);
@@ -217,120 +229,201 @@ struct GemmKernel {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
-    CAPAMD_STAMP();
+    // every wave is past its last fragment read before anyone re-stages the regions for the next tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
-    // ---------------- epilogue: registers -> LDS tile -> 16-byte global stores ----------------
-    // !TRANS: lane holds m = mrow(j) = wm*WMT + j*32 + l31 and n = wn*WNT + i*32 + 8*(r>>2) + 4*half + (r&3)
-    //  TRANS: lane holds n = wn*WNT + i*32 + l31       and m = wm*WMT + j*32 + 8*(r>>2) + 4*half + (r&3)
-    // staged tile rows = m (!TRANS) or n (TRANS), BN (== BM when TRANS) elements per row.
-    constexpr int ROWS = BM / kEpiPasses;
+  // Global element offset of (row r of the wave's 32-row block rb, element column c of its column block cb).
+  // !TRANS: rows are m (block j), columns n.   TRANS (V^T): rows are n (block i), columns m (keys).
+  template <bool TRANS>
+  static __device__ __forceinline__ int64_t out_offset(const GemmArgs& a, int m0, int n0, const Lane& L, int rb, int r, int ccol) {
+    if (!TRANS) {
+      const int m = m0 + L.wm * WMT + rb * 32 + r;
+      const int n = n0 + L.wn * WNT + ccol;
+      if (EPI == kEpiQkv) return (int64_t)m * a.H + (n < a.H ? n : n - a.H);
+      return (int64_t)m * a.N + n;
+    } else {
+      const int nv = n0 + L.wn * WNT + rb * 32 + r - 2 * a.H, head = nv >> 6, d = nv & 63;
+      const int mg = m0 + L.wm * WMT + ccol, psg = mg / a.S, key = mg % a.S;
+      return ((int64_t)(psg * a.heads + head) * 64 + d) * a.S + key;
+    }
+  }
+
+  // residual in the copy-out shape of epilogue round (i, j): lane reads 4 x (row = c >> 3, 4 elements at chunk c & 7)
+  template <int R0, int R1>
+  static __device__ __forceinline__ void load_resid(const GemmArgs& a, int m0, int n0, const Lane& L, bf16x4 (&rs)[R0][R1][4]) {
+    static_assert(R0 == TN && R1 == TM, "residual registers only exist for the residual epilogue");
 #pragma unroll
-    for (int pass = 0; pass < kEpiPasses; ++pass) {
-      if (pass) __syncthreads();
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = L.lane + 64 * k;
+          rs[i][j][k] = *reinterpret_cast<const bf16x4*>(a.resid_bf16 + out_offset<false>(a, m0, n0, L, j, c >> 3, i * 32 + (c & 7) * 4));
+        }
+  }
+
+  static __device__ __forceinline__ void epilogue_resid(const GemmArgs& a, char* wl, int m0, int n0, const Lane& L,
+                                                        f32x16 (&acc)[TN][TM], bf16x4 (&rs)[TN][TM][4]) {
+    epilogue_impl<false>(a, wl, m0, n0, L, acc, rs);
+  }
+  template <bool TRANS>
+  static __device__ __forceinline__ void epilogue(const GemmArgs& a, char* wl, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][TM],
+                                                  bf16x4 (&rs)[1][1][4]) {
+    epilogue_impl<TRANS>(a, wl, m0, n0, L, acc, rs);
+  }
+  template <bool TRANS, int R0, int R1>
+  static __device__ __forceinline__ void epilogue_impl(const GemmArgs& a, char* wl, int m0, int n0, const Lane& L,
+                                                       f32x16 (&acc)[TN][TM], bf16x4 (&rs)[R0][R1][4]) {
+    // value of accumulator element (i, j, g4, e) after bias / scale / GELU
+    auto finish = [&](int i, int j, int g4, float (&v)[4]) {
+      float4 b4;
+      if (TRANS) {
+        const float b = a.bias[n0 + L.wn * WNT + i * 32 + L.l31];
+        b4 = make_float4(b, b, b, b);
+      } else {
+        b4 = *reinterpret_cast<const float4*>(a.bias + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
+      }
+      v[0] = acc[i][j][g4 * 4 + 0] + b4.x;
+      v[1] = acc[i][j][g4 * 4 + 1] + b4.y;
+      v[2] = acc[i][j][g4 * 4 + 2] + b4.z;
+      v[3] = acc[i][j][g4 * 4 + 3] + b4.w;
+      if (EPI == kEpiQkv && n0 < a.H) {  // 1/sqrt(head_dim = 64) folded into Q (exact in bf16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= 0.125f;
+      }
+      if (EPI == kEpiBiasGeluBf16) {
+        const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+        v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+      }
+    };
+    const int swz = (L.l31 & 7);
+    if (kResid) {
+      // fp32 staging, one 32x32 tile per round: lane writes 4 x float4 at row l31, chunk 2*g4 + half
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          const int row_f = TRANS ? wn * WNT + i * 32 + l31 : wm * WMT + j * 32 + l31;  // fixed index of this lane
-          if (row_f / ROWS != pass) continue;
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            const int col = (TRANS ? wm * WMT + j * 32 : wn * WNT + i * 32) + 8 * g4 + 4 * half;
             float v[4];
+            finish(i, j, g4, v);
+            *reinterpret_cast<float4*>(wl + L.l31 * 128 + (((2 * g4 + L.half) ^ swz) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int n = TRANS ? row_f : col + e;
-              float x = acc[i][j][g4 * 4 + e] + a.bias[n0 + n];
-              if (EPI == kEpiQkv && n0 < a.H) x *= 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in bf16)
-              v[e] = x;
-            }
-            if (EPI == kEpiBiasGeluBf16) {
-              const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-              v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
-            }
-            char* dst = lds + (row_f - pass * ROWS) * kEpiRowBytes + col * kEpiElem;
-            if (kEpiElem == 4) {
-              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-              bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-              *reinterpret_cast<bf16x4*>(dst) = o;
+          for (int k = 0; k < 4; ++k) {
+            const int c = L.lane + 64 * k, row = c >> 3, ch = c & 7;
+            const float4 x = *reinterpret_cast<const float4*>(wl + row * 128 + ((ch ^ (row & 7)) << 4));
+            const bf16x4 r4 = rs[kResid ? i : 0][kResid ? j : 0][k];
+            const bf16x4 o = {(__bf16)(x.x + (float)r4[0]), (__bf16)(x.y + (float)r4[1]), (__bf16)(x.z + (float)r4[2]),
+                              (__bf16)(x.w + (float)r4[3])};  // fp32 sum, ONE rounding
+            *reinterpret_cast<bf16x4*>(a.out_bf16 + out_offset<false>(a, m0, n0, L, j, row, i * 32 + ch * 4)) = o;
+          }
+          asm volatile("" ::: "memory");  // next round's writes stay behind these reads (DS ops of a wave execute in order)
+        }
+    } else {
+      // bf16 staging, two 32x32 tiles (64 columns) per round when the wave has them
+      constexpr int RB = TRANS ? TN : TM;            // 32-row blocks of the staged orientation
+      constexpr int CB = TRANS ? TM : TN;            // 32-column blocks
+      constexpr int CP = (CB % 2 == 0) ? 2 : 1;      // column blocks per round
+      __bf16* base = a.out_bf16;
+      if (EPI == kEpiQkv) base = TRANS ? a.out_vt : (n0 < a.H ? a.out_bf16 : a.out_k);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cp = 0; cp < CB / CP; ++cp) {
+#pragma unroll
+          for (int cc = 0; cc < CP; ++cc) {
+            const int cb = cp * CP + cc;
+            const int i = TRANS ? rb : cb, j = TRANS ? cb : rb;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              float v[4];
+              finish(i, j, g4, v);
+              const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              *reinterpret_cast<bf16x4*>(wl + L.l31 * 128 + (((4 * cc + g4) ^ swz) << 4) + L.half * 8) = o;
             }
           }
-        }
-      __syncthreads();
-      CAPAMD_STAMP();
-      constexpr int CH_PER_ROW = BN * kEpiElem / 16;
-      constexpr int ITERS = ROWS * CH_PER_ROW / kThreads;
-      static_assert(ROWS * CH_PER_ROW % kThreads == 0, "write-out loop must divide evenly");
-      // residual loads first, all in flight together (the compiler cannot hoist them over the stores itself:
-      // resid and out may alias as far as it knows, which serialises load -> store -> load ...)
-      float4 rs_f32[(EPI == kEpiBiasResidF32) ? ITERS : 1];
-      bf16x4 rs_b16[(EPI == kEpiBiasResidBf16) ? ITERS : 1];
-      if (EPI == kEpiBiasResidF32 || EPI == kEpiBiasResidBf16) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          const int c = it * kThreads + tid;
-          const int64_t off = (int64_t)(m0 + pass * ROWS + c / CH_PER_ROW) * a.N + n0 + (c % CH_PER_ROW) * 4;
-          if (EPI == kEpiBiasResidF32) rs_f32[it] = *reinterpret_cast<const float4*>(a.resid + off);
-          else rs_b16[it] = *reinterpret_cast<const bf16x4*>(a.resid_bf16 + off);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int c = it * kThreads + tid;
-        const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
-        const char* src = lds + row * kEpiRowBytes + ch * 16;
-        const int grow = pass * ROWS + row;
-        if (EPI == kEpiBiasResidF32) {
-          const int64_t off = (int64_t)(m0 + grow) * a.N + n0 + ch * 4;
-          float4 x = *reinterpret_cast<const float4*>(src);
-          x.x += rs_f32[it].x; x.y += rs_f32[it].y; x.z += rs_f32[it].z; x.w += rs_f32[it].w;
-          *reinterpret_cast<float4*>(a.out_f32 + off) = x;
-        } else if (EPI == kEpiBiasResidBf16) {  // fp32 staged sum + bf16 residual -> ONE rounding to bf16
-          const int64_t off = (int64_t)(m0 + grow) * a.N + n0 + ch * 4;
-          const float4 x = *reinterpret_cast<const float4*>(src);
-          const bf16x4 rsd = rs_b16[it];
-          const bf16x4 o = {(__bf16)(x.x + (float)rsd[0]), (__bf16)(x.y + (float)rsd[1]), (__bf16)(x.z + (float)rsd[2]),
-                            (__bf16)(x.w + (float)rsd[3])};
-          *reinterpret_cast<bf16x4*>(a.out_bf16 + off) = o;
-        } else if (EPI == kEpiQkv) {
-          const uint4 x = *reinterpret_cast<const uint4*>(src);
-          if (!TRANS) {
-            __bf16* dst = (n0 < a.H) ? a.out_bf16 + (int64_t)(m0 + grow) * a.H + n0 + ch * 8
-                                     : a.out_k + (int64_t)(m0 + grow) * a.H + (n0 - a.H) + ch * 8;
-            *reinterpret_cast<uint4*>(dst) = x;
-          } else {
-            const int nv = n0 + grow - 2 * a.H, head = nv >> 6, d = nv & 63;
-            const int mg = m0 + ch * 8, psg = mg / a.S, key = mg % a.S;
-            *reinterpret_cast<uint4*>(a.out_vt + ((int64_t)(psg * a.heads + head) * 64 + d) * a.S + key) = x;
+          for (int k = 0; k < 2 * CP; ++k) {
+            const int c = L.lane + 64 * k;
+            const int row = CP == 2 ? c >> 3 : c >> 2, ch = CP == 2 ? c & 7 : c & 3;
+            const uint4 x = *reinterpret_cast<const uint4*>(wl + row * 128 + ((ch ^ (row & 7)) << 4));
+            *reinterpret_cast<uint4*>(base + out_offset<TRANS>(a, m0, n0, L, rb, row, cp * CP * 32 + ch * 8)) = x;
           }
-        } else {
-          *reinterpret_cast<uint4*>(a.out_bf16 + (int64_t)(m0 + grow) * a.N + n0 + ch * 8) = *reinterpret_cast<const uint4*>(src);
+          asm volatile("" ::: "memory");
         }
+    }
+  }
+
+  // tile -> (m0, n0) of the persistent schedule; returns false when the block has no it-th tile
+  static __device__ __forceinline__ bool tile_of(const GemmArgs& a, int it, int& m0, int& n0) {
+    const int tn = a.N / BN, nblk = (a.M / BM) * tn;
+    const int G = gridDim.x, b = blockIdx.x, xcd = b & 7, p = b >> 3;
+    const int nb_x = (G - xcd + 7) >> 3;                       // blocks resident on this XCD
+    const int q = nblk >> 3, r = nblk & 7;
+    const int cnt = q + (xcd < r ? 1 : 0), start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int t = p + it * nb_x;
+    if (t >= cnt) return false;
+    m0 = ((start + t) / tn) * BM;
+    n0 = ((start + t) % tn) * BN;
+    return true;
+  }
+
+  static __device__ __forceinline__ void run(const GemmArgs& a, char* lds) {
+    Lane L;
+    L.tid = threadIdx.x; L.lane = L.tid & 63; L.wave = L.tid >> 6;
+    L.wm = L.wave % WAVES_M; L.wn = L.wave / WAVES_M; L.l31 = L.lane & 31; L.half = L.lane >> 5;
+    unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
+    int dbg_i = 0;
+#define CAPAMD_STAMP() do { if (dbg && L.tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+    int m0, n0;
+    if (!tile_of(a, 0, m0, n0)) return;
+    CAPAMD_STAMP();
+    issue_prologue(a, lds, m0, n0, L.wave, L.lane);
+    bool pending = false;
+    for (int it = 0;; ++it) {
+      int m1 = 0, n1 = 0;
+      const bool more = tile_of(a, it + 1, m1, n1);
+      f32x16 acc[TN][TM];
+      bf16x4 rs[kResid ? TN : 1][kResid ? TM : 1][4];
+      const bool trans = (EPI == kEpiQkv) && n0 >= 2 * a.H;
+      // with an even number of K steps the region parity carries over, so the next tile's first two K steps are
+      // staged by this tile's last two (the L2->LDS stream never stops); otherwise they are issued after the loop
+      const bool chain = more && ((a.K / BK) & 1) == 0;
+      if (trans) k_loop<true>(a, lds, m0, n0, L, pending, chain, m1, n1, acc);
+      else k_loop<false>(a, lds, m0, n0, L, pending, chain, m1, n1, acc);
+      CAPAMD_STAMP();
+      if constexpr (kResid) load_resid(a, m0, n0, L, rs);  // older than the prefetch: waiting for it does not wait for the bursts
+      if (more && !chain) issue_prologue(a, lds, m1, n1, L.wave, L.lane);
+      char* wl = lds + 2 * kStageBytes + L.wave * kEpiLds;
+      if constexpr (kResid) {
+        epilogue_resid(a, wl, m0, n0, L, acc, rs);
+      } else {
+        if (trans) epilogue<true>(a, wl, m0, n0, L, acc, rs);
+        else epilogue<false>(a, wl, m0, n0, L, acc, rs);
       }
       CAPAMD_STAMP();
+      if (!more) break;
+      pending = true;
+      m0 = m1; n0 = n1;
     }
 #undef CAPAMD_STAMP
   }
 };
 
-// 1-D grid of (M/BM)*(N/BN) blocks.  Hardware block b runs on XCD b % 8 (observed, used for speed only): the
-// remap hands every XCD one contiguous range of tiles, n fastest, so the blocks that share an activation panel
-// run on the same XCD and hit its L2 instead of fetching the panel once per XCD over the fabric.
+// Persistent kernel: grid = min(#tiles, #CUs) blocks of one workgroup per CU.  Hardware block b runs on XCD b % 8
+// (observed, used for speed only): every XCD gets one contiguous range of tiles (n fastest) which its resident
+// blocks walk in lock-step order, so blocks that share an activation panel / weight tile hit the same L2.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmArgs a) {
   using G = GemmKernel<BM, BN, WAVES_M, WAVES_N, EPI>;
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
-  const int tn = a.N / BN;
-  const int nblk = gridDim.x, b = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, p = b >> 3;
-  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + p;  // bijective for any nblk
-  const int n0 = (tile % tn) * BN, m0 = (tile / tn) * BM;
-  if (EPI == kEpiQkv && n0 >= 2 * a.H)
-    G::template run<true>(a, gemm_lds, m0, n0);
-  else
-    G::template run<false>(a, gemm_lds, m0, n0);
+  G::run(a, gemm_lds);
 }
 
 }  // namespace capamd

@@ -131,7 +131,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 /* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
  * the reference calls at ptBERTMaxP.py:82).  bf16 operands, fp32 accumulation.
  * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;
- * 2: + resid[M,N] (fp32), fp32 out; 4: + resid[M,N] (bf16), bf16 out (one rounding).  M, N, K multiples of 64. */
+ * 4: + resid[M,N] (bf16), bf16 out (fp32 sum, one rounding).  M, N, K multiples of 64. */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
                      const void* resid, void* out, void* stream);
 /* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.

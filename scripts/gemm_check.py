@@ -6,16 +6,16 @@ lib = _lib.load(); dev = "cuda:0"
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for (M, N, K) in [(64,64,64),(64,64,128),(64,64,192),(64,64,256),(128,192,320),(64,128,128),(256,256,64),(256,256,128),(256,256,192),(256,256,320),(512,512,256)]:
-    for epi in (0, 2):
+    for epi in (0, 4):
         torch.manual_seed(M + N + K)
         A = (torch.randn((M, K), device=dev) * 0.5).bfloat16()
         W = (torch.randn((N, K), device=dev) * 0.05).bfloat16()
-        bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev)
-        out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
+        bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev).bfloat16()
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         errs = []
         for rep in range(3):
             out.zero_()
             assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st) == 0
-            ref = A.float() @ W.float().t() + bias + (resid if epi == 2 else 0)
+            ref = A.float() @ W.float().t() + bias + (resid.float() if epi == 4 else 0)
             errs.append(float((out.float() - ref).abs().max()))
         print(M, N, K, "epi", epi, "max abs err", ["%.3g" % e for e in errs])

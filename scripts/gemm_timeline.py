@@ -1,4 +1,4 @@
-"""Per-block cycle timeline of the 256x256 GEMM kernel (s_memtime stamps; profiling hook)."""
+"""Per-block cycle timeline of the persistent 256x256 GEMM kernel (s_memtime stamps; profiling hook)."""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -10,10 +10,9 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = 65536
 for name, N, K, epi in [("qkv-like", 2304, 768, 0), ("ffn1", 3072, 768, 1), ("oproj", 768, 768, 4), ("ffn2", 768, 3072, 4)]:
     A = torch.randn((M, K), device=dev).bfloat16(); W = (torch.randn((N, K), device=dev) * 0.05).bfloat16()
-    bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev) if epi == 2 else (torch.randn((M, N), device=dev).bfloat16() if epi == 4 else None)
-    out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
-    nblk = (M // 256) * (N // 256)
-    stamps = torch.zeros((nblk, 32), dtype=torch.int64, device=dev)
+    bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev).bfloat16() if epi == 4 else None
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    stamps = torch.zeros((256, 32), dtype=torch.int64, device=dev)
     for _ in range(2):
         lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st)
     lib.capamd_debug_set_gemm_stamps(vp(stamps))
@@ -24,4 +23,4 @@ for name, N, K, epi in [("qkv-like", 2304, 768, 0), ("ffn1", 3072, 768, 1), ("op
     n = int((s[0] != 0).sum())
     d = (s[:, 1:n] - s[:, : n - 1]).astype("float64")
     med = np.median(d, axis=0)
-    print(name, "stamps", n, "median cycle deltas:", [int(x) for x in med], "total", int(med.sum()))
+    print(name, "stamps", n, "[start | (k-loop, epilogue) per tile] median cycle deltas:", [int(x) for x in med], "total", int(med.sum()))

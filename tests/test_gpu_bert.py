@@ -30,7 +30,7 @@ def _stream():
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 768), (256, 2304, 768), (256, 768, 3072), (64, 64, 64), (128, 192, 320)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 4])
+@pytest.mark.parametrize("epi", [0, 1, 4])
 def test_gemm_vs_torch(M, N, K, epi):
     g = torch.Generator(device=DEV).manual_seed(M + N + K + epi)
     A = (torch.randn((M, K), generator=g, device=DEV) * 0.5).bfloat16()
@@ -40,7 +40,7 @@ def test_gemm_vs_torch(M, N, K, epi):
     resid = torch.randn((M, N), generator=g, device=DEV)
     if epi == 4:
         resid = resid.bfloat16()
-    out = torch.empty((M, N), dtype=torch.float32 if epi == 2 else torch.bfloat16, device=DEV)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     rc = _lib.load().capamd_bert_gemm(_p(A), _p(W), _p(bias), M, N, K, epi, _p(resid), _p(out), _stream())
     assert rc == 0
     ref = A.float() @ W.float().t() + bias
@@ -48,11 +48,7 @@ def test_gemm_vs_torch(M, N, K, epi):
         ref = torch.nn.functional.gelu(ref)
     if epi == 4:
         ref = ref + resid.float()
-    if epi == 2:
-        ref = ref + resid
-        torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-3)  # fp32 accumulation-order noise only
-    else:
-        torch.testing.assert_close(out.float(), ref, rtol=2 ** -7, atol=2e-2)  # one bf16 rounding of the result
+    torch.testing.assert_close(out.float(), ref, rtol=2 ** -7, atol=2e-2)  # one bf16 rounding of the result
 
 
 @pytest.mark.parametrize("S,hidden,heads,npsg", [(64, 128, 2, 4), (128, 192, 3, 2), (256, 768, 12, 2), (256, 768, 12, 3)])
