@@ -107,17 +107,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const __bf16* __restrict__ pre,
   }
 }
 
-// pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]).  One block per kHeadPsg
-// passages: every pooler row is fetched once per block and reused for the block's passages from registers.
-constexpr int kHeadPsg = 2;
+// pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]).
+// grid (ceil(n_psg / kHeadPsg), H / 64): a block owns 64 pooler rows and kHeadPsg passages, so every pooler row is
+// fetched once per kHeadPsg passages; its partial sum over those 64 rows of cls_w[1][j] * tanh(pooler_j) goes to
+// part[psg][slice]; head_reduce_kernel adds the slices in fixed order (deterministic, no atomics).
+constexpr int kHeadPsg = 8;
 __global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf, int64_t n_psg, int S, int H,
                                                    const float* __restrict__ pw, const float* __restrict__ pb,
-                                                   const float* __restrict__ cw, const float* __restrict__ cb,
-                                                   float* __restrict__ logits) {
+                                                   const float* __restrict__ cw, float* __restrict__ part) {
   __shared__ float cls[kHeadPsg][1024];
-  __shared__ float part[4][kHeadPsg];
+  __shared__ float wsum[4][kHeadPsg];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * kHeadPsg;
+  const int nslice = gridDim.y, j0 = blockIdx.y * 64;
 #pragma unroll
   for (int q = 0; q < kHeadPsg; ++q) {
     const int64_t psg = p0 + q < n_psg ? p0 + q : n_psg - 1;
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf
 #pragma unroll
   for (int q = 0; q < kHeadPsg; ++q) acc[q] = 0.f;
   const int nc = (H + 63) >> 6;  // <= 16
-  for (int j = wave; j < H; j += 4) {
+  for (int jj = wave; jj < 64; jj += 4) {
+    const int j = j0 + jj;
     const float* w = pw + (int64_t)j * H;
     float wr[16];
 #pragma unroll
@@ -147,10 +150,18 @@ __global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf
   }
   if (lane == 0)
 #pragma unroll
-    for (int q = 0; q < kHeadPsg; ++q) part[wave][q] = acc[q];
+    for (int q = 0; q < kHeadPsg; ++q) wsum[wave][q] = acc[q];
   __syncthreads();
   if (tid < kHeadPsg && p0 + tid < n_psg)
-    logits[p0 + tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + cb[1];
+    part[(p0 + tid) * nslice + blockIdx.y] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+}
+__global__ void head_reduce_kernel(const float* __restrict__ part, int64_t n_psg, int nslice, const float* __restrict__ cb,
+                                   float* __restrict__ logits) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_psg) return;
+  float s = 0.f;
+  for (int k = 0; k < nslice; ++k) s += part[p * nslice + k];
+  logits[p] = s + cb[1];
 }
 
 // passage pooling (ptBERTMaxP.py:75-94); one wave per document.  agg: 0 max, 1 first, 2 sum, 3 avg
@@ -344,9 +355,9 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
       if (e != hipSuccess) break;
       AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
       const unsigned nblk = (unsigned)(np * m->heads);
-      if (S == 256) hipLaunchKernelGGL(attention_kernel<256>, dim3(nblk), dim3(512), 0, s, at);
-      else if (S == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3(nblk), dim3(256), 0, s, at);
-      else hipLaunchKernelGGL(attention_kernel<64>, dim3(nblk), dim3(128), 0, s, at);
+      if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8>), dim3(nblk), dim3(512), 0, s, at);
+      else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4>), dim3(nblk), dim3(256), 0, s, at);
+      else hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(nblk), dim3(128), 0, s, at);
       // attention output projection + residual -> LayerNorm
       g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
       e = launch_gemm<kEpiBiasResidBf16>(g, s);
@@ -364,8 +375,11 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                          0, 0, S, ln2g, ln2b, M, H, w.xb, status);
     }
     if (e != hipSuccess) break;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg)), dim3(256), 0, s, w.xb, np, S, H, m->pooler_w,
-                       m->pooler_b, m->cls_w, m->cls_b, w.logits + p0);
+    // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
+    float* hpart = reinterpret_cast<float*>(w.pre);
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, w.xb, np, S, H,
+                       m->pooler_w, m->pooler_b, m->cls_w, hpart);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
     e = hipGetLastError();
   }
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
@@ -410,9 +424,9 @@ int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv
   if (launch_gemm<kEpiQkv>(g, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
   AttnArgs at{(const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, mask, (__bf16*)ctx, hidden, heads};
   const unsigned nblk = (unsigned)(n_passages * heads);
-  if (S == 256) hipLaunchKernelGGL(attention_kernel<256>, dim3(nblk), dim3(512), 0, s, at);
-  else if (S == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3(nblk), dim3(256), 0, s, at);
-  else hipLaunchKernelGGL(attention_kernel<64>, dim3(nblk), dim3(128), 0, s, at);
+  if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8>), dim3(nblk), dim3(512), 0, s, at);
+  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4>), dim3(nblk), dim3(256), 0, s, at);
+  else hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(nblk), dim3(128), 0, s, at);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 

@@ -28,9 +28,15 @@ struct AttnArgs {
   int H, heads;
 };
 
-template <int S>
-__global__ __launch_bounds__(2 * S) void attention_kernel(AttnArgs a) {
-  constexpr int NT = S / 32;            // key tiles == waves
+// NW = waves per workgroup (each wave owns 32 queries); S/32/NW workgroups share one (passage, head) and each
+// stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V staged
+// once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us:
+// the kernel is bound by the L2->LDS fill, so the doubled staging costs more than the overlap buys.
+template <int S, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
+  constexpr int NT = S / 32;            // key tiles
+  constexpr int QB = NT / NW;           // workgroups per (passage, head)
+  constexpr int NTHR = 64 * NW;
   constexpr int VROW = S * 2 + 8;       // bytes per V^T row in LDS
   __shared__ __attribute__((aligned(16))) char lds[S * 128 + 64 * VROW + S * 4];
   char* Ks = lds;
@@ -39,33 +45,35 @@ __global__ __launch_bounds__(2 * S) void attention_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int psg = blockIdx.x / a.heads, head = blockIdx.x % a.heads;
+  const int ph = blockIdx.x / QB, qb = blockIdx.x % QB;   // (passage, head) index, query block
+  const int psg = ph / a.heads, head = ph % a.heads;
   const int64_t tok0 = (int64_t)psg * S;
+  const int qwave = qb * NW + wave;                       // which 32-query slice of the passage this wave owns
 
   // ---- stage K (swizzled, via LDS-DMA), V^T (padded rows, via registers), additive mask ----
   {
     const int r8 = lane >> 3, p = lane & 7;
-    constexpr int INSTR = S * 8 / 64 / NT;  // = 4
+    constexpr int INSTR = S * 8 / 64 / NW;
 #pragma unroll
     for (int t = 0; t < INSTR; ++t) {
       const int row = (wave * INSTR + t) * 8 + r8;
       const __bf16* src = a.K + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * INSTR + t) * 1024), 16, 0, 0);
     }
-    const __bf16* vsrc = a.Vt + (int64_t)blockIdx.x * 64 * S;
-    for (int c = tid; c < 64 * S / 8; c += 2 * S) {
+    const __bf16* vsrc = a.Vt + (int64_t)ph * 64 * S;
+    for (int c = tid; c < 64 * S / 8; c += NTHR) {
       const int d = c / (S / 8), k8 = c % (S / 8);
       const uint4 x = *reinterpret_cast<const uint4*>(vsrc + d * S + k8 * 8);
       *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16) = make_uint2(x.x, x.y);
       *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16 + 8) = make_uint2(x.z, x.w);
     }
-    for (int k = tid; k < S; k += 2 * S)
+    for (int k = tid; k < S; k += NTHR)
       madd[k] = a.mask[(int64_t)psg * S + k] != 0 ? 0.f : -3.4028234663852886e38f;  // HF: (1-mask) * finfo.min
   }
-  // this wave's Q fragments (B operand): query = wave*32 + l31, d = (2*ks+half)*8 ..+7
+  // this wave's Q fragments (B operand): query = qwave*32 + l31, d = (2*ks+half)*8 ..+7
   bf16x8 qf[4];
   {
-    const __bf16* qrow = a.Q + (tok0 + wave * 32 + l31) * a.H + head * 64 + half * 8;
+    const __bf16* qrow = a.Q + (tok0 + qwave * 32 + l31) * a.H + head * 64 + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
   }
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(2 * S) void attention_kernel(AttnArgs a) {
         out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, out[dt], 0, 0, 0);
       }
     }
-  __bf16* crow = a.ctx + (tok0 + wave * 32 + l31) * a.H + head * 64;
+  __bf16* crow = a.ctx + (tok0 + qwave * 32 + l31) * a.H + head * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
