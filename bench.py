@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--vocab", type=int, default=400001)
     ap.add_argument("--dim", type=int, default=300)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform instead of Zipf(1.1) term ids (HBM-bound case)")
+    ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -104,9 +105,17 @@ def main():
     if args.model == "knrm":
         mu, sigma = m.kernels.stacked()
         w1, b1 = m.combine[0].weight.detach().contiguous(), m.combine[0].bias.detach()
+        if args.resident:  # one query row per query, one document row per candidate, int32
+            q_tab = q_all[:: args.docs].to(torch.int32).contiguous()
+            d_tab = d_all.to(torch.int32).contiguous()
+            pq = torch.arange(n_pairs, device=dev, dtype=torch.int32) // args.docs
+            pd = torch.arange(n_pairs, device=dev, dtype=torch.int32)
 
-        def launch_one(lo, hi):
-            engine.knrm_forward(q_all[lo:hi], d_all[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+            def launch_one(lo, hi):
+                engine.knrm_forward_indexed(q_tab, d_tab, pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+        else:
+            def launch_one(lo, hi):
+                engine.knrm_forward(q_all[lo:hi], d_all[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
     else:
         edges = m._bin_edges(dev)
         gw = m.gates.weight.detach().contiguous().view(-1)

@@ -25,9 +25,8 @@ constexpr int kMaxNodes = 64;
 constexpr int kMaxQ = 32;
 
 struct DrmmArgs {
-  const int64_t* q_ids;
-  const int64_t* d_ids;
-  const float* idf;
+  IdSource ids;
+  const float* idf;  // [B, Q], or [NQ, Q] indexed by the pair's query row in indexed mode
   int B, Q, L;
   const float* packed;
   int64_t V;
@@ -82,8 +81,7 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   const int lane = tid & 63;
   const int b = blockIdx.x;
   const int NB = a.nbins + 1;
-  const int64_t* qrow = a.q_ids + (int64_t)b * a.Q;
-  const int64_t* drow = a.d_ids + (int64_t)b * a.L;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
 
   if (tid < a.nbins) edges[tid] = a.edges[tid];
 
@@ -91,7 +89,7 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   int n_real = 0, n_oov = 0;
   for (int base = 0; base < a.L; base += kThreads) {
     const int j = base + tid;
-    int64_t did = (j < a.L) ? drow[j] : 0;
+    int64_t did = (j < a.L) ? ids.d(j) : 0;
     if (did >= a.V) {
       atomicOr(a.status, kErrDocIdRange);
       did = 0;
@@ -114,12 +112,12 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
-    if (tid < kQT && q0 + tid < a.Q && qrow[q0 + tid] < 0) atomicOr(a.status, kErrQueryOOV);
+    if (tid < kQT && q0 + tid < a.Q && ids.q(q0 + tid) < 0) atomicOr(a.status, kErrQueryOOV);
     QueryPass<NV> qp;
     if (QLDS)
-      load_query_pass_lds<NV>(a.packed, qrow, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+      load_query_pass_lds<NV>(a.packed, ids, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
     else
-      load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+      load_query_pass<NV>(a.packed, ids, a.Q, q0, a.V, lane16, qp, a.status);
     if (qp.id_my < 0) qp.id_my = 0;
     for (int i = tid; i < kQT * kMaxBins; i += kThreads) hist[i] = 0;
     __syncthreads();
@@ -177,9 +175,9 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
       const float o = wave_sum(contrib) + a.b2[0];
       // term gate logit (DRMM.py:83-95)
       float gl;
-      const int64_t qid = qrow[q];
+      const int64_t qid = ids.q(q);
       if (a.gate_type == 0) {
-        gl = a.gate_w[0] * a.idf[(int64_t)b * a.Q + q];
+        gl = a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q];
       } else {
         const float* e = a.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * a.ld;
         float p = 0.f;
@@ -210,22 +208,19 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
 
 }  // namespace
 
-extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
-                                   const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type,
-                                   int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
-                                   const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
-                                   const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
-  if (B == 0) return CAPAMD_OK;
-  if (!q_ids || !d_ids || !idf || !packed || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out ||
-      !status)
-    return CAPAMD_ERR_ARG;
+namespace {
+
+int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, const float* packed, int64_t V, int D,
+                const float* edges, int nbins, int hist_type, int gate_type, const float* gate_w, const float* emb_raw, int64_t ld,
+                const float* w1, const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
+                const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+  if (!idf || !packed || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out || !status) return CAPAMD_ERR_ARG;
   if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   if (nbins < 1 || nbins + 1 > kMaxBins || nodes < 1 || nodes > kMaxNodes) return CAPAMD_ERR_ARG;
   if (hist_type < 0 || hist_type > 2 || gate_type < 0 || gate_type > 1) return CAPAMD_ERR_ARG;
   if (gate_type == 1 && (!emb_raw || ld < D)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
-  if (B == 0) return CAPAMD_OK;
-  DrmmArgs a{q_ids, d_ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
+  DrmmArgs a{ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
@@ -240,4 +235,31 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
   }
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
+                                   const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type,
+                                   int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
+                                   const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
+                                   const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  return drmm_launch(ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld, w1, b1, nodes, w2,
+                     b2, out_w, out_b, out, counts_out, status, stream);
+}
+
+extern "C" int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const float* idf_table,
+                                           const int32_t* pair_q, const int32_t* pair_d, int B, int Q, int L, const float* packed,
+                                           int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type,
+                                           const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1,
+                                           int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
+                                           float* out, int32_t* counts_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_table || !d_table || !pair_q || !pair_d) return CAPAMD_ERR_ARG;
+  const IdSource ids{nullptr, nullptr, q_table, d_table, pair_q, pair_d};
+  return drmm_launch(ids, idf_table, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld, w1, b1, nodes,
+                     w2, b2, out_w, out_b, out, counts_out, status, stream);
 }

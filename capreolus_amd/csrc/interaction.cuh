@@ -41,6 +41,45 @@ constexpr int kErrQueryOOV = 4;      // negative query id where the reference mo
 __host__ __device__ inline int nv_for_dim(int D) { return (D + 1 + 63) / 64; }
 __host__ __device__ inline int row_stride_for_dim(int D) { return 64 * nv_for_dim(D); }
 
+// Where a batch's term ids come from: the extractor layout (int64 [B,Q] / [B,L], embedtext.py:146-147) or a
+// device-resident candidate store (int32 tables uploaded once + per-pair row indices).
+struct IdSource {
+  const int64_t* q64;     // [B, Q]
+  const int64_t* d64;     // [B, L]
+  const int32_t* q32;     // [NQ, Q] query table   (indexed mode)
+  const int32_t* d32;     // [ND, L] document table
+  const int32_t* pair_q;  // [B] row of q32 for each pair
+  const int32_t* pair_d;  // [B] row of d32 for each pair
+};
+
+struct PairIds {  // the id rows of one pair
+  const int64_t* q64;
+  const int64_t* d64;
+  const int32_t* q32;
+  const int32_t* d32;
+  int qrow;  // row of the query in q32 / idf table (indexed mode), else the pair index
+  __device__ __forceinline__ int64_t q(int t) const { return q32 ? (int64_t)q32[t] : q64[t]; }
+  __device__ __forceinline__ int64_t d(int j) const { return d32 ? (int64_t)d32[j] : d64[j]; }
+};
+
+__device__ __forceinline__ PairIds pair_ids(const IdSource& s, int b, int Q, int L) {
+  PairIds p;
+  if (s.q32) {
+    p.qrow = s.pair_q[b];
+    p.q32 = s.q32 + (int64_t)p.qrow * Q;
+    p.d32 = s.d32 + (int64_t)s.pair_d[b] * L;
+    p.q64 = nullptr;
+    p.d64 = nullptr;
+  } else {
+    p.qrow = b;
+    p.q64 = s.q64 + (int64_t)b * Q;
+    p.d64 = s.d64 + (int64_t)b * L;
+    p.q32 = nullptr;
+    p.d32 = nullptr;
+  }
+  return p;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -98,14 +137,14 @@ struct QueryPass {
 };
 
 template <int NV>
-__device__ __forceinline__ void load_query_pass(const float* __restrict__ packed, const int64_t* __restrict__ qids,
+__device__ __forceinline__ void load_query_pass(const float* __restrict__ packed, const PairIds& ids,
                                                 int Q, int q0, int64_t V, int lane16, QueryPass<NV>& qp, int* status) {
   const int myq = lane16 & 3;
   qp.den_my = 1e-9f;
   qp.id_my = 0;
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
-    int64_t id = (q0 + t < Q) ? qids[q0 + t] : 0;
+    int64_t id = (q0 + t < Q) ? ids.q(q0 + t) : 0;
     if (id >= V) {
       if (status) atomicOr(status, kErrQueryIdRange);
       id = 0;
@@ -182,7 +221,7 @@ __device__ __forceinline__ void rows_sim_my(const RowRegs<NV> (&d)[U], const Que
 
 // query pass whose rows live in LDS: only ids / den of the owned term stay in registers
 template <int NV>
-__device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ packed, const int64_t* __restrict__ qids, int Q,
+__device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ packed, const PairIds& ids, int Q,
                                                     int q0, int64_t V, int tid, int nthreads, int lane16, float4* qlds,
                                                     QueryPass<NV>& qp, int* status) {
   const int myq = lane16 & 3;
@@ -190,7 +229,7 @@ __device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ pa
   qp.id_my = 0;
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
-    int64_t id = (q0 + t < Q) ? qids[q0 + t] : 0;
+    int64_t id = (q0 + t < Q) ? ids.q(q0 + t) : 0;
     if (id >= V) {
       if (status) atomicOr(status, kErrQueryIdRange);
       id = 0;

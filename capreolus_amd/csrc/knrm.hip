@@ -32,8 +32,7 @@ constexpr int kMaxHidden = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct KnrmArgs {
-  const int64_t* q_ids;
-  const int64_t* d_ids;
+  IdSource ids;
   int B, Q, L;
   const float* packed;
   int64_t V;
@@ -70,14 +69,13 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int b = blockIdx.x;
-  const int64_t* qrow = a.q_ids + (int64_t)b * a.Q;
-  const int64_t* drow = a.d_ids + (int64_t)b * a.L;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
 
   // ---- phase 1: compact real document terms in order --------------------------------------
   int n_real = 0;
   for (int base = 0; base < a.L; base += kThreads) {
     const int j = base + tid;
-    int64_t did = (j < a.L) ? drow[j] : 0;
+    int64_t did = (j < a.L) ? ids.d(j) : 0;
     if (did >= a.V) {
       atomicOr(a.status, kErrDocIdRange);
       did = 0;
@@ -109,9 +107,9 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     QueryPass<NV> qp;
     if (QLDS)
-      load_query_pass_lds<NV>(a.packed, qrow, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+      load_query_pass_lds<NV>(a.packed, ids, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
     else
-      load_query_pass<NV>(a.packed, qrow, a.Q, q0, a.V, lane16, qp, a.status);
+      load_query_pass<NV>(a.packed, ids, a.Q, q0, a.V, lane16, qp, a.status);
     if (tid < kQT) n_one[tid] = 0;
     __syncthreads();
     // OOV exact matches (negative ids equal): rare, counted from the raw id row
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
       for (int t = 0; t < kQT; ++t) any_oov_q |= qp.id[t] < 0;
       if (any_oov_q) {
         for (int j = tid; j < a.L; j += kThreads) {
-          const int64_t did = drow[j];
+          const int64_t did = ids.d(j);
           if (did < 0) {
 #pragma unroll
             for (int t = 0; t < kQT; ++t)
@@ -213,22 +211,21 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 
 }  // namespace
 
-extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed,
-                                   int64_t V, int D, const float* mu, const float* sigma, int K, const float* w1,
-                                   const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
-                                   float* out, int* status, void* stream) {
-  if (B == 0) return CAPAMD_OK;
-  if (!q_ids || !d_ids || !packed || !mu || !sigma || !w1 || !b1 || !out || !status) return CAPAMD_ERR_ARG;
+namespace {
+
+int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, int64_t V, int D, const float* mu,
+                const float* sigma, int K, const float* w1, const float* b1, int hidden, const float* w2, const float* b2,
+                int scoretanh, float* out, int* status, void* stream) {
+  if (!packed || !mu || !sigma || !w1 || !b1 || !out || !status) return CAPAMD_ERR_ARG;
   if (B < 0 || Q < 1 || L < 1 || V < 1 || K < 1 || K > kMaxK || hidden < 0 || hidden > kMaxHidden) return CAPAMD_ERR_ARG;
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
-  if (B == 0) return CAPAMD_OK;
-  KnrmArgs a{q_ids, d_ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
+  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
-  // shared LDS copy) and the occupancy target.  Measured on MI355X (DESIGN.md §4): U=1 + LDS query rows + 6
+  // shared LDS copy) and the occupancy target.  Measured on MI355X (DESIGN.md §3.1): U=1 + LDS query rows + 6
   // waves/SIMD (80 VGPRs) is fastest (36.7 M pairs/s vs 29.5 M for U=2/registers/3 waves); deeper unrolls at lower
   // occupancy and any variant that spills are slower.  CAPAMD_KNRM_VARIANT selects the others for profiling.
   static const int variant = [] {
@@ -239,18 +236,8 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
 #define LAUNCH_V(NV_)                          \
   switch (variant) {                           \
     case 1: LAUNCH(NV_, 4, false, 2); break;   \
-    case 2: LAUNCH(NV_, 2, true, 4); break;    \
-    case 3: LAUNCH(NV_, 4, true, 4); break;    \
-    case 4: LAUNCH(NV_, 1, true, 8); break;    \
-    case 5: LAUNCH(NV_, 3, true, 4); break;    \
     case 6: LAUNCH(NV_, 6, true, 2); break;    \
-    case 7: LAUNCH(NV_, 2, true, 6); break;    \
-    case 8: LAUNCH(NV_, 1, true, 7); break;    \
-    case 9: LAUNCH(NV_, 1, true, 6); break;    \
-    case 10: LAUNCH(NV_, 2, true, 5); break;   \
-    case 11: LAUNCH(NV_, 1, false, 4); break;  \
-    case 12: LAUNCH(NV_, 1, false, 3); break;  \
-    case 13: LAUNCH(NV_, 2, true, 3); break;   \
+    case 4: LAUNCH(NV_, 1, true, 8); break;    \
     case 14: LAUNCH(NV_, 1, true, 5); break;   \
     case 15: LAUNCH(NV_, 2, false, 3); break;  \
     default: LAUNCH(NV_, 1, true, 6); break;   \
@@ -265,4 +252,27 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
 #undef LAUNCH_V
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed,
+                                   int64_t V, int D, const float* mu, const float* sigma, int K, const float* w1,
+                                   const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
+                                   float* out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  return knrm_launch(ids, B, Q, L, packed, V, D, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, stream);
+}
+
+extern "C" int capamd_knrm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                                           const int32_t* pair_d, int B, int Q, int L, const float* packed, int64_t V, int D,
+                                           const float* mu, const float* sigma, int K, const float* w1, const float* b1,
+                                           int hidden, const float* w2, const float* b2, int scoretanh, float* out,
+                                           int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_table || !d_table || !pair_q || !pair_d) return CAPAMD_ERR_ARG;
+  const IdSource ids{nullptr, nullptr, q_table, d_table, pair_q, pair_d};
+  return knrm_launch(ids, B, Q, L, packed, V, D, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, stream);
 }

@@ -42,14 +42,14 @@ __global__ __launch_bounds__(kThreads) void simmat_kernel(const int64_t* __restr
   const int b = blockIdx.x;
   const int lane16 = threadIdx.x & 15;
   const int g = threadIdx.x >> 4;
-  const int64_t* qrow = q_ids + (int64_t)b * Q;
-  const int64_t* drow = d_ids + (int64_t)b * L;
+  const IdSource src{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  const PairIds ids = pair_ids(src, b, Q, L);
   float* out = sim_out + (int64_t)b * Q * L;
   for (int q0 = 0; q0 < Q; q0 += kQT) {
     QueryPass<NV> qp;
-    load_query_pass<NV>(packed, qrow, Q, q0, V, lane16, qp, status);
+    load_query_pass<NV>(packed, ids, Q, q0, V, lane16, qp, status);
     for (int j = g; j < L; j += kGroupsPerWG) {
-      int64_t did = drow[j];
+      int64_t did = ids.d(j);
       if (did >= V) {
         atomicOr(status, kErrDocIdRange);
         did = 0;

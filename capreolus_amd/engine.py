@@ -247,3 +247,46 @@ class BertEngine:
         if check:
             st.raise_if_set()
         return (out, plog) if return_passage_logits else out
+
+
+def _i32(t):
+    return t if (t.dtype == torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous()
+
+
+def knrm_forward_indexed(q_table, d_table, pair_q, pair_d, packed, V, D, mu, sigma, w1, b1, w2=None, b2=None, scoretanh=False,
+                         out=None, check=True):
+    """KNRM over a device-resident candidate store (capamd_knrm_forward_indexed): int32 tables + per-pair rows."""
+    _need_gpu(q_table, d_table, pair_q, pair_d, packed, mu, sigma, w1, b1, w2, b2)
+    qt, dt, pq, pd = _i32(q_table), _i32(d_table), _i32(pair_q), _i32(pair_d)
+    B, Q, L = pq.numel(), qt.shape[1], dt.shape[1]
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=pq.device)
+    hidden = 0 if w2 is None else w1.shape[0]
+    st = status_word(pq.device)
+    rc = _lib.load().capamd_knrm_forward_indexed(
+        _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), B, Q, L, _ptr(packed), V, D, _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1),
+        hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_knrm_forward_indexed")
+    if check:
+        st.raise_if_set()
+    return out
+
+
+def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V, D, edges, hist_type, gate_type, gate_w, emb_raw,
+                         w1, b1, w2, b2, out_w, out_b, out=None, check=True):
+    """DRMM over a device-resident candidate store (capamd_drmm_forward_indexed)."""
+    _need_gpu(q_table, d_table, idf_table, pair_q, pair_d, packed, edges, gate_w, w1, b1, w2, b2, out_w, out_b)
+    qt, dt, pq, pd, idf = _i32(q_table), _i32(d_table), _i32(pair_q), _i32(pair_d), _f32(idf_table)
+    B, Q, L = pq.numel(), qt.shape[1], dt.shape[1]
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=pq.device)
+    st = status_word(pq.device)
+    ld = emb_raw.stride(0) if emb_raw is not None else 0
+    rc = _lib.load().capamd_drmm_forward_indexed(
+        _ptr(qt), _ptr(dt), _ptr(idf), _ptr(pq), _ptr(pd), B, Q, L, _ptr(packed), V, D, _ptr(edges), edges.numel(),
+        HIST_TYPES[hist_type], GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0], _ptr(w2),
+        _ptr(b2), _ptr(out_w), _ptr(out_b), _ptr(out), None, _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmm_forward_indexed")
+    if check:
+        st.raise_if_set()
+    return out

@@ -61,6 +61,16 @@ class DRMM_class(nn.Module):
             self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), counts_out=counts_out)
         return out.view(-1, 1)
 
+    def forward_indexed(self, store, pair_q, pair_d):
+        """Scores (query row, document row) pairs of a device-resident `CandidateStore` -> [B]."""
+        w = self.embedding.weight
+        packed = self._packed.get(w)
+        return engine.drmm_forward_indexed(
+            store.q_table, store.d_table, store.idf_table, pair_q, pair_d, packed, w.shape[0], w.shape[1], self._bin_edges(w.device),
+            self.hist_type, self.gate_type, self.gates.weight.detach().contiguous().view(-1), w.detach(),
+            self.ffw[0].weight.detach().contiguous(), self.ffw[0].bias.detach(), self.ffw[2].weight.detach().contiguous().view(-1),
+            self.ffw[2].bias.detach(), self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach())
+
 
 class DRMM(Reranker):
     """Guo et al., A Deep Relevance Matching Model for Ad-hoc Retrieval, CIKM'16 (reference DRMM.py:119-133)."""
@@ -79,3 +89,6 @@ class DRMM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def test_resident(self, store, pair_q, pair_d):
+        return self.model.forward_indexed(store, pair_q, pair_d)

@@ -74,6 +74,18 @@ class KNRM_class(nn.Module):
             lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"])
         return out.view(-1, 1)
 
+    def forward_indexed(self, store, pair_q, pair_d):
+        """Scores (query row, document row) pairs of a device-resident `CandidateStore` -> [B]."""
+        w = self.embedding.weight
+        packed = self._packed.get(w)
+        mu, sigma = self.kernels.stacked()
+        lin1 = self.combine[0]
+        w2 = b2 = None
+        if not self.p["singlefc"]:
+            w2, b2 = self.combine[2].weight.detach(), self.combine[2].bias.detach()
+        return engine.knrm_forward_indexed(store.q_table, store.d_table, pair_q, pair_d, packed, w.shape[0], w.shape[1], mu, sigma,
+                                           lin1.weight.detach().contiguous(), lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"])
+
 
 class KNRM(Reranker):
     """Xiong et al., End-to-End Neural Ad-hoc Ranking with Kernel Pooling, SIGIR'17 (reference KNRM.py:58-69)."""
@@ -92,3 +104,6 @@ class KNRM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def test_resident(self, store, pair_q, pair_d):
+        return self.model.forward_indexed(store, pair_q, pair_d)

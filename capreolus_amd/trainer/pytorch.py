@@ -112,6 +112,42 @@ class PytorchTrainer:
 
         return {k: pad(v) for k, v in batch.items()}
 
+    def predict_resident(self, reranker, store, qid_to_docids, pred_fn=None):
+        """`predict` over a device-resident `capreolus_amd.feeder.CandidateStore`: no DataLoader,
+        no per-batch host->device copy; one kernel launch per `evalbatch` pairs (0 -> the whole run in one launch)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        reranker.model.to(store.device).eval()
+        qids = list(qid_to_docids.keys())
+        b = shard_bounds([len(qid_to_docids[q]) for q in qids], world)
+        mine = {q: qid_to_docids[q] for q in qids[b[rank]:b[rank + 1]]}
+        keys, pq, pd = store.pairs(mine)
+        step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(len(keys), 1)
+        with torch.no_grad():
+            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, len(keys), step)]
+        local = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
+        if world > 1:
+            counts = [sum(len(qid_to_docids[q]) for q in qids[b[r]:b[r + 1]]) for r in range(world)]
+            width = max(counts)
+            padded = torch.zeros(width, dtype=torch.float32, device=store.device)
+            padded[: local.numel()] = local
+            gathered = torch.empty(width * world, dtype=torch.float32, device=store.device)
+            dist.all_gather_into_tensor(gathered, padded)
+            g = gathered.cpu().numpy().reshape(world, width)
+            allscores = np.concatenate([g[r, : counts[r]] for r in range(world)])
+            allkeys = [(q, d) for q in qids for d in qid_to_docids[q]]
+        else:
+            allkeys, allscores = keys, local.cpu().numpy()
+        preds = {}
+        for (qid, docid), score in zip(allkeys, allscores):
+            preds.setdefault(qid, {})[docid] = score.astype(np.float16).item()
+        if pred_fn is not None and rank == 0:
+            os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
+            write_trec_run(preds, pred_fn)
+        return preds
+
     def predict(self, reranker, pred_data, pred_fn=None):
         """Scores every (qid, docid) of `pred_data`; returns {qid: {docid: score}} on every rank and
         writes the TREC run to `pred_fn` (rank 0)."""

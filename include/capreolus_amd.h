@@ -72,6 +72,15 @@ int capamd_knrm_forward(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_ids /*[
                         const float* w1, const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
                         float* out, int* status, void* stream);
 
+/* Same scoring from a device-resident candidate store (replaces the per-sample
+ * PredSampler -> DataLoader collate -> .to(device) of capreolus/sampler/__init__.py:207-264 and
+ * trainer/pytorch.py:334-342): the run's query / document id rows are uploaded ONCE as int32 tables
+ * q_table [NQ, Q], d_table [ND, L]; a batch is B (query row, document row) index pairs. */
+int capamd_knrm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                                const int32_t* pair_d, int B, int Q, int L, const float* packed, int64_t V, int D,
+                                const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden,
+                                const float* w2, const float* b2, int scoretanh, float* out, int* status, void* stream);
+
 /* ---- DRMM_class.forward (capreolus/reranker/DRMM.py:101-116) behind DRMM.test (DRMM.py:150-155)
  * idf fp32 [B,Q]; edges fp32 [nbins] = torch.linspace(-1,1,nbins+1)[1:] (DRMM.py:63);
  * hist_type 0 = CH, 1 = NH, 2 = LCH (DRMM.py:72-79); gate_type 0 = IDF (gate_w fp32 [1]),
@@ -84,6 +93,14 @@ int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float*
                         int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
                         const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
                         const float* out_b, float* out, int32_t* counts_out, int* status, void* stream);
+
+/* indexed variant (see capamd_knrm_forward_indexed); idf_table fp32 [NQ, Q] is indexed by the pair's query row */
+int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const float* idf_table,
+                                const int32_t* pair_q, const int32_t* pair_d, int B, int Q, int L, const float* packed,
+                                int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type,
+                                const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1,
+                                int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
+                                float* out, int32_t* counts_out, int* status, void* stream);
 
 /* ---- PTBERTMaxP_Class.predict_step (capreolus/reranker/ptBERTMaxP.py:67-96) behind PTBERTMaxP.test
  * (ptBERTMaxP.py:134-135), including the transformers.BertForSequenceClassification forward it calls

@@ -61,3 +61,18 @@ def load_bert_case(name):
     for k in ("pos_bert_input", "pos_mask", "pos_seg"):
         c[k] = torch.from_numpy(c[k].astype(np.int64))
     return c
+
+
+def synthetic_qrels(n_docs, seed, n_rel=20):
+    """Graded qrels (0/1/2) for one query over docids d0..d{n-1}: ~n_rel relevant (SURVEY.md §8d parity procedure)."""
+    rs = np.random.RandomState(seed)
+    rel = np.zeros(n_docs, dtype=np.int64)
+    idx = rs.choice(n_docs, size=min(n_rel, n_docs), replace=False)
+    rel[idx] = rs.randint(1, 3, size=len(idx))
+    return {f"d{i}": int(rel[i]) for i in range(n_docs)}
+
+
+def run_from_scores(scores):
+    """What PytorchTrainer.predict builds for one query: docid -> fp16-rounded score (trainer/pytorch.py:346-348)."""
+    s = np.asarray(scores, dtype=np.float32).astype(np.float16)
+    return {f"d{i}": float(s[i]) for i in range(len(s))}

@@ -248,3 +248,101 @@ def test_full_size_drmm_properties(full):
         wide = torch.cat([b["posdoc"], torch.zeros((2000, 133), dtype=torch.int64, device=DEV)], 1)
         s2 = m(wide, b["query"], b["query_idf"]).view(-1)
         assert torch.equal(s, s2)
+
+
+@pytest.mark.parametrize("kind", ["knrm", "drmm"])
+def test_ndcg20_parity_gpu_vs_reference(kind):
+    from capreolus_amd import run_io
+    from tests.helpers import run_from_scores, synthetic_qrels
+
+    c = load_case(kind, "ranklist")
+    r = _knrm_model(c) if kind == "knrm" else _drmm_model(c)
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy()
+    diffs = []
+    for seed in range(5):
+        qrels = {"1": synthetic_qrels(len(got), seed)}
+        ours = run_io.ndcg_cut(qrels, {"1": run_from_scores(got)}, 20)["1"]
+        ref = run_io.ndcg_cut(qrels, {"1": run_from_scores(c["ref_scores"])}, 20)["1"]
+        diffs.append(abs(ours - ref))
+    if kind == "knrm":
+        assert max(diffs) < 1e-12, diffs
+    else:
+        assert np.mean(diffs) < 0.05, diffs
+
+
+def test_predict_end_to_end_on_gpu(tmp_path):
+    """PytorchTrainer.predict -> KNRM.test -> HIP kernel -> fp16 run file, against the oracle's ranking."""
+    from capreolus_amd import run_io
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "default")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = {"7": [f"d{i}" for i in range(B // 2)], "3": [f"d{i}" for i in range(B // 2, B)]}
+
+        def __iter__(self):
+            i = 0
+            for qid, docs in self.qid_to_docids.items():
+                for d in docs:
+                    yield {"qid": qid, "posdocid": d, "query": c["query"][i], "posdoc": c["posdoc"][i], "query_idf": c["query_idf"][i]}
+                    i += 1
+
+        def __len__(self):
+            return B
+
+        def get_qid_docid_pairs(self):
+            for qid, docs in self.qid_to_docids.items():
+                for d in docs:
+                    yield qid, d
+
+    preds = PytorchTrainer({"batch": 5}).predict(r, Sampler(), tmp_path / "run.txt")
+    flat = np.array([preds[q][d] for q, docs in Sampler.qid_to_docids.items() for d in docs], dtype=np.float32)
+    assert rel_err(flat, c["ref_scores"].astype(np.float16).astype(np.float32)).max() < 2e-3  # fp16 grid
+    run = run_io.load_trec_run(tmp_path / "run.txt")
+    assert list(run.keys()) == ["3", "7"]  # qids in integer order (searcher/__init__.py:51)
+
+
+@pytest.mark.parametrize("kind", ["knrm", "drmm"])
+def test_resident_store_matches_extractor_layout(kind, tmp_path):
+    """Row N1: int32 tables + index pairs give bit-identical scores to the int64 [B,Q]/[B,L] layout."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case(kind, "default")
+    r = _knrm_model(c) if kind == "knrm" else _drmm_model(c)
+    B = c["query"].shape[0]
+    # two "queries" (first and second half of the fixture), documents shared between them where ids repeat
+    q2d = {"11": [f"d{i}" for i in range(B // 2)], "4": [f"d{i}" for i in range(B // 2, B)]}
+    row = {(q, d): i for i, (q, d) in enumerate((q, d) for q, ds in q2d.items() for d in ds)}
+    store = CandidateStore(DEV)
+    for (q, d), i in row.items():
+        store.add_query(q + ":" + d, c["query"][i], c["query_idf"][i])  # every pair has its own query row in this fixture
+        store.add_doc(d, c["posdoc"][i])
+    store.finalize()
+    pq = torch.arange(B, dtype=torch.int32, device=DEV)
+    pd = torch.as_tensor([store.drow[d] for (_, d) in row], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        want = r.test(_batch(c))
+        got = r.test_resident(store, pq, pd)
+        assert torch.equal(got, want)
+        perm = torch.randperm(B, device=DEV)
+        assert torch.equal(r.test_resident(store, pq[perm], pd[perm]), want[perm])
+
+
+def test_predict_resident_ranklist():
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "ranklist")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+    q2d = {"301": [f"d{i}" for i in range(B)]}
+    store = CandidateStore.from_id2vec(DEV, q2d, lambda q, d: {"query": c["query"][int(d[1:])], "posdoc": c["posdoc"][int(d[1:])],
+                                                              "query_idf": c["query_idf"][int(d[1:])]})
+    assert store.q_table.shape[0] == 1 and store.d_table.shape[0] == B  # the query is stored once for its 200 candidates
+    preds = PytorchTrainer({"evalbatch": 64}).predict_resident(r, store, q2d)
+    got = np.array([preds["301"][f"d{i}"] for i in range(B)], dtype=np.float16)
+    assert (got == c["ref_scores_f16"]).mean() > 0.98
