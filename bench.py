@@ -63,13 +63,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CAPAMD_FORCE_DIST") == "1"  # the env knob exercises the RCCL path on one rank
+    if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.model == "bert":
-        return bench_bert(args, world, rank, dev)
+        return bench_bert(args, world, rank, dev, use_dist)
 
     from types import SimpleNamespace
 
@@ -96,7 +99,7 @@ def main():
     w = m.embedding.weight
     packed = m._packed.get(w)
     out = torch.empty(n_pairs, dtype=torch.float32, device=dev)
-    gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if use_dist else None
 
     launch = args.launch_docs or n_pairs
     slices = [(i, min(i + launch, n_pairs)) for i in range(0, n_pairs, launch)]
@@ -130,12 +133,12 @@ def main():
     def step():
         for lo, hi in slices:
             launch_one(lo, hi)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,12 +150,14 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     engine.status_word(dev).raise_if_set()
     assert torch.isfinite(out).all()
+    if use_dist:
+        assert torch.equal(gathered[rank * n_pairs:(rank + 1) * n_pairs], out)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around each launch --
     evs = []
@@ -177,7 +182,7 @@ def main():
             traffic = json.load(f).get("hbm_bytes_per_launch")
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -222,9 +227,9 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(args, m, batch, emb, Q, L, D)
-    print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    print(json.dumps(rec), flush=True)
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA")
@@ -235,7 +240,7 @@ def bert_flops_per_passage(S=256, H=768, F=3072, layers=12):
     return layers * (8 * S * H * H + 4 * S * S * H + 4 * S * H * F)
 
 
-def bench_bert(args, world, rank, dev):
+def bench_bert(args, world, rank, dev, use_dist):
     """BASELINE.json configs[3]: BERT-base MaxP, 4 passages x 256 tokens per document, 1000 docs/query."""
     import ctypes
     from types import SimpleNamespace
@@ -244,7 +249,7 @@ def bench_bert(args, world, rank, dev):
     from capreolus_amd.reranker import PTBERTMaxP
     from oracle import bert_port
 
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
     P, S, H, F, LAYERS, HEADS, VOCAB = 4, 256, 768, 3072, 12, 12, 30522
     docs = args.docs * (args.queries if args.queries != 64 else 1)   # default: one query's 1000 candidates per step
@@ -265,17 +270,17 @@ def bench_bert(args, world, rank, dev):
     with torch.no_grad():
         rr.test({k: v[:8] for k, v in d.items()})   # builds the bf16 blob
     eng = m._engine
-    gathered = torch.empty(docs * world, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(docs * world, dtype=torch.float32, device=dev) if use_dist else None
     out = [None]
 
     def step():
         out[0] = eng.forward(d["pos_bert_input"], d["pos_mask"], d["pos_seg"], "max", check=False)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out[0])
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -287,7 +292,7 @@ def bench_bert(args, world, rank, dev):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -315,7 +320,7 @@ def bench_bert(args, world, rank, dev):
     gemm_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
     gemm_tf = 2.0 * Mg * Ng * Kg / gemm_s / 1e12
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     psg_per_s = docs * P * world * args.steps / elapsed
@@ -343,9 +348,9 @@ def bench_bert(args, world, rank, dev):
         dt = time.perf_counter() - t0
         rec["cpu_baseline"] = {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
                                "sample": f"{n} documents ({n * P} passages) through oracle/bert_port.py (fp32 ATen ops, {cores} threads)"}
-    print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    print(json.dumps(rec), flush=True)
 
 
 def cpu_baseline(args, m, batch, emb, Q, L, D):
