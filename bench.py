@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=300)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform instead of Zipf(1.1) term ids (HBM-bound case)")
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
+    ap.add_argument("--bert-dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit operand type of the BERT encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -262,7 +263,8 @@ def bench_bert(args, world, rank, dev, use_dist):
                                       (d["pos_bert_input"] + torch.arange(docs, device=dev)[:, None, None] * 7) % (VOCAB - 1000) + 1000,
                                       d["pos_bert_input"])
     weights = bert_port.random_weights(H, LAYERS, HEADS, F, VOCAB, 512, seed=0)
-    rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": 256},
+    rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": 256,
+                     "compute_dtype": args.bert_dtype},
                     SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
     m = rr.build_model()
     m.bert.load_state_dict(weights, strict=True)
@@ -301,10 +303,11 @@ def bench_bert(args, world, rank, dev, use_dist):
 
     # dominant kernel: the FFN1 GEMM (M = 256 passages x 256 tokens, N = 3072, K = 768, bias+GELU epilogue)
     Mg, Ng, Kg = 256 * S, F, H
-    A = torch.randn((Mg, Kg), device=dev).bfloat16()
-    W = (torch.randn((Ng, Kg), device=dev) * 0.05).bfloat16()
+    tdt, tcode = (torch.float16, 1) if args.bert_dtype == "fp16" else (torch.bfloat16, 0)
+    A = torch.randn((Mg, Kg), device=dev).to(tdt)
+    W = (torch.randn((Ng, Kg), device=dev) * 0.05).to(tdt)
     bias = torch.randn(Ng, device=dev)
-    o = torch.empty((Mg, Ng), dtype=torch.bfloat16, device=dev)
+    o = torch.empty((Mg, Ng), dtype=tdt, device=dev)
     lib = _lib.load()
     vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -312,7 +315,7 @@ def bench_bert(args, world, rank, dev, use_dist):
     for i in range(13):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), Mg, Ng, Kg, 1, None, vp(o), st) == 0
+        assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), Mg, Ng, Kg, 1, None, vp(o), tcode, st) == 0
         e1.record()
         if i >= 3:
             evs.append((e0, e1))
@@ -328,9 +331,9 @@ def bench_bert(args, world, rank, dev, use_dist):
     rec = {
         "metric": "query-doc pairs scored/sec", "value": docs * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.bert_dtype, "data": "synthetic",
         "config": {"workload": f"BERT-base MaxP inference (BASELINE.json configs[3]): {P} passages x {S} tokens per doc, {docs} docs per step "
-                               f"per GPU, seeded random-init weights, bf16 MFMA with fp32 accumulate/residual/LayerNorm/softmax",
+                               f"per GPU, seeded random-init weights, {args.bert_dtype} MFMA operands and activations, fp32 accumulate/LayerNorm statistics/softmax",
                    "passages_per_s": psg_per_s, "parallelism": f"document-sharded x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256,4,2,bias+GELU> (FFN1, M=65536 N=3072 K=768)",
                      "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,

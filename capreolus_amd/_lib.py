@@ -25,7 +25,7 @@ _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_siz
 class BertModel(ctypes.Structure):
     """capamd_bert_model (include/capreolus_amd.h)."""
 
-    _fields_ = [(n, ctypes.c_int) for n in ("hidden", "layers", "heads", "ffn", "vocab", "max_pos", "type_vocab")] + [
+    _fields_ = [(n, ctypes.c_int) for n in ("hidden", "layers", "heads", "ffn", "vocab", "max_pos", "type_vocab", "compute_dtype")] + [
         (n, ctypes.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "pooler_w", "pooler_b",
                                        "cls_w", "cls_b", "blob", "layer_f32")]
 
@@ -51,9 +51,9 @@ SIGNATURES = {
     "capamd_bert_pack_layer": (_i, [_mp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp]),
     "capamd_bert_workspace_bytes": (_i64, [_mp, _i, _i64, _i64]),
     "capamd_bert_maxp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
-    "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

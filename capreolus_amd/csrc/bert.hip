@@ -26,8 +26,9 @@ __device__ __forceinline__ float wave_sum64(float v) {
 }
 
 // ---- fp32 -> bf16 weight conversion (row-major copy into the blob) ----------------------------
-__global__ void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (__bf16)src[i];
+template <typename T>
+__global__ void cvt_bf16_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (T)src[i];
 }
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -36,13 +37,14 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 // One wave per token: v = LayerNorm(x) over H (H % 256 == 0 is NOT required; H % 4 == 0, H <= 1024).
 // MODE 0: x = word[id] + pos[s] + type[seg]  (fp32 embedding tables);  MODE 1: x = pre[token] (bf16 pre-LN sum).
 // Output: bf16 (the activation stream is bf16 end to end; statistics and the affine are fp32).
-template <int MODE>
-__global__ __launch_bounds__(256) void ln_kernel(const __bf16* __restrict__ pre, const int64_t* __restrict__ ids,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, const int64_t* __restrict__ ids,
                                                  const int64_t* __restrict__ seg, const float* __restrict__ word,
                                                  const float* __restrict__ pos, const float* __restrict__ type, int vocab,
                                                  int type_vocab, int S, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int64_t M, int H,
-                                                 __bf16* __restrict__ xb, int* status) {
+                                                 T* __restrict__ xb, int* status) {
+  using bf16x4 = typename Half<T>::x4;
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= M) return;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const __bf16* __restrict__ pre,
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      bf16x4 ob = {(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+      bf16x4 ob = {(T)o.x, (T)o.y, (T)o.z, (T)o.w};
       reinterpret_cast<bf16x4*>(xb + tok * H)[c] = ob;
     }
   }
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const __bf16* __restrict__ pre,
 // fetched once per kHeadPsg passages; its partial sum over those 64 rows of cls_w[1][j] * tanh(pooler_j) goes to
 // part[psg][slice]; head_reduce_kernel adds the slices in fixed order (deterministic, no atomics).
 constexpr int kHeadPsg = 8;
-__global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf, int64_t n_psg, int S, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int64_t n_psg, int S, int H,
                                                    const float* __restrict__ pw, const float* __restrict__ pb,
                                                    const float* __restrict__ cw, float* __restrict__ part) {
   __shared__ float cls[kHeadPsg][1024];
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void head_kernel(const __bf16* __restrict__ xf
 #pragma unroll
   for (int q = 0; q < kHeadPsg; ++q) {
     const int64_t psg = p0 + q < n_psg ? p0 + q : n_psg - 1;
-    const __bf16* h = xf + psg * S * H;  // token 0 ([CLS]) of the passage
+    const T* h = xf + psg * S * H;  // token 0 ([CLS]) of the passage
     for (int i = tid; i < H; i += 256) cls[q][i] = (float)h[i];
   }
   __syncthreads();
@@ -202,7 +205,8 @@ struct Dims {
 
 bool dims_ok(const capamd_bert_model* m) {
   return m && m->hidden >= 64 && m->hidden <= 1024 && m->hidden % 64 == 0 && m->heads * 64 == m->hidden && m->layers >= 1 &&
-         m->ffn >= 64 && m->ffn % 64 == 0 && m->vocab >= 1 && m->max_pos >= 1 && m->type_vocab >= 1;
+         m->ffn >= 64 && m->ffn % 64 == 0 && m->vocab >= 1 && m->max_pos >= 1 && m->type_vocab >= 1 &&
+         (m->compute_dtype == 0 || m->compute_dtype == 1);
 }
 
 int64_t layer_blob_elems(int H, int F) { return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H; }
@@ -220,11 +224,18 @@ int num_cus() {
   return n;
 }
 
-template <int EPI>
+template <typename T>
+void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
+  if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8, T>), dim3(nblk), dim3(512), 0, s, at);
+  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
+  else hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at);
+}
+
+template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.M % 256 == 0 && g.N % 256 == 0) {
-    using G = GemmKernel<256, 256, 4, 2, EPI>;
-    auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI>;
+    using G = GemmKernel<256, 256, 4, 2, EPI, T>;
+    auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
@@ -234,21 +245,21 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
     hipLaunchKernelGGL(k, dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
   } else {
-    using G = GemmKernel<64, 64, 2, 2, EPI>;
+    using G = GemmKernel<64, 64, 2, 2, EPI, T>;
     const int tiles = (g.N / 64) * (g.M / 64), cap = 4 * num_cus(), grid = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI, T>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
   }
   return hipGetLastError();
 }
 
 struct Workspace {
-  __bf16* xb;     // [M, H] activation / residual stream
-  __bf16* q;      // [M, H]
-  __bf16* k;      // [M, H]
-  __bf16* vt;     // [M/S*heads, 64, S]
-  __bf16* ctx;    // [M, H]
-  __bf16* pre;    // [M, H] pre-LayerNorm sums
-  __bf16* mid;    // [M, F]
+  uint16_t* xb;   // [M, H] activation / residual stream      (16-bit type T of the model: bf16 or fp16)
+  uint16_t* q;    // [M, H]
+  uint16_t* k;    // [M, H]
+  uint16_t* vt;   // [M/S*heads, 64, S]
+  uint16_t* ctx;  // [M, H]
+  uint16_t* pre;  // [M, H] pre-LayerNorm sums
+  uint16_t* mid;  // [M, F]
   float* logits;  // [B*P] (whole call)
   int* cnt;       // avg denominator
 };
@@ -266,16 +277,87 @@ Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_to
   const int64_t M = n_psg_mb * S;
   Workspace w;
   auto take = [&](size_t x) { char* r = p; p += (x + 255) & ~(size_t)255; return r; };
-  w.xb = (__bf16*)take((size_t)M * H * 2);
-  w.q = (__bf16*)take((size_t)M * H * 2);
-  w.k = (__bf16*)take((size_t)M * H * 2);
-  w.vt = (__bf16*)take((size_t)M * H * 2);
-  w.ctx = (__bf16*)take((size_t)M * H * 2);
-  w.pre = (__bf16*)take((size_t)M * H * 2);
-  w.mid = (__bf16*)take((size_t)M * F * 2);
+  w.xb = (uint16_t*)take((size_t)M * H * 2);
+  w.q = (uint16_t*)take((size_t)M * H * 2);
+  w.k = (uint16_t*)take((size_t)M * H * 2);
+  w.vt = (uint16_t*)take((size_t)M * H * 2);
+  w.ctx = (uint16_t*)take((size_t)M * H * 2);
+  w.pre = (uint16_t*)take((size_t)M * H * 2);
+  w.mid = (uint16_t*)take((size_t)M * F * 2);
   w.logits = (float*)take((size_t)n_psg_total * 4);
   w.cnt = (int*)take(256);
   return w;
+}
+
+template <typename T>
+hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_t* seg, int64_t NP, int64_t mb, int S,
+                           const capamd_bert_model* m, const Workspace& w, int* status, hipStream_t s) {
+  const int H = m->hidden, F = m->ffn;
+  const T* blob = (const T*)m->blob;
+  hipError_t e = hipSuccess;
+
+  for (int64_t p0 = 0; p0 < NP && e == hipSuccess; p0 += mb) {
+    const int64_t np = (NP - p0 < mb) ? NP - p0 : mb;
+    const int64_t M = np * S;
+    const int64_t* ids_mb = ids + p0 * S;
+    const int64_t* mask_mb = mask + p0 * S;
+    const int64_t* seg_mb = seg + p0 * S;
+    hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, (T*)w.xb, status);
+    for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
+      const T* wl = blob + (int64_t)l * layer_blob_elems(H, F);
+      const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
+      const T *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
+      const float *bqkv = fl, *bo = fl + 3 * H, *ln1g = fl + 4 * H, *ln1b = fl + 5 * H, *b1 = fl + 6 * H, *b2 = fl + 6 * H + F,
+                  *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
+      GemmArgs g{};
+      g.H = H; g.S = S; g.heads = m->heads;
+      // QKV projection (+bias, Q/8, V transposed per head)
+      g.A = w.xb; g.W = wqkv; g.bias = bqkv; g.M = (int)M; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
+      e = launch_gemm<kEpiQkv, T>(g, s);
+      if (e != hipSuccess) break;
+      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
+      const unsigned nblk = (unsigned)(np * m->heads);
+      launch_attention<T>(at, S, nblk, s);
+      // attention output projection + residual -> LayerNorm
+      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasResidBf16, T>(g, s);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL((ln_kernel<1, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status);
+      // feed-forward: 768 -> 3072 (GELU) -> 768 + residual -> LayerNorm
+      g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
+      e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
+      if (e != hipSuccess) break;
+      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasResidBf16, T>(g, s);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL((ln_kernel<1, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status);
+    }
+    if (e != hipSuccess) break;
+    // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
+    float* hpart = reinterpret_cast<float*>(w.pre);
+    hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
+                       m->pooler_w, m->pooler_b, m->cls_w, hpart);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <typename T>
+int gemm_dispatch(GemmArgs& g, int epilogue, const void* resid, void* out, hipStream_t s) {
+  hipError_t e;
+  g.out_bf16 = out;
+  if (epilogue == kEpiBiasBf16) e = launch_gemm<kEpiBiasBf16, T>(g, s);
+  else if (epilogue == kEpiBiasGeluBf16) e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
+  else if (epilogue == kEpiBiasResidBf16) {
+    if (!resid) return CAPAMD_ERR_ARG;
+    g.resid_bf16 = resid;
+    e = launch_gemm<kEpiBiasResidBf16, T>(g, s);
+  } else return CAPAMD_ERR_ARG;
+  return e == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -295,12 +377,15 @@ int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* c
   const int64_t H = m->hidden, F = m->ffn;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  __bf16* wb = (__bf16*)blob + (int64_t)layer * layer_blob_elems(H, F);
+  uint16_t* wb = (uint16_t*)blob + (int64_t)layer * layer_blob_elems(H, F);
   float* fb = layer_f32 + (int64_t)layer * layer_f32_floats(H, F);
   // order of t: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b ffn1.w ffn1.b ffn2.w ffn2.b ln2.g ln2.b
   struct { int src; int64_t off, n; } wcp[] = {{0, 0, H * H}, {2, H * H, H * H}, {4, 2 * H * H, H * H}, {6, 3 * H * H, H * H},
                                                {10, 4 * H * H, F * H}, {12, 4 * H * H + F * H, H * F}};
-  for (auto& c : wcp) hipLaunchKernelGGL(cvt_bf16_kernel, dim3(512), dim3(256), 0, s, t[c.src], wb + c.off, c.n);
+  for (auto& c : wcp) {
+    if (m->compute_dtype == 1) hipLaunchKernelGGL(cvt_bf16_kernel<_Float16>, dim3(512), dim3(256), 0, s, t[c.src], (_Float16*)(wb + c.off), c.n);
+    else hipLaunchKernelGGL(cvt_bf16_kernel<__bf16>, dim3(512), dim3(256), 0, s, t[c.src], (__bf16*)(wb + c.off), c.n);
+  }
   struct { int src; int64_t off, n; } fcp[] = {{1, 0, H}, {3, H, H}, {5, 2 * H, H}, {7, 3 * H, H}, {8, 4 * H, H}, {9, 5 * H, H},
                                                {11, 6 * H, F}, {13, 6 * H + F, H}, {14, 7 * H + F, H}, {15, 8 * H + F, H}};
   for (auto& c : fcp) hipLaunchKernelGGL(copy_f32_kernel, dim3(8), dim3(256), 0, s, t[c.src], fb + c.off, c.n);
@@ -330,58 +415,9 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   Workspace w = carve((char*)workspace, H, F, S, mb, NP);
-  const __bf16* blob = (const __bf16*)m->blob;
-  hipError_t e = hipSuccess;
-
-  for (int64_t p0 = 0; p0 < NP && e == hipSuccess; p0 += mb) {
-    const int64_t np = (NP - p0 < mb) ? NP - p0 : mb;
-    const int64_t M = np * S;
-    const int64_t* ids_mb = ids + p0 * S;
-    const int64_t* mask_mb = mask + p0 * S;
-    const int64_t* seg_mb = seg + p0 * S;
-    hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, w.xb, status);
-    for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
-      const __bf16* wl = blob + (int64_t)l * layer_blob_elems(H, F);
-      const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
-      const __bf16 *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
-      const float *bqkv = fl, *bo = fl + 3 * H, *ln1g = fl + 4 * H, *ln1b = fl + 5 * H, *b1 = fl + 6 * H, *b2 = fl + 6 * H + F,
-                  *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
-      GemmArgs g{};
-      g.H = H; g.S = S; g.heads = m->heads;
-      // QKV projection (+bias, Q/8, V transposed per head)
-      g.A = w.xb; g.W = wqkv; g.bias = bqkv; g.M = (int)M; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
-      e = launch_gemm<kEpiQkv>(g, s);
-      if (e != hipSuccess) break;
-      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
-      const unsigned nblk = (unsigned)(np * m->heads);
-      if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8>), dim3(nblk), dim3(512), 0, s, at);
-      else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4>), dim3(nblk), dim3(256), 0, s, at);
-      else hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(nblk), dim3(128), 0, s, at);
-      // attention output projection + residual -> LayerNorm
-      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
-      e = launch_gemm<kEpiBiasResidBf16>(g, s);
-      if (e != hipSuccess) break;
-      hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln1g, ln1b, M, H, w.xb, status);
-      // feed-forward: 768 -> 3072 (GELU) -> 768 + residual -> LayerNorm
-      g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
-      e = launch_gemm<kEpiBiasGeluBf16>(g, s);
-      if (e != hipSuccess) break;
-      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
-      e = launch_gemm<kEpiBiasResidBf16>(g, s);
-      if (e != hipSuccess) break;
-      hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln2g, ln2b, M, H, w.xb, status);
-    }
-    if (e != hipSuccess) break;
-    // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
-    float* hpart = reinterpret_cast<float*>(w.pre);
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, w.xb, np, S, H,
-                       m->pooler_w, m->pooler_b, m->cls_w, hpart);
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
-    e = hipGetLastError();
-  }
+  const hipError_t e = (m->compute_dtype == 1)
+                           ? encode_passages<_Float16>(ids, mask, seg, NP, mb, S, m, w, status, s)
+                           : encode_passages<__bf16>(ids, mask, seg, NP, mb, S, m, w, status, s);
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
   if (aggregation == 3) (void)hipMemsetAsync(w.cnt, 0, 4, s);
   hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(64), 0, s, w.logits, mask, seg, P, S, aggregation, out, w.cnt);
@@ -395,38 +431,34 @@ static unsigned long long* g_gemm_dbg = nullptr;
 void capamd_debug_set_gemm_stamps(void* p) { g_gemm_dbg = (unsigned long long*)p; }  /* profiling hook (scripts/gemm_timeline.py) */
 
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const void* resid,
-                     void* out, void* stream) {
+                     void* out, int dtype, void* stream) {
   if (!A || !W || !bias || !out || M < 64 || N < 64 || K < 64 || M % 64 || N % 64 || K % 64) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   GemmArgs g{};
-  g.A = (const __bf16*)A; g.W = (const __bf16*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.A = A; g.W = W; g.bias = bias; g.M = M; g.N = N; g.K = K;
   g.dbg = g_gemm_dbg;
-  hipError_t e;
-  if (epilogue == kEpiBiasBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasBf16>(g, (hipStream_t)stream); }
-  else if (epilogue == kEpiBiasGeluBf16) { g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasGeluBf16>(g, (hipStream_t)stream); }
-  else if (epilogue == kEpiBiasResidBf16) {
-    if (!resid) return CAPAMD_ERR_ARG;
-    g.resid_bf16 = (const __bf16*)resid; g.out_bf16 = (__bf16*)out; e = launch_gemm<kEpiBiasResidBf16>(g, (hipStream_t)stream);
-  } else return CAPAMD_ERR_ARG;
-  return e == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+  if (dtype == 1) return gemm_dispatch<_Float16>(g, epilogue, resid, out, (hipStream_t)stream);
+  if (dtype == 0) return gemm_dispatch<__bf16>(g, epilogue, resid, out, (hipStream_t)stream);
+  return CAPAMD_ERR_ARG;
 }
 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,
-                              int hidden, int heads, void* q, void* k, void* vt, void* ctx, void* stream) {
+                              int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream) {
   if (!x || !wqkv || !bqkv || !mask || !q || !k || !vt || !ctx || n_passages < 1 || heads * 64 != hidden) return CAPAMD_ERR_ARG;
   if (!(S == 64 || S == 128 || S == 256)) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};
   g.H = hidden; g.S = S; g.heads = heads;
-  g.A = (const __bf16*)x; g.W = (const __bf16*)wqkv; g.bias = bqkv; g.M = n_passages * S; g.N = 3 * hidden; g.K = hidden;
-  g.out_bf16 = (__bf16*)q; g.out_k = (__bf16*)k; g.out_vt = (__bf16*)vt;
-  if (launch_gemm<kEpiQkv>(g, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
-  AttnArgs at{(const __bf16*)q, (const __bf16*)k, (const __bf16*)vt, mask, (__bf16*)ctx, hidden, heads};
+  g.A = x; g.W = wqkv; g.bias = bqkv; g.M = n_passages * S; g.N = 3 * hidden; g.K = hidden;
+  g.out_bf16 = q; g.out_k = k; g.out_vt = vt;
+  if (dtype != 0 && dtype != 1) return CAPAMD_ERR_ARG;
+  const hipError_t e = dtype == 1 ? launch_gemm<kEpiQkv, _Float16>(g, s) : launch_gemm<kEpiQkv, __bf16>(g, s);
+  if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
+  AttnArgs at{q, k, vt, mask, ctx, hidden, heads};
   const unsigned nblk = (unsigned)(n_passages * heads);
-  if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8>), dim3(nblk), dim3(512), 0, s, at);
-  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4>), dim3(nblk), dim3(256), 0, s, at);
-  else hipLaunchKernelGGL((attention_kernel<64, 2>), dim3(nblk), dim3(128), 0, s, at);
+  if (dtype == 1) launch_attention<_Float16>(at, S, nblk, s);
+  else launch_attention<__bf16>(at, S, nblk, s);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 

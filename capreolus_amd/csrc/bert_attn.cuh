@@ -20,11 +20,11 @@
 namespace capamd {
 
 struct AttnArgs {
-  const __bf16* Q;       // [M, H] (pre-scaled by 1/8)
-  const __bf16* K;       // [M, H]
-  const __bf16* Vt;      // [M/S * heads][64][S]
+  const void* Q;         // [M, H] (pre-scaled by 1/8), 16-bit type T
+  const void* K;         // [M, H]
+  const void* Vt;        // [M/S * heads][64][S]
   const int64_t* mask;   // [M/S, S] attention mask (1 = attend), rows of the current micro-batch
-  __bf16* ctx;           // [M, H]
+  void* ctx;             // [M, H]
   int H, heads;
 };
 
@@ -32,8 +32,10 @@ struct AttnArgs {
 // stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V staged
 // once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us:
 // the kernel is bound by the L2->LDS fill, so the doubled staging costs more than the overlap buys.
-template <int S, int NW>
+template <int S, int NW, typename T>
 __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
   constexpr int NT = S / 32;            // key tiles
   constexpr int QB = NT / NW;           // workgroups per (passage, head)
   constexpr int NTHR = 64 * NW;
@@ -57,10 +59,10 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < INSTR; ++t) {
       const int row = (wave * INSTR + t) * 8 + r8;
-      const __bf16* src = a.K + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
+      const T* src = static_cast<const T*>(a.K) + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * INSTR + t) * 1024), 16, 0, 0);
     }
-    const __bf16* vsrc = a.Vt + (int64_t)ph * 64 * S;
+    const T* vsrc = static_cast<const T*>(a.Vt) + (int64_t)ph * 64 * S;
     for (int c = tid; c < 64 * S / 8; c += NTHR) {
       const int d = c / (S / 8), k8 = c % (S / 8);
       const uint4 x = *reinterpret_cast<const uint4*>(vsrc + d * S + k8 * 8);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   // this wave's Q fragments (B operand): query = qwave*32 + l31, d = (2*ks+half)*8 ..+7
   bf16x8 qf[4];
   {
-    const __bf16* qrow = a.Q + (tok0 + qwave * 32 + l31) * a.H + head * 64 + half * 8;
+    const T* qrow = static_cast<const T*>(a.Q) + (tok0 + qwave * 32 + l31) * a.H + head * 64 + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
   }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
     for (int ks = 0; ks < 4; ++ks) {
       const int row = t * 32 + l31;
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
-      sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+      sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
     }
   }
   // ---- exact softmax over the S keys of this lane's query ----
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 pf;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pf[e] = (__bf16)sc[t][8 * s2 + e];
+      for (int e = 0; e < 8; ++e) pf[e] = (T)sc[t][8 * s2 + e];
       const int kb = (32 * t + 16 * s2 + 4 * half) * 2;  // byte offset of keys {kb/2 .. +3}; second group +8 keys
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -141,16 +143,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
         const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
         const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
         const bf16x8 vf = __builtin_bit_cast(bf16x8, raw);
-        out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, out[dt], 0, 0, 0);
+        out[dt] = Half<T>::mfma(vf, pf, out[dt]);
       }
     }
-  __bf16* crow = a.ctx + (tok0 + qwave * 32 + l31) * a.H + head * 64;
+  T* crow = static_cast<T*>(a.ctx) + (tok0 + qwave * 32 + l31) * a.H + head * 64;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      bf16x4 o = {(__bf16)(out[dt][g4 * 4 + 0] * inv), (__bf16)(out[dt][g4 * 4 + 1] * inv),
-                  (__bf16)(out[dt][g4 * 4 + 2] * inv), (__bf16)(out[dt][g4 * 4 + 3] * inv)};
+      bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv),
+                  (T)(out[dt][g4 * 4 + 2] * inv), (T)(out[dt][g4 * 4 + 3] * inv)};
       *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
     }
 }

@@ -37,9 +37,25 @@
 
 namespace capamd {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// 16-bit operand type of the encoder: __bf16 (default; 8 exponent / 7 mantissa bits) or _Float16 (5 / 10 bits: what
+// the reference's `amp=pred` autocast uses on CUDA, trainer/pytorch.py:323-326, and ~8x smaller rounding error; same
+// MFMA rate).  Selected per model (capamd_bert_model.compute_dtype).
+template <typename T>
+struct Half;
+template <>
+struct Half<__bf16> {
+  typedef __attribute__((ext_vector_type(8))) __bf16 x8;
+  typedef __attribute__((ext_vector_type(4))) __bf16 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Half<_Float16> {
+  typedef __attribute__((ext_vector_type(8))) _Float16 x8;
+  typedef __attribute__((ext_vector_type(4))) _Float16 x4;
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -51,14 +67,14 @@ enum GemmEpilogue {
 };
 
 struct GemmArgs {
-  const __bf16* A;      // [M, K] activations
-  const __bf16* W;      // [N, K] weights
+  const void* A;        // [M, K] activations (16-bit type T)
+  const void* W;        // [N, K] weights
   const float* bias;    // [N]
   int M, N, K;
-  __bf16* out_bf16;     // kEpiBias*: [M, N];  kEpiQkv: Q [M, H]
-  __bf16* out_k;        // kEpiQkv: K [M, H]
-  __bf16* out_vt;       // kEpiQkv: V^T [M/S * heads][64][S]
-  const __bf16* resid_bf16;  // kEpiBiasResidBf16: [M, N]
+  void* out_bf16;       // kEpiBias*: [M, N];  kEpiQkv: Q [M, H]   (16-bit type T, whatever the name says)
+  void* out_k;          // kEpiQkv: K [M, H]
+  void* out_vt;         // kEpiQkv: V^T [M/S * heads][64][S]
+  const void* resid_bf16;    // kEpiBiasResidBf16: [M, N] (type T)
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };
@@ -93,8 +109,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, typename T = __bf16>
 struct GemmKernel {
+  using bf16x8 = typename Half<T>::x8;  // (names kept from the bf16-only version: "the 16-bit vector types")
+  using bf16x4 = typename Half<T>::x4;
   static constexpr int kWaves = WAVES_M * WAVES_N;
   static constexpr int kThreads = 64 * kWaves;
   static constexpr int BK = 64;
@@ -122,14 +140,14 @@ struct GemmKernel {
 #pragma unroll
     for (int t = 0; t < A_INSTR; ++t) {
       const int row = (wave * A_INSTR + t) * 16 + r16;
-      const __bf16* src = a.A + (int64_t)(m0 + row) * a.K + kcol + swz_chunk4(row, p) * 8;
+      const T* src = static_cast<const T*>(a.A) + (int64_t)(m0 + row) * a.K + kcol + swz_chunk4(row, p) * 8;
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(base + (wave * A_INSTR + t) * 1024), 16, 0, 0);
     }
     char* wbase = base + BM * 64;
 #pragma unroll
     for (int t = 0; t < W_INSTR; ++t) {
       const int row = (wave * W_INSTR + t) * 16 + r16;
-      const __bf16* src = a.W + (int64_t)(n0 + row) * a.K + kcol + swz_chunk4(row, p) * 8;
+      const T* src = static_cast<const T*>(a.W) + (int64_t)(n0 + row) * a.K + kcol + swz_chunk4(row, p) * 8;
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(wbase + (wave * W_INSTR + t) * 1024), 16, 0, 0);
     }
   }
@@ -223,8 +241,7 @@ struct GemmKernel {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][j], fw[cur][i], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][i], fa[cur][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = TRANS ? Half<T>::mfma(fa[cur][j], fw[cur][i], acc[i][j]) : Half<T>::mfma(fw[cur][i], fa[cur][j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -261,7 +278,7 @@ struct GemmKernel {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int c = L.lane + 64 * k;
-          rs[i][j][k] = *reinterpret_cast<const bf16x4*>(a.resid_bf16 + out_offset<false>(a, m0, n0, L, j, c >> 3, i * 32 + (c & 7) * 4));
+          rs[i][j][k] = *reinterpret_cast<const bf16x4*>(static_cast<const T*>(a.resid_bf16) + out_offset<false>(a, m0, n0, L, j, c >> 3, i * 32 + (c & 7) * 4));
         }
   }
 
@@ -318,9 +335,9 @@ struct GemmKernel {
             const int c = L.lane + 64 * k, row = c >> 3, ch = c & 7;
             const float4 x = *reinterpret_cast<const float4*>(wl + row * 128 + ((ch ^ (row & 7)) << 4));
             const bf16x4 r4 = rs[kResid ? i : 0][kResid ? j : 0][k];
-            const bf16x4 o = {(__bf16)(x.x + (float)r4[0]), (__bf16)(x.y + (float)r4[1]), (__bf16)(x.z + (float)r4[2]),
-                              (__bf16)(x.w + (float)r4[3])};  // fp32 sum, ONE rounding
-            *reinterpret_cast<bf16x4*>(a.out_bf16 + out_offset<false>(a, m0, n0, L, j, row, i * 32 + ch * 4)) = o;
+            const bf16x4 o = {(T)(x.x + (float)r4[0]), (T)(x.y + (float)r4[1]), (T)(x.z + (float)r4[2]),
+                              (T)(x.w + (float)r4[3])};  // fp32 sum, ONE rounding
+            *reinterpret_cast<bf16x4*>(static_cast<T*>(a.out_bf16) + out_offset<false>(a, m0, n0, L, j, row, i * 32 + ch * 4)) = o;
           }
           asm volatile("" ::: "memory");  // next round's writes stay behind these reads (DS ops of a wave execute in order)
         }
@@ -329,8 +346,8 @@ struct GemmKernel {
       constexpr int RB = TRANS ? TN : TM;            // 32-row blocks of the staged orientation
       constexpr int CB = TRANS ? TM : TN;            // 32-column blocks
       constexpr int CP = (CB % 2 == 0) ? 2 : 1;      // column blocks per round
-      __bf16* base = a.out_bf16;
-      if (EPI == kEpiQkv) base = TRANS ? a.out_vt : (n0 < a.H ? a.out_bf16 : a.out_k);
+      T* base = static_cast<T*>(a.out_bf16);
+      if (EPI == kEpiQkv) base = static_cast<T*>(TRANS ? a.out_vt : (n0 < a.H ? a.out_bf16 : a.out_k));
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -343,7 +360,7 @@ struct GemmKernel {
             for (int g4 = 0; g4 < 4; ++g4) {
               float v[4];
               finish(i, j, g4, v);
-              const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              const bf16x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
               *reinterpret_cast<bf16x4*>(wl + L.l31 * 128 + (((4 * cc + g4) ^ swz) << 4) + L.half * 8) = o;
             }
           }
@@ -419,9 +436,9 @@ struct GemmKernel {
 // Persistent kernel: grid = min(#tiles, #CUs) blocks of one workgroup per CU.  Hardware block b runs on XCD b % 8
 // (observed, used for speed only): every XCD gets one contiguous range of tiles (n fastest) which its resident
 // blocks walk in lock-step order, so blocks that share an activation panel / weight tile hit the same L2.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, typename T>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmArgs a) {
-  using G = GemmKernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+  using G = GemmKernel<BM, BN, WAVES_M, WAVES_N, EPI, T>;
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
   G::run(a, gemm_lds);
 }

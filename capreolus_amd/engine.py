@@ -173,10 +173,15 @@ class BertEngine:
     weight blob is rebuilt whenever any parameter's version counter or storage changes.
     """
 
-    def __init__(self, params, heads, microbatch=256):
+    COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
+
+    def __init__(self, params, heads, microbatch=256, compute_dtype="bf16"):
+        if compute_dtype not in self.COMPUTE_DTYPES:
+            raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
         self.params = params
         self.heads = heads
         self.microbatch = microbatch
+        self.compute_dtype = compute_dtype
         self._key = None
         self._blob = self._lf32 = self._ws = None
         self._model = None
@@ -192,11 +197,12 @@ class BertEngine:
         m.vocab = p["bert.embeddings.word_embeddings.weight"].shape[0]
         m.max_pos = p["bert.embeddings.position_embeddings.weight"].shape[0]
         m.type_vocab = p["bert.embeddings.token_type_embeddings.weight"].shape[0]
+        m.compute_dtype = self.COMPUTE_DTYPES[self.compute_dtype]
         return m
 
     def model(self):
         p = self.params
-        key = tuple((t.data_ptr(), t._version) for t in p.values())
+        key = tuple((t.data_ptr(), t._version) for t in p.values()) + (self.compute_dtype,)
         if key == self._key:
             return self._model
         lib = _lib.load()

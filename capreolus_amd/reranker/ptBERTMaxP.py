@@ -93,7 +93,8 @@ class PTBERTMaxP_Class(nn.Module):
         B = doc_input.shape[0]
         if self._engine is None:
             self._engine = engine.BertEngine(self._params(), self.bert.num_attention_heads,
-                                             microbatch=int(self.config.get("microbatch", 256)))
+                                             microbatch=int(self.config.get("microbatch", 256)),
+                                             compute_dtype=self.config.get("compute_dtype", "bf16"))
         else:
             self._engine.params = self._params()
         shape = (B, P, S)
@@ -105,7 +106,10 @@ class PTBERTMaxP(Reranker):
     (reference ptBERTMaxP.py:99-122)."""
 
     module_name = "ptBERTMaxP"
-    config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256}
+    # the first three are the reference's options (ptBERTMaxP.py:114-122); microbatch / compute_dtype belong to this engine:
+    # compute_dtype "bf16" (default) or "fp16" (the type the reference's amp=pred autocast uses; ~8x smaller rounding error)
+    config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256,
+                   "compute_dtype": "bf16"}
 
     def build_model(self):
         self.model = PTBERTMaxP_Class(self.extractor, self.config)

@@ -113,6 +113,8 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S in {64, 128, 256}. */
 typedef struct capamd_bert_model {
   int hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
+  int compute_dtype;      /* 16-bit operand/activation type: 0 = bf16 (default), 1 = fp16 (the reference's amp autocast type;
+                             ~8x smaller rounding error, same MFMA rate, narrower range) */
   const float* word_emb;  /* [vocab, hidden]      bert.embeddings.word_embeddings.weight */
   const float* pos_emb;   /* [max_pos, hidden]    bert.embeddings.position_embeddings.weight */
   const float* type_emb;  /* [type_vocab, hidden] bert.embeddings.token_type_embeddings.weight */
@@ -146,11 +148,11 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                              int* status, void* stream);
 
 /* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
- * the reference calls at ptBERTMaxP.py:82).  bf16 operands, fp32 accumulation.
+ * the reference calls at ptBERTMaxP.py:82).  16-bit (bf16 or fp16) operands, fp32 accumulation.
  * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;
  * 4: + resid[M,N] (bf16), bf16 out (fp32 sum, one rounding).  M, N, K multiples of 64. */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
-                     const void* resid, void* out, void* stream);
+                     const void* resid, void* out, int dtype /* 0 bf16, 1 fp16 */, void* stream);
 /* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.
  * q, k: bf16 [n_passages*S, hidden]; vt: bf16 [n_passages*heads, 64, S]; ctx: bf16 [n_passages*S, hidden];
  * mask int64 [n_passages, S]. */
@@ -158,7 +160,7 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
  * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off (the default). */
 void capamd_debug_set_gemm_stamps(void* stamps);
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
-                              int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, void* stream);
+                              int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ for name, N, K, epi in shapes:
     for i in range(13):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st) == 0
+        assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), 0, st) == 0
         e1.record()
         torch.cuda.synchronize()
         if i >= 3:

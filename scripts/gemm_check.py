@@ -15,7 +15,7 @@ for (M, N, K) in [(64,64,64),(64,64,128),(64,64,192),(64,64,256),(128,192,320),(
         errs = []
         for rep in range(3):
             out.zero_()
-            assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st) == 0
+            assert lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), 0, st) == 0
             ref = A.float() @ W.float().t() + bias + (resid.float() if epi == 4 else 0)
             errs.append(float((out.float() - ref).abs().max()))
         print(M, N, K, "epi", epi, "max abs err", ["%.3g" % e for e in errs])

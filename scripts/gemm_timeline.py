@@ -14,9 +14,9 @@ for name, N, K, epi in [("qkv-like", 2304, 768, 0), ("ffn1", 3072, 768, 1), ("op
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     stamps = torch.zeros((256, 32), dtype=torch.int64, device=dev)
     for _ in range(2):
-        lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st)
+        lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), 0, st)
     lib.capamd_debug_set_gemm_stamps(vp(stamps))
-    lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), st)
+    lib.capamd_bert_gemm(vp(A), vp(W), vp(bias), M, N, K, epi, vp(resid), vp(out), 0, st)
     torch.cuda.synchronize()
     lib.capamd_debug_set_gemm_stamps(None)
     s = stamps.cpu().numpy()
