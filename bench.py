@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=300)
     ap.add_argument("--uniform-ids", action="store_true", help="uniform instead of Zipf(1.1) term ids (HBM-bound case)")
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
-    ap.add_argument("--bert-dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit operand type of the BERT encoder")
+    ap.add_argument("--bert-dtype", default="fp16", choices=["bf16", "fp16"], help="16-bit operand type of the BERT encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()

@@ -175,7 +175,7 @@ class BertEngine:
 
     COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
 
-    def __init__(self, params, heads, microbatch=256, compute_dtype="bf16"):
+    def __init__(self, params, heads, microbatch=256, compute_dtype="fp16"):
         if compute_dtype not in self.COMPUTE_DTYPES:
             raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
         self.params = params

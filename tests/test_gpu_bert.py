@@ -19,8 +19,8 @@ DEV = "cuda:0"
 # the fp32 residual stream; the north-star 1e-3 is met by fp32, not by a bf16 MFMA path (SURVEY.md §7
 # "BERT parity in bf16": gate on rank order + a documented looser tolerance).
 BF16_E2E_TOL = 1e-2
-# fp16 operands (11 significant bits): observed <= ~1e-3; this is the mode that meets the north-star 1e-3
-FP16_E2E_TOL = 2e-3
+# fp16 operands (11 significant bits), the engine default: observed <= 7e-4 -> the north-star 1e-3 holds
+FP16_E2E_TOL = 1e-3
 TDT = {"bf16": (torch.bfloat16, 0, 2 ** -7), "fp16": (torch.float16, 1, 2 ** -10)}
 
 
@@ -87,7 +87,7 @@ def test_qkv_attention_vs_torch(S, hidden, heads, npsg, dt):
     torch.testing.assert_close(ctx.float(), ref, rtol=2e-2 if dt == "bf16" else 3e-3, atol=atol)  # P is rounded to 16 bits before PV
 
 
-def _model(c, agg, dt="bf16"):
+def _model(c, agg, dt="fp16"):
     pre = dict(hidden=c["hidden"], layers=c["layers"], heads=c["heads"], ffn=c["ffn"], vocab=c["vocab"], max_pos=c["max_pos"])
     B, P, S = c["pos_bert_input"].shape
     r = PTBERTMaxP({"pretrained": pre, "aggregation": agg, "compute_dtype": dt}, SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
