@@ -408,8 +408,10 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
     return CAPAMD_ERR_ARG;
   const int H = m->hidden, F = m->ffn;
   const int64_t NP = (int64_t)B * P;
-  int64_t mb = passages_per_microbatch < NP ? passages_per_microbatch : NP;
-  if (mb < 1) return CAPAMD_ERR_ARG;
+  if (passages_per_microbatch < 1) return CAPAMD_ERR_ARG;
+  // equal-sized micro-batches (4000 passages at a cap of 256 -> 16 x 250, not 15 x 256 + 160: no ragged last pass)
+  const int64_t n_mb = (NP + passages_per_microbatch - 1) / passages_per_microbatch;
+  const int64_t mb = (NP + n_mb - 1) / n_mb;
   if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
