@@ -46,6 +46,7 @@ struct DrmmArgs {
   float* out;
   int32_t* counts_out;
   int* status;
+  float* feat_out;  // optional [B, Q, nbins+1]: the histogram features after CH/NH/LCH (input of the feed-forward net)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -165,6 +166,8 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
       } else if (a.hist_type == 2) {                       // LCH (DRMM.py:75-76)
         hv = lane < NB ? logf(hv) : 0.f;
       }
+      if (a.feat_out && lane < NB) a.feat_out[((int64_t)b * a.Q + q) * NB + lane] = hv;
+      if (a.out) {  // (feature call: the net / gate run under autograd on the host side -- training step, row N3)
       // ffw (DRMM.py:25): lane n holds node n
       float acc = lane < a.nodes ? a.b1[lane] : 0.f;
       for (int i = 0; i < NB; ++i) {
@@ -189,11 +192,12 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
         zlds[q] = tanhf(o);
         glds[q] = gl;
       }
+      }
     }
     __syncthreads();
   }
 
-  if (tid == 0) {  // softmax gate + output layer (DRMM.py:97-98, :112-114)
+  if (tid == 0 && a.out) {  // softmax gate + output layer (DRMM.py:97-98, :112-114)
     float m = glds[0];
     for (int q = 1; q < a.Q; ++q) m = fmaxf(m, glds[q]);
     float den = 0.f, num = 0.f;
@@ -221,7 +225,7 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   if (gate_type == 1 && (!emb_raw || ld < D)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   DrmmArgs a{ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
-             w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status};
+             w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status, nullptr};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
@@ -249,6 +253,30 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   return drmm_launch(ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld, w1, b1, nodes, w2,
                      b2, out_w, out_b, out, counts_out, status, stream);
+}
+
+extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                    int D, const float* edges, int nbins, int hist_type, float* feat_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !edges || !feat_out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (nbins < 1 || nbins + 1 > kMaxBins || hist_type < 0 || hist_type > 2 || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
+             nullptr, nullptr, nullptr, nullptr, status, feat_out};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1, 2, false, 3); break;
+    case 2: LAUNCH(2, 2, false, 3); break;
+    case 3: LAUNCH(3, 2, false, 3); break;
+    case 4: LAUNCH(4, 2, false, 3); break;
+    default: LAUNCH(5, 1, true, 6); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 extern "C" int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const float* idf_table,

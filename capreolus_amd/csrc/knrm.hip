@@ -45,20 +45,27 @@ struct KnrmArgs {
   const float* w2;
   const float* b2;
   int scoretanh;
-  float* out;
+  float* out;       // [B] scores (may be NULL for the feature/gradient call)
   int* status;
+  float* feat;      // GRAD: [B, K] kernel-pooling features f_k (the input of `combine`)
+  float* dfdmu;     // GRAD: [B, K] d f_k / d mu_k      (may be NULL)
+  float* dfdsigma;  // GRAD: [B, K] d f_k / d sigma_k   (may be NULL)
 };
 
-template <int NV, int U, bool QLDS, int MINW>
+// GRAD additionally accumulates sum_j K (s - mu) and sum_j K (s - mu)^2, which give d f_k / d mu_k and d f_k / d sigma_k
+// (RbfKernel parameters are trainable when `gradkernels`, reference common.py:229-230 / KNRM.py:22): the forward half
+// of the training step; `combine` then runs under autograd on the [B, K] features.
+template <int NV, int U, bool QLDS, int MINW, bool GRAD = false>
 __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a) {
+  constexpr int PS = GRAD ? 12 : 4;  // floats per lane in the cross-group reduction buffer
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // carve: tok[L] | partial[16][16][4] | S/aux
   int* tok = reinterpret_cast<int*>(smem_raw);
   const int tok_cap = (a.L + 3) & ~3;
-  float* partial = reinterpret_cast<float*>(tok + tok_cap);      // 1024 floats
-  float* Rlds = partial + kGroupsPerWG * kGroup * 4;             // 48
-  float* Flds = Rlds + 48;                                       // kMaxK (+pad to 16)
-  float* Hlds = Flds + 16;                                       // kMaxHidden
+  float* partial = reinterpret_cast<float*>(tok + tok_cap);      // 256 lanes x PS floats
+  float* Rlds = partial + kGroupsPerWG * kGroup * PS;            // 48 (x3 with GRAD)
+  float* Flds = Rlds + 48 * 3;                                   // kMaxK (+pad to 16) x3: f, df/dmu, df/dsigma
+  float* Hlds = Flds + 48;                                       // kMaxHidden
   int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // 4 (+4 spare)
   int* n_one = wave_cnt + 8;                                     // kQT per pass (+4 spare)
   float4* qlds = reinterpret_cast<float4*>(n_one + 8);           // QLDS: [kQT][NV*16] float4
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
     mu_s[s] = k < a.K ? a.mu[k] : 0.f;
     c_s[s] = k < a.K ? (-0.5f * kLog2e) / (sg * sg) : 0.f;
   }
-  if (tid < 16) Flds[tid] = 0.f;
+  if (tid < 48) Flds[tid] = 0.f;
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     QueryPass<NV> qp;
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
     }
 
     float acc[3] = {0.f, 0.f, 0.f};
+    float acc1[3] = {0.f, 0.f, 0.f}, acc2[3] = {0.f, 0.f, 0.f};  // GRAD: sum K*adj, sum K*adj^2
     float rowsum = 0.f;
     for (int t0 = g; t0 < n_real; t0 += U * kGroupsPerWG) {
       RowRegs<NV> d[U];
@@ -151,39 +159,83 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 #pragma unroll
           for (int s = 0; s < 3; ++s) {
             const float adj = x[u] - mu_s[s];
-            acc[s] += __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+            const float kv = __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
+            acc[s] += kv;
+            if (GRAD) {
+              acc1[s] = __builtin_fmaf(kv, adj, acc1[s]);
+              acc2[s] = __builtin_fmaf(kv * adj, adj, acc2[s]);
+            }
           }
         }
     }
 
     // ---- phase 3: fixed-order cross-group reduction ---------------------------------------
-    *reinterpret_cast<float4*>(partial + (g * kGroup + lane16) * 4) = make_float4(acc[0], acc[1], acc[2], rowsum);
+    {
+      float* pl = partial + (g * kGroup + lane16) * PS;
+      *reinterpret_cast<float4*>(pl) = make_float4(acc[0], acc[1], acc[2], rowsum);
+      if (GRAD) {
+        *reinterpret_cast<float4*>(pl + 4) = make_float4(acc1[0], acc1[1], acc1[2], 0.f);
+        *reinterpret_cast<float4*>(pl + 8) = make_float4(acc2[0], acc2[1], acc2[2], 0.f);
+      }
+    }
     __syncthreads();
     if (tid < 48) {
       const int q = tid & 3, kk = tid >> 2;
       const int src_lane = (kk & 3) * 4 + q, slot = kk >> 2;
-      float s = 0.f, rs = 0.f;
+      float s = 0.f, rs = 0.f, s1 = 0.f, s2 = 0.f;
       for (int gg = 0; gg < kGroupsPerWG; ++gg) {
-        s += partial[(gg * kGroup + src_lane) * 4 + slot];
-        rs += partial[(gg * kGroup + q) * 4 + 3];
+        s += partial[(gg * kGroup + src_lane) * PS + slot];
+        rs += partial[(gg * kGroup + q) * PS + 3];
+        if (GRAD) {
+          s1 += partial[(gg * kGroup + src_lane) * PS + 4 + slot];
+          s2 += partial[(gg * kGroup + src_lane) * PS + 8 + slot];
+        }
       }
-      float R = 0.f;
+      float R = 0.f, Rmu = 0.f, Rsg = 0.f;
       if (kk < a.K) {
         const float mk = a.mu[kk], sg = a.sigma[kk];
         const float ck = (-0.5f * kLog2e) / (sg * sg);
         const int no = n_one[q];
         const int nz = n_nonreal - no;
-        s += (float)nz * __builtin_amdgcn_exp2f(mk * mk * ck);
-        s += (float)no * __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * ck);
+        const float k0 = __builtin_amdgcn_exp2f(mk * mk * ck), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * ck);
+        s += (float)nz * k0;
+        s += (float)no * k1;
         rs += (float)no;
         // KNRM.py:51-52: mask = (sum_j sim != 0); where(mask, log(result + 1e-6), 0)
-        R = (rs != 0.f) ? logf(s + 1e-6f) : 0.f;
+        const bool on = rs != 0.f;
+        R = on ? logf(s + 1e-6f) : 0.f;
+        if (GRAD && on) {
+          s1 += (float)nz * k0 * (-mk) + (float)no * k1 * (1.f - mk);
+          s2 += (float)nz * k0 * mk * mk + (float)no * k1 * (1.f - mk) * (1.f - mk);
+          const float inv = 1.f / (s + 1e-6f);
+          Rmu = s1 / (sg * sg) * inv;        // d/dmu    exp(-(s-mu)^2 / (2 sigma^2)) = K (s-mu) / sigma^2
+          Rsg = s2 / (sg * sg * sg) * inv;   // d/dsigma                              = K (s-mu)^2 / sigma^3
+        }
       }
       Rlds[tid] = R;
+      if (GRAD) {
+        Rlds[48 + tid] = Rmu;
+        Rlds[96 + tid] = Rsg;
+      }
     }
     __syncthreads();
-    if (tid < kMaxK) Flds[tid] += ((Rlds[tid * 4 + 0] + Rlds[tid * 4 + 1]) + Rlds[tid * 4 + 2]) + Rlds[tid * 4 + 3];
+    if (tid < kMaxK) {
+      Flds[tid] += ((Rlds[tid * 4 + 0] + Rlds[tid * 4 + 1]) + Rlds[tid * 4 + 2]) + Rlds[tid * 4 + 3];
+      if (GRAD) {
+        Flds[16 + tid] += ((Rlds[48 + tid * 4 + 0] + Rlds[48 + tid * 4 + 1]) + Rlds[48 + tid * 4 + 2]) + Rlds[48 + tid * 4 + 3];
+        Flds[32 + tid] += ((Rlds[96 + tid * 4 + 0] + Rlds[96 + tid * 4 + 1]) + Rlds[96 + tid * 4 + 2]) + Rlds[96 + tid * 4 + 3];
+      }
+    }
     __syncthreads();
+  }
+
+  if (GRAD) {
+    if (tid < a.K) {
+      a.feat[(int64_t)b * a.K + tid] = Flds[tid];
+      if (a.dfdmu) a.dfdmu[(int64_t)b * a.K + tid] = Flds[16 + tid];
+      if (a.dfdsigma) a.dfdsigma[(int64_t)b * a.K + tid] = Flds[32 + tid];
+    }
+    if (!a.out) return;
   }
 
   // ---- combine (KNRM.py:27-34, :54) ----------------------------------------------------------
@@ -220,8 +272,8 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
   if (B < 0 || Q < 1 || L < 1 || V < 1 || K < 1 || K > kMaxK || hidden < 0 || hidden > kMaxHidden) return CAPAMD_ERR_ARG;
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
-  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 48 + 16 + kMaxHidden + 8 + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, nullptr, nullptr, nullptr};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (1024 + 144 + 48 + kMaxHidden + 8 + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
@@ -264,6 +316,31 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
   if (!q_ids || !d_ids) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   return knrm_launch(ids, B, Q, L, packed, V, D, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, stream);
+}
+
+extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                    int D, const float* mu, const float* sigma, int K, float* feat_out, float* dfdmu_out,
+                                    float* dfdsigma_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !mu || !sigma || !feat_out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || K < 1 || K > kMaxK) return CAPAMD_ERR_ARG;
+  if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
+             dfdsigma_out};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (3072 + 144 + 48 + kMaxHidden + 8 + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+#define LAUNCH(NV_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, 1, true, 4, true>), dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(5); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 extern "C" int capamd_knrm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,

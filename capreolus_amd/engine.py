@@ -296,3 +296,58 @@ def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V,
     if check:
         st.raise_if_set()
     return out
+
+
+def knrm_features(query, doc, packed, V, D, mu, sigma, need_grad=True, check=True):
+    """capamd_knrm_features: kernel-pooling features [B, K] and d f/d mu, d f/d sigma [B, K] (None when not needed)."""
+    _need_gpu(query, doc, packed, mu, sigma)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L, K = d.shape[1], mu.numel()
+    feat = torch.empty((B, K), dtype=torch.float32, device=q.device)
+    dmu = torch.empty_like(feat) if need_grad else None
+    dsg = torch.empty_like(feat) if need_grad else None
+    st = status_word(q.device)
+    rc = _lib.load().capamd_knrm_features(_ptr(q), _ptr(d), B, Q, L, _ptr(packed), V, D, _ptr(mu), _ptr(sigma), K, _ptr(feat),
+                                          _ptr(dmu), _ptr(dsg), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_knrm_features")
+    if check:
+        st.raise_if_set()
+    return feat, dmu, dsg
+
+
+class KnrmFeatures(torch.autograd.Function):
+    """features = f(query, doc; mu, sigma) with the HIP kernel supplying both the value and the two Jacobian diagonals
+    (f_k depends on mu_k / sigma_k only), so `combine` and the loss can sit on top of it under autograd."""
+
+    @staticmethod
+    def forward(ctx, mu, sigma, query, doc, packed, V, D):
+        need = mu.requires_grad or sigma.requires_grad
+        feat, dmu, dsg = knrm_features(query, doc, packed, V, D, mu.detach().float().contiguous(), sigma.detach().float().contiguous(),
+                                       need_grad=need)
+        if need:
+            ctx.save_for_backward(dmu, dsg)
+        ctx.has = need
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.has:
+            return (None,) * 7
+        dmu, dsg = ctx.saved_tensors
+        return (g * dmu).sum(0), (g * dsg).sum(0), None, None, None, None, None
+
+
+def drmm_features(query, doc, packed, V, D, edges, hist_type, check=True):
+    """capamd_drmm_features: matching-histogram features [B, Q, nbins+1] (no trainable inputs)."""
+    _need_gpu(query, doc, packed, edges)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    feat = torch.empty((B, Q, edges.numel() + 1), dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    rc = _lib.load().capamd_drmm_features(_ptr(q), _ptr(d), B, Q, d.shape[1], _ptr(packed), V, D, _ptr(edges), edges.numel(),
+                                          HIST_TYPES[hist_type], _ptr(feat), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmm_features")
+    if check:
+        st.raise_if_set()
+    return feat

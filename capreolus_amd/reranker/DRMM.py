@@ -48,10 +48,7 @@ class DRMM_class(nn.Module):
 
     def forward(self, sentence, query_sentence, query_idf, counts_out=None):
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError(
-                "capreolus_amd scores with hand-written inference kernels; the training step is not part of this "
-                "engine yet. Call under model.eval() / torch.no_grad() as PytorchTrainer.predict does."
-            )
+            return self._forward_train(sentence, query_sentence, query_idf)
         w = self.embedding.weight
         packed = self._packed.get(w)
         out = engine.drmm_forward(
@@ -60,6 +57,24 @@ class DRMM_class(nn.Module):
             self.ffw[0].bias.detach(), self.ffw[2].weight.detach().contiguous().view(-1), self.ffw[2].bias.detach(),
             self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), counts_out=counts_out)
         return out.view(-1, 1)
+
+    def _forward_train(self, sentence, query_sentence, query_idf):
+        """Training step: the matching histogram (everything that touches [B, Q, L]) is the HIP kernel and has no
+        trainable inputs (DRMM.py:22 freezes the embedding); the 30 -> 5 -> 1 net, the gate and the output layer --
+        a few hundred flops per pair -- stay under autograd (DRMM.py:106-114)."""
+        w = self.embedding.weight
+        if (query_sentence < 0).any():
+            raise IndexError("index out of range in self: DRMM cannot score an OOV (negative) query term id")
+        feats = engine.drmm_features(query_sentence, sentence, self._packed.get(w), w.shape[0], w.shape[1], self._bin_edges(w.device),
+                                     self.hist_type)
+        z = self.ffw(feats).squeeze(-1)                                    # [B, Q]
+        qmask = (query_sentence != 0).float()
+        if self.gate_type == "IDF":
+            gl = self.gates(query_idf.float().unsqueeze(-1)).squeeze(-1)
+        else:
+            gl = self.gates(w[query_sentence.clamp(min=0)]).squeeze(-1)
+        g = torch.softmax(gl + (1 - qmask) * -1e7, dim=1)
+        return self.output_layer((g * z).sum(dim=-1, keepdim=True))
 
     def forward_indexed(self, store, pair_q, pair_d):
         """Scores (query row, document row) pairs of a device-resident `CandidateStore` -> [B]."""

@@ -57,10 +57,7 @@ class KNRM_class(nn.Module):
     def forward(self, doctoks, querytoks, query_idf=None):
         """[B, 1] scores.  query_idf is accepted and ignored, as in the reference (KNRM.py:39)."""
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError(
-                "capreolus_amd scores with hand-written inference kernels; the training step (forward+backward) "
-                "is not part of this engine yet. Call under model.eval() / torch.no_grad() as PytorchTrainer.predict does."
-            )
+            return self._forward_train(doctoks, querytoks)
         w = self.embedding.weight
         packed = self._packed.get(w)
         mu, sigma = self.kernels.stacked()
@@ -73,6 +70,19 @@ class KNRM_class(nn.Module):
             querytoks, doctoks, packed, w.shape[0], w.shape[1], mu, sigma, lin1.weight.detach().contiguous(),
             lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"])
         return out.view(-1, 1)
+
+    def _forward_train(self, doctoks, querytoks):
+        """Training step (reference trainer/pytorch.py:96-99 -> KNRM.score): the gather / interaction / kernel pooling --
+        everything that touches the [B, Q, L] tensors -- is the HIP kernel (capamd_knrm_features, which also returns
+        d f/d mu and d f/d sigma); the 11 -> 1 `combine` and the loss stay under autograd on the [B, 11] features."""
+        if self.embedding.weight.requires_grad:
+            raise NotImplementedError("finetune=True (gradients into the embedding table) is not supported by the MI355X engine")
+        w = self.embedding.weight
+        packed = self._packed.get(w)
+        mu = torch.stack([k.mu for k in self.kernels.kernels]).float()
+        sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
+        feats = engine.KnrmFeatures.apply(mu, sigma, querytoks, doctoks, packed, w.shape[0], w.shape[1])
+        return self.combine(feats)
 
     def forward_indexed(self, store, pair_q, pair_d):
         """Scores (query row, document row) pairs of a device-resident `CandidateStore` -> [B]."""

@@ -97,6 +97,76 @@ class PytorchTrainer:
         if c["amp"] not in (None, "train", "pred", "both"):
             raise ValueError("amp must be one of: None, train, pred, both")
 
+    # ---- training (reference trainer/pytorch.py:76-122, 189-300) -------------------------
+    @staticmethod
+    def pair_hinge_loss(pos_neg_scores):
+        """reference reranker/common.py:101-103: MarginRankingLoss(margin=1, reduction="mean") with target +1."""
+        pos, neg = pos_neg_scores
+        return torch.clamp(1.0 - (pos - neg), min=0).mean()
+
+    @staticmethod
+    def pair_softmax_loss(pos_neg_scores):
+        """reference reranker/common.py:96-98."""
+        scores = torch.stack(pos_neg_scores, dim=1)
+        return torch.mean(1.0 - scores.softmax(dim=1)[:, 0])
+
+    def single_train_iteration(self, reranker, train_dataloader):
+        """`itersize // batch` optimisation steps with gradient accumulation (reference :76-122)."""
+        n_batch_per_iter = max(1, self.config["itersize"] // self.config["batch"])
+        losses, since_update = [], 0
+        for bi, batch in enumerate(train_dataloader):
+            batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
+            loss = self.loss(reranker.score(batch))
+            losses.append(loss.detach())
+            loss.backward()
+            since_update += 1
+            if since_update == self.config["gradacc"]:
+                since_update = 0
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+            if (bi + 1) % n_batch_per_iter == 0:
+                break
+        return torch.stack(losses).mean()
+
+    def train(self, reranker, train_dataset, train_output_path, dev_data, dev_output_path, qrels, metric="ndcg_cut_20", relevance_level=1):
+        """Pairwise training with validation on `dev_data` every `validatefreq` iterations and `dev.best` checkpointing
+        (reference :189-300).  Metrics: trec_eval-style ndcg_cut_k from capreolus_amd.run_io (`metric` = "ndcg_cut_<k>").
+        Returns the list of per-iteration mean losses."""
+        from ..run_io import mean_ndcg_cut
+
+        if not metric.startswith("ndcg_cut_"):
+            raise ValueError("this trainer validates with ndcg_cut_<k>")
+        k = int(metric.rsplit("_", 1)[1])
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        model = reranker.model.to(self.device)
+        self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=self.config["lr"])
+        self.loss = self.pair_softmax_loss if self.config["softmaxloss"] else self.pair_hinge_loss
+        loader = torch.utils.data.DataLoader(train_dataset, batch_size=self.config["batch"], pin_memory=self.device.type == "cuda",
+                                             num_workers=1 if self.config["multithread"] else 0)
+        train_output_path, dev_output_path = os.fspath(train_output_path), os.fspath(dev_output_path)
+        os.makedirs(train_output_path, exist_ok=True)
+        os.makedirs(dev_output_path, exist_ok=True)
+        best, train_loss = -np.inf, []
+        for niter in range(1, self.config["niters"] + 1):
+            model.train()
+            train_loss.append(float(self.single_train_iteration(reranker, loader)))
+            if self.config["fastforward"]:
+                reranker.save_weights(os.path.join(train_output_path, "weights", f"{niter}.p"), self.optimizer)
+            if niter % self.config["validatefreq"] == 0:
+                preds = self.predict(reranker, dev_data, os.path.join(dev_output_path, f"{niter}.run"))
+                score = mean_ndcg_cut({q: {d: (r if r >= relevance_level else 0) for d, r in ds.items()} for q, ds in qrels.items()}, preds, k)
+                if score > best:
+                    best = score
+                    reranker.save_weights(os.path.join(train_output_path, "dev.best"), self.optimizer)
+            with open(os.path.join(train_output_path, "loss.txt"), "wt") as f:
+                f.write("\n".join(f"{i} {l}" for i, l in enumerate(train_loss)))
+        return train_loss
+
+    def load_best_model(self, reranker, train_output_path):
+        """reference :302-308."""
+        self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, reranker.model.parameters()), lr=self.config["lr"])
+        reranker.load_weights(os.path.join(os.fspath(train_output_path), "dev.best"), self.optimizer)
+
     def fill_incomplete_batch(self, batch, batch_size=None):
         """Repeat-pad a short final batch (reference trainer/pytorch.py:355-377)."""
         batch_size = batch_size or self.config["batch"]

@@ -72,6 +72,15 @@ int capamd_knrm_forward(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_ids /*[
                         const float* w1, const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
                         float* out, int* status, void* stream);
 
+/* Forward half of the training step (reference trainer/pytorch.py:96-99 -> KNRM.score):
+ * the kernel-pooling features f[b][k] = sum_q mask_q log(sum_j K_k(sim_qj) + 1e-6) (KNRM.py:50-53) that feed `combine`,
+ * and their derivatives w.r.t. the RbfKernel parameters (trainable when `gradkernels`).  The embedding is frozen
+ * (`finetune = False`, KNRM.py:23); `combine` and the loss run under autograd on these [B, K] tensors.
+ * dfdmu_out / dfdsigma_out may be NULL. */
+int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                         int D, const float* mu, const float* sigma, int K, float* feat_out, float* dfdmu_out,
+                         float* dfdsigma_out, int* status, void* stream);
+
 /* Same scoring from a device-resident candidate store (replaces the per-sample
  * PredSampler -> DataLoader collate -> .to(device) of capreolus/sampler/__init__.py:207-264 and
  * trainer/pytorch.py:334-342): the run's query / document id rows are uploaded ONCE as int32 tables
@@ -93,6 +102,12 @@ int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float*
                         int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
                         const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
                         const float* out_b, float* out, int32_t* counts_out, int* status, void* stream);
+
+/* Training-step forward half for DRMM: feat_out fp32 [B, Q, nbins+1] = the matching histogram after CH/NH/LCH
+ * (DRMM._hist_map, DRMM.py:41-81; it has no trainable inputs, the embedding is frozen at DRMM.py:22); the
+ * feed-forward net, gate and output layer run under autograd on it. */
+int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                         int D, const float* edges, int nbins, int hist_type, float* feat_out, int* status, void* stream);
 
 /* indexed variant (see capamd_knrm_forward_indexed); idf_table fp32 [NQ, Q] is indexed by the pair's query row */
 int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const float* idf_table,

@@ -156,6 +156,7 @@ def test_errors_surface_as_exceptions():
     with pytest.raises(RuntimeError):
         r.test({k: v.cpu() for k, v in _batch(c).items()})  # no CPU fallback
     r.model.train()
+    r.model.embedding.weight.requires_grad = True   # finetune=True: gradients into the table are not supported
     with pytest.raises(NotImplementedError):
         r.score({**_batch(c), "negdoc": _batch(c)["posdoc"]})
 
@@ -346,3 +347,125 @@ def test_predict_resident_ranklist():
     preds = PytorchTrainer({"evalbatch": 64}).predict_resident(r, store, q2d)
     got = np.array([preds["301"][f"d{i}"] for i in range(B)], dtype=np.float16)
     assert (got == c["ref_scores_f16"]).mean() > 0.98
+
+
+# ---- training step (row N3): HIP features + Jacobian diagonals vs autograd through the ATen port on CPU ----------
+def test_knrm_training_gradients_match_autograd():
+    from oracle import torch_port
+
+    c = load_case("knrm", "twolayer_tanh")
+    r = _knrm_model(c)
+    m = r.model
+    m.train()
+    q, d = _t(c["query"]), _t(c["posdoc"])
+    neg = d.roll(1, 0)
+    pos_s, neg_s = r.score({"query": q, "posdoc": d, "negdoc": neg, "query_idf": _t(c["query_idf"])})
+    loss = torch.clamp(1.0 - (pos_s - neg_s), min=0).mean() + 0.01 * pos_s.sum()
+    loss.backward()
+    # the same computation with plain ATen ops and autograd on the host
+    emb = torch.as_tensor(c["emb"])
+    mu, sigma, w1, b1, w2, b2 = (torch.as_tensor(x).clone().requires_grad_(True) for x in knrm_weights(c))
+    qc, dc = torch.as_tensor(c["query"]), torch.as_tensor(c["posdoc"])
+    ps = torch_port.knrm(emb, qc, dc, mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
+    ns = torch_port.knrm(emb, qc, dc.roll(1, 0), mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
+    ref_loss = torch.clamp(1.0 - (ps - ns), min=0).mean() + 0.01 * ps.sum()
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+    got_mu = torch.stack([k.mu.grad for k in m.kernels.kernels]).cpu()
+    got_sg = torch.stack([k.sigma.grad for k in m.kernels.kernels]).cpu()
+    scale = lambda t: float(t.abs().max()) + 1e-8  # noqa: E731
+    assert (got_mu - mu.grad).abs().max() <= 2e-3 * scale(mu.grad), (got_mu, mu.grad)
+    assert (got_sg - sigma.grad).abs().max() <= 2e-3 * scale(sigma.grad), (got_sg, sigma.grad)
+    assert (m.combine[0].weight.grad.cpu() - w1.grad).abs().max() <= 2e-3 * scale(w1.grad)
+    assert (m.combine[2].weight.grad.cpu() - w2.grad).abs().max() <= 2e-3 * scale(w2.grad)
+
+
+def test_drmm_training_step_matches_autograd():
+    """Histogram features from the HIP kernel == the C oracle's counts (bit exact); loss and gradients of the tiny net on
+    top of them == the same ATen ops under autograd on the host."""
+    c = load_case("drmm", "zero_idf")
+    r = _drmm_model(c)
+    m = r.model
+    m.train()
+    b = _batch(c)
+    negdoc = c["posdoc"][np.roll(np.arange(len(c["posdoc"])), 1)]
+    s = r.score({**b, "negdoc": _t(negdoc)})
+    loss = torch.clamp(1.0 - (s[0] - s[1]), min=0).mean() + 0.01 * s[0].sum()
+    loss.backward()
+    t = {k[3:]: torch.as_tensor(v).clone().requires_grad_(True) for k, v in c.items() if k.startswith("sd.")}
+    packed = oracle.pack(c["emb"])
+
+    def host_scores(doc):
+        _, counts, err = oracle.drmm(c["query"], doc, c["query_idf"], packed, int(c["D"]), c["edges"], "CH", "IDF", c["sd.gates.weight"], c["emb"],
+                                     c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.ffw.2.weight"], c["sd.ffw.2.bias"],
+                                     c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+        assert err == 0
+        feats = torch.log(torch.as_tensor(counts).float() + 1)                      # LCH (DRMM.py:71, :76)
+        z = torch.tanh(torch.tanh(feats @ t["ffw.0.weight"].t() + t["ffw.0.bias"]) @ t["ffw.2.weight"].t() + t["ffw.2.bias"]).squeeze(-1)
+        q = torch.as_tensor(c["query"])
+        gl = torch.as_tensor(c["query_idf"]) * t["gates.weight"].view(-1)[0] + (q == 0).float() * -1e7
+        return ((torch.softmax(gl, dim=1) * z).sum(1) * t["output_layer.weight"].view(-1)[0] + t["output_layer.bias"].view(-1)[0])
+
+    ps, ns = host_scores(c["posdoc"]), host_scores(negdoc)
+    ref = torch.clamp(1.0 - (ps - ns), min=0).mean() + 0.01 * ps.sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+    for name, mod in (("ffw.0.weight", m.ffw[0].weight), ("ffw.2.weight", m.ffw[2].weight), ("output_layer.weight", m.output_layer.weight)):
+        g, gr = mod.grad.cpu(), t[name].grad
+        assert (g - gr).abs().max() <= 2e-3 * (float(gr.abs().max()) + 1e-8), name
+
+
+def test_train_loop_reduces_loss_and_checkpoints(tmp_path):
+    """PytorchTrainer.train: a few iterations of pairwise training on a synthetic task where the positive document
+    contains the query terms; the loss must go down, dev.best must be written and reloadable."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    rs = np.random.RandomState(5)
+    V, L, Q = 600, 64, 4
+    emb = synthetic.make_embeddings(V, 50, seed=9)
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    r.build_model()
+    r.model.combine[0].weight.data.zero_()  # every pair scores the same at the start -> hinge loss exactly 1
+    queries = {str(q): rs.randint(1, V, size=Q) for q in range(12)}
+
+    def doc(qid, relevant):
+        d = rs.randint(1, V, size=L)
+        if relevant:
+            d[rs.choice(L, 6, replace=False)] = rs.choice(queries[qid], 6)
+        return d
+
+    class Train(torch.utils.data.IterableDataset):
+        def __iter__(self):
+            while True:
+                qid = str(rs.randint(0, 12))
+                yield {"query": torch.as_tensor(queries[qid]), "posdoc": torch.as_tensor(doc(qid, True)),
+                       "negdoc": torch.as_tensor(doc(qid, False)), "query_idf": torch.zeros(Q)}
+
+    docs = {(qid, f"d{i}"): doc(qid, i < 3) for qid in queries for i in range(10)}
+
+    class Dev(torch.utils.data.IterableDataset):
+        qid_to_docids = {qid: [f"d{i}" for i in range(10)] for qid in queries}
+
+        def __iter__(self):
+            for qid, ds in self.qid_to_docids.items():
+                for d in ds:
+                    yield {"qid": qid, "posdocid": d, "query": torch.as_tensor(queries[qid]), "posdoc": torch.as_tensor(docs[(qid, d)]),
+                           "query_idf": torch.zeros(Q)}
+
+        def __len__(self):
+            return 120
+
+        def get_qid_docid_pairs(self):
+            for qid, ds in self.qid_to_docids.items():
+                for d in ds:
+                    yield qid, d
+
+    qrels = {qid: {f"d{i}": int(i < 3) for i in range(10)} for qid in queries}
+    t = PytorchTrainer({"batch": 16, "itersize": 64, "niters": 6, "lr": 0.02, "evalbatch": 40})
+    losses = t.train(r, Train(), tmp_path / "train", Dev(), tmp_path / "dev", qrels, "ndcg_cut_20")
+    assert losses[0] > 0.1 and min(losses[1:]) < 0.2 * losses[0], losses  # starts at 1.0 per pair, separates within a few steps
+    assert (tmp_path / "train" / "dev.best").exists() and (tmp_path / "dev" / "6.run").exists()
+    before = r.model.combine[0].weight.detach().clone()
+    r.model.combine[0].weight.data.zero_()
+    t.load_best_model(r, tmp_path / "train")
+    assert torch.isfinite(r.model.combine[0].weight).all() and not torch.equal(r.model.combine[0].weight, torch.zeros_like(before))
