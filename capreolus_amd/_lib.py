@@ -41,6 +41,7 @@ SIGNATURES = {
     "capamd_pack_embeddings": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),
     "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_knrm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

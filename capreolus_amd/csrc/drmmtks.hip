@@ -1,0 +1,186 @@
+// Fused DRMM-TKS forward for gfx950 (a sibling model on the same fused front end).
+//
+// Reference semantics: DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64): SimilarityMatrix -> per query term
+// the top-k similarities over ALL document positions (pads contribute their 0) -> Linear(k, 1) + tanh -> IDF term gate
+// (softmax over query terms, pads masked with -1e7) -> output layer.
+//
+// Same work layout as knrm.hip / drmm.hip (one workgroup per pair, 16 lanes per document term, real terms compacted in
+// LDS, query rows in an LDS copy).  Back end: every lane keeps a sorted top-k of the similarities of the query term it
+// owns (compare-exchange chain in registers); the 16 groups' lists are merged by one wave per query term (k rounds of
+// a wave-wide arg-max over the list heads), together with the closed-form candidates of the terms that were never
+// gathered: n1 ones (OOV exact matches) and n0 zeros (pads and other OOV terms).
+#include "capreolus_amd.h"
+#include "interaction.cuh"
+
+using namespace capamd;
+
+namespace {
+
+constexpr int kMaxTopK = 16;
+constexpr int kMaxQ = 32;
+
+struct TksArgs {
+  IdSource ids;
+  const float* idf;
+  int B, Q, L;
+  const float* packed;
+  int64_t V;
+  int topk;
+  const float* gate_w;   // [1]  (IDF gate)
+  const float* ffw_w;    // [topk]
+  const float* ffw_b;    // [1]
+  const float* out_w;    // [1]
+  const float* out_b;    // [1]
+  float* out;
+  int* status;
+};
+
+template <int NV>
+__global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  const int tok_cap = (a.L + 3) & ~3;
+  float* lists = reinterpret_cast<float*>(tok + tok_cap);            // [16 groups][kQT][kMaxTopK]
+  float* zlds = lists + kGroupsPerWG * kQT * kMaxTopK;               // [kMaxQ]
+  float* glds = zlds + kMaxQ;                                        // [kMaxQ]
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);              // [4] (+4 spare)
+  int* n_one = wave_cnt + 8;                                         // [kQT] (+4 spare)
+  float4* qlds = reinterpret_cast<float4*>(n_one + 8);               // [kQT][NV*16] float4
+
+  const int tid = threadIdx.x, lane16 = tid & 15, g = tid >> 4, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x, K = a.topk;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+
+  int n_real = 0;
+  for (int base = 0; base < a.L; base += kThreads) {
+    const int j = base + tid;
+    int64_t did = (j < a.L) ? ids.d(j) : 0;
+    if (did >= a.V) {
+      atomicOr(a.status, kErrDocIdRange);
+      did = 0;
+    }
+    const bool real = did > 0;
+    const unsigned long long m = __ballot(real);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_real;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (real) tok[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)did;
+    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int n_nonreal = a.L - n_real;
+
+  for (int q0 = 0; q0 < a.Q; q0 += kQT) {
+    QueryPass<NV> qp;
+    load_query_pass_lds<NV>(a.packed, ids, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+    if (tid < kQT) n_one[tid] = 0;
+    __syncthreads();
+    {
+      bool any_oov_q = false;
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) any_oov_q |= qp.id[t] < 0;
+      if (any_oov_q)
+        for (int j = tid; j < a.L; j += kThreads) {
+          const int64_t did = ids.d(j);
+          if (did < 0) {
+#pragma unroll
+            for (int t = 0; t < kQT; ++t)
+              if (qp.id[t] == (int)did && did > -2147483648LL) atomicAdd(&n_one[t], 1);
+          }
+        }
+    }
+    // sorted (descending) top-k of this lane's query term over the terms its group visits
+    float top[kMaxTopK];
+#pragma unroll
+    for (int i = 0; i < kMaxTopK; ++i) top[i] = -INFINITY;
+    for (int t0 = g; t0 < n_real; t0 += kGroupsPerWG) {
+      RowRegs<NV> d[1];
+      load_row<NV>(a.packed, tok[t0], lane16, d[0]);
+      float x[1];
+      int qoff = 0;
+      asm volatile("" : "+v"(qoff));
+      rows_sim_my<NV, 1, true>(d, qp, qlds + qoff, lane16, x);
+      float v = x[0];
+#pragma unroll
+      for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
+        const float hi = fmaxf(top[i], v);
+        v = fminf(top[i], v);
+        top[i] = hi;
+      }
+    }
+    if (lane16 < kQT) {
+#pragma unroll
+      for (int i = 0; i < kMaxTopK; ++i) lists[(g * kQT + lane16) * kMaxTopK + i] = top[i];
+    }
+    __syncthreads();
+
+    // ---- merge: wave w owns query term q0 + w.  lanes 0..15: the groups' lists; lane 16: n1 ones; lane 17: n0 zeros
+    const int q = q0 + wave;
+    if (q < a.Q) {
+      const int no = n_one[wave], nz = n_nonreal - no;
+      int head = 0;
+      float acc = a.ffw_b[0];
+      for (int r = 0; r < K; ++r) {
+        float cand = -INFINITY;
+        if (lane < kGroupsPerWG) cand = head < kMaxTopK ? lists[(lane * kQT + wave) * kMaxTopK + head] : -INFINITY;
+        else if (lane == 16) cand = head < no ? 1.f : -INFINITY;
+        else if (lane == 17) cand = head < nz ? 0.f : -INFINITY;
+        float best = cand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+        const unsigned long long who = __ballot(cand == best && best > -INFINITY);
+        if (who == 0) break;  // fewer than k candidates (L < k): torch.topk would raise; the host checks L >= k
+        const int winner = __ffsll((long long)who) - 1;
+        if (lane == winner) ++head;
+        acc = __builtin_fmaf(a.ffw_w[r], best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+      }
+      if (lane == 0) {
+        zlds[q] = tanhf(acc);
+        float gl = a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q];
+        if (ids.q(q) == 0) gl += -1e7f;   // DRMMTKS.py:38
+        glds[q] = gl;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (tid == 0) {  // softmax gate + output layer (DRMMTKS.py:47-48, :60-62)
+    float m = glds[0];
+    for (int q = 1; q < a.Q; ++q) m = fmaxf(m, glds[q]);
+    float den = 0.f, num = 0.f;
+    for (int q = 0; q < a.Q; ++q) {
+      const float e = expf(glds[q] - m);
+      den += e;
+      num = __builtin_fmaf(e, zlds[q], num);
+    }
+    a.out[b] = __builtin_fmaf(a.out_w[0], num / den, a.out_b[0]);
+  }
+}
+
+}  // namespace
+
+extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
+                                      const float* packed, int64_t V, int D, int topk, const float* gate_w, const float* ffw_w,
+                                      const float* ffw_b, const float* out_w, const float* out_b, float* out, int* status,
+                                      void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !idf || !packed || !gate_w || !ffw_w || !ffw_b || !out_w || !out_b || !out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  TksArgs a{ids, idf, B, Q, L, packed, V, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out, status};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 16) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+#define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(5); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}

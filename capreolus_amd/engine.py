@@ -351,3 +351,22 @@ def drmm_features(query, doc, packed, V, D, edges, hist_type, check=True):
     if check:
         st.raise_if_set()
     return feat
+
+
+def drmmtks_forward(query, doc, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out=None, check=True):
+    """DRMMTKS_class.forward (reference DRMMTKS.py:50-64): fp32 [B]."""
+    _need_gpu(query, doc, idf, packed, gate_w, ffw_w, ffw_b, out_w, out_b)
+    q, d, idf = _i64(query), _i64(doc), _f32(idf)
+    B, Q = q.shape
+    L = d.shape[1]
+    if topk > L:
+        raise RuntimeError("selected index k out of range")  # what torch.topk raises at DRMMTKS.py:56
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    rc = _lib.load().capamd_drmmtks_forward(_ptr(q), _ptr(d), _ptr(idf), B, Q, L, _ptr(packed), V, D, int(topk), _ptr(gate_w), _ptr(ffw_w),
+                                            _ptr(ffw_b), _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmmtks_forward")
+    if check:
+        st.raise_if_set()
+    return out

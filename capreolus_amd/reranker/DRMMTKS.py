@@ -1,0 +1,59 @@
+"""DRMM-TKS behind the reference plugin surface (capreolus/reranker/DRMMTKS.py:68-110), scored by the fused gfx950
+kernel in capreolus_amd/csrc/drmmtks.hip through the C ABI (a sibling model that reuses the
+gather / similarity front end of KNRM and DRMM).  Parameter names follow the reference state_dict
+(``ffw.0.*``, ``gates.weight``, ``output_layer.*``, ``embedding.weight``)."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from . import Reranker
+
+
+class DRMMTKS_class(nn.Module):
+    def __init__(self, extractor, config):
+        super().__init__()
+        self.topk = config["topk"]
+        self.gate_type = config["gateType"]
+        if self.gate_type != "IDF":
+            raise NotImplementedError("DRMMTKS gateType=TV: the reference feeds integer ids to nn.Linear (DRMMTKS.py:42); only IDF is scored")
+        if not config["freezeemb"]:
+            raise NotImplementedError("freezeemb=False (gradients into the embedding table) is not supported by the MI355X engine")
+        weights = torch.as_tensor(np.asarray(extractor.embeddings, dtype=np.float32))
+        self.embedding = nn.Embedding(*weights.shape)
+        self.embedding.weight.data.copy_(weights)
+        self.embedding.weight.requires_grad = False
+        self.ffw = nn.Sequential(nn.Linear(self.topk, 1), nn.Tanh())
+        self.gates = nn.Linear(1, 1, bias=False)
+        self.output_layer = nn.Linear(1, 1)
+        nn.init.uniform_(self.ffw[0].weight, -0.1, 0.1)   # MatchZoo-style initialisation (DRMMTKS.py:28-30)
+        nn.init.uniform_(self.gates.weight, -0.01, 0.01)
+        self._packed = engine.PackedEmbedding()
+
+    def forward(self, doc, query, query_idf):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("the DRMMTKS training step is not part of the MI355X engine; score under model.eval()")
+        w = self.embedding.weight
+        out = engine.drmmtks_forward(query, doc, query_idf, self._packed.get(w), w.shape[0], w.shape[1], self.topk,
+                                     self.gates.weight.detach().view(-1), self.ffw[0].weight.detach().contiguous().view(-1),
+                                     self.ffw[0].bias.detach(), self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach())
+        return out.view(-1, 1)
+
+
+class DRMMTKS(Reranker):
+    """Guo et al., CIKM'16, MatchZoo's top-k variant (reference DRMMTKS.py:68-80)."""
+
+    module_name = "DRMMTKS"
+    config_spec = {"topk": 10, "gateType": "IDF", "freezeemb": True}
+
+    def build_model(self):
+        if not hasattr(self, "model"):
+            self.model = DRMMTKS_class(self.extractor, self.config)
+        return self.model
+
+    def score(self, d):
+        q, idf = d["query"], d["query_idf"]
+        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+
+    def test(self, d):
+        return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

@@ -67,6 +67,7 @@ class Reranker:
 from .KNRM import KNRM, KNRM_class  # noqa: E402,F401
 from .DRMM import DRMM, DRMM_class  # noqa: E402,F401
 
+from .DRMMTKS import DRMMTKS, DRMMTKS_class  # noqa: E402,F401
 from .ptBERTMaxP import PTBERTMaxP, PTBERTMaxP_Class  # noqa: E402,F401
 
-registry = {"KNRM": KNRM, "DRMM": DRMM, "ptBERTMaxP": PTBERTMaxP}
+registry = {"KNRM": KNRM, "DRMM": DRMM, "DRMMTKS": DRMMTKS, "ptBERTMaxP": PTBERTMaxP}

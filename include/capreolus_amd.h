@@ -117,6 +117,14 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
                                 int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
                                 float* out, int32_t* counts_out, int* status, void* stream);
 
+/* ---- DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64) behind DRMMTKS.test (:105-110) ------------------
+ * A sibling of DRMM on the same fused front end: per query term the top-k similarities over all
+ * L positions -> Linear(topk, 1) + tanh (ffw_w fp32 [topk], ffw_b [1]) -> IDF gate (gate_w [1]) -> output layer.
+ * topk <= 16, topk <= L, Q <= 32.  Only gateType = IDF (the reference's TV branch feeds integer ids to nn.Linear). */
+int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
+                           const float* packed, int64_t V, int D, int topk, const float* gate_w, const float* ffw_w,
+                           const float* ffw_b, const float* out_w, const float* out_b, float* out, int* status, void* stream);
+
 /* ---- PTBERTMaxP_Class.predict_step (capreolus/reranker/ptBERTMaxP.py:67-96) behind PTBERTMaxP.test
  * (ptBERTMaxP.py:134-135), including the transformers.BertForSequenceClassification forward it calls
  * at :82 (embeddings, 12 post-LN encoder layers, pooler, classifier, logit 1).

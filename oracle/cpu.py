@@ -98,3 +98,14 @@ def drmm(q_ids, d_ids, idf, packed, D, edges, hist_type, gate_type, gate_w, emb_
                             ctypes.c_int64(D), _p(w1), _p(b1), nodes, _p(w2), _p(b2), _p(out_w), _p(out_b), _p(out),
                             _p(counts))
     return out, counts, err
+
+
+def drmmtks(q_ids, d_ids, idf, packed, D, topk, gate_w, ffw_w, ffw_b, out_w, out_b):
+    q_ids, d_ids, idf = _i64(q_ids), _i64(d_ids), _f32(idf)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    gate_w, ffw_w, ffw_b, out_w, out_b = (_f32(x).reshape(-1) for x in (gate_w, ffw_w, ffw_b, out_w, out_b))
+    out = np.empty(B, dtype=np.float32)
+    err = lib().oracle_drmmtks(_p(q_ids), _p(d_ids), _p(idf), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D, int(topk),
+                               _p(gate_w), _p(ffw_w), _p(ffw_b), _p(out_w), _p(out_b), _p(out))
+    return out, err

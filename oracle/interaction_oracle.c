@@ -231,3 +231,46 @@ int oracle_drmm(const int64_t* q_ids, const int64_t* d_ids, const float* idf, in
   }
   return err;
 }
+
+/* DRMMTKS_class.forward (reranker/DRMMTKS.py:50-64): cos_mat = SimilarityMatrix(query, doc) (:55); topk over the last
+ * dimension, pads included (:56); ffw = tanh(Linear(topk, 1)) per query term (:22, :57); IDF term gate (:31-48);
+ * output layer (:61). */
+int oracle_drmmtks(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed, int64_t V,
+                   int D, int topk, const float* gate_w, const float* ffw_w, const float* ffw_b, const float* out_w, const float* out_b,
+                   float* out) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b) {
+    double z[64], gl[64];
+    float* sims = (float*)malloc(sizeof(float) * (size_t)L);
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      for (int j = 0; j < L; ++j) {
+        int64_t did = d_ids[(int64_t)b * L + j];
+        if (did >= V) { err |= 1; did = 0; }
+        sims[j] = sim_one(qid, did, packed, RS, NV);
+      }
+      double acc = ffw_b[0];
+      for (int r = 0; r < topk; ++r) { /* selection of the r-th largest */
+        int best = r;
+        for (int j = r + 1; j < L; ++j) if (sims[j] > sims[best]) best = j;
+        const float t = sims[r]; sims[r] = sims[best]; sims[best] = t;
+        acc += (double)ffw_w[r] * (double)sims[r];
+      }
+      z[q] = tanh(acc);
+      double g = (double)gate_w[0] * (double)idf[(int64_t)b * Q + q];
+      if (qid == 0) g += -1e7;
+      gl[q] = (double)(float)g;
+    }
+    free(sims);
+    double m = gl[0];
+    for (int q = 1; q < Q; ++q) if (gl[q] > m) m = gl[q];
+    double den = 0.0, num = 0.0;
+    for (int q = 0; q < Q; ++q) { const double e = exp(gl[q] - m); den += e; num += e * z[q]; }
+    out[b] = (float)((double)out_w[0] * (num / den) + (double)out_b[0]);
+  }
+  return err;
+}

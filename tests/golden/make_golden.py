@@ -163,13 +163,48 @@ def gen_drmm(DRMM):
         print("drmm", name, scores[:6], "n_ambiguous", n_amb.tolist())
 
 
+def gen_drmmtks(TKS):
+    cases = {
+        "default": dict(V=5000, D=300, B=24, Q=4, L=800, cfg=dict(topk=10, gateType="IDF", freezeemb=True)),
+        "top3_short": dict(V=800, D=50, B=16, Q=3, L=100, cfg=dict(topk=3, gateType="IDF", freezeemb=True)),
+        "ranklist": dict(V=20000, D=300, B=200, Q=4, L=800, cfg=dict(topk=10, gateType="IDF", freezeemb=True), same_query=True),
+    }
+    for name, c in cases.items():
+        seed = 300 + len(name)
+        rs = np.random.RandomState(seed)
+        emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
+        same = c.get("same_query", False)
+        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
+                                              query_oov_frac=0.0 if same else 0.1)
+        if not same:
+            batch = _edge_cases(rs, batch, c["V"])
+        torch.manual_seed(seed)
+        model = TKS.DRMMTKS_class(SimpleNamespace(embeddings=emb), dict(c["cfg"])).eval()
+        with torch.no_grad():
+            model.gates.weight.mul_(30.0)
+            model.ffw[0].weight.mul_(8.0)
+        q, d = torch.from_numpy(batch["query"]), torch.from_numpy(batch["posdoc"])
+        with torch.no_grad():
+            scores = model(d, q, torch.from_numpy(batch["query_idf"])).view(-1).numpy()
+        sd = {k: v.detach().numpy() for k, v in model.state_dict().items() if "embedding" not in k}
+        out = dict(emb_seed=np.int64(seed), V=np.int64(c["V"]), D=np.int64(c["D"]), topk=np.int64(c["cfg"]["topk"]),
+                   query=batch["query"].astype(np.int32), posdoc=batch["posdoc"].astype(np.int32), query_idf=batch["query_idf"],
+                   ref_scores=scores.astype(np.float32), ref_scores_f16=scores.astype(np.float16))
+        for k, v in sd.items():
+            out["sd." + k] = v
+        np.savez_compressed(os.path.join(HERE, f"drmmtks_{name}.npz"), **out)
+        print("drmmtks", name, scores[:6], list(sd.keys()))
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert"}
-    common, KNRM, DRMM, MAXP = _refharness.load_reference()
+    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks"}
+    common, KNRM, DRMM, MAXP, TKS = _refharness.load_reference()
     if "knrm" in which:
         gen_knrm(KNRM)
     if "drmm" in which:
         gen_drmm(DRMM)
+    if "drmmtks" in which:
+        gen_drmmtks(TKS)
     if "bert" in which:
         from make_golden_bert import gen_bert
 

@@ -9,6 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist"]
 DRMM_CASES = ["default", "zero_idf", "tv_nh", "ch", "ranklist"]
+DRMMTKS_CASES = ["default", "top3_short", "ranklist"]
 
 # BASELINE.json north_star: "within 1e-3 relative (fp) and rank-order exactly"
 REL_TOL = 1e-3

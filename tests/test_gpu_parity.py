@@ -469,3 +469,24 @@ def test_train_loop_reduces_loss_and_checkpoints(tmp_path):
     r.model.combine[0].weight.data.zero_()
     t.load_best_model(r, tmp_path / "train")
     assert torch.isfinite(r.model.combine[0].weight).all() and not torch.equal(r.model.combine[0].weight, torch.zeros_like(before))
+
+
+@pytest.mark.parametrize("name", ["default", "top3_short", "ranklist"])
+def test_drmmtks_scores(name):
+    from capreolus_amd.reranker import DRMMTKS
+
+    c = load_case("drmmtks", name)
+    r = DRMMTKS({"topk": int(c["topk"])}, SimpleNamespace(embeddings=c["emb"]))
+    m = r.build_model()
+    m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}, strict=False)
+    m.to(DEV).eval()
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy()
+    want, err = oracle.drmmtks(c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), int(c["topk"]), c["sd.gates.weight"],
+                               c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+    assert err == 0
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, rel_err(got, c["ref_scores"]).max()
+    if name == "ranklist":
+        same = got.astype(np.float16) == c["ref_scores_f16"]
+        assert same.mean() > 0.98

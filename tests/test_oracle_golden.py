@@ -147,3 +147,18 @@ def test_ndcg20_parity_oracle_vs_reference(kind):
     else:
         # DRMM: the reference's own cos(a,a) < 1 coin flips move ~1% of some scores; the metric moves with them
         assert np.mean([abs(a - b) for a, b in vals]) < 0.05, vals
+
+
+def _tks_oracle(c):
+    return oracle.drmmtks(c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), int(c["topk"]), c["sd.gates.weight"],
+                          c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+
+
+@pytest.mark.parametrize("name", ["default", "top3_short", "ranklist"])
+def test_drmmtks_oracle_matches_reference(name):
+    c = load_case("drmmtks", name)
+    got, err = _tks_oracle(c)
+    assert err == 0
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
+    if name == "ranklist":
+        assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
