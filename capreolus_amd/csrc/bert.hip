@@ -226,8 +226,22 @@ int num_cus() {
 
 template <typename T>
 void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
-  if (S == 256) hipLaunchKernelGGL((attention_kernel<256, 8, T>), dim3(nblk), dim3(512), 0, s, at);
-  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
+  if (S == 256) {
+    // persistent + double-buffered (bert_attn.cuh); CAPAMD_ATTN_ONESHOT=1 selects the one-shot kernel for A/B runs
+    static const bool oneshot = [] { const char* e = getenv("CAPAMD_ATTN_ONESHOT"); return e && e[0] == '1'; }();
+    if (oneshot) {
+      hipLaunchKernelGGL((attention_kernel<256, 8, T>), dim3(nblk), dim3(512), 0, s, at);
+    } else {
+      constexpr int kAttnLds = 2 * (256 * 128 + 64 * 256 * 2 + 256 * 4);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_persistent_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLds);
+        attr_set = true;
+      }
+      const unsigned grid = nblk < (unsigned)num_cus() ? nblk : (unsigned)num_cus();
+      hipLaunchKernelGGL((attention_persistent_kernel<T>), dim3(grid), dim3(512), kAttnLds, s, at, (int)nblk);
+    }
+  } else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
   else hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at);
 }
 

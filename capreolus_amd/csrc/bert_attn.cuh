@@ -28,6 +28,50 @@ struct AttnArgs {
   int H, heads;
 };
 
+// The softmax of one query row lives in one lane pair (l31, l31+32): NT tiles x 16 registers.  It is VALU work that
+// competes with the MFMAs of the other wave on the SIMD, so it is written for few instructions per score:
+//  * the additive mask is the accumulator's initial value (no add, no zero-fill),
+//  * exp2((s - m) log2e) is one packed fma per two scores (s * log2e - m * log2e) followed by v_exp_f32,
+//  * the row sum is accumulated with packed adds into a 16-wide partial and folded once at the end.
+__device__ inline f32x16 scores_init_from_mask(const float* madd_t) {
+  f32x16 v;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const float4 ma = *reinterpret_cast<const float4*>(madd_t + 8 * g4);
+    v[g4 * 4 + 0] = ma.x;
+    v[g4 * 4 + 1] = ma.y;
+    v[g4 * 4 + 2] = ma.z;
+    v[g4 * 4 + 3] = ma.w;
+  }
+  return v;
+}
+
+template <int NT>
+__device__ inline float softmax_inplace(f32x16 (&sc)[NT]) {
+  float mx = -3.4028234663852886e38f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float nb = -mx * kLog2e;
+  f32x16 part;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x16 x = sc[t] * kLog2e + nb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+    sc[t] = x;
+    part = t == 0 ? x : part + x;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += part[r];
+  sum += __shfl_xor(sum, 32, 64);
+  return 1.f / sum;
+}
+
 // NW = waves per workgroup (each wave owns 32 queries); S/32/NW workgroups share one (passage, head) and each
 // stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V staged
 // once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us:
@@ -86,8 +130,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   f32x16 sc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+    sc[t] = scores_init_from_mask(madd + t * 32 + 4 * half);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int row = t * 32 + l31;
@@ -96,31 +139,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
     }
   }
   // ---- exact softmax over the S keys of this lane's query ----
-  float mx = -3.4028234663852886e38f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const float4 ma = *reinterpret_cast<const float4*>(madd + t * 32 + 8 * g4 + 4 * half);
-      sc[t][g4 * 4 + 0] += ma.x;
-      sc[t][g4 * 4 + 1] += ma.y;
-      sc[t][g4 * 4 + 2] += ma.z;
-      sc[t][g4 * 4 + 3] += ma.w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sc[t][g4 * 4 + e]);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f((sc[t][r] - mx) * 1.4426950408889634f);
-      sc[t][r] = p;
-      sum += p;
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.f / sum;
+  const float inv = softmax_inplace<NT>(sc);
 
   // ---- ctx^T = V^T · P^T : out[dt] lane <- query l31, d = 32dt + 8*(r>>2) + 4*half + (r&3) ----
   f32x16 out[2];
@@ -155,6 +174,136 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
                   (T)(out[dt][g4 * 4 + 2] * inv), (T)(out[dt][g4 * 4 + 3] * inv)};
       *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
     }
+}
+
+// ---- persistent, double-buffered variant for S = 256 ------------------------------------------------------------
+// One workgroup per CU walks the (passage, head) items; K and V^T of item i+1 are fetched by LDS-DMA into the second
+// LDS buffer while item i is computed, so the ~4.8k-cycle fill of an item (96 KiB at ~20 B/clk/CU) hides behind the
+// ~6k cycles of MFMA + softmax instead of preceding them.  V^T is staged by DMA as well (linear rows of 512 B, the
+// 16-byte chunks XOR-swizzled by (d & 31) on the source side; 2-way bank conflict on the ds_read_b64 pairs instead
+// of the padded rows of the one-shot kernel), the additive mask through registers.
+template <typename T>
+__global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, int n_items) {
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
+  constexpr int S = 256, NT = 8, KBYTES = S * 128, VBYTES = 64 * S * 2, BUF = KBYTES + VBYTES + S * 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  auto stage = [&](int item, int buf) {
+    char* Ks = lds + buf * BUF;
+    char* Vs = Ks + KBYTES;
+    const int psg = item / a.heads, head = item % a.heads;
+    const int64_t tok0 = (int64_t)psg * S;
+    {
+      const int r8 = lane >> 3, p = lane & 7;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = (wave * 4 + t) * 8 + r8;
+        const T* src = static_cast<const T*>(a.K) + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * 4 + t) * 1024), 16, 0, 0);
+      }
+    }
+    {
+      const T* vsrc = static_cast<const T*>(a.Vt) + (int64_t)item * 64 * S;
+      const int r2 = lane >> 5, pc = lane & 31;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int d = (wave * 4 + t) * 2 + r2;
+        const T* src = vsrc + d * S + ((pc ^ (d & 31)) * 8);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Vs + (wave * 4 + t) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto load_q = [&](int item, bf16x8 (&qf)[4]) {
+    const int psg = item / a.heads, head = item % a.heads;
+    const T* qrow = static_cast<const T*>(a.Q) + ((int64_t)psg * S + wave * 32 + l31) * a.H + head * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+  };
+  auto write_mask = [&](int item, int buf) {
+    float* madd = reinterpret_cast<float*>(lds + buf * BUF + KBYTES + VBYTES);
+    const int psg = item / a.heads;
+    if (tid < S) madd[tid] = a.mask[(int64_t)psg * S + tid] != 0 ? 0.f : -3.4028234663852886e38f;
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  bf16x8 qf[4];
+  stage(item, 0);
+  load_q(item, qf);
+  write_mask(item, 0);
+  int buf = 0;
+  bool stores_pending = false;
+  for (;; item += gridDim.x, buf ^= 1) {
+    // the DMA of this item (issued one iteration ago) is older than the previous item's 8 ctx stores per wave
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nxt = item + gridDim.x;
+    const bool more = nxt < n_items;
+    if (more) {
+      stage(nxt, buf ^ 1);
+      write_mask(nxt, buf ^ 1);
+    }
+    const char* Ks = lds + buf * BUF;
+    const char* Vs = Ks + KBYTES;
+    const float* madd = reinterpret_cast<const float*>(Vs + VBYTES);
+
+    f32x16 sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      sc[t] = scores_init_from_mask(madd + t * 32 + 4 * half);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = t * 32 + l31;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
+        sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+      }
+    }
+    if (more) load_q(nxt, qf);  // the Q fragments are dead after the score MFMAs: refill them for the next item now
+    const float inv = softmax_inplace<NT>(sc);
+
+    f32x16 out[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (T)sc[t][8 * s2 + e];
+        const int c0 = 4 * t + 2 * s2;  // 16-byte chunk holding keys 32t + 16 s2 + {0..7}; this lane needs the half * 8 B part
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d = dt * 32 + l31;
+          const char* vr = Vs + d * 512 + half * 8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr + ((c0 ^ (d & 31)) << 4));
+          const uint2 hi = *reinterpret_cast<const uint2*>(vr + (((c0 + 1) ^ (d & 31)) << 4));
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          out[dt] = Half<T>::mfma(vf, pf, out[dt]);
+        }
+      }
+    {
+      const int psg = item / a.heads, head = item % a.heads;
+      T* crow = static_cast<T*>(a.ctx) + ((int64_t)psg * S + wave * 32 + l31) * a.H + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
+                      (T)(out[dt][g4 * 4 + 3] * inv)};
+          *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+        }
+    }
+    if (!more) break;
+    stores_pending = true;
+  }
 }
 
 }  // namespace capamd
