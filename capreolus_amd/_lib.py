@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcapreolus_amd.so")
+LIB_PATH = os.environ.get("CAPAMD_LIB_PATH") or os.path.join(_HERE, "csrc", "libcapreolus_amd.so")  # override: profiling builds only
 
 OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
 STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV = 1, 2, 4

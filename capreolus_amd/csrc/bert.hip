@@ -247,7 +247,20 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
 
 template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
-  if (g.M % 256 == 0 && g.N % 256 == 0) {
+  // CAPAMD_GEMM_KLOOP=halves selects the older 256x256 kernel (k-half regions, 4x2 waves) for A/B runs
+  static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
+  if (pingpong && EPI != kEpiBiasResidBf16 && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 128) {
+    using P = GemmPingPong<EPI, T>;
+    auto k = gemm_pingpong_kernel<EPI, T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P::kLdsBytes);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::kThreads), P::kLdsBytes, s, g);
+  } else if (g.M % 256 == 0 && g.N % 256 == 0) {
     using G = GemmKernel<256, 256, 4, 2, EPI, T>;
     auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;
     static bool attr_set = false;

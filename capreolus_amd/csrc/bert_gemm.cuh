@@ -81,6 +81,10 @@ struct GemmArgs {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+#ifndef CAPAMD_GEMM_ABLATE
+#define CAPAMD_GEMM_ABLATE 0   // profiling builds only (ping-pong kernel): 1 skip the MFMAs, 2 skip the LDS-DMA fill
+#endif
+
 // erf-GELU 0.5 x (1 + erf(x/sqrt2)) on two values at once (v_pk_* math; one v_rcp + one v_exp per value).
 // erf by Abramowitz-Stegun 7.1.26: |abs err| < 1.5e-7 (+ ~1e-7 from the approximate rcp/exp2), far below the
 // bf16 rounding (2^-9 relative) applied to the result.
@@ -441,6 +445,246 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmA
   using G = GemmKernel<BM, BN, WAVES_M, WAVES_N, EPI, T>;
   extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
   G::run(a, gemm_lds);
+}
+
+// =====================================================================================================================
+// 256x256 tile, "ping-pong" K loop (the kernel the BERT-base shapes run on).
+//
+// Eight waves as 2 (m) x 4 (n): a wave owns 128 x 64 of the tile = 4 x 2 MFMA tiles of 32x32 (128 accumulator
+// registers).  One K step (64 k) of the two operands is staged as FOUR half-tiles of 128 rows x 128 bytes (full cache
+// lines, 16 KiB each; 2 LDS-DMA instructions per wave per half-tile):
+//     A0 / A1 : rows  wr*128 + h*64 + (0..63)  of the activation panel (both wave rows wr)      -> LDS row wr*64 + r
+//     B0 / B1 : rows  wc*64  + h*32 + (0..31)  of the weight panel     (all four wave columns)  -> LDS row wc*32 + c
+// and consumed in four phases, each one quadrant (64 m x 32 n) of the wave tile over the whole K step (8 MFMAs):
+//     P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
+// so that every phase needs at most one new A half (8 ds_read_b128) and one new B half (4); B0 stays in registers from
+// P1 to P4.  Each half-tile is therefore read in exactly one phase (A0,B0: P1; B1: P2; A1: P3) and its slot is handed
+// back to the fill stream two phases later:  P1 stages B1 of K step g+1, P2 A1 of g+1, P3 A0 of g+2, P4 B0 of g+2 -
+// one half-tile per phase, four to five phases (~1.2 K steps, 64-80 KiB per CU) ahead of its use, across tile
+// boundaries of the persistent schedule (the next tile's first K steps are fetched during this tile's last ones).
+//
+// The two wave rows run half a phase apart: a phase is  [loads] barrier [8 MFMAs] barrier,  and wave row 1 starts with
+// one extra barrier, so while the four waves of one row (one per SIMD) issue MFMAs, the other four do their LDS reads,
+// their LDS-DMA issue and their waits.  Hazards, with that stagger:
+//   * read after fill: a half-tile is read in phase p by both rows only after every wave has waited (counted vmcnt,
+//     never 0 in steady state: 8 = the four half-tiles issued after the needed one) for its own two pieces in its
+//     loads of phase p-1, and a barrier has followed;
+//   * fill after read: the LDS reads of phase p are retired (lgkmcnt(0)) right after the phase's first barrier, at the
+//     head of its MFMA half - the loads half never waits for LDS latency - so the slot is re-staged from the loads of
+//     phase p+2 on (row 1 retires its reads of phase p one barrier before row 0 starts the loads of phase p+2).
+// =====================================================================================================================
+template <int EPI, typename T>
+struct GemmPingPong {
+  using G = GemmKernel<256, 256, 2, 4, EPI, T>;  // epilogues and wave-tile geometry (WMT 128, WNT 64, TM 4, TN 2)
+  using Lane = typename G::Lane;
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
+  static constexpr int kHalfTile = 128 * 128;     // bytes
+  static constexpr int kBuf = 4 * kHalfTile;      // one K step
+  static constexpr int kLdsBytes = 2 * kBuf + 8 * G::kEpiLds;
+  static constexpr int kThreads = 512;
+  enum { kA0 = 0, kA1 = 1, kB0 = 2, kB1 = 3 };
+
+  struct Ctx {
+    const T* A; const T* W;   // operand bases
+    int K, KT;
+    int64_t a_off[2], b_off[2];  // per-lane element offsets of this wave's two pieces of an A / B half-tile (half 0)
+    int koff[4];               // per-lane byte offset of k-slice ks inside a 128-byte LDS row (XOR-swizzled chunk)
+    int a_row, b_row;          // per-lane LDS byte offset of row (wr*64 + l31) / (wc*32 + l31)
+    int piece;                 // wave * 2048 (scalar): this wave's pieces inside a half-tile
+  };
+
+  static __device__ __forceinline__ void make_ctx(const GemmArgs& a, const Lane& L, Ctx& c) {
+    c.A = static_cast<const T*>(a.A); c.W = static_cast<const T*>(a.W);
+    c.K = a.K; c.KT = a.K / 64;
+    const int r8 = L.lane >> 3, p = L.lane & 7;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = (L.wave * 2 + t) * 8 + r8;            // LDS row of the half-tile this lane fills
+      const int chunk = p ^ ((row >> 1) & 7);               // which 16 bytes of the source line land in slot p
+      c.a_off[t] = (int64_t)((row >> 6) * 128 + (row & 63)) * a.K + chunk * 8;
+      c.b_off[t] = (int64_t)((row >> 5) * 64 + (row & 31)) * a.K + chunk * 8;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) c.koff[ks] = ((2 * ks + L.half) ^ ((L.l31 >> 1) & 7)) * 16;
+    c.a_row = (L.wm * 64 + L.l31) * 128;
+    c.b_row = (L.wn * 32 + L.l31) * 128;
+    c.piece = __builtin_amdgcn_readfirstlane(L.wave) * 2048;
+  }
+
+  struct Tiles {   // where the fill stream is: this tile, the next one (if any), and the running K-step parity
+    int m0, n0, m1, n1;
+    bool more;
+    int gk;        // K steps of all earlier tiles of this block (buffer of step g of this tile = (gk + g) & 1)
+  };
+  struct Src {     // scalar: the operand panels of one K step, A + m0*K + kt*64 and W + n0*K + kt*64
+    const T* a; const T* w;
+  };
+  // K step g relative to the current tile; g >= KT runs on into the next tile (caller guarantees there is one)
+  static __device__ __forceinline__ Src src_of(const Ctx& c, const Tiles& t, int g) {
+    const bool in = g < c.KT;
+    const int kt = in ? g : g - c.KT, m = in ? t.m0 : t.m1, n = in ? t.n0 : t.n1;
+    return Src{c.A + (int64_t)m * c.K + kt * 64, c.W + (int64_t)n * c.K + kt * 64};
+  }
+
+  // LDS-DMA of half-tile KIND of the K step at `s` into buffer `buf`: two 1-KiB pieces per wave
+  template <int KIND>
+  static __device__ __forceinline__ void stage(const Ctx& c, char* lds, int buf, const Src& s) {
+#if CAPAMD_GEMM_ABLATE & 2
+    return;
+#endif
+    char* dst = lds + buf * kBuf + KIND * kHalfTile + c.piece;
+    const T* base = KIND < 2 ? s.a + (int64_t)(KIND & 1) * 64 * c.K : s.w + (int64_t)(KIND & 1) * 32 * c.K;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const T* src = base + (KIND < 2 ? c.a_off[t] : c.b_off[t]);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + t * 1024), 16, 0, 0);
+    }
+  }
+
+  static __device__ __forceinline__ bf16x8 rd(const char* half_tile, int row_off, int koff) {
+    return *reinterpret_cast<const bf16x8*>(half_tile + row_off + koff);
+  }
+
+  // ---- one K step = four phases.  FILL: 2 = the fill stream is running (every phase stages one half-tile and the
+  // waits are counted), 1 = only P1 stages (second-to-last K step of the block's last tile), 0 = nothing left to stage.
+  template <bool TRANS, int FILL>
+  static __device__ __forceinline__ void k_step(const Ctx& c, char* lds, int bcur, const Src& s1, const Src& s2, bool last,
+                                                f32x16 (&acc)[2][4], bf16x8 (&fa)[2][4], bf16x8 (&fb0)[4], bf16x8 (&fb1)[4]) {
+    const char* buf = lds + bcur * kBuf;
+    // end of a phase's loads: the half-tile(s) read in the NEXT phase have landed as far as this wave's pieces go (eight
+    // newer LDS-DMA instructions = the four half-tiles issued after the needed one).  The phase's own LDS reads are
+    // only waited for after the barrier, at the head of the MFMA half of the phase.
+    auto landed = [&](bool needed) {
+      if (needed) {
+        if (FILL == 2) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma8 = [&](const bf16x8 (&b)[4], int i, int j0) {
+      __builtin_amdgcn_s_setprio(1);
+#if CAPAMD_GEMM_ABLATE & 1
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(b[ks]), "v"(fa[0][ks]), "v"(fa[1][ks]));
+#else
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[i][j0 + jj] = TRANS ? Half<T>::mfma(fa[jj][ks], b[ks], acc[i][j0 + jj]) : Half<T>::mfma(b[ks], fa[jj][ks], acc[i][j0 + jj]);
+#endif
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    // P1: (A0, B0)
+    if (FILL >= 1) stage<kB1>(c, lds, bcur ^ 1, s1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = rd(buf + kB0 * kHalfTile, c.b_row, c.koff[ks]);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[jj][ks] = rd(buf + kA0 * kHalfTile, c.a_row + jj * 4096, c.koff[ks]);
+    landed(true);                    // B1 of this K step
+    mfma8(fb0, 0, 0);
+    // P2: (A0, B1)
+    if (FILL >= 1) stage<kA1>(c, lds, bcur ^ 1, s1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = rd(buf + kB1 * kHalfTile, c.b_row, c.koff[ks]);
+    landed(true);                    // A1 of this K step
+    mfma8(fb1, 1, 0);
+    // P3: (A1, B1)
+    if (FILL == 2) stage<kA0>(c, lds, bcur, s2);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[jj][ks] = rd(buf + kA1 * kHalfTile, c.a_row + jj * 4096, c.koff[ks]);
+    landed(false);
+    mfma8(fb1, 1, 2);
+    // P4: (A1, B0)
+    if (FILL == 2) stage<kB0>(c, lds, bcur, s2);
+    landed(!last);                   // A0, B0 of the next K step
+    mfma8(fb0, 0, 2);
+  }
+
+  // ---- one tile's K loop (the first six half-tiles of the tile are already in flight / landed) ---------------------
+  template <bool TRANS>
+  static __device__ __forceinline__ void k_loop(const Ctx& c, char* lds, const Tiles& t, const Lane& L, f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][4], fb0[4], fb1[4];
+    if (L.wm == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs half a phase behind
+    int g = 0;
+    const int steady = t.more ? c.KT : c.KT - 2;   // K steps whose stages (g+1, g+2) all exist
+    for (; g < steady; ++g) k_step<TRANS, 2>(c, lds, (t.gk + g) & 1, src_of(c, t, g + 1), src_of(c, t, g + 2), false, acc, fa, fb0, fb1);
+    if (!t.more) {
+      k_step<TRANS, 1>(c, lds, (t.gk + g) & 1, src_of(c, t, g + 1), Src{nullptr, nullptr}, false, acc, fa, fb0, fb1);
+      ++g;
+      k_step<TRANS, 0>(c, lds, (t.gk + g) & 1, Src{nullptr, nullptr}, Src{nullptr, nullptr}, true, acc, fa, fb0, fb1);
+    }
+    if (L.wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows: both run the epilogue at once
+  }
+
+  static __device__ __forceinline__ void run(const GemmArgs& a, char* lds) {
+    Lane L;
+    L.tid = threadIdx.x; L.lane = L.tid & 63; L.wave = L.tid >> 6;
+    L.wm = L.wave >> 2; L.wn = L.wave & 3; L.l31 = L.lane & 31; L.half = L.lane >> 5;
+    unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr;
+    int dbg_i = 0;
+#define CAPAMD_STAMP() do { if (dbg && L.tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+    Tiles t;
+    t.gk = 0;
+    if (!G::tile_of(a, 0, t.m0, t.n0)) return;
+    Ctx c;
+    make_ctx(a, L, c);
+    CAPAMD_STAMP();
+    t.m1 = t.n1 = 0;
+    t.more = G::tile_of(a, 1, t.m1, t.n1);
+    // prologue, in the order the steady state would have issued them: A0 B0 B1 A1 of step 0, A0 B0 of step 1
+    {
+      const Src s0 = src_of(c, t, 0), s1 = src_of(c, t, 1);
+      stage<kA0>(c, lds, 0, s0); stage<kB0>(c, lds, 0, s0); stage<kB1>(c, lds, 0, s0); stage<kA1>(c, lds, 0, s0);
+      stage<kA0>(c, lds, 1, s1); stage<kB0>(c, lds, 1, s1);
+      wait_vmcnt<8>();
+      __builtin_amdgcn_s_barrier();
+    }
+    for (int it = 0;; ++it) {
+      f32x16 acc[2][4];
+      bf16x4 rs[G::kResid ? 2 : 1][G::kResid ? 4 : 1][4];
+      const bool trans = (EPI == kEpiQkv) && t.n0 >= 2 * a.H;
+      if (trans) k_loop<true>(c, lds, t, L, acc);
+      else k_loop<false>(c, lds, t, L, acc);
+      CAPAMD_STAMP();
+      if constexpr (G::kResid) G::load_resid(a, t.m0, t.n0, L, rs);
+      char* wl = lds + 2 * kBuf + L.wave * G::kEpiLds;
+      if constexpr (G::kResid) {
+        G::epilogue_resid(a, wl, t.m0, t.n0, L, acc, rs);
+      } else {
+        if (trans) G::template epilogue<true>(a, wl, t.m0, t.n0, L, acc, rs);
+        else G::template epilogue<false>(a, wl, t.m0, t.n0, L, acc, rs);
+      }
+      CAPAMD_STAMP();
+      if (!t.more) break;
+      t.gk += c.KT;
+      t.m0 = t.m1; t.n0 = t.n1;
+      t.more = G::tile_of(a, it + 2, t.m1, t.n1);
+    }
+#undef CAPAMD_STAMP
+  }
+};
+
+template <int EPI, typename T>
+__global__ __launch_bounds__(512) void gemm_pingpong_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char gemm_lds[];
+  GemmPingPong<EPI, T>::run(a, gemm_lds);
 }
 
 }  // namespace capamd
