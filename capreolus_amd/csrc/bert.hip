@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
                                                  const float* __restrict__ pos, const float* __restrict__ type, int vocab,
                                                  int type_vocab, int S, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int64_t M, int H,
-                                                 T* __restrict__ xb, int* status) {
+                                                 T* xb, int* status) {
   using bf16x4 = typename Half<T>::x4;
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
       if (MODE == 1) {
         const bf16x4 b = reinterpret_cast<const bf16x4*>(pre + tok * H)[c];
         x = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+      } else if (MODE == 2) {  // residual sum in fp32: projection output + the stream row it will replace
+        const bf16x4 b = reinterpret_cast<const bf16x4*>(pre + tok * H)[c];
+        const bf16x4 r = reinterpret_cast<const bf16x4*>(xb + tok * H)[c];
+        x = make_float4((float)b[0] + (float)r[0], (float)b[1] + (float)r[1], (float)b[2] + (float)r[2], (float)b[3] + (float)r[3]);
       } else {
         x = reinterpret_cast<const float4*>(r0)[c];
       }
@@ -346,20 +350,21 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
       const unsigned nblk = (unsigned)(np * m->heads);
       launch_attention<T>(at, S, nblk, s);
-      // attention output projection + residual -> LayerNorm
-      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
-      e = launch_gemm<kEpiBiasResidBf16, T>(g, s);
+      // attention output projection; the residual is added in fp32 inside the LayerNorm pass (one rounding, and the
+      // GEMM keeps its cheap 16-bit epilogue)
+      g.A = w.ctx; g.W = wo; g.bias = bo; g.N = H; g.K = H; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasBf16, T>(g, s);
       if (e != hipSuccess) break;
-      hipLaunchKernelGGL((ln_kernel<1, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+      hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status);
-      // feed-forward: 768 -> 3072 (GELU) -> 768 + residual -> LayerNorm
+      // feed-forward: 768 -> 3072 (GELU) -> 768, residual + LayerNorm
       g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
       e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
       if (e != hipSuccess) break;
-      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.resid_bf16 = w.xb; g.out_bf16 = w.pre;
-      e = launch_gemm<kEpiBiasResidBf16, T>(g, s);
+      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.out_bf16 = w.pre;
+      e = launch_gemm<kEpiBiasBf16, T>(g, s);
       if (e != hipSuccess) break;
-      hipLaunchKernelGGL((ln_kernel<1, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
+      hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status);
     }
     if (e != hipSuccess) break;

