@@ -81,6 +81,9 @@ struct GemmArgs {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+#ifndef CAPAMD_PP_GLDS_POS
+#define CAPAMD_PP_GLDS_POS 2   // where a phase issues its LDS-DMA pair: 0 before its LDS reads, 1 after them, 2 after its first MFMA pair, 3 one after the first and one after the third pair
+#endif
 #ifndef CAPAMD_GEMM_ABLATE
 #define CAPAMD_GEMM_ABLATE 0   // profiling builds only (ping-pong kernel): 1 skip the MFMAs, 2 skip the LDS-DMA fill
 #endif
@@ -528,7 +531,7 @@ struct GemmPingPong {
   }
 
   // LDS-DMA of half-tile KIND of the K step at `s` into buffer `buf`: two 1-KiB pieces per wave
-  template <int KIND>
+  template <int KIND, int PIECES = 3>
   static __device__ __forceinline__ void stage(const Ctx& c, char* lds, int buf, const Src& s) {
 #if CAPAMD_GEMM_ABLATE & 2
     return;
@@ -537,6 +540,7 @@ struct GemmPingPong {
     const T* base = KIND < 2 ? s.a + (int64_t)(KIND & 1) * 64 * c.K : s.w + (int64_t)(KIND & 1) * 32 * c.K;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (!((PIECES >> t) & 1)) continue;
       const T* src = base + (KIND < 2 ? c.a_off[t] : c.b_off[t]);
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + t * 1024), 16, 0, 0);
     }
@@ -552,63 +556,72 @@ struct GemmPingPong {
   static __device__ __forceinline__ void k_step(const Ctx& c, char* lds, int bcur, const Src& s1, const Src& s2, bool last,
                                                 f32x16 (&acc)[2][4], bf16x8 (&fa)[2][4], bf16x8 (&fb0)[4], bf16x8 (&fb1)[4]) {
     const char* buf = lds + bcur * kBuf;
-    // end of a phase's loads: the half-tile(s) read in the NEXT phase have landed as far as this wave's pieces go (eight
-    // newer LDS-DMA instructions = the four half-tiles issued after the needed one).  The phase's own LDS reads are
-    // only waited for after the barrier, at the head of the MFMA half of the phase.
-    auto landed = [&](bool needed) {
+    // One phase = [fragment reads + one half-tile staged] barrier [8 MFMAs] barrier.  At the end of the loads half
+    // the half-tile(s) read in the NEXT phase must have landed as far as this wave's pieces go: vmcnt(8) = the four
+    // half-tiles issued after the needed one stay in flight.  The phase's own LDS reads are only waited for after the
+    // barrier, at the head of the MFMA half.
+    auto phase = [&](auto&& stage_fn, auto&& reads_fn, bool needed, const bf16x8 (&b)[4], int i, int j0) {
+#if CAPAMD_PP_GLDS_POS == 0
+      stage_fn(3);
+      reads_fn();
+#elif CAPAMD_PP_GLDS_POS == 1
+      reads_fn();
+      stage_fn(3);
+#else
+      reads_fn();
+#endif
       if (needed) {
-        if (FILL == 2) wait_vmcnt<8>();
+        if (FILL == 2) wait_vmcnt<(CAPAMD_PP_GLDS_POS >= 2 ? 6 : 8)>();
         else wait_vmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mfma8 = [&](const bf16x8 (&b)[4], int i, int j0) {
       __builtin_amdgcn_s_setprio(1);
 #if CAPAMD_GEMM_ABLATE & 1
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(b[ks]), "v"(fa[0][ks]), "v"(fa[1][ks]));
 #else
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
           acc[i][j0 + jj] = TRANS ? Half<T>::mfma(fa[jj][ks], b[ks], acc[i][j0 + jj]) : Half<T>::mfma(b[ks], fa[jj][ks], acc[i][j0 + jj]);
+#if CAPAMD_PP_GLDS_POS == 2
+        if (ks == 0) { __builtin_amdgcn_sched_barrier(0); stage_fn(3); __builtin_amdgcn_sched_barrier(0); }
+#elif CAPAMD_PP_GLDS_POS == 3
+        if (ks == 0) { __builtin_amdgcn_sched_barrier(0); stage_fn(1); __builtin_amdgcn_sched_barrier(0); }
+        if (ks == 2) { __builtin_amdgcn_sched_barrier(0); stage_fn(2); __builtin_amdgcn_sched_barrier(0); }
+#endif
+      }
 #endif
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
     };
-    // P1: (A0, B0)
-    if (FILL >= 1) stage<kB1>(c, lds, bcur ^ 1, s1);
+    auto read_a = [&](int kind) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = rd(buf + kB0 * kHalfTile, c.b_row, c.koff[ks]);
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+        for (int ks = 0; ks < 4; ++ks) fa[jj][ks] = rd(buf + kind * kHalfTile, c.a_row + jj * 4096, c.koff[ks]);
+    };
+    auto read_b = [&](int kind, bf16x8 (&fb)[4]) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[jj][ks] = rd(buf + kA0 * kHalfTile, c.a_row + jj * 4096, c.koff[ks]);
-    landed(true);                    // B1 of this K step
-    mfma8(fb0, 0, 0);
-    // P2: (A0, B1)
-    if (FILL >= 1) stage<kA1>(c, lds, bcur ^ 1, s1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = rd(buf + kB1 * kHalfTile, c.b_row, c.koff[ks]);
-    landed(true);                    // A1 of this K step
-    mfma8(fb1, 1, 0);
-    // P3: (A1, B1)
-    if (FILL == 2) stage<kA0>(c, lds, bcur, s2);
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[jj][ks] = rd(buf + kA1 * kHalfTile, c.a_row + jj * 4096, c.koff[ks]);
-    landed(false);
-    mfma8(fb1, 1, 2);
-    // P4: (A1, B0)
-    if (FILL == 2) stage<kB0>(c, lds, bcur, s2);
-    landed(!last);                   // A0, B0 of the next K step
-    mfma8(fb0, 0, 2);
+      for (int ks = 0; ks < 4; ++ks) fb[ks] = rd(buf + kind * kHalfTile, c.b_row, c.koff[ks]);
+    };
+    // P1 (A0, B0): stages B1 of step g+1; needs B1 of this step next
+    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kB1>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kB1, 1>(c, lds, bcur ^ 1, s1); else stage<kB1, 2>(c, lds, bcur ^ 1, s1); } },
+          [&] { read_b(kB0, fb0); read_a(kA0); }, true, fb0, 0, 0);
+    // P2 (A0, B1): stages A1 of step g+1; needs A1 of this step next
+    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kA1>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kA1, 1>(c, lds, bcur ^ 1, s1); else stage<kA1, 2>(c, lds, bcur ^ 1, s1); } },
+          [&] { read_b(kB1, fb1); }, true, fb1, 1, 0);
+    // P3 (A1, B1): stages A0 of step g+2
+    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kA0>(c, lds, bcur, s2); else if (pc == 1) stage<kA0, 1>(c, lds, bcur, s2); else stage<kA0, 2>(c, lds, bcur, s2); } },
+          [&] { read_a(kA1); }, false, fb1, 1, 2);
+    // P4 (A1, B0): stages B0 of step g+2; needs A0, B0 of the next step next
+    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kB0>(c, lds, bcur, s2); else if (pc == 1) stage<kB0, 1>(c, lds, bcur, s2); else stage<kB0, 2>(c, lds, bcur, s2); } },
+          [&] {}, !last, fb0, 0, 2);
   }
 
   // ---- one tile's K loop (the first six half-tiles of the tile are already in flight / landed) ---------------------
