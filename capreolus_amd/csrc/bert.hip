@@ -253,7 +253,8 @@ template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   // CAPAMD_GEMM_KLOOP=halves selects the older 256x256 kernel (k-half regions, 4x2 waves) for A/B runs
   static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
-  if (pingpong && EPI != kEpiBiasResidBf16 && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 128) {
+  if (pingpong && EPI != kEpiBiasResidBf16 && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 128 && (size_t)g.M * g.K < (1ull << 31) &&
+      (size_t)g.N * g.K < (1ull << 31)) {  // (buffer addressing: operands below 4 GiB)
     using P = GemmPingPong<EPI, T>;
     auto k = gemm_pingpong_kernel<EPI, T>;
     static bool attr_set = false;

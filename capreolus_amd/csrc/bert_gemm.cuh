@@ -371,7 +371,8 @@ struct GemmKernel {
               *reinterpret_cast<bf16x4*>(wl + L.l31 * 128 + (((4 * cc + g4) ^ swz) << 4) + L.half * 8) = o;
             }
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          // no wait between a wave's own LDS writes and reads (its DS operations execute in issue order); the reads of
+          // this round are only waited for by the global stores, with the next round's LDS traffic already issued
 #pragma unroll
           for (int k = 0; k < 2 * CP; ++k) {
             const int c = L.lane + 64 * k;
@@ -379,7 +380,6 @@ struct GemmKernel {
             const uint4 x = *reinterpret_cast<const uint4*>(wl + row * 128 + ((ch ^ (row & 7)) << 4));
             *reinterpret_cast<uint4*>(base + out_offset<TRANS>(a, m0, n0, L, rb, row, cp * CP * 32 + ch * 8)) = x;
           }
-          asm volatile("" ::: "memory");
         }
     }
   }
@@ -491,7 +491,9 @@ struct GemmPingPong {
   struct Ctx {
     const T* A; const T* W;   // operand bases
     int K, KT;
-    int64_t a_off[2], b_off[2];  // per-lane element offsets of this wave's two pieces of an A / B half-tile (half 0)
+    int a_off[2], b_off[2];    // per-lane BYTE offsets of this wave's two pieces of an A / B half-tile (half 0, K step 0)
+    unsigned a_bytes, w_bytes; // extents of the A / W tensors: the LDS-DMA goes through buffer addressing (resource over
+                               // the whole tensor + 32-bit lane offset + scalar tile/K-step offset)
     int koff[4];               // per-lane byte offset of k-slice ks inside a 128-byte LDS row (XOR-swizzled chunk)
     int a_row, b_row;          // per-lane LDS byte offset of row (wr*64 + l31) / (wc*32 + l31)
     int piece;                 // wave * 2048 (scalar): this wave's pieces inside a half-tile
@@ -505,14 +507,16 @@ struct GemmPingPong {
     for (int t = 0; t < 2; ++t) {
       const int row = (L.wave * 2 + t) * 8 + r8;            // LDS row of the half-tile this lane fills
       const int chunk = p ^ ((row >> 1) & 7);               // which 16 bytes of the source line land in slot p
-      c.a_off[t] = (int64_t)((row >> 6) * 128 + (row & 63)) * a.K + chunk * 8;
-      c.b_off[t] = (int64_t)((row >> 5) * 64 + (row & 31)) * a.K + chunk * 8;
+      c.a_off[t] = (((row >> 6) * 128 + (row & 63)) * a.K + chunk * 8) * 2;
+      c.b_off[t] = (((row >> 5) * 64 + (row & 31)) * a.K + chunk * 8) * 2;
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) c.koff[ks] = ((2 * ks + L.half) ^ ((L.l31 >> 1) & 7)) * 16;
     c.a_row = (L.wm * 64 + L.l31) * 128;
     c.b_row = (L.wn * 32 + L.l31) * 128;
     c.piece = __builtin_amdgcn_readfirstlane(L.wave) * 2048;
+    c.a_bytes = (unsigned)((size_t)a.M * a.K * 2);   // the dispatcher guarantees both tensors are below 4 GiB
+    c.w_bytes = (unsigned)((size_t)a.N * a.K * 2);
   }
 
   struct Tiles {   // where the fill stream is: this tile, the next one (if any), and the running K-step parity
@@ -520,14 +524,14 @@ struct GemmPingPong {
     bool more;
     int gk;        // K steps of all earlier tiles of this block (buffer of step g of this tile = (gk + g) & 1)
   };
-  struct Src {     // scalar: the operand panels of one K step, A + m0*K + kt*64 and W + n0*K + kt*64
-    const T* a; const T* w;
+  struct Src {     // scalar byte offsets of the operand panels of one K step: (m0*K + kt*64)*2 and (n0*K + kt*64)*2
+    unsigned a, w;
   };
   // K step g relative to the current tile; g >= KT runs on into the next tile (caller guarantees there is one)
   static __device__ __forceinline__ Src src_of(const Ctx& c, const Tiles& t, int g) {
     const bool in = g < c.KT;
     const int kt = in ? g : g - c.KT, m = in ? t.m0 : t.m1, n = in ? t.n0 : t.n1;
-    return Src{c.A + (int64_t)m * c.K + kt * 64, c.W + (int64_t)n * c.K + kt * 64};
+    return Src{(unsigned)(((int64_t)m * c.K + kt * 64) * 2), (unsigned)(((int64_t)n * c.K + kt * 64) * 2)};
   }
 
   // LDS-DMA of half-tile KIND of the K step at `s` into buffer `buf`: two 1-KiB pieces per wave
@@ -536,14 +540,22 @@ struct GemmPingPong {
 #if CAPAMD_GEMM_ABLATE & 2
     return;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in the host pass of hipcc)
     char* dst = lds + buf * kBuf + KIND * kHalfTile + c.piece;
-    const T* base = KIND < 2 ? s.a + (int64_t)(KIND & 1) * 64 * c.K : s.w + (int64_t)(KIND & 1) * 32 * c.K;
+    const unsigned soff = KIND < 2 ? s.a + (unsigned)((KIND & 1) * 64 * c.K * 2) : s.w + (unsigned)((KIND & 1) * 32 * c.K * 2);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (!((PIECES >> t) & 1)) continue;
-      const T* src = base + (KIND < 2 ? c.a_off[t] : c.b_off[t]);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + t * 1024), 16, 0, 0);
+      // raw buffer (stride 0, dword format) over the operand; loop-invariant scalar registers
+      if constexpr (KIND < 2) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(c.A), 0, (int)c.a_bytes, 0x00020000),
+                                                 (lds_void_t*)(dst + t * 1024), 16, c.a_off[t], (int)soff, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(c.W), 0, (int)c.w_bytes, 0x00020000),
+                                                 (lds_void_t*)(dst + t * 1024), 16, c.b_off[t], (int)soff, 0, 0);
+      }
     }
+#endif
   }
 
   static __device__ __forceinline__ bf16x8 rd(const char* half_tile, int row_off, int koff) {
@@ -611,16 +623,16 @@ struct GemmPingPong {
       for (int ks = 0; ks < 4; ++ks) fb[ks] = rd(buf + kind * kHalfTile, c.b_row, c.koff[ks]);
     };
     // P1 (A0, B0): stages B1 of step g+1; needs B1 of this step next
-    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kB1>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kB1, 1>(c, lds, bcur ^ 1, s1); else stage<kB1, 2>(c, lds, bcur ^ 1, s1); } },
+    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kB1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kB1, 1>(c, lds, bcur ^ 1, s1); else stage<kB1, 2>(c, lds, bcur ^ 1, s1); } },
           [&] { read_b(kB0, fb0); read_a(kA0); }, true, fb0, 0, 0);
     // P2 (A0, B1): stages A1 of step g+1; needs A1 of this step next
-    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kA1>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kA1, 1>(c, lds, bcur ^ 1, s1); else stage<kA1, 2>(c, lds, bcur ^ 1, s1); } },
+    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kA1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kA1, 1>(c, lds, bcur ^ 1, s1); else stage<kA1, 2>(c, lds, bcur ^ 1, s1); } },
           [&] { read_b(kB1, fb1); }, true, fb1, 1, 0);
     // P3 (A1, B1): stages A0 of step g+2
-    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kA0>(c, lds, bcur, s2); else if (pc == 1) stage<kA0, 1>(c, lds, bcur, s2); else stage<kA0, 2>(c, lds, bcur, s2); } },
+    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kA0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kA0, 1>(c, lds, bcur, s2); else stage<kA0, 2>(c, lds, bcur, s2); } },
           [&] { read_a(kA1); }, false, fb1, 1, 2);
     // P4 (A1, B0): stages B0 of step g+2; needs A0, B0 of the next step next
-    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kB0>(c, lds, bcur, s2); else if (pc == 1) stage<kB0, 1>(c, lds, bcur, s2); else stage<kB0, 2>(c, lds, bcur, s2); } },
+    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kB0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kB0, 1>(c, lds, bcur, s2); else stage<kB0, 2>(c, lds, bcur, s2); } },
           [&] {}, !last, fb0, 0, 2);
   }
 
@@ -639,9 +651,9 @@ struct GemmPingPong {
     const int steady = t.more ? c.KT : c.KT - 2;   // K steps whose stages (g+1, g+2) all exist
     for (; g < steady; ++g) k_step<TRANS, 2>(c, lds, (t.gk + g) & 1, src_of(c, t, g + 1), src_of(c, t, g + 2), false, acc, fa, fb0, fb1);
     if (!t.more) {
-      k_step<TRANS, 1>(c, lds, (t.gk + g) & 1, src_of(c, t, g + 1), Src{nullptr, nullptr}, false, acc, fa, fb0, fb1);
+      k_step<TRANS, 1>(c, lds, (t.gk + g) & 1, src_of(c, t, g + 1), Src{0u, 0u}, false, acc, fa, fb0, fb1);
       ++g;
-      k_step<TRANS, 0>(c, lds, (t.gk + g) & 1, Src{nullptr, nullptr}, Src{nullptr, nullptr}, true, acc, fa, fb0, fb1);
+      k_step<TRANS, 0>(c, lds, (t.gk + g) & 1, Src{0u, 0u}, Src{0u, 0u}, true, acc, fa, fb0, fb1);
     }
     if (L.wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows: both run the epilogue at once
   }
@@ -664,8 +676,8 @@ struct GemmPingPong {
     // prologue, in the order the steady state would have issued them: A0 B0 B1 A1 of step 0, A0 B0 of step 1
     {
       const Src s0 = src_of(c, t, 0), s1 = src_of(c, t, 1);
-      stage<kA0>(c, lds, 0, s0); stage<kB0>(c, lds, 0, s0); stage<kB1>(c, lds, 0, s0); stage<kA1>(c, lds, 0, s0);
-      stage<kA0>(c, lds, 1, s1); stage<kB0>(c, lds, 1, s1);
+      stage<kA0, 3>(c, lds, 0, s0); stage<kB0, 3>(c, lds, 0, s0); stage<kB1, 3>(c, lds, 0, s0); stage<kA1, 3>(c, lds, 0, s0);
+      stage<kA0, 3>(c, lds, 1, s1); stage<kB0, 3>(c, lds, 1, s1);
       wait_vmcnt<8>();
       __builtin_amdgcn_s_barrier();
     }
