@@ -56,6 +56,21 @@ def test_gemm_vs_torch(M, N, K, epi, dt):
     torch.testing.assert_close(out.float(), ref, rtol=rtol, atol=2e-2 if dt == "bf16" else 3e-3)  # one rounding of the result
 
 
+def test_gemm_gelu_accuracy():
+    """The fused erf-GELU on its own: x sweeps [-12, 12] through an identity weight; the result may differ from the exact
+    erf form only by the fp16 rounding of the output plus the 1.2e-6 bound of the in-kernel approximation."""
+    M, N, K = 256, 64, 64
+    x = torch.linspace(-12, 12, M * K, device=DEV).reshape(M, K).to(torch.float16)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 65504.0, -65504.0, 3.6, -3.6], device=DEV, dtype=torch.float16)
+    W = torch.eye(N, K, device=DEV, dtype=torch.float16)
+    bias = torch.zeros(N, device=DEV)
+    out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    assert _lib.load().capamd_bert_gemm(_p(x), _p(W), _p(bias), M, N, K, 1, None, _p(out), 1, _stream()) == 0
+    ref = torch.nn.functional.gelu(x.double())
+    err = (out.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 1.5e-6).all()), float((err - ref.abs() * 2.0 ** -11).max())
+
+
 @pytest.mark.parametrize("S,hidden,heads,npsg", [(64, 128, 2, 4), (128, 192, 3, 2), (256, 768, 12, 2), (256, 768, 12, 3)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qkv_attention_vs_torch(S, hidden, heads, npsg, dt):
