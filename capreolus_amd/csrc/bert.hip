@@ -249,6 +249,21 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
   else hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at);
 }
 
+// Column tiles scheduled together.  All of them when the whole weight matrix fits an XCD's 4 MB L2 next to the activation
+// panels in flight (<= 3.6 MB) or there are few (every group re-reads the activations once: tn / group passes over A);
+// otherwise the largest divisor of tn whose weight panels (256 x K, 16-bit) stay within ~1.6 MB.  Measured on MI355X,
+// FFN1 of BERT-base (tn = 12, 4.7 MB of weights): 381 us with 12, 358 with 4 or 3, 391 with 1.  CAPAMD_GEMM_NGROUP overrides.
+int column_group(int tn, int K) {
+  static const int forced = [] { const char* e = getenv("CAPAMD_GEMM_NGROUP"); return e ? atoi(e) : 0; }();
+  if (forced > 0 && tn % forced == 0) return forced;
+  const long panel = 256L * K * 2;
+  if (tn <= 4 || tn * panel <= 3774873L) return tn;
+  int best = 1;
+  for (int g = 1; g <= tn; ++g)
+    if (tn % g == 0 && g * panel <= 1677721L) best = g;
+  return best;
+}
+
 template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   // CAPAMD_GEMM_KLOOP=halves selects the older 256x256 kernel (k-half regions, 4x2 waves) for A/B runs
@@ -264,7 +279,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       attr_set = true;
     }
     const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
-    hipLaunchKernelGGL(k, dim3(grid), dim3(P::kThreads), P::kLdsBytes, s, g);
+    GemmArgs gg = g;
+    gg.ngroup = column_group(g.N / 256, g.K);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::kThreads), P::kLdsBytes, s, gg);
   } else if (g.M % 256 == 0 && g.N % 256 == 0) {
     using G = GemmKernel<256, 256, 4, 2, EPI, T>;
     auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;

@@ -76,6 +76,7 @@ struct GemmArgs {
   void* out_vt;         // kEpiQkv: V^T [M/S * heads][64][S]
   const void* resid_bf16;    // kEpiBiasResidBf16: [M, N] (type T)
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
+  int ngroup;           // column tiles per scheduling group (divides N / 256; 0 = all of them)
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };
 
@@ -391,8 +392,12 @@ struct GemmKernel {
     const int cnt = q + (xcd < r ? 1 : 0), start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int t = p + it * nb_x;
     if (t >= cnt) return false;
-    m0 = ((start + t) / tn) * BM;
-    n0 = ((start + t) % tn) * BN;
+    // tile id -> (m, n): n runs fastest inside a group of a.ngroup column tiles, then m, then the group - so the
+    // workgroups of an XCD that run at the same time share ngroup weight panels (kept L2-resident) instead of all tn
+    const int id = start + t, grp = a.ngroup > 0 ? a.ngroup : tn, per = (a.M / BM) * grp;
+    const int ng = id / per, rem = id - ng * per;
+    m0 = (rem / grp) * BM;
+    n0 = (ng * grp + rem % grp) * BN;
     return true;
   }
 
