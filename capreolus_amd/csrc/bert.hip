@@ -34,7 +34,7 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-// One wave per token: v = LayerNorm(x) over H (H % 256 == 0 is NOT required; H % 4 == 0, H <= 1024).
+// One wave per token: v = LayerNorm(x) over H (H % 8 == 0, H <= 1024; 16-byte accesses on the 16-bit stream).
 // MODE 0: x = word[id] + pos[s] + type[seg]  (fp32 embedding tables);  MODE 1: x = pre[token] (bf16 pre-LN sum).
 // Output: bf16 (the activation stream is bf16 end to end; statistics and the affine are fp32).
 template <int MODE, typename T>
@@ -44,12 +44,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
                                                  int type_vocab, int S, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int64_t M, int H,
                                                  T* xb, int* status) {
-  using bf16x4 = typename Half<T>::x4;
+  // one wave per token row, 8 elements (16 bytes of the 16-bit stream) per lane and step; H <= 1024
+  using bf16x8 = typename Half<T>::x8;
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= M) return;
-  const int nchunk = H >> 2;  // float4 chunks per row
-  float4 v[4];
+  const int nchunk = H >> 3;
+  float v[2][8];
   const float* r0 = nullptr;
   const float* r1 = nullptr;
   const float* r2 = nullptr;
@@ -66,49 +67,57 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
   }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
-      float4 x;
-      if (MODE == 1) {
-        const bf16x4 b = reinterpret_cast<const bf16x4*>(pre + tok * H)[c];
-        x = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
-      } else if (MODE == 2) {  // residual sum in fp32: projection output + the stream row it will replace
-        const bf16x4 b = reinterpret_cast<const bf16x4*>(pre + tok * H)[c];
-        const bf16x4 r = reinterpret_cast<const bf16x4*>(xb + tok * H)[c];
-        x = make_float4((float)b[0] + (float)r[0], (float)b[1] + (float)r[1], (float)b[2] + (float)r[2], (float)b[3] + (float)r[3]);
-      } else {
-        x = reinterpret_cast<const float4*>(r0)[c];
-      }
       if (MODE == 0) {
-        const float4 y = reinterpret_cast<const float4*>(r1)[c], z = reinterpret_cast<const float4*>(r2)[c];
-        x.x += y.x + z.x; x.y += y.y + z.y; x.z += y.z + z.z; x.w += y.w + z.w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 x = reinterpret_cast<const float4*>(r0)[2 * c + h], y = reinterpret_cast<const float4*>(r1)[2 * c + h],
+                       z = reinterpret_cast<const float4*>(r2)[2 * c + h];
+          v[i][4 * h + 0] = x.x + (y.x + z.x); v[i][4 * h + 1] = x.y + (y.y + z.y);
+          v[i][4 * h + 2] = x.z + (y.z + z.z); v[i][4 * h + 3] = x.w + (y.w + z.w);
+        }
+      } else {
+        const bf16x8 b = reinterpret_cast<const bf16x8*>(pre + tok * H)[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (float)b[e];
+        if (MODE == 2) {  // residual sum in fp32: projection output + the stream row it will replace
+          const bf16x8 r = reinterpret_cast<const bf16x8*>(xb + tok * H)[c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] += (float)r[e];
+        }
       }
-      v[i] = x;
-      s += (x.x + x.y) + (x.z + x.w);
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) s += (v[i][e] + v[i][e + 1]) + (v[i][e + 2] + v[i][e + 3]);
     }
   }
   const float mean = wave_sum64(s) / (float)H;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
     if (lane + 64 * i < nchunk) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-      q += (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        const float a = v[i][e] - mean, b = v[i][e + 1] - mean, c = v[i][e + 2] - mean, d = v[i][e + 3] - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
     }
   const float rstd = rsqrtf(wave_sum64(q) / (float)H + kLnEps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * g.x + b.x;
-      o.y = (v[i].y - mean) * rstd * g.y + b.y;
-      o.z = (v[i].z - mean) * rstd * g.z + b.z;
-      o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      bf16x4 ob = {(T)o.x, (T)o.y, (T)o.z, (T)o.w};
-      reinterpret_cast<bf16x4*>(xb + tok * H)[c] = ob;
+      bf16x8 ob;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[2 * c + h], b = reinterpret_cast<const float4*>(beta)[2 * c + h];
+        ob[4 * h + 0] = (T)((v[i][4 * h + 0] - mean) * rstd * g.x + b.x);
+        ob[4 * h + 1] = (T)((v[i][4 * h + 1] - mean) * rstd * g.y + b.y);
+        ob[4 * h + 2] = (T)((v[i][4 * h + 2] - mean) * rstd * g.z + b.z);
+        ob[4 * h + 3] = (T)((v[i][4 * h + 3] - mean) * rstd * g.w + b.w);
+      }
+      reinterpret_cast<bf16x8*>(xb + tok * H)[c] = ob;
     }
   }
 }
