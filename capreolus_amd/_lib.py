@@ -56,6 +56,8 @@ SIGNATURES = {
     "capamd_bert_maxp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
+    "capamd_debug_ffn1_timing": (None, [_i]),
+    "capamd_debug_ffn1_timing_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 

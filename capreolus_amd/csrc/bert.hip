@@ -12,6 +12,8 @@
 #include "bert_gemm.cuh"
 #include "capreolus_amd.h"
 #include <stdlib.h>
+#include <utility>
+#include <vector>
 
 using namespace capamd;
 
@@ -310,6 +312,25 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
+// profiling hook (capamd_debug_ffn1_timing): HIP events around the FFN1 launches of the timed forward passes
+struct Ffn1Timing {
+  static inline bool on = false;
+  static inline std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  static inline int64_t rows = 0;
+  static void begin(hipStream_t s) {
+    if (!on) return;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    ev.emplace_back(a, b);
+    hipEventRecord(a, s);
+  }
+  static void end(hipStream_t s, int64_t m) {
+    if (!on) return;
+    hipEventRecord(ev.back().second, s);
+    rows += m;
+  }
+};
+
 struct Workspace {
   uint16_t* xb;   // [M, H] activation / residual stream      (16-bit type T of the model: bf16 or fp16)
   uint16_t* q;    // [M, H]
@@ -386,7 +407,9 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
                          0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status);
       // feed-forward: 768 -> 3072 (GELU) -> 768, residual + LayerNorm
       g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
+      Ffn1Timing::begin(s);
       e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
+      Ffn1Timing::end(s, M);
       if (e != hipSuccess) break;
       g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.out_bf16 = w.pre;
       e = launch_gemm<kEpiBiasBf16, T>(g, s);
@@ -488,6 +511,20 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 }
 
 /* building blocks, exported for unit tests and for callers that want the encoder pieces */
+void capamd_debug_ffn1_timing(int enable) { Ffn1Timing::on = enable != 0; }
+int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows) {
+  if (!total_ms || !launches || !rows) return CAPAMD_ERR_ARG;
+  double t = 0;
+  for (auto& p : Ffn1Timing::ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess) return CAPAMD_ERR_LAUNCH;
+    t += ms;
+    hipEventDestroy(p.first); hipEventDestroy(p.second);
+  }
+  *total_ms = t; *launches = (int64_t)Ffn1Timing::ev.size(); *rows = Ffn1Timing::rows;
+  Ffn1Timing::ev.clear(); Ffn1Timing::rows = 0;
+  return CAPAMD_OK;
+}
 static unsigned long long* g_gemm_dbg = nullptr;
 void capamd_debug_set_gemm_stamps(void* p) { g_gemm_dbg = (unsigned long long*)p; }  /* profiling hook (scripts/gemm_timeline.py) */
 

@@ -182,6 +182,12 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
 /* Profiling hook: when non-NULL, capamd_bert_gemm blocks write up to 32 s_memtime stamps each into
  * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off (the default). */
 void capamd_debug_set_gemm_stamps(void* stamps);
+/* Profiling hook used by bench.py (the `roofline` object): while enabled, capamd_bert_maxp_forward brackets every
+ * launch of its dominant kernel (the FFN1 GEMM, bias + GELU) with HIP events on the caller's stream;
+ * capamd_debug_ffn1_timing_read synchronises those events, returns the summed duration in milliseconds and the
+ * number of launches since the last read, and clears the list.  Off by default. */
+void capamd_debug_ffn1_timing(int enable);
+int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows);
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
                               int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream);
 

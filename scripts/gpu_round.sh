@@ -21,7 +21,9 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/knrm_write -o k
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/knrm_tcc -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/knrm_uni_fetch -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --uniform-ids > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/drmm_fetch -o drmm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --model drmm > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/bert_mfma -o bert -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/bert_mfma -o bert -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
 cd $R
+timeout 200 python scripts/gemm_bench.py 2>/dev/null | tail -5 > gpurun_out/gemm_bench.txt; cat gpurun_out/gemm_bench.txt
+bash scripts/pmc_gemm_vs_vendor.sh > /dev/null 2>&1; cat gpurun_out/gemm_vs_vendor.txt | cut -c1-220
 for f in $(find $P -name "*.csv" -size -3000k); do d=gpurun_out/prof/$(basename $(dirname $f)); mkdir -p $d; cp $f $d/; done
 ls gpurun_out/prof/*/ | head -40
