@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAPAMD_LIB_PATH") or os.path.join(_HERE, "csrc", "libcapreolus_amd.so")  # override: profiling builds only
 
 OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
-STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV = 1, 2, 4
+STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV, STATUS_SCORE_NAN, STATUS_TIE_RANGE = 1, 2, 4, 8, 16
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -55,6 +55,8 @@ SIGNATURES = {
     "capamd_bert_workspace_bytes": (_i64, [_mp, _i, _i64, _i64]),
     "capamd_bert_maxp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "capamd_rank_candidates": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "capamd_ndcg_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
     "capamd_debug_ffn1_timing": (None, [_i]),
     "capamd_debug_ffn1_timing_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),

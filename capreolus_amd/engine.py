@@ -57,6 +57,9 @@ class StatusWord:
                 msgs.append("a query term id is >= the embedding table size")
             if bits & _lib.STATUS_QUERY_OOV:
                 msgs.append("DRMM cannot score an OOV (negative) query term id (reference DRMM.py:109 raises IndexError)")
+            if bits & (_lib.STATUS_SCORE_NAN | _lib.STATUS_TIE_RANGE):
+                raise ValueError("ranking: " + ("a score is NaN; " if bits & _lib.STATUS_SCORE_NAN else "") +
+                                 ("a tie-break rank is outside 0..n-1" if bits & _lib.STATUS_TIE_RANGE else ""))
             raise IndexError("index out of range in self: " + "; ".join(msgs))
 
 

@@ -218,6 +218,27 @@ class PytorchTrainer:
             write_trec_run(preds, pred_fn)
         return preds
 
+    def evaluate_resident(self, reranker, store, qid_to_docids, qrels, k=20):
+        """Dev-set nDCG@k of `reranker` over a device-resident candidate store without bringing the scores to the host
+        (SURVEY.md §8f row N2): scoring kernels -> `capamd_ndcg_cut`; only one fp64 per query is copied back.  The value
+        equals `evaluator.eval_runs(predict(...), qrels, ["ndcg_cut_k"])` of the reference (mean over the queries that have
+        qrels; scores rounded to fp16 first, as `predict` stores them)."""
+        from .. import ranking
+
+        reranker.model.to(store.device).eval()
+        keys, pq, pd = store.pairs(qid_to_docids)
+        step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(len(keys), 1)
+        with torch.no_grad():
+            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, len(keys), step)]
+        scores = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
+        rel, tie, idcg, offsets = ranking.eval_arrays(qid_to_docids, qrels, k, store.device)
+        per_query = ranking.ndcg_cut(scores, offsets, rel, tie, idcg, k=k)
+        from ..engine import status_word
+
+        status_word(store.device).raise_if_set()
+        judged = torch.tensor([q in qrels for q in qid_to_docids], dtype=torch.bool, device=store.device)
+        return float(per_query[judged].mean().item()) if bool(judged.any()) else 0.0
+
     def predict(self, reranker, pred_data, pred_fn=None):
         """Scores every (qid, docid) of `pred_data`; returns {qid: {docid: score}} on every rank and
         writes the TREC run to `pred_fn` (rank 0)."""

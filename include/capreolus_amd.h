@@ -41,6 +41,8 @@ extern "C" {
 #define CAPAMD_STATUS_DOC_ID_RANGE 1   /* a document term id >= V        (torch raises IndexError) */
 #define CAPAMD_STATUS_QUERY_ID_RANGE 2 /* a query term id >= V */
 #define CAPAMD_STATUS_QUERY_OOV 4      /* negative query id in DRMM      (reference DRMM.py:109 raises IndexError) */
+#define CAPAMD_STATUS_SCORE_NAN 8      /* a NaN score reached the ranking kernels (ranked last) */
+#define CAPAMD_STATUS_TIE_RANGE 16     /* capamd_ndcg_cut: a tie-break rank outside 0..n-1 */
 
 /* library identity */
 int capamd_version(void);
@@ -179,17 +181,38 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
 /* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.
  * q, k: bf16 [n_passages*S, hidden]; vt: bf16 [n_passages*heads, 64, S]; ctx: bf16 [n_passages*S, hidden];
  * mask int64 [n_passages, S]. */
-/* Profiling hook: when non-NULL, capamd_bert_gemm blocks write up to 32 s_memtime stamps each into
- * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off (the default). */
-void capamd_debug_set_gemm_stamps(void* stamps);
-/* Profiling hook used by bench.py (the `roofline` object): while enabled, capamd_bert_maxp_forward brackets every
- * launch of its dominant kernel (the FFN1 GEMM, bias + GELU) with HIP events on the caller's stream;
- * capamd_debug_ffn1_timing_read synchronises those events, returns the summed duration in milliseconds and the
- * number of launches since the last read, and clears the list.  Off by default. */
-void capamd_debug_ffn1_timing(int enable);
-int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows);
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
                               int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream);
+
+/* ---- ranking of scored candidate lists ---------------------------------------------
+ * What follows the scoring call in the reference, kept on the device:
+ *   - score.astype(np.float16)                         capreolus/trainer/pytorch.py:346-348
+ *   - Searcher.write_trec_run's per-query stable sort  capreolus/searcher/__init__.py:48-58
+ *   - trec_eval's ndcg_cut_k behind evaluator.py:55-85 (score desc, ties by docid desc, gain = level, log2 discount)
+ * scores fp32 [total]; offsets int64 [n_queries + 1] (CSR: query q owns scores[offsets[q] .. offsets[q+1])),
+ * max_candidates >= the longest list (<= 16384).
+ * capamd_rank_candidates: out_idx int32 [n_queries, k] = positions inside the query's list in run-file order
+ *   (rounded score descending, equal scores in list order; -1 beyond the list), out_f16 uint16 [n_queries, k] = the
+ *   rounded scores' fp16 bits.
+ * capamd_ndcg_cut (k <= 256): rel int32 [total] relevance level of each candidate (0 = unjudged), tie int32 [total] =
+ *   the candidate's rank in docid-descending order inside its query (a permutation of 0..n-1), idcg fp64 [n_queries] =
+ *   the ideal DCG@k from the query's qrels (host side); out fp64 [n_queries] = nDCG@k (0 when idcg is 0).
+ * Status bits: CAPAMD_STATUS_SCORE_NAN, CAPAMD_STATUS_TIE_RANGE. */
+int capamd_rank_candidates(const float* scores, const int64_t* offsets, int n_queries, int max_candidates, int k,
+                           int32_t* out_idx, uint16_t* out_f16, int* status, void* stream);
+int capamd_ndcg_cut(const float* scores, const int64_t* offsets, const int32_t* rel, const int32_t* tie, const double* idcg,
+                    int n_queries, int max_candidates, int k, double* out, int* status, void* stream);
+
+/* ---- profiling hooks (off by default; not part of the scoring interface) -----------------------------------
+ * capamd_debug_set_gemm_stamps: when non-NULL, capamd_bert_gemm blocks write up to 32 s_memtime stamps each into
+ * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off.
+ * capamd_debug_ffn1_timing (used by bench.py's `roofline` object): while enabled, capamd_bert_maxp_forward brackets
+ * every launch of its dominant kernel (the FFN1 GEMM, bias + GELU) with HIP events on the caller's stream;
+ * capamd_debug_ffn1_timing_read synchronises those events, returns the summed duration in milliseconds, the number of
+ * launches and the summed GEMM rows since the last read, and clears the list. */
+void capamd_debug_set_gemm_stamps(void* stamps);
+void capamd_debug_ffn1_timing(int enable);
+int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from capreolus_amd import engine, synthetic
+from capreolus_amd import engine, run_io, synthetic
 from capreolus_amd.reranker import DRMM, KNRM
 from oracle import cpu as oracle
 from tests.helpers import DRMM_CASES, KNRM_CASES, REL_TOL, knrm_weights, load_case, rank_order, rel_err
@@ -347,6 +347,115 @@ def test_predict_resident_ranklist():
     preds = PytorchTrainer({"evalbatch": 64}).predict_resident(r, store, q2d)
     got = np.array([preds["301"][f"d{i}"] for i in range(B)], dtype=np.float16)
     assert (got == c["ref_scores_f16"]).mean() > 0.98
+
+
+# ---- row N2: fp16 rounding + run-file order + nDCG@k on the device vs the host twins (run_io) --------------------------
+def _ranking_case(seed, counts, coarse):
+    rng = np.random.default_rng(seed)
+    total = int(sum(counts))
+    scores = rng.normal(size=total).astype(np.float32) * (3.0 if not coarse else 0.02)
+    if coarse:  # few distinct fp16 values -> many ties
+        scores = np.round(scores * 40) / 40
+    if total > 12:
+        scores[3] = 0.0
+        scores[7] = -0.0
+        scores[5] = 70000.0   # rounds to +inf in fp16
+        scores[11] = 1e-8     # fp16 subnormal range -> 0
+    q2d, k0 = {}, 0
+    for qi, n in enumerate(counts):
+        # docids whose string order differs from their list order
+        q2d[str(100 - qi)] = [f"D{(i * 7919 + qi) % 100003:06d}" for i in range(n)]
+        k0 += n
+    return scores, q2d
+
+
+@pytest.mark.parametrize("counts,coarse", [((1000,), False), ((1000, 37, 1, 0, 513), True), ((16384, 2), True), ((200,) * 64, True)])
+def test_rank_candidates_matches_run_writer(counts, coarse, tmp_path):
+    from capreolus_amd import ranking
+
+    scores, q2d = _ranking_case(sum(counts), counts, coarse)
+    off = ranking.offsets_of(counts, DEV)
+    k = 1000
+    idx, f16 = ranking.rank_candidates(torch.as_tensor(scores, device=DEV), off, k)
+    engine.status_word(torch.device(DEV)).raise_if_set()
+    idx, f16 = idx.cpu().numpy(), f16.cpu().numpy()
+    # the reference's host path: astype(float16).item() into a dict, then write_trec_run's sort
+    preds, pos = {}, 0
+    for qid, docs in q2d.items():
+        preds[qid] = {d: scores[pos + i].astype(np.float16).item() for i, d in enumerate(docs)}
+        pos += len(docs)
+    run_io.write_trec_run(preds, tmp_path / "run.txt")
+    want = {}
+    for line in open(tmp_path / "run.txt"):
+        qid, _, docid, rank, score, _ = line.split()
+        want.setdefault(qid, []).append((docid, float(score)))
+    for qi, (qid, docs) in enumerate(q2d.items()):
+        n = min(len(docs), k)
+        got = [(docs[i], float(s)) for i, s in zip(idx[qi, :n], f16[qi, :n])]
+        assert got == want.get(qid, [])[:n], qid
+        assert (idx[qi, n:] == -1).all()
+
+
+@pytest.mark.parametrize("counts,coarse", [((1000,) * 8, True), ((1000, 37, 1, 0, 513), False), ((5000, 20), True)])
+def test_ndcg_cut_matches_host(counts, coarse):
+    from capreolus_amd import ranking
+
+    scores, q2d = _ranking_case(7 + sum(counts), counts, coarse)
+    rng = np.random.default_rng(3)
+    qrels = {}
+    for qi, (qid, docs) in enumerate(q2d.items()):
+        if qi == 2:
+            continue  # a query without qrels
+        qrels[qid] = {d: int(rng.integers(-1, 4)) for d in docs if rng.random() < 0.3}
+        qrels[qid]["UNRETRIEVED"] = 3  # judged documents outside the candidate list count in the ideal ranking
+    for k in (20, 10):
+        rel, tie, idcg, off = ranking.eval_arrays(q2d, qrels, k, DEV)
+        got = ranking.ndcg_cut(torch.as_tensor(scores, device=DEV), off, rel, tie, idcg, k=k).cpu().numpy()
+        engine.status_word(torch.device(DEV)).raise_if_set()
+        preds, pos = {}, 0
+        for qid, docs in q2d.items():
+            preds[qid] = {d: scores[pos + i].astype(np.float16).item() for i, d in enumerate(docs)}
+            pos += len(docs)
+        want = run_io.ndcg_cut(qrels, preds, k)
+        for qi, qid in enumerate(q2d):
+            if qid in want:
+                assert abs(got[qi] - want[qid]) <= 1e-12, (qid, got[qi], want[qid])
+            else:
+                assert got[qi] == 0.0
+
+
+def test_ranking_flags_nan_and_bad_ties():
+    from capreolus_amd import ranking
+
+    s = torch.tensor([1.0, float("nan"), 0.5], device=DEV)
+    off = ranking.offsets_of([3], DEV)
+    idx, _ = ranking.rank_candidates(s, off, 3)
+    assert idx.cpu().tolist() == [[0, 2, 1]]  # NaN ranked last
+    with pytest.raises(ValueError):
+        engine.status_word(torch.device(DEV)).raise_if_set()
+    rel = torch.zeros(3, dtype=torch.int32, device=DEV)
+    tie = torch.tensor([0, 1, 7], dtype=torch.int32, device=DEV)
+    ranking.ndcg_cut(torch.tensor([1.0, 2.0, 3.0], device=DEV), off, rel, tie, torch.ones(1, dtype=torch.float64, device=DEV), k=2)
+    with pytest.raises(ValueError):
+        engine.status_word(torch.device(DEV)).raise_if_set()
+
+
+def test_evaluate_resident_equals_host_pipeline():
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "ranklist")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+    q2d = {"301": [f"d{i}" for i in range(B // 2)], "302": [f"d{i}" for i in range(B // 2, B)]}
+    store = CandidateStore.from_id2vec(DEV, q2d, lambda q, d: {"query": c["query"][int(d[1:])], "posdoc": c["posdoc"][int(d[1:])],
+                                                              "query_idf": c["query_idf"][int(d[1:])]})
+    rng = np.random.default_rng(0)
+    qrels = {q: {d: int(rng.integers(0, 3)) for d in ds if rng.random() < 0.2} for q, ds in q2d.items()}
+    tr = PytorchTrainer({"evalbatch": 64})
+    got = tr.evaluate_resident(r, store, q2d, qrels, k=20)
+    want = run_io.mean_ndcg_cut(qrels, tr.predict_resident(r, store, q2d), 20)
+    assert abs(got - want) <= 1e-12
 
 
 # ---- training step (row N3): HIP features + Jacobian diagonals vs autograd through the ATen port on CPU ----------
