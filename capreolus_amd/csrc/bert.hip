@@ -1,13 +1,13 @@
 // BERT-MaxP passage scoring for gfx950: PTBERTMaxP_Class.predict_step (reference
 // capreolus/reranker/ptBERTMaxP.py:67-96) with the transformers BertForSequenceClassification it
-// calls at :82 re-built as hand-written kernels: embedding sum + LayerNorm, bf16 MFMA GEMMs with
-// fused bias / GELU / residual epilogues (bert_gemm.cuh), fused exact-softmax attention
-// (bert_attn.cuh), LayerNorm, pooler + classifier, passage pooling.
+// calls at :82 re-built as hand-written kernels: embedding sum + LayerNorm, 16-bit MFMA GEMMs with
+// fused bias / GELU / QKV epilogues (bert_gemm.cuh), fused exact-softmax attention (bert_attn.cuh),
+// residual + LayerNorm, pooler + classifier, passage pooling.
 //
-// Precision: the activation stream (incl. the residual path) is bf16 end to end; every accumulation, the
-// pre-LayerNorm sum (one rounding), LayerNorm statistics, softmax and the pooler/classifier are fp32.
-// (A fp32 residual stream was measured to give the same 6e-3 logit error: the error is set by the bf16
-// GEMM operands, not by the residual precision.)
+// Precision: the activation stream is 16-bit end to end (fp16 by default - the reference's autocast type - or
+// bf16, `compute_dtype` of the model); every accumulation, the residual sums (added in fp32 inside the LayerNorm
+// pass, one rounding), LayerNorm statistics, softmax and the pooler/classifier are fp32.  (A fp32 residual stream
+// was measured to give the same logit error: the error is set by the 16-bit GEMM operands.)
 #include "bert_attn.cuh"
 #include "bert_gemm.cuh"
 #include "capreolus_amd.h"
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
                                                  const float* __restrict__ pos, const float* __restrict__ type, int vocab,
                                                  int type_vocab, int S, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int64_t M, int H,
-                                                 T* xb, int* status) {
+                                                 T* xb, int* status, int out_cm) {
   // one wave per token row, 8 elements (16 bytes of the 16-bit stream) per lane and step; H <= 1024
   using bf16x8 = typename Half<T>::x8;
   const int lane = threadIdx.x & 63;
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
         ob[4 * h + 2] = (T)((v[i][4 * h + 2] - mean) * rstd * g.z + b.z);
         ob[4 * h + 3] = (T)((v[i][4 * h + 3] - mean) * rstd * g.w + b.w);
       }
-      reinterpret_cast<bf16x8*>(xb + tok * H)[c] = ob;
+      if (out_cm) *reinterpret_cast<bf16x8*>(xb + cm_offset(tok, c * 8, H)) = ob;   // chunk-major stream (bert_gemm.cuh)
+      else reinterpret_cast<bf16x8*>(xb + tok * H)[c] = ob;
     }
   }
 }
@@ -132,7 +133,9 @@ constexpr int kHeadPsg = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int64_t n_psg, int S, int H,
                                                    const float* __restrict__ pw, const float* __restrict__ pb,
-                                                   const float* __restrict__ cw, float* __restrict__ part) {
+                                                   const float* __restrict__ cw, float* __restrict__ part,
+                                                   const float* __restrict__ ln_mu, const float* __restrict__ ln_rstd,
+                                                   const float* __restrict__ ln_g, const float* __restrict__ ln_b) {
   __shared__ float cls[kHeadPsg][1024];
   __shared__ float wsum[4][kHeadPsg];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,8 +144,14 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int
 #pragma unroll
   for (int q = 0; q < kHeadPsg; ++q) {
     const int64_t psg = p0 + q < n_psg ? p0 + q : n_psg - 1;
-    const T* h = xf + psg * S * H;  // token 0 ([CLS]) of the passage
-    for (int i = tid; i < H; i += 256) cls[q][i] = (float)h[i];
+    const int64_t tok = psg * S;    // token 0 ([CLS]) of the passage
+    if (ln_mu) {  // fused-LayerNorm path: xf holds the chunk-major pre-LayerNorm sums of the last layer
+      const float mu = ln_mu[tok], rs = ln_rstd[tok];
+      for (int i = tid; i < H; i += 256) cls[q][i] = ((float)xf[cm_offset(tok, i, H)] - mu) * rs * ln_g[i] + ln_b[i];
+    } else {
+      const T* h = xf + tok * H;
+      for (int i = tid; i < H; i += 256) cls[q][i] = (float)h[i];
+    }
   }
   __syncthreads();
   float acc[kHeadPsg];
@@ -224,8 +233,15 @@ bool dims_ok(const capamd_bert_model* m) {
          (m->compute_dtype == 0 || m->compute_dtype == 1);
 }
 
-int64_t layer_blob_elems(int H, int F) { return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H; }
-int64_t layer_f32_floats(int H, int F) { return (int64_t)3 * H + H + H + H + F + H + H + H; }
+// LayerNorm folded into the GEMMs (bert_gemm.cuh) needs every encoder GEMM on the ping-pong kernel: N and K multiples of 256
+bool fused_capable(int H, int F) { return H % 256 == 0 && F % 256 == 0; }
+// per layer, 16-bit: wqkv [3H,H] | wo [H,H] | w1 [F,H] | w2 [H,F]   (+ wqkv' = wqkv . gamma_in | w1' = w1 . ln1_gamma when fused_capable)
+int64_t layer_blob_elems(int H, int F) {
+  return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H + (fused_capable(H, F) ? (int64_t)3 * H * H + (int64_t)F * H : 0);
+}
+// per layer, fp32: bqkv 3H | bo H | ln1g H | ln1b H | b1 F | b2 H | ln2g H | ln2b H
+//                | cs_qkv 3H | c_qkv 3H | cs_1 F | c_1 F | g_in H | bo + beta_in H | b2 + ln1b H      (folded-LayerNorm vectors)
+int64_t layer_f32_floats(int H, int F) { return (int64_t)9 * H + F + (int64_t)9 * H + 2 * F; }
 
 int num_cus() {
   static int n = [] {
@@ -275,41 +291,122 @@ int column_group(int tn, int K) {
   return best;
 }
 
+// Shapes the ping-pong kernel takes (buffer addressing: operands below 4 GiB).  CAPAMD_GEMM_KLOOP=halves selects the
+// older 256x256 kernel (k-half regions, 4x2 waves) for A/B runs; CAPAMD_GEMM_CM=0 keeps every activation row-major.
+bool pingpong_shape(int64_t M, int N, int K) {
+  static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
+  return pingpong && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
+}
+bool fused_ln_enabled() {  // CAPAMD_BERT_FUSED_LN=0 keeps the separate residual + LayerNorm passes (A/B runs)
+  static const bool on = [] { const char* e = getenv("CAPAMD_BERT_FUSED_LN"); return !(e && e[0] == '0'); }();
+  return on;
+}
+bool chunk_major_enabled() {
+  static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_CM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
-  // CAPAMD_GEMM_KLOOP=halves selects the older 256x256 kernel (k-half regions, 4x2 waves) for A/B runs
-  static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
-  if (pingpong && EPI != kEpiBiasResidBf16 && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 128 && (size_t)g.M * g.K < (1ull << 31) &&
-      (size_t)g.N * g.K < (1ull << 31)) {  // (buffer addressing: operands below 4 GiB)
-    using P = GemmPingPong<EPI, T>;
-    auto k = gemm_pingpong_kernel<EPI, T>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P::kLdsBytes);
-      if (e != hipSuccess) return e;
-      attr_set = true;
+  if constexpr (EPI != kEpiBiasResidBf16) {
+    if (pingpong_shape(g.M, g.N, g.K)) {
+      using P = GemmPingPong<EPI, T>;
+      auto k = gemm_pingpong_kernel<EPI, T>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+      GemmArgs gg = g;
+      gg.ngroup = column_group(g.N / 256, g.K);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(P::kThreads), P::kLdsBytes, s, gg);
+      return hipGetLastError();
     }
-    const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
-    GemmArgs gg = g;
-    gg.ngroup = column_group(g.N / 256, g.K);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(P::kThreads), P::kLdsBytes, s, gg);
-  } else if (g.M % 256 == 0 && g.N % 256 == 0) {
-    using G = GemmKernel<256, 256, 4, 2, EPI, T>;
-    auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
-    const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
-    hipLaunchKernelGGL(k, dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
-  } else {
-    using G = GemmKernel<64, 64, 2, 2, EPI, T>;
-    const int tiles = (g.N / 64) * (g.M / 64), cap = 4 * num_cus(), grid = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI, T>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
   }
-  return hipGetLastError();
+  if constexpr (EPI == kEpiResidStats) {
+    return hipErrorInvalidValue;  // the fused-LayerNorm producer exists on the ping-pong kernel only
+  } else {
+    if (g.a_cm || g.out_cm || g.ln_mu) return hipErrorInvalidValue;  // layouts / folded LayerNorm: ping-pong kernel only
+    if (g.M % 256 == 0 && g.N % 256 == 0) {
+      using G = GemmKernel<256, 256, 4, 2, EPI, T>;
+      auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+      hipLaunchKernelGGL(k, dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
+    } else {
+      using G = GemmKernel<64, 64, 2, 2, EPI, T>;
+      const int tiles = (g.N / 64) * (g.M / 64), cap = 4 * num_cus(), grid = tiles < cap ? tiles : cap;
+      hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, 2, EPI, T>), dim3(grid), dim3(G::kThreads), G::kLdsBytes, s, g);
+    }
+    return hipGetLastError();
+  }
+}
+
+// ---- folded-LayerNorm packing (once per model) ---------------------------------------------------------------
+// one wave per output row n of a LayerNorm-consuming weight matrix:
+//   W'[n][k] = (T)(gamma[k] W[n][k] - mean_k(gamma W[n]))    the row is CENTRED: the normalised activations sum to zero over
+//              k, so a constant added to a weight row changes nothing - but it removes the common-mode term mu_m * cs_n
+//              that the folded form would otherwise have to cancel in fp32 (cs_n shrinks to the rounding residue)
+//   cs[n] = sum_k (float)W'[n][k]   (of the ROUNDED operand the MFMA sees),   c[n] = bias[n] + sum_k beta[k] W[n][k]
+template <typename T>
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ bias,
+                                                        const float* __restrict__ beta, T* __restrict__ Wp, float* __restrict__ cs,
+                                                        float* __restrict__ c, int rows, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= rows) return;
+  const float* w = W + (int64_t)n * K;
+  float m = 0.f, b = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    m = __builtin_fmaf(gamma[k], w[k], m);
+    b = __builtin_fmaf(beta[k], w[k], b);
+  }
+  m = wave_sum64(m) / (float)K;
+  b = wave_sum64(b);
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const T r = (T)(gamma[k] * w[k] - m);
+    Wp[(int64_t)n * K + k] = r;
+    a += (float)r;
+  }
+  a = wave_sum64(a);
+  if (lane == 0) { cs[n] = a; c[n] = bias[n] + b; }
+}
+__global__ void vec_fill_kernel(float* __restrict__ out, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
+}
+__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+// row statistics of a pre-LayerNorm sum from the partials its producing GEMM wrote (kEpiResidStats), fixed order
+__global__ void ln_stats_kernel(const float* __restrict__ part, int nslot, int H, int64_t M, float* __restrict__ mu, float* __restrict__ rstd,
+                                float2* __restrict__ mr) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nslot; ++k) {
+    const float2 p = *reinterpret_cast<const float2*>(part + (m * nslot + k) * 2);
+    s1 += p.x;
+    s2 += p.y;
+  }
+  const float mean = s1 / (float)H;
+  const float var = fmaxf(s2 / (float)H - mean * mean, 0.f);
+  const float r = rsqrtf(var + kLnEps);
+  mu[m] = mean;    // separate arrays: float4 loads of 4 consecutive rows (transposed V^T epilogue)
+  rstd[m] = r;
+  mr[m] = make_float2(mean, r);  // interleaved: one load per row where a lane owns a row
+}
+__global__ void neutral_stats_kernel(int64_t M, float* __restrict__ mu, float* __restrict__ rstd, float2* __restrict__ mr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    mu[i] = 0.f; rstd[i] = 1.f; mr[i] = make_float2(0.f, 1.f);
+  }
 }
 
 // profiling hook (capamd_debug_ffn1_timing): HIP events around the FFN1 launches of the timed forward passes
@@ -341,6 +438,10 @@ struct Workspace {
   uint16_t* mid;  // [M, F]
   float* logits;  // [B*P] (whole call)
   int* cnt;       // avg denominator
+  // fused LayerNorm: row-statistic partials of the GEMM that wrote a pre-LayerNorm sum, and (mu, rstd) of the tensors in xb / pre
+  float* part;    // [M][H/64][2]
+  float* mu_x; float* rstd_x; float* mu_p; float* rstd_p;  // [M] each
+  float2* mr_x; float2* mr_p;                              // [M] the same, interleaved
 };
 
 size_t ws_bytes_for(int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_total) {
@@ -349,6 +450,8 @@ size_t ws_bytes_for(int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_total) 
   auto add = [&](size_t x) { b += (x + 255) & ~(size_t)255; };
   add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * H * 2);
   add((size_t)M * H * 2); add((size_t)M * H * 2); add((size_t)M * F * 2); add((size_t)n_psg_total * 4); add(256);
+  add((size_t)M * (H / 64) * 8); add((size_t)M * 4); add((size_t)M * 4); add((size_t)M * 4); add((size_t)M * 4);
+  add((size_t)M * 8); add((size_t)M * 8);
   return b;
 }
 
@@ -365,6 +468,10 @@ Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_to
   w.mid = (uint16_t*)take((size_t)M * F * 2);
   w.logits = (float*)take((size_t)n_psg_total * 4);
   w.cnt = (int*)take(256);
+  w.part = (float*)take((size_t)M * (H / 64) * 8);
+  w.mu_x = (float*)take((size_t)M * 4); w.rstd_x = (float*)take((size_t)M * 4);
+  w.mu_p = (float*)take((size_t)M * 4); w.rstd_p = (float*)take((size_t)M * 4);
+  w.mr_x = (float2*)take((size_t)M * 8); w.mr_p = (float2*)take((size_t)M * 8);
   return w;
 }
 
@@ -381,8 +488,69 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     const int64_t* ids_mb = ids + p0 * S;
     const int64_t* mask_mb = mask + p0 * S;
     const int64_t* seg_mb = seg + p0 * S;
+    // LayerNorm folded into the GEMMs: every encoder GEMM of this microbatch must be a ping-pong shape
+    const bool fused = fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
+                       pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
     hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, (T*)w.xb, status);
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, (T*)w.xb, status, fused ? 1 : 0);
+    if (fused) {
+      // Activation stream: xb and pre hold UN-normalised pre-LayerNorm sums in the chunk-major layout, (mu, rstd) of
+      // their rows next to them; no LayerNorm pass exists.  Consumers fold the normalisation into their epilogue
+      // (weights pre-scaled by gamma when packed), producers rebuild the normalised residual on the fly and emit the row
+      // statistics of what they write.  Layer 0 reads the (normalised) embedding output: neutral statistics.
+      hipLaunchKernelGGL(neutral_stats_kernel, dim3(256), dim3(256), 0, s, M, w.mu_x, w.rstd_x, w.mr_x);
+      const float *last_g = nullptr, *last_b = nullptr;
+      for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
+        const T* wl = blob + (int64_t)l * layer_blob_elems(H, F);
+        const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
+        const T *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
+        const T *wqkv_s = w2 + (int64_t)H * F, *w1_s = wqkv_s + (int64_t)3 * H * H;
+        const float *bqkv = fl, *ln1g = fl + 4 * H, *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
+        const float* fx = fl + 9 * H + F;
+        const float *cs_qkv = fx, *c_qkv = fx + 3 * H, *cs_1 = fx + 6 * H, *c_1 = fx + 6 * H + F, *g_in = fx + 6 * H + 2 * F, *bo_f = g_in + H,
+                    *b2_f = bo_f + H;
+        GemmArgs g{};
+        g.H = H; g.S = S; g.heads = m->heads; g.M = (int)M;
+        // QKV projection of LN_in(xb): layer 0 reads the normalised embeddings with the plain weights
+        g.A = w.xb; g.a_cm = 1; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
+        if (l == 0) { g.W = wqkv; g.bias = bqkv; }
+        else { g.W = wqkv_s; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
+        e = launch_gemm<kEpiQkv, T>(g, s);
+        if (e != hipSuccess) break;
+        AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
+        launch_attention<T>(at, S, (unsigned)(np * m->heads), s);
+        // pre = ctx Wo^T + bo + LN_in(xb)   (+ row statistics of pre)
+        g = GemmArgs{};
+        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.W = wo; g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
+        g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
+        e = launch_gemm<kEpiResidStats, T>(g, s);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_p, w.rstd_p, w.mr_p);
+        // mid = gelu(LN1(pre) W1^T + b1)
+        g = GemmArgs{};
+        g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
+        g.out_bf16 = w.mid; g.out_cm = 1;
+        Ffn1Timing::begin(s);
+        e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
+        Ffn1Timing::end(s, M);
+        if (e != hipSuccess) break;
+        // xb = mid W2^T + b2 + LN1(pre)   (+ row statistics of xb)
+        g = GemmArgs{};
+        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2; g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
+        g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
+        e = launch_gemm<kEpiResidStats, T>(g, s);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_x, w.rstd_x, w.mr_x);
+        last_g = ln2g; last_b = ln2b;
+      }
+      if (e != hipSuccess) break;
+      float* hpart = reinterpret_cast<float*>(w.pre);
+      hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
+                         m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)w.mu_x, (const float*)w.rstd_x, last_g, last_b);
+      hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
+      e = hipGetLastError();
+      continue;
+    }
     for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
       const T* wl = blob + (int64_t)l * layer_blob_elems(H, F);
       const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
@@ -404,28 +572,56 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       e = launch_gemm<kEpiBiasBf16, T>(g, s);
       if (e != hipSuccess) break;
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status);
+                         0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status, 0);
       // feed-forward: 768 -> 3072 (GELU) -> 768, residual + LayerNorm
-      g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid;
+      const bool cm = chunk_major_enabled() && pingpong_shape(M, F, H) && pingpong_shape(M, H, F);  // mid in the chunk-major layout (bert_gemm.cuh)
+      g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid; g.out_cm = cm;
       Ffn1Timing::begin(s);
       e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
       Ffn1Timing::end(s, M);
       if (e != hipSuccess) break;
-      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.out_bf16 = w.pre;
+      g.A = w.mid; g.W = w2; g.bias = b2; g.N = H; g.K = F; g.out_bf16 = w.pre; g.out_cm = 0; g.a_cm = cm;
       e = launch_gemm<kEpiBiasBf16, T>(g, s);
+      g.a_cm = 0;
       if (e != hipSuccess) break;
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status);
+                         0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status, 0);
     }
     if (e != hipSuccess) break;
     // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
     float* hpart = reinterpret_cast<float*>(w.pre);
     hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
-                       m->pooler_w, m->pooler_b, m->cls_w, hpart);
+                       m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr);
     hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
     e = hipGetLastError();
   }
   return e;
+}
+
+template <typename T>
+void pack_folded(const float* const* t, int64_t H, int64_t F, uint16_t* wb, float* fb, hipStream_t s) {
+  // gamma_in / beta_in: the LayerNorm whose output feeds this layer (t[16], t[17]; NULL for layer 0 = identity)
+  float* fx = fb + 9 * H + F;
+  float *cs_qkv = fx, *c_qkv = fx + 3 * H, *cs_1 = fx + 6 * H, *c_1 = fx + 6 * H + F, *g_in = fx + 6 * H + 2 * F, *bo_f = g_in + H, *b2_f = bo_f + H;
+  float* zeros = b2_f;  // scratch for beta_in = 0 until b2_f is written at the end
+  if (t[16]) {
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(8), dim3(256), 0, s, t[16], g_in, H);
+    hipLaunchKernelGGL(vec_add_kernel, dim3(8), dim3(256), 0, s, t[7], t[17], bo_f, H);
+  } else {
+    hipLaunchKernelGGL(vec_fill_kernel, dim3(8), dim3(256), 0, s, g_in, 1.f, H);
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(8), dim3(256), 0, s, t[7], bo_f, H);
+    hipLaunchKernelGGL(vec_fill_kernel, dim3(8), dim3(256), 0, s, zeros, 0.f, H);
+  }
+  const float* beta_in = t[17] ? t[17] : zeros;
+  T* wqkv_s = (T*)(wb + 4 * H * H + 2 * F * H);
+  T* w1_s = wqkv_s + 3 * H * H;
+  for (int part = 0; part < 3; ++part) {  // q, k, v
+    hipLaunchKernelGGL(fold_rows_kernel<T>, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, s, t[2 * part], (const float*)g_in, t[2 * part + 1], beta_in,
+                       wqkv_s + part * H * H, cs_qkv + part * H, c_qkv + part * H, (int)H, (int)H);
+  }
+  hipLaunchKernelGGL(fold_rows_kernel<T>, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, s, t[10], t[8], t[11], t[9], w1_s, cs_1, c_1, (int)F, (int)H);
+  hipLaunchKernelGGL(vec_add_kernel, dim3(8), dim3(256), 0, s, t[13], t[9], b2_f, H);  // b2 + ln1.beta (last: b2_f doubled as the zero vector)
 }
 
 template <typename T>
@@ -451,17 +647,18 @@ int64_t capamd_bert_blob_bytes(const capamd_bert_model* m) {
 }
 int64_t capamd_bert_layer_f32_floats(const capamd_bert_model* m) { return dims_ok(m) ? layer_f32_floats(m->hidden, m->ffn) : -1; }
 
-int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* const* t /* 16 device pointers, host array */,
+int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* const* t /* 18 device pointers, host array */,
                            void* blob, float* layer_f32, void* stream) {
   if (!dims_ok(m) || !t || !blob || !layer_f32 || layer < 0 || layer >= m->layers) return CAPAMD_ERR_ARG;
   for (int i = 0; i < 16; ++i)
     if (!t[i]) return CAPAMD_ERR_ARG;
+  if ((t[16] == nullptr) != (t[17] == nullptr)) return CAPAMD_ERR_ARG;
   const int64_t H = m->hidden, F = m->ffn;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   uint16_t* wb = (uint16_t*)blob + (int64_t)layer * layer_blob_elems(H, F);
   float* fb = layer_f32 + (int64_t)layer * layer_f32_floats(H, F);
-  // order of t: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b ffn1.w ffn1.b ffn2.w ffn2.b ln2.g ln2.b
+  // order of t: q.w q.b k.w k.b v.w v.b o.w o.b ln1.g ln1.b ffn1.w ffn1.b ffn2.w ffn2.b ln2.g ln2.b  [in.g in.b]
   struct { int src; int64_t off, n; } wcp[] = {{0, 0, H * H}, {2, H * H, H * H}, {4, 2 * H * H, H * H}, {6, 3 * H * H, H * H},
                                                {10, 4 * H * H, F * H}, {12, 4 * H * H + F * H, H * F}};
   for (auto& c : wcp) {
@@ -471,6 +668,10 @@ int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* c
   struct { int src; int64_t off, n; } fcp[] = {{1, 0, H}, {3, H, H}, {5, 2 * H, H}, {7, 3 * H, H}, {8, 4 * H, H}, {9, 5 * H, H},
                                                {11, 6 * H, F}, {13, 6 * H + F, H}, {14, 7 * H + F, H}, {15, 8 * H + F, H}};
   for (auto& c : fcp) hipLaunchKernelGGL(copy_f32_kernel, dim3(8), dim3(256), 0, s, t[c.src], fb + c.off, c.n);
+  if (fused_capable((int)H, (int)F)) {
+    if (m->compute_dtype == 1) pack_folded<_Float16>(t, H, F, wb, fb, s);
+    else pack_folded<__bf16>(t, H, F, wb, fb, s);
+  }
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
@@ -535,9 +736,44 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.M = M; g.N = N; g.K = K;
   g.dbg = g_gemm_dbg;
+  // layout bits of `epilogue`: the chunk-major activation layout exists only on the ping-pong kernel's shapes
+  g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
+  g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
+  epilogue &= 0xff;
+  if ((g.a_cm || g.out_cm) && (!pingpong_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
   if (dtype == 1) return gemm_dispatch<_Float16>(g, epilogue, resid, out, (hipStream_t)stream);
   if (dtype == 0) return gemm_dispatch<__bf16>(g, epilogue, resid, out, (hipStream_t)stream);
   return CAPAMD_ERR_ARG;
+}
+
+int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const float* ln_mu,
+                        const float* ln_rstd, const float* ln_mr, const float* ln_cs, const void* res_src, const float* res_mr,
+                        const float* res_gamma, float* stat_part, void* out, int dtype, void* stream) {
+  if (!A || !W || !bias || !out || !pingpong_shape(M, N, K) || (dtype != 0 && dtype != 1)) return CAPAMD_ERR_ARG;
+  (void)hipGetLastError();
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out_bf16 = out;
+  g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
+  g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
+  epilogue &= 0xff;
+  if (ln_mu) {
+    if (!ln_rstd || !ln_mr || !ln_cs) return CAPAMD_ERR_ARG;
+    g.ln_mu = ln_mu; g.ln_rstd = ln_rstd; g.ln_mr = (const float2*)ln_mr; g.ln_cs = ln_cs;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (epilogue == kEpiResidStats) {
+    if (!res_src || !res_mr || !res_gamma || !stat_part || !g.out_cm) return CAPAMD_ERR_ARG;
+    g.res_src = res_src; g.res_mr = (const float2*)res_mr; g.res_gamma = res_gamma; g.stat_part = stat_part;
+    e = dtype == 1 ? launch_gemm<kEpiResidStats, _Float16>(g, s) : launch_gemm<kEpiResidStats, __bf16>(g, s);
+  } else if (epilogue == kEpiBiasGeluBf16) {
+    e = dtype == 1 ? launch_gemm<kEpiBiasGeluBf16, _Float16>(g, s) : launch_gemm<kEpiBiasGeluBf16, __bf16>(g, s);
+  } else if (epilogue == kEpiBiasBf16) {
+    e = dtype == 1 ? launch_gemm<kEpiBiasBf16, _Float16>(g, s) : launch_gemm<kEpiBiasBf16, __bf16>(g, s);
+  } else {
+    return CAPAMD_ERR_ARG;
+  }
+  return e == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,

@@ -64,6 +64,7 @@ enum GemmEpilogue {
   kEpiBiasGeluBf16 = 1,  // out_bf16[m][n] = gelu(acc + bias[n])                      (erf GELU)
   kEpiQkv = 3,           // n < H: Q[m][n] = (acc+bias)/8 ; n < 2H: K[m][n-H] ; else V^T[(psg,head)][d][key]
   kEpiBiasResidBf16 = 4, // out_bf16[m][n] = acc + bias[n] + resid_bf16[m][n]         (pre-LayerNorm sum, bf16 stream)
+  kEpiResidStats = 5,    // chunk-major pre-LayerNorm sum with the residual re-normalised on the fly + row statistics (fused LayerNorm)
 };
 
 struct GemmArgs {
@@ -77,6 +78,20 @@ struct GemmArgs {
   const void* resid_bf16;    // kEpiBiasResidBf16: [M, N] (type T)
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
   int ngroup;           // column tiles per scheduling group (divides N / 256; 0 = all of them)
+  int a_cm, out_cm;     // A operand / output in the chunk-major activation layout (see cm_offset) instead of row-major
+  // ---- fused LayerNorm (see "LayerNorm folded into the GEMMs" below) ----
+  // consumer side: A holds the UN-normalised pre-LayerNorm sums P; with W' = W . gamma packed as the weight matrix,
+  //   LN(P) W^T + b  ==  rstd_m (acc - mu_m cs_n) + c_n ,   cs_n = sum_k W'[n][k],  c_n = b_n + sum_k beta_k W[n][k]  (passed as `bias`)
+  const float* ln_mu;   // [M] row means of A            (NULL: A is already normalised, plain bias epilogue)
+  const float* ln_rstd; // [M] 1 / sqrt(var + eps)
+  const float2* ln_mr;  // [M] the same two, interleaved (mu, rstd): one 8-byte load per row where a lane owns a row
+  const float* ln_cs;   // [N]
+  // producer side (kEpiResidStats): out = acc + bias' + resid,  resid = (R - rmu_m) rrstd_m rgamma_n   (+ beta folded into bias')
+  const void* res_src;  // [M, N] chunk-major: the un-normalised tensor the residual is the LayerNorm of (or an already
+                        // normalised tensor with rmu = 0, rrstd = 1, rgamma = 1 - the embedding output of layer 0)
+  const float2* res_mr;                        // [M] (mu, rstd) of the rows of R
+  const float* res_gamma;                      // [N]
+  float* stat_part;     // [M][N / 64][2]: (sum, sum of squares) of the 64 output columns each wave column writes
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };
 
@@ -84,6 +99,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #ifndef CAPAMD_PP_GLDS_POS
 #define CAPAMD_PP_GLDS_POS 2   // where a phase issues its LDS-DMA pair: 0 before its LDS reads, 1 after them, 2 after its first MFMA pair, 3 one after the first and one after the third pair
+#endif
+#ifndef CAPAMD_PP_A_NT
+#define CAPAMD_PP_A_NT 0   // 1: activation-panel LDS-DMA with the nt (streaming) cache policy - A/B builds only
 #endif
 #ifndef CAPAMD_GEMM_ABLATE
 #define CAPAMD_GEMM_ABLATE 0   // profiling builds only (ping-pong kernel): 1 skip the MFMAs, 2 skip the LDS-DMA fill
@@ -113,6 +131,16 @@ __device__ __forceinline__ int swz_chunk4(int row, int chunk) { return chunk ^ (
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// Chunk-major activation layout of a [M][C] 16-bit tensor (M % 32 == 0, C % 8 == 0): blocks of 32 rows, and inside a
+// block the 16-byte chunks (8 elements) of one column position of all 32 rows are contiguous:
+//     element (m, c) -> (((m >> 5) * (C / 8) + (c >> 3)) * 32 + (m & 31)) * 8 + (c & 7)
+// A GEMM epilogue whose lanes own rows (one lane = one m, 8 consecutive n after a lane-pair exchange) then stores
+// 1 KiB contiguous per instruction straight from registers (no LDS regrouping), and a consumer's LDS-DMA still reads
+// full 128-byte lines (8 consecutive rows of one chunk).
+__device__ __host__ __forceinline__ int64_t cm_offset(int64_t m, int c, int C) {
+  return (((m >> 5) * (C >> 3) + (c >> 3)) * 32 + (m & 31)) * 8 + (c & 7);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, typename T = __bf16>
@@ -300,6 +328,10 @@ struct GemmKernel {
   template <bool TRANS, int R0, int R1>
   static __device__ __forceinline__ void epilogue_impl(const GemmArgs& a, char* wl, int m0, int n0, const Lane& L,
                                                        f32x16 (&acc)[TN][TM], bf16x4 (&rs)[R0][R1][4]) {
+    // folded LayerNorm, lane <-> row orientation: (mu, rstd) of this lane's TM rows, one 8-byte load each
+    float2 mr_row[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) mr_row[j] = (!TRANS && a.ln_mu) ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
     // value of accumulator element (i, j, g4, e) after bias / scale / GELU
     auto finish = [&](int i, int j, int g4, float (&v)[4]) {
       float4 b4;
@@ -309,10 +341,29 @@ struct GemmKernel {
       } else {
         b4 = *reinterpret_cast<const float4*>(a.bias + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
       }
-      v[0] = acc[i][j][g4 * 4 + 0] + b4.x;
-      v[1] = acc[i][j][g4 * 4 + 1] + b4.y;
-      v[2] = acc[i][j][g4 * 4 + 2] + b4.z;
-      v[3] = acc[i][j][g4 * 4 + 3] + b4.w;
+      if (a.ln_mu) {  // A was an un-normalised pre-LayerNorm sum: rstd_m (acc - mu_m cs_n) + c_n
+        if (TRANS) {    // registers <-> 4 consecutive rows m, lane <-> n
+          const int mrow = m0 + L.wm * WMT + j * 32 + 8 * g4 + 4 * L.half;
+          const float4 mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow), rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
+          const float cs = a.ln_cs[n0 + L.wn * WNT + i * 32 + L.l31];
+          v[0] = rs.x * (acc[i][j][g4 * 4 + 0] - mu.x * cs) + b4.x;
+          v[1] = rs.y * (acc[i][j][g4 * 4 + 1] - mu.y * cs) + b4.y;
+          v[2] = rs.z * (acc[i][j][g4 * 4 + 2] - mu.z * cs) + b4.z;
+          v[3] = rs.w * (acc[i][j][g4 * 4 + 3] - mu.w * cs) + b4.w;
+        } else {        // lane <-> row m, registers <-> 4 consecutive n
+          const float mu = mr_row[j].x, rs = mr_row[j].y;
+          const float4 cs = *reinterpret_cast<const float4*>(a.ln_cs + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
+          v[0] = rs * (acc[i][j][g4 * 4 + 0] - mu * cs.x) + b4.x;
+          v[1] = rs * (acc[i][j][g4 * 4 + 1] - mu * cs.y) + b4.y;
+          v[2] = rs * (acc[i][j][g4 * 4 + 2] - mu * cs.z) + b4.z;
+          v[3] = rs * (acc[i][j][g4 * 4 + 3] - mu * cs.w) + b4.w;
+        }
+      } else {
+        v[0] = acc[i][j][g4 * 4 + 0] + b4.x;
+        v[1] = acc[i][j][g4 * 4 + 1] + b4.y;
+        v[2] = acc[i][j][g4 * 4 + 2] + b4.z;
+        v[3] = acc[i][j][g4 * 4 + 3] + b4.w;
+      }
       if (EPI == kEpiQkv && n0 < a.H) {  // 1/sqrt(head_dim = 64) folded into Q (exact in bf16)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= 0.125f;
@@ -493,7 +544,7 @@ struct GemmPingPong {
 
   struct Ctx {
     const T* A; const T* W;   // operand bases
-    int K, KT;
+    int K, KT, a_cm;
     int a_off[2], b_off[2];    // per-lane BYTE offsets of this wave's two pieces of an A / B half-tile (half 0, K step 0)
     unsigned a_bytes, w_bytes; // extents of the A / W tensors: the LDS-DMA goes through buffer addressing (resource over
                                // the whole tensor + 32-bit lane offset + scalar tile/K-step offset)
@@ -504,13 +555,14 @@ struct GemmPingPong {
 
   static __device__ __forceinline__ void make_ctx(const GemmArgs& a, const Lane& L, Ctx& c) {
     c.A = static_cast<const T*>(a.A); c.W = static_cast<const T*>(a.W);
-    c.K = a.K; c.KT = a.K / 64;
+    c.K = a.K; c.KT = a.K / 64; c.a_cm = a.a_cm;
     const int r8 = L.lane >> 3, p = L.lane & 7;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = (L.wave * 2 + t) * 8 + r8;            // LDS row of the half-tile this lane fills
       const int chunk = p ^ ((row >> 1) & 7);               // which 16 bytes of the source line land in slot p
-      c.a_off[t] = (((row >> 6) * 128 + (row & 63)) * a.K + chunk * 8) * 2;
+      const int rr = (row >> 6) * 128 + (row & 63);         // row inside the 256-row tile (half 0)
+      c.a_off[t] = a.a_cm ? (((rr >> 5) * (a.K >> 3) + chunk) * 32 + (rr & 31)) * 16 : (rr * a.K + chunk * 8) * 2;
       c.b_off[t] = (((row >> 5) * 64 + (row & 31)) * a.K + chunk * 8) * 2;
     }
 #pragma unroll
@@ -534,7 +586,10 @@ struct GemmPingPong {
   static __device__ __forceinline__ Src src_of(const Ctx& c, const Tiles& t, int g) {
     const bool in = g < c.KT;
     const int kt = in ? g : g - c.KT, m = in ? t.m0 : t.m1, n = in ? t.n0 : t.n1;
-    return Src{(unsigned)(((int64_t)m * c.K + kt * 64) * 2), (unsigned)(((int64_t)n * c.K + kt * 64) * 2)};
+    // (chunk-major A: a 32-row block is 32 * K * 2 bytes and a K step advances 8 chunks of 512 bytes; the half-tile
+    // offset of 64 rows is 64 * K * 2 bytes in both layouts)
+    const unsigned a_byte = c.a_cm ? (unsigned)((int64_t)(m >> 5) * c.K * 64 + kt * 4096) : (unsigned)(((int64_t)m * c.K + kt * 64) * 2);
+    return Src{a_byte, (unsigned)(((int64_t)n * c.K + kt * 64) * 2)};
   }
 
   // LDS-DMA of half-tile KIND of the K step at `s` into buffer `buf`: two 1-KiB pieces per wave
@@ -551,8 +606,13 @@ struct GemmPingPong {
       if (!((PIECES >> t) & 1)) continue;
       // raw buffer (stride 0, dword format) over the operand; loop-invariant scalar registers
       if constexpr (KIND < 2) {
+#if CAPAMD_PP_A_NT
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(c.A), 0, (int)c.a_bytes, 0x00020000),
+                                                 (lds_void_t*)(dst + t * 1024), 16, c.a_off[t], (int)soff, 0, 2);
+#else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(c.A), 0, (int)c.a_bytes, 0x00020000),
                                                  (lds_void_t*)(dst + t * 1024), 16, c.a_off[t], (int)soff, 0, 0);
+#endif
       } else {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(c.W), 0, (int)c.w_bytes, 0x00020000),
                                                  (lds_void_t*)(dst + t * 1024), 16, c.b_off[t], (int)soff, 0, 0);
@@ -661,6 +721,144 @@ struct GemmPingPong {
     if (L.wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows: both run the epilogue at once
   }
 
+  // lanes 32..63 of x <-> lanes 0..31 of y
+  // (inline asm: the compiler's hazard recogniser cannot see the cross-lane read, so the wait states a VALU-written
+  // operand needs before a lane-crossing instruction are inserted by hand)
+  static __device__ __forceinline__ void swap32(unsigned& x, unsigned& y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  }
+
+  // Epilogue into a chunk-major output (cm_offset): bias (or the folded-LayerNorm form) (+ Q/8, + GELU) in registers, the
+  // two lanes that share a row exchange their 8-byte halves (v_permlane32_swap) so each ends up with one whole 16-byte
+  // chunk, and every store instruction writes 1 KiB contiguous (two adjacent chunks x 32 rows).  No LDS, no waits.
+  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[2][4]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    int ncols = a.N, nloc = n0 + L.wn * 64;
+    float scale = 1.f;
+    if (EPI == kEpiQkv) {
+      ncols = a.H;
+      if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
+      else scale = 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in 16-bit)
+    }
+    const bool ln = a.ln_mu != nullptr;
+    float2 mr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * 128 + j * 32 + L.l31] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 b4[4], cs4[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + L.wn * 64 + i * 32 + 8 * g4 + 4 * L.half;
+        b4[g4] = *reinterpret_cast<const float4*>(a.bias + n);
+        cs4[g4] = ln ? *reinterpret_cast<const float4*>(a.ln_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t mblk = (m0 + L.wm * 128 + j * 32) >> 5;
+        const float mu = mr[j].x, rs = mr[j].y;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // rstd_m (acc - mu_m cs_n) + c_n ; with mu = 0, rstd = 1 this is acc + bias exactly
+          float v[4] = {rs * (acc[i][j][g4 * 4 + 0] - mu * cs4[g4].x) + b4[g4].x, rs * (acc[i][j][g4 * 4 + 1] - mu * cs4[g4].y) + b4[g4].y,
+                        rs * (acc[i][j][g4 * 4 + 2] - mu * cs4[g4].z) + b4[g4].z, rs * (acc[i][j][g4 * 4 + 3] - mu * cs4[g4].w) + b4[g4].w};
+          if (EPI == kEpiQkv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+          }
+          if (EPI == kEpiBiasGeluBf16) {
+            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+            v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+          }
+          const bf16x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          pk[g4][0] = u.x; pk[g4][1] = u.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          // the lower lane collects chunk 2p (its own 4 values + the upper lane's), the upper lane chunk 2p+1
+          swap32(pk[2 * p][0], pk[2 * p + 1][0]);
+          swap32(pk[2 * p][1], pk[2 * p + 1][1]);
+          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
+          const int64_t off = ((mblk * (ncols >> 3) + chunk) * 32 + L.l31) * 8;
+          *reinterpret_cast<uint4*>(base + off) = make_uint4(pk[2 * p][0], pk[2 * p][1], pk[2 * p + 1][0], pk[2 * p + 1][1]);
+        }
+      }
+    }
+  }
+
+  // kEpiResidStats: the pre-LayerNorm sum of a residual block, chunk-major, with the LayerNorm of the block's input
+  // re-computed on the fly and the row statistics of the result collected for the next LayerNorm:
+  //     P[m][n] = acc + bias'[n] + (R[m][n] - rmu_m) rrstd_m rgamma_n           (bias' = b + rbeta, folded when packed)
+  //     stat_part[m][n0/64 + wn] = (sum_n P, sum_n P^2) over this wave's 64 columns, of the ROUNDED values the consumers
+  //     will read.  fp32 sum, one rounding; the residual is read with coalesced 8-byte loads at the positions the lane's
+  //     own values will occupy (chunk-major), so no LDS and no transposition is involved.
+  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[2][4]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    const T* rsrc = static_cast<const T*>(a.res_src);
+    const int nchunks = a.N >> 3, nloc = n0 + L.wn * 64, nslot = a.N >> 6;
+    float2 mr[4];
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mr[j] = a.res_mr[m0 + L.wm * 128 + j * 32 + L.l31];
+      s1[j] = s2[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
+      float4 bb[2][2], gg[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = n0 + L.wn * 64 + i * 32 + (2 * p + L.half) * 8;
+        bb[p][0] = *reinterpret_cast<const float4*>(a.bias + n); bb[p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        gg[p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); gg[p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t mblk = (m0 + L.wm * 128 + j * 32) >> 5;
+        const float rmu = mr[j].x, rrs = mr[j].y;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          // fp32 exchange: lanes 32..63 of the first operand <-> lanes 0..31 of the second.  Afterwards the lower lane holds
+          // chunk 2p (n 0..3 its own, 4..7 from the upper lane), the upper lane chunk 2p+1, both as v[0..7] in order
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (element -> named float -> bits: __builtin_bit_cast applied directly to a vector element picked element 0 every time)
+            const float fx = acc[i][j][(2 * p) * 4 + e], fy = acc[i][j][(2 * p + 1) * 4 + e];
+            unsigned x = __float_as_uint(fx), y = __float_as_uint(fy);
+            swap32(x, y);
+            v[e] = __uint_as_float(x);
+            v[4 + e] = __uint_as_float(y);
+          }
+          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
+          const int64_t off = ((mblk * nchunks + chunk) * 32 + L.l31) * 8;
+          const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rsrc + off);
+          const float bv[8] = {bb[p][0].x, bb[p][0].y, bb[p][0].z, bb[p][0].w, bb[p][1].x, bb[p][1].y, bb[p][1].z, bb[p][1].w};
+          const float gv[8] = {gg[p][0].x, gg[p][0].y, gg[p][0].z, gg[p][0].w, gg[p][1].x, gg[p][1].y, gg[p][1].z, gg[p][1].w};
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = (T)(v[e] + bv[e] + ((float)r8[e] - rmu) * rrs * gv[e]);   // fp32 sum, ONE rounding
+            const float q = (float)o[e];                                    // statistics of what the consumers will read
+            s1[j] += q;
+            s2[j] = __builtin_fmaf(q, q, s2[j]);
+          }
+          *reinterpret_cast<bf16x8*>(base + off) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // the two lanes of a row hold its 2 x 32 columns: add them and let the lower lane write the wave's partial
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      const int mrow = m0 + L.wm * 128 + j * 32 + L.l31;
+      if (L.half == 0) *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + (n0 >> 6) + L.wn) * 2) = make_float2(t1, t2);
+    }
+  }
+
   static __device__ __forceinline__ void run(const GemmArgs& a, char* lds) {
     Lane L;
     L.tid = threadIdx.x; L.lane = L.tid & 63; L.wave = L.tid >> 6;
@@ -696,7 +894,9 @@ struct GemmPingPong {
       if constexpr (G::kResid) {
         G::epilogue_resid(a, wl, t.m0, t.n0, L, acc, rs);
       } else {
-        if (trans) G::template epilogue<true>(a, wl, t.m0, t.n0, L, acc, rs);
+        if constexpr (EPI == kEpiResidStats) epilogue_cm_resid(a, t.m0, t.n0, L, acc);
+        else if (trans) G::template epilogue<true>(a, wl, t.m0, t.n0, L, acc, rs);
+        else if (a.out_cm) epilogue_cm(a, t.m0, t.n0, L, acc);
         else G::template epilogue<false>(a, wl, t.m0, t.n0, L, acc, rs);
       }
       CAPAMD_STAMP();

@@ -219,7 +219,11 @@ class BertEngine:
         lf32 = torch.empty(nf * m.layers, dtype=torch.float32, device=some.device)
         keep = {k: _f32(v.detach()) for k, v in p.items()}
         for layer in range(m.layers):
-            arr = (ctypes.c_void_p * 16)(*[keep[f"bert.encoder.layer.{layer}.{n}"].data_ptr() for n in _LAYER_TENSORS])
+            ptrs = [keep[f"bert.encoder.layer.{layer}.{n}"].data_ptr() for n in _LAYER_TENSORS]
+            # + the LayerNorm whose output feeds this layer (the previous layer's output LayerNorm; layer 0 reads the
+            # already normalised embeddings): folded into this layer's QKV / O-proj epilogues (bert_gemm.cuh)
+            prev = [keep[f"bert.encoder.layer.{layer - 1}.output.LayerNorm.{n}"].data_ptr() for n in ("weight", "bias")] if layer > 0 else [None, None]
+            arr = (ctypes.c_void_p * 18)(*(ptrs + prev))
             _lib.check(lib.capamd_bert_pack_layer(ctypes.byref(m), layer, arr, _ptr(blob), _ptr(lf32), _stream()), "capamd_bert_pack_layer")
         for field, name in (("word_emb", "bert.embeddings.word_embeddings.weight"), ("pos_emb", "bert.embeddings.position_embeddings.weight"),
                             ("type_emb", "bert.embeddings.token_type_embeddings.weight"), ("emb_ln_g", "bert.embeddings.LayerNorm.weight"),

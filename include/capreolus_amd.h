@@ -149,16 +149,19 @@ typedef struct capamd_bert_model {
   const float* pooler_b;  /* [hidden] */
   const float* cls_w;     /* [2, hidden]          classifier.weight */
   const float* cls_b;     /* [2] */
-  const void* blob;       /* capamd_bert_blob_bytes(): per layer Wqkv[3H,H] | Wo[H,H] | W1[F,H] | W2[H,F], bf16 */
-  const float* layer_f32; /* layers * capamd_bert_layer_f32_floats(): bqkv | bo | ln1.g | ln1.b | b1 | b2 | ln2.g | ln2.b */
+  const void* blob;       /* capamd_bert_blob_bytes(): per layer Wqkv[3H,H] | Wo[H,H] | W1[F,H] | W2[H,F] (+ gamma-scaled Wqkv, W1), 16-bit */
+  const float* layer_f32; /* layers * capamd_bert_layer_f32_floats(): bqkv | bo | ln1.g | ln1.b | b1 | b2 | ln2.g | ln2.b | folded-LayerNorm vectors */
 } capamd_bert_model;
 
 int64_t capamd_bert_blob_bytes(const capamd_bert_model* m);        /* only the int fields are read */
 int64_t capamd_bert_layer_f32_floats(const capamd_bert_model* m);  /* floats per layer */
-/* tensors_host: HOST array of 16 DEVICE pointers for encoder layer `layer`, in this order:
+/* tensors_host: HOST array of 18 DEVICE pointers for encoder layer `layer`, in this order:
  * attention.self.query.{weight,bias}, .key.{weight,bias}, .value.{weight,bias}, attention.output.dense.{weight,bias},
  * attention.output.LayerNorm.{weight,bias}, intermediate.dense.{weight,bias}, output.dense.{weight,bias},
- * output.LayerNorm.{weight,bias} */
+ * output.LayerNorm.{weight,bias}, and [16], [17] = {weight, bias} of the LayerNorm whose output is this layer's input
+ * (the previous layer's output.LayerNorm; both NULL for layer 0, which reads the normalised embeddings).  The last
+ * two are folded into this layer's QKV and attention-output epilogues (LayerNorm fused into the GEMMs: weights
+ * pre-scaled by gamma, per-column sums and folded biases stored behind the plain vectors of `layer_f32`). */
 int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* const* tensors_host, void* blob,
                            float* layer_f32, void* stream);
 /* workspace for scoring `total_passages` = B*P passages in micro-batches of `passages_per_microbatch` */
@@ -175,9 +178,26 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 /* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
  * the reference calls at ptBERTMaxP.py:82).  16-bit (bf16 or fp16) operands, fp32 accumulation.
  * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;
- * 4: + resid[M,N] (bf16), bf16 out (fp32 sum, one rounding).  M, N, K multiples of 64. */
+ * 4: + resid[M,N] (bf16), bf16 out (fp32 sum, one rounding).  M, N, K multiples of 64.
+ * Layout bits OR-ed into `epilogue` (M, N multiples of 256, K >= 128; not with epilogue 4): the engine's internal
+ * "chunk-major" activation layout of a [R][C] 16-bit tensor - blocks of 32 rows, inside a block the 16-byte chunks
+ * of one column position of all 32 rows contiguous:  (r, c) -> (((r/32)*(C/8) + c/8)*32 + r%32)*8 + c%8.
+ * Its producers store straight from MFMA registers (no LDS regrouping), its consumers still fetch full 128-byte lines. */
+#define CAPAMD_GEMM_A_CHUNK_MAJOR 0x200   /* A is chunk-major */
+#define CAPAMD_GEMM_OUT_CHUNK_MAJOR 0x100 /* out is chunk-major */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
                      const void* resid, void* out, int dtype /* 0 bf16, 1 fp16 */, void* stream);
+/* The same GEMM with LayerNorm folded in (what capamd_bert_maxp_forward runs on BERT-base shapes; exported for the unit
+ * tests).  M, N multiples of 256, K >= 128 and a multiple of 64.  `epilogue`: 0 / 1 as above, or 5, plus the layout bits.
+ * Consumer side (ln_mu != NULL): A holds UN-normalised rows P, W = W0 . gamma (column-scaled), ln_cs[n] = sum_k W[n][k],
+ *   bias[n] = b[n] + sum_k beta[k] W0[n][k]; the epilogue computes rstd_m (acc - mu_m cs_n) + bias_n == LN(P) W0^T + b.
+ *   ln_mu, ln_rstd fp32 [M]; ln_mr fp32 [M][2] the same two interleaved.
+ * Producer side (epilogue 5, chunk-major out): out = acc + bias + (R - mu_m) rstd_m gamma_n with R = res_src [M, N] chunk-major,
+ *   res_mr [M][2] its (mu, rstd), res_gamma [N]; stat_part fp32 [M][N/64][2] receives (sum, sum of squares) of the rounded
+ *   output over each 64-column slice (fixed slots, no atomics). */
+int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const float* ln_mu,
+                        const float* ln_rstd, const float* ln_mr, const float* ln_cs, const void* res_src, const float* res_mr,
+                        const float* res_gamma, float* stat_part, void* out, int dtype, void* stream);
 /* x bf16 [n_passages*S, hidden] -> fused QKV projection (+bias, Q/8) -> softmax(QK^T + pad mask) V.
  * q, k: bf16 [n_passages*S, hidden]; vt: bf16 [n_passages*heads, 64, S]; ctx: bf16 [n_passages*S, hidden];
  * mask int64 [n_passages, S]. */

@@ -8,9 +8,10 @@ lib = _lib.load(); dev = "cuda:0"
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = 65536
-for name, N, K, epi in [("qkv-like", 2304, 768, 0), ("ffn1", 3072, 768, 1), ("oproj", 768, 768, 4), ("ffn2", 768, 3072, 4)]:
+for name, N, K, epi in [("qkv-like", 2304, 768, 0), ("ffn1", 3072, 768, 1), ("ffn1 out chunk-major", 3072, 768, 0x101), ("oproj", 768, 768, 0),
+                        ("ffn2", 768, 3072, 0), ("ffn2 A chunk-major", 768, 3072, 0x200)]:
     A = torch.randn((M, K), device=dev).bfloat16(); W = (torch.randn((N, K), device=dev) * 0.05).bfloat16()
-    bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev).bfloat16() if epi == 4 else None
+    bias = torch.randn(N, device=dev); resid = torch.randn((M, N), device=dev).bfloat16() if (epi & 0xff) == 4 else None
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     stamps = torch.zeros((256, 32), dtype=torch.int64, device=dev)
     for _ in range(2):

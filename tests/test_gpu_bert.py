@@ -56,6 +56,74 @@ def test_gemm_vs_torch(M, N, K, epi, dt):
     torch.testing.assert_close(out.float(), ref, rtol=rtol, atol=2e-2 if dt == "bf16" else 3e-3)  # one rounding of the result
 
 
+def _to_cm(x):
+    """row-major [M, C] -> the engine's chunk-major layout (include/capreolus_amd.h), flattened"""
+    M, C = x.shape
+    return x.reshape(M // 32, 32, C // 8, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
+
+
+def _from_cm(flat, M, C):
+    return flat.reshape(M // 32, C // 8, 32, 8).permute(0, 2, 1, 3).contiguous().reshape(M, C)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(512, 768, 768, 0), (256, 3072, 768, 1), (768, 256, 256, 0)])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_gemm_folded_layernorm_consumer(M, N, K, epi, dt):
+    """LN(P) W0^T + b computed from the un-normalised P with gamma-scaled weights and the (mu, rstd, cs, c) epilogue."""
+    tdt, code, rtol = TDT[dt]
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + epi)
+    P = (torch.randn((M, K), generator=g, device=DEV) * 1.7 + torch.randn((M, 1), generator=g, device=DEV) * 0.8).to(tdt)
+    W0 = torch.randn((N, K), generator=g, device=DEV) * 0.04 + torch.arange(N, device=DEV)[:, None] * 2e-4
+    b = torch.randn(N, generator=g, device=DEV) * 0.3
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device=DEV)
+    beta = 0.1 * torch.randn(K, generator=g, device=DEV)
+    Pf = P.float()
+    mu = Pf.mean(1)
+    rstd = torch.rsqrt(Pf.var(1, unbiased=False) + 1e-12)
+    Wg = W0 * gamma[None, :]
+    Ws = (Wg - Wg.mean(1, keepdim=True)).to(tdt)  # centred rows, as the engine packs them: LN(P) sums to zero over k
+    cs = Ws.float().sum(1)
+    c = b + W0 @ beta
+    mr = torch.stack([mu, rstd], 1).contiguous()
+    out = torch.empty(M * N, dtype=tdt, device=DEV)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(_to_cm(P)), _p(Ws), _p(c), M, N, K, epi | 0x300, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+                                         _p(out), code, _stream())
+    assert rc == 0
+    x = (Pf - mu[:, None]) * rstd[:, None] * gamma + beta
+    ref = x @ W0.t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    torch.testing.assert_close(_from_cm(out, M, N).float(), ref, rtol=4 * rtol, atol=5e-2 if dt == "bf16" else 8e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (256, 768, 3072), (768, 256, 128)])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_gemm_residual_stats_producer(M, N, K, dt):
+    """out = A W^T + b' + LN-without-beta(R), chunk-major, plus the row statistics of the rounded output."""
+    tdt, code, rtol = TDT[dt]
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn((M, K), generator=g, device=DEV) * 0.5).to(tdt)
+    W = (torch.randn((N, K), generator=g, device=DEV) * 0.05 + torch.arange(N, device=DEV)[:, None] * 1e-3).to(tdt)
+    bp = torch.randn(N, generator=g, device=DEV)
+    R = (torch.randn((M, N), generator=g, device=DEV) * 2.0 + 0.5).to(tdt)
+    gamma = 1.0 + 0.2 * torch.randn(N, generator=g, device=DEV)
+    Rf = R.float()
+    mu = Rf.mean(1)
+    rstd = torch.rsqrt(Rf.var(1, unbiased=False) + 1e-12)
+    mr = torch.stack([mu, rstd], 1).contiguous()
+    out = torch.empty(M * N, dtype=tdt, device=DEV)
+    part = torch.zeros((M, N // 64, 2), device=DEV)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A), _p(W), _p(bp), M, N, K, 5 | 0x100, None, None, None, None, _p(_to_cm(R)), _p(mr), _p(gamma), _p(part),
+                                         _p(out), code, _stream())
+    assert rc == 0
+    ref = A.float() @ W.float().t() + bp + (Rf - mu[:, None]) * rstd[:, None] * gamma
+    got = _from_cm(out, M, N).float()
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=2e-2 if dt == "bf16" else 3e-3)
+    # the statistics are those of the ROUNDED output, slice by slice
+    want = torch.stack([got.reshape(M, N // 64, 64).sum(2), (got * got).reshape(M, N // 64, 64).sum(2)], 2)
+    torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-3)
+
+
 def test_gemm_gelu_accuracy():
     """The fused erf-GELU on its own: x sweeps [-12, 12] through an identity weight; the result may differ from the exact
     erf form only by the fp16 rounding of the output plus the 1.2e-6 bound of the in-kernel approximation."""
