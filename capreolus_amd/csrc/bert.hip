@@ -512,12 +512,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         GemmArgs g{};
         g.H = H; g.S = S; g.heads = m->heads; g.M = (int)M;
         // QKV projection of LN_in(xb): layer 0 reads the normalised embeddings with the plain weights
-        g.A = w.xb; g.a_cm = 1; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
+        g.A = w.xb; g.a_cm = 1; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt; g.out_cm = 1;  // Q, K chunk-major
         if (l == 0) { g.W = wqkv; g.bias = bqkv; }
         else { g.W = wqkv_s; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
-        AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
+        AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1};
         launch_attention<T>(at, S, (unsigned)(np * m->heads), s);
         // pre = ctx Wo^T + bo + LN_in(xb)   (+ row statistics of pre)
         g = GemmArgs{};
@@ -563,7 +563,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       g.A = w.xb; g.W = wqkv; g.bias = bqkv; g.M = (int)M; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
       e = launch_gemm<kEpiQkv, T>(g, s);
       if (e != hipSuccess) break;
-      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads};
+      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 0};
       const unsigned nblk = (unsigned)(np * m->heads);
       launch_attention<T>(at, S, nblk, s);
       // attention output projection; the residual is added in fp32 inside the LayerNorm pass (one rounding, and the
@@ -789,7 +789,7 @@ int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv
   if (dtype != 0 && dtype != 1) return CAPAMD_ERR_ARG;
   const hipError_t e = dtype == 1 ? launch_gemm<kEpiQkv, _Float16>(g, s) : launch_gemm<kEpiQkv, __bf16>(g, s);
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
-  AttnArgs at{q, k, vt, mask, ctx, hidden, heads};
+  AttnArgs at{q, k, vt, mask, ctx, hidden, heads, 0};
   const unsigned nblk = (unsigned)(n_passages * heads);
   if (dtype == 1) launch_attention<_Float16>(at, S, nblk, s);
   else launch_attention<__bf16>(at, S, nblk, s);

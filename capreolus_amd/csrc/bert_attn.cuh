@@ -26,7 +26,13 @@ struct AttnArgs {
   const int64_t* mask;   // [M/S, S] attention mask (1 = attend), rows of the current micro-batch
   void* ctx;             // [M, H]
   int H, heads;
+  int qk_cm;             // Q and K in the chunk-major activation layout (bert_gemm.cuh cm_offset) instead of row-major
 };
+
+// element offset of the 16-byte chunk `chunk` (0..H/8) of token row `tok` in a [M, H] activation, either layout
+__device__ __forceinline__ int64_t qk_offset(const AttnArgs& a, int64_t tok, int chunk) {
+  return a.qk_cm ? (((tok >> 5) * (a.H >> 3) + chunk) * 32 + (tok & 31)) * 8 : tok * a.H + chunk * 8;
+}
 
 // The softmax of one query row lives in one lane pair (l31, l31+32): NT tiles x 16 registers.  It is VALU work that
 // competes with the MFMAs of the other wave on the SIMD, so it is written for few instructions per score:
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < INSTR; ++t) {
       const int row = (wave * INSTR + t) * 8 + r8;
-      const T* src = static_cast<const T*>(a.K) + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
+      const T* src = static_cast<const T*>(a.K) + qk_offset(a, tok0 + row, head * 8 + swz_chunk(row, p));
       __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * INSTR + t) * 1024), 16, 0, 0);
     }
     const T* vsrc = static_cast<const T*>(a.Vt) + (int64_t)ph * 64 * S;
@@ -119,9 +125,9 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   // this wave's Q fragments (B operand): query = qwave*32 + l31, d = (2*ks+half)*8 ..+7
   bf16x8 qf[4];
   {
-    const T* qrow = static_cast<const T*>(a.Q) + (tok0 + qwave * 32 + l31) * a.H + head * 64 + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, tok0 + qwave * 32 + l31, head * 8 + 2 * ks + half));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of K: hipcc does not wait for it at the barrier by itself
   __syncthreads();
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = (wave * 4 + t) * 8 + r8;
-        const T* src = static_cast<const T*>(a.K) + (tok0 + row) * a.H + head * 64 + swz_chunk(row, p) * 8;
+        const T* src = static_cast<const T*>(a.K) + qk_offset(a, tok0 + row, head * 8 + swz_chunk(row, p));
         __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * 4 + t) * 1024), 16, 0, 0);
       }
     }
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
   };
   auto load_q = [&](int item, bf16x8 (&qf)[4]) {
     const int psg = item / a.heads, head = item % a.heads;
-    const T* qrow = static_cast<const T*>(a.Q) + ((int64_t)psg * S + wave * 32 + l31) * a.H + head * 64 + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, (int64_t)psg * S + wave * 32 + l31, head * 8 + 2 * ks + half));
   };
   auto write_mask = [&](int item, int buf) {
     float* madd = reinterpret_cast<float*>(lds + buf * BUF + KBYTES + VBYTES);
