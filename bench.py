@@ -14,6 +14,7 @@ rank scores its own 64 queries per step) and each step ends with one RCCL all-ga
 score vectors.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -51,6 +52,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
+
+
+def emit(rec):
+    """The ONE JSON line, and the last line of stdout: RCCL prints a version banner through C stdio, which would otherwise
+    be flushed at process exit, after Python's own line."""
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(rec), flush=True)
 
 
 def main():
@@ -230,7 +242,7 @@ def main():
         rec["cpu_baseline"] = cpu_baseline(args, m, batch, emb, Q, L, D)
     if use_dist:
         dist.destroy_process_group()
-    print(json.dumps(rec), flush=True)
+    emit(rec)
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA")
@@ -342,7 +354,7 @@ def bench_bert(args, world, rank, dev, use_dist):
                                "sample": f"{n} documents ({n * P} passages) through oracle/bert_port.py (fp32 ATen ops, {cores} threads)"}
     if use_dist:
         dist.destroy_process_group()
-    print(json.dumps(rec), flush=True)
+    emit(rec)
 
 
 def cpu_baseline(args, m, batch, emb, Q, L, D):
