@@ -1,4 +1,5 @@
-"""Fill-rate probe: K-loop cycle stamps of the 256x256 GEMM on a grid of few / many CUs (profiling only)."""
+"""Fill-rate probe: K-loop cycle stamps of the 256x256 GEMM on a grid of few / many CUs (profiling only).
+Run it against the default library and against a -DCAPAMD_GEMM_ABLATE=1|2|3 build (CAPAMD_LIB_PATH, see scripts/gemm_variants.sh)."""
 import ctypes, os, sys
 import numpy as np
 import torch
