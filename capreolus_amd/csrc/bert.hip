@@ -390,14 +390,22 @@ __global__ void ln_stats_kernel(const float* __restrict__ part, int nslot, int H
                                 float2* __restrict__ mr) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  float s1 = 0.f, s2 = 0.f;
+  // every slot covers 64 columns: per-slot (mean, M2) merged pairwise-style (equal counts), so that a row whose mean is large
+  // against its spread does not lose its variance in E[x^2] - mean^2 over all H columns
+  float msum = 0.f, m2 = 0.f;
   for (int k = 0; k < nslot; ++k) {
     const float2 p = *reinterpret_cast<const float2*>(part + (m * nslot + k) * 2);
-    s1 += p.x;
-    s2 += p.y;
+    const float ms = p.x * (1.f / 64.f);
+    msum += ms;
+    m2 += fmaxf(p.y - p.x * ms, 0.f);
   }
-  const float mean = s1 / (float)H;
-  const float var = fmaxf(s2 / (float)H - mean * mean, 0.f);
+  const float mean = msum / (float)nslot;
+  float between = 0.f;
+  for (int k = 0; k < nslot; ++k) {
+    const float d = part[(m * nslot + k) * 2] * (1.f / 64.f) - mean;
+    between = __builtin_fmaf(d, d, between);
+  }
+  const float var = (m2 + 64.f * between) / (float)H;
   const float r = rsqrtf(var + kLnEps);
   mu[m] = mean;    // separate arrays: float4 loads of 4 consecutive rows (transposed V^T epilogue)
   rstd[m] = r;
