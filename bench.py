@@ -423,6 +423,16 @@ def cpu_baseline(args, m, batch, emb, Q, L, D):
                 if time.perf_counter() - t0 > 8.0:
                     break
     t_rate = done / (time.perf_counter() - t0)
+    # the same op sequence on ONE thread (SURVEY.md §8d asks for the single-thread figure too): 2 s
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        done1 = 0
+        while time.perf_counter() - t0 < 2.0:
+            trun(0, min(256, nb))
+            done1 += min(256, nb)
+    t1_rate = done1 / (time.perf_counter() - t0)
+    torch.set_num_threads(cores)
     return {
         "value": c_rate,
         "unit": "pairs/s",
@@ -431,6 +441,7 @@ def cpu_baseline(args, m, batch, emb, Q, L, D):
         "sample": f"first {n} pairs of the step's batch, oracle/interaction_oracle.c with OpenMP over pairs ({reps} repetitions)",
         "aten_port_value": t_rate,
         "aten_port_note": f"oracle/torch_port.py (the reference's ATen op sequence) on {cores} threads, batches of 1000 pairs",
+        "aten_port_single_thread_value": t1_rate,
     }
 
 
