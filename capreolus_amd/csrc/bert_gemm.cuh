@@ -333,10 +333,17 @@ struct GemmKernel {
 #pragma unroll
     for (int j = 0; j < TM; ++j) mr_row[j] = (!TRANS && a.ln_mu) ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
     // value of accumulator element (i, j, g4, e) after bias / scale / GELU
+    // TRANS: this lane's column n = l31 of each of the TN column tiles (hoisted: one load per tile, not per call)
+    float bias_t[TN], cs_t[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      bias_t[i] = TRANS ? a.bias[n0 + L.wn * WNT + i * 32 + L.l31] : 0.f;
+      cs_t[i] = (TRANS && a.ln_mu) ? a.ln_cs[n0 + L.wn * WNT + i * 32 + L.l31] : 0.f;
+    }
     auto finish = [&](int i, int j, int g4, float (&v)[4]) {
       float4 b4;
       if (TRANS) {
-        const float b = a.bias[n0 + L.wn * WNT + i * 32 + L.l31];
+        const float b = bias_t[i];
         b4 = make_float4(b, b, b, b);
       } else {
         b4 = *reinterpret_cast<const float4*>(a.bias + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
@@ -345,7 +352,7 @@ struct GemmKernel {
         if (TRANS) {    // registers <-> 4 consecutive rows m, lane <-> n
           const int mrow = m0 + L.wm * WMT + j * 32 + 8 * g4 + 4 * L.half;
           const float4 mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow), rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
-          const float cs = a.ln_cs[n0 + L.wn * WNT + i * 32 + L.l31];
+          const float cs = cs_t[i];
           v[0] = rs.x * (acc[i][j][g4 * 4 + 0] - mu.x * cs) + b4.x;
           v[1] = rs.y * (acc[i][j][g4 * 4 + 1] - mu.y * cs) + b4.y;
           v[2] = rs.z * (acc[i][j][g4 * 4 + 2] - mu.z * cs) + b4.z;
