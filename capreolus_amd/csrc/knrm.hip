@@ -285,8 +285,12 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
     return e ? atoi(e) : 0;
   }();
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+  // One candidate list per launch (B <= the 1536 workgroups the chip holds at once): the launch is as long as its longest
+  // document, so four rows in flight per 16-lane group (U = 4) beat occupancy - 62 vs 77 us at B = 1000; from B = 2000 on
+  // the 6-waves-per-SIMD variant wins again (96 vs 100 us; 33.0 vs 25.6 M pairs/s at B = 16000).  Same summation order.
+  const int chosen = variant ? variant : (B <= 1536 ? 1 : 0);
 #define LAUNCH_V(NV_)                          \
-  switch (variant) {                           \
+  switch (chosen) {                            \
     case 1: LAUNCH(NV_, 4, false, 2); break;   \
     case 6: LAUNCH(NV_, 6, true, 2); break;    \
     case 4: LAUNCH(NV_, 1, true, 8); break;    \
