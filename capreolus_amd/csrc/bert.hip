@@ -272,7 +272,8 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
       const unsigned grid = nblk < (unsigned)num_cus() ? nblk : (unsigned)num_cus();
       hipLaunchKernelGGL((attention_persistent_kernel<T>), dim3(grid), dim3(512), kAttnLds, s, at, (int)nblk);
     }
-  } else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
+  } else if (S == 192) hipLaunchKernelGGL((attention_kernel<192, 6, T>), dim3(nblk), dim3(384), 0, s, at);
+  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
   else hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at);
 }
 
@@ -685,7 +686,21 @@ int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* c
 
 int64_t capamd_bert_workspace_bytes(const capamd_bert_model* m, int S, int64_t passages_per_microbatch, int64_t total_passages) {
   if (!dims_ok(m) || S < 1 || passages_per_microbatch < 1 || total_passages < 1) return -1;
-  return (int64_t)ws_bytes_for(m->hidden, m->ffn, S, passages_per_microbatch, total_passages);
+  const int64_t q = S == 64 ? 4 : (S == 128 ? 2 : (S == 192 ? 4 : 1));   // (micro-batches are whole 256-row tiles, see capamd_bert_maxp_forward)
+  return (int64_t)ws_bytes_for(m->hidden, m->ffn, S, (passages_per_microbatch + q - 1) / q * q, total_passages);
+}
+
+int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int64_t* seg, int B, int P, int S, int aggregation,
+                     float* out, int* count_scratch, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!passage_logits || !mask || !seg || !out || !count_scratch || B < 0 || P < 1 || S < 1 || aggregation < 0 || aggregation > 3)
+    return CAPAMD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  if (aggregation == 3) (void)hipMemsetAsync(count_scratch, 0, 4, s);
+  hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(64), 0, s, passage_logits, mask, seg, P, S, aggregation, out, count_scratch);
+  if (aggregation == 3) hipLaunchKernelGGL(avg_div_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out, B, count_scratch);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
@@ -693,7 +708,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                              int64_t workspace_bytes, float* out, float* passage_logits_out, int* status, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !out || !status || B < 0 || P < 1) return CAPAMD_ERR_ARG;
-  if (!(S == 64 || S == 128 || S == 256) || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
+  if (!(S == 64 || S == 128 || S == 192 || S == 256) || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
   if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->pooler_w || !m->pooler_b || !m->cls_w ||
       !m->cls_b || !m->blob || !m->layer_f32)
     return CAPAMD_ERR_ARG;
@@ -702,7 +717,13 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
   if (passages_per_microbatch < 1) return CAPAMD_ERR_ARG;
   // equal-sized micro-batches (4000 passages at a cap of 256 -> 16 x 250, not 15 x 256 + 160: no ragged last pass)
   const int64_t n_mb = (NP + passages_per_microbatch - 1) / passages_per_microbatch;
-  const int64_t mb = (NP + n_mb - 1) / n_mb;
+  int64_t mb = (NP + n_mb - 1) / n_mb;
+  // rows of a micro-batch in multiples of 256 where the passage length allows it: the 256x256-tile GEMM kernels (and the
+  // folded-LayerNorm path) need M % 256 == 0; only the last micro-batch of a call may then fall back to the small tiles
+  if (S < 256) {
+    const int64_t q = S == 128 ? 2 : 4;   // 64 x 4 = 256, 128 x 2 = 256, 192 x 4 = 3 x 256
+    mb = (mb + q - 1) / q * q;
+  }
   if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
@@ -787,7 +808,7 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,
                               int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream) {
   if (!x || !wqkv || !bqkv || !mask || !q || !k || !vt || !ctx || n_passages < 1 || heads * 64 != hidden) return CAPAMD_ERR_ARG;
-  if (!(S == 64 || S == 128 || S == 256)) return CAPAMD_ERR_ARG;
+  if (!(S == 64 || S == 128 || S == 192 || S == 256)) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};

@@ -178,13 +178,14 @@ class BertEngine:
 
     COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
 
-    def __init__(self, params, heads, microbatch=256, compute_dtype="fp16"):
+    def __init__(self, params, heads, microbatch=256, compute_dtype="fp16", skip_padding=True):
         if compute_dtype not in self.COMPUTE_DTYPES:
             raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
         self.params = params
         self.heads = heads
         self.microbatch = microbatch
         self.compute_dtype = compute_dtype
+        self.skip_padding = skip_padding
         self._key = None
         self._blob = self._lf32 = self._ws = None
         self._model = None
@@ -234,8 +235,31 @@ class BertEngine:
         self._blob, self._lf32, self._keep, self._model, self._key = blob, lf32, keep, m, key
         return m
 
-    def forward(self, doc_input, doc_mask, doc_seg, aggregation="max", return_passage_logits=False, check=True):
-        """PTBERTMaxP_Class.predict_step (reference ptBERTMaxP.py:67-96): int64 [B,P,S] x3 -> fp32 [B]."""
+    def _encode(self, ids, mask, seg, B, P, S, aggregation, out, plog, check):
+        """One capamd_bert_maxp_forward call over [B, P, S] (all passages at length S)."""
+        m = self.model()
+        lib = _lib.load()
+        mb = min(self.microbatch, B * P)
+        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
+        if need < 0:
+            raise ValueError(f"unsupported passage length {S} (supported: 64, 128, 192, 256)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        st = status_word(ids.device)
+        rc = lib.capamd_bert_maxp_forward(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), AGGREGATIONS[aggregation], mb,
+                                          _ptr(self._ws), self._ws.numel(), _ptr(out), _ptr(plog), _ptr(st.t), _stream())
+        _lib.check(rc, "capamd_bert_maxp_forward")
+        if check:
+            st.raise_if_set()
+
+    def forward(self, doc_input, doc_mask, doc_seg, aggregation="max", return_passage_logits=False, check=True, skip_padding=None):
+        """PTBERTMaxP_Class.predict_step (reference ptBERTMaxP.py:67-96): int64 [B,P,S] x3 -> fp32 [B].
+
+        skip_padding (default: the engine's setting): encode every passage at the shortest supported length (64 / 128 / 192 / 256) that
+        holds its last attended token instead of at S.  Passages are independent, padded key positions get an attention
+        weight of exactly 0 and padded query positions never reach the [CLS] row, so the passage logits are bit-identical to
+        the full-length computation; only the dead rows are not computed.  Costs one small device->host copy (the bucket
+        sizes) per call, like the reference's own `.cpu()` per batch."""
         _need_gpu(doc_input, doc_mask, doc_seg)
         if aggregation not in AGGREGATIONS:
             raise ValueError("Unknown aggregation method: {}".format(aggregation))
@@ -244,21 +268,42 @@ class BertEngine:
         out = torch.empty(B, dtype=torch.float32, device=ids.device)
         if B == 0:
             return (out, torch.empty(0, device=ids.device)) if return_passage_logits else out
-        m = self.model()
-        lib = _lib.load()
-        mb = min(self.microbatch, B * P)
-        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
-        if need < 0:
-            raise ValueError(f"unsupported passage length {S} (supported: 64, 128, 256)")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
-        plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
-        st = status_word(ids.device)
-        rc = lib.capamd_bert_maxp_forward(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), AGGREGATIONS[aggregation], mb,
-                                          _ptr(self._ws), self._ws.numel(), _ptr(out), _ptr(plog), _ptr(st.t), _stream())
-        _lib.check(rc, "capamd_bert_maxp_forward")
-        if check:
-            st.raise_if_set()
+        if skip_padding is None:
+            skip_padding = self.skip_padding
+        lengths = [x for x in (64, 128, 192) if x < S] if (skip_padding and S in (128, 192, 256)) else []
+        if not lengths:
+            plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
+            self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
+            return (out, plog) if return_passage_logits else out
+
+        NP = B * P
+        fids, fmask, fseg = ids.view(NP, S), mask.view(NP, S), seg.view(NP, S)
+        # position after the last attended token of each passage (masks with holes keep their full extent)
+        end = ((fmask != 0) * torch.arange(1, S + 1, device=ids.device)).amax(dim=1)
+        bounds = lengths + [S]
+        bucket = torch.bucketize(end, torch.tensor(lengths, device=ids.device), right=False)   # 0: <= lengths[0], ...
+        order = torch.argsort(bucket, stable=True)
+        counts = torch.bincount(bucket, minlength=len(bounds)).cpu().tolist()   # the one host round trip of this call
+        plog = torch.empty(NP, dtype=torch.float32, device=ids.device)
+        lo = 0
+        for Sb, n in zip(bounds, counts):
+            if n == 0:
+                continue
+            sel = order[lo:lo + n]
+            lo += n
+            q = {64: 4, 128: 2, 192: 4}.get(Sb, 1)      # whole 256-row tiles: pad the bucket with copies of its last passage
+            pad = (-n) % q
+            if pad:
+                sel_p = torch.cat([sel, sel[-1:].expand(pad)])
+            else:
+                sel_p = sel
+            bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
+            o = torch.empty(n + pad, dtype=torch.float32, device=ids.device)
+            self._encode(bi, bm, bs, n + pad, 1, Sb, "first", o, None, check)
+            plog.index_copy_(0, sel, o[:n])
+        cnt = torch.empty(1, dtype=torch.int32, device=ids.device)
+        _lib.check(_lib.load().capamd_maxp_pool(_ptr(plog), _ptr(mask), _ptr(seg), B, P, S, AGGREGATIONS[aggregation], _ptr(out), _ptr(cnt),
+                                                _stream()), "capamd_maxp_pool")
         return (out, plog) if return_passage_logits else out
 
 

@@ -94,7 +94,8 @@ class PTBERTMaxP_Class(nn.Module):
         if self._engine is None:
             self._engine = engine.BertEngine(self._params(), self.bert.num_attention_heads,
                                              microbatch=int(self.config.get("microbatch", 256)),
-                                             compute_dtype=self.config.get("compute_dtype", "fp16"))
+                                             compute_dtype=self.config.get("compute_dtype", "fp16"),
+                                             skip_padding=bool(self.config.get("skip_padding", True)))
         else:
             self._engine.params = self._params()
         shape = (B, P, S)
@@ -110,8 +111,10 @@ class PTBERTMaxP(Reranker):
     # compute_dtype "fp16" (default: the type the reference's amp=pred autocast uses, trainer/pytorch.py:323-326; measured
     # 5.7e-4 relative error on BERT-base logits, inside the 1e-3 parity bar) or "bf16" (BASELINE.json's wording; same
     # MFMA rate, wider range, 7e-3 error)
+    # skip_padding (default True): passages are encoded in length buckets 64 / 128 / maxseqlen - bit-identical logits, the
+    # padded rows are simply not computed (engine.BertEngine.forward)
     config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256,
-                   "compute_dtype": "fp16"}
+                   "compute_dtype": "fp16", "skip_padding": True}
 
     def build_model(self):
         self.model = PTBERTMaxP_Class(self.extractor, self.config)

@@ -175,6 +175,14 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                              void* workspace, int64_t workspace_bytes, float* out, float* passage_logits_out,
                              int* status, void* stream);
 
+/* The passage pooling of predict_step alone (capreolus/reranker/ptBERTMaxP.py:75-94) over fp32 passage logits [B*P]:
+ * aggregation 0 max, 1 first, 2 sum, 3 avg, with passage_mask = (sum(mask*seg) > 5) from the FULL [B,P,S] mask / seg
+ * arrays.  Used when the passages of a call are encoded in length buckets (capreolus_amd.engine.BertEngine,
+ * skip_padding): passages are independent and padded positions never reach a real token, so a passage whose tokens end
+ * before position 64 / 128 can be encoded at S = 64 / 128 with bit-identical logits.  count_scratch: 4 bytes. */
+int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int64_t* seg, int B, int P, int S, int aggregation,
+                     float* out, int* count_scratch, void* stream);
+
 /* Encoder building blocks (what BertSelfAttention / nn.Linear + activation compute inside the HF model
  * the reference calls at ptBERTMaxP.py:82).  16-bit (bf16 or fp16) operands, fp32 accumulation.
  * capamd_bert_gemm: out[M,N] = A[M,K] · W[N,K]^T + bias, epilogue 0: bf16 out; 1: erf-GELU, bf16 out;

@@ -139,7 +139,7 @@ def test_gemm_gelu_accuracy():
     assert bool((err <= ref.abs() * 2.0 ** -11 + 1.5e-6).all()), float((err - ref.abs() * 2.0 ** -11).max())
 
 
-@pytest.mark.parametrize("S,hidden,heads,npsg", [(64, 128, 2, 4), (128, 192, 3, 2), (256, 768, 12, 2), (256, 768, 12, 3)])
+@pytest.mark.parametrize("S,hidden,heads,npsg", [(64, 128, 2, 4), (128, 192, 3, 2), (192, 128, 2, 4), (256, 768, 12, 2), (256, 768, 12, 3)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qkv_attention_vs_torch(S, hidden, heads, npsg, dt):
     tdt, code, rtol = TDT[dt]
@@ -203,7 +203,7 @@ def test_bert_maxp_end_to_end(name, dt):
     print(name, dt, "max rel err on passage logits", rel_err(plog.cpu().numpy(), ref_l).max())
 
 
-@pytest.mark.parametrize("S,n_docs,P", [(64, 4, 4), (128, 4, 2), (256, 3, 1), (256, 2, 3)])
+@pytest.mark.parametrize("S,n_docs,P", [(64, 4, 4), (128, 4, 2), (192, 4, 1), (256, 3, 1), (256, 2, 3)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_fused_layernorm_path_other_geometries(S, n_docs, P, dt):
     """hidden 256 / ffn 512 / 3 layers: every encoder GEMM is a ping-pong shape, so the folded-LayerNorm path runs (K = 256
@@ -229,6 +229,42 @@ def test_fused_layernorm_path_other_geometries(S, n_docs, P, dt):
     # BERT-base fixture (measured: folded LayerNorm 1.2-1.8e-3, separate passes 2.4-2.9e-3 in fp16): path coverage, not the 1e-3 bar
     e = rel_err(got.cpu().numpy(), ref.numpy())
     assert e.max() <= (4e-2 if dt == "bf16" else 4e-3), (S, dt, e.max())
+
+
+@pytest.mark.parametrize("name", BERT_CASES)
+def test_length_buckets_give_identical_logits(name):
+    """skip_padding: passages encoded at 64 / 128 / S by the position of their last attended token.  Pads get an attention
+    weight of exactly 0 and never reach a real row, so every passage logit must come out bit-identical."""
+    c = load_bert_case(name)
+    d = {k: c[k].to(DEV).clone() for k in ("pos_bert_input", "pos_mask", "pos_seg")}
+    B, P, S = d["pos_bert_input"].shape
+    if S < 128:
+        pytest.skip("nothing to bucket below S = 128")
+    # make sure all buckets occur: cut some passages short, punch a hole into one mask
+    g = torch.Generator().manual_seed(5)
+    for b in range(B):
+        for p in range(P):
+            r = float(torch.rand(1, generator=g))
+            if r < 0.35:
+                n = int(torch.randint(6, 60, (1,), generator=g))
+            elif r < 0.55 and S > 128:
+                n = int(torch.randint(70, 128, (1,), generator=g))
+            elif r < 0.75 and S > 192:
+                n = int(torch.randint(130, 192, (1,), generator=g))
+            else:
+                continue
+            d["pos_mask"][b, p, n:] = 0
+            d["pos_bert_input"][b, p, n:] = 0
+    d["pos_mask"][0, 0, 3] = 0
+    for agg in ("max", "avg"):
+        r = _model(c, agg)
+        eng_args = (d["pos_bert_input"], d["pos_mask"], d["pos_seg"], agg)
+        with torch.no_grad():
+            r.test(d)
+            full, pl_full = r.model._engine.forward(*eng_args, return_passage_logits=True, skip_padding=False)
+            buck, pl_buck = r.model._engine.forward(*eng_args, return_passage_logits=True, skip_padding=True)
+        assert torch.equal(pl_full, pl_buck)
+        assert torch.equal(full, buck)
 
 
 def test_bert_microbatching_and_errors():
