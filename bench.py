@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
     ap.add_argument("--bert-dtype", default="fp16", choices=["bf16", "fp16"], help="16-bit operand type of the BERT encoder")
     ap.add_argument("--bert-skip-padding", action="store_true",
-                    help="BERT: encode passages in length buckets (64/128/256) - identical scores, padded rows not computed. Off by "
+                    help="BERT: encode passages in length buckets (multiples of 32 tokens) - identical scores, padded rows not computed. Off by "
                          "default here: the headline line times the reference's full 4 x 256-token computation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
@@ -347,7 +347,7 @@ def bench_bert(args, world, rank, dev, use_dist):
     }
     if args.bert_skip_padding:
         # the nominal FLOP count (every passage at S tokens) no longer describes the executed work: no whole-step MFMA figure
-        rec["config"]["padding"] = "passages encoded in length buckets 64/128/256 (identical scores; rows beyond a passage's last token are not computed)"
+        rec["config"]["padding"] = "passages encoded in length buckets of 32 tokens (identical scores; rows beyond a passage's last token are not computed)"
         rec["roofline"]["whole_step_achieved"] = rec["roofline"]["whole_step_frac"] = None
     if not args.no_cpu_baseline and world == 1:
         n = args.cpu_pairs or 4

@@ -272,9 +272,18 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
       const unsigned grid = nblk < (unsigned)num_cus() ? nblk : (unsigned)num_cus();
       hipLaunchKernelGGL((attention_persistent_kernel<T>), dim3(grid), dim3(512), kAttnLds, s, at, (int)nblk);
     }
-  } else if (S == 192) hipLaunchKernelGGL((attention_kernel<192, 6, T>), dim3(nblk), dim3(384), 0, s, at);
-  else if (S == 128) hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at);
-  else hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at);
+  } else {
+    // every other multiple of 32: the one-shot kernel, one wave per 32 queries (the length buckets of BertEngine)
+    switch (S) {
+      case 32: hipLaunchKernelGGL((attention_kernel<32, 1, T>), dim3(nblk), dim3(64), 0, s, at); break;
+      case 64: hipLaunchKernelGGL((attention_kernel<64, 2, T>), dim3(nblk), dim3(128), 0, s, at); break;
+      case 96: hipLaunchKernelGGL((attention_kernel<96, 3, T>), dim3(nblk), dim3(192), 0, s, at); break;
+      case 128: hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at); break;
+      case 160: hipLaunchKernelGGL((attention_kernel<160, 5, T>), dim3(nblk), dim3(320), 0, s, at); break;
+      case 192: hipLaunchKernelGGL((attention_kernel<192, 6, T>), dim3(nblk), dim3(384), 0, s, at); break;
+      default: hipLaunchKernelGGL((attention_kernel<224, 7, T>), dim3(nblk), dim3(448), 0, s, at); break;
+    }
+  }
 }
 
 // Column tiles scheduled together.  All of them when the whole weight matrix fits an XCD's 4 MB L2 next to the activation
@@ -298,6 +307,9 @@ bool pingpong_shape(int64_t M, int N, int K) {
   static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
   return pingpong && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
+// passages of S tokens (a multiple of 32) that make whole 256-row GEMM tiles: 256 / gcd(S, 256)
+int64_t tile_passages(int S) { return (S % 256 == 0) ? 1 : (S % 128 == 0) ? 2 : (S % 64 == 0) ? 4 : 8; }
+
 bool fused_ln_enabled() {  // CAPAMD_BERT_FUSED_LN=0 keeps the separate residual + LayerNorm passes (A/B runs)
   static const bool on = [] { const char* e = getenv("CAPAMD_BERT_FUSED_LN"); return !(e && e[0] == '0'); }();
   return on;
@@ -686,7 +698,7 @@ int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* c
 
 int64_t capamd_bert_workspace_bytes(const capamd_bert_model* m, int S, int64_t passages_per_microbatch, int64_t total_passages) {
   if (!dims_ok(m) || S < 1 || passages_per_microbatch < 1 || total_passages < 1) return -1;
-  const int64_t q = S == 64 ? 4 : (S == 128 ? 2 : (S == 192 ? 4 : 1));   // (micro-batches are whole 256-row tiles, see capamd_bert_maxp_forward)
+  const int64_t q = tile_passages(S);   // (micro-batches are whole 256-row tiles, see capamd_bert_maxp_forward)
   return (int64_t)ws_bytes_for(m->hidden, m->ffn, S, (passages_per_microbatch + q - 1) / q * q, total_passages);
 }
 
@@ -708,7 +720,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                              int64_t workspace_bytes, float* out, float* passage_logits_out, int* status, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !out || !status || B < 0 || P < 1) return CAPAMD_ERR_ARG;
-  if (!(S == 64 || S == 128 || S == 192 || S == 256) || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
+  if (S < 32 || S > 256 || S % 32 != 0 || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
   if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->pooler_w || !m->pooler_b || !m->cls_w ||
       !m->cls_b || !m->blob || !m->layer_f32)
     return CAPAMD_ERR_ARG;
@@ -720,8 +732,8 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
   int64_t mb = (NP + n_mb - 1) / n_mb;
   // rows of a micro-batch in multiples of 256 where the passage length allows it: the 256x256-tile GEMM kernels (and the
   // folded-LayerNorm path) need M % 256 == 0; only the last micro-batch of a call may then fall back to the small tiles
-  if (S < 256) {
-    const int64_t q = S == 128 ? 2 : 4;   // 64 x 4 = 256, 128 x 2 = 256, 192 x 4 = 3 x 256
+  {
+    const int64_t q = tile_passages(S);
     mb = (mb + q - 1) / q * q;
   }
   if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
@@ -808,7 +820,7 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,
                               int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream) {
   if (!x || !wqkv || !bqkv || !mask || !q || !k || !vt || !ctx || n_passages < 1 || heads * 64 != hidden) return CAPAMD_ERR_ARG;
-  if (!(S == 64 || S == 128 || S == 192 || S == 256)) return CAPAMD_ERR_ARG;
+  if (S < 32 || S > 256 || S % 32 != 0) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};

@@ -6,6 +6,7 @@ scoring path happens inside libcapreolus_amd.so (capreolus_amd/csrc/*.hip).  The
 or eager-PyTorch fallback: inputs that are not on a HIP device raise.
 """
 import ctypes
+import math
 
 import torch
 
@@ -186,6 +187,7 @@ class BertEngine:
         self.microbatch = microbatch
         self.compute_dtype = compute_dtype
         self.skip_padding = skip_padding
+        self.bucket_step = 32   # granularity of the length buckets (the attention kernels exist for every multiple of 32)
         self._key = None
         self._blob = self._lf32 = self._ws = None
         self._model = None
@@ -242,7 +244,7 @@ class BertEngine:
         mb = min(self.microbatch, B * P)
         need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
         if need < 0:
-            raise ValueError(f"unsupported passage length {S} (supported: 64, 128, 192, 256)")
+            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256)")
         if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
         st = status_word(ids.device)
@@ -255,7 +257,7 @@ class BertEngine:
     def forward(self, doc_input, doc_mask, doc_seg, aggregation="max", return_passage_logits=False, check=True, skip_padding=None):
         """PTBERTMaxP_Class.predict_step (reference ptBERTMaxP.py:67-96): int64 [B,P,S] x3 -> fp32 [B].
 
-        skip_padding (default: the engine's setting): encode every passage at the shortest supported length (64 / 128 / 192 / 256) that
+        skip_padding (default: the engine's setting): encode every passage at the shortest multiple of `bucket_step` (32) tokens that
         holds its last attended token instead of at S.  Passages are independent, padded key positions get an attention
         weight of exactly 0 and padded query positions never reach the [CLS] row, so the passage logits are bit-identical to
         the full-length computation; only the dead rows are not computed.  Costs one small device->host copy (the bucket
@@ -270,7 +272,7 @@ class BertEngine:
             return (out, torch.empty(0, device=ids.device)) if return_passage_logits else out
         if skip_padding is None:
             skip_padding = self.skip_padding
-        lengths = [x for x in (64, 128, 192) if x < S] if (skip_padding and S in (128, 192, 256)) else []
+        lengths = list(range(self.bucket_step, S, self.bucket_step)) if (skip_padding and S % self.bucket_step == 0 and S > self.bucket_step) else []
         if not lengths:
             plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
             self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
@@ -291,7 +293,7 @@ class BertEngine:
                 continue
             sel = order[lo:lo + n]
             lo += n
-            q = {64: 4, 128: 2, 192: 4}.get(Sb, 1)      # whole 256-row tiles: pad the bucket with copies of its last passage
+            q = 256 // math.gcd(Sb, 256)                # whole 256-row tiles: pad the bucket with copies of its last passage
             pad = (-n) % q
             if pad:
                 sel_p = torch.cat([sel, sel[-1:].expand(pad)])

@@ -111,7 +111,7 @@ class PTBERTMaxP(Reranker):
     # compute_dtype "fp16" (default: the type the reference's amp=pred autocast uses, trainer/pytorch.py:323-326; measured
     # 5.7e-4 relative error on BERT-base logits, inside the 1e-3 parity bar) or "bf16" (BASELINE.json's wording; same
     # MFMA rate, wider range, 7e-3 error)
-    # skip_padding (default True): passages are encoded in length buckets 64 / 128 / maxseqlen - bit-identical logits, the
+    # skip_padding (default True): passages are encoded in length buckets (multiples of 32 tokens up to maxseqlen) - bit-identical logits, the
     # padded rows are simply not computed (engine.BertEngine.forward)
     config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256,
                    "compute_dtype": "fp16", "skip_padding": True}

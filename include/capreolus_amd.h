@@ -179,7 +179,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
  * aggregation 0 max, 1 first, 2 sum, 3 avg, with passage_mask = (sum(mask*seg) > 5) from the FULL [B,P,S] mask / seg
  * arrays.  Used when the passages of a call are encoded in length buckets (capreolus_amd.engine.BertEngine,
  * skip_padding): passages are independent and padded positions never reach a real token, so a passage whose tokens end
- * before position 64 / 128 can be encoded at S = 64 / 128 with bit-identical logits.  count_scratch: 4 bytes. */
+ * before position 32k can be encoded at S = 32k (any multiple of 32 up to 256) with bit-identical logits.  count_scratch: 4 bytes. */
 int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int64_t* seg, int B, int P, int S, int aggregation,
                      float* out, int* count_scratch, void* stream);
 
