@@ -135,7 +135,7 @@ int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const flo
  * nn.Module parameters; the GEMM weights are converted once to bf16 into a caller-owned `blob`
  * (capamd_bert_pack_layer; re-run it after load_weights / an optimizer step), the per-layer
  * biases and LayerNorm vectors are gathered into `layer_f32`.
- * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S in {64, 128, 256}. */
+ * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S a multiple of 32, 32 <= S <= 256. */
 typedef struct capamd_bert_model {
   int hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
   int compute_dtype;      /* 16-bit operand/activation type: 0 = bf16 (default), 1 = fp16 (the reference's amp autocast type;
