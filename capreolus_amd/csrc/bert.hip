@@ -314,6 +314,10 @@ bool fused_ln_enabled() {  // CAPAMD_BERT_FUSED_LN=0 keeps the separate residual
   static const bool on = [] { const char* e = getenv("CAPAMD_BERT_FUSED_LN"); return !(e && e[0] == '0'); }();
   return on;
 }
+bool cls_tail_enabled() {  // CAPAMD_BERT_CLS_TAIL=0: compute the last layer for every token (A/B runs)
+  static const bool on = [] { const char* e = getenv("CAPAMD_BERT_CLS_TAIL"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool chunk_major_enabled() {
   static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_CM"); return !(e && e[0] == '0'); }();
   return on;
@@ -424,6 +428,18 @@ __global__ void ln_stats_kernel(const float* __restrict__ part, int nslot, int H
   rstd[m] = r;
   mr[m] = make_float2(mean, r);  // interleaved: one load per row where a lane owns a row
 }
+// x_cls[psg][:] = LayerNorm_in(P[psg * S][:]) for the [CLS] row of every passage: chunk-major un-normalised stream -> compact
+// row-major rows (the input of the last layer's row-wise tail).  beta may be NULL (0).
+template <typename T>
+__global__ void cls_rows_kernel(const T* __restrict__ P, const float2* __restrict__ mr, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int64_t n_psg, int S, int H, T* __restrict__ out) {
+  const int64_t psg = blockIdx.x;
+  if (psg >= n_psg) return;
+  const int64_t tok = psg * S;
+  const float2 st = mr[tok];
+  for (int i = threadIdx.x; i < H; i += blockDim.x)
+    out[psg * H + i] = (T)(((float)P[cm_offset(tok, i, H)] - st.x) * st.y * gamma[i] + (beta ? beta[i] : 0.f));
+}
 __global__ void neutral_stats_kernel(int64_t M, float* __restrict__ mu, float* __restrict__ rstd, float2* __restrict__ mr) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     mu[i] = 0.f; rstd[i] = 1.f; mr[i] = make_float2(0.f, 1.f);
@@ -521,6 +537,8 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       // statistics of what they write.  Layer 0 reads the (normalised) embedding output: neutral statistics.
       hipLaunchKernelGGL(neutral_stats_kernel, dim3(256), dim3(256), 0, s, M, w.mu_x, w.rstd_x, w.mr_x);
       const float *last_g = nullptr, *last_b = nullptr;
+      bool cls_done = false;
+      const T* cls_x = nullptr;
       for (int l = 0; l < m->layers && e == hipSuccess; ++l) {
         const T* wl = blob + (int64_t)l * layer_blob_elems(H, F);
         const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
@@ -539,6 +557,36 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
         AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1};
+        if (l == m->layers - 1 && cls_tail_enabled()) {
+          // Last layer: only the [CLS] row of every passage is read afterwards and everything after the attention is
+          // row-wise - attention for that one query, then the output projection / LayerNorm / FFN / LayerNorm on n_psg
+          // rows (padded to whole 256-row tiles) instead of n_psg * S, through the plain row-major kernels.
+          const int64_t npad = (np + 255) / 256 * 256;
+          T *ctx_c = (T*)w.ctx, *x_c = (T*)w.q, *pre_c = (T*)w.pre, *mid_c = (T*)w.mid;   // (x_c reuses the Q buffer once Q is dead)
+          const float *bo = fl + 3 * H, *ln1b = fl + 5 * H, *b1 = fl + 6 * H, *b2 = fl + 6 * H + F;
+          const float* beta_in = l > 0 ? (fl - layer_f32_floats(H, F)) + 8 * H + F : nullptr;
+          (void)hipMemsetAsync(ctx_c + np * H, 0, (size_t)(npad - np) * H * 2, s);
+          hipLaunchKernelGGL(cls_attention_kernel<T>, dim3((unsigned)(np * m->heads)), dim3(64), 0, s, at, S, ctx_c);
+          (void)hipMemsetAsync(x_c + np * H, 0, (size_t)(npad - np) * H * 2, s);   // (inside the Q buffer: only after its last reader)
+          hipLaunchKernelGGL(cls_rows_kernel<T>, dim3((unsigned)np), dim3(256), 0, s, (const T*)w.xb, (const float2*)w.mr_x, g_in, beta_in, np, S, H, x_c);
+          g = GemmArgs{};
+          g.M = (int)npad; g.N = H; g.K = H; g.A = ctx_c; g.W = wo; g.bias = bo; g.out_bf16 = pre_c;
+          e = launch_gemm<kEpiBiasBf16, T>(g, s);
+          if (e != hipSuccess) break;
+          hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, (const T*)pre_c, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             0, 0, 1, ln1g, ln1b, npad, H, x_c, status, 0);
+          g.N = F; g.K = H; g.A = x_c; g.W = w1; g.bias = b1; g.out_bf16 = mid_c;
+          e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
+          if (e != hipSuccess) break;
+          g.N = H; g.K = F; g.A = mid_c; g.W = w2; g.bias = b2; g.out_bf16 = pre_c;
+          e = launch_gemm<kEpiBiasBf16, T>(g, s);
+          if (e != hipSuccess) break;
+          hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, (const T*)pre_c, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             0, 0, 1, ln2g, ln2b, npad, H, x_c, status, 0);
+          cls_done = true;
+          cls_x = x_c;
+          break;
+        }
         launch_attention<T>(at, S, (unsigned)(np * m->heads), s);
         // pre = ctx Wo^T + bo + LN_in(xb)   (+ row statistics of pre)
         g = GemmArgs{};
@@ -565,7 +613,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         last_g = ln2g; last_b = ln2b;
       }
       if (e != hipSuccess) break;
-      float* hpart = reinterpret_cast<float*>(w.pre);
+      float* hpart = reinterpret_cast<float*>(cls_done ? w.ctx : w.pre);
+      if (cls_done)   // compact, already normalised [CLS] rows: one row per passage
+        hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, cls_x, np, 1, H,
+                           m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr);
+      else
       hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
                          m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)w.mu_x, (const float*)w.rstd_x, last_g, last_b);
       hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);

@@ -312,4 +312,67 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
   }
 }
 
+// ---- last layer: attention for the [CLS] query only -----------------------------------------------------------------
+// After the last encoder layer only row 0 of every passage is read (the pooler, ptBERTMaxP.py:82 -> [:, 1] of the
+// classifier on the pooled [CLS] state), and every operation after the attention is row-wise: the last layer's attention
+// output is needed for ONE query per (passage, head), and its output projection / FFN only on those rows (bert.hip).
+// One wave per (passage, head): lane j scores keys j, j+64, ...; exact softmax by wave reductions; lane d accumulates
+// output dimension d over the keys.  Same arithmetic as the full kernels: fp32 dot products of the 16-bit Q (pre-scaled by
+// 1/8) and K, additive -FLT_MAX mask, probabilities rounded to the 16-bit type before the P V product, fp32 accumulation.
+template <typename T>
+__global__ __launch_bounds__(64) void cls_attention_kernel(AttnArgs a, int S, T* __restrict__ ctx_cls) {
+  using bf16x8 = typename Half<T>::x8;
+  __shared__ float prob[256];
+  const int lane = threadIdx.x, ph = blockIdx.x;
+  const int psg = ph / a.heads, head = ph % a.heads;
+  const int64_t tok0 = (int64_t)psg * S;
+  float q[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, tok0, head * 8 + c));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+  }
+  float sc[4];
+  float mx = -3.4028234663852886e38f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = lane + 64 * r;
+    float s = -3.4028234663852886e38f;
+    if (j < S) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 k = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.K) + qk_offset(a, tok0 + j, head * 8 + c));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(q[c * 8 + e], (float)k[e], acc);
+      }
+      s = acc + (a.mask[tok0 + j] != 0 ? 0.f : -3.4028234663852886e38f);
+    }
+    sc[r] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = lane + 64 * r;
+    const float p = j < S ? __builtin_amdgcn_exp2f((sc[r] - mx) * 1.4426950408889634f) : 0.f;
+    sum += p;
+    if (j < S) prob[j] = (float)(T)p;   // the P V product consumes 16-bit probabilities, as in the MFMA kernels
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  __syncthreads();
+  const T* vrow = static_cast<const T*>(a.Vt) + ((int64_t)ph * 64 + lane) * S;   // V^T row d = lane
+  float out = 0.f;
+  for (int j0 = 0; j0 < S; j0 += 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(vrow + j0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out = __builtin_fmaf(prob[j0 + e], (float)v[e], out);
+  }
+  ctx_cls[(int64_t)psg * a.H + head * 64 + lane] = (T)(out / sum);
+}
+
 }  // namespace capamd
