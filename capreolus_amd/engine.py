@@ -272,6 +272,9 @@ class BertEngine:
             return (out, torch.empty(0, device=ids.device)) if return_passage_logits else out
         if skip_padding is None:
             skip_padding = self.skip_padding
+        if aggregation == "first" and not return_passage_logits and P > 1 and skip_padding:
+            # ptBERTMaxP.py:85-86 takes scores[:, 0]: the other passages of a document are never read
+            return self.forward(ids[:, :1], mask[:, :1], seg[:, :1], "first", False, check, skip_padding)
         lengths = list(range(self.bucket_step, S, self.bucket_step)) if (skip_padding and S % self.bucket_step == 0 and S > self.bucket_step) else []
         if not lengths:
             plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None

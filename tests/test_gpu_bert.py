@@ -257,9 +257,15 @@ def test_length_buckets_give_identical_logits(name):
             d["pos_mask"][b, p, n:] = 0
             d["pos_bert_input"][b, p, n:] = 0
     d["pos_mask"][0, 0, 3] = 0
-    for agg in ("max", "avg"):
+    for agg in ("max", "avg", "first"):
         r = _model(c, agg)
         eng_args = (d["pos_bert_input"], d["pos_mask"], d["pos_seg"], agg)
+        if agg == "first":   # only passage 0 of every document is encoded at all
+            with torch.no_grad():
+                r.test(d)
+                full = r.model._engine.forward(*eng_args, skip_padding=False)
+                assert torch.equal(full, r.model._engine.forward(*eng_args, skip_padding=True))
+            continue
         with torch.no_grad():
             r.test(d)
             full, pl_full = r.model._engine.forward(*eng_args, return_passage_logits=True, skip_padding=False)
