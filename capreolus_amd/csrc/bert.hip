@@ -314,6 +314,10 @@ bool fused_ln_enabled() {  // CAPAMD_BERT_FUSED_LN=0 keeps the separate residual
   static const bool on = [] { const char* e = getenv("CAPAMD_BERT_FUSED_LN"); return !(e && e[0] == '0'); }();
   return on;
 }
+bool small_tiles_enabled() {  // CAPAMD_GEMM_SMALL_TILES=0: A/B switch
+  static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_SMALL_TILES"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool cls_tail_enabled() {  // CAPAMD_BERT_CLS_TAIL=0: compute the last layer for every token (A/B runs)
   static const bool on = [] { const char* e = getenv("CAPAMD_BERT_CLS_TAIL"); return !(e && e[0] == '0'); }();
   return on;
@@ -326,7 +330,11 @@ bool chunk_major_enabled() {
 template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if constexpr (EPI != kEpiBiasResidBf16) {
-    if (pingpong_shape(g.M, g.N, g.K)) {
+    // a handful of 256x256 tiles would leave most of the chip idle (the last layer's [CLS]-row tail: M = 256): plain
+    // row-major GEMMs with fewer than 64 such tiles go to the 64x64-tile kernel instead (16x the workgroups)
+    const bool few_tiles = !g.a_cm && !g.out_cm && !g.ln_mu && EPI != kEpiResidStats && EPI != kEpiQkv &&
+                           (int64_t)(g.M / 256) * (g.N / 256) < 64 && small_tiles_enabled();
+    if (pingpong_shape(g.M, g.N, g.K) && !few_tiles) {
       using P = GemmPingPong<EPI, T>;
       auto k = gemm_pingpong_kernel<EPI, T>;
       static bool attr_set = false;
@@ -346,7 +354,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     return hipErrorInvalidValue;  // the fused-LayerNorm producer exists on the ping-pong kernel only
   } else {
     if (g.a_cm || g.out_cm || g.ln_mu) return hipErrorInvalidValue;  // layouts / folded LayerNorm: ping-pong kernel only
-    if (g.M % 256 == 0 && g.N % 256 == 0) {
+    const bool few = (int64_t)(g.M / 256) * (g.N / 256) < 64 && small_tiles_enabled();
+    if (g.M % 256 == 0 && g.N % 256 == 0 && !few) {
       using G = GemmKernel<256, 256, 4, 2, EPI, T>;
       auto k = gemm_bf16_kernel<256, 256, 4, 2, EPI, T>;
       static bool attr_set = false;
