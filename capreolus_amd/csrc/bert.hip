@@ -272,6 +272,17 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
       const unsigned grid = nblk < (unsigned)num_cus() ? nblk : (unsigned)num_cus();
       hipLaunchKernelGGL((attention_persistent_kernel<T>), dim3(grid), dim3(512), kAttnLds, s, at, (int)nblk);
     }
+  } else if (S > 256) {
+    // 384 / 512: keys walked in chunks with the running-maximum softmax (bert_attn.cuh), K and V^T of the passage in LDS
+    constexpr int kLds384 = 384 * 128 + 64 * (384 * 2 + 8) + 384 * 4, kLds512 = 512 * 128 + 64 * (512 * 2 + 8) + 512 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<384, T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds384);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<512, T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds512);
+      attr_set = true;
+    }
+    if (S == 384) hipLaunchKernelGGL((attention_long_kernel<384, T>), dim3(nblk), dim3(768), kLds384, s, at);
+    else hipLaunchKernelGGL((attention_long_kernel<512, T>), dim3(nblk), dim3(1024), kLds512, s, at);
   } else {
     // every other multiple of 32: the one-shot kernel, one wave per 32 queries (the length buckets of BertEngine)
     switch (S) {
@@ -307,6 +318,8 @@ bool pingpong_shape(int64_t M, int N, int K) {
   static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
   return pingpong && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
+// passage lengths the attention kernels exist for: every multiple of 32 up to 256, then 384 and 512
+bool supported_length(int S) { return (S >= 32 && S <= 256 && S % 32 == 0) || S == 384 || S == 512; }
 // passages of S tokens (a multiple of 32) that make whole 256-row GEMM tiles: 256 / gcd(S, 256)
 int64_t tile_passages(int S) { return (S % 256 == 0) ? 1 : (S % 128 == 0) ? 2 : (S % 64 == 0) ? 4 : 8; }
 
@@ -782,7 +795,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
                              int64_t workspace_bytes, float* out, float* passage_logits_out, int* status, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !out || !status || B < 0 || P < 1) return CAPAMD_ERR_ARG;
-  if (S < 32 || S > 256 || S % 32 != 0 || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
+  if (!supported_length(S) || S > m->max_pos || aggregation < 0 || aggregation > 3) return CAPAMD_ERR_ARG;
   if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->pooler_w || !m->pooler_b || !m->cls_w ||
       !m->cls_b || !m->blob || !m->layer_f32)
     return CAPAMD_ERR_ARG;
@@ -882,7 +895,7 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages, int S,
                               int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream) {
   if (!x || !wqkv || !bqkv || !mask || !q || !k || !vt || !ctx || n_passages < 1 || heads * 64 != hidden) return CAPAMD_ERR_ARG;
-  if (S < 32 || S > 256 || S % 32 != 0) return CAPAMD_ERR_ARG;
+  if (!supported_length(S)) return CAPAMD_ERR_ARG;
   (void)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   GemmArgs g{};

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
 template <typename T>
 __global__ __launch_bounds__(64) void cls_attention_kernel(AttnArgs a, int S, T* __restrict__ ctx_cls) {
   using bf16x8 = typename Half<T>::x8;
-  __shared__ float prob[256];
+  __shared__ float prob[512];
   const int lane = threadIdx.x, ph = blockIdx.x;
   const int psg = ph / a.heads, head = ph % a.heads;
   const int64_t tok0 = (int64_t)psg * S;
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(64) void cls_attention_kernel(AttnArgs a, int S, T*
 #pragma unroll
     for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
   }
-  float sc[4];
+  float sc[8];
   float mx = -3.4028234663852886e38f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 8; ++r) {
     const int j = lane + 64 * r;
     float s = -3.4028234663852886e38f;
     if (j < S) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void cls_attention_kernel(AttnArgs a, int S, T*
   for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 8; ++r) {
     const int j = lane + 64 * r;
     const float p = j < S ? __builtin_amdgcn_exp2f((sc[r] - mx) * 1.4426950408889634f) : 0.f;
     sum += p;
@@ -373,6 +373,126 @@ __global__ __launch_bounds__(64) void cls_attention_kernel(AttnArgs a, int S, T*
     for (int e = 0; e < 8; ++e) out = __builtin_fmaf(prob[j0 + e], (float)v[e], out);
   }
   ctx_cls[(int64_t)psg * a.H + head * 64 + lane] = (T)(out / sum);
+}
+
+// ---- long passages: S = 384 and 512 (BERT's position table ends at 512) ----------------------------------------------------
+// The kernels above keep the scores of one query against ALL keys in registers (S / 2 VGPRs per lane), which stops at
+// S = 256.  Here the keys are walked in chunks of 64 with the running-maximum recurrence - the same exact softmax,
+// associated differently:
+//     m' = max(m, max_chunk);  alpha = 2^((m - m') log2e);  l = l alpha + sum 2^((s - m') log2e);  out = out alpha + V^T P
+// One workgroup per (passage, head), one wave per 32 queries (12 / 16 waves), K and V^T of the whole passage in LDS
+// (132 KiB at S = 512).
+template <int S, typename T>
+__global__ __launch_bounds__(S * 2) void attention_long_kernel(AttnArgs a) {
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
+  constexpr int NW = S / 32, NTHR = 64 * NW, NC = 2, NCHUNK = S / (32 * NC);
+  constexpr int VROW = S * 2 + 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* Ks = lds;
+  char* Vs = lds + S * 128;
+  float* madd = reinterpret_cast<float*>(lds + S * 128 + 64 * VROW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int ph = blockIdx.x;
+  const int psg = ph / a.heads, head = ph % a.heads;
+  const int64_t tok0 = (int64_t)psg * S;
+  {
+    const int r8 = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = (wave * 4 + t) * 8 + r8;
+      const T* src = static_cast<const T*>(a.K) + qk_offset(a, tok0 + row, head * 8 + swz_chunk(row, p));
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * 4 + t) * 1024), 16, 0, 0);
+    }
+    const T* vsrc = static_cast<const T*>(a.Vt) + (int64_t)ph * 64 * S;
+    for (int c = tid; c < 64 * S / 8; c += NTHR) {
+      const int d = c / (S / 8), k8 = c % (S / 8);
+      const uint4 x = *reinterpret_cast<const uint4*>(vsrc + d * S + k8 * 8);
+      *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16) = make_uint2(x.x, x.y);
+      *reinterpret_cast<uint2*>(Vs + d * VROW + k8 * 16 + 8) = make_uint2(x.z, x.w);
+    }
+    for (int k = tid; k < S; k += NTHR) madd[k] = a.mask[tok0 + k] != 0 ? 0.f : -3.4028234663852886e38f;  // HF: (1-mask) * finfo.min
+  }
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, tok0 + wave * 32 + l31, head * 8 + 2 * ks + half));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of K: hipcc does not wait for it at the barrier by itself
+  __syncthreads();
+
+  constexpr float kLog2e = 1.4426950408889634f;
+  f32x16 out[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
+  float m_run = -3.4028234663852886e38f, l_run = 0.f;
+#pragma unroll 1
+  for (int c = 0; c < NCHUNK; ++c) {
+    f32x16 sc[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+      const int tt = c * NC + t;
+      sc[t] = scores_init_from_mask(madd + tt * 32 + 4 * half);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = tt * 32 + l31;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
+        sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+      }
+    }
+    float mx = m_run;
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // a fully masked prefix keeps m at -FLT_MAX: (m - m') = 0 there, alpha = 1 on zeros - still exact
+    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * kLog2e);
+    const float nb = -mx * kLog2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], kLog2e, nb));
+        sc[t][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = mx;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) out[dt] = out[dt] * alpha;
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (T)sc[t][8 * s2 + e];
+        const int kb = (32 * (c * NC + t) + 16 * s2 + 4 * half) * 2;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vr = Vs + (dt * 32 + l31) * VROW + kb;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          out[dt] = Half<T>::mfma(vf, pf, out[dt]);
+        }
+      }
+  }
+  const float inv = 1.f / l_run;
+  T* crow = static_cast<T*>(a.ctx) + (tok0 + wave * 32 + l31) * a.H + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
+                  (T)(out[dt][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+    }
 }
 
 }  // namespace capamd

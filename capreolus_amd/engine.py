@@ -169,6 +169,9 @@ _LAYER_TENSORS = (
 )
 
 
+SUPPORTED_LENGTHS = tuple(range(32, 257, 32)) + (384, 512)   # the attention kernels of the library (capamd_bert_maxp_forward)
+
+
 class BertEngine:
     """Device-side state of one BERT sequence classifier for capamd_bert_maxp_forward.
 
@@ -187,7 +190,6 @@ class BertEngine:
         self.microbatch = microbatch
         self.compute_dtype = compute_dtype
         self.skip_padding = skip_padding
-        self.bucket_step = 32   # granularity of the length buckets (the attention kernels exist for every multiple of 32)
         self._key = None
         self._blob = self._lf32 = self._ws = None
         self._model = None
@@ -244,7 +246,7 @@ class BertEngine:
         mb = min(self.microbatch, B * P)
         need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
         if need < 0:
-            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256)")
+            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
         if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
         st = status_word(ids.device)
@@ -257,7 +259,7 @@ class BertEngine:
     def forward(self, doc_input, doc_mask, doc_seg, aggregation="max", return_passage_logits=False, check=True, skip_padding=None):
         """PTBERTMaxP_Class.predict_step (reference ptBERTMaxP.py:67-96): int64 [B,P,S] x3 -> fp32 [B].
 
-        skip_padding (default: the engine's setting): encode every passage at the shortest multiple of `bucket_step` (32) tokens that
+        skip_padding (default: the engine's setting): encode every passage at the shortest supported length (SUPPORTED_LENGTHS) that
         holds its last attended token instead of at S.  Passages are independent, padded key positions get an attention
         weight of exactly 0 and padded query positions never reach the [CLS] row, so the passage logits are bit-identical to
         the full-length computation; only the dead rows are not computed.  Costs one small device->host copy (the bucket
@@ -275,7 +277,7 @@ class BertEngine:
         if aggregation == "first" and not return_passage_logits and P > 1 and skip_padding:
             # ptBERTMaxP.py:85-86 takes scores[:, 0]: the other passages of a document are never read
             return self.forward(ids[:, :1], mask[:, :1], seg[:, :1], "first", False, check, skip_padding)
-        lengths = list(range(self.bucket_step, S, self.bucket_step)) if (skip_padding and S % self.bucket_step == 0 and S > self.bucket_step) else []
+        lengths = [x for x in SUPPORTED_LENGTHS if x < S] if (skip_padding and S in SUPPORTED_LENGTHS) else []
         if not lengths:
             plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
             self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)

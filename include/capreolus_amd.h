@@ -135,7 +135,7 @@ int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const flo
  * nn.Module parameters; the GEMM weights are converted once to bf16 into a caller-owned `blob`
  * (capamd_bert_pack_layer; re-run it after load_weights / an optimizer step), the per-layer
  * biases and LayerNorm vectors are gathered into `layer_f32`.
- * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S a multiple of 32, 32 <= S <= 256. */
+ * hidden = 64*heads, hidden % 64 == 0, hidden <= 1024, ffn % 64 == 0; S a multiple of 32 up to 256, or 384, or 512. */
 typedef struct capamd_bert_model {
   int hidden, layers, heads, ffn, vocab, max_pos, type_vocab;
   int compute_dtype;      /* 16-bit operand/activation type: 0 = bf16 (default), 1 = fp16 (the reference's amp autocast type;
@@ -179,7 +179,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
  * aggregation 0 max, 1 first, 2 sum, 3 avg, with passage_mask = (sum(mask*seg) > 5) from the FULL [B,P,S] mask / seg
  * arrays.  Used when the passages of a call are encoded in length buckets (capreolus_amd.engine.BertEngine,
  * skip_padding): passages are independent and padded positions never reach a real token, so a passage whose tokens end
- * before position 32k can be encoded at S = 32k (any multiple of 32 up to 256) with bit-identical logits.  count_scratch: 4 bytes. */
+ * before position 32k can be encoded at S = 32k (any supported length) with bit-identical logits.  count_scratch: 4 bytes. */
 int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int64_t* seg, int B, int P, int S, int aggregation,
                      float* out, int* count_scratch, void* stream);
 

@@ -140,7 +140,7 @@ def test_gemm_gelu_accuracy():
 
 
 @pytest.mark.parametrize("S,hidden,heads,npsg", [(32, 128, 2, 8), (64, 128, 2, 4), (96, 128, 2, 8), (128, 192, 3, 2), (160, 128, 2, 8), (192, 128, 2, 4),
-                                                 (224, 128, 2, 8), (256, 768, 12, 2), (256, 768, 12, 3)])
+                                                 (224, 128, 2, 8), (256, 768, 12, 2), (256, 768, 12, 3), (384, 128, 2, 2), (512, 128, 2, 3)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qkv_attention_vs_torch(S, hidden, heads, npsg, dt):
     tdt, code, rtol = TDT[dt]
@@ -204,7 +204,7 @@ def test_bert_maxp_end_to_end(name, dt):
     print(name, dt, "max rel err on passage logits", rel_err(plog.cpu().numpy(), ref_l).max())
 
 
-@pytest.mark.parametrize("S,n_docs,P", [(64, 4, 4), (128, 4, 2), (192, 4, 1), (256, 3, 1), (256, 2, 3)])
+@pytest.mark.parametrize("S,n_docs,P", [(64, 4, 4), (128, 4, 2), (192, 4, 1), (256, 3, 1), (256, 2, 3), (384, 2, 1), (512, 2, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_fused_layernorm_path_other_geometries(S, n_docs, P, dt):
     """hidden 256 / ffn 512 / 3 layers: every encoder GEMM is a ping-pong shape, so the folded-LayerNorm path runs (K = 256
