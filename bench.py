@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--bert-skip-padding", action="store_true",
                     help="BERT: encode passages in length buckets (multiples of 32 tokens) - identical scores, padded rows not computed. Off by "
                          "default here: the headline line times the reference's full 4 x 256-token computation")
+    ap.add_argument("--bert-two-streams", action="store_true",
+                    help="BERT, full-length mode: the engine's default of running two halves of a large batch on two streams (+2.6 %). "
+                         "Off here so that the dominant kernel's HIP-event duration in `roofline` is not inflated by a concurrent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -294,6 +297,7 @@ def bench_bert(args, world, rank, dev, use_dist):
     m.to(dev).eval()
     with torch.no_grad():
         rr.test({k: v[:8] for k, v in d.items()})   # builds the bf16 blob
+    m._engine.two_streams = bool(args.bert_two_streams)
     eng = m._engine
     gathered = torch.empty(docs * world, dtype=torch.float32, device=dev) if use_dist else None
     out = [None]

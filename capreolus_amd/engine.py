@@ -7,6 +7,7 @@ or eager-PyTorch fallback: inputs that are not on a HIP device raise.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -191,7 +192,10 @@ class BertEngine:
         self.compute_dtype = compute_dtype
         self.skip_padding = skip_padding
         self._key = None
-        self._blob = self._lf32 = self._ws = None
+        self._blob = self._lf32 = None
+        self._wss = {}        # workspaces: None -> the full-length call, Sb -> the length bucket running on its own stream
+        self._streams = {}
+        self.two_streams = os.environ.get("CAPAMD_BERT_TWO_STREAMS", "1") != "0"   # A/B switch of the full-length path
         self._model = None
         self._keep = None
 
@@ -239,19 +243,21 @@ class BertEngine:
         self._blob, self._lf32, self._keep, self._model, self._key = blob, lf32, keep, m, key
         return m
 
-    def _encode(self, ids, mask, seg, B, P, S, aggregation, out, plog, check):
-        """One capamd_bert_maxp_forward call over [B, P, S] (all passages at length S)."""
+    def _encode(self, ids, mask, seg, B, P, S, aggregation, out, plog, check, ws_key=None):
+        """One capamd_bert_maxp_forward call over [B, P, S] (all passages at length S) on the current stream; `ws_key` selects
+        the workspace (one per concurrently running stream)."""
         m = self.model()
         lib = _lib.load()
         mb = min(self.microbatch, B * P)
         need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
         if need < 0:
             raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != ids.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        ws = self._wss.get(ws_key)
+        if ws is None or ws.numel() < need or ws.device != ids.device:
+            ws = self._wss[ws_key] = torch.empty(need, dtype=torch.uint8, device=ids.device)
         st = status_word(ids.device)
         rc = lib.capamd_bert_maxp_forward(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), AGGREGATIONS[aggregation], mb,
-                                          _ptr(self._ws), self._ws.numel(), _ptr(out), _ptr(plog), _ptr(st.t), _stream())
+                                          _ptr(ws), ws.numel(), _ptr(out), _ptr(plog), _ptr(st.t), _stream())
         _lib.check(rc, "capamd_bert_maxp_forward")
         if check:
             st.raise_if_set()
@@ -279,8 +285,35 @@ class BertEngine:
             return self.forward(ids[:, :1], mask[:, :1], seg[:, :1], "first", False, check, skip_padding)
         lengths = [x for x in SUPPORTED_LENGTHS if x < S] if (skip_padding and S in SUPPORTED_LENGTHS) else []
         if not lengths:
-            plog = torch.empty(B * P, dtype=torch.float32, device=ids.device) if return_passage_logits else None
-            self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
+            NP = B * P
+            if NP < 2 * self.microbatch or not self.two_streams:
+                plog = torch.empty(NP, dtype=torch.float32, device=ids.device) if return_passage_logits else None
+                self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
+                return (out, plog) if return_passage_logits else out
+            # full-length computation of a large batch: two halves on two streams (own workspaces) - the persistent GEMM
+            # kernels of one half start on the CUs the other half's last tiles and launch gaps leave idle
+            fids, fmask, fseg = ids.view(NP, S), mask.view(NP, S), seg.view(NP, S)
+            plog = torch.empty(NP, dtype=torch.float32, device=ids.device)
+            self.model()
+            main = torch.cuda.current_stream(ids.device)
+            q = 256 // math.gcd(S, 256)
+            cut = (NP // 2 + q - 1) // q * q
+            sides = []
+            for k, (a0, a1) in enumerate(((0, cut), (cut, NP))):
+                side = self._streams.get(("half", k))
+                if side is None:
+                    side = self._streams[("half", k)] = torch.cuda.Stream(device=ids.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._encode(fids[a0:a1], fmask[a0:a1], fseg[a0:a1], a1 - a0, 1, S, "first", plog[a0:a1], None, False, ws_key=("half", k))
+                sides.append(side)
+            for side in sides:
+                main.wait_stream(side)
+            if check:
+                status_word(ids.device).raise_if_set()
+            cnt = torch.empty(1, dtype=torch.int32, device=ids.device)
+            _lib.check(_lib.load().capamd_maxp_pool(_ptr(plog), _ptr(mask), _ptr(seg), B, P, S, AGGREGATIONS[aggregation], _ptr(out), _ptr(cnt),
+                                                    _stream()), "capamd_maxp_pool")
             return (out, plog) if return_passage_logits else out
 
         NP = B * P
@@ -292,22 +325,36 @@ class BertEngine:
         order = torch.argsort(bucket, stable=True)
         counts = torch.bincount(bucket, minlength=len(bounds)).cpu().tolist()   # the one host round trip of this call
         plog = torch.empty(NP, dtype=torch.float32, device=ids.device)
+        self.model()                                  # (re)pack on the caller's stream before the buckets fan out
+        main = torch.cuda.current_stream(ids.device)
         lo = 0
+        used = []
         for Sb, n in zip(bounds, counts):
             if n == 0:
                 continue
             sel = order[lo:lo + n]
             lo += n
-            q = 256 // math.gcd(Sb, 256)                # whole 256-row tiles: pad the bucket with copies of its last passage
-            pad = (-n) % q
-            if pad:
-                sel_p = torch.cat([sel, sel[-1:].expand(pad)])
-            else:
-                sel_p = sel
-            bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
-            o = torch.empty(n + pad, dtype=torch.float32, device=ids.device)
-            self._encode(bi, bm, bs, n + pad, 1, Sb, "first", o, None, check)
-            plog.index_copy_(0, sel, o[:n])
+            # the buckets are independent: each runs on its own stream with its own workspace, so one bucket's kernels fill the
+            # CUs another bucket's last tiles leave idle and the launch gaps of one hide behind the work of the others
+            side = self._streams.get(Sb)
+            if side is None:
+                side = self._streams[Sb] = torch.cuda.Stream(device=ids.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                q = 256 // math.gcd(Sb, 256)            # whole 256-row tiles: pad the bucket with copies of its last passage
+                pad = (-n) % q
+                sel_p = torch.cat([sel, sel[-1:].expand(pad)]) if pad else sel
+                bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
+                o = torch.empty(n + pad, dtype=torch.float32, device=ids.device)
+                self._encode(bi, bm, bs, n + pad, 1, Sb, "first", o, None, False, ws_key=Sb)
+                plog.index_copy_(0, sel, o[:n])
+                for t in (bi, bm, bs, o, sel_p):
+                    t.record_stream(side)
+            used.append(side)
+        for side in used:
+            main.wait_stream(side)
+        if check:
+            status_word(ids.device).raise_if_set()
         cnt = torch.empty(1, dtype=torch.int32, device=ids.device)
         _lib.check(_lib.load().capamd_maxp_pool(_ptr(plog), _ptr(mask), _ptr(seg), B, P, S, AGGREGATIONS[aggregation], _ptr(out), _ptr(cnt),
                                                 _stream()), "capamd_maxp_pool")
