@@ -248,7 +248,9 @@ class BertEngine:
         the workspace (one per concurrently running stream)."""
         m = self.model()
         lib = _lib.load()
-        mb = min(self.microbatch, B * P)
+        # `microbatch` counts passages of 256 tokens: shorter passages go in proportionally larger micro-batches (same rows, same
+        # workspace, and the GEMMs of a short-passage bucket still see 65,536 rows)
+        mb = min(self.microbatch * max(1, 256 // S), B * P)
         need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
         if need < 0:
             raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
