@@ -109,3 +109,22 @@ def drmmtks(q_ids, d_ids, idf, packed, D, topk, gate_w, ffw_w, ffw_b, out_w, out
     err = lib().oracle_drmmtks(_p(q_ids), _p(d_ids), _p(idf), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D, int(topk),
                                _p(gate_w), _p(ffw_w), _p(ffw_b), _p(out_w), _p(out_b), _p(out))
     return out, err
+
+
+NONLIN = {"none": 0, "relu": 1, "tanh": 2}
+
+
+def pacrr(q_ids, d_ids, idf, packed, D, mingram, maxgram, nfilters, kmax, conv_ws, conv_bs, use_idf, w1, b1, w2, b2, w3, b3, nonlinearity="relu"):
+    """conv_ws: list of [nfilters, 1, ng, ng] arrays (ng = mingram..maxgram); conv_bs: list of [nfilters]."""
+    q_ids, d_ids, idf = _i64(q_ids), _i64(d_ids), _f32(idf)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    cw = np.ascontiguousarray(np.concatenate([_f32(w).reshape(-1) for w in conv_ws]))
+    cb = np.ascontiguousarray(np.concatenate([_f32(b).reshape(-1) for b in conv_bs]))
+    w1, b1, w2, b2, w3, b3 = (_f32(x) for x in (w1, b1, w2, b2, w3, b3))
+    C = w1.shape[0]
+    out = np.empty(B, dtype=np.float32)
+    err = lib().oracle_pacrr(_p(q_ids), _p(d_ids), _p(idf), B, Q, L, _p(packed), ctypes.c_int64(packed.shape[0]), D, int(mingram), int(maxgram),
+                             int(nfilters), int(kmax), _p(cw), _p(cb), int(bool(use_idf)), int(C), _p(w1), _p(b1), _p(w2), _p(b2),
+                             _p(w3.reshape(-1)), _p(b3.reshape(-1)), NONLIN[nonlinearity], _p(out))
+    return out, err

@@ -274,3 +274,87 @@ int oracle_drmmtks(const int64_t* q_ids, const int64_t* d_ids, const float* idf,
   }
   return err;
 }
+
+/* PACRR forward (row N4), restating PACRR_class.forward / PACRRConvMax2dModule.forward of the reference
+ * (capreolus/reranker/PACRR.py:42-78) on top of the same SimilarityMatrix as KNRM:
+ *   simmat [Q, L] (cosine + OOV exact match, pads zeroed, common.py:170-182)
+ *   for ng = mingram..maxgram: zero-pad right/bottom by ng-1 (:61), Conv2d(1 -> nfilters, ng x ng) + bias (:64), ReLU (:72), max over
+ *     the filters (:73), the kmax largest values along the document axis (:74), over ALL L positions (pads included)
+ *   optional idf channel: softmax over the Q raw idf values (:48-50)
+ *   per query term the channels [ng1 top-1..k, ng2 top-1..k, ..., idf], flattened query-major (:51-52), then
+ *   Linear -> nonlin -> Linear -> nonlin -> Linear (:30-40).  nonlin: 0 none, 1 relu, 2 tanh.
+ * conv_w: the Conv2d weights of the n-gram modules back to back, each [nfilters][ng][ng]; conv_b [n_ngrams][nfilters]. */
+static double pacrr_act(double x, int nonlin) { return nonlin == 1 ? (x > 0 ? x : 0) : (nonlin == 2 ? tanh(x) : x); }
+
+int oracle_pacrr(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed, int64_t V, int D,
+                 int mingram, int maxgram, int nfilters, int kmax, const float* conv_w, const float* conv_b, int use_idf, int C,
+                 const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int nonlin,
+                 float* out) {
+  const int64_t RS = oracle_row_stride(D);
+  const int NV = (int)(RS / 64);
+  const int n_ng = maxgram - mingram + 1, qts = n_ng * kmax + (use_idf ? 1 : 0);
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b) {
+    const int LP = L + maxgram, QP = Q + maxgram;
+    float* sim = (float*)calloc((size_t)QP * LP, sizeof(float));   /* zero-padded on the right / bottom */
+    float* top = (float*)malloc(sizeof(float) * (size_t)L);
+    double* feat = (double*)calloc((size_t)Q * qts, sizeof(double));
+    double h1[256], h2[256];
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      for (int j = 0; j < L; ++j) {
+        int64_t did = d_ids[(int64_t)b * L + j];
+        if (did >= V) { err |= 1; did = 0; }
+        sim[(size_t)q * LP + j] = sim_one(qid, did, packed, RS, NV);
+      }
+    }
+    const float* w = conv_w;
+    for (int gi = 0; gi < n_ng; ++gi) {
+      const int ng = mingram + gi;
+      for (int q = 0; q < Q; ++q) {
+        for (int j = 0; j < L; ++j) {
+          float best = 0.f; /* ReLU output is >= 0 */
+          for (int f = 0; f < nfilters; ++f) {
+            float acc = conv_b[gi * nfilters + f];
+            for (int a = 0; a < ng; ++a)
+              for (int c = 0; c < ng; ++c) acc = fmaf(w[(f * ng + a) * ng + c], sim[(size_t)(q + a) * LP + j + c], acc);
+            if (acc > best) best = acc;
+          }
+          top[j] = best;
+        }
+        for (int r = 0; r < kmax; ++r) { /* the r-th largest */
+          int bi = r;
+          for (int j = r + 1; j < L; ++j) if (top[j] > top[bi]) bi = j;
+          const float t = top[r]; top[r] = top[bi]; top[bi] = t;
+          feat[q * qts + gi * kmax + r] = top[r];
+        }
+      }
+      w += (size_t)nfilters * ng * ng;
+    }
+    if (use_idf) {
+      double m = idf[(int64_t)b * Q];
+      for (int q = 1; q < Q; ++q) if (idf[(int64_t)b * Q + q] > m) m = idf[(int64_t)b * Q + q];
+      double den = 0.0;
+      for (int q = 0; q < Q; ++q) den += exp((double)idf[(int64_t)b * Q + q] - m);
+      for (int q = 0; q < Q; ++q) feat[q * qts + qts - 1] = exp((double)idf[(int64_t)b * Q + q] - m) / den;
+    }
+    const int nin = Q * qts;
+    for (int c = 0; c < C; ++c) {
+      double s = b1[c];
+      for (int i = 0; i < nin; ++i) s += (double)w1[c * nin + i] * feat[i];
+      h1[c] = pacrr_act(s, nonlin);
+    }
+    for (int c = 0; c < C; ++c) {
+      double s = b2[c];
+      for (int i = 0; i < C; ++i) s += (double)w2[c * C + i] * h1[i];
+      h2[c] = pacrr_act(s, nonlin);
+    }
+    double s = b3[0];
+    for (int i = 0; i < C; ++i) s += (double)w3[i] * h2[i];
+    out[b] = (float)s;
+    free(sim); free(top); free(feat);
+  }
+  return err;
+}

@@ -196,9 +196,68 @@ def gen_drmmtks(TKS):
         print("drmmtks", name, scores[:6], list(sd.keys()))
 
 
+class _IdfTensor(torch.Tensor):
+    """query_idf for the reference's PACRR forward: reshape(shape_tuple, 1) -> [*shape, 1] (see gen_pacrr)."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t)
+
+    def reshape(self, *shape):
+        flat = []
+        for x in shape:
+            flat.extend(list(x) if isinstance(x, (tuple, list, torch.Size)) else [x])
+        return torch.Tensor.reshape(torch.Tensor._make_subclass(torch.Tensor, self), *flat)
+
+
+def gen_pacrr(PACRR):
+    cases = {
+        "default": dict(V=5000, D=300, B=24, Q=4, L=800,
+                        cfg=dict(mingram=1, maxgram=3, nfilters=32, idf=True, kmax=2, combine=32, nonlinearity="relu")),
+        "tanh_noidf_short": dict(V=800, D=50, B=16, Q=3, L=100,
+                                 cfg=dict(mingram=2, maxgram=3, nfilters=8, idf=False, kmax=3, combine=16, nonlinearity="tanh")),
+        "ranklist": dict(V=20000, D=300, B=200, Q=4, L=800,
+                         cfg=dict(mingram=1, maxgram=3, nfilters=32, idf=True, kmax=2, combine=32, nonlinearity="relu"), same_query=True),
+    }
+    for name, c in cases.items():
+        seed = 400 + len(name)
+        rs = np.random.RandomState(seed)
+        emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
+        same = c.get("same_query", False)
+        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
+                                              query_oov_frac=0.0 if same else 0.1)
+        if not same:
+            batch = _edge_cases(rs, batch, c["V"])
+        torch.manual_seed(seed)
+        ext = SimpleNamespace(embeddings=emb, config={"maxqlen": c["Q"]})
+        model = PACRR.PACRR_class(ext, dict(c["cfg"])).eval()
+        with torch.no_grad():   # make every stage matter: larger conv weights, non-trivial biases
+            for ng in model.ngrams:
+                ng.conv.weight.mul_(3.0)
+                ng.conv.bias.uniform_(-0.2, 0.3)
+        q, d = torch.from_numpy(batch["query"]), torch.from_numpy(batch["posdoc"])
+        with torch.no_grad():
+            # PACRR.py:49 calls query_idf.reshape(query_idf.shape, 1), which raises TypeError under torch (shape tuple AND an int):
+            # the reference's idf=True path (its default) cannot run as written.  The fixtures feed it a tensor subclass whose
+            # reshape accepts that argument list and means what the line evidently intends - [B, Q] -> [B, Q, 1] - so the rest of
+            # the reference's own code (softmax over dim 1, view, cat, combine) produces the expected scores.
+            scores = model(d, q, _IdfTensor(torch.from_numpy(batch["query_idf"]))).view(-1).numpy()
+        sd = {k: v.detach().numpy() for k, v in model.state_dict().items() if "embedding" not in k}
+        out = dict(emb_seed=np.int64(seed), V=np.int64(c["V"]), D=np.int64(c["D"]), query=batch["query"].astype(np.int32),
+                   posdoc=batch["posdoc"].astype(np.int32), query_idf=batch["query_idf"], ref_scores=scores.astype(np.float32),
+                   ref_scores_f16=scores.astype(np.float16), nonlinearity=np.array(c["cfg"]["nonlinearity"]),
+                   **{"cfg." + k: np.int64(v) for k, v in c["cfg"].items() if k != "nonlinearity"})
+        for k, v in sd.items():
+            out["sd." + k] = v
+        np.savez_compressed(os.path.join(HERE, f"pacrr_{name}.npz"), **out)
+        print("pacrr", name, scores[:6], list(sd.keys()))
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks"}
-    common, KNRM, DRMM, MAXP, TKS = _refharness.load_reference()
+    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks", "pacrr"}
+    common, KNRM, DRMM, MAXP, TKS, PACRR = _refharness.load_reference()
+    if "pacrr" in which:
+        gen_pacrr(PACRR)
     if "knrm" in which:
         gen_knrm(KNRM)
     if "drmm" in which:

@@ -10,6 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist"]
 DRMM_CASES = ["default", "zero_idf", "tv_nh", "ch", "ranklist"]
 DRMMTKS_CASES = ["default", "top3_short", "ranklist"]
+PACRR_CASES = ["default", "tanh_noidf_short", "ranklist"]
 
 # BASELINE.json north_star: "within 1e-3 relative (fp) and rank-order exactly"
 REL_TOL = 1e-3
@@ -77,3 +78,12 @@ def run_from_scores(scores):
     """What PytorchTrainer.predict builds for one query: docid -> fp16-rounded score (trainer/pytorch.py:346-348)."""
     s = np.asarray(scores, dtype=np.float32).astype(np.float16)
     return {f"d{i}": float(s[i]) for i in range(len(s))}
+
+
+def pacrr_args(c):
+    """(mingram, maxgram, nfilters, kmax, conv_ws, conv_bs, use_idf, w1, b1, w2, b2, w3, b3, nonlinearity) of a PACRR fixture."""
+    lo, hi = int(c["cfg.mingram"]), int(c["cfg.maxgram"])
+    n = hi - lo + 1
+    return (lo, hi, int(c["cfg.nfilters"]), int(c["cfg.kmax"]), [c[f"sd.ngrams.{i}.conv.weight"] for i in range(n)],
+            [c[f"sd.ngrams.{i}.conv.bias"] for i in range(n)], bool(int(c["cfg.idf"])), c["sd.linear1.weight"], c["sd.linear1.bias"],
+            c["sd.linear2.weight"], c["sd.linear2.bias"], c["sd.linear3.weight"], c["sd.linear3.bias"], str(c["nonlinearity"]))

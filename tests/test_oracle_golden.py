@@ -162,3 +162,15 @@ def test_drmmtks_oracle_matches_reference(name):
     assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
     if name == "ranklist":
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
+
+
+@pytest.mark.parametrize("name", ["default", "tanh_noidf_short", "ranklist"])
+def test_pacrr_oracle_matches_reference(name):
+    from tests.helpers import pacrr_args
+
+    c = load_case("pacrr", name)
+    got, err = oracle.pacrr(c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), *pacrr_args(c))
+    assert err == 0
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
+    if name == "ranklist":
+        assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
