@@ -478,3 +478,28 @@ def drmmtks_forward(query, doc, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b, o
     if check:
         st.raise_if_set()
     return out
+
+
+NONLINEARITIES = {"none": 0, "relu": 1, "tanh": 2}
+
+
+def pacrr_forward(query, doc, idf, packed, V, D, mingram, maxgram, nfilters, kmax, conv_w, conv_b, use_idf, nonlinearity, w1, b1, w2, b2,
+                  w3, b3, out=None, check=True):
+    """PACRR_class.forward (reference PACRR.py:42-55): fp32 [B].  conv_w / conv_b: the n-gram modules' Conv2d weights /
+    biases, flattened back to back (capamd_pacrr_forward)."""
+    _need_gpu(query, doc, idf, packed, conv_w, conv_b, w1, b1, w2, b2, w3, b3)
+    q, d, idf = _i64(query), _i64(doc), _f32(idf)
+    B, Q = q.shape
+    L = d.shape[1]
+    if kmax > L:
+        raise RuntimeError("selected index k out of range")  # what torch.topk raises at PACRR.py:74
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    rc = _lib.load().capamd_pacrr_forward(_ptr(q), _ptr(d), _ptr(idf), B, Q, L, _ptr(packed), V, D, int(mingram), int(maxgram), int(nfilters),
+                                          int(kmax), _ptr(conv_w), _ptr(conv_b), int(bool(use_idf)), w1.shape[0], NONLINEARITIES[nonlinearity],
+                                          _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_pacrr_forward")
+    if check:
+        st.raise_if_set()
+    return out

@@ -1,0 +1,73 @@
+"""PACRR behind the reference plugin surface (capreolus/reranker/PACRR.py:81-117), scored by the fused gfx950 kernel in
+capreolus_amd/csrc/pacrr.hip through the C ABI (a sibling model on the gather / similarity front end of
+KNRM and DRMM).  Parameter names follow the reference state_dict (``ngrams.{i}.conv.*``, ``linear1..3.*`` - which the
+reference also exposes as ``combine.{0,2,4}.*`` - and ``embedding.weight``)."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from . import Reranker
+
+
+class _ConvMax2d(nn.Module):
+    """Parameter holder with the reference's names (PACRRConvMax2dModule, PACRR.py:57-70); the arithmetic is in pacrr.hip."""
+
+    def __init__(self, shape, n_filters, k):
+        super().__init__()
+        self.shape, self.k = shape, k
+        self.conv = nn.Conv2d(1, n_filters, shape)
+
+
+class PACRR_class(nn.Module):
+    def __init__(self, extractor, config):
+        super().__init__()
+        p = dict(config)
+        self.p = p
+        if p["nonlinearity"] not in engine.NONLINEARITIES:
+            raise ValueError("nonlinearity must be none, relu or tanh")
+        weights = torch.as_tensor(np.asarray(extractor.embeddings, dtype=np.float32))
+        self.embedding = nn.Embedding(*weights.shape)
+        self.embedding.weight.data.copy_(weights)
+        self.embedding.weight.requires_grad = False
+        self.ngrams = nn.ModuleList(_ConvMax2d(ng, p["nfilters"], p["kmax"]) for ng in range(p["mingram"], p["maxgram"] + 1))
+        qterm_size = len(self.ngrams) * p["kmax"] + (1 if p["idf"] else 0)
+        self.linear1 = nn.Linear(extractor.config["maxqlen"] * qterm_size, p["combine"])
+        self.linear2 = nn.Linear(p["combine"], p["combine"])
+        self.linear3 = nn.Linear(p["combine"], 1)
+        act = {"none": nn.Identity, "relu": nn.ReLU, "tanh": nn.Tanh}[p["nonlinearity"]]
+        self.combine = nn.Sequential(self.linear1, act(), self.linear2, act(), self.linear3)   # same tensors, the reference's second set of names
+        self._packed = engine.PackedEmbedding()
+
+    def forward(self, doc, query, query_idf):
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("the PACRR training step is not part of the MI355X engine; score under model.eval()")
+        w = self.embedding.weight
+        conv_w = torch.cat([m.conv.weight.detach().reshape(-1) for m in self.ngrams]).contiguous()
+        conv_b = torch.cat([m.conv.bias.detach().reshape(-1) for m in self.ngrams]).contiguous()
+        p = self.p
+        out = engine.pacrr_forward(query, doc, query_idf, self._packed.get(w), w.shape[0], w.shape[1], p["mingram"], p["maxgram"], p["nfilters"],
+                                   p["kmax"], conv_w, conv_b, p["idf"], p["nonlinearity"], self.linear1.weight.detach().contiguous(),
+                                   self.linear1.bias.detach(), self.linear2.weight.detach().contiguous(), self.linear2.bias.detach(),
+                                   self.linear3.weight.detach().contiguous().view(-1), self.linear3.bias.detach())
+        return out.view(-1, 1)
+
+
+class PACRR(Reranker):
+    """Hui, Yates, Berberich, de Melo. PACRR: A Position-Aware Neural IR Model for Relevance Matching. EMNLP 2017
+    (reference PACRR.py:81-98)."""
+
+    module_name = "PACRR"
+    config_spec = {"mingram": 1, "maxgram": 3, "nfilters": 32, "idf": True, "kmax": 2, "combine": 32, "nonlinearity": "relu"}
+
+    def build_model(self):
+        if not hasattr(self, "model"):
+            self.model = PACRR_class(self.extractor, self.config)
+        return self.model
+
+    def score(self, d):
+        q, idf = d["query"], d["query_idf"]
+        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+
+    def test(self, d):
+        return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

@@ -68,6 +68,7 @@ from .KNRM import KNRM, KNRM_class  # noqa: E402,F401
 from .DRMM import DRMM, DRMM_class  # noqa: E402,F401
 
 from .DRMMTKS import DRMMTKS, DRMMTKS_class  # noqa: E402,F401
+from .PACRR import PACRR, PACRR_class  # noqa: E402,F401
 from .ptBERTMaxP import PTBERTMaxP, PTBERTMaxP_Class  # noqa: E402,F401
 
-registry = {"KNRM": KNRM, "DRMM": DRMM, "DRMMTKS": DRMMTKS, "ptBERTMaxP": PTBERTMaxP}
+registry = {"KNRM": KNRM, "DRMM": DRMM, "DRMMTKS": DRMMTKS, "PACRR": PACRR, "ptBERTMaxP": PTBERTMaxP}

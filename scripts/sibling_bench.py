@@ -1,0 +1,41 @@
+"""Throughput of the sibling rerankers (row N4: DRMMTKS, PACRR) on the KNRM benchmark's candidate lists (64 queries x 1000 candidates,
+Q=4, L=800, D=300, Zipf ids).  Prints one JSON line per model; not part of bench.py's contract."""
+import argparse
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from capreolus_amd import synthetic  # noqa: E402
+from capreolus_amd.reranker import DRMMTKS, PACRR  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--queries", type=int, default=64)
+ap.add_argument("--docs", type=int, default=1000)
+ap.add_argument("--vocab", type=int, default=400001)
+ap.add_argument("--dim", type=int, default=300)
+ap.add_argument("--steps", type=int, default=10)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+emb = synthetic.make_embeddings(args.vocab, args.dim, seed=0)
+batch = synthetic.make_candidate_list_torch(args.queries, args.docs, args.vocab, dev)
+ext = SimpleNamespace(embeddings=emb, config={"maxqlen": 4})
+for name, r in (("DRMMTKS", DRMMTKS({}, ext)), ("PACRR", PACRR({}, ext)), ("PACRR-kmax4-128", PACRR({"kmax": 4, "combine": 128}, ext))):
+    torch.manual_seed(0)
+    m = r.build_model().to(dev).eval()
+    with torch.no_grad():
+        for _ in range(2):
+            s = r.test(batch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            s = r.test(batch)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    n = batch["query"].shape[0]
+    print(json.dumps({"model": name, "pairs_per_s": round(n / ms * 1e3), "ms_per_step": round(ms, 3), "pairs": n, "finite": bool(torch.isfinite(s).all())}))

@@ -7,9 +7,10 @@ import pytest
 import torch
 
 from capreolus_amd import engine, run_io, synthetic
+from capreolus_amd._lib import EngineError
 from capreolus_amd.reranker import DRMM, KNRM
 from oracle import cpu as oracle
-from tests.helpers import DRMM_CASES, KNRM_CASES, REL_TOL, knrm_weights, load_case, rank_order, rel_err
+from tests.helpers import DRMM_CASES, KNRM_CASES, PACRR_CASES, REL_TOL, knrm_weights, load_case, pacrr_args, rank_order, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -599,3 +600,79 @@ def test_drmmtks_scores(name):
     if name == "ranklist":
         same = got.astype(np.float16) == c["ref_scores_f16"]
         assert same.mean() > 0.98
+
+
+def _pacrr_reranker(c):
+    from capreolus_amd.reranker import PACRR
+
+    cfg = {k: int(c[f"cfg.{k}"]) for k in ("mingram", "maxgram", "nfilters", "kmax", "combine")}
+    cfg.update(idf=bool(int(c["cfg.idf"])), nonlinearity=str(c["nonlinearity"]))
+    r = PACRR(cfg, SimpleNamespace(embeddings=c["emb"], config={"maxqlen": c["query"].shape[1]}))
+    m = r.build_model()
+    missing, unexpected = m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}, strict=False)
+    assert not unexpected and set(missing) <= {"embedding.weight"}, (missing, unexpected)   # the reference's parameter names, all of them
+    m.to(DEV).eval()
+    return r
+
+
+@pytest.mark.parametrize("name", PACRR_CASES)
+def test_pacrr_scores(name):
+    c = load_case("pacrr", name)
+    r = _pacrr_reranker(c)
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy()
+    want, err = oracle.pacrr(c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), *pacrr_args(c))
+    assert err == 0
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, rel_err(got, c["ref_scores"]).max()
+    if name == "ranklist":
+        assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
+
+
+@pytest.mark.parametrize("Q,L,lo,hi,nf,kmax,idf,nonlin,comb", [
+    (1, 1, 1, 1, 1, 1, False, "none", 1),        # smallest everything
+    (8, 800, 1, 3, 32, 4, True, "relu", 128),    # the kernel's compile-time limits
+    (5, 37, 2, 3, 7, 3, True, "tanh", 9),        # no unigram module, odd sizes
+    (3, 256, 1, 2, 16, 2, False, "relu", 32),    # run length exactly 4
+    (4, 1000, 1, 3, 8, 2, True, "relu", 16),     # longest supported document
+    (2, 2, 3, 3, 4, 2, False, "relu", 4),        # window larger than the matrix: only padding contributes beyond (0,0)
+])
+def test_pacrr_geometries_match_oracle(Q, L, lo, hi, nf, kmax, idf, nonlin, comb):
+    rng = np.random.default_rng(Q * 1000 + L)
+    V, D, B = 150, 60, 19
+    emb = synthetic.make_embeddings(V, D, seed=5)
+    q = rng.integers(0, V, (B, Q)); d = rng.integers(0, V, (B, L))
+    q[:, Q - 1:] *= rng.integers(0, 2, (B, 1)); d[:, L // 2:] *= rng.integers(0, 2, (B, 1))     # padded tails
+    if B > 3:
+        d[3] = 0                                                                                # all-padding document
+    idfv = rng.random((B, Q), dtype=np.float32) * 6
+    n = hi - lo + 1
+    cws = [rng.standard_normal((nf, 1, g, g)).astype(np.float32) * 0.5 for g in range(lo, hi + 1)]
+    cbs = [rng.standard_normal(nf).astype(np.float32) * 0.1 for _ in range(n)]
+    F = Q * (n * kmax + int(idf))
+    w1 = rng.standard_normal((comb, F)).astype(np.float32) * 0.3; b1 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w2 = rng.standard_normal((comb, comb)).astype(np.float32) * 0.3; b2 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w3 = rng.standard_normal((1, comb)).astype(np.float32) * 0.3; b3 = rng.standard_normal(1).astype(np.float32)
+    want, err = oracle.pacrr(q, d, idfv, oracle.pack(emb), D, lo, hi, nf, kmax, cws, cbs, idf, w1, b1, w2, b2, w3, b3, nonlin)
+    assert err == 0
+    pe = engine.PackedEmbedding()
+    got = engine.pacrr_forward(_t(q), _t(d), _t(idfv), pe.get(_t(emb)), V, D, lo, hi, nf, kmax, _t(np.concatenate([w.ravel() for w in cws])),
+                               _t(np.concatenate(cbs)), idf, nonlin, _t(w1), _t(b1), _t(w2), _t(b2), _t(w3.ravel()), _t(b3)).cpu().numpy()
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+
+
+def test_pacrr_errors():
+    c = load_case("pacrr", "tanh_noidf_short")
+    r = _pacrr_reranker(c)
+    b = _batch(c)
+    bad = dict(b, posdoc=b["posdoc"].clone())
+    bad["posdoc"][2, 5] = int(c["V"]) + 3
+    with pytest.raises(IndexError):
+        r.test(bad)
+    with pytest.raises(RuntimeError):                       # torch.topk's error for k > L (PACRR.py:74)
+        r.test(dict(b, posdoc=b["posdoc"][:, :1]))
+    pe = engine.PackedEmbedding()
+    with pytest.raises(EngineError):                        # beyond the compile-time limits: refused, never truncated
+        z = torch.zeros(4096, device=DEV)
+        engine.pacrr_forward(b["query"], b["posdoc"], b["query_idf"], pe.get(_t(c["emb"])), int(c["V"]), int(c["D"]), 1, 4, 8, 2, z, z, False,
+                             "relu", z, z, z, z, z, z)
