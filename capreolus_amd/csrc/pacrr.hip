@@ -14,7 +14,18 @@
 //                once (LDS broadcast) and applied to the whole run; running max over the filters (ReLU = the 0 it starts
 //                from); per-lane sorted top-k, then k rounds of a wave-wide arg-max merge.
 //   head       = idf softmax and the three small linear layers by the first threads.
-// The convolutions are ~1.4 MFLOP of fp32 VALU per pair next to ~1 MB of gathered rows: the kernel stays gather-bound.
+//                (pacrr_forward_kernel: any geometry within the limits below.)
+//   MFMA back end (pacrr_mfma_kernel: Q <= 5, nfilters <= 32 - the reference defaults) = the convolutions as matrix products
+//                on v_mfma_f32_32x32x16_f16.  M = the 32 filters, N = 32 document positions, K = the 8 rows of the padded
+//                similarity matrix at position l + dl (lanes 0-31) and at l + dl + 1 (lanes 32-63): with the matrix kept
+//                TRANSPOSED in LDS ([position][8 rows] f16) the B fragment of a lane is one aligned 16-byte LDS read and
+//                needs no VALU work, and the A fragment is the filter's column dl of weights placed at rows q .. q + ng - 1
+//                (a Toeplitz image, built once per query row in registers).  Row 7 of the matrix is a constant 1 that
+//                carries the bias.  fp32 accuracy comes from a two-term f16 split of both operands (hi + lo, 3 products;
+//                the dropped lo*lo term is 2^-22 relative), accumulated in fp32 by the matrix pipe.  ReLU + max over the
+//                filters = max over the lane's 16 accumulator registers and 0, then one v_permlane32_swap joins the two
+//                halves of two adjacent tiles so that all 64 lanes carry one position each into the top-k insertion.
+//                (Most K slots multiply zeros - 3 of 16 carry weights - and the matrix pipe is still ~9x the VALU form.)
 #include "capreolus_amd.h"
 #include "interaction.cuh"
 
@@ -46,33 +57,12 @@ struct PacrrArgs {
 
 __device__ __forceinline__ float pacrr_act(float x, int nonlin) { return nonlin == 1 ? fmaxf(x, 0.f) : (nonlin == 2 ? tanhf(x) : x); }
 
-// PPL = document positions per lane in the back end (64 * PPL >= L)
-template <int NV, int PPL>
-__global__ __launch_bounds__(kThreads, 4) void pacrr_forward_kernel(PacrrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int LS = 64 * PPL + kPacrrMaxGram;                       // row stride of the similarity matrix (zero tail = right padding)
-  const int QS = a.Q + kPacrrMaxGram - 1;                        // rows incl. the zero bottom padding
-  int* tok = reinterpret_cast<int*>(smem_raw);
-  const int tok_cap = (a.L + 3) & ~3;
-  int* pos = tok + tok_cap;                                      // position of each compacted term
-  float* sim = reinterpret_cast<float*>(pos + tok_cap);          // [QS][LS]
-  float* wts = sim + QS * LS;                                    // conv_w | conv_b
-  float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;   // [Q][qts]
-  float* h1 = feat + kPacrrMaxFeat;                              // [C]
-  float* h2 = h1 + kPacrrMaxC;                                   // [C]
-  int* wave_cnt = reinterpret_cast<int*>(h2 + kPacrrMaxC);       // [4] (+4 spare)
-  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);        // [kQT][NV*16] float4
+// ---- pieces shared by the two kernels ----
 
-  const int tid = threadIdx.x, lane16 = tid & 15, g = tid >> 4, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
-  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
-
-  for (int i = tid; i < QS * LS; i += kThreads) sim[i] = 0.f;
-  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
-  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
-
-  // ---- compact the real document terms (id > 0) in document order, with their positions ----
+// Real document terms (id > 0) compacted in document order, with their positions.  Returns their number.
+template <typename Pos>
+__device__ __forceinline__ int pacrr_compact(const PacrrArgs& a, const PairIds& ids, int* tok, Pos* pos, int* wave_cnt, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
   int n_real = 0;
   for (int base = 0; base < a.L; base += kThreads) {
     const int j = base + tid;
@@ -90,13 +80,19 @@ __global__ __launch_bounds__(kThreads, 4) void pacrr_forward_kernel(PacrrArgs a)
     if (real) {
       const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
       tok[slot] = (int)did;
-      pos[slot] = j;
+      pos[slot] = (Pos)j;
     }
     n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
   }
+  return n_real;
+}
 
-  // ---- similarity matrix: kQT query terms per pass ----
+// The pair's similarity matrix, kQT query terms per pass; put(row, position, value) stores one entry.
+template <int NV, int U, typename Pos, typename Put>
+__device__ __forceinline__ void pacrr_similarities(const PacrrArgs& a, const PairIds& ids, const int* tok, const Pos* pos, int n_real,
+                                                   float4* qlds, int tid, Put put) {
+  const int lane16 = tid & 15, g = tid >> 4;
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     QueryPass<NV> qp;
     load_query_pass_lds<NV>(a.packed, ids, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
@@ -111,21 +107,119 @@ __global__ __launch_bounds__(kThreads, 4) void pacrr_forward_kernel(PacrrArgs a)
           if (did < 0) {
 #pragma unroll
             for (int t = 0; t < kQT; ++t)
-              if (qp.id[t] == (int)did && did > -2147483648LL) sim[(q0 + t) * LS + j] = 1.f;
+              if (qp.id[t] == (int)did && did > -2147483648LL) put(q0 + t, j, 1.f);
           }
         }
     }
-    for (int t0 = g; t0 < n_real; t0 += kGroupsPerWG) {
-      RowRegs<NV> d[1];
-      load_row<NV>(a.packed, tok[t0], lane16, d[0]);
-      float x[1];
+    for (int t0 = g; t0 < n_real; t0 += U * kGroupsPerWG) {   // U rows in flight per 16-lane group
+      RowRegs<NV> d[U];
+      bool has[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tu = t0 + u * kGroupsPerWG;
+        has[u] = tu < n_real;
+        load_row<NV>(a.packed, has[u] ? tok[tu] : 0, lane16, d[u]);
+      }
+      float x[U];
       int qoff = 0;
       asm volatile("" : "+v"(qoff));
-      rows_sim_my<NV, 1, true>(d, qp, qlds + qoff, lane16, x);
-      if (lane16 < kQT && q0 + lane16 < a.Q) sim[(q0 + lane16) * LS + pos[t0]] = x[0];   // lane l of a group owns query term l & 3
+      rows_sim_my<NV, U, true>(d, qp, qlds + qoff, lane16, x);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (has[u] && lane16 < kQT && q0 + lane16 < a.Q) put(q0 + lane16, (int)pos[t0 + u * kGroupsPerWG], x[u]);   // lane l owns query term l & 3
     }
     __syncthreads();
   }
+}
+
+// Per-lane sorted candidate lists -> the kmax largest of the wave, written to dst[0 .. kmax).
+template <int KM>
+__device__ __forceinline__ void pacrr_wave_topk(float (&top)[KM], int kmax, int lane, float* dst) {
+  int head = 0;
+  for (int r = 0; r < kmax; ++r) {
+    float cand = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < KM; ++i)
+      if (i == head) cand = top[i];
+    float bst = cand;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bst = fmaxf(bst, __shfl_xor(bst, o, 64));
+    const unsigned long long who = __ballot(cand == bst && bst > -INFINITY);
+    if (who == 0) break;
+    if (lane == __ffsll((long long)who) - 1) ++head;
+    if (lane == 0) dst[r] = bst;
+  }
+}
+
+template <int KM>
+__device__ __forceinline__ void pacrr_insert(float (&top)[KM], float v) {
+#pragma unroll
+  for (int i = 0; i < KM; ++i) {
+    const float hi = fmaxf(top[i], v);
+    v = fminf(top[i], v);
+    top[i] = hi;
+  }
+}
+
+// idf channel + the three linear layers (PACRR.py:48-55); feat = [Q][qts] in LDS
+__device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& ids, float* feat, float* h1, float* h2, int qts, int tid, int b) {
+  if (a.use_idf && tid == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50)
+    const float* idf = a.idf + (int64_t)ids.qrow * a.Q;
+    float m = idf[0];
+    for (int q = 1; q < a.Q; ++q) m = fmaxf(m, idf[q]);
+    float den = 0.f;
+    for (int q = 0; q < a.Q; ++q) den += expf(idf[q] - m);
+    for (int q = 0; q < a.Q; ++q) feat[q * qts + qts - 1] = expf(idf[q] - m) / den;
+  }
+  __syncthreads();
+  const int nin = a.Q * qts;
+  if (tid < a.C) {
+    float s = a.b1[tid];
+    for (int i = 0; i < nin; ++i) s = __builtin_fmaf(a.w1[tid * nin + i], feat[i], s);
+    h1[tid] = pacrr_act(s, a.nonlin);
+  }
+  __syncthreads();
+  if (tid < a.C) {
+    float s = a.b2[tid];
+    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w2[tid * a.C + i], h1[i], s);
+    h2[tid] = pacrr_act(s, a.nonlin);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = a.b3[0];
+    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w3[i], h2[i], s);
+    a.out[b] = s;
+  }
+}
+
+// ---- general kernel: fp32 VALU convolutions.  PPL = document positions per lane in the back end (64 * PPL >= L) ----
+template <int NV, int PPL>
+__global__ __launch_bounds__(kThreads, 4) void pacrr_forward_kernel(PacrrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int LS = 64 * PPL + kPacrrMaxGram;                       // row stride of the similarity matrix (zero tail = right padding)
+  const int QS = a.Q + kPacrrMaxGram - 1;                        // rows incl. the zero bottom padding
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  const int tok_cap = (a.L + 3) & ~3;
+  int* pos = tok + tok_cap;                                      // position of each compacted term
+  float* sim = reinterpret_cast<float*>(pos + tok_cap);          // [QS][LS]
+  float* wts = sim + QS * LS;                                    // conv_w | conv_b
+  float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;   // [Q][qts]
+  float* h1 = feat + kPacrrMaxFeat;                              // [C]
+  float* h2 = h1 + kPacrrMaxC;                                   // [C]
+  int* wave_cnt = reinterpret_cast<int*>(h2 + kPacrrMaxC);       // [4] (+4 spare)
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);        // [kQT][NV*16] float4
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
+
+  for (int i = tid; i < QS * LS; i += kThreads) sim[i] = 0.f;
+  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
+  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
+
+  const int n_real = pacrr_compact(a, ids, tok, pos, wave_cnt, tid);
+  pacrr_similarities<NV, 1>(a, ids, tok, pos, n_real, qlds, tid, [&](int row, int j, float x) { sim[row * LS + j] = x; });
 
   // ---- convolutions, ReLU, max over filters, k-max over the document: wave w owns query rows w, w + 4, ... ----
   for (int q = wave; q < a.Q; q += 4) {
@@ -168,63 +262,209 @@ __global__ __launch_bounds__(kThreads, 4) void pacrr_forward_kernel(PacrrArgs a)
 #pragma unroll
       for (int i = 0; i < kPacrrMaxK; ++i) top[i] = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < PPL; ++r) {
-        float v = (j0 + r < a.L) ? best[r] : -INFINITY;
-#pragma unroll
-        for (int i = 0; i < kPacrrMaxK; ++i) {
-          const float hi = fmaxf(top[i], v);
-          v = fminf(top[i], v);
-          top[i] = hi;
-        }
-      }
-      int head = 0;
-      for (int r = 0; r < a.kmax; ++r) {
-        float cand = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < kPacrrMaxK; ++i)
-          if (i == head) cand = top[i];
-        float bst = cand;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) bst = fmaxf(bst, __shfl_xor(bst, o, 64));
-        const unsigned long long who = __ballot(cand == bst && bst > -INFINITY);
-        if (who == 0) break;
-        if (lane == __ffsll((long long)who) - 1) ++head;
-        if (lane == 0) feat[q * qts + gi * a.kmax + r] = bst;
-      }
+      for (int r = 0; r < PPL; ++r) pacrr_insert(top, (j0 + r < a.L) ? best[r] : -INFINITY);
+      pacrr_wave_topk(top, a.kmax, lane, feat + q * qts + gi * a.kmax);
     }
   }
-  if (a.use_idf && tid == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50)
-    const float* idf = a.idf + (int64_t)ids.qrow * a.Q;
-    float m = idf[0];
-    for (int q = 1; q < a.Q; ++q) m = fmaxf(m, idf[q]);
-    float den = 0.f;
-    for (int q = 0; q < a.Q; ++q) den += expf(idf[q] - m);
-    for (int q = 0; q < a.Q; ++q) feat[q * qts + qts - 1] = expf(idf[q] - m) / den;
-  }
-  __syncthreads();
+  pacrr_head(a, ids, feat, h1, h2, qts, tid, b);
+}
 
-  // ---- combine: Linear(Q*qts, C) -> nonlin -> Linear(C, C) -> nonlin -> Linear(C, 1) ----
-  const int nin = a.Q * qts;
-  if (tid < a.C) {
-    float s = a.b1[tid];
-    for (int i = 0; i < nin; ++i) s = __builtin_fmaf(a.w1[tid * nin + i], feat[i], s);
-    h1[tid] = pacrr_act(s, a.nonlin);
+// ---- MFMA kernel (Q <= kMfmaMaxQ, nfilters <= 32): see the header comment ----
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#ifndef CAPAMD_PACRR_ABLATE
+#define CAPAMD_PACRR_ABLATE 0       // profiling builds only: 1 = no convolutions, 2 = no gather, 3 = no combine layers
+#endif
+#ifndef CAPAMD_PACRR_U
+#define CAPAMD_PACRR_U 3            // embedding rows in flight per 16-lane group in the gather loop (measured: 1 -> 5.1 ms, 2 -> 4.4, 3 -> 4.1 per 64,000 pairs)
+#endif
+#ifndef CAPAMD_PACRR_WAVES
+#define CAPAMD_PACRR_WAVES 3        // register budget: waves per SIMD (the 40 KB LDS image of an 800-term pair allows 3 workgroups per CU anyway)
+#endif
+constexpr int kMfmaMaxQ = 5;        // rows 0 .. Q + 1 of the padded matrix + the bias row fit the 8 K slots of a half-wave
+constexpr int kBiasRow = 7;
+
+__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float f16_round(float x) { return (float)(_Float16)x; }
+
+// x (three f16 in bits 0..47) placed at halfword `q` of a 128-bit fragment
+__device__ __forceinline__ u32x4 place_halfwords(unsigned long long x, int q) {
+  unsigned long long lo, hi;
+  if (q == 0) {
+    lo = x;
+    hi = 0;
+  } else if (q < 4) {
+    lo = x << (16 * q);
+    hi = x >> (64 - 16 * q);
+  } else {
+    lo = 0;
+    hi = x << (16 * (q - 4));
   }
-  __syncthreads();
-  if (tid < a.C) {
-    float s = a.b2[tid];
-    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w2[tid * a.C + i], h1[i], s);
-    h2[tid] = pacrr_act(s, a.nonlin);
+  u32x4 r;
+  r[0] = (unsigned)lo;
+  r[1] = (unsigned)(lo >> 32);
+  r[2] = (unsigned)hi;
+  r[3] = (unsigned)(hi >> 32);
+  return r;
+}
+
+// A fragments (hi, lo) of one product: rows = this lane's filter, K slots q .. q + ng - 1 = column `dl` of its ng x ng weights,
+// slot kBiasRow = its bias (lanes 0-31 of the first product of an n-gram size only).
+__device__ __forceinline__ void pacrr_a_fragment(const float* w_ng, const float* b_ng, int ng, int dl, int nfilters, int q, bool with_bias,
+                                                 int lane, h8& a_hi, h8& a_lo) {
+  const int f = lane & 31;
+  const bool live = f < nfilters && dl < ng;
+  unsigned long long xh = 0, xl = 0;
+#pragma unroll
+  for (int dq = 0; dq < kPacrrMaxGram; ++dq)
+    if (dq < ng) {
+      const float w = live ? w_ng[(f * ng + dq) * ng + dl] : 0.f;
+      const float h = f16_round(w);
+      xh |= (unsigned long long)f16_bits(h) << (16 * dq);
+      xl |= (unsigned long long)f16_bits(w - h) << (16 * dq);
+    }
+  u32x4 fh = place_halfwords(xh, q), fl = place_halfwords(xl, q);
+  if (with_bias && lane < 32 && f < nfilters) {
+    const float bv = b_ng[f], h = f16_round(bv);
+    fh[3] |= f16_bits(h) << 16;
+    fl[3] |= f16_bits(bv - h) << 16;
   }
-  __syncthreads();
-  if (tid == 0) {
-    float s = a.b3[0];
-    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w3[i], h2[i], s);
-    a.out[b] = s;
+  a_hi = __builtin_bit_cast(h8, fh);
+  a_lo = __builtin_bit_cast(h8, fl);
+}
+
+__device__ __forceinline__ void pacrr_swap32(float& x, float& y) {
+  unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ux), "+v"(uy));
+  x = __uint_as_float(ux);
+  y = __uint_as_float(uy);
+}
+
+__device__ __forceinline__ float pacrr_relu_max(const f32x16& c) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = fmaxf(m, c[i]);
+  return m;
+}
+
+// KM = length of the per-lane candidate lists (>= kmax)
+template <int NV, int KM>
+__global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kernel(PacrrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tok_cap = (a.L + 7) & ~7;
+  const int LP = ((a.L + 63) & ~63) + 4;                         // positions in the LDS image (zero tail = right padding)
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  unsigned short* pos = reinterpret_cast<unsigned short*>(tok + tok_cap);
+  _Float16* s_hi = reinterpret_cast<_Float16*>(pos + tok_cap);   // [LP][8]: f16(sim[row][position]), row kBiasRow = 1
+  _Float16* s_lo = s_hi + LP * 8;                                // [LP][8]: f16(sim - hi)
+  float* wts = reinterpret_cast<float*>(s_lo + LP * 8);          // conv_w | conv_b
+  float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;
+  float* h1 = feat + kPacrrMaxFeat;
+  float* h2 = h1 + kPacrrMaxC;
+  int* wave_cnt = reinterpret_cast<int*>(h2 + kPacrrMaxC);
+  float4* qlds = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(wave_cnt + 8) + 15) & ~(uintptr_t)15);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
+
+  {
+    u32x4 z = {0u, 0u, 0u, 0u}, one = {0u, 0u, 0u, 0x3C000000u};   // row 7 = 1.0
+    for (int i = tid; i < LP; i += kThreads) {
+      reinterpret_cast<u32x4*>(s_hi)[i] = one;
+      reinterpret_cast<u32x4*>(s_lo)[i] = z;
+    }
   }
+  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
+  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
+
+  int n_real = pacrr_compact(a, ids, tok, pos, wave_cnt, tid);
+  if (CAPAMD_PACRR_ABLATE == 2) n_real = 0;
+  pacrr_similarities<NV, CAPAMD_PACRR_U>(a, ids, tok, pos, n_real, qlds, tid, [&](int row, int j, float x) {
+    const float h = f16_round(x);
+    s_hi[j * 8 + row] = (_Float16)h;
+    s_lo[j * 8 + row] = (_Float16)(x - h);
+  });
+
+  // ---- convolutions on the matrix pipe; wave w owns query rows w, w + 4 ----
+  for (int q = wave; q < (CAPAMD_PACRR_ABLATE == 1 ? 0 : a.Q); q += 4) {
+    // products: [0] ng=1 (dl 0 | -), [1] ng=2 (dl 0 | 1), [2] ng=3 (dl 0 | 1), [3] ng=3 (dl 2 | -); lanes 32-63 take the second dl
+    h8 ah[4], al[4];
+    const int half = lane >> 5;
+    {
+      const float* w = wts;
+      const float* bb = wts + a.n_conv_w;
+#pragma unroll
+      for (int ng = 1; ng <= kPacrrMaxGram; ++ng) {
+        const bool on = ng >= a.mingram && ng <= a.maxgram;
+        const int first = ng == 1 ? 0 : (ng == 2 ? 1 : 2);
+        // an n-gram size that is switched off keeps all-zero fragments (nfilters = 0)
+        pacrr_a_fragment(w, bb, ng, half, on ? a.nfilters : 0, q, true, lane, ah[first], al[first]);
+        if (ng == 3) pacrr_a_fragment(w, bb, ng, 2 + half, on ? a.nfilters : 0, q, false, lane, ah[3], al[3]);
+        if (on) {
+          w += a.nfilters * ng * ng;
+          bb += a.nfilters;
+        }
+      }
+    }
+    float top[kPacrrMaxGram][KM];
+#pragma unroll
+    for (int g = 0; g < kPacrrMaxGram; ++g)
+#pragma unroll
+      for (int i = 0; i < KM; ++i) top[g][i] = -INFINITY;
+
+    for (int l0 = 0; l0 < a.L; l0 += 64) {
+      float m[kPacrrMaxGram][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int p = l0 + 32 * t + (lane & 31) + half;            // lanes 32-63 read the next position: the second dl of a product
+        const h8 bh0 = *reinterpret_cast<const h8*>(s_hi + p * 8), bl0 = *reinterpret_cast<const h8*>(s_lo + p * 8);
+        const h8 bh2 = *reinterpret_cast<const h8*>(s_hi + (p + 2) * 8), bl2 = *reinterpret_cast<const h8*>(s_lo + (p + 2) * 8);
+        f32x16 c1 = {0}, c2 = {0}, c3 = {0};
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh0, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bh0, c3, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh0, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[2], bh0, c3, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl0, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[2], bl0, c3, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[3], bh2, c3, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[3], bh2, c3, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[3], bl2, c3, 0, 0, 0);
+        m[0][t] = pacrr_relu_max(c1);   // ReLU + max over this lane's 16 filters
+        m[1][t] = pacrr_relu_max(c2);
+        m[2][t] = pacrr_relu_max(c3);
+      }
+#pragma unroll
+      for (int g = 0; g < kPacrrMaxGram; ++g) {
+        // lanes 0-31 end with tile 0's position (lane), lanes 32-63 with tile 1's (lane - 32): the value of position l0 + lane
+        pacrr_swap32(m[g][0], m[g][1]);
+        const float v = fmaxf(m[g][0], m[g][1]);
+        pacrr_insert(top[g], (l0 + lane < a.L) ? v : -INFINITY);
+      }
+    }
+#pragma unroll
+    for (int ng = 1; ng <= kPacrrMaxGram; ++ng)
+      if (ng >= a.mingram && ng <= a.maxgram) pacrr_wave_topk(top[ng - 1], a.kmax, lane, feat + q * qts + (ng - a.mingram) * a.kmax);
+  }
+  if (CAPAMD_PACRR_ABLATE == 3) {
+    __syncthreads();
+    if (tid == 0) a.out[b] = feat[0];
+    return;
+  }
+  pacrr_head(a, ids, feat, h1, h2, qts, tid, b);
 }
 
 }  // namespace
+
+static bool pacrr_force_valu() {   // CAPAMD_PACRR_VALU=1: the general kernel for every geometry (A/B measurements, tests)
+  const char* e = getenv("CAPAMD_PACRR_VALU");
+  return e && e[0] == '1';
+}
 
 extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed,
                                     int64_t V, int D, int mingram, int maxgram, int nfilters, int kmax, const float* conv_w,
@@ -243,13 +483,31 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   PacrrArgs a{ids, idf, B, Q, L, packed, V, mingram, maxgram, nfilters, kmax, conv_w, conv_b, ncw, use_idf ? 1 : 0, combine, nonlinearity,
               w1, b1, w2, b2, w3, b3, out, status};
-  const int ppl = L <= 256 ? 4 : (L <= 512 ? 8 : (L <= 832 ? 13 : 16));
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(Q + kPacrrMaxGram - 1) * (64 * ppl + kPacrrMaxGram) * 4 +
-                      (size_t)(ncw + (maxgram - mingram + 1) * nfilters) * 4 + (size_t)(kPacrrMaxFeat + 2 * kPacrrMaxC + 8) * 4 +
-                      (size_t)kQT * kMaxNV * 16 * 16;
-  if (smem > 160 * 1024) return CAPAMD_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
+  const size_t tail = (size_t)(ncw + (maxgram - mingram + 1) * nfilters) * 4 + (size_t)(kPacrrMaxFeat + 2 * kPacrrMaxC + 8) * 4 + 16 +
+                      (size_t)kQT * kMaxNV * 16 * 16;
+  if (Q <= kMfmaMaxQ && nfilters <= 32 && !pacrr_force_valu()) {
+    const size_t smem = (size_t)((L + 7) & ~7) * 6 + (size_t)(((L + 63) & ~63) + 4) * 32 + tail;
+#define LAUNCH_M(NV_)                                                                                                           \
+  do {                                                                                                                          \
+    auto k = kmax <= 2 ? pacrr_mfma_kernel<NV_, 2> : pacrr_mfma_kernel<NV_, kPacrrMaxK>;                                       \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(k, dim3(B), dim3(kThreads), smem, s, a);                                                                 \
+  } while (0)
+    switch (nv_for_dim(D)) {
+      case 1: LAUNCH_M(1); break;
+      case 2: LAUNCH_M(2); break;
+      case 3: LAUNCH_M(3); break;
+      case 4: LAUNCH_M(4); break;
+      default: LAUNCH_M(5); break;
+    }
+#undef LAUNCH_M
+    return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+  }
+  const int ppl = L <= 256 ? 4 : (L <= 512 ? 8 : (L <= 832 ? 13 : 16));
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(Q + kPacrrMaxGram - 1) * (64 * ppl + kPacrrMaxGram) * 4 + tail;
+  if (smem > 160 * 1024) return CAPAMD_ERR_ARG;
 #define LAUNCH(NV_, PPL_)                                                                                                       \
   do {                                                                                                                          \
     auto k = pacrr_forward_kernel<NV_, PPL_>;                                                                                   \

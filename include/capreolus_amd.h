@@ -214,12 +214,14 @@ int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv
 
 /* ---- PACRR ---------------------------------------------------------------------------
  * Replaces PACRR_class.forward + PACRRConvMax2dModule.forward, capreolus/reranker/PACRR.py:42-78 (called from PACRR.test
- * :113-117): similarity matrix as in KNRM -> per n-gram size Conv2d(1 -> nfilters, ng x ng) on the zero-padded matrix,
+ * :114-118): similarity matrix as in KNRM -> per n-gram size Conv2d(1 -> nfilters, ng x ng) on the zero-padded matrix,
  * ReLU, max over filters, kmax largest values over ALL document positions -> optional idf channel (softmax over the
  * query's raw idf values) -> three linear layers with `nonlinearity` (0 none, 1 relu, 2 tanh) in between.
  * conv_w: Conv2d weights of the n-gram modules (mingram..maxgram) back to back, each [nfilters][ng][ng]; conv_b
  * [n_ngrams][nfilters]; w1 [combine][Q * (n_ngrams * kmax + use_idf)], w2 [combine][combine], w3 [combine].
- * Limits: Q <= 8, L <= 1024, maxgram <= 3, kmax <= 4, combine <= 128.  Status bits as for capamd_knrm_forward. */
+ * Limits: Q <= 8, L <= 1024, maxgram <= 3, kmax <= 4, nfilters <= 256, combine <= 128 (CAPAMD_ERR_ARG beyond them).  Q <= 5
+ * with nfilters <= 32 (the reference defaults) runs the convolutions on the matrix pipe (f16 hi/lo split, fp32 accumulate,
+ * ~1e-6 of the fp32 form); other geometries an fp32 VALU kernel.  Status bits as for capamd_knrm_forward. */
 int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed,
                          int64_t V, int D, int mingram, int maxgram, int nfilters, int kmax, const float* conv_w,
                          const float* conv_b, int use_idf, int combine, int nonlinearity, const float* w1, const float* b1,

@@ -615,8 +615,10 @@ def _pacrr_reranker(c):
     return r
 
 
+@pytest.mark.parametrize("valu", ["0", "1"])
 @pytest.mark.parametrize("name", PACRR_CASES)
-def test_pacrr_scores(name):
+def test_pacrr_scores(name, valu, monkeypatch):
+    monkeypatch.setenv("CAPAMD_PACRR_VALU", valu)           # "1": the general fp32-VALU kernel instead of the matrix-pipe one
     c = load_case("pacrr", name)
     r = _pacrr_reranker(c)
     with torch.no_grad():
@@ -636,6 +638,11 @@ def test_pacrr_scores(name):
     (3, 256, 1, 2, 16, 2, False, "relu", 32),    # run length exactly 4
     (4, 1000, 1, 3, 8, 2, True, "relu", 16),     # longest supported document
     (2, 2, 3, 3, 4, 2, False, "relu", 4),        # window larger than the matrix: only padding contributes beyond (0,0)
+    (5, 800, 1, 3, 32, 4, True, "relu", 32),     # the matrix-pipe kernel at its limits (Q = 5, 32 filters)
+    (5, 64, 1, 3, 32, 2, False, "relu", 32),     # exactly one 64-position step
+    (4, 65, 3, 3, 32, 2, False, "relu", 32),     # one position into the second step, trigrams only
+    (6, 300, 1, 3, 32, 2, True, "relu", 32),     # one query row too many for it: general kernel
+    (4, 300, 1, 3, 33, 2, True, "relu", 32),     # one filter too many for it: general kernel
 ])
 def test_pacrr_geometries_match_oracle(Q, L, lo, hi, nf, kmax, idf, nonlin, comb):
     rng = np.random.default_rng(Q * 1000 + L)
