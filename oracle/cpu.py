@@ -128,3 +128,23 @@ def pacrr(q_ids, d_ids, idf, packed, D, mingram, maxgram, nfilters, kmax, conv_w
                              int(nfilters), int(kmax), _p(cw), _p(cb), int(bool(use_idf)), int(C), _p(w1), _p(b1), _p(w2), _p(b2),
                              _p(w3.reshape(-1)), _p(b3.reshape(-1)), NONLIN[nonlinearity], _p(out))
     return out, err
+
+
+def convknrm(q_ids, d_ids, emb, conv_ws, conv_bs, crossmatch, mu, sigma, w1, b1, w2=None, b2=None, score_tanh=False):
+    """conv_ws: list of Conv1d weights [F, D, g] for g = 1..G; conv_bs: list of [F].  w2 is None: single combine layer."""
+    q_ids, d_ids, emb = _i64(q_ids), _i64(d_ids), _f32(emb)
+    B, Q = q_ids.shape
+    L = d_ids.shape[1]
+    V, D = emb.shape
+    G, F = len(conv_ws), conv_ws[0].shape[0]
+    cw = np.ascontiguousarray(np.concatenate([_f32(w).reshape(-1) for w in conv_ws]))
+    cb = np.ascontiguousarray(np.concatenate([_f32(b).reshape(-1) for b in conv_bs]))
+    mu, sigma, w1, b1 = _f32(mu), _f32(sigma), _f32(w1), _f32(b1)
+    H = 0 if w2 is None else w1.shape[0]
+    w2 = None if w2 is None else _f32(w2).reshape(-1)
+    b2 = None if b2 is None else _f32(b2).reshape(-1)
+    out = np.empty(B, dtype=np.float32)
+    err = lib().oracle_convknrm(_p(q_ids), _p(d_ids), B, Q, L, _p(emb), ctypes.c_int64(V), D, G, F, _p(cw), _p(cb), int(bool(crossmatch)),
+                                _p(mu), _p(sigma), mu.shape[0], _p(w1.reshape(-1)), _p(b1.reshape(-1)), H, _p(w2), _p(b2), int(bool(score_tanh)),
+                                _p(out))
+    return out, err

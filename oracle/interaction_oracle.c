@@ -358,3 +358,100 @@ int oracle_pacrr(const int64_t* q_ids, const int64_t* d_ids, const float* idf, i
   }
   return err;
 }
+
+/* ---- ConvKNRM: ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-77 ---------------------------
+ *   embeddings (common.py:279-288; ids outside [0, V) make nn.Embedding raise -> error bits) of the query and the document;
+ *   per n-gram size g = 1..maxngram: right zero padding by g-1 and Conv1d(D -> F, g) over the sequence (:46-49, built at :24-32):
+ *       rep_g[j][f] = bias_g[f] + sum_c sum_d W_g[f][d][c] * E[tok[j + c]][d]       (terms with j + c beyond the sequence are 0)
+ *   StackedSimilarityMatrix (common.py:195-221) of every query view with every document view (crossmatch, :52-55; view = a * G + b)
+ *   or of equal sizes only (:57-59): cos = a.b / ((|a| + 1e-9)(|b| + 1e-9)), 0 where the query or document token AT the position
+ *   is the pad id 0; RbfKernelBank (common.py:232-234, 249-250): exp(-0.5 (s - mu)^2 / sigma / sigma); sum over the document
+ *   (:71), log(. + 1e-6) where the row's similarities do not sum to 0, else 0 (:72-73); sum over the query (:74); feature index
+ *   = kernel * VIEWS + view (:63-64); combine (:35-41): Linear(K * VIEWS, 1), or Linear(., H) -> tanh -> Linear(H, 1); optional tanh.
+ * conv_w: Conv1d weights of g = 1..G back to back, each [F][D][g]; conv_b [G][F].  H = 0: single layer (w1 [K*VIEWS], b1 [1]).
+ * Accumulations are in double (this is the checker, not the measured path). */
+int oracle_convknrm(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* emb, int64_t V, int D, int G, int F,
+                    const float* conv_w, const float* conv_b, int crossmatch, const float* mu, const float* sigma, int K,
+                    const float* w1, const float* b1, int H, const float* w2, const float* b2, int score_tanh, float* out) {
+  const int views = crossmatch ? G * G : G;
+  int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+  for (int b = 0; b < B; ++b) {
+    const int64_t* qi = q_ids + (int64_t)b * Q;
+    const int64_t* di = d_ids + (int64_t)b * L;
+    float* qrep = (float*)malloc(sizeof(float) * (size_t)G * Q * F);
+    float* drep = (float*)malloc(sizeof(float) * (size_t)G * L * F);
+    float* qn = (float*)malloc(sizeof(float) * (size_t)G * Q);
+    float* dn = (float*)malloc(sizeof(float) * (size_t)G * L);
+    double* feat = (double*)calloc((size_t)K * views, sizeof(double));
+    for (int side = 0; side < 2; ++side) {
+      const int64_t* ids = side ? di : qi;
+      const int n = side ? L : Q;
+      float* rep = side ? drep : qrep;
+      float* nrm = side ? dn : qn;
+      const float* w = conv_w;
+      for (int g = 1; g <= G; ++g) {
+        for (int j = 0; j < n; ++j) {
+          double ss = 0.0;
+          for (int f = 0; f < F; ++f) {
+            double s = conv_b[(g - 1) * F + f];
+            for (int c = 0; c < g && j + c < n; ++c) {
+              int64_t id = ids[j + c];
+              if (id < 0 || id >= V) { err |= side ? 1 : 2; id = 0; }
+              const float* e = emb + id * D;
+              for (int d = 0; d < D; ++d) s += (double)w[((size_t)f * D + d) * g + c] * e[d];
+            }
+            const float r = (float)s;
+            rep[((size_t)(g - 1) * n + j) * F + f] = r;
+            ss += (double)r * r;
+          }
+          nrm[(g - 1) * n + j] = (float)sqrt(ss);
+        }
+        w += (size_t)F * D * g;
+      }
+    }
+    for (int v = 0; v < views; ++v) {
+      const int ga = crossmatch ? v / G : v, gb = crossmatch ? v % G : v;
+      for (int q = 0; q < Q; ++q) {
+        double rowsum = 0.0;
+        double* ks = (double*)calloc((size_t)K, sizeof(double));
+        const float* a = qrep + ((size_t)ga * Q + q) * F;
+        const float an = qn[ga * Q + q] + 1e-9f;
+        for (int j = 0; j < L; ++j) {
+          float s = 0.f;
+          if (qi[q] != 0 && di[j] != 0) {
+            const float* bb = drep + ((size_t)gb * L + j) * F;
+            double dot = 0.0;
+            for (int f = 0; f < F; ++f) dot += (double)a[f] * bb[f];
+            s = (float)dot / (an * (dn[gb * L + j] + 1e-9f));
+          }
+          rowsum += s;
+          for (int k = 0; k < K; ++k) {
+            const double adj = (double)s - mu[k];
+            ks[k] += exp(-0.5 * adj * adj / sigma[k] / sigma[k]);
+          }
+        }
+        if (rowsum != 0.0)
+          for (int k = 0; k < K; ++k) feat[k * views + v] += log((double)(float)ks[k] + 1e-6);
+        free(ks);
+      }
+    }
+    const int nin = K * views;
+    double s;
+    if (H == 0) {
+      s = b1[0];
+      for (int i = 0; i < nin; ++i) s += (double)w1[i] * (float)feat[i];
+    } else {
+      s = b2[0];
+      for (int h = 0; h < H; ++h) {
+        double t = b1[h];
+        for (int i = 0; i < nin; ++i) t += (double)w1[(size_t)h * nin + i] * (float)feat[i];
+        s += (double)w2[h] * tanh(t);
+      }
+    }
+    if (score_tanh) s = tanh(s);
+    out[b] = (float)s;
+    free(qrep); free(drep); free(qn); free(dn); free(feat);
+  }
+  return err;
+}

@@ -253,9 +253,59 @@ def gen_pacrr(PACRR):
         print("pacrr", name, scores[:6], list(sd.keys()))
 
 
+def gen_convknrm(CONVKNRM):
+    from tests.helpers import convknrm_conv_weights
+
+    cases = {
+        "default": dict(V=5000, D=300, B=12, Q=4, L=800,
+                        cfg=dict(gradkernels=True, maxngram=3, crossmatch=True, filters=128, scoretanh=False, singlefc=True)),
+        "nocross_2fc_short": dict(V=800, D=50, B=16, Q=3, L=60, perturb_kernels=True,
+                                  cfg=dict(gradkernels=True, maxngram=2, crossmatch=False, filters=32, scoretanh=True, singlefc=False)),
+        "ranklist": dict(V=20000, D=300, B=100, Q=4, L=800, same_query=True,
+                         cfg=dict(gradkernels=True, maxngram=3, crossmatch=True, filters=128, scoretanh=False, singlefc=True)),
+    }
+    for name, c in cases.items():
+        seed = 500 + len(name)
+        rs = np.random.RandomState(seed)
+        emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
+        same = c.get("same_query", False)
+        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40, query_oov_frac=0.0)
+        if not same:
+            batch = _edge_cases(rs, batch, c["V"])
+        # nn.Embedding takes ids in [0, V) only (the slowembedtext extractor has no negative OOV ids): fold the negatives in
+        for k in ("query", "posdoc"):
+            ids = batch[k].astype(np.int64)
+            batch[k] = np.where(ids < 0, (-ids) % (c["V"] - 1) + 1, ids)
+        torch.manual_seed(seed)
+        ext = SimpleNamespace(embeddings=emb, pad=0)
+        model = CONVKNRM.ConvKNRM_class(ext, dict(c["cfg"])).eval()
+        ws, bs = convknrm_conv_weights(seed, c["cfg"]["filters"], c["D"], c["cfg"]["maxngram"])
+        with torch.no_grad():
+            for g, (w, b) in enumerate(zip(ws, bs)):
+                model.convs[g][0].weight.copy_(torch.from_numpy(w))
+                model.convs[g][0].bias.copy_(torch.from_numpy(b))
+            model.combine[0].weight.mul_(4.0)
+            if c.get("perturb_kernels"):
+                for k in model.kernels.kernels:
+                    k.mu.add_(0.03)
+                    k.sigma.mul_(1.2)
+            q, d = torch.from_numpy(batch["query"]), torch.from_numpy(batch["posdoc"])
+            scores = model(d, q, torch.from_numpy(batch["query_idf"])).view(-1).numpy()
+        sd = {k: v.detach().numpy() for k, v in model.state_dict().items() if "embeddings" not in k and not k.startswith("convs.")}
+        out = dict(emb_seed=np.int64(seed), conv_seed=np.int64(seed), V=np.int64(c["V"]), D=np.int64(c["D"]), query=batch["query"].astype(np.int32),
+                   posdoc=batch["posdoc"].astype(np.int32), query_idf=batch["query_idf"], ref_scores=scores.astype(np.float32),
+                   ref_scores_f16=scores.astype(np.float16), **{"cfg." + k: np.int64(v) for k, v in c["cfg"].items()})
+        for k, v in sd.items():
+            out["sd." + k] = v
+        np.savez_compressed(os.path.join(HERE, f"convknrm_{name}.npz"), **out)
+        print("convknrm", name, scores[:6], list(sd.keys())[-4:])
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks", "pacrr"}
-    common, KNRM, DRMM, MAXP, TKS, PACRR = _refharness.load_reference()
+    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks", "pacrr", "convknrm"}
+    common, KNRM, DRMM, MAXP, TKS, PACRR, CONVKNRM = _refharness.load_reference()
+    if "convknrm" in which:
+        gen_convknrm(CONVKNRM)
     if "pacrr" in which:
         gen_pacrr(PACRR)
     if "knrm" in which:

@@ -10,6 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist"]
 DRMM_CASES = ["default", "zero_idf", "tv_nh", "ch", "ranklist"]
 DRMMTKS_CASES = ["default", "top3_short", "ranklist"]
+CONVKNRM_CASES = ["default", "nocross_2fc_short", "ranklist"]
 PACRR_CASES = ["default", "tanh_noidf_short", "ranklist"]
 
 # BASELINE.json north_star: "within 1e-3 relative (fp) and rank-order exactly"
@@ -87,3 +88,23 @@ def pacrr_args(c):
     return (lo, hi, int(c["cfg.nfilters"]), int(c["cfg.kmax"]), [c[f"sd.ngrams.{i}.conv.weight"] for i in range(n)],
             [c[f"sd.ngrams.{i}.conv.bias"] for i in range(n)], bool(int(c["cfg.idf"])), c["sd.linear1.weight"], c["sd.linear1.bias"],
             c["sd.linear2.weight"], c["sd.linear2.bias"], c["sd.linear3.weight"], c["sd.linear3.bias"], str(c["nonlinearity"]))
+
+
+def convknrm_conv_weights(seed, F, D, G):
+    """The Conv1d weights / biases of a ConvKNRM fixture ([F, D, g] for g = 1..G, [F]), regenerated from their seed (the generator loads
+    the same arrays into the reference module, so the fixtures do not have to carry ~1 MB of weights each)."""
+    rs = np.random.RandomState(seed + 7)
+    ws = [(rs.standard_normal((F, D, g)) / np.sqrt(D * g)).astype(np.float32) for g in range(1, G + 1)]
+    bs = [rs.uniform(-0.2, 0.2, F).astype(np.float32) for _ in range(G)]
+    return ws, bs
+
+
+def convknrm_args(c):
+    """(conv_ws, conv_bs, crossmatch, mu, sigma, w1, b1, w2, b2, score_tanh) of a ConvKNRM fixture."""
+    G, F = int(c["cfg.maxngram"]), int(c["cfg.filters"])
+    ws, bs = convknrm_conv_weights(int(c["conv_seed"]), F, int(c["D"]), G)
+    K = sum(1 for k in c if k.startswith("sd.kernels.kernels.") and k.endswith(".mu"))
+    mu = np.array([c[f"sd.kernels.kernels.{k}.mu"] for k in range(K)], dtype=np.float32)
+    sigma = np.array([c[f"sd.kernels.kernels.{k}.sigma"] for k in range(K)], dtype=np.float32)
+    w2, b2 = c.get("sd.combine.2.weight"), c.get("sd.combine.2.bias")
+    return ws, bs, bool(int(c["cfg.crossmatch"])), mu, sigma, c["sd.combine.0.weight"], c["sd.combine.0.bias"], w2, b2, bool(int(c["cfg.scoretanh"]))

@@ -174,3 +174,15 @@ def test_pacrr_oracle_matches_reference(name):
     assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
     if name == "ranklist":
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
+
+
+@pytest.mark.parametrize("name", ["default", "nocross_2fc_short", "ranklist"])
+def test_convknrm_oracle_matches_reference(name):
+    from tests.helpers import convknrm_args
+
+    c = load_case("convknrm", name)
+    got, err = oracle.convknrm(c["query"], c["posdoc"], c["emb"], *convknrm_args(c))
+    assert err == 0
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
+    if name == "ranklist":
+        assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
