@@ -44,6 +44,9 @@ SIGNATURES = {
     "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_pacrr_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
+    "capamd_convknrm_table_bytes": (_i64, [_i64, _i, _i]),
+    "capamd_convknrm_pack_tables": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
+    "capamd_convknrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capamd_knrm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

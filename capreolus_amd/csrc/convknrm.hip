@@ -1,0 +1,459 @@
+// Fused ConvKNRM forward for gfx950.
+//
+// Reference semantics: ConvKNRM_class.forward (capreolus/reranker/ConvKNRM.py:42-77): embeddings of query and document ->
+// per n-gram size g = 1..G a Conv1d(D -> F, g) over the right-zero-padded sequence -> cosine similarity of every query view
+// with every document view (crossmatch) or of equal sizes only (StackedSimilarityMatrix, common.py:195-221; 0 where the query
+// or document token at the position is pad) -> the KNRM kernel pooling over each view -> Linear / (Linear, tanh, Linear).
+//
+// MI355X design: the convolutions never run at scoring time.  The embedding table is frozen (ConvKNRM.py:17, non_trainable) and
+// a Conv1d is linear in its taps, so rep_g[j] = sum_c W_g[:, :, c] E[tok[j + c]] + b_g is a sum of per-token projections.
+// capamd_convknrm_pack_tables computes them once for the whole vocabulary - G(G+1)/2 parts of F floats per token, 1.2 GB for
+// 400k tokens x 6 parts x 128 filters, a small corner of the 288 GB of HBM - and a position's three n-gram vectors become a
+// gather of 3 KB (6 parts from 3 adjacent tokens) plus 3 vector adds instead of 0.46 MFLOP of convolution: 368 MFLOP per
+// 800-term document drop to ~1 MB of gathered rows, the same kind of work as KNRM's own front end.
+//   parts of token t, in this order so that what a position needs from each of its tokens is contiguous:
+//     tap 0 of g = 1..G (bias folded in) | tap 1 of g = 2..G | tap 2 of g = 3
+// One workgroup (4 waves) per pair; document positions whose own token is pad are never touched (their similarity is exactly 0
+// in every view: closed-form kernel contribution, as in KNRM).  Real positions go through tiles of 32:
+//   A  gather + add + L2-normalise (16 lanes per position), two-term f16 split, transposed into LDS [view][position][F]
+//   B  similarities on the matrix pipe: v_mfma_f32_32x32x16_f16, M = the G*Q normalised query vectors, N = 32 positions,
+//      K = F; hi/lo split of both operands (3 products, fp32 accumulate, ~2^-22 relative); wave g owns document view g
+//   C  kernel pooling: every thread owns one (view, query term) row and a slice of the tile's positions; K exp2 per value
+// and a fixed-order reduction, log, query sum and the combine layers at the end.
+#include "capreolus_amd.h"
+#include "interaction.cuh"
+
+using namespace capamd;
+
+namespace {
+
+constexpr int kCkMaxG = 3;
+constexpr int kCkMaxQ = 8;
+constexpr int kCkMaxK = 11;
+constexpr int kCkMaxF = 128;
+constexpr int kCkMaxH = 64;
+constexpr int kCkTile = 32;
+constexpr int kCkMaxRows = kCkMaxG * kCkMaxG * kCkMaxQ;   // (view, query term) rows
+constexpr int kCkMaxTpr = 8;                              // threads per row in the pooling phase
+constexpr float kLog2e = 1.4426950408889634f;
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__host__ __device__ inline int ck_parts(int G) { return G * (G + 1) / 2; }
+// part index of tap c of n-gram size g (1-based)
+__host__ __device__ inline int ck_part(int G, int g, int c) { return (c == 0 ? 0 : (c == 1 ? G : 2 * G - 1)) + (g - 1 - c); }
+
+// ---- table pack: tables[t][part(g, c)][f] = (c == 0 ? bias_g[f] : 0) + sum_d E[t][d] * W_g[f][d][c] ----
+constexpr int kPackTokens = 16;
+
+__global__ __launch_bounds__(256) void convknrm_pack_kernel(const float* __restrict__ emb, int64_t V, int D, int64_t ld,
+                                                            const float* __restrict__ conv_w, const float* __restrict__ conv_b, int G,
+                                                            int F, float* __restrict__ tables) {
+  extern __shared__ __attribute__((aligned(16))) float e_t[];   // [D][16 tokens]
+  const int64_t t0 = (int64_t)blockIdx.x * kPackTokens;
+  for (int i = threadIdx.x; i < D * kPackTokens; i += blockDim.x) {
+    const int t = i / D, d = i - t * D;
+    e_t[d * kPackTokens + t] = (t0 + t < V) ? emb[(t0 + t) * ld + d] : 0.f;
+  }
+  __syncthreads();
+  const int P = ck_parts(G);
+  for (int o = threadIdx.x; o < P * F; o += blockDim.x) {
+    const int p = o / F, f = o - p * F;
+    const int c = p < G ? 0 : (p < 2 * G - 1 ? 1 : 2);
+    const int g = p - (c == 0 ? 0 : (c == 1 ? G : 2 * G - 1)) + 1 + c;
+    int64_t woff = 0;
+    for (int gg = 1; gg < g; ++gg) woff += (int64_t)F * D * gg;
+    const float* w = conv_w + woff + (int64_t)f * D * g + c;
+    float acc[kPackTokens];
+    const float b0 = c == 0 ? conv_b[(g - 1) * F + f] : 0.f;
+#pragma unroll
+    for (int t = 0; t < kPackTokens; ++t) acc[t] = b0;
+    for (int d = 0; d < D; ++d) {
+      const float wv = w[(int64_t)d * g];
+      const float4* e4 = reinterpret_cast<const float4*>(e_t + d * kPackTokens);
+#pragma unroll
+      for (int t4 = 0; t4 < kPackTokens / 4; ++t4) {
+        const float4 e = e4[t4];
+        acc[t4 * 4 + 0] = __builtin_fmaf(e.x, wv, acc[t4 * 4 + 0]);
+        acc[t4 * 4 + 1] = __builtin_fmaf(e.y, wv, acc[t4 * 4 + 1]);
+        acc[t4 * 4 + 2] = __builtin_fmaf(e.z, wv, acc[t4 * 4 + 2]);
+        acc[t4 * 4 + 3] = __builtin_fmaf(e.w, wv, acc[t4 * 4 + 3]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kPackTokens; ++t)
+      if (t0 + t < V) tables[((t0 + t) * P + p) * F + f] = acc[t];
+  }
+}
+
+// byte offsets of the workgroup's LDS regions (host: size of the launch; device: the carve-up)
+struct CkLayout {
+  int tok, pos, d_hi, d_lo, q_hi, q_lo, sims, kr, misc, total;
+};
+
+__host__ __device__ inline CkLayout ck_layout(int L, int F, int G, int Q, int views) {
+  const int lcap = (L + 7) & ~7, RS = F + 8, R = views * Q;
+  CkLayout l;
+  int o = 0;
+  l.tok = o, o += lcap * 4;
+  l.pos = o, o += lcap * 2;
+  l.d_hi = o, o += G * kCkTile * RS * 2;
+  l.d_lo = o, o += G * kCkTile * RS * 2;
+  l.q_hi = o, o += ((G * Q * RS * 2) + 15) & ~15;
+  l.q_lo = o, o += ((G * Q * RS * 2) + 15) & ~15;
+  l.sims = o, o += R * kCkTile * 4;
+  l.kr = o, o += ((R * kCkMaxK * 4) + 15) & ~15;
+  l.misc = o, o += (3 * (kCkMaxK + 1) + kCkMaxK * kCkMaxG * kCkMaxG + 1 + kCkMaxH + kCkMaxQ + kCkMaxG * 32 + 4) * 4;
+  l.total = (o + 15) & ~15;
+  return l;
+}
+
+struct ConvKnrmArgs {
+  const int64_t* q_ids;
+  const int64_t* d_ids;
+  int B, Q, L;
+  const float* tables;
+  int64_t V;
+  int G, F, crossmatch;
+  const float* mu;
+  const float* sigma;
+  int K;
+  const float *w1, *b1;
+  int H;
+  const float *w2, *b2;
+  int score_tanh;
+  float* out;
+  int* status;
+};
+
+// The lane's share (NF4 float4 per view) of the n-gram vectors of one position: tokens t0 (the position's own), t1, t2 (-1: beyond
+// the sequence, contributes nothing).  All loads are issued before the first add.
+template <int NF4>
+__device__ __forceinline__ void ck_rep(const ConvKnrmArgs& a, int t0, int t1, int t2, int lane16, float4 (&rep)[kCkMaxG][NF4]) {
+  const int F4 = a.F >> 2, P = ck_parts(a.G);
+  const float4* r0 = reinterpret_cast<const float4*>(a.tables) + (int64_t)t0 * P * F4;
+  const float4* r1 = reinterpret_cast<const float4*>(a.tables) + (int64_t)(t1 < 0 ? 0 : t1) * P * F4;
+  const float4* r2 = reinterpret_cast<const float4*>(a.tables) + (int64_t)(t2 < 0 ? 0 : t2) * P * F4;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 c1[kCkMaxG][NF4], c2[NF4];
+#pragma unroll
+  for (int g = 1; g <= kCkMaxG; ++g)
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int x = i * 16 + lane16;
+      const bool act = g <= a.G && x < F4;
+      rep[g - 1][i] = act ? r0[(g - 1) * F4 + x] : z;
+      c1[g - 1][i] = (g >= 2 && act && t1 >= 0) ? r1[(a.G + g - 2) * F4 + x] : z;
+      if (g == 3) c2[i] = (act && t2 >= 0) ? r2[(2 * a.G - 1) * F4 + x] : z;
+    }
+#pragma unroll
+  for (int g = 1; g <= kCkMaxG; ++g)
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      float4 v = rep[g - 1][i];
+      if (g >= 2) {
+        v.x += c1[g - 1][i].x;
+        v.y += c1[g - 1][i].y;
+        v.z += c1[g - 1][i].z;
+        v.w += c1[g - 1][i].w;
+      }
+      if (g == 3) {
+        v.x += c2[i].x;
+        v.y += c2[i].y;
+        v.z += c2[i].z;
+        v.w += c2[i].w;
+      }
+      rep[g - 1][i] = v;
+    }
+}
+
+// L2-normalise (x / (|x| + 1e-9), common.py:210-213), split into f16 hi + lo and store the lane's share of row `row` of a
+// [rows][RS] plane pair.
+template <int NF4>
+__device__ __forceinline__ void ck_store_unit(const float4 (&v)[NF4], int F4, int lane16, _Float16* hi, _Float16* lo, int row, int RS) {
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    ss = __builtin_fmaf(v[i].x, v[i].x, ss);
+    ss = __builtin_fmaf(v[i].y, v[i].y, ss);
+    ss = __builtin_fmaf(v[i].z, v[i].z, ss);
+    ss = __builtin_fmaf(v[i].w, v[i].w, ss);
+  }
+  ss = group_allreduce(ss);
+  const float inv = 1.f / (__builtin_sqrtf(ss) + 1e-9f);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int x = i * 16 + lane16;
+    if (x < F4) {
+      const float e[4] = {v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv};
+      h4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (_Float16)e[j];
+        l[j] = (_Float16)(e[j] - (float)h[j]);
+      }
+      *reinterpret_cast<h4*>(hi + row * RS + x * 4) = h;
+      *reinterpret_cast<h4*>(lo + row * RS + x * 4) = l;
+    }
+  }
+}
+
+template <int NF4>
+__global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lane16 = tid & 15, grp = tid >> 4;
+  const int b = blockIdx.x;
+  const int G = a.G, Q = a.Q, F = a.F, F4 = F >> 2, K = a.K;
+  const int views = a.crossmatch ? G * G : G, R = views * Q, GQ = G * Q;
+  const int RS = F + 8;                                  // f16 per row of an operand plane: 16 B of padding spreads the rows over the banks
+  int tpr = kThreads / R;
+  if (tpr > kCkMaxTpr) tpr = kCkMaxTpr;
+
+  const CkLayout lay = ck_layout(a.L, F, G, Q, views);
+  int* tok = reinterpret_cast<int*>(smem_raw + lay.tok);                 // [lcap] every token of the document
+  unsigned short* pos = reinterpret_cast<unsigned short*>(smem_raw + lay.pos);   // [lcap] positions whose own token is real
+  _Float16* d_hi = reinterpret_cast<_Float16*>(smem_raw + lay.d_hi);     // [G][32][RS]
+  _Float16* d_lo = reinterpret_cast<_Float16*>(smem_raw + lay.d_lo);
+  _Float16* q_hi = reinterpret_cast<_Float16*>(smem_raw + lay.q_hi);     // [G*Q][RS]
+  _Float16* q_lo = reinterpret_cast<_Float16*>(smem_raw + lay.q_lo);
+  float* sims = reinterpret_cast<float*>(smem_raw + lay.sims);           // [R][32]
+  float* kr = reinterpret_cast<float*>(smem_raw + lay.kr);               // [R][K] log kernel sums
+  float* kmu = reinterpret_cast<float*>(smem_raw + lay.misc);            // [K]
+  float* kco = kmu + kCkMaxK + 1;                                        // [K]
+  float* kz = kco + kCkMaxK + 1;                                         // [K] kernel value of a similarity of exactly 0
+  float* feat = kz + kCkMaxK + 1;                                        // [K * views]
+  float* hid = feat + kCkMaxK * kCkMaxG * kCkMaxG + 1;                   // [H]
+  int* qtok = reinterpret_cast<int*>(hid + kCkMaxH);                     // [Q]
+  int* rowmap = qtok + kCkMaxQ;                                          // [G][32]: sims row of MFMA row m for document view g, or -1
+  int* wave_cnt = rowmap + kCkMaxG * 32;                                 // [4]
+  float* partial = reinterpret_cast<float*>(d_hi);                       // [R][tpr][kCkMaxK + 1], after the last tile
+
+  const int64_t* qi = a.q_ids + (int64_t)b * Q;
+  const int64_t* di = a.d_ids + (int64_t)b * a.L;
+
+  // ---- tokens, compaction of the real positions, constants ----
+  if (tid < Q) {
+    int64_t id = qi[tid];
+    if (id < 0 || id >= a.V) {
+      atomicOr(a.status, id < 0 ? kErrQueryOOV : kErrQueryIdRange);
+      id = 0;
+    }
+    qtok[tid] = (int)id;
+  }
+  if (tid < K) {
+    const float m = a.mu[tid], sg = a.sigma[tid];
+    const float c = (-0.5f * kLog2e) / (sg * sg);
+    kmu[tid] = m;
+    kco[tid] = c;
+    kz[tid] = __builtin_amdgcn_exp2f(m * m * c);
+  }
+  for (int i = tid; i < G * 32; i += kThreads) {
+    const int gb = i >> 5, m = i & 31;
+    int r = -1;
+    if (m < GQ) {
+      const int ga = m / Q, q = m - ga * Q;
+      if (a.crossmatch) r = (ga * G + gb) * Q + q;
+      else if (ga == gb) r = gb * Q + q;
+    }
+    rowmap[i] = r;
+  }
+  int n_real = 0;
+  for (int base = 0; base < a.L; base += kThreads) {
+    const int j = base + tid;
+    int64_t id = (j < a.L) ? di[j] : 0;
+    if (id < 0 || id >= a.V) {
+      atomicOr(a.status, kErrDocIdRange);
+      id = 0;
+    }
+    if (j < a.L) tok[j] = (int)id;
+    const bool real = id != 0;
+    const unsigned long long m = __ballot(real);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_real;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (real) pos[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)j;
+    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+
+  // ---- query vectors: group q builds the G views of query position q ----
+  if (grp < Q) {
+    const int q = grp;
+    float4 rep[kCkMaxG][NF4];
+    ck_rep<NF4>(a, qtok[q], q + 1 < Q ? qtok[q + 1] : -1, q + 2 < Q ? qtok[q + 2] : -1, lane16, rep);
+#pragma unroll
+    for (int g = 0; g < kCkMaxG; ++g)
+      if (g < G) ck_store_unit<NF4>(rep[g], F4, lane16, q_hi, q_lo, g * Q + q, RS);
+  }
+
+  // ---- pooling state: thread -> (row, slice of positions) ----
+  const int prow = tid / tpr, psub = tid - prow * tpr;
+  const bool pool = prow < R && qtok[prow % Q] != 0;     // rows of pad query terms stay all-zero (masked at the end)
+  float kacc[kCkMaxK];
+#pragma unroll
+  for (int k = 0; k < kCkMaxK; ++k) kacc[k] = 0.f;
+  float rowsum = 0.f;
+  __syncthreads();
+
+  for (int base = 0; base < n_real; base += kCkTile) {
+    const int nv = min(kCkTile, n_real - base);
+    // -- A: gather, add, normalise, split --
+#pragma unroll 1
+    for (int s = grp; s < nv; s += kGroupsPerWG) {
+      const int j = pos[base + s];
+      float4 rep[kCkMaxG][NF4];
+      ck_rep<NF4>(a, tok[j], j + 1 < a.L ? tok[j + 1] : -1, j + 2 < a.L ? tok[j + 2] : -1, lane16, rep);
+#pragma unroll
+      for (int g = 0; g < kCkMaxG; ++g)
+        if (g < G) ck_store_unit<NF4>(rep[g], F4, lane16, d_hi + g * kCkTile * RS, d_lo + g * kCkTile * RS, s, RS);
+    }
+    __syncthreads();
+    // -- B: wave g < G: similarities of document view g with every query vector --
+    if (wave < G) {
+      const int m = lane & 31, half = lane >> 5;
+      const _Float16* ah = q_hi + m * RS + 8 * half;
+      const _Float16* al = q_lo + m * RS + 8 * half;
+      const _Float16* bh = d_hi + (wave * kCkTile + m) * RS + 8 * half;
+      const _Float16* bl = d_lo + (wave * kCkTile + m) * RS + 8 * half;
+      const bool arow = m < GQ;
+      f32x16 c = {0};
+      const h8 zero = {0};
+      for (int kk = 0; kk < F; kk += 16) {
+        const h8 a_hi = arow ? *reinterpret_cast<const h8*>(ah + kk) : zero;
+        const h8 a_lo = arow ? *reinterpret_cast<const h8*>(al + kk) : zero;
+        const h8 b_hi = *reinterpret_cast<const h8*>(bh + kk);
+        const h8 b_lo = *reinterpret_cast<const h8*>(bl + kk);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, c, 0, 0, 0);
+      }
+      if (m < nv) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i >> 2) * 8 + half * 4 + (i & 3);
+          const int r = rowmap[wave * 32 + row];
+          if (r >= 0) sims[r * kCkTile + m] = c[i];
+        }
+      }
+    }
+    __syncthreads();
+    // -- C: kernel pooling --
+    if (pool) {
+      for (int n = psub; n < nv; n += tpr) {
+        const float s = sims[prow * kCkTile + n];
+        rowsum += s;
+#pragma unroll
+        for (int k = 0; k < kCkMaxK; ++k)
+          if (k < K) {
+            const float adj = s - kmu[k];
+            kacc[k] += __builtin_amdgcn_exp2f(adj * adj * kco[k]);
+          }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- fixed-order reduction over the slices, pads in closed form, log, sum over the query ----
+  if (prow < R) {
+    float* p = partial + (prow * tpr + psub) * (kCkMaxK + 1);
+#pragma unroll
+    for (int k = 0; k < kCkMaxK; ++k) p[k] = kacc[k];
+    p[kCkMaxK] = rowsum;
+  }
+  __syncthreads();
+  const float n_zero = (float)(a.L - n_real);
+  for (int i = tid; i < R * K; i += kThreads) {
+    const int r = i / K, k = i - r * K;
+    float s = 0.f, rs = 0.f;
+    for (int u = 0; u < tpr; ++u) {
+      s += partial[(r * tpr + u) * (kCkMaxK + 1) + k];
+      rs += partial[(r * tpr + u) * (kCkMaxK + 1) + kCkMaxK];
+    }
+    s = __builtin_fmaf(n_zero, kz[k], s);
+    kr[r * K + k] = rs != 0.f ? logf(s + 1e-6f) : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < K * views; i += kThreads) {
+    const int k = i / views, v = i - k * views;
+    float s = 0.f;
+    for (int q = 0; q < Q; ++q) s += kr[(v * Q + q) * K + k];
+    feat[i] = s;
+  }
+  __syncthreads();
+  const int nin = K * views;
+  if (a.H == 0) {
+    if (wave == 0) {
+      float s = 0.f;
+      for (int i = lane; i < nin; i += 64) s = __builtin_fmaf(a.w1[i], feat[i], s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) {
+        s += a.b1[0];
+        a.out[b] = a.score_tanh ? tanhf(s) : s;
+      }
+    }
+  } else {
+    if (tid < a.H) {
+      float s = a.b1[tid];
+      for (int i = 0; i < nin; ++i) s = __builtin_fmaf(a.w1[tid * nin + i], feat[i], s);
+      hid[tid] = tanhf(s);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float s = a.b2[0];
+      for (int h = 0; h < a.H; ++h) s = __builtin_fmaf(a.w2[h], hid[h], s);
+      a.out[b] = a.score_tanh ? tanhf(s) : s;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t capamd_convknrm_table_bytes(int64_t V, int maxngram, int filters) {
+  if (V < 1 || maxngram < 1 || maxngram > kCkMaxG || filters < 16 || filters > kCkMaxF || (filters & 15)) return -1;
+  return V * ck_parts(maxngram) * filters * (int64_t)sizeof(float);
+}
+
+extern "C" int capamd_convknrm_pack_tables(const float* emb, int64_t V, int D, int64_t ld, const float* conv_w, const float* conv_b,
+                                           int maxngram, int filters, float* tables, void* stream) {
+  if (!emb || !conv_w || !conv_b || !tables || D < 1 || D > 1024 || ld < D) return CAPAMD_ERR_ARG;
+  if (capamd_convknrm_table_bytes(V, maxngram, filters) < 0) return CAPAMD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(tables) & 15) != 0) return CAPAMD_ERR_ALIGN;
+  (void)hipGetLastError();
+  const int64_t blocks = (V + kPackTokens - 1) / kPackTokens;
+  hipLaunchKernelGGL(convknrm_pack_kernel, dim3((unsigned)blocks), dim3(256), (size_t)D * kPackTokens * sizeof(float), (hipStream_t)stream, emb,
+                     V, D, ld, conv_w, conv_b, maxngram, filters, tables);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+extern "C" int capamd_convknrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* tables, int64_t V,
+                                       int maxngram, int filters, int crossmatch, const float* mu, const float* sigma, int K, const float* w1,
+                                       const float* b1, int H, const float* w2, const float* b2, int score_tanh, float* out, int* status,
+                                       void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !tables || !mu || !sigma || !w1 || !b1 || !out || !status) return CAPAMD_ERR_ARG;
+  if (H != 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kCkMaxQ || L < 1 || L > 4096 || V > 0x7fffffffLL || K < 1 || K > kCkMaxK || H < 0 || H > kCkMaxH)
+    return CAPAMD_ERR_ARG;
+  if (capamd_convknrm_table_bytes(V, maxngram, filters) < 0) return CAPAMD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(tables) & 15) != 0) return CAPAMD_ERR_ALIGN;
+  const size_t smem = (size_t)ck_layout(L, filters, maxngram, Q, crossmatch ? maxngram * maxngram : maxngram).total;
+  if (smem > 160 * 1024) return CAPAMD_ERR_ARG;
+  ConvKnrmArgs a{q_ids, d_ids, B, Q, L, tables, V, maxngram, filters, crossmatch ? 1 : 0, mu, sigma, K, w1, b1, H, w2, b2, score_tanh ? 1 : 0,
+                 out, status};
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+#define LAUNCH(NF4_)                                                                                                            \
+  do {                                                                                                                          \
+    auto k = convknrm_forward_kernel<NF4_>;                                                                                     \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(k, dim3(B), dim3(kThreads), smem, s, a);                                                                 \
+  } while (0)
+  if (filters <= 64) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}

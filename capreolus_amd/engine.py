@@ -54,11 +54,11 @@ class StatusWord:
             self.t.zero_()
             msgs = []
             if bits & _lib.STATUS_DOC_ID_RANGE:
-                msgs.append("a document term id is >= the embedding table size")
+                msgs.append("a document term id is outside the embedding table")
             if bits & _lib.STATUS_QUERY_ID_RANGE:
                 msgs.append("a query term id is >= the embedding table size")
             if bits & _lib.STATUS_QUERY_OOV:
-                msgs.append("DRMM cannot score an OOV (negative) query term id (reference DRMM.py:109 raises IndexError)")
+                msgs.append("a negative (OOV) query term id where the reference model cannot take one (DRMM.py:109, nn.Embedding in ConvKNRM.py:43)")
             if bits & (_lib.STATUS_SCORE_NAN | _lib.STATUS_TIE_RANGE):
                 raise ValueError("ranking: " + ("a score is NaN; " if bits & _lib.STATUS_SCORE_NAN else "") +
                                  ("a tie-break rank is outside 0..n-1" if bits & _lib.STATUS_TIE_RANGE else ""))
@@ -500,6 +500,54 @@ def pacrr_forward(query, doc, idf, packed, V, D, mingram, maxgram, nfilters, kma
                                           int(kmax), _ptr(conv_w), _ptr(conv_b), int(bool(use_idf)), w1.shape[0], NONLINEARITIES[nonlinearity],
                                           _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(st.t), _stream())
     _lib.check(rc, "capamd_pacrr_forward")
+    if check:
+        st.raise_if_set()
+    return out
+
+
+class ConvProjectionTables:
+    """ConvKNRM's Conv1d layers folded into per-token projection tables (capamd_convknrm_pack_tables).  Rebuilt whenever the
+    embedding table or any convolution parameter changes (version counters + storage pointers)."""
+
+    def __init__(self):
+        self._key = None
+        self.tables = None
+
+    def get(self, weight, conv_ws, conv_bs):
+        _need_gpu(weight, *conv_ws, *conv_bs)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (weight, *conv_ws, *conv_bs)) + (weight.device.index,)
+        if key != self._key:
+            lib = _lib.load()
+            w = _f32(weight.detach())
+            V, D = w.shape
+            G, F = len(conv_ws), conv_ws[0].shape[0]
+            nbytes = lib.capamd_convknrm_table_bytes(V, G, F)
+            if nbytes < 0:
+                raise ValueError(f"ConvKNRM geometry maxngram={G}, filters={F} is not supported (maxngram <= 3, filters a multiple of 16 up to 128)")
+            cw = torch.cat([_f32(c.detach()).reshape(-1) for c in conv_ws]).contiguous()
+            cb = torch.cat([_f32(c.detach()).reshape(-1) for c in conv_bs]).contiguous()
+            tables = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            _lib.check(lib.capamd_convknrm_pack_tables(_ptr(w), V, D, w.stride(0), _ptr(cw), _ptr(cb), G, F, _ptr(tables), _stream()),
+                       "capamd_convknrm_pack_tables")
+            self.tables, self._key = tables, key
+        return self.tables
+
+
+def convknrm_forward(query, doc, tables, V, maxngram, filters, crossmatch, mu, sigma, w1, b1, w2=None, b2=None, score_tanh=False, out=None,
+                     check=True):
+    """ConvKNRM_class.forward (reference ConvKNRM.py:42-77): fp32 [B].  w2 is None: single combine layer."""
+    _need_gpu(query, doc, tables, mu, sigma, w1, b1)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L = d.shape[1]
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    H = 0 if w2 is None else w1.shape[0]
+    rc = _lib.load().capamd_convknrm_forward(_ptr(q), _ptr(d), B, Q, L, _ptr(tables), V, int(maxngram), int(filters), int(bool(crossmatch)),
+                                             _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), H, None if w2 is None else _ptr(w2),
+                                             None if b2 is None else _ptr(b2), int(bool(score_tanh)), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_convknrm_forward")
     if check:
         st.raise_if_set()
     return out

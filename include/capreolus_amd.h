@@ -212,6 +212,24 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
                               int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream);
 
+/* ---- ConvKNRM ------------------------------------------------------------------------
+ * Replaces ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-77 (called from ConvKNRM.test :112-116).
+ * The Conv1d layers (ConvKNRM.py:24-32) over the frozen embedding table (:17) are folded, once per model, into a table of
+ * per-token projections: tables[t][part][f], maxngram*(maxngram+1)/2 parts per token in the order
+ *     tap 0 of g = 1..G (bias added) | tap 1 of g = 2..G | tap 2 of g = 3,
+ * so that rep_g[j] = part(g,0)[tok j] + part(g,1)[tok j+1] + part(g,2)[tok j+2] (terms beyond the sequence end dropped).
+ * conv_w: Conv1d weights of g = 1..maxngram back to back, each [filters][D][g]; conv_b [maxngram][filters].
+ * Limits: maxngram <= 3; filters a multiple of 16, 16..128; Q <= 8; K <= 11 kernels; H (hidden width of the two-layer
+ * combine, 0 = single Linear) <= 64; L <= 4096.  Ids must lie in [0, V): others set the status bits (nn.Embedding raises).
+ * w1 [K*views] (H = 0) or [H][K*views]; feature index = kernel * views + view, view = query_g * G + doc_g (crossmatch) or g. */
+int64_t capamd_convknrm_table_bytes(int64_t V, int maxngram, int filters);   /* -1: unsupported geometry */
+int capamd_convknrm_pack_tables(const float* emb, int64_t V, int D, int64_t ld, const float* conv_w, const float* conv_b,
+                                int maxngram, int filters, float* tables, void* stream);
+int capamd_convknrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* tables, int64_t V,
+                            int maxngram, int filters, int crossmatch, const float* mu, const float* sigma, int K, const float* w1,
+                            const float* b1, int H, const float* w2, const float* b2, int score_tanh, float* out, int* status,
+                            void* stream);
+
 /* ---- PACRR ---------------------------------------------------------------------------
  * Replaces PACRR_class.forward + PACRRConvMax2dModule.forward, capreolus/reranker/PACRR.py:42-78 (called from PACRR.test
  * :114-118): similarity matrix as in KNRM -> per n-gram size Conv2d(1 -> nfilters, ng x ng) on the zero-padded matrix,

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from capreolus_amd import synthetic  # noqa: E402
-from capreolus_amd.reranker import DRMMTKS, PACRR  # noqa: E402
+from capreolus_amd.reranker import DRMMTKS, PACRR, ConvKNRM  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--queries", type=int, default=64)
@@ -18,12 +18,18 @@ ap.add_argument("--docs", type=int, default=1000)
 ap.add_argument("--vocab", type=int, default=400001)
 ap.add_argument("--dim", type=int, default=300)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--only", default="", help="comma-separated model names")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 emb = synthetic.make_embeddings(args.vocab, args.dim, seed=0)
 batch = synthetic.make_candidate_list_torch(args.queries, args.docs, args.vocab, dev)
-ext = SimpleNamespace(embeddings=emb, config={"maxqlen": 4})
-for name, r in (("DRMMTKS", DRMMTKS({}, ext)), ("PACRR", PACRR({}, ext)), ("PACRR-kmax4-128", PACRR({"kmax": 4, "combine": 128}, ext))):
+ext = SimpleNamespace(embeddings=emb, config={"maxqlen": 4}, pad=0)
+batch_pos = {k: (v.abs() if v.dtype == torch.int64 else v) for k, v in batch.items()}   # ConvKNRM: nn.Embedding ids only (no negative OOV ids)
+for name, r in (("DRMMTKS", DRMMTKS({}, ext)), ("PACRR", PACRR({}, ext)), ("PACRR-kmax4-128", PACRR({"kmax": 4, "combine": 128}, ext)),
+                ("ConvKNRM", ConvKNRM({}, ext))):
+    if args.only and name not in args.only.split(","):
+        continue
+    batch = batch_pos if name == "ConvKNRM" else batch
     torch.manual_seed(0)
     m = r.build_model().to(dev).eval()
     with torch.no_grad():

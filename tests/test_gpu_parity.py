@@ -10,7 +10,8 @@ from capreolus_amd import engine, run_io, synthetic
 from capreolus_amd._lib import EngineError
 from capreolus_amd.reranker import DRMM, KNRM
 from oracle import cpu as oracle
-from tests.helpers import DRMM_CASES, KNRM_CASES, PACRR_CASES, REL_TOL, knrm_weights, load_case, pacrr_args, rank_order, rel_err
+from tests.helpers import (CONVKNRM_CASES, DRMM_CASES, KNRM_CASES, PACRR_CASES, REL_TOL, convknrm_args, convknrm_conv_weights, knrm_weights,
+                           load_case, pacrr_args, rank_order, rel_err)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -683,3 +684,98 @@ def test_pacrr_errors():
         z = torch.zeros(4096, device=DEV)
         engine.pacrr_forward(b["query"], b["posdoc"], b["query_idf"], pe.get(_t(c["emb"])), int(c["V"]), int(c["D"]), 1, 4, 8, 2, z, z, False,
                              "relu", z, z, z, z, z, z)
+
+
+CONVKNRM_ORACLE_TOL = 5e-5   # the oracle accumulates in double; the kernel in fp32 (two-term f16 split on the matrix pipe, ~2^-22)
+
+
+def _convknrm_reranker(c):
+    from capreolus_amd.reranker import ConvKNRM
+
+    cfg = {k: int(c[f"cfg.{k}"]) for k in ("maxngram", "filters")}
+    cfg.update({k: bool(int(c[f"cfg.{k}"])) for k in ("gradkernels", "crossmatch", "scoretanh", "singlefc")})
+    r = ConvKNRM(cfg, SimpleNamespace(embeddings=c["emb"], pad=0))
+    m = r.build_model()
+    sd = {k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}
+    ws, bs = convknrm_conv_weights(int(c["conv_seed"]), cfg["filters"], int(c["D"]), cfg["maxngram"])
+    for g, (w, b) in enumerate(zip(ws, bs)):
+        sd[f"convs.{g}.0.weight"], sd[f"convs.{g}.0.bias"] = torch.as_tensor(w), torch.as_tensor(b)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {"embeddings.weight"}, (missing, unexpected)   # the reference's parameter names, all of them
+    m.to(DEV).eval()
+    return r
+
+
+@pytest.mark.parametrize("name", CONVKNRM_CASES)
+def test_convknrm_scores(name):
+    c = load_case("convknrm", name)
+    r = _convknrm_reranker(c)
+    with torch.no_grad():
+        got = r.test(_batch(c)).cpu().numpy()
+    want, err = oracle.convknrm(c["query"], c["posdoc"], c["emb"], *convknrm_args(c))
+    assert err == 0
+    assert rel_err(got, want).max() <= CONVKNRM_ORACLE_TOL, rel_err(got, want).max()
+    assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, rel_err(got, c["ref_scores"]).max()
+    if name == "ranklist":
+        assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
+
+
+def test_convknrm_tables_match_direct_projection():
+    rng = np.random.default_rng(3)
+    V, D, F, G = 123, 77, 48, 3
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    ws = [rng.standard_normal((F, D, g)).astype(np.float32) for g in range(1, G + 1)]
+    bs = [rng.standard_normal(F).astype(np.float32) for _ in range(G)]
+    t = engine.ConvProjectionTables().get(_t(emb), [_t(w) for w in ws], [_t(b) for b in bs]).cpu().numpy().reshape(V, 6, F)
+    order = [(1, 0), (2, 0), (3, 0), (2, 1), (3, 1), (3, 2)]          # (n-gram size, tap) of the six parts
+    for p, (g, tap) in enumerate(order):
+        want = emb.astype(np.float64) @ ws[g - 1][:, :, tap].T.astype(np.float64) + (bs[g - 1] if tap == 0 else 0.0)
+        assert np.abs(t[:, p] - want).max() <= 1e-4 * np.abs(want).max(), (p, np.abs(t[:, p] - want).max())
+
+
+@pytest.mark.parametrize("Q,L,G,F,cross,single,tanh", [
+    (1, 1, 1, 16, True, True, False),       # smallest everything
+    (8, 300, 3, 128, True, True, False),    # 72 (view, query term) rows
+    (5, 33, 2, 64, False, False, True),     # one position into the second tile
+    (3, 1000, 3, 96, True, False, False),   # filters not a power of two
+    (4, 64, 3, 32, False, True, False),     # exactly two tiles when every token is real
+])
+def test_convknrm_geometries_match_oracle(Q, L, G, F, cross, single, tanh):
+    rng = np.random.default_rng(Q * 1000 + L)
+    V, D, B = 150, 40, 13
+    emb = synthetic.make_embeddings(V, D, seed=9)
+    emb[0] = rng.standard_normal(D) * 0.1                     # a pad row that is NOT zero: it still feeds the neighbours' n-grams
+    q = rng.integers(1, V, (B, Q)); d = rng.integers(1, V, (B, L))
+    q[:, Q - 1:] *= rng.integers(0, 2, (B, 1)); d[:, L // 2:] *= rng.integers(0, 2, (B, 1))
+    d[:, ::7] *= rng.integers(0, 2, (B, d[:, ::7].shape[1]))   # pads inside the document
+    if L > 1:
+        d[3] = 0                                              # all-padding document
+        q[5] = 0                                              # all-padding query
+    ws, bs = convknrm_conv_weights(17, F, D, G)
+    K = 11
+    views = G * G if cross else G
+    mu = np.array([-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9, 1.0], dtype=np.float32)
+    sigma = np.array([0.1] * 10 + [0.001], dtype=np.float32)
+    H = 0 if single else 30
+    w1 = (rng.standard_normal((max(H, 1), K * views)) * 0.2).astype(np.float32); b1 = rng.standard_normal(max(H, 1)).astype(np.float32) * 0.1
+    w2 = None if single else (rng.standard_normal((1, H)) * 0.3).astype(np.float32)
+    b2 = None if single else rng.standard_normal(1).astype(np.float32)
+    want, err = oracle.convknrm(q, d, emb, ws, bs, cross, mu, sigma, w1, b1, w2, b2, tanh)
+    assert err == 0
+    tables = engine.ConvProjectionTables().get(_t(emb), [_t(w) for w in ws], [_t(b) for b in bs])
+    got = engine.convknrm_forward(_t(q), _t(d), tables, V, G, F, cross, _t(mu), _t(sigma), _t(w1), _t(b1), None if single else _t(w2.ravel()),
+                                  None if single else _t(b2), tanh).cpu().numpy()
+    assert rel_err(got, want).max() <= CONVKNRM_ORACLE_TOL, rel_err(got, want).max()
+
+
+def test_convknrm_errors():
+    c = load_case("convknrm", "nocross_2fc_short")
+    r = _convknrm_reranker(c)
+    b = _batch(c)
+    for bad_id in (int(c["V"]) + 3, -2):                      # nn.Embedding raises IndexError for both
+        bad = dict(b, posdoc=b["posdoc"].clone())
+        bad["posdoc"][2, 5] = bad_id
+        with pytest.raises(IndexError):
+            r.test(bad)
+    with pytest.raises(ValueError):                           # filters not a multiple of 16: refused when the tables are built
+        engine.ConvProjectionTables().get(_t(c["emb"]), [torch.zeros((20, int(c["D"]), 1), device=DEV)], [torch.zeros(20, device=DEV)])
