@@ -14,10 +14,13 @@
 //   parts of token t, in this order so that what a position needs from each of its tokens is contiguous:
 //     tap 0 of g = 1..G (bias folded in) | tap 1 of g = 2..G | tap 2 of g = 3
 // One workgroup (4 waves) per pair; document positions whose own token is pad are never touched (their similarity is exactly 0
-// in every view: closed-form kernel contribution, as in KNRM).  Real positions go through tiles of 32:
-//   A  gather + add + L2-normalise (16 lanes per position), two-term f16 split, transposed into LDS [view][position][F]
-//   B  similarities on the matrix pipe: v_mfma_f32_32x32x16_f16, M = the G*Q normalised query vectors, N = 32 positions,
-//      K = F; hi/lo split of both operands (3 products, fp32 accumulate, ~2^-22 relative); wave g owns document view g
+// in every view: closed-form kernel contribution, as in KNRM).  Real positions go through tiles of 16 (one per 16-lane group):
+//   A  gather + add + L2-normalise (16 lanes per position), two-term f16 split, transposed into LDS [view][position][F];
+//      the 12 loads of the NEXT tile's position are issued before phases B and C of the current one and stay in flight
+//      across them (48 registers), so the gather latency is covered by the tile's own arithmetic
+//   B  similarities on the matrix pipe: v_mfma_f32_16x16x32_f16, M = 16 of the G*Q normalised query vectors, N = 16
+//      positions, K = F; hi/lo split of both operands (3 products, fp32 accumulate, ~2^-22 relative); one wave per
+//      (document view, block of 16 query vectors)
 //   C  kernel pooling: every thread owns one (view, query term) row and a slice of the tile's positions; K exp2 per value
 // and a fixed-order reduction, log, query sum and the combine layers at the end.
 #include "capreolus_amd.h"
@@ -32,14 +35,17 @@ constexpr int kCkMaxQ = 8;
 constexpr int kCkMaxK = 11;
 constexpr int kCkMaxF = 128;
 constexpr int kCkMaxH = 64;
-constexpr int kCkTile = 32;
+constexpr int kCkTile = 16;
 constexpr int kCkMaxRows = kCkMaxG * kCkMaxG * kCkMaxQ;   // (view, query term) rows
 constexpr int kCkMaxTpr = 8;                              // threads per row in the pooling phase
 constexpr float kLog2e = 1.4426950408889634f;
+#ifndef CAPAMD_CK_ABLATE
+#define CAPAMD_CK_ABLATE 0   // profiling builds only, bit mask: 1 = no gather (phase A), 2 = no MFMA (phase B), 4 = no pooling (phase C)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __host__ __device__ inline int ck_parts(int G) { return G * (G + 1) / 2; }
 // part index of tap c of n-gram size g (1-based)
@@ -99,8 +105,10 @@ __host__ __device__ inline CkLayout ck_layout(int L, int F, int G, int Q, int vi
   int o = 0;
   l.tok = o, o += lcap * 4;
   l.pos = o, o += lcap * 2;
-  l.d_hi = o, o += G * kCkTile * RS * 2;
-  l.d_lo = o, o += G * kCkTile * RS * 2;
+  int tpr = kThreads / R;
+  if (tpr > kCkMaxTpr) tpr = kCkMaxTpr;
+  const int planes = 2 * G * kCkTile * RS * 2, part = R * tpr * (kCkMaxK + 1) * 4;   // the partial sums reuse the planes at the end
+  l.d_hi = o, l.d_lo = o + planes / 2, o += ((planes > part ? planes : part) + 15) & ~15;
   l.q_hi = o, o += ((G * Q * RS * 2) + 15) & ~15;
   l.q_lo = o, o += ((G * Q * RS * 2) + 15) & ~15;
   l.sims = o, o += R * kCkTile * 4;
@@ -128,46 +136,64 @@ struct ConvKnrmArgs {
   int* status;
 };
 
-// The lane's share (NF4 float4 per view) of the n-gram vectors of one position: tokens t0 (the position's own), t1, t2 (-1: beyond
-// the sequence, contributes nothing).  All loads are issued before the first add.
+// The lane's share (NF4 float4 per part) of what one position gathers: tap 0 from its own token t0, tap 1 from t1, tap 2 from t2
+// (-1: beyond the sequence, contributes nothing).  Loads only: the sums are taken when the tile is built.
 template <int NF4>
-__device__ __forceinline__ void ck_rep(const ConvKnrmArgs& a, int t0, int t1, int t2, int lane16, float4 (&rep)[kCkMaxG][NF4]) {
+struct CkGather {
+  float4 c0[kCkMaxG][NF4], c1[kCkMaxG][NF4], c2[NF4];
+  int taps;   // bit 0: tap 1 exists (t1 >= 0), bit 1: tap 2 exists
+};
+
+// Loads only, each from a clamped, always valid address: nothing here depends on the loaded data, so the loads stay in flight
+// until ck_sum - one tile later - masks and adds them.  (A select between a global address and a zero constant would also
+// turn the loads into flat loads through a scratch copy of the constant.)
+template <int NF4>
+__device__ __forceinline__ void ck_load(const ConvKnrmArgs& a, int t0, int t1, int t2, int lane16, CkGather<NF4>& r) {
   const int F4 = a.F >> 2, P = ck_parts(a.G);
   const float4* r0 = reinterpret_cast<const float4*>(a.tables) + (int64_t)t0 * P * F4;
   const float4* r1 = reinterpret_cast<const float4*>(a.tables) + (int64_t)(t1 < 0 ? 0 : t1) * P * F4;
   const float4* r2 = reinterpret_cast<const float4*>(a.tables) + (int64_t)(t2 < 0 ? 0 : t2) * P * F4;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 c1[kCkMaxG][NF4], c2[NF4];
+  r.taps = (t1 >= 0 ? 1 : 0) | (t2 >= 0 ? 2 : 0);
 #pragma unroll
   for (int g = 1; g <= kCkMaxG; ++g)
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
-      const int x = i * 16 + lane16;
-      const bool act = g <= a.G && x < F4;
-      rep[g - 1][i] = act ? r0[(g - 1) * F4 + x] : z;
-      c1[g - 1][i] = (g >= 2 && act && t1 >= 0) ? r1[(a.G + g - 2) * F4 + x] : z;
-      if (g == 3) c2[i] = (act && t2 >= 0) ? r2[(2 * a.G - 1) * F4 + x] : z;
-    }
-#pragma unroll
-  for (int g = 1; g <= kCkMaxG; ++g)
-#pragma unroll
-    for (int i = 0; i < NF4; ++i) {
-      float4 v = rep[g - 1][i];
-      if (g >= 2) {
-        v.x += c1[g - 1][i].x;
-        v.y += c1[g - 1][i].y;
-        v.z += c1[g - 1][i].z;
-        v.w += c1[g - 1][i].w;
-      }
-      if (g == 3) {
-        v.x += c2[i].x;
-        v.y += c2[i].y;
-        v.z += c2[i].z;
-        v.w += c2[i].w;
-      }
-      rep[g - 1][i] = v;
+      const int x = i * 16 + lane16, xc = x < F4 ? x : F4 - 1;
+      r.c0[g - 1][i] = r0[(g <= a.G ? g - 1 : 0) * F4 + xc];
+      if (g >= 2) r.c1[g - 1][i] = r1[(g <= a.G ? a.G + g - 2 : 0) * F4 + xc];
+      if (g == 3) r.c2[i] = r2[(g <= a.G ? 2 * a.G - 1 : 0) * F4 + xc];
     }
 }
+
+// rep_g = (tap 0 + tap 1) + tap 2; lanes beyond F, n-gram sizes beyond G and taps beyond the sequence end contribute 0
+template <int NF4>
+__device__ __forceinline__ void ck_sum(const ConvKnrmArgs& a, const CkGather<NF4>& r, int lane16, float4 (&rep)[kCkMaxG][NF4]) {
+  const int F4 = a.F >> 2;
+#pragma unroll
+  for (int g = 1; g <= kCkMaxG; ++g)
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const bool act = g <= a.G && i * 16 + lane16 < F4;
+      float4 v = r.c0[g - 1][i];
+      if (g >= 2) {
+        const float4 u = r.c1[g - 1][i];
+        v.x += (r.taps & 1) ? u.x : 0.f;
+        v.y += (r.taps & 1) ? u.y : 0.f;
+        v.z += (r.taps & 1) ? u.z : 0.f;
+        v.w += (r.taps & 1) ? u.w : 0.f;
+      }
+      if (g == 3) {
+        const float4 u = r.c2[i];
+        v.x += (r.taps & 2) ? u.x : 0.f;
+        v.y += (r.taps & 2) ? u.y : 0.f;
+        v.z += (r.taps & 2) ? u.z : 0.f;
+        v.w += (r.taps & 2) ? u.w : 0.f;
+      }
+      rep[g - 1][i] = act ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void ck_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // L2-normalise (x / (|x| + 1e-9), common.py:210-213), split into f16 hi + lo and store the lane's share of row `row` of a
 // [rows][RS] plane pair.
@@ -201,7 +227,7 @@ __device__ __forceinline__ void ck_store_unit(const float4 (&v)[NF4], int F4, in
 }
 
 template <int NF4>
-__global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmArgs a) {
+__global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lane16 = tid & 15, grp = tid >> 4;
   const int b = blockIdx.x;
@@ -214,19 +240,18 @@ __global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmA
   const CkLayout lay = ck_layout(a.L, F, G, Q, views);
   int* tok = reinterpret_cast<int*>(smem_raw + lay.tok);                 // [lcap] every token of the document
   unsigned short* pos = reinterpret_cast<unsigned short*>(smem_raw + lay.pos);   // [lcap] positions whose own token is real
-  _Float16* d_hi = reinterpret_cast<_Float16*>(smem_raw + lay.d_hi);     // [G][32][RS]
+  _Float16* d_hi = reinterpret_cast<_Float16*>(smem_raw + lay.d_hi);     // [G][16][RS]
   _Float16* d_lo = reinterpret_cast<_Float16*>(smem_raw + lay.d_lo);
   _Float16* q_hi = reinterpret_cast<_Float16*>(smem_raw + lay.q_hi);     // [G*Q][RS]
   _Float16* q_lo = reinterpret_cast<_Float16*>(smem_raw + lay.q_lo);
-  float* sims = reinterpret_cast<float*>(smem_raw + lay.sims);           // [R][32]
+  float* sims = reinterpret_cast<float*>(smem_raw + lay.sims);           // [R][16]
   float* kr = reinterpret_cast<float*>(smem_raw + lay.kr);               // [R][K] log kernel sums
-  float* kmu = reinterpret_cast<float*>(smem_raw + lay.misc);            // [K]
-  float* kco = kmu + kCkMaxK + 1;                                        // [K]
-  float* kz = kco + kCkMaxK + 1;                                         // [K] kernel value of a similarity of exactly 0
+  float* kmu = reinterpret_cast<float*>(smem_raw + lay.misc);            // [12] (mu, coefficient) pairs, zero beyond K
+  float* kz = kmu + 2 * (kCkMaxK + 1);                                   // [K] kernel value of a similarity of exactly 0
   float* feat = kz + kCkMaxK + 1;                                        // [K * views]
   float* hid = feat + kCkMaxK * kCkMaxG * kCkMaxG + 1;                   // [H]
   int* qtok = reinterpret_cast<int*>(hid + kCkMaxH);                     // [Q]
-  int* rowmap = qtok + kCkMaxQ;                                          // [G][32]: sims row of MFMA row m for document view g, or -1
+  int* rowmap = qtok + kCkMaxQ;                                          // [G][32]: sims row of query vector m for document view g, or -1
   int* wave_cnt = rowmap + kCkMaxG * 32;                                 // [4]
   float* partial = reinterpret_cast<float*>(d_hi);                       // [R][tpr][kCkMaxK + 1], after the last tile
 
@@ -242,11 +267,11 @@ __global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmA
     }
     qtok[tid] = (int)id;
   }
-  if (tid < K) {
-    const float m = a.mu[tid], sg = a.sigma[tid];
-    const float c = (-0.5f * kLog2e) / (sg * sg);
-    kmu[tid] = m;
-    kco[tid] = c;
+  if (tid < kCkMaxK + 1) {
+    const float m = tid < K ? a.mu[tid] : 0.f, sg = tid < K ? a.sigma[tid] : 1.f;
+    const float c = tid < K ? (-0.5f * kLog2e) / (sg * sg) : 0.f;
+    kmu[2 * tid] = m;
+    kmu[2 * tid + 1] = c;
     kz[tid] = __builtin_amdgcn_exp2f(m * m * c);
   }
   for (int i = tid; i < G * 32; i += kThreads) {
@@ -282,8 +307,10 @@ __global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmA
   // ---- query vectors: group q builds the G views of query position q ----
   if (grp < Q) {
     const int q = grp;
+    CkGather<NF4> gq;
+    ck_load<NF4>(a, qtok[q], q + 1 < Q ? qtok[q + 1] : -1, q + 2 < Q ? qtok[q + 2] : -1, lane16, gq);
     float4 rep[kCkMaxG][NF4];
-    ck_rep<NF4>(a, qtok[q], q + 1 < Q ? qtok[q + 1] : -1, q + 2 < Q ? qtok[q + 2] : -1, lane16, rep);
+    ck_sum<NF4>(a, gq, lane16, rep);
 #pragma unroll
     for (int g = 0; g < kCkMaxG; ++g)
       if (g < G) ck_store_unit<NF4>(rep[g], F4, lane16, q_hi, q_lo, g * Q + q, RS);
@@ -298,59 +325,87 @@ __global__ __launch_bounds__(kThreads, 2) void convknrm_forward_kernel(ConvKnrmA
   float rowsum = 0.f;
   __syncthreads();
 
+  const int n_mb = (GQ + 15) >> 4, n_jobs = G * n_mb;    // phase B jobs: (document view, block of 16 query vectors)
+  CkGather<NF4> gat;                                     // the position this group owns in the NEXT tile, in flight
+  auto issue = [&](int base) {
+    if (!(CAPAMD_CK_ABLATE & 1) && base + grp < n_real) {
+      const int j = pos[base + grp];
+      ck_load<NF4>(a, tok[j], j + 1 < a.L ? tok[j + 1] : -1, j + 2 < a.L ? tok[j + 2] : -1, lane16, gat);
+    }
+  };
+  issue(0);
   for (int base = 0; base < n_real; base += kCkTile) {
     const int nv = min(kCkTile, n_real - base);
-    // -- A: gather, add, normalise, split --
-#pragma unroll 1
-    for (int s = grp; s < nv; s += kGroupsPerWG) {
-      const int j = pos[base + s];
+    // -- A: add, normalise, split (the loads were issued one tile ago) --
+    if (!(CAPAMD_CK_ABLATE & 1) && grp < nv) {
       float4 rep[kCkMaxG][NF4];
-      ck_rep<NF4>(a, tok[j], j + 1 < a.L ? tok[j + 1] : -1, j + 2 < a.L ? tok[j + 2] : -1, lane16, rep);
+      ck_sum<NF4>(a, gat, lane16, rep);
 #pragma unroll
       for (int g = 0; g < kCkMaxG; ++g)
-        if (g < G) ck_store_unit<NF4>(rep[g], F4, lane16, d_hi + g * kCkTile * RS, d_lo + g * kCkTile * RS, s, RS);
+        if (g < G) ck_store_unit<NF4>(rep[g], F4, lane16, d_hi + g * kCkTile * RS, d_lo + g * kCkTile * RS, grp, RS);
     }
-    __syncthreads();
-    // -- B: wave g < G: similarities of document view g with every query vector --
-    if (wave < G) {
-      const int m = lane & 31, half = lane >> 5;
-      const _Float16* ah = q_hi + m * RS + 8 * half;
-      const _Float16* al = q_lo + m * RS + 8 * half;
-      const _Float16* bh = d_hi + (wave * kCkTile + m) * RS + 8 * half;
-      const _Float16* bl = d_lo + (wave * kCkTile + m) * RS + 8 * half;
-      const bool arow = m < GQ;
-      f32x16 c = {0};
-      const h8 zero = {0};
-      for (int kk = 0; kk < F; kk += 16) {
-        const h8 a_hi = arow ? *reinterpret_cast<const h8*>(ah + kk) : zero;
-        const h8 a_lo = arow ? *reinterpret_cast<const h8*>(al + kk) : zero;
-        const h8 b_hi = *reinterpret_cast<const h8*>(bh + kk);
-        const h8 b_lo = *reinterpret_cast<const h8*>(bl + kk);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, c, 0, 0, 0);
-      }
-      if (m < nv) {
+    ck_lds_barrier();
+    issue(base + kCkTile);
+    // -- B: similarities of document view gb with query vectors mb * 16 .. +15 --
+    if (!(CAPAMD_CK_ABLATE & 2))
+      for (int job = wave; job < n_jobs; job += 4) {
+        const int gb = job / n_mb, mb = job - gb * n_mb;
+        const int n = lane & 15, kg = lane >> 4, m = mb * 16 + n;
+        const bool arow = m < GQ;
+        const _Float16* ah = q_hi + (arow ? m : 0) * RS + 8 * kg;
+        const _Float16* al = q_lo + (arow ? m : 0) * RS + 8 * kg;
+        const _Float16* bh = d_hi + (gb * kCkTile + n) * RS + 8 * kg;
+        const _Float16* bl = d_lo + (gb * kCkTile + n) * RS + 8 * kg;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};   // two chains (even / odd K steps)
+        const h8 zero = {0};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i >> 2) * 8 + half * 4 + (i & 3);
-          const int r = rowmap[wave * 32 + row];
-          if (r >= 0) sims[r * kCkTile + m] = c[i];
+        for (int pr = 0; pr < kCkMaxF / 64; ++pr)               // two K steps (one per chain) at a time: 8 fragment reads, then 6 MFMAs
+          if (pr * 64 < F) {
+            h8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+              const int kk = pr * 64 + st * 32;
+              const bool kin = kk + 8 * kg < F;                 // F is a multiple of 16: the last step may be partly or wholly empty
+              a_hi[st] = (arow && kin) ? *reinterpret_cast<const h8*>(ah + kk) : zero;
+              a_lo[st] = (arow && kin) ? *reinterpret_cast<const h8*>(al + kk) : zero;
+              b_hi[st] = kin ? *reinterpret_cast<const h8*>(bh + kk) : zero;
+              b_lo[st] = kin ? *reinterpret_cast<const h8*>(bl + kk) : zero;
+            }
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0], b_hi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1], b_hi[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0], b_hi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1], b_hi[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0], b_lo[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1], b_lo[1], c1, 0, 0, 0);
+          }
+        if (n < nv) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = mb * 16 + kg * 4 + i;           // query vector of accumulator register i
+            const int r = row < 32 ? rowmap[gb * 32 + row] : -1;
+            if (r >= 0) sims[r * kCkTile + n] = c0[i] + c1[i];
+          }
         }
       }
-    }
-    __syncthreads();
+    ck_lds_barrier();
     // -- C: kernel pooling --
-    if (pool) {
+    if (pool && !(CAPAMD_CK_ABLATE & 4)) {
       for (int n = psub; n < nv; n += tpr) {
         const float s = sims[prow * kCkTile + n];
         rowsum += s;
+        // (mu, coefficient) pairs are re-read from LDS for every value - broadcast reads, two kernels per 16-byte read - instead
+        // of living in 22 registers next to the 48 of the gather in flight (the opaque offset keeps the reads inside the loop:
+        // hoisted, they spill, and a scratch reload would have to wait for the whole gather because loads return in order)
+        int koff = 0;
+        asm volatile("" : "+v"(koff));
+        const float4* kc4 = reinterpret_cast<const float4*>(kmu + koff);
 #pragma unroll
-        for (int k = 0; k < kCkMaxK; ++k)
-          if (k < K) {
-            const float adj = s - kmu[k];
-            kacc[k] += __builtin_amdgcn_exp2f(adj * adj * kco[k]);
-          }
+        for (int k2 = 0; k2 < (kCkMaxK + 1) / 2; ++k2) {        // kernels beyond K have mu = 0, coefficient 0: their sums are never read
+          const float4 c = kc4[k2];
+          const float a0 = s - c.x, a1 = s - c.z;
+          kacc[2 * k2] += __builtin_amdgcn_exp2f(a0 * a0 * c.y);
+          if (2 * k2 + 1 < kCkMaxK) kacc[2 * k2 + 1] += __builtin_amdgcn_exp2f(a1 * a1 * c.w);
+        }
       }
     }
   }
