@@ -37,7 +37,8 @@ constexpr int kCkMaxF = 128;
 constexpr int kCkMaxH = 64;
 constexpr int kCkTile = 16;
 constexpr int kCkMaxRows = kCkMaxG * kCkMaxG * kCkMaxQ;   // (view, query term) rows
-constexpr int kCkMaxTpr = 8;                              // threads per row in the pooling phase
+constexpr int kCkMaxTpr = 16;                             // threads per row in the pooling phase
+constexpr int kCkPoolCols = 2 * kCkTile;                  // the pooling phase runs once per two tiles
 constexpr float kLog2e = 1.4426950408889634f;
 #ifndef CAPAMD_CK_ABLATE
 #define CAPAMD_CK_ABLATE 0   // profiling builds only, bit mask: 1 = no gather (phase A), 2 = no MFMA (phase B), 4 = no pooling (phase C)
@@ -105,13 +106,11 @@ __host__ __device__ inline CkLayout ck_layout(int L, int F, int G, int Q, int vi
   int o = 0;
   l.tok = o, o += lcap * 4;
   l.pos = o, o += lcap * 2;
-  int tpr = kThreads / R;
-  if (tpr > kCkMaxTpr) tpr = kCkMaxTpr;
-  const int planes = 2 * G * kCkTile * RS * 2, part = R * tpr * (kCkMaxK + 1) * 4;   // the partial sums reuse the planes at the end
+  const int planes = 2 * G * kCkTile * RS * 2, part = kThreads * (kCkMaxK + 1) * 4;   // the partial sums reuse the planes at the end
   l.d_hi = o, l.d_lo = o + planes / 2, o += ((planes > part ? planes : part) + 15) & ~15;
   l.q_hi = o, o += ((G * Q * RS * 2) + 15) & ~15;
   l.q_lo = o, o += ((G * Q * RS * 2) + 15) & ~15;
-  l.sims = o, o += R * kCkTile * 4;
+  l.sims = o, o += R * kCkPoolCols * 4;
   l.kr = o, o += ((R * kCkMaxK * 4) + 15) & ~15;
   l.misc = o, o += (3 * (kCkMaxK + 1) + kCkMaxK * kCkMaxG * kCkMaxG + 1 + kCkMaxH + kCkMaxQ + kCkMaxG * 32 + 4) * 4;
   l.total = (o + 15) & ~15;
@@ -193,6 +192,12 @@ __device__ __forceinline__ void ck_sum(const ConvKnrmArgs& a, const CkGather<NF4
     }
 }
 
+// the query token as the kernel uses it (ids outside [0, V) count as pad; the status word reports them)
+__device__ __forceinline__ int qtok_early(const int64_t* qi, int q, int64_t V) {
+  const int64_t id = qi[q];
+  return (id < 0 || id >= V) ? 0 : (int)id;
+}
+
 __device__ __forceinline__ void ck_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // L2-normalise (x / (|x| + 1e-9), common.py:210-213), split into f16 hi + lo and store the lane's share of row `row` of a
@@ -234,8 +239,6 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   const int G = a.G, Q = a.Q, F = a.F, F4 = F >> 2, K = a.K;
   const int views = a.crossmatch ? G * G : G, R = views * Q, GQ = G * Q;
   const int RS = F + 8;                                  // f16 per row of an operand plane: 16 B of padding spreads the rows over the banks
-  int tpr = kThreads / R;
-  if (tpr > kCkMaxTpr) tpr = kCkMaxTpr;
 
   const CkLayout lay = ck_layout(a.L, F, G, Q, views);
   int* tok = reinterpret_cast<int*>(smem_raw + lay.tok);                 // [lcap] every token of the document
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   _Float16* d_lo = reinterpret_cast<_Float16*>(smem_raw + lay.d_lo);
   _Float16* q_hi = reinterpret_cast<_Float16*>(smem_raw + lay.q_hi);     // [G*Q][RS]
   _Float16* q_lo = reinterpret_cast<_Float16*>(smem_raw + lay.q_lo);
-  float* sims = reinterpret_cast<float*>(smem_raw + lay.sims);           // [R][16]
+  float* sims = reinterpret_cast<float*>(smem_raw + lay.sims);           // [R][32]: two tiles side by side
   float* kr = reinterpret_cast<float*>(smem_raw + lay.kr);               // [R][K] log kernel sums
   float* kmu = reinterpret_cast<float*>(smem_raw + lay.misc);            // [12] (mu, coefficient) pairs, zero beyond K
   float* kz = kmu + 2 * (kCkMaxK + 1);                                   // [K] kernel value of a similarity of exactly 0
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   int* qtok = reinterpret_cast<int*>(hid + kCkMaxH);                     // [Q]
   int* rowmap = qtok + kCkMaxQ;                                          // [G][32]: sims row of query vector m for document view g, or -1
   int* wave_cnt = rowmap + kCkMaxG * 32;                                 // [4]
-  float* partial = reinterpret_cast<float*>(d_hi);                       // [R][tpr][kCkMaxK + 1], after the last tile
+  float* partial = reinterpret_cast<float*>(d_hi);                       // [pooled rows][tpr][kCkMaxK + 1], after the last tile
 
   const int64_t* qi = a.q_ids + (int64_t)b * Q;
   const int64_t* di = a.d_ids + (int64_t)b * a.L;
@@ -317,8 +320,33 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   }
 
   // ---- pooling state: thread -> (row, slice of positions) ----
+  // Only rows of real query terms are pooled (a pad term's row is all zero and masked at the end, ConvKNRM.py:72-73): with nq real
+  // terms there are views * nq rows, each shared by as many threads as fit.
+  int nq = 0, qreal[kCkMaxQ];
+#pragma unroll
+  for (int q = 0; q < kCkMaxQ; ++q) {
+    qreal[q] = 0;
+    if (q < Q && qtok_early(qi, q, a.V) != 0) {
+#pragma unroll
+      for (int j = 0; j < kCkMaxQ; ++j)
+        if (j == nq) qreal[j] = q;
+      ++nq;
+    }
+  }
+  const int racts = views * nq;
+  int tpr = racts > 0 ? kThreads / racts : 1;
+  if (tpr > kCkMaxTpr) tpr = kCkMaxTpr;
   const int prow = tid / tpr, psub = tid - prow * tpr;
-  const bool pool = prow < R && qtok[prow % Q] != 0;     // rows of pad query terms stay all-zero (masked at the end)
+  const bool pool = prow < racts;
+  int srow = 0;                                          // the row of `sims` this thread pools
+  if (pool) {
+    const int v = prow / nq, qi2 = prow - v * nq;
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < kCkMaxQ; ++j)
+      if (j == qi2) q = qreal[j];
+    srow = v * Q + q;
+  }
   float kacc[kCkMaxK];
 #pragma unroll
   for (int k = 0; k < kCkMaxK; ++k) kacc[k] = 0.f;
@@ -336,6 +364,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   issue(0);
   for (int base = 0; base < n_real; base += kCkTile) {
     const int nv = min(kCkTile, n_real - base);
+    const int col0 = base & kCkTile;                        // even tiles fill columns 0..15 of `sims`, odd tiles 16..31
     // -- A: add, normalise, split (the loads were issued one tile ago) --
     if (!(CAPAMD_CK_ABLATE & 1) && grp < nv) {
       float4 rep[kCkMaxG][NF4];
@@ -383,15 +412,17 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
           for (int i = 0; i < 4; ++i) {
             const int row = mb * 16 + kg * 4 + i;           // query vector of accumulator register i
             const int r = row < 32 ? rowmap[gb * 32 + row] : -1;
-            if (r >= 0) sims[r * kCkTile + n] = c0[i] + c1[i];
+            if (r >= 0) sims[r * kCkPoolCols + col0 + n] = c0[i] + c1[i];
           }
         }
       }
     ck_lds_barrier();
     // -- C: kernel pooling --
-    if (pool && !(CAPAMD_CK_ABLATE & 4)) {
-      for (int n = psub; n < nv; n += tpr) {
-        const float s = sims[prow * kCkTile + n];
+    // once per two tiles (or at the last one): 32 columns split over the row's threads balance better than 16
+    if (pool && !(CAPAMD_CK_ABLATE & 4) && (col0 != 0 || base + kCkTile >= n_real)) {
+      const int ncols = col0 + nv;
+      for (int n = psub; n < ncols; n += tpr) {
+        const float s = sims[srow * kCkPoolCols + n];
         rowsum += s;
         // (mu, coefficient) pairs are re-read from LDS for every value - broadcast reads, two kernels per 16-byte read - instead
         // of living in 22 registers next to the 48 of the gather in flight (the opaque offset keeps the reads inside the loop:
@@ -412,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   __syncthreads();
 
   // ---- fixed-order reduction over the slices, pads in closed form, log, sum over the query ----
-  if (prow < R) {
+  if (pool) {
     float* p = partial + (prow * tpr + psub) * (kCkMaxK + 1);
 #pragma unroll
     for (int k = 0; k < kCkMaxK; ++k) p[k] = kacc[k];
@@ -420,7 +451,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   }
   __syncthreads();
   const float n_zero = (float)(a.L - n_real);
-  for (int i = tid; i < R * K; i += kThreads) {
+  for (int i = tid; i < racts * K; i += kThreads) {
     const int r = i / K, k = i - r * K;
     float s = 0.f, rs = 0.f;
     for (int u = 0; u < tpr; ++u) {
@@ -434,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   for (int i = tid; i < K * views; i += kThreads) {
     const int k = i / views, v = i - k * views;
     float s = 0.f;
-    for (int q = 0; q < Q; ++q) s += kr[(v * Q + q) * K + k];
+    for (int q = 0; q < nq; ++q) s += kr[(v * nq + q) * K + k];
     feat[i] = s;
   }
   __syncthreads();
