@@ -62,6 +62,14 @@ def _ln(x, w, b, eps=1e-12):
 
 def encode_passages(w, input_ids, attention_mask, token_type_ids, heads, layers):
     """[N, S] int64 x3 -> logits [N, 2] (BertForSequenceClassification.forward in eval mode)."""
+    x = encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers)[-1]
+    pooled = torch.tanh(x[:, 0] @ w["bert.pooler.dense.weight"].t() + w["bert.pooler.dense.bias"])
+    return pooled @ w["classifier.weight"].t() + w["classifier.bias"]
+
+
+def encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers):
+    """[N, S] int64 x3 -> the layers + 1 hidden states [N, S, H] (BertModel(output_hidden_states=True).hidden_states:
+    the embedding output, then every encoder layer's output)."""
     N, S = input_ids.shape
     H = w["bert.embeddings.word_embeddings.weight"].shape[1]
     dh = H // heads
@@ -70,6 +78,7 @@ def encode_passages(w, input_ids, attention_mask, token_type_ids, heads, layers)
          + w["bert.embeddings.token_type_embeddings.weight"][token_type_ids])
     x = _ln(x, w["bert.embeddings.LayerNorm.weight"], w["bert.embeddings.LayerNorm.bias"])
     bias = (1.0 - attention_mask.float()).view(N, 1, 1, S) * torch.finfo(torch.float32).min
+    hidden = [x]
     for i in range(layers):
         p = f"bert.encoder.layer.{i}."
 
@@ -85,8 +94,8 @@ def encode_passages(w, input_ids, attention_mask, token_type_ids, heads, layers)
                 w[p + "attention.output.LayerNorm.bias"])
         h = F.gelu(lin("intermediate.dense", x))  # erf GELU
         x = _ln(lin("output.dense", h) + x, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"])
-    pooled = torch.tanh(x[:, 0] @ w["bert.pooler.dense.weight"].t() + w["bert.pooler.dense.bias"])
-    return pooled @ w["classifier.weight"].t() + w["classifier.bias"]
+        hidden.append(x)
+    return hidden
 
 
 def maxp(w, doc_input, doc_mask, doc_seg, heads, layers, aggregation="max", chunk=64):
@@ -109,3 +118,46 @@ def maxp(w, doc_input, doc_mask, doc_seg, heads, layers, aggregation="max", chun
     if aggregation == "avg":
         return torch.sum(passage_mask * s, dim=1) / torch.sum(passage_mask)  # batch-wide denominator (:92)
     raise ValueError("Unknown aggregation method: {}".format(aggregation))
+
+
+def cedr_knrm(w, head, doc_input, doc_mask, doc_seg, heads, layers, maxqlen, simmat_layers, mus, sigmas, cls_mode, chunk=32):
+    """CEDRKNRM_Class.forward (reference capreolus/reranker/CEDRKNRM.py:151-185): [B, P, S] int64 x3 -> [B] fp32.
+    head: combine.{0,1}.weight|bias (or combine.0 only); mus / sigmas: the kernel bank incl. the exact-match kernel (:43-46);
+    maxqlen: the extractor's (the model adds 1 for [SEP], :79); cls_mode "avg" | "max" | None."""
+    B, P, S = doc_input.shape
+    A = maxqlen + 1
+    flat = [t.reshape(B * P, S) for t in (doc_input, doc_mask, doc_seg)]
+    hs = None
+    with torch.no_grad():
+        for lo in range(0, B * P, chunk):
+            part = encode_hidden(w, flat[0][lo:lo + chunk], flat[1][lo:lo + chunk], flat[2][lo:lo + chunk], heads, layers)
+            hs = [[h] for h in part] if hs is None else [a + [h] for a, h in zip(hs, part)]
+        hs = [torch.cat(h) for h in hs]
+        mask, seg = flat[1].float(), flat[2]
+        feats = []
+        if cls_mode:
+            cls = hs[-1][:, 0, :].view(B, P, -1)                                                     # :160-165
+            feats.append(cls.max(dim=1)[0] if cls_mode == "max" else cls.mean(dim=1))
+        mu = torch.tensor(mus, dtype=torch.float32).view(1, -1, 1, 1)
+        sg = torch.tensor(sigmas, dtype=torch.float32).view(1, -1, 1, 1)
+        for li in simmat_layers:
+            emb, m, sgm = hs[li][:, 1:], mask[:, 1:], seg[:, 1:]                                     # :114-116 (skip [CLS])
+            qmask = m * (sgm == 0).float()                                                           # :98
+            q = (qmask.unsqueeze(2) * emb)[:, :A]
+            qmask = qmask[:, :A]
+            dmask = m * (sgm == 1).float()                                                           # :102
+            d = dmask.unsqueeze(2) * emb
+            sim = q.bmm(d.transpose(1, 2)) / ((q.norm(dim=2).unsqueeze(2) + 1e-9) * (d.norm(dim=2).unsqueeze(1) + 1e-9))   # :86-93
+            sim = sim * qmask.unsqueeze(2) * dmask.unsqueeze(1)
+            sim = sim.view(B, P, A, S - 1).permute(0, 2, 1, 3).reshape(B, A, P * (S - 1))            # :117-122 passages side by side
+            dm = dmask.view(B, 1, 1, P * (S - 1))
+            qm = qmask.view(B, P, A)[:, 0].view(B, 1, A, 1)                                          # :123 the first passage's query mask
+            adj = sim.unsqueeze(1) - mu
+            pre = torch.exp(-0.5 * adj * adj / sg / sg) * dm * qm                                    # :126-127
+            f = torch.log(torch.clamp(pre.sum(dim=3), min=1e-10)) * 0.01                             # :130-131
+            feats.append(f.sum(dim=2))                                                               # :134
+        x = torch.cat(feats, dim=1)
+        x = x @ head["combine.0.weight"].t() + head["combine.0.bias"]
+        if "combine.1.weight" in head:
+            x = x @ head["combine.1.weight"].t() + head["combine.1.bias"]
+        return x.view(-1)

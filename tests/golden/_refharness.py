@@ -29,7 +29,7 @@ def _stub(name, **attrs):
 
 
 def load_reference():
-    """Returns (common, KNRM, DRMM, ptBERTMaxP, DRMMTKS, PACRR, ConvKNRM) reference modules."""
+    """Returns (common, KNRM, DRMM, ptBERTMaxP, DRMMTKS, PACRR, ConvKNRM, CEDRKNRM) reference modules."""
     sys.dont_write_bytecode = True
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     if not os.path.isdir(REF_ROOT):
@@ -86,5 +86,5 @@ def load_reference():
     _stub("tensorflow_ranking.python.keras")
     _stub("tensorflow_ranking.python.keras.losses", PairwiseHingeLoss=object)
 
-    mods = [importlib.import_module("capreolus.reranker." + n) for n in ("common", "KNRM", "DRMM", "ptBERTMaxP", "DRMMTKS", "PACRR", "ConvKNRM")]
+    mods = [importlib.import_module("capreolus.reranker." + n) for n in ("common", "KNRM", "DRMM", "ptBERTMaxP", "DRMMTKS", "PACRR", "ConvKNRM", "CEDRKNRM")]
     return tuple(mods)

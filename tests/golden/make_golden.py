@@ -302,8 +302,12 @@ def gen_convknrm(CONVKNRM):
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks", "pacrr", "convknrm"}
-    common, KNRM, DRMM, MAXP, TKS, PACRR, CONVKNRM = _refharness.load_reference()
+    which = set(sys.argv[1:]) or {"knrm", "drmm", "bert", "drmmtks", "pacrr", "convknrm", "cedr"}
+    common, KNRM, DRMM, MAXP, TKS, PACRR, CONVKNRM, CEDR = _refharness.load_reference()
+    if "cedr" in which:
+        from make_golden_bert import gen_cedr
+
+        gen_cedr(CEDR)
     if "convknrm" in which:
         gen_convknrm(CONVKNRM)
     if "pacrr" in which:

@@ -55,3 +55,55 @@ def gen_bert(MAXP):
             pos_bert_input=batch["pos_bert_input"].astype(np.int32), pos_mask=batch["pos_mask"].astype(np.int8),
             pos_seg=batch["pos_seg"].astype(np.int8), **out)
         print("bert", name, {k: v[:3] for k, v in out.items() if k.startswith("ref_") and v.ndim == 1})
+
+
+CEDR_CASES = {
+    # name: encoder dims + inputs (as above), then the CEDR-KNRM options
+    "mini": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=1000, max_pos=128, B=5, P=3, S=64, seed=21,
+                 maxqlen=12, simmat_layers=[0, 1, 2], cls="avg", combine_hidden=32),
+    "mini_max_single": dict(hidden=192, layers=1, heads=3, ffn=256, vocab=1200, max_pos=128, B=4, P=2, S=128, seed=22,
+                            maxqlen=8, simmat_layers=[1], cls="max", combine_hidden=0),
+    "mini_nocls": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=1000, max_pos=128, B=3, P=3, S=64, seed=23,
+                       maxqlen=12, simmat_layers=[0, 2], cls=None, combine_hidden=16),
+    "base": dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, B=2, P=4, S=256, seed=24,
+                 maxqlen=12, simmat_layers=list(range(13)), cls="avg", combine_hidden=1024),
+}
+CEDR_MUS = [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9]
+
+
+def gen_cedr(CEDR):
+    from transformers import BertConfig, BertModel
+
+    from tests.helpers import cedr_head
+
+    for name, c in CEDR_CASES.items():
+        cfg = BertConfig(hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"], intermediate_size=c["ffn"],
+                         vocab_size=c["vocab"], max_position_embeddings=c["max_pos"], output_hidden_states=True)
+        w = bert_port.random_weights(c["hidden"], c["layers"], c["heads"], c["ffn"], c["vocab"], c["max_pos"], seed=c["seed"])
+        orig = BertModel.from_pretrained
+        BertModel.from_pretrained = staticmethod(lambda *a, **k: BertModel(cfg))
+        try:
+            rs = np.random.RandomState(c["seed"])
+            batch = synthetic.make_bert_passages(rs, c["B"], c["P"], c["S"], vocab=c["vocab"], same_query=False)
+            ti = {k: torch.from_numpy(v) for k, v in batch.items()}
+            model = CEDR.CEDRKNRM_Class(
+                SimpleNamespace(config={"numpassages": c["P"], "maxseqlen": c["S"], "maxqlen": c["maxqlen"]}),
+                {"pretrained": "bert-base-uncased", "mus": CEDR_MUS, "sigma": 0.1, "gradkernels": True, "hidden_dropout_prob": 0.1,
+                 "simmat_layers": c["simmat_layers"], "combine_hidden": c["combine_hidden"], "cls": c["cls"]})
+            missing = model.bert.load_state_dict({k[5:]: v for k, v in w.items() if k.startswith("bert.")}, strict=False)
+            assert not [k for k in missing.missing_keys if "position_ids" not in k], missing
+            n_in = (c["hidden"] if c["cls"] else 0) + 11 * len(c["simmat_layers"])
+            head = cedr_head(c["seed"], n_in, c["combine_hidden"])
+            model.combine.load_state_dict({k[len("combine."):]: v for k, v in head.items()})
+            model.eval()
+            with torch.no_grad():
+                ref = model(ti["pos_bert_input"], ti["pos_mask"], ti["pos_seg"]).view(-1).numpy().astype(np.float32)
+        finally:
+            BertModel.from_pretrained = orig
+        np.savez_compressed(
+            os.path.join(HERE, f"cedr_{name}.npz"), weight_seed=np.int64(c["seed"]),
+            dims=np.array([c["hidden"], c["layers"], c["heads"], c["ffn"], c["vocab"], c["max_pos"]], dtype=np.int64),
+            maxqlen=np.int64(c["maxqlen"]), simmat_layers=np.array(c["simmat_layers"], dtype=np.int64), cls=np.array(c["cls"] or "none"),
+            combine_hidden=np.int64(c["combine_hidden"]), pos_bert_input=batch["pos_bert_input"].astype(np.int32),
+            pos_mask=batch["pos_mask"].astype(np.int8), pos_seg=batch["pos_seg"].astype(np.int8), ref_scores=ref)
+        print("cedr", name, ref)

@@ -108,3 +108,35 @@ def convknrm_args(c):
     sigma = np.array([c[f"sd.kernels.kernels.{k}.sigma"] for k in range(K)], dtype=np.float32)
     w2, b2 = c.get("sd.combine.2.weight"), c.get("sd.combine.2.bias")
     return ws, bs, bool(int(c["cfg.crossmatch"])), mu, sigma, c["sd.combine.0.weight"], c["sd.combine.0.bias"], w2, b2, bool(int(c["cfg.scoretanh"]))
+
+
+CEDR_CASES = ["mini", "mini_max_single", "mini_nocls", "base"]
+CEDR_MUS = [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9]
+
+
+def cedr_head(seed, n_in, hidden):
+    """Seeded combine layers of a CEDR-KNRM fixture (state_dict names of the reference's nn.Sequential, CEDRKNRM.py:62-74); the
+    generator loads the same tensors into the reference module."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed + 1000)
+    h = {"combine.0.weight": torch.randn(hidden or 1, n_in, generator=g) * 0.3, "combine.0.bias": torch.randn(hidden or 1, generator=g) * 0.1}
+    if hidden:
+        h["combine.1.weight"] = torch.randn(1, hidden, generator=g) * 0.3
+        h["combine.1.bias"] = torch.randn(1, generator=g) * 0.1
+    return h
+
+
+def load_cedr_case(name):
+    """(fixture dict, encoder weights, combine head, kernel mus, kernel sigmas) of a CEDR-KNRM fixture."""
+    from oracle import bert_port
+
+    z = np.load(os.path.join(GOLDEN, f"cedr_{name}.npz"))
+    c = {k: z[k] for k in z.files}
+    hidden, layers, heads, ffn, vocab, max_pos = (int(x) for x in c["dims"])
+    w = bert_port.random_weights(hidden, layers, heads, ffn, vocab, max_pos, seed=int(c["weight_seed"]))
+    cls = str(c["cls"])
+    c["cls_mode"] = None if cls == "none" else cls
+    n_in = (hidden if c["cls_mode"] else 0) + 11 * len(c["simmat_layers"])
+    head = cedr_head(int(c["weight_seed"]), n_in, int(c["combine_hidden"]))
+    return c, w, head, CEDR_MUS + [1.0], [0.1] * 10 + [0.01]

@@ -186,3 +186,18 @@ def test_convknrm_oracle_matches_reference(name):
     assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
     if name == "ranklist":
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
+
+
+@pytest.mark.parametrize("name", ["mini", "mini_max_single", "mini_nocls", "base"])
+def test_cedr_port_matches_reference(name):
+    import torch
+
+    from oracle import bert_port
+    from tests.helpers import load_cedr_case
+
+    c, w, head, mus, sigmas = load_cedr_case(name)
+    heads, layers = int(c["dims"][2]), int(c["dims"][1])
+    t = [torch.from_numpy(c[k].astype(np.int64)) for k in ("pos_bert_input", "pos_mask", "pos_seg")]
+    got = bert_port.cedr_knrm(w, head, *t, heads, layers, int(c["maxqlen"]), [int(x) for x in c["simmat_layers"]], mus, sigmas,
+                              c["cls_mode"]).numpy()
+    assert rel_err(got, c["ref_scores"]).max() <= 2e-5, (name, rel_err(got, c["ref_scores"]).max())
