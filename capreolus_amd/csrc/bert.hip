@@ -11,6 +11,7 @@
 #include "bert_attn.cuh"
 #include "bert_gemm.cuh"
 #include "capreolus_amd.h"
+#include "cedr_tap.cuh"
 #include <stdlib.h>
 #include <utility>
 #include <vector>
@@ -536,7 +537,7 @@ Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_to
 
 template <typename T>
 hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_t* seg, int64_t NP, int64_t mb, int S,
-                           const capamd_bert_model* m, const Workspace& w, int* status, hipStream_t s) {
+                           const capamd_bert_model* m, const Workspace& w, int* status, hipStream_t s, const CedrTap* tap = nullptr) {
   const int H = m->hidden, F = m->ffn;
   const T* blob = (const T*)m->blob;
   hipError_t e = hipSuccess;
@@ -548,10 +549,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     const int64_t* mask_mb = mask + p0 * S;
     const int64_t* seg_mb = seg + p0 * S;
     // LayerNorm folded into the GEMMs: every encoder GEMM of this microbatch must be a ping-pong shape
-    const bool fused = fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
+    // (a CEDR-KNRM call reads every layer's normalised output: it runs the path that materialises them)
+    const bool fused = !tap && fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
                        pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
     hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
                        m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, (T*)w.xb, status, fused ? 1 : 0);
+    if (tap) cedr_tap_layer<T>(*tap, 0, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s);
     if (fused) {
       // Activation stream: xb and pre hold UN-normalised pre-LayerNorm sums in the chunk-major layout, (mu, rstd) of
       // their rows next to them; no LayerNorm pass exists.  Consumers fold the normalisation into their epilogue
@@ -682,8 +685,14 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       if (e != hipSuccess) break;
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status, 0);
+      if (tap) cedr_tap_layer<T>(*tap, l + 1, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s);
     }
     if (e != hipSuccess) break;
+    if (tap) {   // CEDR-KNRM reads the [CLS] rows of the last hidden state itself (CEDRKNRM.py:160); no pooler / classifier
+      hipLaunchKernelGGL(cedr_cls_rows_kernel<T>, dim3((unsigned)np), dim3(256), 0, s, (const T*)w.xb, S, H, tap->cls + p0 * H);
+      e = hipGetLastError();
+      continue;
+    }
     // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
     float* hpart = reinterpret_cast<float*>(w.pre);
     hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
@@ -824,6 +833,39 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
   hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(64), 0, s, w.logits, mask, seg, P, S, aggregation, out, w.cnt);
   if (aggregation == 3) hipLaunchKernelGGL(avg_div_kernel, dim3((B + 255) / 256), dim3(256), 0, s, out, B, w.cnt);
   if (passage_logits_out) (void)hipMemcpyAsync(passage_logits_out, w.logits, (size_t)NP * 4, hipMemcpyDeviceToDevice, s);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
+                                 const capamd_bert_model* m, int64_t passages_per_microbatch, void* workspace, int64_t workspace_bytes,
+                                 int maxqlen, const int* simmat_layers /* host */, int n_layers, const float* mu, const float* sigma, int K,
+                                 float* passage_kernel_sums, float* cls_rows, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !status || B < 0 || P < 1 || !cls_rows) return CAPAMD_ERR_ARG;
+  if (!supported_length(S) || S > m->max_pos || passages_per_microbatch < 1) return CAPAMD_ERR_ARG;
+  if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->blob || !m->layer_f32) return CAPAMD_ERR_ARG;
+  if (n_layers < 0 || n_layers > m->layers + 1 || maxqlen < 1 || maxqlen + 1 > kCedrMaxA) return CAPAMD_ERR_ARG;
+  if (n_layers > 0 && (!simmat_layers || !mu || !sigma || !passage_kernel_sums || K < 1 || K > kCedrMaxK)) return CAPAMD_ERR_ARG;
+  for (int i = 0; i < n_layers; ++i)
+    if (simmat_layers[i] < 0 || simmat_layers[i] > m->layers) return CAPAMD_ERR_ARG;
+  const int H = m->hidden, F = m->ffn;
+  const int64_t NP = (int64_t)B * P;
+  const int64_t n_mb = (NP + passages_per_microbatch - 1) / passages_per_microbatch;
+  int64_t mb = (NP + n_mb - 1) / n_mb;
+  {
+    const int64_t q = tile_passages(S);
+    mb = (mb + q - 1) / q * q;
+  }
+  if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
+  if (cedr_pool_smem(S, maxqlen + 1) > 160 * 1024) return CAPAMD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  Workspace w = carve((char*)workspace, H, F, S, mb, NP);
+  CedrTap tap{maxqlen + 1, P, K, n_layers, simmat_layers, mu, sigma, mask, seg, passage_kernel_sums, cls_rows, NP};
+  const hipError_t e = (m->compute_dtype == 1) ? encode_passages<_Float16>(ids, mask, seg, NP, mb, S, m, w, status, s, &tap)
+                                                : encode_passages<__bf16>(ids, mask, seg, NP, mb, S, m, w, status, s, &tap);
+  if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 

@@ -551,3 +551,55 @@ def convknrm_forward(query, doc, tables, V, maxngram, filters, crossmatch, mu, s
     if check:
         st.raise_if_set()
     return out
+
+
+CLS_MODES = {None: 0, "avg": 1, "max": 2}
+
+
+class CedrEngine:
+    """CEDR-KNRM on top of a BertEngine's packed encoder: capamd_cedr_passage_features (encoder + per-layer masked cosine matrices +
+    kernel pooling) followed by capamd_cedr_score (document-level log / sums, [CLS] feature, combine layers)."""
+
+    def __init__(self, bert_engine):
+        self.be = bert_engine
+        self._ws = None
+
+    def forward(self, doc_input, doc_mask, doc_seg, maxqlen, simmat_layers, mu, sigma, cls_mode, w1, b1, w2=None, b2=None, check=True,
+                return_features=False):
+        """CEDRKNRM_Class.forward (reference CEDRKNRM.py:151-185): int64 [B, P, S] x3 -> fp32 [B]."""
+        _need_gpu(doc_input, doc_mask, doc_seg, mu, sigma, w1, b1)
+        if cls_mode not in CLS_MODES:
+            raise ValueError("cls must be 'avg', 'max' or None")
+        ids, mask, seg = _i64(doc_input), _i64(doc_mask), _i64(doc_seg)
+        B, P, S = ids.shape
+        dev = ids.device
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+        if B == 0:
+            return out
+        m = self.be.model()
+        lib = _lib.load()
+        layers = sorted(int(x) for x in simmat_layers if int(x) >= 0)      # -1 alone = no similarity matrices (CEDRKNRM.py:48-52)
+        n_sel, K, A, H = len(layers), mu.numel(), maxqlen + 1, m.hidden
+        mb = min(self.be.microbatch * max(1, 256 // S), B * P)
+        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
+        if need < 0:
+            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        pk = torch.empty(max(1, n_sel * B * P * K * A), dtype=torch.float32, device=dev)
+        cls = torch.empty(B * P * H, dtype=torch.float32, device=dev)
+        st = status_word(dev)
+        arr = (ctypes.c_int * max(1, n_sel))(*layers)
+        rc = lib.capamd_cedr_passage_features(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), mb, _ptr(self._ws), self._ws.numel(),
+                                              int(maxqlen), arr, n_sel, _ptr(mu), _ptr(sigma), K, _ptr(pk), _ptr(cls), _ptr(st.t), _stream())
+        _lib.check(rc, "capamd_cedr_passage_features")
+        n_in = (H if cls_mode else 0) + n_sel * K
+        feats = torch.empty((B, n_in), dtype=torch.float32, device=dev) if return_features else None
+        hidden = 0 if w2 is None else w1.shape[0]
+        rc = lib.capamd_cedr_score(_ptr(pk), _ptr(cls), B, P, int(maxqlen), n_sel, K, H, CLS_MODES[cls_mode], _ptr(w1), _ptr(b1), hidden,
+                                   None if w2 is None else _ptr(w2), None if b2 is None else _ptr(b2), _ptr(out),
+                                   None if feats is None else _ptr(feats), _stream())
+        _lib.check(rc, "capamd_cedr_score")
+        if check:
+            st.raise_if_set()
+        return (out, feats) if return_features else out

@@ -71,5 +71,6 @@ from .DRMMTKS import DRMMTKS, DRMMTKS_class  # noqa: E402,F401
 from .ConvKNRM import ConvKNRM, ConvKNRM_class  # noqa: E402,F401
 from .PACRR import PACRR, PACRR_class  # noqa: E402,F401
 from .ptBERTMaxP import PTBERTMaxP, PTBERTMaxP_Class  # noqa: E402,F401
+from .CEDRKNRM import CEDRKNRM, CEDRKNRM_Class  # noqa: E402,F401
 
-registry = {"KNRM": KNRM, "DRMM": DRMM, "DRMMTKS": DRMMTKS, "PACRR": PACRR, "ConvKNRM": ConvKNRM, "ptBERTMaxP": PTBERTMaxP}
+registry = {"KNRM": KNRM, "DRMM": DRMM, "DRMMTKS": DRMMTKS, "PACRR": PACRR, "ConvKNRM": ConvKNRM, "ptBERTMaxP": PTBERTMaxP, "CEDRKNRM": CEDRKNRM}

@@ -32,14 +32,21 @@ def _encoder_layer(H, F):
     )
 
 
-def bert_container(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2):
-    """Parameter tree of BertForSequenceClassification(num_labels=2) (state_dict names as HF)."""
+def bert_body(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2):
+    """Parameter tree of transformers.BertModel (state_dict names as HF)."""
     body = _Box(
         embeddings=_Box(word_embeddings=nn.Embedding(vocab, hidden, padding_idx=0), position_embeddings=nn.Embedding(max_pos, hidden),
                         token_type_embeddings=nn.Embedding(type_vocab, hidden), LayerNorm=nn.LayerNorm(hidden, eps=1e-12)),
         encoder=_Box(layer=nn.ModuleList([_encoder_layer(hidden, ffn) for _ in range(layers)])),
         pooler=_Box(dense=nn.Linear(hidden, hidden)),
     )
+    body.num_attention_heads = heads
+    return body
+
+
+def bert_container(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2):
+    """Parameter tree of BertForSequenceClassification(num_labels=2) (state_dict names as HF)."""
+    body = bert_body(hidden, layers, heads, ffn, vocab, max_pos, type_vocab)
     box = _Box(bert=body, classifier=nn.Linear(hidden, 2))
     box.num_attention_heads = heads
     return box

@@ -212,6 +212,26 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
 int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv, const int64_t* mask, int n_passages,
                               int S, int hidden, int heads, void* q, void* k, void* vt, void* ctx, int dtype, void* stream);
 
+/* ---- CEDR-KNRM -----------------------------------------------------------------------
+ * Replaces CEDRKNRM_Class.forward, capreolus/reranker/CEDRKNRM.py:151-185 (called from CEDRKNRM.test :216-217), BERT-architecture
+ * encoders only.  Two calls:
+ *  capamd_cedr_passage_features: runs the encoder (same model / workspace as capamd_bert_maxp_forward; the pooler and classifier
+ *   pointers of the model may be NULL) over all B*P passages and, for every hidden state listed in simmat_layers (host array,
+ *   0 = embedding output .. layers), leaves passage_kernel_sums[layer][passage][kernel][query row] =
+ *   sum over the passage's document tokens of the RBF kernels of the masked cosine similarity matrix (masked_simmats /
+ *   _cos_simmat / knrm, CEDRKNRM.py:83-130; query rows = sequence positions 1..maxqlen+1), plus cls_rows[passage][hidden] = the
+ *   last hidden state's [CLS] row in fp32 (:160).  maxqlen + 1 <= 32, K <= 11.
+ *  capamd_cedr_score: the document level (:117-136, 160-185): sums over a document's P passages, clamp / log / 0.01, sum over
+ *   the query rows; cls feature (cls_mode 0 none, 1 avg, 2 max); combine = Linear(n_in, 1) (combine_hidden = 0) or
+ *   Linear(n_in, combine_hidden) -> Linear(combine_hidden, 1).  features_out (optional) [B][n_in]. */
+int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
+                                 const capamd_bert_model* m, int64_t passages_per_microbatch, void* workspace, int64_t workspace_bytes,
+                                 int maxqlen, const int* simmat_layers, int n_layers, const float* mu, const float* sigma, int K,
+                                 float* passage_kernel_sums, float* cls_rows, int* status, void* stream);
+int capamd_cedr_score(const float* passage_kernel_sums, const float* cls_rows, int B, int P, int maxqlen, int n_layers, int K, int hidden,
+                      int cls_mode, const float* w1, const float* b1, int combine_hidden, const float* w2, const float* b2, float* out,
+                      float* features_out, void* stream);
+
 /* ---- ConvKNRM ------------------------------------------------------------------------
  * Replaces ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-77 (called from ConvKNRM.test :112-116).
  * The Conv1d layers (ConvKNRM.py:24-32) over the frozen embedding table (:17) are folded, once per model, into a table of
