@@ -45,3 +45,30 @@ for name, r in (("DRMMTKS", DRMMTKS({}, ext)), ("PACRR", PACRR({}, ext)), ("PACR
     ms = e0.elapsed_time(e1) / args.steps
     n = batch["query"].shape[0]
     print(json.dumps({"model": name, "pairs_per_s": round(n / ms * 1e3), "ms_per_step": round(ms, 3), "pairs": n, "finite": bool(torch.isfinite(s).all())}))
+
+if not args.only or "CEDRKNRM" in args.only.split(","):
+    # CEDR-KNRM on the BERT benchmark's input: 1000 documents x 4 passages x 256 tokens, BERT-base geometry, default-initialised weights
+    import numpy as np
+
+    from capreolus_amd.reranker import CEDRKNRM
+
+    P, S, docs = 4, 256, 1000
+    host = synthetic.make_bert_passages(np.random.RandomState(5), 64, P, S, vocab=30522)
+    d = {k: torch.as_tensor(np.tile(v, (16, 1, 1))[:docs]).to(dev) for k, v in host.items()}
+    r = CEDRKNRM({"pretrained": dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512)},
+                 SimpleNamespace(config={"numpassages": P, "maxseqlen": S, "maxqlen": 12}))
+    torch.manual_seed(0)
+    r.build_model().to(dev).eval()
+    with torch.no_grad():
+        for _ in range(2):
+            s = r.test(d)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            s = r.test(d)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(json.dumps({"model": "CEDRKNRM (BERT-base, 13 hidden states)", "docs_per_s": round(docs / ms * 1e3, 1), "ms_per_step": round(ms, 2), "docs": docs,
+                      "finite": bool(torch.isfinite(s).all())}))
