@@ -274,7 +274,6 @@ def bench_bert(args, world, rank, dev, use_dist):
 
     from capreolus_amd import _lib, engine, synthetic
     from capreolus_amd.reranker import PTBERTMaxP
-    from oracle import bert_port
 
     if use_dist:
         import torch.distributed as dist
@@ -288,7 +287,7 @@ def bench_bert(args, world, rank, dev, use_dist):
     d["pos_bert_input"] = torch.where((d["pos_mask"] == 1) & (d["pos_bert_input"] > 999),
                                       (d["pos_bert_input"] + torch.arange(docs, device=dev)[:, None, None] * 7) % (VOCAB - 1000) + 1000,
                                       d["pos_bert_input"])
-    weights = bert_port.random_weights(H, LAYERS, HEADS, F, VOCAB, 512, seed=0)
+    weights = synthetic.random_bert_weights(H, LAYERS, HEADS, F, VOCAB, 512, seed=0)
     rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": 256,
                      "compute_dtype": args.bert_dtype, "skip_padding": bool(args.bert_skip_padding)},
                     SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
@@ -367,6 +366,8 @@ def bench_bert(args, world, rank, dev, use_dist):
         n = args.cpu_pairs or 4
         cores = os.cpu_count() or 1
         torch.set_num_threads(cores)
+        from oracle import bert_port   # the CPU leg only
+
         hd = {k: v[:n].cpu() for k, v in d.items()}
         t0 = time.perf_counter()
         bert_port.maxp(weights, hd["pos_bert_input"], hd["pos_mask"], hd["pos_seg"], HEADS, LAYERS, "max", chunk=16)

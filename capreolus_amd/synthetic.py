@@ -166,3 +166,41 @@ def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, em
             mask[b, p, :n] = [0 if t == PAD else 1 for t in toks]
             seg[b, p, nq + 2:] = 1
     return {"pos_bert_input": inp, "pos_mask": mask, "pos_seg": seg}
+
+
+def random_bert_weights(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2, seed=0, std=0.05):
+    """Seeded stand-in for a checkpoint (there is no network for real ones).  Wider than HF's 0.02
+    init and with non-trivial LayerNorm/bias terms so that every term of the forward matters.  HF state_dict names of a
+    BertForSequenceClassification with these dimensions, values torch fp32."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+
+    def n(*shape, s=std):
+        return torch.randn(*shape, generator=g) * s
+
+    w = {
+        "bert.embeddings.word_embeddings.weight": n(vocab, hidden),
+        "bert.embeddings.position_embeddings.weight": n(max_pos, hidden),
+        "bert.embeddings.token_type_embeddings.weight": n(type_vocab, hidden),
+        "bert.embeddings.LayerNorm.weight": 1.0 + n(hidden, s=0.1),
+        "bert.embeddings.LayerNorm.bias": n(hidden, s=0.1),
+        "bert.pooler.dense.weight": n(hidden, hidden),
+        "bert.pooler.dense.bias": n(hidden, s=0.1),
+        "classifier.weight": n(2, hidden, s=0.2),
+        "classifier.bias": n(2, s=0.1),
+    }
+    w["bert.embeddings.word_embeddings.weight"][0] = 0  # padding_idx row
+    for i in range(layers):
+        p = f"bert.encoder.layer.{i}."
+        for name in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            w[p + name + ".weight"] = n(hidden, hidden)
+            w[p + name + ".bias"] = n(hidden, s=0.1)
+        w[p + "intermediate.dense.weight"] = n(ffn, hidden)
+        w[p + "intermediate.dense.bias"] = n(ffn, s=0.1)
+        w[p + "output.dense.weight"] = n(hidden, ffn)
+        w[p + "output.dense.bias"] = n(hidden, s=0.1)
+        for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
+            w[p + ln + ".weight"] = 1.0 + n(hidden, s=0.1)
+            w[p + ln + ".bias"] = n(hidden, s=0.1)
+    return w

@@ -21,39 +21,7 @@ import torch
 import torch.nn.functional as F
 
 
-def random_weights(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2, seed=0, std=0.05):
-    """Seeded stand-in for a checkpoint (there is no network for real ones).  Wider than HF's 0.02
-    init and with non-trivial LayerNorm/bias terms so that every term of the forward matters."""
-    g = torch.Generator().manual_seed(seed)
-
-    def n(*shape, s=std):
-        return torch.randn(*shape, generator=g) * s
-
-    w = {
-        "bert.embeddings.word_embeddings.weight": n(vocab, hidden),
-        "bert.embeddings.position_embeddings.weight": n(max_pos, hidden),
-        "bert.embeddings.token_type_embeddings.weight": n(type_vocab, hidden),
-        "bert.embeddings.LayerNorm.weight": 1.0 + n(hidden, s=0.1),
-        "bert.embeddings.LayerNorm.bias": n(hidden, s=0.1),
-        "bert.pooler.dense.weight": n(hidden, hidden),
-        "bert.pooler.dense.bias": n(hidden, s=0.1),
-        "classifier.weight": n(2, hidden, s=0.2),
-        "classifier.bias": n(2, s=0.1),
-    }
-    w["bert.embeddings.word_embeddings.weight"][0] = 0  # padding_idx row
-    for i in range(layers):
-        p = f"bert.encoder.layer.{i}."
-        for name in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-            w[p + name + ".weight"] = n(hidden, hidden)
-            w[p + name + ".bias"] = n(hidden, s=0.1)
-        w[p + "intermediate.dense.weight"] = n(ffn, hidden)
-        w[p + "intermediate.dense.bias"] = n(ffn, s=0.1)
-        w[p + "output.dense.weight"] = n(hidden, ffn)
-        w[p + "output.dense.bias"] = n(hidden, s=0.1)
-        for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
-            w[p + ln + ".weight"] = 1.0 + n(hidden, s=0.1)
-            w[p + ln + ".bias"] = n(hidden, s=0.1)
-    return w
+from capreolus_amd.synthetic import random_bert_weights as random_weights  # noqa: E402,F401  (seeded stand-in for a checkpoint)
 
 
 def _ln(x, w, b, eps=1e-12):
