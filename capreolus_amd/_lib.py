@@ -59,7 +59,7 @@ SIGNATURES = {
     "capamd_bert_pack_layer": (_i, [_mp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp]),
     "capamd_bert_workspace_bytes": (_i64, [_mp, _i, _i64, _i64]),
     "capamd_bert_maxp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "capamd_cedr_passage_features": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i64, _vp, _i64, _i, ctypes.POINTER(_i), _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "capamd_cedr_passage_features": (_i, [_vp, _vp, _vp, _i, _i, _i, _mp, _i64, _vp, _i64, _i, _vp, ctypes.POINTER(_i), _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "capamd_cedr_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_maxp_pool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "capamd_bert_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -838,14 +838,14 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
 
 int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
                                  const capamd_bert_model* m, int64_t passages_per_microbatch, void* workspace, int64_t workspace_bytes,
-                                 int maxqlen, const int* simmat_layers /* host */, int n_layers, const float* mu, const float* sigma, int K,
-                                 float* passage_kernel_sums, float* cls_rows, int* status, void* stream) {
+                                 int maxqlen, const float* query_mask0, const int* simmat_layers /* host */, int n_layers, const float* mu,
+                                 const float* sigma, int K, float* passage_kernel_sums, float* cls_rows, int* status, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!ids || !mask || !seg || !dims_ok(m) || !workspace || !status || B < 0 || P < 1 || !cls_rows) return CAPAMD_ERR_ARG;
   if (!supported_length(S) || S > m->max_pos || passages_per_microbatch < 1) return CAPAMD_ERR_ARG;
   if (!m->word_emb || !m->pos_emb || !m->type_emb || !m->emb_ln_g || !m->emb_ln_b || !m->blob || !m->layer_f32) return CAPAMD_ERR_ARG;
   if (n_layers < 0 || n_layers > m->layers + 1 || maxqlen < 1 || maxqlen + 1 > kCedrMaxA) return CAPAMD_ERR_ARG;
-  if (n_layers > 0 && (!simmat_layers || !mu || !sigma || !passage_kernel_sums || K < 1 || K > kCedrMaxK)) return CAPAMD_ERR_ARG;
+  if (n_layers > 0 && (!simmat_layers || !mu || !sigma || !passage_kernel_sums || !query_mask0 || K < 1 || K > kCedrMaxK)) return CAPAMD_ERR_ARG;
   for (int i = 0; i < n_layers; ++i)
     if (simmat_layers[i] < 0 || simmat_layers[i] > m->layers) return CAPAMD_ERR_ARG;
   const int H = m->hidden, F = m->ffn;
@@ -862,7 +862,7 @@ int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const 
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   Workspace w = carve((char*)workspace, H, F, S, mb, NP);
-  CedrTap tap{maxqlen + 1, P, K, n_layers, simmat_layers, mu, sigma, mask, seg, passage_kernel_sums, cls_rows, NP};
+  CedrTap tap{maxqlen + 1, K, n_layers, simmat_layers, mu, sigma, query_mask0, passage_kernel_sums, cls_rows, NP};
   const hipError_t e = (m->compute_dtype == 1) ? encode_passages<_Float16>(ids, mask, seg, NP, mb, S, m, w, status, s, &tap)
                                                 : encode_passages<__bf16>(ids, mask, seg, NP, mb, S, m, w, status, s, &tap);
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;

@@ -5,7 +5,8 @@
 //   sequence positions 1 .. A (A = maxqlen + 1; [CLS] is dropped, :114)  = query rows   (mask & segment 0, :98-100)
 //   sequence positions 1 .. S-1                                          = document columns (mask & segment 1, :102-104)
 //   sim[a][b] = x_a . x_b / ((|x_a| + 1e-9)(|x_b| + 1e-9)) * qmask[a] * dmask[b]                           (:86-93)
-//   pk[k][a]  = sum_b exp(-0.5 (sim - mu_k)^2 / sigma_k^2) * dmask[b] * qmask_of_the_document's_first_passage[a]   (:123-130)
+//   pk[k][a]  = sum_b exp(-0.5 (sim - mu_k)^2 / sigma_k^2) * dmask[b] * qmask0[a]   (:123-130; qmask0 = the query mask of the
+//               document's FIRST passage, handed in per passage so that passages can be regrouped by length)
 // The per-passage sums are added over a document's passages, clamped, logged and summed over the query by cedr.hip.
 //
 // One workgroup per passage: row norms (one wave per row), the A x S dot products on v_mfma_f32_32x32x16 straight from the
@@ -21,12 +22,11 @@ constexpr int kCedrMaxK = 11;
 constexpr int kCedrMaxTpr = 32;
 
 struct CedrTap {          // what a CEDR-KNRM call asks of encode_passages
-  int A, P, K, n_sel;
+  int A, K, n_sel;
   const int* layers;      // host array [n_sel]: hidden states to pool (0 = embedding output .. L), ascending
   const float* mu;        // device [K]
   const float* sigma;     // device [K]
-  const int64_t* mask_all;   // the whole call's [NP][S] mask / segment ids (a document's first passage supplies the query mask)
-  const int64_t* seg_all;
+  const float* qmask0;    // device [NP][A]: the query mask of the first passage of each passage's document (CEDRKNRM.py:123)
   float* pk;              // device [n_sel][NP][K][A]
   float* cls;             // device [NP][H]: the last hidden state's [CLS] row, fp32
   int64_t NP;
@@ -34,8 +34,8 @@ struct CedrTap {          // what a CEDR-KNRM call asks of encode_passages
 
 template <typename T>
 __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x, const int64_t* __restrict__ mask,
-                                                        const int64_t* __restrict__ seg, const int64_t* __restrict__ mask_all,
-                                                        const int64_t* __restrict__ seg_all, int64_t p0, int P, int S, int H, int A, int K,
+                                                        const int64_t* __restrict__ seg, const float* __restrict__ qmask0, int64_t p0, int S,
+                                                        int H, int A, int K,
                                                         const float* __restrict__ mu, const float* __restrict__ sigma,
                                                         float* __restrict__ pk) {
   typedef typename Half<T>::x8 x8;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x,
   float* partial = dm + S;                                        // [256][K + 1]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int p = blockIdx.x;
-  const int64_t pg = p0 + p, first = pg / P * P;
+  const int64_t pg = p0 + p;
   const T* xp = x + (int64_t)p * S * H;
   const int64_t* mk = mask + (int64_t)p * S;
   const int64_t* sg = seg + (int64_t)p * S;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x,
   for (int i = tid; i < S; i += 256) dm[i] = (mk[i] != 0 && sg[i] == 1) ? 1.f : 0.f;   // ([CLS] is segment 0: never a document column)
   if (tid < A) {
     qm[tid] = (1 + tid < S && mk[1 + tid] != 0 && sg[1 + tid] == 0) ? 1.f : 0.f;
-    qm0[tid] = (1 + tid < S && mask_all[first * S + 1 + tid] != 0 && seg_all[first * S + 1 + tid] == 0) ? 1.f : 0.f;
+    qm0[tid] = qmask0[pg * A + tid] != 0.f ? 1.f : 0.f;
   }
   if (tid < kCedrMaxK + 1) {
     const float m = tid < K ? mu[tid] : 0.f, s = tid < K ? sigma[tid] : 1.f;
@@ -161,7 +161,7 @@ void cedr_tap_layer(const CedrTap& tap, int index, const T* x, const int64_t* ma
       auto k = cedr_pool_kernel<T>;
       const size_t smem = cedr_pool_smem(S, tap.A);
       if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(k, dim3((unsigned)np), dim3(256), smem, s, x, mask_mb, seg_mb, tap.mask_all, tap.seg_all, p0, tap.P, S, H, tap.A, tap.K,
+      hipLaunchKernelGGL(k, dim3((unsigned)np), dim3(256), smem, s, x, mask_mb, seg_mb, tap.qmask0, p0, S, H, tap.A, tap.K,
                          tap.mu, tap.sigma, tap.pk + (int64_t)i * tap.NP * tap.K * tap.A);
     }
 }

@@ -562,11 +562,34 @@ class CedrEngine:
 
     def __init__(self, bert_engine):
         self.be = bert_engine
-        self._ws = None
+        self._wss = {}
+        self._streams = {}
+
+    def _passages(self, ids, mask, seg, S, qm0, maxqlen, layers, mu, sigma, pk, cls, ws_key):
+        """One capamd_cedr_passage_features call over n passages of length S ([n, S] x3; qm0 [n, A]) on the current stream."""
+        m, lib = self.be.model(), _lib.load()
+        n = ids.shape[0]
+        mb = min(self.be.microbatch * max(1, 256 // S), n)
+        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, n)
+        if need < 0:
+            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
+        ws = self._wss.get(ws_key)
+        if ws is None or ws.numel() < need or ws.device != ids.device:
+            ws = self._wss[ws_key] = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        arr = (ctypes.c_int * max(1, len(layers)))(*layers)
+        rc = lib.capamd_cedr_passage_features(_ptr(ids), _ptr(mask), _ptr(seg), n, 1, S, ctypes.byref(m), mb, _ptr(ws), ws.numel(), int(maxqlen),
+                                              _ptr(qm0), arr, len(layers), _ptr(mu), _ptr(sigma), mu.numel(), _ptr(pk), _ptr(cls),
+                                              _ptr(status_word(ids.device).t), _stream())
+        _lib.check(rc, "capamd_cedr_passage_features")
 
     def forward(self, doc_input, doc_mask, doc_seg, maxqlen, simmat_layers, mu, sigma, cls_mode, w1, b1, w2=None, b2=None, check=True,
-                return_features=False):
-        """CEDRKNRM_Class.forward (reference CEDRKNRM.py:151-185): int64 [B, P, S] x3 -> fp32 [B]."""
+                return_features=False, skip_padding=None):
+        """CEDRKNRM_Class.forward (reference CEDRKNRM.py:151-185): int64 [B, P, S] x3 -> fp32 [B].
+
+        skip_padding (default: the encoder engine's setting): as in BertEngine.forward, every passage is encoded at the shortest
+        supported length that holds its last attended token.  Padded key positions get an attention weight of exactly 0 and
+        padded document columns are masked out of every kernel sum, so the per-passage sums and [CLS] rows are those of the
+        full-length computation; only the dead rows and columns are not computed."""
         _need_gpu(doc_input, doc_mask, doc_seg, mu, sigma, w1, b1)
         if cls_mode not in CLS_MODES:
             raise ValueError("cls must be 'avg', 'max' or None")
@@ -579,20 +602,52 @@ class CedrEngine:
         m = self.be.model()
         lib = _lib.load()
         layers = sorted(int(x) for x in simmat_layers if int(x) >= 0)      # -1 alone = no similarity matrices (CEDRKNRM.py:48-52)
-        n_sel, K, A, H = len(layers), mu.numel(), maxqlen + 1, m.hidden
-        mb = min(self.be.microbatch * max(1, 256 // S), B * P)
-        need = lib.capamd_bert_workspace_bytes(ctypes.byref(m), S, mb, B * P)
-        if need < 0:
-            raise ValueError(f"unsupported passage length {S} (supported: multiples of 32 up to 256, 384, 512)")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        pk = torch.empty(max(1, n_sel * B * P * K * A), dtype=torch.float32, device=dev)
-        cls = torch.empty(B * P * H, dtype=torch.float32, device=dev)
-        st = status_word(dev)
-        arr = (ctypes.c_int * max(1, n_sel))(*layers)
-        rc = lib.capamd_cedr_passage_features(_ptr(ids), _ptr(mask), _ptr(seg), B, P, S, ctypes.byref(m), mb, _ptr(self._ws), self._ws.numel(),
-                                              int(maxqlen), arr, n_sel, _ptr(mu), _ptr(sigma), K, _ptr(pk), _ptr(cls), _ptr(st.t), _stream())
-        _lib.check(rc, "capamd_cedr_passage_features")
+        n_sel, K, A, H, NP = len(layers), mu.numel(), maxqlen + 1, m.hidden, B * P
+        if A + 1 > S:
+            raise ValueError("maxqlen + 2 exceeds the passage length")
+        # the query mask the reference applies to every passage of a document: its FIRST passage's (CEDRKNRM.py:123)
+        qm0 = ((mask[:, 0, 1:A + 1] != 0) & (seg[:, 0, 1:A + 1] == 0)).float().repeat_interleave(P, dim=0).contiguous()   # [NP, A]
+        pk = torch.empty((max(1, n_sel), NP, K * A), dtype=torch.float32, device=dev)
+        cls = torch.empty((NP, H), dtype=torch.float32, device=dev)
+        fids, fmask, fseg = ids.view(NP, S), mask.view(NP, S), seg.view(NP, S)
+        if skip_padding is None:
+            skip_padding = self.be.skip_padding
+        lengths = [x for x in SUPPORTED_LENGTHS if x < S and x > A + 1] if (skip_padding and S in SUPPORTED_LENGTHS) else []
+        if not lengths:
+            self._passages(fids, fmask, fseg, S, qm0, maxqlen, layers, mu, sigma, pk, cls, None)
+        else:
+            end = ((fmask != 0) * torch.arange(1, S + 1, device=dev)).amax(dim=1)
+            bounds = lengths + [S]
+            bucket = torch.bucketize(end, torch.tensor(lengths, device=dev), right=False)
+            order = torch.argsort(bucket, stable=True)
+            counts = torch.bincount(bucket, minlength=len(bounds)).cpu().tolist()   # the one host round trip of this call
+            main = torch.cuda.current_stream(dev)
+            lo, used = 0, []
+            for Sb, n in zip(bounds, counts):
+                if n == 0:
+                    continue
+                sel = order[lo:lo + n]
+                lo += n
+                side = self._streams.get(Sb)
+                if side is None:
+                    side = self._streams[Sb] = torch.cuda.Stream(device=dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    q = 256 // math.gcd(Sb, 256)            # whole 256-row tiles: pad the bucket with copies of its last passage
+                    pad = (-n) % q
+                    sel_p = torch.cat([sel, sel[-1:].expand(pad)]) if pad else sel
+                    bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
+                    bq = qm0.index_select(0, sel_p)
+                    pk_b = torch.empty((max(1, n_sel), n + pad, K * A), dtype=torch.float32, device=dev)
+                    cls_b = torch.empty((n + pad, H), dtype=torch.float32, device=dev)
+                    self._passages(bi, bm, bs, Sb, bq, maxqlen, layers, mu, sigma, pk_b, cls_b, Sb)
+                    pk.index_copy_(1, sel, pk_b[:, :n])
+                    cls.index_copy_(0, sel, cls_b[:n])
+                    for t in (bi, bm, bs, bq, pk_b, cls_b, sel_p):
+                        t.record_stream(side)
+                used.append(side)
+            for side in used:
+                main.wait_stream(side)
         n_in = (H if cls_mode else 0) + n_sel * K
         feats = torch.empty((B, n_in), dtype=torch.float32, device=dev) if return_features else None
         hidden = 0 if w2 is None else w1.shape[0]
@@ -601,5 +656,5 @@ class CedrEngine:
                                    None if feats is None else _ptr(feats), _stream())
         _lib.check(rc, "capamd_cedr_score")
         if check:
-            st.raise_if_set()
+            status_word(dev).raise_if_set()
         return (out, feats) if return_features else out

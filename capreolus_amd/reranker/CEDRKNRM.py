@@ -90,7 +90,7 @@ class CEDRKNRM_Class(nn.Module):
         shape = (B, self.num_passages, self.maxseqlen)
         if self._engine is None:
             be = engine.BertEngine(self._params(), self.bert.num_attention_heads, microbatch=int(self.config.get("microbatch", 256)),
-                                   compute_dtype=self.config.get("compute_dtype", "fp16"))
+                                   compute_dtype=self.config.get("compute_dtype", "fp16"), skip_padding=bool(self.config.get("skip_padding", True)))
             self._engine = engine.CedrEngine(be)
         else:
             self._engine.be.params = self._params()
@@ -106,12 +106,12 @@ class CEDRKNRM_Class(nn.Module):
 
 class CEDRKNRM(Reranker):
     """MacAvaney, Yates, Cohan, Goharian. CEDR: Contextualized Embeddings for Document Ranking. SIGIR 2019 (reference CEDRKNRM.py:188-203).
-    The first eight keys are the reference's options; microbatch / compute_dtype belong to this engine (as in ptBERTMaxP)."""
+    The first eight keys are the reference's options; microbatch / compute_dtype / skip_padding belong to this engine (as in ptBERTMaxP)."""
 
     module_name = "CEDRKNRM"
     config_spec = {"pretrained": "bert-base-uncased", "mus": [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9], "sigma": 0.1,
                    "gradkernels": True, "hidden_dropout_prob": 0.1, "simmat_layers": list(range(13)), "combine_hidden": 1024, "cls": "avg",
-                   "microbatch": 256, "compute_dtype": "fp16"}
+                   "microbatch": 256, "compute_dtype": "fp16", "skip_padding": True}
 
     def build_model(self):
         if not hasattr(self, "model"):

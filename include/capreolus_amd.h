@@ -220,14 +220,17 @@ int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv
  *   0 = embedding output .. layers), leaves passage_kernel_sums[layer][passage][kernel][query row] =
  *   sum over the passage's document tokens of the RBF kernels of the masked cosine similarity matrix (masked_simmats /
  *   _cos_simmat / knrm, CEDRKNRM.py:83-130; query rows = sequence positions 1..maxqlen+1), plus cls_rows[passage][hidden] = the
- *   last hidden state's [CLS] row in fp32 (:160).  maxqlen + 1 <= 32, K <= 11.
+ *   last hidden state's [CLS] row in fp32 (:160).  query_mask0 [B*P][maxqlen+1] (fp32 0/1): for every passage, the query mask
+ *   (attention mask & segment 0 at sequence positions 1..maxqlen+1) of the FIRST passage of its document - the mask the
+ *   reference applies to all of a document's passages (:123); handing it in per passage lets a caller regroup passages (e.g. by
+ *   length, with P = 1) without losing their document.  maxqlen + 1 <= 32, K <= 11.
  *  capamd_cedr_score: the document level (:117-136, 160-185): sums over a document's P passages, clamp / log / 0.01, sum over
  *   the query rows; cls feature (cls_mode 0 none, 1 avg, 2 max); combine = Linear(n_in, 1) (combine_hidden = 0) or
  *   Linear(n_in, combine_hidden) -> Linear(combine_hidden, 1).  features_out (optional) [B][n_in]. */
 int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const int64_t* seg, int B, int P, int S,
                                  const capamd_bert_model* m, int64_t passages_per_microbatch, void* workspace, int64_t workspace_bytes,
-                                 int maxqlen, const int* simmat_layers, int n_layers, const float* mu, const float* sigma, int K,
-                                 float* passage_kernel_sums, float* cls_rows, int* status, void* stream);
+                                 int maxqlen, const float* query_mask0, const int* simmat_layers, int n_layers, const float* mu,
+                                 const float* sigma, int K, float* passage_kernel_sums, float* cls_rows, int* status, void* stream);
 int capamd_cedr_score(const float* passage_kernel_sums, const float* cls_rows, int B, int P, int maxqlen, int n_layers, int K, int hidden,
                       int cls_mode, const float* w1, const float* b1, int combine_hidden, const float* w2, const float* b2, float* out,
                       float* features_out, void* stream);

@@ -296,7 +296,7 @@ def test_bert_microbatching_and_errors():
 
 # ---- CEDR-KNRM (row N4): encoder + per-layer masked cosine matrices + kernel pooling + combine ----
 
-def _cedr_model(c, w, head, dt):
+def _cedr_model(c, w, head, dt, skip_padding=True):
     from capreolus_amd.reranker import CEDRKNRM
     from tests.helpers import CEDR_MUS
 
@@ -304,7 +304,7 @@ def _cedr_model(c, w, head, dt):
     P, S = c["pos_bert_input"].shape[1:]
     cfg = {"pretrained": dict(hidden=hidden, layers=layers, heads=heads, ffn=ffn, vocab=vocab, max_pos=max_pos), "mus": CEDR_MUS, "sigma": 0.1,
            "gradkernels": True, "hidden_dropout_prob": 0.1, "simmat_layers": [int(x) for x in c["simmat_layers"]],
-           "combine_hidden": int(c["combine_hidden"]), "cls": c["cls_mode"], "compute_dtype": dt}
+           "combine_hidden": int(c["combine_hidden"]), "cls": c["cls_mode"], "compute_dtype": dt, "skip_padding": skip_padding}
     r = CEDRKNRM(cfg, SimpleNamespace(config={"numpassages": P, "maxseqlen": S, "maxqlen": int(c["maxqlen"])}))
     m = r.build_model()
     sd = dict(w)
@@ -318,12 +318,13 @@ def _cedr_model(c, w, head, dt):
 
 @pytest.mark.parametrize("name", ["mini", "mini_max_single", "mini_nocls", "base"])
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-def test_cedr_knrm_end_to_end(name, dt):
+@pytest.mark.parametrize("skip_padding", [True, False])
+def test_cedr_knrm_end_to_end(name, dt, skip_padding):
     from oracle import bert_port
     from tests.helpers import load_cedr_case
 
     c, w, head, mus, sigmas = load_cedr_case(name)
-    r = _cedr_model(c, w, head, dt)
+    r = _cedr_model(c, w, head, dt, skip_padding)
     d = {k: torch.from_numpy(c[k].astype(np.int64)).to(DEV) for k in ("pos_bert_input", "pos_mask", "pos_seg")}
     with torch.no_grad():
         got = r.test(d).cpu().numpy()
@@ -364,3 +365,27 @@ def test_cedr_features_match_port_on_mini():
     H = int(c["dims"][0])
     assert np.abs(got[:, :H] - want[:, :H]).max() <= 2e-3 * np.abs(want[:, :H]).max()     # [CLS] rows of a 16-bit encoder
     assert np.abs(got[:, H:] - want[:, H:]).max() <= 2e-3 * np.abs(want[:, H:]).max(), np.abs(got[:, H:] - want[:, H:]).max()
+
+
+@pytest.mark.parametrize("name", ["mini", "base"])
+def test_cedr_length_buckets_give_the_same_features(name):
+    """Passages regrouped by length (P = 1 calls, explicit first-passage query mask) vs one full-length call: same encoder
+    arithmetic per passage, so the per-document features agree to the last bits of the fp32 sums."""
+    from tests.helpers import load_cedr_case
+
+    c, w, head, mus, sigmas = load_cedr_case(name)
+    r = _cedr_model(c, w, head, "fp16")
+    d = [torch.from_numpy(c[k].astype(np.int64)).to(DEV) for k in ("pos_bert_input", "pos_mask", "pos_seg")]
+    m = r.model
+    with torch.no_grad():
+        m(*d)
+        mu, sigma = m.kernels.stacked()
+        lin = m.combine[0]
+        w2 = m.combine[1].weight.detach().view(-1) if len(m.combine) == 2 else None
+        b2 = m.combine[1].bias.detach() if len(m.combine) == 2 else None
+        args = (int(c["maxqlen"]), m._layers, mu, sigma, c["cls_mode"], lin.weight.detach().contiguous(), lin.bias.detach(), w2, b2)
+        s1, f1 = m._engine.forward(*d, *args, return_features=True, skip_padding=True)
+        s0, f0 = m._engine.forward(*d, *args, return_features=True, skip_padding=False)
+    assert torch.equal(f1[:, :int(c["dims"][0])], f0[:, :int(c["dims"][0])])                    # [CLS] rows: bit-identical
+    assert (f1 - f0).abs().max().item() <= 1e-6 * f0.abs().max().item() + 1e-7, (f1 - f0).abs().max().item()
+    assert (s1 - s0).abs().max().item() <= 1e-5 * s0.abs().max().item()
