@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="knrm", choices=["knrm", "drmm", "bert"])
+    ap.add_argument("--model", default="knrm", choices=["knrm", "drmm", "bert", "drmmtks", "pacrr", "convknrm"],
+                    help="knrm (default, BASELINE.json's metric) | drmm | bert | the row-N4 siblings drmmtks, pacrr, convknrm")
     ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU")
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
@@ -92,6 +93,8 @@ def main():
 
     if args.model == "bert":
         return bench_bert(args, world, rank, dev, use_dist)
+    if args.model in ("drmmtks", "pacrr", "convknrm"):
+        return bench_sibling(args, world, rank, dev, use_dist)
 
     from types import SimpleNamespace
 
@@ -246,6 +249,148 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         rec["cpu_baseline"] = cpu_baseline(args, m, batch, emb, Q, L, D)
+    if use_dist:
+        dist.destroy_process_group()
+    emit(rec)
+
+
+def bench_sibling(args, world, rank, dev, use_dist):
+    """Row N4 models on the KNRM benchmark's candidate lists: DRMM-TKS, PACRR (KNRM's gather; same algorithmic bytes) and
+    ConvKNRM (per position 6 projection-table parts of `filters` floats instead of one embedding row)."""
+    from types import SimpleNamespace
+
+    from capreolus_amd import engine, synthetic
+    from capreolus_amd.reranker import DRMMTKS, PACRR, ConvKNRM
+
+    if use_dist:
+        import torch.distributed as dist
+    Q, L, V, D = 4, 800, args.vocab, args.dim
+    n_pairs = args.queries * args.docs
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    emb = torch.randn((V, D), generator=g, device=dev) * 0.4
+    emb[0] = 0
+    batch = synthetic.make_candidate_list_torch(args.queries, args.docs, V, dev, seed=1 + rank, maxqlen=Q, maxdoclen=L, uniform_ids=args.uniform_ids)
+    if args.model == "convknrm":      # nn.Embedding ids only (the slowembedtext extractor has no negative OOV ids)
+        batch = {k: (v.abs() if v.dtype == torch.int64 else v) for k, v in batch.items()}
+    torch.manual_seed(0)
+    stub = SimpleNamespace(embeddings=np.zeros((2, D), dtype=np.float32), config={"maxqlen": Q}, pad=0)
+    rr = {"drmmtks": DRMMTKS, "pacrr": PACRR, "convknrm": ConvKNRM}[args.model]({}, stub)
+    m = rr.build_model().to(dev).eval()
+    name = "embeddings" if args.model == "convknrm" else "embedding"
+    setattr(m, name, torch.nn.Embedding.from_pretrained(emb, freeze=True))
+    q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
+    gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if use_dist else None
+    out = [None]
+
+    def step():
+        with torch.no_grad():
+            out[0] = m(d_all, q_all, idf_all).view(-1)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, out[0])
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0]).all()
+    evs = []
+    for _ in range(max(3, min(args.steps, 10))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+    nonpad = float((d_all != 0).sum().item()) / n_pairs
+    if args.model == "convknrm":
+        G, F = m.p["maxngram"], m.p["filters"]
+        row = G * (G + 1) // 2 * F * 4
+        abytes = L * (8 + row) + Q * (8 + row) + 4
+        kname = "convknrm_forward_kernel<2>"
+    else:
+        row = 4 * D
+        abytes = algorithmic_bytes_per_pair("knrm", Q, L, D) + 4 * Q
+        kname = {"drmmtks": "drmmtks_forward_kernel<5>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[args.model]
+    achieved = n_pairs * abytes / kern_s / 1e9
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    rec = {
+        "metric": "query-doc pairs scored/sec", "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{rr.module_name} inference (SURVEY.md §8f row N4) on the KNRM benchmark's lists: qlen={Q} dlen={L} embed={D} vocab={V}, "
+                               f"{args.docs} docs/query x {args.queries} queries per step per GPU, {'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, "
+                               "reference default model options",
+                   "pairs_per_step_per_gpu": n_pairs, "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_pair": abytes, "pairs_per_launch": n_pairs, "kernel_ms": kern_s * 1e3,
+                     "note": "achieved = (int64 ids + one gathered row per term, all L positions) / event-timed duration of one scoring call; pad "
+                             "positions are scored in closed form without a gather, so the bytes actually requested are achieved_gathered",
+                     "achieved_gathered": n_pairs * (L * 8 + (nonpad + Q) * row + 4) / kern_s / 1e9, "mean_nonpad_terms_per_doc": nonpad},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import cpu as oracle   # the CPU leg only
+
+        cores = os.cpu_count() or 1
+        n = args.cpu_pairs or (2000 if args.model == "convknrm" else min(n_pairs, 2000 * max(1, cores // 4)))
+        q, d, idf = (t[:n].cpu().numpy() for t in (q_all, d_all, idf_all))
+        emb_h = emb.cpu().numpy()
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+        if args.model == "drmmtks":
+            packed = oracle.pack(emb_h)
+
+            def run():
+                return oracle.drmmtks(q, d, idf, packed, D, m.topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"],
+                                      sd["output_layer.weight"], sd["output_layer.bias"])
+        elif args.model == "pacrr":
+            packed = oracle.pack(emb_h)
+            p = m.p
+            n_ng = p["maxgram"] - p["mingram"] + 1
+
+            def run():
+                return oracle.pacrr(q, d, idf, packed, D, p["mingram"], p["maxgram"], p["nfilters"], p["kmax"],
+                                    [sd[f"ngrams.{i}.conv.weight"] for i in range(n_ng)], [sd[f"ngrams.{i}.conv.bias"] for i in range(n_ng)], p["idf"],
+                                    sd["linear1.weight"], sd["linear1.bias"], sd["linear2.weight"], sd["linear2.bias"], sd["linear3.weight"],
+                                    sd["linear3.bias"], p["nonlinearity"])
+        else:
+            p = m.p
+            mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+
+            def run():
+                return oracle.convknrm(q, d, emb_h, [sd[f"convs.{i}.0.weight"] for i in range(p["maxngram"])],
+                                       [sd[f"convs.{i}.0.bias"] for i in range(p["maxngram"])], p["crossmatch"], mu, sigma, sd["combine.0.weight"],
+                                       sd["combine.0.bias"])
+        want, err = run()
+        assert err == 0
+        got = out[0][:n].cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max()), np.abs(got - want).max()   # the timed scores are the oracle's
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            run()
+            reps += 1
+            if time.perf_counter() - t0 > 8.0 or reps >= 5:
+                break
+        rec["cpu_baseline"] = {"value": n * reps / (time.perf_counter() - t0), "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"first {n} pairs of the step's batch, oracle/interaction_oracle.c with OpenMP over pairs ({reps} repetitions)"}
     if use_dist:
         dist.destroy_process_group()
     emit(rec)

@@ -4,7 +4,7 @@ set -eu
 D=profiles/${1:-r01}
 G=gpurun_out
 mkdir -p $D
-for f in bench_knrm bench_knrm_uniform bench_knrm_b1000 bench_drmm bench_bert bench_bert_skip_padding; do cp $G/$f.json $D/; done
+for f in bench_knrm bench_knrm_uniform bench_knrm_b1000 bench_drmm bench_bert bench_bert_skip_padding bench_drmmtks bench_pacrr bench_convknrm; do cp $G/$f.json $D/; done
 cp $G/bench_siblings.jsonl $D/
 cp $G/prof/knrm/knrm_kernel_stats.csv $D/knrm_bench_kernel_stats.csv
 cp $G/prof/drmm/drmm_kernel_stats.csv $D/drmm_bench_kernel_stats.csv

@@ -12,8 +12,9 @@ timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --launch-doc
 timeout 300 python bench.py --steps 20 --warmup 3 --model drmm 2>/dev/null | tail -1 > gpurun_out/bench_drmm.json
 timeout 600 python bench.py --steps 3 --warmup 1 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
 timeout 600 python bench.py --steps 3 --warmup 1 --model bert --no-cpu-baseline --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
+for mdl in drmmtks pacrr convknrm; do timeout 300 python bench.py --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
 timeout 600 python scripts/sibling_bench.py 2>/dev/null | grep model > gpurun_out/bench_siblings.jsonl; cat gpurun_out/bench_siblings.jsonl
-for f in knrm_uniform knrm_b1000 drmm bert; do python -c "import json;r=json.load(open('gpurun_out/bench_$f.json'));print('$f', round(r['value'],1), r['roofline']['frac'])"; done
+for f in knrm_uniform knrm_b1000 drmm bert drmmtks pacrr convknrm; do python -c "import json;r=json.load(open('gpurun_out/bench_$f.json'));print('$f', round(r['value'],1), r['roofline']['frac'])"; done
 cd /tmp; P=/tmp/prof; rm -rf $P; mkdir -p $P
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/knrm -o knrm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/drmm -o drmm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --model drmm > /dev/null 2>&1
