@@ -779,3 +779,54 @@ def test_convknrm_errors():
             r.test(bad)
     with pytest.raises(ValueError):                           # filters not a multiple of 16: refused when the tables are built
         engine.ConvProjectionTables().get(_t(c["emb"]), [torch.zeros((20, int(c["D"]), 1), device=DEV)], [torch.zeros(20, device=DEV)])
+
+
+@pytest.mark.parametrize("kind", ["drmmtks", "pacrr", "convknrm"])
+def test_full_size_sibling_properties(full, kind):
+    """Row-N4 models at the benchmark's geometry (vocabulary 400,001 x 300, 800-term documents; ConvKNRM: the 1.2 GB projection table):
+    pairs are independent (a permutation of the batch permutes the scores bit for bit), the launch size does not matter (chunked
+    calls == one call, bit for bit), and a sample of pairs agrees with the oracle."""
+    from capreolus_amd.reranker import DRMMTKS, PACRR, ConvKNRM
+
+    emb, batch = full
+    if kind == "convknrm":
+        batch = {k: (v.abs() if v.dtype == torch.int64 else v) for k, v in batch.items()}
+    torch.manual_seed(3)
+    ext = SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32), config={"maxqlen": 4}, pad=0)
+    r = {"drmmtks": DRMMTKS, "pacrr": PACRR, "convknrm": ConvKNRM}[kind]({}, ext)
+    m = r.build_model().to(DEV).eval()
+    setattr(m, "embeddings" if kind == "convknrm" else "embedding", torch.nn.Embedding.from_pretrained(emb, freeze=True))
+    with torch.no_grad():
+        s = r.test(batch)
+        assert s.shape == (2000,) and torch.isfinite(s).all()
+        perm = torch.randperm(2000, device=DEV)
+        assert torch.equal(r.test({k: v[perm] for k, v in batch.items()}), s[perm])
+        sc = torch.cat([r.test({k: v[i:i + 333] for k, v in batch.items()}) for i in range(0, 2000, 333)])
+        assert torch.equal(sc, s)
+    idx = np.arange(0, 2000, 125)
+    q, d, idf = (batch[k][idx].cpu().numpy() for k in ("query", "posdoc", "query_idf"))
+    used = np.unique(np.concatenate([q.ravel(), d.ravel()]))
+    used = used[used > 0]
+    remap = np.zeros(400001, dtype=np.int64)
+    remap[used] = np.arange(1, len(used) + 1)
+    small = np.concatenate([np.zeros((1, 300), np.float32), emb[torch.as_tensor(used, device=DEV)].cpu().numpy()])
+    rq, rd = np.where(q > 0, remap[np.maximum(q, 0)], q), np.where(d > 0, remap[np.maximum(d, 0)], d)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    if kind == "drmmtks":
+        want, err = oracle.drmmtks(rq, rd, idf, oracle.pack(small), 300, m.topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"],
+                                   sd["output_layer.weight"], sd["output_layer.bias"])
+        tol = ORACLE_TOL
+    elif kind == "pacrr":
+        p = m.p
+        want, err = oracle.pacrr(rq, rd, idf, oracle.pack(small), 300, p["mingram"], p["maxgram"], p["nfilters"], p["kmax"],
+                                 [sd[f"ngrams.{i}.conv.weight"] for i in range(3)], [sd[f"ngrams.{i}.conv.bias"] for i in range(3)], p["idf"],
+                                 sd["linear1.weight"], sd["linear1.bias"], sd["linear2.weight"], sd["linear2.bias"], sd["linear3.weight"],
+                                 sd["linear3.bias"], p["nonlinearity"])
+        tol = ORACLE_TOL
+    else:
+        mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+        want, err = oracle.convknrm(rq, rd, small, [sd[f"convs.{i}.0.weight"] for i in range(3)], [sd[f"convs.{i}.0.bias"] for i in range(3)], True,
+                                    mu, sigma, sd["combine.0.weight"], sd["combine.0.bias"])
+        tol = CONVKNRM_ORACLE_TOL
+    assert err == 0
+    assert rel_err(s[idx].cpu().numpy(), want).max() <= tol, rel_err(s[idx].cpu().numpy(), want).max()
