@@ -277,10 +277,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define CAPAMD_PACRR_ABLATE 0       // profiling builds only: 1 = no convolutions, 2 = no gather, 3 = no combine layers
 #endif
 #ifndef CAPAMD_PACRR_U
-#define CAPAMD_PACRR_U 3            // embedding rows in flight per 16-lane group in the gather loop (measured: 1 -> 5.1 ms, 2 -> 4.4, 3 -> 4.1 per 64,000 pairs)
+#define CAPAMD_PACRR_U 1            // embedding rows in flight per 16-lane group in the gather loop
 #endif
 #ifndef CAPAMD_PACRR_WAVES
-#define CAPAMD_PACRR_WAVES 3        // register budget: waves per SIMD (the 40 KB LDS image of an 800-term pair allows 3 workgroups per CU anyway)
+#define CAPAMD_PACRR_WAVES 4        // register budget: waves per SIMD.  Measured per 64,000 pairs with the 36.7 KB LDS image (4 workgroups per CU):
+                                    // U1/W4 3.47 ms (no spills), U2/W4 3.45 (20 spilled registers), U3/W3 3.52, U4/W3 3.65, U3/W4 5.64 (47 spills)
 #endif
 constexpr int kMfmaMaxQ = 5;        // rows 0 .. Q + 1 of the padded matrix + the bias row fit the 8 K slots of a half-wave
 constexpr int kBiasRow = 7;
@@ -348,22 +349,30 @@ __device__ __forceinline__ float pacrr_relu_max(const f32x16& c) {
   return m;
 }
 
+// bytes of the LDS region shared by the front end's term list and the back end's weights / head vectors
+__host__ __device__ inline int pacrr_mfma_region0(int L, int n_weights) {
+  const int front = ((L + 7) & ~7) * 6, back = (n_weights + kPacrrMaxFeat + 2 * kPacrrMaxC) * 4;
+  return ((front > back ? front : back) + 15) & ~15;
+}
+
 // KM = length of the per-lane candidate lists (>= kmax)
 template <int NV, int KM>
 __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kernel(PacrrArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tok_cap = (a.L + 7) & ~7;
   const int LP = ((a.L + 63) & ~63) + 4;                         // positions in the LDS image (zero tail = right padding)
+  // region 0 is used twice: the compacted terms (front end), then the convolution weights and the head's vectors (back end)
+  const int r0 = pacrr_mfma_region0(a.L, a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters);
   int* tok = reinterpret_cast<int*>(smem_raw);
   unsigned short* pos = reinterpret_cast<unsigned short*>(tok + tok_cap);
-  _Float16* s_hi = reinterpret_cast<_Float16*>(pos + tok_cap);   // [LP][8]: f16(sim[row][position]), row kBiasRow = 1
-  _Float16* s_lo = s_hi + LP * 8;                                // [LP][8]: f16(sim - hi)
-  float* wts = reinterpret_cast<float*>(s_lo + LP * 8);          // conv_w | conv_b
+  float* wts = reinterpret_cast<float*>(smem_raw);               // conv_w | conv_b   (after the front end)
   float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;
   float* h1 = feat + kPacrrMaxFeat;
   float* h2 = h1 + kPacrrMaxC;
-  int* wave_cnt = reinterpret_cast<int*>(h2 + kPacrrMaxC);
-  float4* qlds = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(wave_cnt + 8) + 15) & ~(uintptr_t)15);
+  _Float16* s_hi = reinterpret_cast<_Float16*>(smem_raw + r0);   // [LP][8]: f16(sim[row][position]), row kBiasRow = 1
+  _Float16* s_lo = s_hi + LP * 8;                                // [LP][8]: f16(sim - hi)
+  int* wave_cnt = reinterpret_cast<int*>(s_lo + LP * 8);
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);        // (32 bytes after a 16-byte aligned plane: aligned)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
@@ -377,9 +386,6 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
       reinterpret_cast<u32x4*>(s_lo)[i] = z;
     }
   }
-  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
-  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
-
   int n_real = pacrr_compact(a, ids, tok, pos, wave_cnt, tid);
   if (CAPAMD_PACRR_ABLATE == 2) n_real = 0;
   pacrr_similarities<NV, CAPAMD_PACRR_U>(a, ids, tok, pos, n_real, qlds, tid, [&](int row, int j, float x) {
@@ -387,6 +393,10 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
     s_hi[j * 8 + row] = (_Float16)h;
     s_lo[j * 8 + row] = (_Float16)(x - h);
   });
+  // (the front end ended on a barrier: tok / pos are dead, region 0 now takes the weights)
+  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
+  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
+  __syncthreads();
 
   // ---- convolutions on the matrix pipe; wave w owns query rows w, w + 4 ----
   for (int q = wave; q < (CAPAMD_PACRR_ABLATE == 1 ? 0 : a.Q); q += 4) {
@@ -488,7 +498,8 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
   const size_t tail = (size_t)(ncw + (maxgram - mingram + 1) * nfilters) * 4 + (size_t)(kPacrrMaxFeat + 2 * kPacrrMaxC + 8) * 4 + 16 +
                       (size_t)kQT * kMaxNV * 16 * 16;
   if (Q <= kMfmaMaxQ && nfilters <= 32 && !pacrr_force_valu()) {
-    const size_t smem = (size_t)((L + 7) & ~7) * 6 + (size_t)(((L + 63) & ~63) + 4) * 32 + tail;
+    const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 32 +
+                        (size_t)kQT * kMaxNV * 16 * 16;
 #define LAUNCH_M(NV_)                                                                                                           \
   do {                                                                                                                          \
     auto k = kmax <= 2 ? pacrr_mfma_kernel<NV_, 2> : pacrr_mfma_kernel<NV_, kPacrrMaxK>;                                       \
