@@ -295,28 +295,28 @@ def bench_sibling(args, world, rank, dev, use_dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    with torch.no_grad():
+        m(d_all[:8], q_all[:8], idf_all[:8])          # packs the tables and checks the status word once, synchronously
+    status = engine.deferred_status(dev)              # the timed calls are queued back to back like bench.py's KNRM / DRMM launches
+    status.__enter__()                                # (check=False there); the accumulated status bits are raised at the end
     for _ in range(args.warmup):
         step()
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # HIP events on the launch stream over the timed region
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    kern_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps      # one scoring call = the model's kernel + a few tiny torch ops of the mirror
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out[0]).all()
-    evs = []
-    for _ in range(max(3, min(args.steps, 10))):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        step()
-        e1.record()
-        evs.append((e0, e1))
-    torch.cuda.synchronize()
-    kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+    status.__exit__(None, None, None)
     nonpad = float((d_all != 0).sum().item()) / n_pairs
     if args.model == "convknrm":
         G, F = m.p["maxngram"], m.p["filters"]

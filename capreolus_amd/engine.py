@@ -42,6 +42,30 @@ def _f32(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
 
 
+_deferred = [0]
+
+
+class deferred_status:
+    """Inside this context the per-call status read-backs (one 4-byte device->host copy, i.e. one synchronisation, per scoring
+    call) are skipped; the bits keep accumulating in the device word and are raised when the context exits.  For callers that
+    queue many scoring calls back to back (bench.py, a resident evaluation loop)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __enter__(self):
+        _deferred[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _deferred[0] -= 1
+        if exc[0] is None and _deferred[0] == 0:
+            status_word(self.device).raise_if_set()
+        return False
+
+
 class StatusWord:
     """The device int32 the kernels OR data-dependent error bits into (include/capreolus_amd.h)."""
 
@@ -49,6 +73,8 @@ class StatusWord:
         self.t = torch.zeros(1, dtype=torch.int32, device=device)
 
     def raise_if_set(self):
+        if _deferred[0]:
+            return
         bits = int(self.t.item())  # synchronises, like the reference's .cpu() (trainer/pytorch.py:345)
         if bits:
             self.t.zero_()

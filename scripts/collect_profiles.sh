@@ -9,6 +9,7 @@ cp $G/bench_siblings.jsonl $D/
 cp $G/prof/knrm/knrm_kernel_stats.csv $D/knrm_bench_kernel_stats.csv
 cp $G/prof/drmm/drmm_kernel_stats.csv $D/drmm_bench_kernel_stats.csv
 cp $G/prof/bert/bert_kernel_stats.csv $D/bert_bench_kernel_stats.csv
+for m in drmmtks pacrr convknrm; do [ -f $G/prof/$m/${m}_kernel_stats.csv ] && cp $G/prof/$m/${m}_kernel_stats.csv $D/${m}_bench_kernel_stats.csv; done
 cp $G/prof/knrm_fetch/knrm_counter_collection.csv $D/knrm_fetch_counters.csv
 cp $G/prof/knrm_write/knrm_counter_collection.csv $D/knrm_write_counters.csv
 cp $G/prof/knrm_tcc/knrm_counter_collection.csv $D/knrm_tcc_counters.csv

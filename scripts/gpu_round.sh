@@ -19,6 +19,7 @@ cd /tmp; P=/tmp/prof; rm -rf $P; mkdir -p $P
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/knrm -o knrm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/drmm -o drmm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --model drmm > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/bert -o bert -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --model bert > /dev/null 2>&1
+for mdl in drmmtks pacrr convknrm; do timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$mdl -o $mdl -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/knrm_fetch -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/knrm_write -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/knrm_tcc -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1

@@ -830,3 +830,20 @@ def test_full_size_sibling_properties(full, kind):
         tol = CONVKNRM_ORACLE_TOL
     assert err == 0
     assert rel_err(s[idx].cpu().numpy(), want).max() <= tol, rel_err(s[idx].cpu().numpy(), want).max()
+
+
+def test_deferred_status_raises_at_exit():
+    """engine.deferred_status: the per-call status read-back is skipped inside the context, the accumulated bits are raised when it exits."""
+    c = load_case("knrm", KNRM_CASES[0])
+    r = KNRM({"gradkernels": True, "scoretanh": False, "singlefc": True, "finetune": False}, SimpleNamespace(embeddings=c["emb"]))
+    r.build_model().to(DEV).eval()
+    b = _batch(c)
+    bad = dict(b, posdoc=b["posdoc"].clone())
+    bad["posdoc"][1, 3] = int(c["V"]) + 5
+    with torch.no_grad():
+        with pytest.raises(IndexError):
+            with engine.deferred_status(DEV):
+                r.test(bad)           # no exception here
+                s = r.test(b)         # ... and later calls still run
+                assert torch.isfinite(s).all()
+        assert torch.isfinite(r.test(b)).all()   # the word was cleared when the error was raised
