@@ -36,6 +36,16 @@ class Reranker:
     def test(self, d):
         raise NotImplementedError
 
+    def test_resident(self, store, pair_q, pair_d):
+        """Scores (query row, document row) pairs of a device-resident `capreolus_amd.feeder.CandidateStore`.
+        Default for the interaction models: the id rows are gathered ON THE DEVICE from the store's int32 tables (no host
+        round trip, no DataLoader) and handed to `test`; KNRM and DRMM override this with kernels that read the tables directly."""
+        import torch
+
+        pq, pd = pair_q.long(), pair_d.long()
+        return self.test({"query": store.q_table.index_select(0, pq).long(), "posdoc": store.d_table.index_select(0, pd).long(),
+                          "query_idf": store.idf_table.index_select(0, pq).to(torch.float32)})
+
     def add_summary(self, summary_writer, niter):
         for name, weight in self.model.named_parameters():
             summary_writer.add_histogram(name, weight.data.cpu(), niter)

@@ -847,3 +847,38 @@ def test_deferred_status_raises_at_exit():
                 s = r.test(b)         # ... and later calls still run
                 assert torch.isfinite(s).all()
         assert torch.isfinite(r.test(b)).all()   # the word was cleared when the error was raised
+
+
+@pytest.mark.parametrize("kind", ["drmmtks", "pacrr", "convknrm"])
+def test_resident_store_serves_the_sibling_models(kind):
+    """Row N1 for the row-N4 models: int32 tables + index pairs (id rows gathered on the device) give bit-identical scores to the
+    int64 [B, Q] / [B, L] layout, in any pair order, and `PytorchTrainer.predict_resident` returns them rounded to fp16."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.reranker import DRMMTKS
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case(kind, "ranklist")
+    if kind == "drmmtks":
+        r = DRMMTKS({"topk": int(c["topk"])}, SimpleNamespace(embeddings=c["emb"]))
+        m = r.build_model()
+        m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}, strict=False)
+        m.to(DEV).eval()
+    else:
+        r = _pacrr_reranker(c) if kind == "pacrr" else _convknrm_reranker(c)
+    B = c["query"].shape[0]
+    store = CandidateStore(DEV)
+    for i in range(B):   # (the fixture draws an idf row per pair, so every pair gets its own query row)
+        store.add_query(f"q{i}", c["query"][i], c["query_idf"][i])
+        store.add_doc(f"d{i}", c["posdoc"][i])
+    store.finalize()
+    pq = torch.arange(B, dtype=torch.int32, device=DEV)
+    pd = torch.as_tensor([store.drow[f"d{i}"] for i in range(B)], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        want = r.test(_batch(c))
+        assert torch.equal(r.test_resident(store, pq, pd), want)
+        perm = torch.randperm(B, device=DEV)
+        assert torch.equal(r.test_resident(store, pq[perm], pd[perm]), want[perm])
+    preds = PytorchTrainer({"evalbatch": 64}).predict_resident(r, store, {f"q{i}": [f"d{i}"] for i in range(B)})
+    got = np.array([preds[f"q{i}"][f"d{i}"] for i in range(B)], dtype=np.float16)
+    assert (got == want.cpu().numpy().astype(np.float16)).all()
+    assert (got == c["ref_scores_f16"]).mean() > 0.98
