@@ -42,6 +42,7 @@ SIGNATURES = {
     "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "capamd_drmmtks_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "capamd_pacrr_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
     "capamd_convknrm_table_bytes": (_i64, [_i64, _i, _i]),

@@ -33,6 +33,7 @@ struct TksArgs {
   const float* out_b;    // [1]
   float* out;
   int* status;
+  float* feat;           // training-step mode (capamd_drmmtks_features): [B][Q][topk] sorted top-k similarities instead of scores
 };
 
 template <int NV>
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a)
     if (q < a.Q) {
       const int no = n_one[wave], nz = n_nonreal - no;
       int head = 0;
-      float acc = a.ffw_b[0];
+      float acc = a.feat ? 0.f : a.ffw_b[0];
       for (int r = 0; r < K; ++r) {
         float cand = -INFINITY;
         if (lane < kGroupsPerWG) cand = head < kMaxTopK ? lists[(lane * kQT + wave) * kMaxTopK + head] : -INFINITY;
@@ -133,9 +134,13 @@ __global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a)
         if (who == 0) break;  // fewer than k candidates (L < k): torch.topk would raise; the host checks L >= k
         const int winner = __ffsll((long long)who) - 1;
         if (lane == winner) ++head;
-        acc = __builtin_fmaf(a.ffw_w[r], best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+        if (a.feat) {
+          if (lane == 0) a.feat[((int64_t)b * a.Q + q) * K + r] = best;
+        } else {
+          acc = __builtin_fmaf(a.ffw_w[r], best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+        }
       }
-      if (lane == 0) {
+      if (lane == 0 && !a.feat) {
         zlds[q] = tanhf(acc);
         float gl = a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q];
         if (ids.q(q) == 0) gl += -1e7f;   // DRMMTKS.py:38
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a)
     __syncthreads();
   }
 
-  if (tid == 0) {  // softmax gate + output layer (DRMMTKS.py:47-48, :60-62)
+  if (tid == 0 && !a.feat) {  // softmax gate + output layer (DRMMTKS.py:47-48, :60-62)
     float m = glds[0];
     for (int q = 1; q < a.Q; ++q) m = fmaxf(m, glds[q]);
     float den = 0.f, num = 0.f;
@@ -169,7 +174,30 @@ extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids
   if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
-  TksArgs a{ids, idf, B, Q, L, packed, V, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out, status};
+  TksArgs a{ids, idf, B, Q, L, packed, V, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out, status, nullptr};
+  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 16) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+#define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)
+  switch (nv_for_dim(D)) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(5); break;
+  }
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                       int D, int topk, float* features, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !features || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  TksArgs a{ids, nullptr, B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, features};
   const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 16) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();

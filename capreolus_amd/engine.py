@@ -506,6 +506,23 @@ def drmmtks_forward(query, doc, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b, o
     return out
 
 
+def drmmtks_features(query, doc, packed, V, D, topk, check=True):
+    """The sorted top-k similarities of every query term (DRMMTKS.py:55-56): fp32 [B, Q, topk] (capamd_drmmtks_features)."""
+    _need_gpu(query, doc, packed)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L = d.shape[1]
+    if topk > L:
+        raise RuntimeError("selected index k out of range")
+    out = torch.empty((B, Q, topk), dtype=torch.float32, device=q.device)
+    st = status_word(q.device)
+    rc = _lib.load().capamd_drmmtks_features(_ptr(q), _ptr(d), B, Q, L, _ptr(packed), V, D, int(topk), _ptr(out), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmmtks_features")
+    if check:
+        st.raise_if_set()
+    return out
+
+
 NONLINEARITIES = {"none": 0, "relu": 1, "tanh": 2}
 
 

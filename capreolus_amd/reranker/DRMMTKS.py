@@ -32,12 +32,27 @@ class DRMMTKS_class(nn.Module):
 
     def forward(self, doc, query, query_idf):
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("the DRMMTKS training step is not part of the MI355X engine; score under model.eval()")
+            return self._forward_train(doc, query, query_idf)
         w = self.embedding.weight
         out = engine.drmmtks_forward(query, doc, query_idf, self._packed.get(w), w.shape[0], w.shape[1], self.topk,
                                      self.gates.weight.detach().view(-1), self.ffw[0].weight.detach().contiguous().view(-1),
                                      self.ffw[0].bias.detach(), self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach())
         return out.view(-1, 1)
+
+
+    def _forward_train(self, doc, query, query_idf):
+        """Training step (reference trainer/pytorch.py:96-99 -> DRMMTKS.score): the gather / similarity / top-k - everything that
+        touches the [B, Q, L] tensors - is the HIP kernel (capamd_drmmtks_features); the embedding table is frozen, so no
+        gradient flows through the similarities, and the Linear(topk, 1)/tanh, the idf gate and the output layer
+        (DRMMTKS.py:57-62) run under autograd on the [B, Q, topk] features."""
+        if self.embedding.weight.requires_grad:
+            raise NotImplementedError("freezeemb=False (gradients into the embedding table) is not supported by the MI355X engine")
+        w = self.embedding.weight
+        topk = engine.drmmtks_features(query, doc, self._packed.get(w), w.shape[0], w.shape[1], self.topk)
+        ffw_vec = self.ffw(topk).squeeze(-1)                                            # (B, Q)
+        gate = self.gates(query_idf.float()[:, :, None]).squeeze(-1) + (1 - (query != 0).float()) * -1e7
+        wgt = torch.softmax(gate, dim=1)
+        return self.output_layer((wgt * ffw_vec).sum(dim=-1, keepdim=True))
 
 
 class DRMMTKS(Reranker):

@@ -126,6 +126,11 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
 int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L,
                            const float* packed, int64_t V, int D, int topk, const float* gate_w, const float* ffw_w,
                            const float* ffw_b, const float* out_w, const float* out_b, float* out, int* status, void* stream);
+/* Training-step half of DRMM-TKS (row N3; reference trainer/pytorch.py:96-99 -> DRMMTKS.score): features[B][Q][topk] = the sorted
+ * top-k similarities of every query term (DRMMTKS.py:55-56).  The embedding table is frozen (freezeemb), so no gradient flows
+ * through them; the Linear(topk,1)/tanh, the idf gate and the output layer (a few dozen flops per pair) run under autograd. */
+int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V, int D,
+                            int topk, float* features, int* status, void* stream);
 
 /* ---- PTBERTMaxP_Class.predict_step (capreolus/reranker/ptBERTMaxP.py:67-96) behind PTBERTMaxP.test
  * (ptBERTMaxP.py:134-135), including the transformers.BertForSequenceClassification forward it calls

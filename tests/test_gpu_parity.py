@@ -882,3 +882,45 @@ def test_resident_store_serves_the_sibling_models(kind):
     got = np.array([preds[f"q{i}"][f"d{i}"] for i in range(B)], dtype=np.float16)
     assert (got == want.cpu().numpy().astype(np.float16)).all()
     assert (got == c["ref_scores_f16"]).mean() > 0.98
+
+
+def test_drmmtks_training_step_matches_autograd():
+    """Row N3 for DRMM-TKS: the [B, Q, topk] features of the HIP kernel are the top-k rows of the oracle's similarity matrix (bit
+    exact), and the loss / gradients of the small net on top equal the same ATen ops under autograd on the host."""
+    from capreolus_amd.reranker import DRMMTKS
+
+    c = load_case("drmmtks", "default")
+    K = int(c["topk"])
+    r = DRMMTKS({"topk": K}, SimpleNamespace(embeddings=c["emb"]))
+    m = r.build_model()
+    m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}, strict=False)
+    m.to(DEV).train()
+    b = _batch(c)
+    negdoc = c["posdoc"][np.roll(np.arange(len(c["posdoc"])), 1)]
+    s = r.score({**b, "negdoc": _t(negdoc)})
+    loss = torch.clamp(1.0 - (s[0] - s[1]), min=0).mean() + 0.01 * s[0].sum()
+    loss.backward()
+    packed = oracle.pack(c["emb"])
+    feats = engine.drmmtks_features(b["query"], b["posdoc"], m._packed.get(m.embedding.weight), int(c["V"]), int(c["D"]), K).cpu().numpy()
+    sim, err = oracle.simmat(c["query"], c["posdoc"], packed, int(c["D"]))
+    assert err == 0
+    assert np.array_equal(feats, -np.sort(-sim, axis=-1)[:, :, :K])                        # torch.topk values: sorted descending
+    t = {k[3:]: torch.as_tensor(v).clone().requires_grad_(True) for k, v in c.items() if k.startswith("sd.")}
+
+    def host_scores(doc):
+        sm, e = oracle.simmat(c["query"], doc, packed, int(c["D"]))
+        assert e == 0
+        top = torch.as_tensor(-np.sort(-sm, axis=-1)[:, :, :K].copy())
+        z = torch.tanh(top @ t["ffw.0.weight"].t() + t["ffw.0.bias"]).squeeze(-1)           # DRMMTKS.py:57
+        q = torch.as_tensor(c["query"])
+        gl = torch.as_tensor(c["query_idf"]) * t["gates.weight"].view(-1)[0] + (q == 0).float() * -1e7   # :38-41
+        return (torch.softmax(gl, dim=1) * z).sum(1) * t["output_layer.weight"].view(-1)[0] + t["output_layer.bias"].view(-1)[0]
+
+    ps, ns = host_scores(c["posdoc"]), host_scores(negdoc)
+    ref = torch.clamp(1.0 - (ps - ns), min=0).mean() + 0.01 * ps.sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+    for name, mod in (("ffw.0.weight", m.ffw[0].weight), ("gates.weight", m.gates.weight), ("output_layer.weight", m.output_layer.weight),
+                      ("ffw.0.bias", m.ffw[0].bias)):
+        g, gr = mod.grad.cpu(), t[name].grad
+        assert (g - gr).abs().max() <= 2e-3 * (float(gr.abs().max()) + 1e-8), name
