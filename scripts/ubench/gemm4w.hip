@@ -12,6 +12,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int kStage = 64 * 1024;   // A 32 KB | B 32 KB
+#ifndef ABL
+#define ABL 0      // bit 0: no LDS-DMA fill in the loop, bit 1: fragments read once (no LDS reads in the loop), bit 2: one fill pair per 4 MFMAs
+#endif
 
 __global__ __launch_bounds__(256, 1) void gemm4w(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M,
                                                  int N, int K, unsigned long long* stamps) {
@@ -62,18 +65,20 @@ __global__ __launch_bounds__(256, 1) void gemm4w(const _Float16* __restrict__ A,
     const bool more = kt + 1 < KT;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (more) fill((kt + 1) & 1, kt + 1, kk * 2, kk * 2 + 2);   // 4 of the 16 DMA instructions of the next step per k-slice
+      if (more && !(ABL & 1) && !(ABL & 4)) fill((kt + 1) & 1, kt + 1, kk * 2, kk * 2 + 2);   // 4 of the 16 DMA instructions of the next step per k-slice
       h8 fa[4], fb[4];
-      const int ko = ((2 * kk + half) ^ sw) * 16;
+      const int ko = (ABL & 2) ? 0 : ((2 * kk + half) ^ sw) * 16;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const h8*>(st + arow[i] + ko);
-        fb[i] = *reinterpret_cast<const h8*>(st + brow[i] + ko);
+        fa[i] = *reinterpret_cast<const h8*>(((ABL & 2) ? lds : st) + arow[i] + ko);
+        fb[i] = *reinterpret_cast<const h8*>(((ABL & 2) ? lds : st) + brow[i] + ko);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (more && !(ABL & 1) && (ABL & 4) && (i & 1) == 0) fill((kt + 1) & 1, kt + 1, kk * 2 + (i >> 1), kk * 2 + (i >> 1) + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
