@@ -13,7 +13,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int kStage = 64 * 1024;   // A 32 KB | B 32 KB
 #ifndef ABL
-#define ABL 0      // bit 0: no LDS-DMA fill in the loop, bit 1: fragments read once (no LDS reads in the loop), bit 2: one fill pair per 4 MFMAs
+#define ABL 0      // bit 0: no LDS-DMA fill in the loop, bit 1: fragments read once (no LDS reads in the loop), bit 2: one fill pair per 4 MFMAs,
+                   // bit 3: fill through registers (global_load_dwordx4 at the top of the K step, ds_write_b128 at its end) instead of LDS-DMA
 #endif
 
 __global__ __launch_bounds__(256, 1) void gemm4w(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M,
@@ -60,12 +61,31 @@ __global__ __launch_bounds__(256, 1) void gemm4w(const _Float16* __restrict__ A,
   __builtin_amdgcn_s_barrier();
   unsigned long long t0 = 0;
   if (stamps && tid == 0) t0 = __builtin_readcyclecounter();
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  // register-staged fill: lane loads chunk (lane & 7) of row wave*64 + i*8 + lane/8 and writes it to the swizzled slot
+  int g_off[8], l_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wave * 64 + i * 8 + (lane >> 3), chunk = lane & 7;
+    g_off[i] = (row * K + chunk * 8) * 2;
+    l_off[i] = row * 128 + ((chunk ^ (row & 7)) << 4);
+  }
+  const char* Ab = reinterpret_cast<const char*>(A) + (size_t)m0 * K * 2;
+  const char* Wb = reinterpret_cast<const char*>(W) + (size_t)n0 * K * 2;
   for (int kt = 0; kt < KT; ++kt) {
     const char* st = lds + (kt & 1) * kStage;
     const bool more = kt + 1 < KT;
+    u4 ra4[8], rb4[8];
+    if ((ABL & 8) && more) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ra4[i] = *reinterpret_cast<const u4*>(Ab + g_off[i] + (kt + 1) * 128);
+        rb4[i] = *reinterpret_cast<const u4*>(Wb + g_off[i] + (kt + 1) * 128);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (more && !(ABL & 1) && !(ABL & 4)) fill((kt + 1) & 1, kt + 1, kk * 2, kk * 2 + 2);   // 4 of the 16 DMA instructions of the next step per k-slice
+      if (more && !(ABL & 1) && !(ABL & 4) && !(ABL & 8)) fill((kt + 1) & 1, kt + 1, kk * 2, kk * 2 + 2);   // 4 of the 16 DMA instructions of the next step per k-slice
       h8 fa[4], fb[4];
       const int ko = (ABL & 2) ? 0 : ((2 * kk + half) ^ sw) * 16;
 #pragma unroll
@@ -75,12 +95,20 @@ __global__ __launch_bounds__(256, 1) void gemm4w(const _Float16* __restrict__ A,
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (more && !(ABL & 1) && (ABL & 4) && (i & 1) == 0) fill((kt + 1) & 1, kt + 1, kk * 2 + (i >> 1), kk * 2 + (i >> 1) + 1);
+        if (more && !(ABL & 1) && (ABL & 4) && !(ABL & 8) && (i & 1) == 0) fill((kt + 1) & 1, kt + 1, kk * 2 + (i >> 1), kk * 2 + (i >> 1) + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((ABL & 8) && more) {
+      char* dn = lds + ((kt + 1) & 1) * kStage;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        *reinterpret_cast<u4*>(dn + l_off[i]) = ra4[i];
+        *reinterpret_cast<u4*>(dn + 32768 + l_off[i]) = rb4[i];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   if (stamps && tid == 0) {
