@@ -244,7 +244,7 @@ class BertEngine:
         if key == self._key:
             return self._model
         lib = _lib.load()
-        some = p["classifier.weight"]
+        some = p["bert.embeddings.word_embeddings.weight"]
         _need_gpu(*p.values())
         m = self._dims()
         nblob, nf = lib.capamd_bert_blob_bytes(ctypes.byref(m)), lib.capamd_bert_layer_f32_floats(ctypes.byref(m))
@@ -264,7 +264,9 @@ class BertEngine:
                             ("type_emb", "bert.embeddings.token_type_embeddings.weight"), ("emb_ln_g", "bert.embeddings.LayerNorm.weight"),
                             ("emb_ln_b", "bert.embeddings.LayerNorm.bias"), ("pooler_w", "bert.pooler.dense.weight"),
                             ("pooler_b", "bert.pooler.dense.bias"), ("cls_w", "classifier.weight"), ("cls_b", "classifier.bias")):
-            setattr(m, field, keep[name].data_ptr())
+            # (pooler / classifier are absent for encoders that are only tapped - CEDR-KNRM on an ELECTRA body; capamd_bert_maxp_forward
+            # refuses a model without them)
+            setattr(m, field, keep[name].data_ptr() if name in keep else None)
         m.blob, m.layer_f32 = blob.data_ptr(), lf32.data_ptr()
         self._blob, self._lf32, self._keep, self._model, self._key = blob, lf32, keep, m, key
         return m

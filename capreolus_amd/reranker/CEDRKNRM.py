@@ -3,8 +3,8 @@ ptBERTMaxP plus the kernels in capreolus_amd/csrc/cedr_tap.cuh / cedr.hip throug
 
 The module holds the parameters under the reference's state_dict names (``bert.embeddings.*``, ``bert.encoder.layer.N.*``,
 ``bert.pooler.dense.*``, ``kernels.kernels.{k}.mu|sigma``, ``combine.{0,1}.weight|bias``, ``one``, ``zero``) so checkpoints
-interchange.  BERT-architecture encoders only (bert-base-uncased, Capreolus/bert-base-msmarco, or an explicit geometry); the
-ELECTRA checkpoints of the reference's default raise.
+interchange.  BERT-architecture encoders: BertModel checkpoints and ElectraModel checkpoints whose embedding size equals the
+hidden size (electra-base: the same encoder without a pooler), or an explicit geometry.
 """
 import torch
 from torch import nn
@@ -23,8 +23,6 @@ class CEDRKNRM_Class(nn.Module):
         pre = config["pretrained"]
         if isinstance(pre, dict):            # explicit geometry, weights loaded later with load_state_dict
             self.bert = bert_body(**pre)
-        elif isinstance(pre, str) and "electra" in pre:
-            raise NotImplementedError(f"{pre}: only BERT-architecture encoders are scored by the MI355X engine")
         else:
             self.bert = self._from_hf(pre, config["hidden_dropout_prob"])
         self.hidden_size = self.bert.embeddings.word_embeddings.weight.shape[1]
@@ -60,16 +58,17 @@ class CEDRKNRM_Class(nn.Module):
     @staticmethod
     def _from_hf(name, hidden_dropout_prob):
         """Reads a local/cached HF checkpoint (no network here) and copies its tensors into the container."""
-        from transformers import BertModel
+        from transformers import AutoModel
 
-        if name == "bert-base-msmarco":
-            name = "Capreolus/bert-base-msmarco"
-        hf = BertModel.from_pretrained(name, hidden_dropout_prob=hidden_dropout_prob)
+        name = {"bert-base-msmarco": "Capreolus/bert-base-msmarco", "electra-base-msmarco": "Capreolus/electra-base-msmarco",
+                "electra-base": "google/electra-base-discriminator"}.get(name, name)      # the reference's aliases (CEDRKNRM.py:20-35)
+        hf = AutoModel.from_pretrained(name, hidden_dropout_prob=hidden_dropout_prob)
         c = hf.config
-        if c.model_type != "bert" or c.hidden_act != "gelu":
+        # BERT, or ELECTRA whose embedding size equals its hidden size (no embeddings_project): the same encoder arithmetic
+        if c.model_type not in ("bert", "electra") or c.hidden_act != "gelu" or getattr(c, "embedding_size", c.hidden_size) != c.hidden_size:
             raise NotImplementedError(f"{name}: unsupported architecture {c.model_type}/{c.hidden_act}")
         body = bert_body(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size, c.vocab_size,
-                         c.max_position_embeddings, c.type_vocab_size)
+                         c.max_position_embeddings, c.type_vocab_size, pooler=c.model_type == "bert")
         missing = body.load_state_dict(hf.state_dict(), strict=False)
         if missing.missing_keys:
             raise RuntimeError(f"checkpoint lacks {missing.missing_keys}")
@@ -77,10 +76,6 @@ class CEDRKNRM_Class(nn.Module):
 
     def _params(self):
         p = {"bert." + k: v for k, v in self.bert.state_dict(keep_vars=True).items()}
-        dev = p["bert.embeddings.word_embeddings.weight"].device
-        if self._dummy is None or self._dummy[0].device != dev:   # the encoder engine's model record has classifier slots; CEDR never runs them
-            self._dummy = (torch.zeros((2, self.hidden_size), device=dev), torch.zeros(2, device=dev))
-        p["classifier.weight"], p["classifier.bias"] = self._dummy
         return p
 
     def forward(self, bert_input, bert_mask, bert_segments):

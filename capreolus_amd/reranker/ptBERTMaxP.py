@@ -32,14 +32,17 @@ def _encoder_layer(H, F):
     )
 
 
-def bert_body(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2):
-    """Parameter tree of transformers.BertModel (state_dict names as HF)."""
-    body = _Box(
+def bert_body(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, type_vocab=2, pooler=True):
+    """Parameter tree of transformers.BertModel (state_dict names as HF); pooler=False: of transformers.ElectraModel, which is the same
+    encoder without a pooler (for checkpoints whose embedding size equals the hidden size)."""
+    mods = dict(
         embeddings=_Box(word_embeddings=nn.Embedding(vocab, hidden, padding_idx=0), position_embeddings=nn.Embedding(max_pos, hidden),
                         token_type_embeddings=nn.Embedding(type_vocab, hidden), LayerNorm=nn.LayerNorm(hidden, eps=1e-12)),
         encoder=_Box(layer=nn.ModuleList([_encoder_layer(hidden, ffn) for _ in range(layers)])),
-        pooler=_Box(dense=nn.Linear(hidden, hidden)),
     )
+    if pooler:
+        mods["pooler"] = _Box(dense=nn.Linear(hidden, hidden))
+    body = _Box(**mods)
     body.num_attention_heads = heads
     return body
 

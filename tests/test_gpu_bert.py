@@ -389,3 +389,27 @@ def test_cedr_length_buckets_give_the_same_features(name):
     assert torch.equal(f1[:, :int(c["dims"][0])], f0[:, :int(c["dims"][0])])                    # [CLS] rows: bit-identical
     assert (f1 - f0).abs().max().item() <= 1e-6 * f0.abs().max().item() + 1e-7, (f1 - f0).abs().max().item()
     assert (s1 - s0).abs().max().item() <= 1e-5 * s0.abs().max().item()
+
+
+def test_cedr_knrm_on_an_electra_shaped_body():
+    """ElectraModel = the same encoder without a pooler (CEDRKNRM.py:20-27 loads one by default): scores are those of the BERT body."""
+    from capreolus_amd.reranker import CEDRKNRM
+    from tests.helpers import CEDR_MUS, load_cedr_case
+
+    c, w, head, mus, sigmas = load_cedr_case("mini")
+    hidden, layers, heads, ffn, vocab, max_pos = (int(x) for x in c["dims"])
+    P, S = c["pos_bert_input"].shape[1:]
+    cfg = {"pretrained": dict(hidden=hidden, layers=layers, heads=heads, ffn=ffn, vocab=vocab, max_pos=max_pos, pooler=False), "mus": CEDR_MUS,
+           "simmat_layers": [int(x) for x in c["simmat_layers"]], "combine_hidden": int(c["combine_hidden"]), "cls": c["cls_mode"]}
+    r = CEDRKNRM(cfg, SimpleNamespace(config={"numpassages": P, "maxseqlen": S, "maxqlen": int(c["maxqlen"])}))
+    m = r.build_model()
+    sd = {k: v for k, v in w.items() if "pooler" not in k and not k.startswith("classifier")}
+    sd.update(head)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m.to(DEV).eval()
+    d = {k: torch.from_numpy(c[k].astype(np.int64)).to(DEV) for k in ("pos_bert_input", "pos_mask", "pos_seg")}
+    with torch.no_grad():
+        got = r.test(d).cpu().numpy()
+        want = _cedr_model(c, w, head, "fp16").test(d).cpu().numpy()
+    assert np.array_equal(got, want)

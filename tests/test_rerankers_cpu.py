@@ -75,7 +75,8 @@ def test_cedrknrm_mirror_names():
     x = torch.zeros((1, 2, 32), dtype=torch.int64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         r.test({"pos_bert_input": x, "pos_mask": x, "pos_seg": x})
-    with pytest.raises(NotImplementedError):
-        rr.CEDRKNRM(dict(cfg, pretrained="electra-base"), r.extractor).build_model()
+    # an ELECTRA-shaped body (the reference's default checkpoint family): the same encoder without a pooler
+    e = rr.CEDRKNRM(dict(cfg, pretrained=dict(dims, pooler=False)), r.extractor).build_model()
+    assert not any("pooler" in k for k in e.state_dict()) and "bert.encoder.layer.1.output.dense.bias" in e.state_dict()
     with pytest.raises(AssertionError):
         rr.CEDRKNRM(dict(cfg, simmat_layers=[-1], cls=None), r.extractor).build_model()
