@@ -9,9 +9,9 @@
 //               document's FIRST passage, handed in per passage so that passages can be regrouped by length)
 // The per-passage sums are added over a document's passages, clamped, logged and summed over the query by cedr.hip.
 //
-// One workgroup per passage: row norms (one wave per row), the A x S dot products on v_mfma_f32_32x32x16 straight from the
-// 16-bit hidden state in global memory (operands are the stored activations: one product, fp32 accumulate), similarities into
-// LDS, then one thread per (query row, slice of columns) for the K exponentials.
+// One workgroup per passage: the A x S dot products on v_mfma_f32_32x32x16 straight from the 16-bit hidden state in global
+// memory (operands are the stored activations: one product, fp32 accumulate; the row norms are accumulated from the same operand
+// loads), similarities into LDS, then one thread per (query row, slice of columns) for the K exponentials.
 #pragma once
 #include "bert_gemm.cuh"
 
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x,
                                                         float* __restrict__ pk) {
   typedef typename Half<T>::x8 x8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* rn = reinterpret_cast<float*>(smem_raw);                 // [S] row norms
-  float* sims = rn + S;                                           // [A][S]
+  float* rn = reinterpret_cast<float*>(smem_raw);                 // [4][32] query-row norms, one copy per wave (+ padding up to S floats)
+  float* sims = rn + (S < 4 * kCedrMaxA ? 4 * kCedrMaxA : S);     // [A][S]
   float* kc = sims + A * S;                                       // [12] (mu, coefficient) pairs
   float* qm = kc + 2 * (kCedrMaxK + 1);                           // [A] this passage's query mask
   float* qm0 = qm + kCedrMaxA;                                    // [A] the query mask of the document's first passage
@@ -64,45 +64,69 @@ __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x,
     kc[2 * tid] = m;
     kc[2 * tid + 1] = tid < K ? (-0.5f * 1.4426950408889634f) / (s * s) : 0.f;
   }
-  // row norms
-  for (int i = wave; i < S; i += 4) {
-    const unsigned* row = reinterpret_cast<const unsigned*>(xp + (int64_t)i * H);
-    float ss = 0.f;
-    for (int j = lane; j < H / 2; j += 64) {
-      const unsigned u = row[j];
-      T lo, hi;
-      __builtin_memcpy(&lo, &u, 2);
-      __builtin_memcpy(&hi, reinterpret_cast<const char*>(&u) + 2, 2);
-      const float a = (float)lo, b = (float)hi;
-      ss = __builtin_fmaf(a, a, ss);
-      ss = __builtin_fmaf(b, b, ss);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (lane == 0) rn[i] = __builtin_sqrtf(ss);
-  }
   __syncthreads();
-  // dot products: query rows (sequence positions 1 + m) x document columns (sequence positions 32 t + n)
+  // dot products: query rows (sequence positions 1 + m) x document columns (sequence positions 32 t + n).  The squared row norms
+  // come from the matrix pipe too: the diagonal of B B^T (and of A A^T, once per wave) accumulated next to A B^T from the same
+  // operand registers - no second pass over the hidden state, no VALU work in the K loop.
   {
     const int m = lane & 31, half = lane >> 5;
-    const bool arow = m < A && 1 + m < S;
-    const T* ap = xp + (int64_t)(arow ? 1 + m : 0) * H + 8 * half;
+    const T* ap = xp + (int64_t)((m < A && 1 + m < S) ? 1 + m : 0) * H + 8 * half;   // rows beyond A: a valid row, output never read
+    float* qn = rn + wave * kCedrMaxA;                                                // this wave's copy of the query-row norms
+    // accumulator register of this lane that holds the diagonal element (n, n) of a 32x32 product, if its half-wave holds it at all
+    const int di = ((m >> 3) << 2) | (m & 3);
+    const bool dmine = half == ((m >> 2) & 1);
+    auto diagonal = [&](const f32x16& g) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v = (dmine && i == di) ? g[i] : v;
+      return v + __shfl_xor(v, 32, 64);
+    };
+    bool first = true;
     for (int t = wave; t * 32 < S; t += 4) {
       const int pos = t * 32 + m;
-      const bool brow = pos < S;
-      const T* bp = xp + (int64_t)(brow ? pos : 0) * H + 8 * half;
-      f32x16 c = {0};
-      const x8 zero = {0};
-      for (int kk = 0; kk < H; kk += 16) {
-        const x8 av = *reinterpret_cast<const x8*>(ap + kk), bv = *reinterpret_cast<const x8*>(bp + kk);
-        c = Half<T>::mfma(arow ? av : zero, brow ? bv : zero, c);
+      const T* bp = xp + (int64_t)(pos < S ? pos : 0) * H + 8 * half;
+      f32x16 c = {0}, gb = {0}, ga = {0};
+      if (first) {
+        for (int k0 = 0; k0 < H; k0 += 64) {          // H is a multiple of 64: four K steps per trip, their eight operand loads first
+          x8 av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = *reinterpret_cast<const x8*>(ap + k0 + 16 * u);
+            bv[u] = *reinterpret_cast<const x8*>(bp + k0 + 16 * u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            c = Half<T>::mfma(av[u], bv[u], c);
+            gb = Half<T>::mfma(bv[u], bv[u], gb);
+            ga = Half<T>::mfma(av[u], av[u], ga);
+          }
+        }
+        const float na = diagonal(ga);
+        if (lane < 32) qn[lane] = __builtin_sqrtf(na);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        first = false;
+      } else {
+        for (int k0 = 0; k0 < H; k0 += 64) {
+          x8 av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = *reinterpret_cast<const x8*>(ap + k0 + 16 * u);
+            bv[u] = *reinterpret_cast<const x8*>(bp + k0 + 16 * u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            c = Half<T>::mfma(av[u], bv[u], c);
+            gb = Half<T>::mfma(bv[u], bv[u], gb);
+          }
+        }
       }
-      if (brow) {
-        const float bden = rn[pos] + 1e-9f, bmask = dm[pos];
+      const float nb = diagonal(gb);
+      if (pos < S) {
+        const float bden = __builtin_sqrtf(nb) + 1e-9f, bmask = dm[pos];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = (i >> 2) * 8 + half * 4 + (i & 3);
-          if (r < A) sims[r * S + pos] = (1 + r < S) ? c[i] / ((rn[1 + r] + 1e-9f) * bden) * qm[r] * bmask : 0.f;
+          if (r < A) sims[r * S + pos] = (1 + r < S) ? c[i] / ((qn[r] + 1e-9f) * bden) * qm[r] * bmask : 0.f;
         }
       }
     }
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(256) void cedr_pool_kernel(const T* __restrict__ x,
 }
 
 inline size_t cedr_pool_smem(int S, int A) {
-  return (size_t)(S + A * S + 2 * (kCedrMaxK + 1) + 2 * kCedrMaxA + S + 256 * (kCedrMaxK + 1)) * sizeof(float);
+  return (size_t)((S < 4 * kCedrMaxA ? 4 * kCedrMaxA : S) + A * S + 2 * (kCedrMaxK + 1) + 2 * kCedrMaxA + S + 256 * (kCedrMaxK + 1)) * sizeof(float);
 }
 
 template <typename T>
