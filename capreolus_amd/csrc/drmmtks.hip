@@ -36,8 +36,15 @@ struct TksArgs {
   float* feat;           // training-step mode (capamd_drmmtks_features): [B][Q][topk] sorted top-k similarities instead of scores
 };
 
+#ifndef CAPAMD_TKS_U
+#define CAPAMD_TKS_U 1
+#endif
+#ifndef CAPAMD_TKS_WAVES
+#define CAPAMD_TKS_WAVES 6   // measured per 64,000 pairs: 5 -> 2.20 ms, 6 -> 2.12 ms; two rows in flight per group (CAPAMD_TKS_U 2) spill and lose 2-5x
+#endif
+
 template <int NV>
-__global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a) {
+__global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_kernel(TksArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* tok = reinterpret_cast<int*>(smem_raw);
   const int tok_cap = (a.L + 3) & ~3;
@@ -95,19 +102,28 @@ __global__ __launch_bounds__(kThreads, 5) void drmmtks_forward_kernel(TksArgs a)
     float top[kMaxTopK];
 #pragma unroll
     for (int i = 0; i < kMaxTopK; ++i) top[i] = -INFINITY;
-    for (int t0 = g; t0 < n_real; t0 += kGroupsPerWG) {
-      RowRegs<NV> d[1];
-      load_row<NV>(a.packed, tok[t0], lane16, d[0]);
-      float x[1];
+    for (int t0 = g; t0 < n_real; t0 += CAPAMD_TKS_U * kGroupsPerWG) {   // CAPAMD_TKS_U rows in flight per 16-lane group
+      RowRegs<NV> d[CAPAMD_TKS_U];
+      bool has[CAPAMD_TKS_U];
+#pragma unroll
+      for (int u = 0; u < CAPAMD_TKS_U; ++u) {
+        const int tu = t0 + u * kGroupsPerWG;
+        has[u] = tu < n_real;
+        load_row<NV>(a.packed, has[u] ? tok[tu] : 0, lane16, d[u]);
+      }
+      float x[CAPAMD_TKS_U];
       int qoff = 0;
       asm volatile("" : "+v"(qoff));
-      rows_sim_my<NV, 1, true>(d, qp, qlds + qoff, lane16, x);
-      float v = x[0];
+      rows_sim_my<NV, CAPAMD_TKS_U, true>(d, qp, qlds + qoff, lane16, x);
 #pragma unroll
-      for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
-        const float hi = fmaxf(top[i], v);
-        v = fminf(top[i], v);
-        top[i] = hi;
+      for (int u = 0; u < CAPAMD_TKS_U; ++u) {
+        float v = has[u] ? x[u] : -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
+          const float hi = fmaxf(top[i], v);
+          v = fminf(top[i], v);
+          top[i] = hi;
+        }
       }
     }
     if (lane16 < kQT) {
