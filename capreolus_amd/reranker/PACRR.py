@@ -41,7 +41,7 @@ class PACRR_class(nn.Module):
 
     def forward(self, doc, query, query_idf):
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("the PACRR training step is not part of the MI355X engine; score under model.eval()")
+            return self._forward_train(doc, query, query_idf)
         w = self.embedding.weight
         conv_w = torch.cat([m.conv.weight.detach().reshape(-1) for m in self.ngrams]).contiguous()
         conv_b = torch.cat([m.conv.bias.detach().reshape(-1) for m in self.ngrams]).contiguous()
@@ -51,6 +51,28 @@ class PACRR_class(nn.Module):
                                    self.linear1.bias.detach(), self.linear2.weight.detach().contiguous(), self.linear2.bias.detach(),
                                    self.linear3.weight.detach().contiguous().view(-1), self.linear3.bias.detach())
         return out.view(-1, 1)
+
+
+    def _forward_train(self, doc, query, query_idf):
+        """Training step (reference trainer/pytorch.py:96-99 -> PACRR.score): the part that touches the embedding table - the
+        [B, Q, L] similarity matrix - is the HIP kernel (capamd_similarity_matrix; the table is frozen, no gradient flows
+        through it); the trainable part (PACRR.py:68-78: zero padding, the n-gram Conv2d, ReLU, max over filters, k-max over
+        the document; :46-54: idf softmax, combine) runs under autograd on that matrix, at training batch sizes."""
+        import torch.nn.functional as F
+
+        w = self.embedding.weight
+        sim = engine.similarity_matrix(query, doc, self._packed.get(w), w.shape[0], w.shape[1])
+        B, Q, L = sim.shape
+        x = sim.view(B, 1, Q, L)
+        feats = []
+        for m in self.ngrams:
+            xp = F.pad(x, (0, m.shape - 1, 0, m.shape - 1)) if m.shape != 1 else x
+            top_filters = F.relu(m.conv(xp)).max(dim=1)[0]
+            feats.append(top_filters.topk(m.k, dim=2)[0])
+        if self.p["idf"]:
+            feats.append(F.softmax(query_idf.float(), dim=1).view(B, Q, 1))
+        scores = torch.cat(feats, dim=2).reshape(B, -1)
+        return self.combine(scores)
 
 
 class PACRR(Reranker):

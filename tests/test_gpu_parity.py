@@ -924,3 +924,51 @@ def test_drmmtks_training_step_matches_autograd():
                       ("ffw.0.bias", m.ffw[0].bias)):
         g, gr = mod.grad.cpu(), t[name].grad
         assert (g - gr).abs().max() <= 2e-3 * (float(gr.abs().max()) + 1e-8), name
+
+
+def test_pacrr_training_step_matches_autograd():
+    """Row N3 for PACRR: in training mode the similarity matrix comes from the HIP kernel and the convolutions / k-max / combine run
+    under autograd; in eval mode everything is the fused kernel.  The two forwards agree, and the loss and gradients equal the same ATen
+    ops applied to the oracle's similarity matrix on the host."""
+    import torch.nn.functional as F
+
+    c = load_case("pacrr", "default")
+    r = _pacrr_reranker(c)
+    m = r.model
+    b = _batch(c)
+    with torch.no_grad():
+        ev = r.test(b)
+    m.train()
+    negdoc = c["posdoc"][np.roll(np.arange(len(c["posdoc"])), 1)]
+    s = r.score({**b, "negdoc": _t(negdoc)})
+    assert (s[0].detach() - ev).abs().max() <= 2e-5 * ev.abs().max()          # same scores as the fused inference kernel
+    loss = torch.clamp(1.0 - (s[0] - s[1]), min=0).mean() + 0.01 * s[0].sum()
+    loss.backward()
+    t = {k[3:]: torch.as_tensor(v).clone().requires_grad_(True) for k, v in c.items() if k.startswith("sd.") and not k.startswith("sd.combine")}
+    packed = oracle.pack(c["emb"])
+    lo, hi, kmax = int(c["cfg.mingram"]), int(c["cfg.maxgram"]), int(c["cfg.kmax"])
+    act = {"relu": torch.relu, "tanh": torch.tanh, "none": lambda v: v}[str(c["nonlinearity"])]
+
+    def host_scores(doc):
+        sm, e = oracle.simmat(c["query"], doc, packed, int(c["D"]))
+        assert e == 0
+        x = torch.as_tensor(sm).unsqueeze(1)
+        feats = []
+        for i, g in enumerate(range(lo, hi + 1)):
+            conv = F.conv2d(F.pad(x, (0, g - 1, 0, g - 1)), t[f"ngrams.{i}.conv.weight"], t[f"ngrams.{i}.conv.bias"])
+            feats.append(torch.relu(conv).max(dim=1)[0].topk(kmax, dim=2)[0])
+        if bool(int(c["cfg.idf"])):
+            feats.append(torch.softmax(torch.as_tensor(c["query_idf"]), dim=1).unsqueeze(2))
+        h = torch.cat(feats, dim=2).reshape(x.shape[0], -1)
+        h = act(h @ t["linear1.weight"].t() + t["linear1.bias"])
+        h = act(h @ t["linear2.weight"].t() + t["linear2.bias"])
+        return (h @ t["linear3.weight"].t() + t["linear3.bias"]).view(-1)
+
+    ps, ns = host_scores(c["posdoc"]), host_scores(negdoc)
+    ref = torch.clamp(1.0 - (ps - ns), min=0).mean() + 0.01 * ps.sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+    for name, par in (("ngrams.0.conv.weight", m.ngrams[0].conv.weight), ("ngrams.2.conv.weight", m.ngrams[2].conv.weight),
+                      ("ngrams.1.conv.bias", m.ngrams[1].conv.bias), ("linear1.weight", m.linear1.weight), ("linear3.weight", m.linear3.weight)):
+        g, gr = par.grad.cpu(), t[name].grad
+        assert (g - gr).abs().max() <= 2e-3 * (float(gr.abs().max()) + 1e-8), name

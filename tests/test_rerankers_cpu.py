@@ -38,7 +38,7 @@ def test_pacrr_mirror_names_and_no_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         r.test(_batch(c))
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # training mode: the similarity matrix is still the HIP kernel's
         with torch.enable_grad():
             r.test(_batch(c))
     with pytest.raises(ValueError):
