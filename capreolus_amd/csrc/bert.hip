@@ -544,7 +544,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
 
   for (int64_t p0 = 0; p0 < NP && e == hipSuccess; p0 += mb) {
     const int64_t np = (NP - p0 < mb) ? NP - p0 : mb;
-    const int64_t M = np * S;
+    // The GEMM kernels schedule whole row tiles only: a ragged micro-batch (np * S not a multiple of 256 - an odd passage count
+    // at S = 32, 96, 160, 224, ...) runs on np_pad passages; the extra rows are zero embeddings / zero context (rows are
+    // independent in every GEMM and LayerNorm, attention and the head run on the np real passages), so nothing they hold
+    // reaches a real row.  The workspace is sized for whole tiles (capamd_bert_workspace_bytes).
+    const int64_t tq = tile_passages(S), np_pad = (np + tq - 1) / tq * tq;
+    const int64_t M = np_pad * S, M_real = np * S;
     const int64_t* ids_mb = ids + p0 * S;
     const int64_t* mask_mb = mask + p0 * S;
     const int64_t* seg_mb = seg + p0 * S;
@@ -552,8 +557,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     // (a CEDR-KNRM call reads every layer's normalised output: it runs the path that materialises them)
     const bool fused = !tap && fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
                        pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
-    hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M, H, (T*)w.xb, status, fused ? 1 : 0);
+    hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M_real + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M_real, H, (T*)w.xb, status, fused ? 1 : 0);
+    if (M > M_real) {   // (S % 32 == 0: the pad rows are whole 32-row groups, contiguous in the row-major and the chunk-major layout alike)
+      (void)hipMemsetAsync(w.xb + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
+      (void)hipMemsetAsync(w.ctx + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
+    }
     if (tap) cedr_tap_layer<T>(*tap, 0, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s);
     if (fused) {
       // Activation stream: xb and pre hold UN-normalised pre-LayerNorm sums in the chunk-major layout, (mu, rstd) of

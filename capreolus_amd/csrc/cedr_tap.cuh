@@ -23,7 +23,7 @@ constexpr int kCedrMaxTpr = 32;
 
 struct CedrTap {          // what a CEDR-KNRM call asks of encode_passages
   int A, K, n_sel;
-  const int* layers;      // host array [n_sel]: hidden states to pool (0 = embedding output .. L), ascending
+  const int* layers;      // host array [n_sel]: hidden states to pool (0 = embedding output .. L), in the caller's order (slot i of pk)
   const float* mu;        // device [K]
   const float* sigma;     // device [K]
   const float* qmask0;    // device [NP][A]: the query mask of the first passage of each passage's document (CEDRKNRM.py:123)

@@ -371,14 +371,12 @@ class BertEngine:
                 side = self._streams[Sb] = torch.cuda.Stream(device=ids.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                q = 256 // math.gcd(Sb, 256)            # whole 256-row tiles: pad the bucket with copies of its last passage
-                pad = (-n) % q
-                sel_p = torch.cat([sel, sel[-1:].expand(pad)]) if pad else sel
-                bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
-                o = torch.empty(n + pad, dtype=torch.float32, device=ids.device)
-                self._encode(bi, bm, bs, n + pad, 1, Sb, "first", o, None, False, ws_key=Sb)
-                plog.index_copy_(0, sel, o[:n])
-                for t in (bi, bm, bs, o, sel_p):
+                # (a ragged bucket is padded to whole 256-row GEMM tiles inside capamd_bert_maxp_forward)
+                bi, bm, bs = (t.index_select(0, sel)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
+                o = torch.empty(n, dtype=torch.float32, device=ids.device)
+                self._encode(bi, bm, bs, n, 1, Sb, "first", o, None, False, ws_key=Sb)
+                plog.index_copy_(0, sel, o)
+                for t in (bi, bm, bs, o, sel):
                     t.record_stream(side)
             used.append(side)
         for side in used:
@@ -646,7 +644,9 @@ class CedrEngine:
             return out
         m = self.be.model()
         lib = _lib.load()
-        layers = sorted(int(x) for x in simmat_layers if int(x) >= 0)      # -1 alone = no similarity matrices (CEDRKNRM.py:48-52)
+        # in the configured order: the reference concatenates the per-layer features as listed (CEDRKNRM.py:166-168), so the
+        # columns of `combine` follow it; -1 alone = no similarity matrices (CEDRKNRM.py:48-52)
+        layers = [int(x) for x in simmat_layers if int(x) >= 0]
         n_sel, K, A, H, NP = len(layers), mu.numel(), maxqlen + 1, m.hidden, B * P
         if A + 1 > S:
             raise ValueError("maxqlen + 2 exceeds the passage length")
@@ -678,17 +678,15 @@ class CedrEngine:
                     side = self._streams[Sb] = torch.cuda.Stream(device=dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    q = 256 // math.gcd(Sb, 256)            # whole 256-row tiles: pad the bucket with copies of its last passage
-                    pad = (-n) % q
-                    sel_p = torch.cat([sel, sel[-1:].expand(pad)]) if pad else sel
-                    bi, bm, bs = (t.index_select(0, sel_p)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
-                    bq = qm0.index_select(0, sel_p)
-                    pk_b = torch.empty((max(1, n_sel), n + pad, K * A), dtype=torch.float32, device=dev)
-                    cls_b = torch.empty((n + pad, H), dtype=torch.float32, device=dev)
+                    # (a ragged bucket is padded to whole GEMM tiles inside capamd_cedr_passage_features)
+                    bi, bm, bs = (t.index_select(0, sel)[:, :Sb].contiguous() for t in (fids, fmask, fseg))
+                    bq = qm0.index_select(0, sel)
+                    pk_b = torch.empty((max(1, n_sel), n, K * A), dtype=torch.float32, device=dev)
+                    cls_b = torch.empty((n, H), dtype=torch.float32, device=dev)
                     self._passages(bi, bm, bs, Sb, bq, maxqlen, layers, mu, sigma, pk_b, cls_b, Sb)
-                    pk.index_copy_(1, sel, pk_b[:, :n])
-                    cls.index_copy_(0, sel, cls_b[:n])
-                    for t in (bi, bm, bs, bq, pk_b, cls_b, sel_p):
+                    pk.index_copy_(1, sel, pk_b)
+                    cls.index_copy_(0, sel, cls_b)
+                    for t in (bi, bm, bs, bq, pk_b, cls_b, sel):
                         t.record_stream(side)
                 used.append(side)
             for side in used:

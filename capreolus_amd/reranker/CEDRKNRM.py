@@ -75,7 +75,7 @@ class CEDRKNRM_Class(nn.Module):
         return body
 
     def _params(self):
-        p = {"bert." + k: v for k, v in self.bert.state_dict(keep_vars=True).items()}
+        p = {"bert." + k: v for k, v in self.bert.state_dict(keep_vars=True).items() if not k.endswith("position_ids")}
         return p
 
     def forward(self, bert_input, bert_mask, bert_segments):
@@ -104,7 +104,7 @@ class CEDRKNRM(Reranker):
     The first eight keys are the reference's options; microbatch / compute_dtype / skip_padding belong to this engine (as in ptBERTMaxP)."""
 
     module_name = "CEDRKNRM"
-    config_spec = {"pretrained": "bert-base-uncased", "mus": [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9], "sigma": 0.1,
+    config_spec = {"pretrained": "electra-base", "mus": [-0.9, -0.7, -0.5, -0.3, -0.1, 0.1, 0.3, 0.5, 0.7, 0.9], "sigma": 0.1,
                    "gradkernels": True, "hidden_dropout_prob": 0.1, "simmat_layers": list(range(13)), "combine_hidden": 1024, "cls": "avg",
                    "microbatch": 256, "compute_dtype": "fp16", "skip_padding": True}
 

@@ -66,7 +66,8 @@ class Reranker:
         weights_fn = os.fspath(weights_fn)
         with open(weights_fn, "rb") as f:
             d = pickle.load(f)
-        missing = set(self._saved_keys(self.model.state_dict())) - set(d)
+        # (position_ids: a persistent buffer only in the transformers the reference pins; newer checkpoints do not carry it)
+        missing = {k for k in set(self._saved_keys(self.model.state_dict())) - set(d) if not k.endswith("position_ids")}
         if missing:
             raise RuntimeError("loading state_dict with keys that do not match current model: %s" % missing)
         self.model.load_state_dict(d, strict=False)

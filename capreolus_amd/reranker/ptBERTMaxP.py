@@ -23,6 +23,17 @@ class _Box(nn.Module):
             setattr(box, k, v)
 
 
+class _Embeddings(_Box):
+    """transformers 4.9 (the reference's pin) keeps `position_ids` as a persistent buffer: it is in the reference's checkpoints and
+    the reference's load_weights key check (reranker/__init__.py:44-50) requires it, so checkpoints written here carry it; newer
+    transformers do not save it, so a state_dict without it still loads (strict or not)."""
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if prefix + "position_ids" in missing_keys:
+            missing_keys.remove(prefix + "position_ids")
+
+
 def _encoder_layer(H, F):
     return _Box(
         attention=_Box(self=_Box(query=nn.Linear(H, H), key=nn.Linear(H, H), value=nn.Linear(H, H)),
@@ -36,10 +47,11 @@ def bert_body(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=51
     """Parameter tree of transformers.BertModel (state_dict names as HF); pooler=False: of transformers.ElectraModel, which is the same
     encoder without a pooler (for checkpoints whose embedding size equals the hidden size)."""
     mods = dict(
-        embeddings=_Box(word_embeddings=nn.Embedding(vocab, hidden, padding_idx=0), position_embeddings=nn.Embedding(max_pos, hidden),
+        embeddings=_Embeddings(word_embeddings=nn.Embedding(vocab, hidden, padding_idx=0), position_embeddings=nn.Embedding(max_pos, hidden),
                         token_type_embeddings=nn.Embedding(type_vocab, hidden), LayerNorm=nn.LayerNorm(hidden, eps=1e-12)),
         encoder=_Box(layer=nn.ModuleList([_encoder_layer(hidden, ffn) for _ in range(layers)])),
     )
+    mods["embeddings"].register_buffer("position_ids", torch.arange(max_pos).expand((1, -1)).clone())
     if pooler:
         mods["pooler"] = _Box(dense=nn.Linear(hidden, hidden))
     body = _Box(**mods)
@@ -88,7 +100,7 @@ class PTBERTMaxP_Class(nn.Module):
         return box
 
     def _params(self):
-        return {k: v for k, v in self.bert.state_dict(keep_vars=True).items()}
+        return {k: v for k, v in self.bert.state_dict(keep_vars=True).items() if not k.endswith("position_ids")}
 
     def forward(self, doc_input, doc_mask, doc_seg):
         if self.training:

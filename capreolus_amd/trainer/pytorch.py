@@ -78,6 +78,9 @@ class PytorchTrainer:
         "fastforward": False, "validatefreq": 1, "multithread": False, "boardname": "default", "warmupiters": 0,
         "decay": 0.0, "decayiters": 3, "decaytype": None, "amp": None, "seed": 123,
     }
+    # amp = "pred" / "both" at prediction time (reference :323-326, 343: autocast around `reranker.test`) selects nothing here: the
+    # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
+    # those of the non-autocast reference within the parity bar either way.
 
     def __init__(self, config=None):
         cfg = dict(self.config_spec)
@@ -89,13 +92,50 @@ class PytorchTrainer:
         self.build()
 
     def build(self):
+        """The reference's sanity checks and seeding (trainer/pytorch.py:47-74)."""
         c = self.config
         if c["batch"] < 1:
             raise ValueError("batch must be >= 1")
         if c["evalbatch"] < 0:
             raise ValueError("evalbatch must be 0 (to use the training batch size) or  >= 1")
+        if c["niters"] <= 0:
+            raise ValueError("niters must be > 0")
+        if c["niters"] < c["validatefreq"]:
+            raise ValueError("niters must be equal or greater than validatefreq")
+        if c["itersize"] < c["batch"]:
+            raise ValueError("itersize must be >= batch")
+        if c["gradacc"] < 1 or not float(c["gradacc"]).is_integer():
+            raise ValueError("gradacc must be an integer >= 1")
+        if c["lr"] <= 0:
+            raise ValueError("lr must be > 0")
         if c["amp"] not in (None, "train", "pred", "both"):
             raise ValueError("amp must be one of: None, train, pred, both")
+        if c["decaytype"] not in (None, "exponential", "linear"):
+            raise ValueError("decaytype must be one of: None, exponential, linear")
+        torch.manual_seed(c["seed"])
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(c["seed"])
+
+    @property
+    def n_batch_per_iter(self):
+        return (self.config["itersize"] // self.config["batch"]) or 1     # reference trainer/__init__.py:74-76
+
+    def lr_multiplier(self, step):
+        """Warm-up, then exponential / linear decay per optimisation step (reference trainer/__init__.py:98-109)."""
+        c = self.config
+        warmup_steps = c["warmupiters"] * self.n_batch_per_iter
+        if warmup_steps and step <= warmup_steps:
+            return min((step + 1) / warmup_steps, 1)
+        if c["decaytype"] == "exponential":
+            return c["decay"] ** ((step - warmup_steps) / (c["decayiters"] * self.n_batch_per_iter))
+        if c["decaytype"] == "linear":
+            return 1 / (1 + c["decay"] * ((step - warmup_steps) / self.n_batch_per_iter))
+        return 1
+
+    def _set_lr(self, step):
+        # what `LambdaLR.step(epoch=step)` leaves behind in the reference (:118-120): lr = base lr x multiplier(step)
+        for group in self.optimizer.param_groups:
+            group["lr"] = self.config["lr"] * self.lr_multiplier(step)
 
     # ---- training (SURVEY.md §8f row N3; reference trainer/pytorch.py:76-122, 189-300) -------------------------
     @staticmethod
@@ -110,28 +150,85 @@ class PytorchTrainer:
         scores = torch.stack(pos_neg_scores, dim=1)
         return torch.mean(1.0 - scores.softmax(dim=1)[:, 0])
 
-    def single_train_iteration(self, reranker, train_dataloader):
-        """`itersize // batch` optimisation steps with gradient accumulation (reference :76-122)."""
-        n_batch_per_iter = max(1, self.config["itersize"] // self.config["batch"])
+    def single_train_iteration(self, reranker, train_dataloader, cur_iter=1):
+        """`itersize // batch` batches with gradient accumulation, the per-step learning-rate schedule and (amp = train / both,
+        on a GPU) autocast + loss scaling around the small trainable layers (reference :76-122).  The interaction kernels
+        compute in fp32 whatever `amp` says."""
+        n_batch_per_iter = self.n_batch_per_iter
+        cur_step = cur_iter * n_batch_per_iter
         losses, since_update = [], 0
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
-            loss = self.loss(reranker.score(batch))
+            with self._train_autocast():
+                loss = self.loss(reranker.score(batch))
             losses.append(loss.detach())
-            loss.backward()
+            (self.scaler.scale(loss) if self.scaler else loss).backward()
             since_update += 1
             if since_update == self.config["gradacc"]:
                 since_update = 0
-                self.optimizer.step()
+                if self.scaler:
+                    self.scaler.step(self.optimizer)
+                    self.scaler.update()
+                else:
+                    self.optimizer.step()
                 self.optimizer.zero_grad()
             if (bi + 1) % n_batch_per_iter == 0:
                 break
+            self._set_lr(cur_step)
+            cur_step += 1
         return torch.stack(losses).mean()
 
+    @staticmethod
+    def _early_stopping_paths(train_output_path, dev_output_path):
+        """reference trainer/__init__.py:78-90"""
+        weights, info = os.path.join(train_output_path, "weights"), os.path.join(train_output_path, "info")
+        for p in (dev_output_path, weights, info):
+            os.makedirs(p, exist_ok=True)
+        return os.path.join(train_output_path, "dev.best"), weights, os.path.join(info, "loss.txt"), os.path.join(dev_output_path, "metrics.json")
+
+    @staticmethod
+    def load_loss_file(fn):
+        """reference trainer/__init__.py:22-48: `<iteration> <loss>` lines, iterations consecutive from 0."""
+        loss = []
+        with open(fn, "rt") as f:
+            for lineidx, line in enumerate(f):
+                line = line.strip()
+                if not line:
+                    continue
+                iteridx, iterloss = line.rstrip().split()
+                if int(iteridx) != lineidx:
+                    raise IOError(f"malformed loss file {fn} ... did two processes write to it?")
+                loss.append(float(iterloss))
+        return loss
+
+    def fastforward_training(self, reranker, weights_path, loss_fn, metric_fn):
+        """Resume from the last iteration whose weights were saved (reference :76-122 of trainer/pytorch.py `fastforward_training`):
+        returns (next iteration, best metrics so far); (0, {}) when nothing usable is on disk."""
+        import json
+
+        if not (os.path.exists(weights_path) and os.path.exists(loss_fn)):
+            return 0, {}
+        try:
+            loss = self.load_loss_file(loss_fn)
+            with open(metric_fn, "rt") as f:
+                metrics = json.load(f)
+        except (IOError, ValueError):
+            return 0, {}
+        last = len(loss) - 1
+        try:
+            reranker.load_weights(os.path.join(weights_path, f"{last}.p"), self.optimizer)
+            return last + 1, metrics
+        except Exception:  # noqa: BLE001  (as the reference: any failure means "start over")
+            return 0, {}
+
     def train(self, reranker, train_dataset, train_output_path, dev_data, dev_output_path, qrels, metric="ndcg_cut_20", relevance_level=1):
-        """Pairwise training with validation on `dev_data` every `validatefreq` iterations and `dev.best` checkpointing
-        (reference :189-300).  Metrics: trec_eval-style ndcg_cut_k from capreolus_amd.run_io (`metric` = "ndcg_cut_<k>").
-        Returns the list of per-iteration mean losses."""
+        """Pairwise training with validation on `dev_data` every `validatefreq` iterations, `dev.best` checkpointing and
+        `fastforward` resume (reference :189-300).  Metrics: trec_eval-style ndcg_cut_k from capreolus_amd.run_io (`metric` =
+        "ndcg_cut_<k>"); `relevance_level` does not change it - pytrec_eval's ndcg_cut uses the graded judgments whatever the
+        level is (evaluator.py:55-85: the level applies to the binary metrics).  Returns the list of per-iteration mean losses."""
+        import contextlib
+        import json
+
         from ..run_io import mean_ndcg_cut
 
         if not metric.startswith("ndcg_cut_"):
@@ -140,25 +237,39 @@ class PytorchTrainer:
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         model = reranker.model.to(self.device)
         self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=self.config["lr"])
+        if self.config["amp"] in ("both", "train") and self.device.type == "cuda":
+            self._train_autocast = lambda: torch.autocast("cuda", dtype=torch.float16)
+            self.scaler = torch.amp.GradScaler("cuda")
+        else:
+            self._train_autocast, self.scaler = contextlib.nullcontext, None
+        self._set_lr(0)                      # LambdaLR's construction applies multiplier(0)
         self.loss = self.pair_softmax_loss if self.config["softmaxloss"] else self.pair_hinge_loss
         loader = torch.utils.data.DataLoader(train_dataset, batch_size=self.config["batch"], pin_memory=self.device.type == "cuda",
                                              num_workers=1 if self.config["multithread"] else 0)
         train_output_path, dev_output_path = os.fspath(train_output_path), os.fspath(dev_output_path)
-        os.makedirs(train_output_path, exist_ok=True)
-        os.makedirs(dev_output_path, exist_ok=True)
-        best, train_loss = -np.inf, []
-        for niter in range(1, self.config["niters"] + 1):
+        best_fn, weights_path, loss_fn, metric_fn = self._early_stopping_paths(train_output_path, dev_output_path)
+        initial_iter, metrics = self.fastforward_training(reranker, weights_path, loss_fn, metric_fn) if self.config["fastforward"] else (0, {})
+        best, train_loss = metrics.get(metric, -np.inf), []
+        if initial_iter > 0:
+            train_loss = self.load_loss_file(loss_fn)
+            if initial_iter < self.config["niters"]:       # skip the batches the finished iterations consumed (reference :258-264)
+                for i, _ in enumerate(loader):
+                    if i + 1 == initial_iter * self.n_batch_per_iter:
+                        break
+        for niter in range(initial_iter + 1, self.config["niters"] + 1):
             model.train()
-            train_loss.append(float(self.single_train_iteration(reranker, loader)))
+            train_loss.append(float(self.single_train_iteration(reranker, loader, cur_iter=niter)))
             if self.config["fastforward"]:
-                reranker.save_weights(os.path.join(train_output_path, "weights", f"{niter}.p"), self.optimizer)
+                reranker.save_weights(os.path.join(weights_path, f"{niter}.p"), self.optimizer)
             if niter % self.config["validatefreq"] == 0:
                 preds = self.predict(reranker, dev_data, os.path.join(dev_output_path, f"{niter}.run"))
-                score = mean_ndcg_cut({q: {d: (r if r >= relevance_level else 0) for d, r in ds.items()} for q, ds in qrels.items()}, preds, k)
+                score = mean_ndcg_cut(qrels, preds, k)
                 if score > best:
                     best = score
-                    reranker.save_weights(os.path.join(train_output_path, "dev.best"), self.optimizer)
-            with open(os.path.join(train_output_path, "loss.txt"), "wt") as f:
+                    reranker.save_weights(best_fn, self.optimizer)
+                    with open(metric_fn, "wt") as f:
+                        json.dump({metric: score}, f)
+            with open(loss_fn, "wt") as f:
                 f.write("\n".join(f"{i} {l}" for i, l in enumerate(train_loss)))
         return train_loss
 

@@ -173,3 +173,111 @@ def test_abi_header_and_library_agree():
     assert lib.capamd_packed_row_stride(300) == 320 and lib.capamd_packed_row_stride(63) == 64
     assert lib.capamd_packed_row_stride(64) == 128 and lib.capamd_packed_row_stride(320) == -1
     assert lib.capamd_packed_table_bytes(400001, 300) == 400001 * 320 * 4
+
+
+# ---- training control flow on the host (reference trainer/pytorch.py:47-122, 124-300; trainer/__init__.py:98-109) ----
+
+def test_build_checks_and_lr_schedule():
+    for bad in ({"niters": 0}, {"niters": 2, "validatefreq": 3}, {"itersize": 8, "batch": 16}, {"gradacc": 0}, {"gradacc": 1.5}, {"lr": 0.0},
+                {"decaytype": "cosine"}):
+        with pytest.raises(ValueError):
+            PytorchTrainer(bad)
+    t = PytorchTrainer({"batch": 4, "itersize": 16, "warmupiters": 2, "decaytype": "linear", "decay": 0.5})
+    assert t.n_batch_per_iter == 4
+    # warm-up over 2 iterations x 4 steps, then 1 / (1 + decay * epochs since the warm-up)
+    assert [t.lr_multiplier(s) for s in (0, 3, 7, 8)] == [1 / 8, 4 / 8, 1.0, 1.0]
+    assert t.lr_multiplier(12) == pytest.approx(1 / 1.5) and t.lr_multiplier(16) == pytest.approx(1 / 2.0)
+    e = PytorchTrainer({"batch": 4, "itersize": 16, "decaytype": "exponential", "decay": 0.1, "decayiters": 2})
+    assert e.lr_multiplier(0) == 1.0 and e.lr_multiplier(8) == pytest.approx(0.1) and e.lr_multiplier(4) == pytest.approx(0.1 ** 0.5)
+    assert PytorchTrainer({}).lr_multiplier(1000) == 1
+    # seeding happens in build(), as in the reference (:73-74)
+    PytorchTrainer({"seed": 7})
+    a = torch.rand(3)
+    PytorchTrainer({"seed": 7})
+    assert torch.equal(a, torch.rand(3))
+
+
+class _PairData(torch.utils.data.IterableDataset):
+    def __init__(self):
+        self.served = 0
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(0)
+        while True:
+            self.served += 1
+            x = torch.randn(3, generator=g)
+            yield {"pos": x + 1.0, "neg": x - 1.0}
+
+
+class _LinearReranker:
+    """score() on CPU tensors, the reference's checkpoint format through the Reranker base class."""
+
+    def __init__(self):
+        from capreolus_amd.reranker import Reranker
+
+        torch.manual_seed(0)
+        self.model = torch.nn.Linear(3, 1)
+        self._base = Reranker.__new__(Reranker)
+        self._base.model = self.model
+
+    def score(self, d):
+        return [self.model(d["pos"]).view(-1), self.model(d["neg"]).view(-1)]
+
+    def test(self, d):
+        return d["query_idf"][:, 0]
+
+    def save_weights(self, fn, opt):
+        self._base.save_weights(fn, opt)
+
+    def load_weights(self, fn, opt):
+        self._base.load_weights(fn, opt)
+
+
+def test_train_loop_schedule_gradacc_and_fastforward(tmp_path):
+    s = FakeSampler(3)
+    qrels = {q: {d: (i % 3) for i, d in enumerate(ds)} for q, ds in s.qid_to_docids.items()}
+    cfg = {"batch": 4, "itersize": 16, "niters": 3, "lr": 0.01, "gradacc": 2, "warmupiters": 1, "fastforward": True, "evalbatch": 8}
+    t, r = PytorchTrainer(cfg), _LinearReranker()
+    lrs = []
+    step = torch.optim.Adam.step
+
+    def spy(self, *a, **k):
+        lrs.append(self.param_groups[0]["lr"])
+        return step(self, *a, **k)
+
+    torch.optim.Adam.step = spy
+    try:
+        data = _PairData()
+        losses = t.train(r, data, tmp_path / "train", s, tmp_path / "dev", qrels, "ndcg_cut_20", relevance_level=2)
+    finally:
+        torch.optim.Adam.step = step
+    assert len(losses) == 3 and losses[-1] < losses[0]
+    # 4 batches per iteration, an update every 2nd; the schedule is advanced after every batch but the last of an iteration with
+    # step = iteration * 4 + batch (reference :88, 118-120): update k of iteration i sees multiplier(i*4 + 2k - 1 ... ) as below
+    mult = [t.lr_multiplier(x) for x in (4, 6, 8, 10, 12, 14)]
+    assert lrs == pytest.approx([0.01 * m for m in mult])
+    assert data.served == 3 * 4 * 4 + 1 or data.served == 3 * 4 * 4        # 12 batches of 4 (the loader may prefetch one sample)
+    info = (tmp_path / "train" / "info" / "loss.txt").read_text().splitlines()
+    assert [ln.split()[0] for ln in info] == ["0", "1", "2"]
+    assert (tmp_path / "train" / "dev.best").exists() and (tmp_path / "train" / "weights" / "3.p").exists()
+    assert (tmp_path / "dev" / "metrics.json").exists() and (tmp_path / "dev" / "3.run").exists()
+    # the dev metric is nDCG over the GRADED judgments whatever relevance_level is (pytrec_eval's ndcg_cut ignores the level)
+    import json
+
+    m = json.loads((tmp_path / "dev" / "metrics.json").read_text())["ndcg_cut_20"]
+    runs = [run_io.mean_ndcg_cut(qrels, run_io.load_trec_run(tmp_path / "dev" / f"{i}.run"), 20) for i in (1, 2, 3)]
+    assert m == pytest.approx(max(runs), abs=1e-6)
+    # resume: 3 iterations are on disk -> the reference loads weights/<len(loss) - 1>.p and continues with iteration len(loss) + 1
+    w3 = pickle_load(tmp_path / "train" / "weights" / "2.p")
+    t2, r2 = PytorchTrainer(dict(cfg, niters=4)), _LinearReranker()
+    losses2 = t2.train(r2, _PairData(), tmp_path / "train", s, tmp_path / "dev", qrels, "ndcg_cut_20")
+    assert len(losses2) == 4 and losses2[:3] == pytest.approx(losses)
+    assert (tmp_path / "train" / "weights" / "4.p").exists()
+    assert set(w3) == {"weight", "bias"}
+
+
+def pickle_load(fn):
+    import pickle
+
+    with open(fn, "rb") as f:
+        return pickle.load(f)
