@@ -100,6 +100,21 @@ def drmm(q_ids, d_ids, idf, packed, D, edges, hist_type, gate_type, gate_w, emb_
     return out, counts, err
 
 
+def drmm_from_counts(counts, q_ids, idf, V, D, hist_type, gate_type, gate_w, emb_raw, w1, b1, w2, b2, out_w, out_b):
+    """The back end of `drmm` (histogram type -> ffw -> gate -> output layer) on given raw bin counts [B, Q, nbins + 1]."""
+    q_ids, idf = _i64(q_ids), _f32(idf)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    B, Q, NB = counts.shape
+    w1, b1, w2, b2 = _f32(w1), _f32(b1), _f32(w2).reshape(-1), _f32(b2).reshape(-1)
+    gate_w, out_w, out_b = _f32(gate_w).reshape(-1), _f32(out_w).reshape(-1), _f32(out_b).reshape(-1)
+    emb_raw = None if emb_raw is None else _f32(emb_raw)
+    out = np.empty(B, dtype=np.float32)
+    err = lib().oracle_drmm_from_counts(_p(counts), _p(q_ids), _p(idf), B, Q, ctypes.c_int64(V), D, NB - 1, HIST_TYPES[hist_type],
+                                        GATE_TYPES[gate_type], _p(gate_w), _p(emb_raw), ctypes.c_int64(D), _p(w1), _p(b1), w1.shape[0],
+                                        _p(w2), _p(b2), _p(out_w), _p(out_b), _p(out))
+    return out, err
+
+
 def drmmtks(q_ids, d_ids, idf, packed, D, topk, gate_w, ffw_w, ffw_b, out_w, out_b):
     q_ids, d_ids, idf = _i64(q_ids), _i64(d_ids), _f32(idf)
     B, Q = q_ids.shape

@@ -172,6 +172,43 @@ int oracle_knrm(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L,
  *   output_layer (:34, :114).
  * hist_type 0 CH, 1 NH, 2 LCH; gate_type 0 IDF, 1 TV.  A negative query id returns error bit 4
  * (the reference raises IndexError at DRMM.py:109). */
+/* back end of one query term from its raw bin counts (DRMM.py:71-79 histogram types, :25 ffw): z_q */
+static double drmm_term_z(const int32_t* cnt, int NB, int hist_type, const float* w1, const float* b1, int nodes, const float* w2,
+                          const float* b2) {
+  double h[128], hs = 0.0;
+  for (int i = 0; i < NB; ++i) { h[i] = (double)cnt[i] + 1.0; hs += h[i]; }
+  if (hist_type == 1) for (int i = 0; i < NB; ++i) h[i] /= hs;
+  else if (hist_type == 2) for (int i = 0; i < NB; ++i) h[i] = log(h[i]);
+  double o = b2[0];
+  for (int n = 0; n < nodes; ++n) {
+    double a = b1[n];
+    for (int i = 0; i < NB; ++i) a += (double)w1[n * NB + i] * h[i];
+    o += (double)w2[n] * tanh(a);
+  }
+  return tanh(o);
+}
+/* gate logit of one query term (DRMM.py:83-99), rounded through fp32 as the reference computes it */
+static double drmm_gate_logit(int64_t qid, float idf, int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, int D) {
+  double gl;
+  if (gate_type == 0) gl = (double)gate_w[0] * (double)idf;
+  else {
+    gl = 0.0;
+    const float* e = emb_raw + qid * ld; /* un-normalised query embedding (DRMM.py:109) */
+    for (int c = 0; c < D; ++c) gl += (double)gate_w[c] * (double)e[c];
+  }
+  if (qid == 0) gl += -1e7;
+  /* the reference adds in fp32: w*idf + (-1e7) rounds to exactly -1e7 for |w*idf| < 0.5 */
+  return (double)(float)gl;
+}
+/* softmax gate over the query terms and the output layer (DRMM.py:97, 112-114) */
+static float drmm_combine(const double* z, const double* glogit, int Q, const float* out_w, const float* out_b) {
+  double m = glogit[0];
+  for (int q = 1; q < Q; ++q) if (glogit[q] > m) m = glogit[q];
+  double den = 0.0, num = 0.0;
+  for (int q = 0; q < Q; ++q) { const double e = exp(glogit[q] - m); den += e; num += e * z[q]; }
+  return (float)((double)out_w[0] * (num / den) + (double)out_b[0]);
+}
+
 int oracle_drmm(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed,
                 int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type, const float* gate_w,
                 const float* emb_raw, int64_t ld, const float* w1, const float* b1, int nodes, const float* w2,
@@ -201,33 +238,33 @@ int oracle_drmm(const int64_t* q_ids, const int64_t* d_ids, const float* idf, in
       }
       if (counts_out)
         for (int i = 0; i < NB; ++i) counts_out[((int64_t)b * Q + q) * NB + i] = cnt[i];
-      double h[128], hs = 0.0;
-      for (int i = 0; i < NB; ++i) { h[i] = (double)cnt[i] + 1.0; hs += h[i]; }
-      if (hist_type == 1) for (int i = 0; i < NB; ++i) h[i] /= hs;
-      else if (hist_type == 2) for (int i = 0; i < NB; ++i) h[i] = log(h[i]);
-      double o = b2[0];
-      for (int n = 0; n < nodes; ++n) {
-        double a = b1[n];
-        for (int i = 0; i < NB; ++i) a += (double)w1[n * NB + i] * h[i];
-        o += (double)w2[n] * tanh(a);
-      }
-      z[q] = tanh(o);
-      double gl;
-      if (gate_type == 0) gl = (double)gate_w[0] * (double)idf[(int64_t)b * Q + q];
-      else {
-        gl = 0.0;
-        const float* e = emb_raw + qid * ld; /* un-normalised query embedding (DRMM.py:109) */
-        for (int c = 0; c < D; ++c) gl += (double)gate_w[c] * (double)e[c];
-      }
-      if (qid == 0) gl += -1e7;
-      /* the reference adds in fp32: w*idf + (-1e7) rounds to exactly -1e7 for |w*idf| < 0.5 */
-      glogit[q] = (double)(float)gl;
+      z[q] = drmm_term_z(cnt, NB, hist_type, w1, b1, nodes, w2, b2);
+      glogit[q] = drmm_gate_logit(qid, idf[(int64_t)b * Q + q], gate_type, gate_w, emb_raw, ld, D);
     }
-    double m = glogit[0];
-    for (int q = 1; q < Q; ++q) if (glogit[q] > m) m = glogit[q];
-    double den = 0.0, num = 0.0;
-    for (int q = 0; q < Q; ++q) { const double e = exp(glogit[q] - m); den += e; num += e * z[q]; }
-    out[b] = (float)((double)out_w[0] * (num / den) + (double)out_b[0]);
+    out[b] = drmm_combine(z, glogit, Q, out_w, out_b);
+  }
+  return err;
+}
+
+/* The back end of oracle_drmm on GIVEN raw bin counts [B][Q][nbins+1] (what `_hist_map` counts before the +1, DRMM.py:62-70):
+ * histogram type -> ffw -> term gate -> output layer.  Fed with the reference's own counts it must reproduce the reference's
+ * scores on EVERY pair, including those where the front end's cos(a, a) < 1.0 coin flips differently. */
+int oracle_drmm_from_counts(const int32_t* counts, const int64_t* q_ids, const float* idf, int B, int Q, int64_t V, int D, int nbins,
+                            int hist_type, int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
+                            const float* b1, int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
+                            float* out) {
+  const int NB = nbins + 1;
+  int err = 0;
+  for (int b = 0; b < B; ++b) {
+    double z[64], glogit[64];
+    for (int q = 0; q < Q; ++q) {
+      int64_t qid = q_ids[(int64_t)b * Q + q];
+      if (qid >= V) { err |= 2; qid = 0; }
+      if (qid < 0) { err |= 4; qid = 0; }
+      z[q] = drmm_term_z(counts + ((int64_t)b * Q + q) * NB, NB, hist_type, w1, b1, nodes, w2, b2);
+      glogit[q] = drmm_gate_logit(qid, idf[(int64_t)b * Q + q], gate_type, gate_w, emb_raw, ld, D);
+    }
+    out[b] = drmm_combine(z, glogit, Q, out_w, out_b);
   }
   return err;
 }

@@ -140,3 +140,30 @@ def load_cedr_case(name):
     n_in = (hidden if c["cls_mode"] else 0) + 11 * len(c["simmat_layers"])
     head = cedr_head(int(c["weight_seed"]), n_in, int(c["combine_hidden"]))
     return c, w, head, CEDR_MUS + [1.0], [0.1] * 10 + [0.01]
+
+
+# ---- published nDCG vectors (third-party arithmetic: pytrec_eval / trec_eval `ndcg_cut`, reference evaluator.py:75-76) -----------
+# Each case: (source, qrels, run, k, expected per query).  Values are the ones the sources print; where a source rounds to three
+# decimals the tolerance says so.  Conventions they pin: gain = the judged level itself (linear), discount log2(rank + 1), ideal DCG
+# over ALL judged documents of the query (retrieved or not), unjudged documents gain 0, cut-off below the list length.
+NDCG_PUBLISHED = [
+    # pytrec_eval README (cvangysel/pytrec_eval, "Example"): RelevanceEvaluator(qrel, {'map', 'ndcg'}) prints
+    # q1 ndcg 0.5, q2 ndcg 0.6934264036172708 ('ndcg' = ndcg_cut at the full list length).  q2 retrieves an unjudged document first.
+    ("pytrec_eval README", {"q1": {"d1": 0, "d2": 1, "d3": 0}, "q2": {"d2": 1, "d3": 1}},
+     {"q1": {"d1": 1.0, "d2": 0.0, "d3": 1.5}, "q2": {"d1": 1.5, "d2": 0.2, "d3": 0.5}}, 1000,
+     {"q1": (0.5, 1e-15), "q2": (0.6934264036172708, 1e-15)}),
+    # Wikipedia, "Discounted cumulative gain", section Example: six results with graded relevance 3,2,3,0,1,2:
+    # DCG_6 = 6.861, IDCG_6 = 7.141 (ideal order of these six), nDCG_6 = 0.961.
+    ("Wikipedia DCG example", {"w": {"D1": 3, "D2": 2, "D3": 3, "D4": 0, "D5": 1, "D6": 2}},
+     {"w": {"D1": 6.0, "D2": 5.0, "D3": 4.0, "D4": 3.0, "D5": 2.0, "D6": 1.0}}, 6, {"w": (0.961, 5e-4)}),
+    # same article: two more judged documents (levels 3 and 2) that the system did not retrieve -> ideal order 3,3,3,2,2,2,1,0,
+    # IDCG_6 = 8.740, nDCG_6 = 6.861 / 8.740 = 0.785: the ideal ranking comes from the qrels, not from the retrieved list.
+    ("Wikipedia DCG example, unretrieved judged documents",
+     {"w": {"D1": 3, "D2": 2, "D3": 3, "D4": 0, "D5": 1, "D6": 2, "D7": 3, "D8": 2}},
+     {"w": {"D1": 6.0, "D2": 5.0, "D3": 4.0, "D4": 3.0, "D5": 2.0, "D6": 1.0}}, 6, {"w": (0.785, 5e-4)}),
+    # the same list cut at 3 (k below the list length): DCG_3 = 3 + 2/log2(3) + 3/2, IDCG_3 = 3 + 3/log2(3) + 3/2 (three level-3 documents)
+    ("Wikipedia DCG example, cut at 3",
+     {"w": {"D1": 3, "D2": 2, "D3": 3, "D4": 0, "D5": 1, "D6": 2, "D7": 3, "D8": 2}},
+     {"w": {"D1": 6.0, "D2": 5.0, "D3": 4.0, "D4": 3.0, "D5": 2.0, "D6": 1.0}}, 3,
+     {"w": ((3 + 2 / np.log2(3) + 1.5) / (3 + 3 / np.log2(3) + 1.5), 1e-15)}),
+]

@@ -251,6 +251,22 @@ def test_full_size_drmm_properties(full):
         wide = torch.cat([b["posdoc"], torch.zeros((2000, 133), dtype=torch.int64, device=DEV)], 1)
         s2 = m(wide, b["query"], b["query_idf"]).view(-1)
         assert torch.equal(s, s2)
+    # (c) a stride-63 sample of pairs against the oracle: bin counts bit-exact, scores to ORACLE_TOL
+    idx = np.arange(0, 2000, 63)
+    q, d = b["query"][idx].cpu().numpy(), b["posdoc"][idx].cpu().numpy()
+    used = np.unique(np.concatenate([q.ravel(), d.ravel()]))
+    used = used[used > 0]
+    remap = np.zeros(400001, dtype=np.int64)
+    remap[used] = np.arange(1, len(used) + 1)
+    small = np.concatenate([np.zeros((1, 300), np.float32), emb[torch.as_tensor(used, device=DEV)].cpu().numpy()])
+    rq, rd = np.where(q > 0, remap[np.maximum(q, 0)], q), np.where(d > 0, remap[np.maximum(d, 0)], d)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    want, wcounts, err = oracle.drmm(rq, rd, b["query_idf"][idx].cpu().numpy(), oracle.pack(small), 300, torch.linspace(-1, 1, 30)[1:].numpy(), "LCH", "IDF",
+                                     sd["gates.weight"], small, sd["ffw.0.weight"], sd["ffw.0.bias"], sd["ffw.2.weight"], sd["ffw.2.bias"],
+                                     sd["output_layer.weight"], sd["output_layer.bias"])
+    assert err == 0
+    assert np.array_equal(c0[idx].cpu().numpy(), wcounts)
+    assert rel_err(s[idx].cpu().numpy(), want).max() <= ORACLE_TOL
 
 
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
@@ -270,8 +286,24 @@ def test_ndcg20_parity_gpu_vs_reference(kind):
         diffs.append(abs(ours - ref))
     if kind == "knrm":
         assert max(diffs) < 1e-12, diffs
-    else:
-        assert np.mean(diffs) < 0.05, diffs
+        return
+    # DRMM: the reference's own `(sim < 1.0).sum()` on cos(a, a) = 1 +- ulp moves bin counts on 78 of these 200 pairs (see
+    # tests/test_oracle_golden.py::test_drmm_coin_flip_statistics), so against the REFERENCE the ranking agrees only within that noise
+    # (measured: nDCG@20 delta <= 0.064 on these five qrel sets).  What must hold exactly is GPU == oracle: the two share their bin
+    # counts bit for bit, and the oracle's back end reproduces the reference on the reference's counts (test_drmm_back_end_on_
+    # reference_counts), so any difference between them would be a bug, not noise.
+    assert max(diffs) <= 0.064 + 1e-9, diffs
+    packed = oracle.pack(c["emb"])
+    want, wcounts, err = oracle.drmm(c["query"], c["posdoc"], c["query_idf"], packed, int(c["D"]), c["edges"], str(c["histType"]), str(c["gateType"]),
+                                     c["sd.gates.weight"], c["emb"], c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.ffw.2.weight"],
+                                     c["sd.ffw.2.bias"], c["sd.output_layer.weight"], c["sd.output_layer.bias"])
+    assert err == 0
+    g16, w16 = got.astype(np.float16), want.astype(np.float16)
+    assert np.array_equal(g16, w16), np.nonzero(g16 != w16)[0]                       # the fp16 scores predict() stores
+    assert np.array_equal(rank_order(g16), rank_order(w16))
+    for seed in range(5):
+        qrels = {"1": synthetic_qrels(len(got), seed)}
+        assert run_io.ndcg_cut(qrels, {"1": run_from_scores(got)}, 20)["1"] == run_io.ndcg_cut(qrels, {"1": run_from_scores(want)}, 20)["1"]
 
 
 def test_predict_end_to_end_on_gpu(tmp_path):
@@ -424,6 +456,27 @@ def test_ndcg_cut_matches_host(counts, coarse):
                 assert abs(got[qi] - want[qid]) <= 1e-12, (qid, got[qi], want[qid])
             else:
                 assert got[qi] == 0.0
+
+
+def test_ndcg_cut_published_vectors_on_device():
+    """capamd_ndcg_cut against the numbers pytrec_eval's README and the DCG article print (tests/helpers.py: NDCG_PUBLISHED)."""
+    from capreolus_amd import ranking
+    from tests.helpers import NDCG_PUBLISHED
+
+    for source, qrels, run, k, want in NDCG_PUBLISHED:
+        q2d = {qid: list(docs) for qid, docs in run.items()}
+        scores = torch.tensor([s for docs in run.values() for s in docs.values()], dtype=torch.float32, device=DEV)
+        rel, tie, idcg, off = ranking.eval_arrays(q2d, qrels, k, DEV)
+        got = ranking.ndcg_cut(scores, off, rel, tie, idcg, k=k).cpu().numpy()
+        engine.status_word(torch.device(DEV)).raise_if_set()
+        for qi, qid in enumerate(q2d):
+            v, tol = want[qid]
+            assert abs(got[qi] - v) <= max(tol, 1e-12), (source, qid, got[qi], v)
+    # score ties: docid descending, whatever the list order
+    qrels = {"1": {"a": 1, "b": 0}}
+    for docs in (["a", "b"], ["b", "a"]):
+        rel, tie, idcg, off = ranking.eval_arrays({"1": docs}, qrels, 1, DEV)
+        assert ranking.ndcg_cut(torch.ones(2, device=DEV), off, rel, tie, idcg, k=1).item() == 0.0
 
 
 def test_ranking_flags_nan_and_bad_ties():

@@ -153,6 +153,24 @@ def test_ndcg_cut_hand_computed():
     assert run_io.mean_ndcg_cut(qrels, run) == pytest.approx((dcg / idcg) / 2)
 
 
+def test_ndcg_cut_published_vectors():
+    """run_io.ndcg_cut (the host twin of capamd_ndcg_cut and the dev metric of PytorchTrainer.train) against numbers printed by
+    pytrec_eval's README and the worked example of the DCG article (tests/helpers.py: NDCG_PUBLISHED)."""
+    from tests.helpers import NDCG_PUBLISHED
+
+    for source, qrels, run, k, want in NDCG_PUBLISHED:
+        got = run_io.ndcg_cut(qrels, run, k)
+        assert set(got) == set(want), source
+        for qid, (v, tol) in want.items():
+            assert abs(got[qid] - v) <= tol, (source, qid, got[qid], v)
+    # trec_eval breaks score ties by docid DESCENDING, whatever order the run lists them in (its README: "ties are broken
+    # deterministically (using docno)"; form_res_rels sorts by sim, then docno, both descending)
+    qrels = {"1": {"a": 1, "b": 0}}
+    for run in ({"1": {"a": 1.0, "b": 1.0}}, {"1": {"b": 1.0, "a": 1.0}}):
+        assert run_io.ndcg_cut(qrels, run, 1)["1"] == 0.0          # "b" > "a": b is ranked first
+        assert run_io.ndcg_cut(qrels, run, 2)["1"] == pytest.approx(1 / np.log2(3))
+
+
 def test_abi_header_and_library_agree():
     """Every function include/capreolus_amd.h declares is exported by the built library, and the
     ctypes table binds exactly that set (no compute calls: there is no GPU here)."""
