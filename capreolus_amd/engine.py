@@ -316,7 +316,9 @@ class BertEngine:
         lengths = [x for x in SUPPORTED_LENGTHS if x < S] if (skip_padding and S in SUPPORTED_LENGTHS) else []
         if not lengths:
             NP = B * P
-            if NP < 2 * self.microbatch or not self.two_streams:
+            q = 256 // math.gcd(S, 256)                      # passages per whole 256-row GEMM tile
+            cut = (NP // 2 + q - 1) // q * q                 # first half of a two-stream split, in whole tiles
+            if NP < 2 * self.microbatch or not self.two_streams or cut >= NP:
                 plog = torch.empty(NP, dtype=torch.float32, device=ids.device) if return_passage_logits else None
                 self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
                 return (out, plog) if return_passage_logits else out
@@ -326,8 +328,6 @@ class BertEngine:
             plog = torch.empty(NP, dtype=torch.float32, device=ids.device)
             self.model()
             main = torch.cuda.current_stream(ids.device)
-            q = 256 // math.gcd(S, 256)
-            cut = (NP // 2 + q - 1) // q * q
             sides = []
             for k, (a0, a1) in enumerate(((0, cut), (cut, NP))):
                 side = self._streams.get(("half", k))

@@ -86,7 +86,8 @@ def test_gemm_folded_layernorm_consumer(M, N, K, epi, dt):
     c = b + W0 @ beta
     mr = torch.stack([mu, rstd], 1).contiguous()
     out = torch.empty(M * N, dtype=tdt, device=DEV)
-    rc = _lib.load().capamd_bert_gemm_ln(_p(_to_cm(P)), _p(Ws), _p(c), M, N, K, epi | 0x300, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+    P_cm = _to_cm(P)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(Ws), _p(c), M, N, K, epi | 0x300, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
                                          _p(out), code, _stream())
     assert rc == 0
     x = (Pf - mu[:, None]) * rstd[:, None] * gamma + beta
@@ -113,7 +114,8 @@ def test_gemm_residual_stats_producer(M, N, K, dt):
     mr = torch.stack([mu, rstd], 1).contiguous()
     out = torch.empty(M * N, dtype=tdt, device=DEV)
     part = torch.zeros((M, N // 64, 2), device=DEV)
-    rc = _lib.load().capamd_bert_gemm_ln(_p(A), _p(W), _p(bp), M, N, K, 5 | 0x100, None, None, None, None, _p(_to_cm(R)), _p(mr), _p(gamma), _p(part),
+    R_cm = _to_cm(R)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A), _p(W), _p(bp), M, N, K, 5 | 0x100, None, None, None, None, _p(R_cm), _p(mr), _p(gamma), _p(part),
                                          _p(out), code, _stream())
     assert rc == 0
     ref = A.float() @ W.float().t() + bp + (Rf - mu[:, None]) * rstd[:, None] * gamma
@@ -413,3 +415,201 @@ def test_cedr_knrm_on_an_electra_shaped_body():
         got = r.test(d).cpu().numpy()
         want = _cedr_model(c, w, head, "fp16").test(d).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+# ---- the code paths the benchmark runs: persistent kernels with far more tiles / items than CUs -------------------------------
+# BASELINE.json configs[3] encodes 256-passage micro-batches (M = 65,536 rows): 3,072 tiles per FFN1 launch and 3,072 attention
+# items per layer on 256 CUs, i.e. the cross-tile fill chaining of gemm_pingpong_kernel and the next-item prefetch of
+# attention_persistent_kernel, which the small shapes above never reach.
+
+BIG_M = 65536
+
+
+def _big_operands(M, N, K, seed, tdt):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    A = (torch.randn((M, K), generator=g, device=DEV) * 0.5).to(tdt)
+    # every row tile and every column tile differ (a tile written to / read from the wrong place cannot cancel out)
+    A += (torch.arange(M, device=DEV)[:, None] % 509).to(tdt) * 1e-3
+    W = (torch.randn((N, K), generator=g, device=DEV) * 0.05 + torch.arange(N, device=DEV)[:, None] * 2e-4).to(tdt)
+    return g, A, W
+
+
+def _assert_close_big(got, ref, rtol, atol, what):
+    """row-blocked comparison: 65,536 x 3,072 fp32 temporaries stay below a few GB"""
+    M = ref.shape[0]
+    for lo in range(0, M, 16384):
+        torch.testing.assert_close(got[lo:lo + 16384].float(), ref[lo:lo + 16384], rtol=rtol, atol=atol, msg=lambda m: f"{what} rows {lo}..: {m}")
+
+
+@pytest.mark.parametrize("N,K,epi", [(768, 768, 0), (2304, 768, 0), (3072, 768, 1), (768, 3072, 0)])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_gemm_at_benchmark_scale(N, K, epi, dt):
+    M = BIG_M
+    tdt, code, rtol = TDT[dt]
+    g, A, W = _big_operands(M, N, K, N + K + epi, tdt)
+    bias = torch.randn(N, generator=g, device=DEV)
+    out = torch.empty((M, N), dtype=tdt, device=DEV)
+    assert _lib.load().capamd_bert_gemm(_p(A), _p(W), _p(bias), M, N, K, epi, None, _p(out), code, _stream()) == 0
+    ref = A.float() @ W.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    _assert_close_big(out, ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"gemm {N}x{K} epi {epi}")
+    # chunk-major in and out (the layout the encoder runs on): same numbers, other addresses
+    out_cm, A_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(A)
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W), _p(bias), M, N, K, epi | 0x300, None, _p(out_cm), code, _stream()) == 0
+    assert torch.equal(_from_cm(out_cm, M, N), out)
+
+
+@pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1)])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_gemm_folded_layernorm_consumer_at_benchmark_scale(N, K, epi, dt):
+    M = BIG_M
+    tdt, code, rtol = TDT[dt]
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    P = (torch.randn((M, K), generator=g, device=DEV) * 1.7 + torch.randn((M, 1), generator=g, device=DEV) * 0.8).to(tdt)
+    W0 = torch.randn((N, K), generator=g, device=DEV) * 0.04 + torch.arange(N, device=DEV)[:, None] * 2e-4
+    b = torch.randn(N, generator=g, device=DEV) * 0.3
+    gamma = 1.0 + 0.2 * torch.randn(K, generator=g, device=DEV)
+    beta = 0.1 * torch.randn(K, generator=g, device=DEV)
+    Pf = P.float()
+    mu = Pf.mean(1)
+    rstd = torch.rsqrt(Pf.var(1, unbiased=False) + 1e-12)
+    Wg = W0 * gamma[None, :]
+    Ws = (Wg - Wg.mean(1, keepdim=True)).to(tdt)
+    cs = Ws.float().sum(1)
+    c = b + W0 @ beta
+    mr = torch.stack([mu, rstd], 1).contiguous()
+    out, P_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(P)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(Ws), _p(c), M, N, K, epi | 0x300, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+                                         _p(out), code, _stream())
+    assert rc == 0
+    ref = ((Pf - mu[:, None]) * rstd[:, None] * gamma + beta) @ W0.t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    _assert_close_big(_from_cm(out, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K}")
+
+
+@pytest.mark.parametrize("N,K", [(768, 768), (768, 3072)])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_gemm_residual_stats_producer_at_benchmark_scale(N, K, dt):
+    M = BIG_M
+    tdt, code, rtol = TDT[dt]
+    g, A, W = _big_operands(M, N, K, N + K + 5, tdt)
+    bp = torch.randn(N, generator=g, device=DEV)
+    R = (torch.randn((M, N), generator=g, device=DEV) * 2.0 + 0.5).to(tdt)
+    gamma = 1.0 + 0.2 * torch.randn(N, generator=g, device=DEV)
+    Rf = R.float()
+    mu = Rf.mean(1)
+    rstd = torch.rsqrt(Rf.var(1, unbiased=False) + 1e-12)
+    mr = torch.stack([mu, rstd], 1).contiguous()
+    out = torch.empty(M * N, dtype=tdt, device=DEV)
+    part = torch.zeros((M, N // 64, 2), device=DEV)
+    A_cm, R_cm = _to_cm(A), _to_cm(R)       # (named: a temporary's memory could be handed to the next temporary before the launch)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W), _p(bp), M, N, K, 5 | 0x300, None, None, None, None, _p(R_cm), _p(mr), _p(gamma), _p(part),
+                                         _p(out), code, _stream())
+    assert rc == 0
+    ref = A.float() @ W.float().t() + bp + (Rf - mu[:, None]) * rstd[:, None] * gamma
+    got = _from_cm(out, M, N).float()
+    _assert_close_big(got, ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"residual+stats producer {N}x{K}")
+    want = torch.stack([got.reshape(M, N // 64, 64).sum(2), (got * got).reshape(M, N // 64, 64).sum(2)], 2)
+    torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("hidden,heads,npsg", [(768, 12, 400), (128, 2, 1024)])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_qkv_attention_many_items(hidden, heads, npsg, dt):
+    """S = 256 with 4,800 / 2,048 (passage, head) items on 256 CUs: every persistent workgroup walks several items, K / V^T of the next
+    item arriving in the second LDS buffer while the current one is computed."""
+    S = 256
+    tdt, code, rtol = TDT[dt]
+    atol = 2e-2 if dt == "bf16" else 3e-3
+    g = torch.Generator(device=DEV).manual_seed(hidden + npsg)
+    M = npsg * S
+    x = torch.randn((M, hidden), generator=g, device=DEV).to(tdt)
+    w = (torch.randn((3 * hidden, hidden), generator=g, device=DEV) * 0.06).to(tdt)
+    b = torch.randn(3 * hidden, generator=g, device=DEV) * 0.1
+    lens = torch.randint(5, S + 1, (npsg,), generator=g, device=DEV)
+    mask = (torch.arange(S, device=DEV)[None, :] < lens[:, None]).long()
+    mask[::7, 9] = 0
+    q, k, ctx = (torch.empty((M, hidden), dtype=tdt, device=DEV) for _ in range(3))
+    vt = torch.empty((npsg * heads, 64, S), dtype=tdt, device=DEV)
+    rc = _lib.load().capamd_bert_qkv_attention(_p(x), _p(w), _p(b), _p(mask), npsg, S, hidden, heads, _p(q), _p(k), _p(vt), _p(ctx), code, _stream())
+    assert rc == 0
+    for lo in range(0, npsg, 100):      # reference in blocks of 100 passages
+        hi = min(lo + 100, npsg)
+        n = hi - lo
+        qkv = x[lo * S:hi * S].float() @ w.float().t() + b
+        qr, kr, vr = (t.view(n, S, heads, 64).transpose(1, 2) for t in qkv.split(hidden, dim=1))
+        torch.testing.assert_close(q[lo * S:hi * S].float().view(n, S, heads, 64).transpose(1, 2), qr / 8, rtol=rtol, atol=atol)
+        torch.testing.assert_close(k[lo * S:hi * S].float().view(n, S, heads, 64).transpose(1, 2), kr, rtol=rtol, atol=atol)
+        torch.testing.assert_close(vt[lo * heads:hi * heads].float().view(n, heads, 64, S).transpose(2, 3), vr, rtol=rtol, atol=atol)
+        qb = q[lo * S:hi * S].float().view(n, S, heads, 64).transpose(1, 2)
+        kb = k[lo * S:hi * S].float().view(n, S, heads, 64).transpose(1, 2)
+        vb = vt[lo * heads:hi * heads].float().view(n, heads, 64, S).transpose(2, 3)
+        att = torch.softmax(qb @ kb.transpose(-1, -2) + (1.0 - mask[lo:hi].float()).view(n, 1, 1, S) * torch.finfo(torch.float32).min, dim=-1)
+        ref = (att @ vb).transpose(1, 2).reshape(n * S, hidden)
+        torch.testing.assert_close(ctx[lo * S:hi * S].float(), ref, rtol=2e-2 if dt == "bf16" else 3e-3, atol=atol)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_bert_base_benchmark_microbatch_matches_fixture_sized_runs(dt):
+    """A 256-passage micro-batch (the size bench.py times: 65,536 rows, every GEMM > 256 tiles) gives BIT-IDENTICAL passage logits
+    to the same passages encoded 12 at a time - the size at which tests/golden/bert_base.npz pins the engine to the reference.
+    The first 12 passages ARE that fixture's passages and weights, so the chain reference -> 12-passage run -> benchmark-sized run
+    is closed: their logits also stay within the fixture's tolerance of the reference."""
+    from capreolus_amd import synthetic
+
+    c = load_bert_case("base")
+    B0, P, S = c["pos_bert_input"].shape                      # 3 documents x 4 passages x 256 tokens
+    extra = synthetic.make_bert_passages(np.random.RandomState(77), 61, P, S, vocab=c["vocab"])
+    d = {k: torch.cat([c[k], torch.as_tensor(extra[k])]).to(DEV) for k in ("pos_bert_input", "pos_mask", "pos_seg")}   # 64 docs = 256 passages
+    r = _model(c, "max", dt)
+    eng_args = (d["pos_bert_input"], d["pos_mask"], d["pos_seg"], "max")
+    with torch.no_grad():
+        r.test({k: v[:B0] for k, v in d.items()})
+        eng = r.model._engine
+        eng.two_streams = False
+        eng.microbatch = 256
+        s256, pl256 = eng.forward(*eng_args, return_passage_logits=True, skip_padding=False)
+        eng.microbatch = 12
+        s12, pl12 = eng.forward(*eng_args, return_passage_logits=True, skip_padding=False)
+    assert torch.equal(pl256, pl12) and torch.equal(s256, s12)
+    tol = BF16_E2E_TOL if dt == "bf16" else FP16_E2E_TOL
+    assert rel_err(pl256[:B0 * P].cpu().numpy(), c["ref_passage_logits"][:, 1]).max() <= tol
+    # and 1,000 passages (four micro-batches, the last one ragged) through the two-stream path the engine uses by default
+    with torch.no_grad():
+        eng.microbatch, eng.two_streams = 256, True
+        big = {k: torch.cat([v] * 4)[:250] for k, v in d.items()}
+        sb, plb = eng.forward(big["pos_bert_input"], big["pos_mask"], big["pos_seg"], "max", return_passage_logits=True, skip_padding=False)
+    assert torch.equal(plb[:256], pl256) and torch.equal(plb[256:512], pl256) and torch.equal(plb[768:], pl256[:232])
+
+
+@pytest.mark.parametrize("S,n_passages", [(32, 1), (32, 13), (96, 5), (160, 7), (224, 3), (64, 5), (128, 3)])
+@pytest.mark.parametrize("dt", ["fp16"])
+def test_ragged_passage_counts(S, n_passages, dt):
+    """Passage counts whose rows do not fill whole 64- / 256-row GEMM tiles (an odd count at S = 32, 96, 160, 224; a single
+    32-token passage): the library pads the micro-batch itself.  Every passage must score exactly as it does inside a batch that
+    needs no padding, and the scores must match the fp32 port."""
+    from capreolus_amd.engine import BertEngine
+    from oracle import bert_port
+
+    heads, layers, vocab = 4, 2, 500
+    w = bert_port.random_weights(hidden=256, layers=layers, heads=heads, ffn=512, vocab=vocab, max_pos=S, seed=S + n_passages)
+    g = torch.Generator().manual_seed(S * 3 + n_passages)
+    n_full = 16                                               # 16 passages of any supported S are whole 256-row tiles
+    ids = torch.randint(1, vocab, (n_full, 1, S), generator=g)
+    lens = torch.randint(8, S + 1, (n_full, 1), generator=g)
+    mask = (torch.arange(S)[None, None, :] < lens[:, :, None]).long()
+    seg = ((torch.arange(S)[None, None, :] >= 6) & (mask > 0)).long()
+    ids = ids * mask
+    eng = BertEngine({k: v.to(DEV) for k, v in w.items()}, heads, compute_dtype=dt, skip_padding=False)
+    with torch.no_grad():
+        full = eng.forward(ids.to(DEV), mask.to(DEV), seg.to(DEV), "max")
+        n = n_passages
+        part = eng.forward(ids[:n].to(DEV), mask[:n].to(DEV), seg[:n].to(DEV), "max")
+        eng.microbatch = 1                                    # ... and with a ragged LAST micro-batch (S = 32: 8 passages per micro-batch)
+        split = eng.forward(ids[:n].to(DEV), mask[:n].to(DEV), seg[:n].to(DEV), "max")
+    assert torch.equal(part, full[:n]) and torch.equal(split, full[:n])
+    ref = bert_port.maxp(w, ids[:n], mask[:n], seg[:n], heads, layers, "max")
+    # (a 2-layer random model has small scores: measured against the batch's score scale, as for the mini CEDR fixtures)
+    assert np.abs(part.cpu().numpy() - ref.numpy()).max() <= 4e-3 * max(1.0, float(ref.abs().max()))
