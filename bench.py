@@ -57,6 +57,12 @@ def parse():
     ap.add_argument("--queries", type=int, default=0, help="queries per step per GPU (0 = 64 for the interaction models, 1 for bert)")
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
+    ap.add_argument("--launch-streams", type=int, default=4,
+                    help="with --launch-docs: the launches of a step go round-robin over this many HIP streams, so the tail of one candidate "
+                         "list (as long as its longest document) overlaps the next list's launch; 1 = one stream, strictly serial launches")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="with --launch-docs: issue every launch of a step from Python instead of replaying the step's launches as one captured "
+                         "HIP graph (64 launches of 1000 pairs are host-bound at ~25 us of Python / ctypes per launch)")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches the steps rotate through (consecutive steps never score the same batch)")
     ap.add_argument("--vocab", type=int, default=400001)
     ap.add_argument("--dim", type=int, default=300)
@@ -226,20 +232,56 @@ class InteractionLeg:
                 engine.drmm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
                                     f2w, f2b, ow, ob, out=out[lo:hi], check=False)
         self.launch_one = launch_one
+        n_side = min(args.launch_streams, len(self.slices)) if len(self.slices) > 1 else 1
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(n_side)] if n_side > 1 else []
+        from capreolus_amd import _lib
+
+        _lib.load().capamd_set_concurrent_launches(1 if self.side else 0)
         self.gathered = torch.empty(self.n_pairs * ctx.world, dtype=torch.float32, device=dev) if ctx.use_dist else None
         self.last_batch = 0
 
+    def capture(self):
+        """one HIP graph per batch: the step's launches (fork over the side streams, join) replayed with a single host call"""
+        self.graphs = []
+        if len(self.slices) == 1 or self.args.no_graph:
+            return
+        for bi in range(len(self.batches)):
+            self._launch_all(bi)                       # eager once: module load, workspace
+        torch.cuda.synchronize()
+        for bi in range(len(self.batches)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_all(bi)
+            self.graphs.append(g)
+
     def step(self, i):
         bi = i % len(self.batches)
-        for lo, hi in self.slices:
-            self.launch_one(bi, lo, hi)
+        if getattr(self, "graphs", None):
+            self.graphs[bi].replay()
+        else:
+            self._launch_all(bi)
         if self.ctx.use_dist:
             self.ctx.dist.all_gather_into_tensor(self.gathered, self.out)
         self.last_batch = bi
 
+    def _launch_all(self, bi):
+        if self.side:      # independent candidate lists: round-robin over side streams, joined before the step ends
+            main = torch.cuda.current_stream()
+            for st in self.side:
+                st.wait_stream(main)
+            for k, (lo, hi) in enumerate(self.slices):
+                with torch.cuda.stream(self.side[k % len(self.side)]):
+                    self.launch_one(bi, lo, hi)
+            for st in self.side:
+                main.wait_stream(st)
+        else:
+            for lo, hi in self.slices:
+                self.launch_one(bi, lo, hi)
+
     def run(self, warmup, steps):
         from capreolus_amd import engine
 
+        self.capture()
         elapsed, dev_s = timed_loop(self.ctx, self.step, warmup, steps)
         engine.status_word(self.ctx.dev).raise_if_set()
         assert torch.isfinite(self.out).all()
@@ -350,7 +392,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             "workload": f"{model.upper()} inference (BASELINE.json configs[{1 if model == 'knrm' else 2}]): qlen={Q} dlen={L} "
                         f"embed={D} vocab={args.vocab}, {args.docs} docs/query x {per_rank_q} queries per step per GPU, "
                         f"{'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, lognormal doc lengths, "
-                        f"{launches} launch(es) per step, {len(leg.batches)} distinct batches in rotation",
+                        f"{launches} launch(es) per step" + (f" round-robin over {len(leg.side)} HIP streams" if leg.side else "") + (", replayed as one captured HIP graph" if leg.graphs else "") +
+                        f", {len(leg.batches)} distinct batches in rotation",
             "pairs_per_step_per_gpu": n_pairs,
             "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU",
         },

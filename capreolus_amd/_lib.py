@@ -36,6 +36,7 @@ _mp = ctypes.POINTER(BertModel)
 SIGNATURES = {
     "capamd_version": (_i, []),
     "capamd_arch": (ctypes.c_char_p, []),
+    "capamd_set_concurrent_launches": (_i, [_i]),
     "capamd_packed_row_stride": (_i64, [_i]),
     "capamd_packed_table_bytes": (_i64, [_i64, _i]),
     "capamd_pack_embeddings": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),

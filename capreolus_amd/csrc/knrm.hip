@@ -288,7 +288,10 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
   // One candidate list per launch (B <= the 1536 workgroups the chip holds at once): the launch is as long as its longest
   // document, so four rows in flight per 16-lane group (U = 4) beat occupancy - 62 vs 77 us at B = 1000; from B = 2000 on
   // the 6-waves-per-SIMD variant wins again (96 vs 100 us; 33.0 vs 25.6 M pairs/s at B = 16000).  Same summation order.
-  const int chosen = variant ? variant : (B <= 1536 ? 1 : 0);
+  // ... unless the caller keeps several launches in flight on different streams (capamd_set_concurrent_launches): the small
+  // launches then share the chip and occupancy wins again - 64 lists of 1000 pairs over 4 streams: 34.3 M pairs/s with the
+  // 6-wave variant, 26.2 M with U = 4 (and 16.9 M strictly serial).
+  const int chosen = variant ? variant : ((B <= 1536 && !g_concurrent_launches) ? 1 : 0);
 #define LAUNCH_V(NV_)                          \
   switch (chosen) {                            \
     case 1: LAUNCH(NV_, 4, false, 2); break;   \

@@ -101,6 +101,19 @@ def status_word(device):
     return _status_words[key]
 
 
+class concurrent_launches:
+    """Context: the caller keeps several scoring calls in flight on different streams (capamd_set_concurrent_launches), e.g.
+    one candidate list per launch round-robin over a few streams so that the tail of one list overlaps the next launch."""
+
+    def __enter__(self):
+        self.prev = _lib.load().capamd_set_concurrent_launches(1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().capamd_set_concurrent_launches(self.prev)
+        return False
+
+
 class PackedEmbedding:
     """The embedding table re-laid out for the gather kernels (capamd_pack_embeddings).
 

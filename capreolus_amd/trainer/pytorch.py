@@ -77,6 +77,10 @@ class PytorchTrainer:
         "batch": 32, "evalbatch": 0, "niters": 20, "itersize": 512, "gradacc": 1, "lr": 0.001, "softmaxloss": False,
         "fastforward": False, "validatefreq": 1, "multithread": False, "boardname": "default", "warmupiters": 0,
         "decay": 0.0, "decayiters": 3, "decaytype": None, "amp": None, "seed": 123,
+        # this engine's own: `predict` hands the scorer one batch per `coalesce` pairs instead of one per DataLoader batch (the
+        # reference default evalbatch = batch = 32 would be 32-workgroup launches on a 256-CU chip); 0 = one call per DataLoader
+        # batch with the reference's fill-by-repetition of the last one.  The scores do not depend on it (pairs are independent).
+        "coalesce": 16384,
     }
     # amp = "pred" / "both" at prediction time (reference :323-326, 343: autocast around `reranker.test`) selects nothing here: the
     # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
@@ -371,15 +375,42 @@ class PytorchTrainer:
         if count > 0:
             loader = torch.utils.data.DataLoader(part, batch_size=evalbatch, pin_memory=self.device.type == "cuda",
                                                  num_workers=workers)
+            coalesce = self.config["coalesce"]
+            pending, n_pending = [], 0
+
+            def score(batch, n):
+                dbatch = {k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in batch.items()}
+                scores = reranker.test(dbatch).view(-1)[:n]
+                chunks.append(scores.float())      # stays on the device: no per-batch sync
+                keys.extend(zip(batch["qid"][:n], batch["posdocid"][:n]))
+
+            def flush():
+                if not pending:
+                    return
+                if len(pending) == 1:
+                    merged = pending[0]
+                else:
+                    merged = {k: (torch.cat([b[k] for b in pending]) if torch.is_tensor(v) else
+                                  np.concatenate([b[k] for b in pending]) if isinstance(v, np.ndarray) else
+                                  [x for b in pending for x in b[k]])
+                              for k, v in pending[0].items()}
+                score(merged, len(merged["qid"]))
+                pending.clear()
+
             with torch.no_grad():
                 for batch in loader:
                     n = len(batch["qid"])
+                    if coalesce > 0:
+                        pending.append(batch)
+                        n_pending += n
+                        if n_pending >= coalesce:
+                            flush()
+                            n_pending = 0
+                        continue
                     if n != evalbatch:
                         batch = self.fill_incomplete_batch(batch, batch_size=evalbatch)
-                    dbatch = {k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in batch.items()}
-                    scores = reranker.test(dbatch).view(-1)[:n]
-                    chunks.append(scores.float())      # stays on the device: no per-batch sync
-                    keys.extend(zip(batch["qid"][:n], batch["posdocid"][:n]))
+                    score(batch, n)
+                flush()
         local = torch.cat(chunks) if chunks else torch.zeros(0, device=self.device)
         if local.numel() != count:
             raise RuntimeError(f"rank {rank} scored {local.numel()} pairs, expected {count}")

@@ -48,6 +48,12 @@ extern "C" {
 int capamd_version(void);
 const char* capamd_arch(void); /* "gfx950" */
 
+/* Launch hint (process-wide; returns the previous value).  on = 1: the caller keeps several scoring calls in flight on different
+ * streams (one candidate list per launch, the reference's PytorchTrainer.predict loop at small evalbatch, trainer/pytorch.py:334-348),
+ * so a small launch no longer has the chip to itself: the interaction kernels then use their occupancy-oriented variant at every
+ * batch size instead of the latency-oriented one they pick for a lone launch of <= 1536 pairs.  Scores are bit-identical either way. */
+int capamd_set_concurrent_launches(int on);
+
 /* ---- embedding table ------------------------------------------------------------------------
  * Replaces create_emb_layer + nn.Embedding lookup (capreolus/reranker/common.py:279-288, :161).
  * The fp32 [V, D] table (row 0 = zeros, extractor/common.py:38-40) is re-laid out once into

@@ -340,6 +340,40 @@ def test_predict_end_to_end_on_gpu(tmp_path):
     assert list(run.keys()) == ["3", "7"]  # qids in integer order (searcher/__init__.py:51)
 
 
+def test_predict_at_the_reference_default_evalbatch_coalesces_launches():
+    """evalbatch = batch = 32 (reference trainer/pytorch.py:24-25, 334) would be 32-workgroup launches: `predict` hands the kernel one
+    batch per `coalesce` pairs instead.  Same predictions bit for bit as one scoring call per DataLoader batch; 1 launch, not 7."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "ranklist")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = {"1": [f"d{i}" for i in range(B)]}
+
+        def __iter__(self):
+            for i in range(B):
+                yield {"qid": "1", "posdocid": f"d{i}", "query": c["query"][i], "posdoc": c["posdoc"][i], "query_idf": c["query_idf"][i]}
+
+        def __len__(self):
+            return B
+
+        def get_qid_docid_pairs(self):
+            return (("1", f"d{i}") for i in range(B))
+
+    calls = []
+    orig = r.test
+    r.test = lambda d: (calls.append(len(d["qid"])), orig(d))[1]
+    per_batch = PytorchTrainer({"batch": 32, "coalesce": 0}).predict(r, Sampler())
+    assert calls == [32] * 7                                # 200 pairs: six full batches + one filled by repetition
+    calls.clear()
+    merged = PytorchTrainer({"batch": 32}).predict(r, Sampler())
+    assert calls == [B] and merged == per_batch
+    got = np.array([merged["1"][f"d{i}"] for i in range(B)], dtype=np.float16)
+    assert (got == c["ref_scores_f16"]).mean() > 0.98        # (fp16 rounding-boundary flips only, as test_knrm_rank_order)
+
+
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
 def test_resident_store_matches_extractor_layout(kind, tmp_path):
     """Row N1: int32 tables + index pairs give bit-identical scores to the int64 [B,Q]/[B,L] layout."""

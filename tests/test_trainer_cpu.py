@@ -62,10 +62,16 @@ def _expected(s):
 
 def test_predict_single_process(tmp_path):
     s, r = FakeSampler(), FakeReranker()
-    t = PytorchTrainer({"batch": 8})
+    t = PytorchTrainer({"batch": 8, "coalesce": 0})       # the reference's control flow: one scoring call per DataLoader batch
     preds = t.predict(r, s, tmp_path / "sub" / "run.txt")
     assert preds == _expected(s)
     assert set(r.calls) == {8}  # the short last batch is filled by repetition (reference :339-340)
+    # default: DataLoader batches are coalesced into few large scoring calls - same predictions, far fewer launches
+    r2 = FakeReranker()
+    assert PytorchTrainer({"batch": 8}).predict(r2, s) == preds and r2.calls == [len(s)]
+    r3 = FakeReranker()
+    assert PytorchTrainer({"batch": 8, "coalesce": 20}).predict(r3, s) == preds
+    assert sum(r3.calls) == len(s) and all(c == 24 for c in r3.calls[:-1]) and len(r3.calls) == -(-len(s) // 24)
     run = run_io.load_trec_run(tmp_path / "sub" / "run.txt")
     assert list(run.keys()) == sorted(preds.keys(), key=int)
     for qid in run:
