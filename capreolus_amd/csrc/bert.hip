@@ -10,6 +10,7 @@
 // was measured to give the same logit error: the error is set by the 16-bit GEMM operands.)
 #include "bert_attn.cuh"
 #include "bert_gemm.cuh"
+#include "bert_gemm_ring.cuh"
 #include "capreolus_amd.h"
 #include "cedr_tap.cuh"
 #include <stdlib.h>
@@ -237,9 +238,11 @@ bool dims_ok(const capamd_bert_model* m) {
 // LayerNorm folded into the GEMMs (bert_gemm.cuh) needs every encoder GEMM on the ping-pong kernel: N and K multiples of 256
 bool fused_capable(int H, int F) { return H % 256 == 0 && F % 256 == 0; }
 // per layer, 16-bit: wqkv [3H,H] | wo [H,H] | w1 [F,H] | w2 [H,F]   (+ wqkv' = wqkv . gamma_in | w1' = w1 . ln1_gamma when fused_capable)
-int64_t layer_blob_elems(int H, int F) {
+//   (+ when fused_capable: a chunk-major copy of all six, same order, for the ring kernel)
+int64_t layer_rowmajor_elems(int H, int F) {
   return (int64_t)3 * H * H + (int64_t)H * H + (int64_t)2 * F * H + (fused_capable(H, F) ? (int64_t)3 * H * H + (int64_t)F * H : 0);
 }
+int64_t layer_blob_elems(int H, int F) { return layer_rowmajor_elems(H, F) * (fused_capable(H, F) ? 2 : 1); }
 // per layer, fp32: bqkv 3H | bo H | ln1g H | ln1b H | b1 F | b2 H | ln2g H | ln2b H
 //                | cs_qkv 3H | c_qkv 3H | cs_1 F | c_1 F | g_in H | bo + beta_in H | b2 + ln1b H      (folded-LayerNorm vectors)
 int64_t layer_f32_floats(int H, int F) { return (int64_t)9 * H + F + (int64_t)9 * H + 2 * F; }
@@ -319,6 +322,15 @@ bool pingpong_shape(int64_t M, int N, int K) {
   static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
   return pingpong && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
+// Shapes the 4-wave ring kernel takes (bert_gemm_ring.cuh): whole 256 x 256 tiles, at least 16 k-slices (the ring holds 8 and the
+// tile loop has a head and a tail of 8), an even number of them.  CAPAMD_GEMM_RING=0 keeps the 8-wave ping-pong kernel (A/B runs).
+bool ring_shape(int64_t M, int N, int K) {
+  return M % 256 == 0 && N % 256 == 0 && K % 32 == 0 && K >= 256 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
+}
+bool ring_enabled() {
+  static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_RING"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // passage lengths the attention kernels exist for: every multiple of 32 up to 256, then 384 and 512
 bool supported_length(int S) { return (S >= 32 && S <= 256 && S % 32 == 0) || S == 384 || S == 512; }
 // passages of S tokens (a multiple of 32) that make whole 256-row GEMM tiles: 256 / gcd(S, 256)
@@ -343,6 +355,26 @@ bool chunk_major_enabled() {
 
 template <int EPI, typename T>
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+  if (g.w_cm) {   // both operands chunk-major: the ring kernel or nothing
+    if constexpr (EPI != kEpiBiasResidBf16) {
+      if (!g.a_cm || !ring_shape(g.M, g.N, g.K) || (EPI == kEpiResidStats && !g.out_cm)) return hipErrorInvalidValue;
+      using R = GemmRing<EPI, T>;
+      auto k = gemm_ring_kernel<EPI, T>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+      GemmArgs gg = g;
+      gg.ngroup = column_group(g.N / 256, g.K);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if constexpr (EPI != kEpiBiasResidBf16) {
     // a handful of 256x256 tiles would leave most of the chip idle (the last layer's [CLS]-row tail: M = 256): plain
     // row-major GEMMs with fewer than 64 such tiles go to the 64x64-tile kernel instead (16x the workgroups)
@@ -578,6 +610,9 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
         const T *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
         const T *wqkv_s = w2 + (int64_t)H * F, *w1_s = wqkv_s + (int64_t)3 * H * H;
+        // both operands chunk-major -> the 4-wave ring kernel (bert_gemm_ring.cuh); its weights are the copies behind the row-major ones
+        const bool ring = ring_enabled() && ring_shape(M, 3 * H, H) && ring_shape(M, H, H) && ring_shape(M, F, H) && ring_shape(M, H, F);
+        const int64_t cmo = ring ? layer_rowmajor_elems(H, F) : 0;
         const float *bqkv = fl, *ln1g = fl + 4 * H, *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
         const float* fx = fl + 9 * H + F;
         const float *cs_qkv = fx, *c_qkv = fx + 3 * H, *cs_1 = fx + 6 * H, *c_1 = fx + 6 * H + F, *g_in = fx + 6 * H + 2 * F, *bo_f = g_in + H,
@@ -586,11 +621,12 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         g.H = H; g.S = S; g.heads = m->heads; g.M = (int)M;
         // QKV projection of LN_in(xb): layer 0 reads the normalised embeddings with the plain weights
         g.A = w.xb; g.a_cm = 1; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt; g.out_cm = 1;  // Q, K chunk-major
-        if (l == 0) { g.W = wqkv; g.bias = bqkv; }
-        else { g.W = wqkv_s; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
+        if (l == 0) { g.W = wqkv + cmo; g.bias = bqkv; }
+        else { g.W = wqkv_s + cmo; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
+        g.w_cm = ring;
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
-        AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1};
+        AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1, ring ? 1 : 0};
         if (l == m->layers - 1 && cls_tail_enabled()) {
           // Last layer: only the [CLS] row of every passage is read afterwards and everything after the attention is
           // row-wise - attention for that one query, then the output projection / LayerNorm / FFN / LayerNorm on n_psg
@@ -599,6 +635,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
           T *ctx_c = (T*)w.ctx, *x_c = (T*)w.q, *pre_c = (T*)w.pre, *mid_c = (T*)w.mid;   // (x_c reuses the Q buffer once Q is dead)
           const float *bo = fl + 3 * H, *ln1b = fl + 5 * H, *b1 = fl + 6 * H, *b2 = fl + 6 * H + F;
           const float* beta_in = l > 0 ? (fl - layer_f32_floats(H, F)) + 8 * H + F : nullptr;
+          at.ctx_cm = 0;   // (the [CLS]-row tail runs on compact row-major rows)
           (void)hipMemsetAsync(ctx_c + np * H, 0, (size_t)(npad - np) * H * 2, s);
           hipLaunchKernelGGL(cls_attention_kernel<T>, dim3((unsigned)(np * m->heads)), dim3(64), 0, s, at, S, ctx_c);
           (void)hipMemsetAsync(x_c + np * H, 0, (size_t)(npad - np) * H * 2, s);   // (inside the Q buffer: only after its last reader)
@@ -624,14 +661,14 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         launch_attention<T>(at, S, (unsigned)(np * m->heads), s);
         // pre = ctx Wo^T + bo + LN_in(xb)   (+ row statistics of pre)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.W = wo; g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
+        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
         g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_p, w.rstd_p, w.mr_p);
         // mid = gelu(LN1(pre) W1^T + b1)
         g = GemmArgs{};
-        g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
+        g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s + cmo; g.w_cm = ring; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
         g.out_bf16 = w.mid; g.out_cm = 1;
         Ffn1Timing::begin(s);
         e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
@@ -639,7 +676,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         if (e != hipSuccess) break;
         // xb = mid W2^T + b2 + LN1(pre)   (+ row statistics of xb)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2; g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
+        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
         g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
@@ -671,7 +708,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       g.A = w.xb; g.W = wqkv; g.bias = bqkv; g.M = (int)M; g.N = 3 * H; g.K = H; g.out_bf16 = w.q; g.out_k = w.k; g.out_vt = w.vt;
       e = launch_gemm<kEpiQkv, T>(g, s);
       if (e != hipSuccess) break;
-      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 0};
+      AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 0, 0};
       const unsigned nblk = (unsigned)(np * m->heads);
       launch_attention<T>(at, S, nblk, s);
       // attention output projection; the residual is added in fp32 inside the LayerNorm pass (one rounding, and the
@@ -785,6 +822,12 @@ int capamd_bert_pack_layer(const capamd_bert_model* m, int layer, const float* c
   if (fused_capable((int)H, (int)F)) {
     if (m->compute_dtype == 1) pack_folded<_Float16>(t, H, F, wb, fb, s);
     else pack_folded<__bf16>(t, H, F, wb, fb, s);
+    // chunk-major copies of the six matrices (same order, after the row-major ones): the ring kernel's weight operand
+    struct { int64_t off, rows, K; } mats[] = {{0, 3 * H, H}, {3 * H * H, H, H}, {4 * H * H, F, H}, {4 * H * H + F * H, H, F},
+                                               {4 * H * H + 2 * F * H, 3 * H, H}, {7 * H * H + 2 * F * H, F, H}};
+    uint16_t* cmb = wb + layer_rowmajor_elems((int)H, (int)F);
+    for (auto& mt : mats)   // (a 16-bit copy: the element type does not matter)
+      hipLaunchKernelGGL(to_chunk_major_kernel<uint16_t>, dim3(512), dim3(256), 0, s, (const uint16_t*)(wb + mt.off), cmb + mt.off, (int)mt.rows, (int)mt.K);
   }
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
@@ -906,8 +949,10 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   // layout bits of `epilogue`: the chunk-major activation layout exists only on the ping-pong kernel's shapes
   g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
+  g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   epilogue &= 0xff;
   if ((g.a_cm || g.out_cm) && (!pingpong_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
+  if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
   if (dtype == 1) return gemm_dispatch<_Float16>(g, epilogue, resid, out, (hipStream_t)stream);
   if (dtype == 0) return gemm_dispatch<__bf16>(g, epilogue, resid, out, (hipStream_t)stream);
   return CAPAMD_ERR_ARG;
@@ -922,7 +967,9 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
   g.A = A; g.W = W; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out_bf16 = out;
   g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
+  g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   epilogue &= 0xff;
+  if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K))) return CAPAMD_ERR_ARG;
   if (ln_mu) {
     if (!ln_rstd || !ln_mr || !ln_cs) return CAPAMD_ERR_ARG;
     g.ln_mu = ln_mu; g.ln_rstd = ln_rstd; g.ln_mr = (const float2*)ln_mr; g.ln_cs = ln_cs;
@@ -956,7 +1003,7 @@ int capamd_bert_qkv_attention(const void* x, const void* wqkv, const float* bqkv
   if (dtype != 0 && dtype != 1) return CAPAMD_ERR_ARG;
   const hipError_t e = dtype == 1 ? launch_gemm<kEpiQkv, _Float16>(g, s) : launch_gemm<kEpiQkv, __bf16>(g, s);
   if (e != hipSuccess) return CAPAMD_ERR_LAUNCH;
-  AttnArgs at{q, k, vt, mask, ctx, hidden, heads, 0};
+  AttnArgs at{q, k, vt, mask, ctx, hidden, heads, 0, 0};
   const unsigned nblk = (unsigned)(n_passages * heads);
   if (dtype == 1) launch_attention<_Float16>(at, S, nblk, s);
   else launch_attention<__bf16>(at, S, nblk, s);

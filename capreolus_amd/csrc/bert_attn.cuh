@@ -27,7 +27,17 @@ struct AttnArgs {
   void* ctx;             // [M, H]
   int H, heads;
   int qk_cm;             // Q and K in the chunk-major activation layout (bert_gemm.cuh cm_offset) instead of row-major
+  int ctx_cm;            // ctx written chunk-major (the A operand of the ring GEMM, bert_gemm_ring.cuh) instead of row-major
 };
+
+// where lane (query row `tok`, half) stores its 4 consecutive output dimensions d = 32 dt + 8 g4 + 4 half .. + 3 of head `head`:
+// chunk-major, the 32 rows of a wave x one 16-byte chunk are 512 contiguous bytes (both halves of a lane pair fill one chunk)
+template <typename T>
+__device__ __forceinline__ T* ctx_slot(const AttnArgs& a, int64_t tok, int head, int dt, int g4, int half) {
+  T* c = static_cast<T*>(a.ctx);
+  if (a.ctx_cm) return c + (((tok >> 5) * (a.H >> 3) + head * 8 + dt * 4 + g4) * 32 + (tok & 31)) * 8 + 4 * half;
+  return c + tok * a.H + head * 64 + dt * 32 + 8 * g4 + 4 * half;
+}
 
 // element offset of the 16-byte chunk `chunk` (0..H/8) of token row `tok` in a [M, H] activation, either layout
 __device__ __forceinline__ int64_t qk_offset(const AttnArgs& a, int64_t tok, int chunk) {
@@ -171,14 +181,14 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
         out[dt] = Half<T>::mfma(vf, pf, out[dt]);
       }
     }
-  T* crow = static_cast<T*>(a.ctx) + (tok0 + qwave * 32 + l31) * a.H + head * 64;
+  const int64_t ctok = tok0 + qwave * 32 + l31;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv),
                   (T)(out[dt][g4 * 4 + 2] * inv), (T)(out[dt][g4 * 4 + 3] * inv)};
-      *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+      *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
     }
 }
 
@@ -297,14 +307,14 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
       }
     {
       const int psg = item / a.heads, head = item % a.heads;
-      T* crow = static_cast<T*>(a.ctx) + ((int64_t)psg * S + wave * 32 + l31) * a.H + head * 64;
+      const int64_t ctok = (int64_t)psg * S + wave * 32 + l31;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
                       (T)(out[dt][g4 * 4 + 3] * inv)};
-          *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+          *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
         }
     }
     if (!more) break;
@@ -484,14 +494,14 @@ __global__ __launch_bounds__(S * 2) void attention_long_kernel(AttnArgs a) {
       }
   }
   const float inv = 1.f / l_run;
-  T* crow = static_cast<T*>(a.ctx) + (tok0 + wave * 32 + l31) * a.H + head * 64;
+  const int64_t ctok = tok0 + wave * 32 + l31;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
                   (T)(out[dt][g4 * 4 + 3] * inv)};
-      *reinterpret_cast<bf16x4*>(crow + dt * 32 + 8 * g4 + 4 * half) = o;
+      *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
     }
 }
 

@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace capamd {
 
@@ -79,6 +80,7 @@ struct GemmArgs {
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
   int ngroup;           // column tiles per scheduling group (divides N / 256; 0 = all of them)
   int a_cm, out_cm;     // A operand / output in the chunk-major activation layout (see cm_offset) instead of row-major
+  int w_cm;             // W chunk-major as well: the 4-wave ring kernel (bert_gemm_ring.cuh; needs a_cm too)
   // ---- fused LayerNorm (see "LayerNorm folded into the GEMMs" below) ----
   // consumer side: A holds the UN-normalised pre-LayerNorm sums P; with W' = W . gamma packed as the weight matrix,
   //   LN(P) W^T + b  ==  rstd_m (acc - mu_m cs_n) + c_n ,   cs_n = sum_k W'[n][k],  c_n = b_n + sum_k beta_k W[n][k]  (passed as `bias`)
@@ -99,6 +101,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #ifndef CAPAMD_PP_GLDS_POS
 #define CAPAMD_PP_GLDS_POS 2   // where a phase issues its LDS-DMA pair: 0 before its LDS reads, 1 after them, 2 after its first MFMA pair, 3 one after the first and one after the third pair
+#endif
+#ifndef CAPAMD_PP_LOADS_HALF
+#define CAPAMD_PP_LOADS_HALF 0     // four decimal digits (phases P1..P4): pieces of the phase's LDS-DMA pair issued in its loads half, before the LDS reads
+#endif
+#ifndef CAPAMD_PP_MFMA_SLOT
+#define CAPAMD_PP_MFMA_SLOT 0      // after which MFMA pair (0..3) of the MFMA half the remaining pieces are issued
 #endif
 #ifndef CAPAMD_PP_A_NT
 #define CAPAMD_PP_A_NT 0   // 1: activation-panel LDS-DMA with the nt (streaming) cache policy - A/B builds only
@@ -537,9 +545,164 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmA
 //     head of its MFMA half - the loads half never waits for LDS latency - so the slot is re-staged from the loads of
 //     phase p+2 on (row 1 retires its reads of phase p one barrier before row 0 starts the loads of phase p+2).
 // =====================================================================================================================
+// Register-direct epilogues into the chunk-major layout, shared by the 8-wave ping-pong kernel (wave tile 128 x 64) and the 4-wave ring
+// kernel (128 x 128): G = the GemmKernel<> geometry (TN 32-column tiles per wave, WMT x WNT wave tile, Lane).
+template <typename G, int EPI, typename T>
+struct CmEpilogue {
+  using Lane = typename G::Lane;
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
+  static constexpr int TN = G::TN, WNT = G::WNT, WMT = G::WMT;
+  static_assert(G::TM == 4 && TN % 2 == 0, "a wave owns 128 rows and whole 64-column statistic slots");
+
+  // lanes 32..63 of x <-> lanes 0..31 of y
+  // (inline asm: the compiler's hazard recogniser cannot see the cross-lane read, so the wait states a VALU-written
+  // operand needs before a lane-crossing instruction are inserted by hand)
+  static __device__ __forceinline__ void swap32(unsigned& x, unsigned& y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  }
+
+  // Epilogue into a chunk-major output (cm_offset): bias (or the folded-LayerNorm form) (+ Q/8, + GELU) in registers, the
+  // two lanes that share a row exchange their 8-byte halves (v_permlane32_swap) so each ends up with one whole 16-byte
+  // chunk, and every store instruction writes 1 KiB contiguous (two adjacent chunks x 32 rows).  No LDS, no waits.
+  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][4]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    int ncols = a.N, nloc = n0 + L.wn * WNT;
+    float scale = 1.f;
+    if (EPI == kEpiQkv) {
+      ncols = a.H;
+      if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
+      else scale = 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in 16-bit)
+    }
+    const bool ln = a.ln_mu != nullptr;
+    float2 mr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      float4 b4[4], cs4[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half;
+        b4[g4] = *reinterpret_cast<const float4*>(a.bias + n);
+        cs4[g4] = ln ? *reinterpret_cast<const float4*>(a.ln_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
+        const float mu = mr[j].x, rs = mr[j].y;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // rstd_m (acc - mu_m cs_n) + c_n ; with mu = 0, rstd = 1 this is acc + bias exactly
+          float v[4] = {rs * (acc[i][j][g4 * 4 + 0] - mu * cs4[g4].x) + b4[g4].x, rs * (acc[i][j][g4 * 4 + 1] - mu * cs4[g4].y) + b4[g4].y,
+                        rs * (acc[i][j][g4 * 4 + 2] - mu * cs4[g4].z) + b4[g4].z, rs * (acc[i][j][g4 * 4 + 3] - mu * cs4[g4].w) + b4[g4].w};
+          if (EPI == kEpiQkv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+          }
+          if (EPI == kEpiBiasGeluBf16) {
+            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+            v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+          }
+          const bf16x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          pk[g4][0] = u.x; pk[g4][1] = u.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          // the lower lane collects chunk 2p (its own 4 values + the upper lane's), the upper lane chunk 2p+1
+          swap32(pk[2 * p][0], pk[2 * p + 1][0]);
+          swap32(pk[2 * p][1], pk[2 * p + 1][1]);
+          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
+          const int64_t off = ((mblk * (ncols >> 3) + chunk) * 32 + L.l31) * 8;
+          *reinterpret_cast<uint4*>(base + off) = make_uint4(pk[2 * p][0], pk[2 * p][1], pk[2 * p + 1][0], pk[2 * p + 1][1]);
+        }
+      }
+    }
+  }
+
+  // kEpiResidStats: the pre-LayerNorm sum of a residual block, chunk-major, with the LayerNorm of the block's input
+  // re-computed on the fly and the row statistics of the result collected for the next LayerNorm:
+  //     P[m][n] = acc + bias'[n] + (R[m][n] - rmu_m) rrstd_m rgamma_n           (bias' = b + rbeta, folded when packed)
+  //     stat_part[m][n0/64 + wn] = (sum_n P, sum_n P^2) over this wave's 64 columns, of the ROUNDED values the consumers
+  //     will read.  fp32 sum, one rounding; the residual is read with coalesced 8-byte loads at the positions the lane's
+  //     own values will occupy (chunk-major), so no LDS and no transposition is involved.
+  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][4]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    const T* rsrc = static_cast<const T*>(a.res_src);
+    const int nchunks = a.N >> 3, nloc = n0 + L.wn * WNT, nslot = a.N >> 6;
+    float2 mr[4];
+    float s1[TN / 2][4], s2[TN / 2][4];     // per 64-column slot of the wave's WNT columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mr[j] = a.res_mr[m0 + L.wm * WMT + j * 32 + L.l31];
+#pragma unroll
+      for (int sl = 0; sl < TN / 2; ++sl) s1[sl][j] = s2[sl][j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
+      float4 bb[2][2], gg[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = n0 + L.wn * WNT + i * 32 + (2 * p + L.half) * 8;
+        bb[p][0] = *reinterpret_cast<const float4*>(a.bias + n); bb[p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        gg[p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); gg[p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
+        const float rmu = mr[j].x, rrs = mr[j].y;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          // fp32 exchange: lanes 32..63 of the first operand <-> lanes 0..31 of the second.  Afterwards the lower lane holds
+          // chunk 2p (n 0..3 its own, 4..7 from the upper lane), the upper lane chunk 2p+1, both as v[0..7] in order
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (element -> named float -> bits: __builtin_bit_cast applied directly to a vector element picked element 0 every time)
+            const float fx = acc[i][j][(2 * p) * 4 + e], fy = acc[i][j][(2 * p + 1) * 4 + e];
+            unsigned x = __float_as_uint(fx), y = __float_as_uint(fy);
+            swap32(x, y);
+            v[e] = __uint_as_float(x);
+            v[4 + e] = __uint_as_float(y);
+          }
+          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
+          const int64_t off = ((mblk * nchunks + chunk) * 32 + L.l31) * 8;
+          const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rsrc + off);
+          const float bv[8] = {bb[p][0].x, bb[p][0].y, bb[p][0].z, bb[p][0].w, bb[p][1].x, bb[p][1].y, bb[p][1].z, bb[p][1].w};
+          const float gv[8] = {gg[p][0].x, gg[p][0].y, gg[p][0].z, gg[p][0].w, gg[p][1].x, gg[p][1].y, gg[p][1].z, gg[p][1].w};
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = (T)(v[e] + bv[e] + ((float)r8[e] - rmu) * rrs * gv[e]);   // fp32 sum, ONE rounding
+            const float q = (float)o[e];                                    // statistics of what the consumers will read
+            s1[i >> 1][j] += q;
+            s2[i >> 1][j] = __builtin_fmaf(q, q, s2[i >> 1][j]);
+          }
+          *reinterpret_cast<bf16x8*>(base + off) = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < TN / 2; ++sl)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // the two lanes of a row hold its 2 x 32 columns: add them and let the lower lane write the wave's partial
+        const float t1 = s1[sl][j] + __shfl_xor(s1[sl][j], 32, 64), t2 = s2[sl][j] + __shfl_xor(s2[sl][j], 32, 64);
+        const int mrow = m0 + L.wm * WMT + j * 32 + L.l31;
+        if (L.half == 0)
+          *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + ((n0 + L.wn * WNT) >> 6) + sl) * 2) = make_float2(t1, t2);
+      }
+  }
+
+};
+
 template <int EPI, typename T>
 struct GemmPingPong {
   using G = GemmKernel<256, 256, 2, 4, EPI, T>;  // epilogues and wave-tile geometry (WMT 128, WNT 64, TM 4, TN 2)
+  using CE = CmEpilogue<G, EPI, T>;
   using Lane = typename G::Lane;
   using bf16x8 = typename Half<T>::x8;
   using bf16x4 = typename Half<T>::x4;
@@ -642,18 +805,27 @@ struct GemmPingPong {
     // the half-tile(s) read in the NEXT phase must have landed as far as this wave's pieces go: vmcnt(8) = the four
     // half-tiles issued after the needed one stay in flight.  The phase's own LDS reads are only waited for after the
     // barrier, at the head of the MFMA half.
-    auto phase = [&](auto&& stage_fn, auto&& reads_fn, bool needed, const bf16x8 (&b)[4], int i, int j0) {
+    // LH = pieces (0, 1, 2) of the phase's half-tile issued in the LOADS half, before its LDS reads; the rest go between the MFMAs.
+    // (CAPAMD_PP_GLDS_POS 0 / 1 / 3: the older all-or-nothing placements, kept for A/B builds.)
+    auto phase = [&](auto lh_c, auto&& stage_fn, auto&& reads_fn, bool needed, const bf16x8 (&b)[4], int i, int j0) {
+      constexpr int LH = decltype(lh_c)::value;
 #if CAPAMD_PP_GLDS_POS == 0
       stage_fn(3);
       reads_fn();
 #elif CAPAMD_PP_GLDS_POS == 1
       reads_fn();
       stage_fn(3);
+#elif CAPAMD_PP_GLDS_POS == 2
+      if (LH == 1) stage_fn(1);
+      if (LH == 2) stage_fn(3);
+      reads_fn();
 #else
       reads_fn();
 #endif
       if (needed) {
-        if (FILL == 2) wait_vmcnt<(CAPAMD_PP_GLDS_POS >= 2 ? 6 : 8)>();
+        // the half-tile read in the next phase was issued four phases ago: the six pieces of the three phases in between and this
+        // phase's LH pieces may stay in flight
+        if (FILL == 2) wait_vmcnt<(CAPAMD_PP_GLDS_POS == 2 ? 6 + LH : CAPAMD_PP_GLDS_POS == 3 ? 6 : 8)>();
         else wait_vmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -671,7 +843,7 @@ struct GemmPingPong {
         for (int jj = 0; jj < 2; ++jj)
           acc[i][j0 + jj] = TRANS ? Half<T>::mfma(fa[jj][ks], b[ks], acc[i][j0 + jj]) : Half<T>::mfma(b[ks], fa[jj][ks], acc[i][j0 + jj]);
 #if CAPAMD_PP_GLDS_POS == 2
-        if (ks == 0) { __builtin_amdgcn_sched_barrier(0); stage_fn(3); __builtin_amdgcn_sched_barrier(0); }
+        if (ks == CAPAMD_PP_MFMA_SLOT && LH < 2) { __builtin_amdgcn_sched_barrier(0); stage_fn(LH == 1 ? 2 : 3); __builtin_amdgcn_sched_barrier(0); }
 #elif CAPAMD_PP_GLDS_POS == 3
         if (ks == 0) { __builtin_amdgcn_sched_barrier(0); stage_fn(1); __builtin_amdgcn_sched_barrier(0); }
         if (ks == 2) { __builtin_amdgcn_sched_barrier(0); stage_fn(2); __builtin_amdgcn_sched_barrier(0); }
@@ -682,6 +854,10 @@ struct GemmPingPong {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
     };
+    using LH1 = std::integral_constant<int, (CAPAMD_PP_LOADS_HALF / 1000) % 10>;
+    using LH2 = std::integral_constant<int, (CAPAMD_PP_LOADS_HALF / 100) % 10>;
+    using LH3 = std::integral_constant<int, (CAPAMD_PP_LOADS_HALF / 10) % 10>;
+    using LH4 = std::integral_constant<int, CAPAMD_PP_LOADS_HALF % 10>;
     auto read_a = [&](int kind) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -693,16 +869,16 @@ struct GemmPingPong {
       for (int ks = 0; ks < 4; ++ks) fb[ks] = rd(buf + kind * kHalfTile, c.b_row, c.koff[ks]);
     };
     // P1 (A0, B0): stages B1 of step g+1; needs B1 of this step next
-    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kB1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kB1, 1>(c, lds, bcur ^ 1, s1); else stage<kB1, 2>(c, lds, bcur ^ 1, s1); } },
+    phase(LH1{}, [&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kB1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kB1, 1>(c, lds, bcur ^ 1, s1); else stage<kB1, 2>(c, lds, bcur ^ 1, s1); } },
           [&] { read_b(kB0, fb0); read_a(kA0); }, true, fb0, 0, 0);
     // P2 (A0, B1): stages A1 of step g+1; needs A1 of this step next
-    phase([&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kA1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kA1, 1>(c, lds, bcur ^ 1, s1); else stage<kA1, 2>(c, lds, bcur ^ 1, s1); } },
+    phase(LH2{}, [&](int pc) { if (FILL >= 1) { if (pc == 3) stage<kA1, 3>(c, lds, bcur ^ 1, s1); else if (pc == 1) stage<kA1, 1>(c, lds, bcur ^ 1, s1); else stage<kA1, 2>(c, lds, bcur ^ 1, s1); } },
           [&] { read_b(kB1, fb1); }, true, fb1, 1, 0);
     // P3 (A1, B1): stages A0 of step g+2
-    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kA0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kA0, 1>(c, lds, bcur, s2); else stage<kA0, 2>(c, lds, bcur, s2); } },
+    phase(LH3{}, [&](int pc) { if (FILL == 2) { if (pc == 3) stage<kA0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kA0, 1>(c, lds, bcur, s2); else stage<kA0, 2>(c, lds, bcur, s2); } },
           [&] { read_a(kA1); }, false, fb1, 1, 2);
     // P4 (A1, B0): stages B0 of step g+2; needs A0, B0 of the next step next
-    phase([&](int pc) { if (FILL == 2) { if (pc == 3) stage<kB0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kB0, 1>(c, lds, bcur, s2); else stage<kB0, 2>(c, lds, bcur, s2); } },
+    phase(LH4{}, [&](int pc) { if (FILL == 2) { if (pc == 3) stage<kB0, 3>(c, lds, bcur, s2); else if (pc == 1) stage<kB0, 1>(c, lds, bcur, s2); else stage<kB0, 2>(c, lds, bcur, s2); } },
           [&] {}, !last, fb0, 0, 2);
   }
 
@@ -726,144 +902,6 @@ struct GemmPingPong {
       k_step<TRANS, 0>(c, lds, (t.gk + g) & 1, Src{0u, 0u}, Src{0u, 0u}, true, acc, fa, fb0, fb1);
     }
     if (L.wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two wave rows: both run the epilogue at once
-  }
-
-  // lanes 32..63 of x <-> lanes 0..31 of y
-  // (inline asm: the compiler's hazard recogniser cannot see the cross-lane read, so the wait states a VALU-written
-  // operand needs before a lane-crossing instruction are inserted by hand)
-  static __device__ __forceinline__ void swap32(unsigned& x, unsigned& y) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-  }
-
-  // Epilogue into a chunk-major output (cm_offset): bias (or the folded-LayerNorm form) (+ Q/8, + GELU) in registers, the
-  // two lanes that share a row exchange their 8-byte halves (v_permlane32_swap) so each ends up with one whole 16-byte
-  // chunk, and every store instruction writes 1 KiB contiguous (two adjacent chunks x 32 rows).  No LDS, no waits.
-  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[2][4]) {
-    T* base = static_cast<T*>(a.out_bf16);
-    int ncols = a.N, nloc = n0 + L.wn * 64;
-    float scale = 1.f;
-    if (EPI == kEpiQkv) {
-      ncols = a.H;
-      if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
-      else scale = 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in 16-bit)
-    }
-    const bool ln = a.ln_mu != nullptr;
-    float2 mr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * 128 + j * 32 + L.l31] : make_float2(0.f, 1.f);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float4 b4[4], cs4[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + L.wn * 64 + i * 32 + 8 * g4 + 4 * L.half;
-        b4[g4] = *reinterpret_cast<const float4*>(a.bias + n);
-        cs4[g4] = ln ? *reinterpret_cast<const float4*>(a.ln_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t mblk = (m0 + L.wm * 128 + j * 32) >> 5;
-        const float mu = mr[j].x, rs = mr[j].y;
-        unsigned pk[4][2];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          // rstd_m (acc - mu_m cs_n) + c_n ; with mu = 0, rstd = 1 this is acc + bias exactly
-          float v[4] = {rs * (acc[i][j][g4 * 4 + 0] - mu * cs4[g4].x) + b4[g4].x, rs * (acc[i][j][g4 * 4 + 1] - mu * cs4[g4].y) + b4[g4].y,
-                        rs * (acc[i][j][g4 * 4 + 2] - mu * cs4[g4].z) + b4[g4].z, rs * (acc[i][j][g4 * 4 + 3] - mu * cs4[g4].w) + b4[g4].w};
-          if (EPI == kEpiQkv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= scale;
-          }
-          if (EPI == kEpiBiasGeluBf16) {
-            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
-            v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
-          }
-          const bf16x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-          const uint2 u = __builtin_bit_cast(uint2, o);
-          pk[g4][0] = u.x; pk[g4][1] = u.y;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          // the lower lane collects chunk 2p (its own 4 values + the upper lane's), the upper lane chunk 2p+1
-          swap32(pk[2 * p][0], pk[2 * p + 1][0]);
-          swap32(pk[2 * p][1], pk[2 * p + 1][1]);
-          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
-          const int64_t off = ((mblk * (ncols >> 3) + chunk) * 32 + L.l31) * 8;
-          *reinterpret_cast<uint4*>(base + off) = make_uint4(pk[2 * p][0], pk[2 * p][1], pk[2 * p + 1][0], pk[2 * p + 1][1]);
-        }
-      }
-    }
-  }
-
-  // kEpiResidStats: the pre-LayerNorm sum of a residual block, chunk-major, with the LayerNorm of the block's input
-  // re-computed on the fly and the row statistics of the result collected for the next LayerNorm:
-  //     P[m][n] = acc + bias'[n] + (R[m][n] - rmu_m) rrstd_m rgamma_n           (bias' = b + rbeta, folded when packed)
-  //     stat_part[m][n0/64 + wn] = (sum_n P, sum_n P^2) over this wave's 64 columns, of the ROUNDED values the consumers
-  //     will read.  fp32 sum, one rounding; the residual is read with coalesced 8-byte loads at the positions the lane's
-  //     own values will occupy (chunk-major), so no LDS and no transposition is involved.
-  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[2][4]) {
-    T* base = static_cast<T*>(a.out_bf16);
-    const T* rsrc = static_cast<const T*>(a.res_src);
-    const int nchunks = a.N >> 3, nloc = n0 + L.wn * 64, nslot = a.N >> 6;
-    float2 mr[4];
-    float s1[4], s2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mr[j] = a.res_mr[m0 + L.wm * 128 + j * 32 + L.l31];
-      s1[j] = s2[j] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
-      float4 bb[2][2], gg[2][2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int n = n0 + L.wn * 64 + i * 32 + (2 * p + L.half) * 8;
-        bb[p][0] = *reinterpret_cast<const float4*>(a.bias + n); bb[p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
-        gg[p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); gg[p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t mblk = (m0 + L.wm * 128 + j * 32) >> 5;
-        const float rmu = mr[j].x, rrs = mr[j].y;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          // fp32 exchange: lanes 32..63 of the first operand <-> lanes 0..31 of the second.  Afterwards the lower lane holds
-          // chunk 2p (n 0..3 its own, 4..7 from the upper lane), the upper lane chunk 2p+1, both as v[0..7] in order
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // (element -> named float -> bits: __builtin_bit_cast applied directly to a vector element picked element 0 every time)
-            const float fx = acc[i][j][(2 * p) * 4 + e], fy = acc[i][j][(2 * p + 1) * 4 + e];
-            unsigned x = __float_as_uint(fx), y = __float_as_uint(fy);
-            swap32(x, y);
-            v[e] = __uint_as_float(x);
-            v[4 + e] = __uint_as_float(y);
-          }
-          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
-          const int64_t off = ((mblk * nchunks + chunk) * 32 + L.l31) * 8;
-          const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rsrc + off);
-          const float bv[8] = {bb[p][0].x, bb[p][0].y, bb[p][0].z, bb[p][0].w, bb[p][1].x, bb[p][1].y, bb[p][1].z, bb[p][1].w};
-          const float gv[8] = {gg[p][0].x, gg[p][0].y, gg[p][0].z, gg[p][0].w, gg[p][1].x, gg[p][1].y, gg[p][1].z, gg[p][1].w};
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] = (T)(v[e] + bv[e] + ((float)r8[e] - rmu) * rrs * gv[e]);   // fp32 sum, ONE rounding
-            const float q = (float)o[e];                                    // statistics of what the consumers will read
-            s1[j] += q;
-            s2[j] = __builtin_fmaf(q, q, s2[j]);
-          }
-          *reinterpret_cast<bf16x8*>(base + off) = o;
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // the two lanes of a row hold its 2 x 32 columns: add them and let the lower lane write the wave's partial
-      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-      const int mrow = m0 + L.wm * 128 + j * 32 + L.l31;
-      if (L.half == 0) *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + (n0 >> 6) + L.wn) * 2) = make_float2(t1, t2);
-    }
   }
 
   static __device__ __forceinline__ void run(const GemmArgs& a, char* lds) {
@@ -901,9 +939,9 @@ struct GemmPingPong {
       if constexpr (G::kResid) {
         G::epilogue_resid(a, wl, t.m0, t.n0, L, acc, rs);
       } else {
-        if constexpr (EPI == kEpiResidStats) epilogue_cm_resid(a, t.m0, t.n0, L, acc);
+        if constexpr (EPI == kEpiResidStats) CE::epilogue_cm_resid(a, t.m0, t.n0, L, acc);
         else if (trans) G::template epilogue<true>(a, wl, t.m0, t.n0, L, acc, rs);
-        else if (a.out_cm) epilogue_cm(a, t.m0, t.n0, L, acc);
+        else if (a.out_cm) CE::epilogue_cm(a, t.m0, t.n0, L, acc);
         else G::template epilogue<false>(a, wl, t.m0, t.n0, L, acc, rs);
       }
       CAPAMD_STAMP();

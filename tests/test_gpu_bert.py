@@ -458,6 +458,13 @@ def test_gemm_at_benchmark_scale(N, K, epi, dt):
     out_cm, A_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(A)
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W), _p(bias), M, N, K, epi | 0x300, None, _p(out_cm), code, _stream()) == 0
     assert torch.equal(_from_cm(out_cm, M, N), out)
+    # weights chunk-major too -> the 4-wave ring kernel (bert_gemm_ring.cuh): same accumulation order, identical bits
+    out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(W)
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700, None, _p(out_ring), code, _stream()) == 0
+    assert torch.equal(out_ring, out_cm)
+    out_ring_rm = torch.empty((M, N), dtype=tdt, device=DEV)      # ... and its row-major (LDS-staged) epilogue
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x600, None, _p(out_ring_rm), code, _stream()) == 0
+    assert torch.equal(out_ring_rm, out)
 
 
 @pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1)])
@@ -487,6 +494,10 @@ def test_gemm_folded_layernorm_consumer_at_benchmark_scale(N, K, epi, dt):
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
     _assert_close_big(_from_cm(out, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K}")
+    out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(Ws)      # the ring kernel: identical bits
+    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0x700, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+                                         _p(out_ring), code, _stream())
+    assert rc == 0 and torch.equal(out_ring, out)
 
 
 @pytest.mark.parametrize("N,K", [(768, 768), (768, 3072)])
@@ -513,6 +524,31 @@ def test_gemm_residual_stats_producer_at_benchmark_scale(N, K, dt):
     _assert_close_big(got, ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"residual+stats producer {N}x{K}")
     want = torch.stack([got.reshape(M, N // 64, 64).sum(2), (got * got).reshape(M, N // 64, 64).sum(2)], 2)
     torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-3)
+    out_ring, part_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), torch.zeros((M, N // 64, 2), device=DEV), _to_cm(W)
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0x700, None, None, None, None, _p(R_cm), _p(mr), _p(gamma), _p(part_ring),
+                                         _p(out_ring), code, _stream())
+    assert rc == 0 and torch.equal(out_ring, out) and torch.equal(part_ring, part)      # the ring kernel: identical bits
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (512, 768, 512, 1), (768, 256, 1024, 0)])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_ring_gemm_small_shapes(M, N, K, epi, dt):
+    """The 4-wave ring kernel on a handful of tiles (fewer tiles than CUs, the minimum of 16 k-slices, a tile count that is not a
+    multiple of 8) against fp32 torch."""
+    tdt, code, rtol = TDT[dt]
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + epi)
+    A = (torch.randn((M, K), generator=g, device=DEV) * 0.5).to(tdt)
+    W = (torch.randn((N, K), generator=g, device=DEV) * 0.05 + torch.arange(N, device=DEV)[:, None] * 1e-3).to(tdt)
+    bias = torch.randn(N, generator=g, device=DEV)
+    A_cm, W_cm, out = _to_cm(A), _to_cm(W), torch.empty(M * N, dtype=tdt, device=DEV)
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700, None, _p(out), code, _stream()) == 0
+    ref = A.float() @ W.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    torch.testing.assert_close(_from_cm(out, M, N).float(), ref, rtol=rtol, atol=2e-2 if dt == "bf16" else 3e-3)
+    # shapes / layouts the ring kernel does not take are refused, not mis-computed
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, 128, epi | 0x700, None, _p(out), code, _stream()) != 0
+    assert _lib.load().capamd_bert_gemm(_p(A), _p(W_cm), _p(bias), M, N, K, epi | 0x400, None, _p(out), code, _stream()) != 0
 
 
 @pytest.mark.parametrize("hidden,heads,npsg", [(768, 12, 400), (128, 2, 1024)])
