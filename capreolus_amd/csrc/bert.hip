@@ -327,6 +327,18 @@ bool pingpong_shape(int64_t M, int N, int K) {
 bool ring_shape(int64_t M, int N, int K) {
   return M % 256 == 0 && N % 256 == 0 && K % 32 == 0 && K >= 256 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
+int ring_rows() {   // CAPAMD_RING_BM=256: one workgroup per CU with 128 x 128 wave tiles; default 128: two workgroups per CU (see bert_gemm_ring.cuh)
+  static const int bm = [] { const char* e = getenv("CAPAMD_RING_BM"); return (e && atoi(e) == 256) ? 256 : 128; }();
+  return bm;
+}
+int producer_ring_rows() {   // tile rows of the residual + statistics GEMMs (O-proj, FFN2); CAPAMD_RING_BM overrides every GEMM alike
+  static const int v = [] { const char* e = getenv("CAPAMD_RING_BM"); return e ? 0 : 256; }();
+  return v;
+}
+int ring_stagger_override() {
+  static const int v = [] { const char* e = getenv("CAPAMD_RING_STAGGER"); return e ? atoi(e) : -1; }();
+  return v;
+}
 bool ring_enabled() {
   static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_RING"); return !(e && e[0] == '0'); }();
   return on;
@@ -358,18 +370,34 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if (g.w_cm) {   // both operands chunk-major: the ring kernel or nothing
     if constexpr (EPI != kEpiBiasResidBf16) {
       if (!g.a_cm || !ring_shape(g.M, g.N, g.K) || (EPI == kEpiResidStats && !g.out_cm)) return hipErrorInvalidValue;
-      using R = GemmRing<EPI, T>;
-      auto k = gemm_ring_kernel<EPI, T>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-      }
-      const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
       GemmArgs gg = g;
       gg.ngroup = column_group(g.N / 256, g.K);
-      hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256) {
+        using R = GemmRing<EPI, T, 256>;
+        auto k = gemm_ring_kernel<EPI, T, 256>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
+          if (e != hipSuccess) return e;
+          attr_set = true;
+        }
+        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+        hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      } else {
+        using R = GemmRing<EPI, T, 128>;
+        auto k = gemm_ring_kernel<EPI, T, 128>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
+          if (e != hipSuccess) return e;
+          attr_set = true;
+        }
+        const int tiles = (g.N / 256) * (g.M / 128), cap = 2 * num_cus(), grid = tiles < cap ? tiles : cap;  // two persistent workgroups per CU
+        // (a deliberate half-tile start offset of the grid's second half - CAPAMD_RING_STAGGER, in units of 64 cycles - measured 0.7 %
+        // SLOWER end to end than letting the two workgroups of a CU drift apart by themselves: default 0)
+        gg.ring_stagger = ring_stagger_override() >= 0 ? ring_stagger_override() : 0;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      }
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
@@ -661,7 +689,11 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         launch_attention<T>(at, S, (unsigned)(np * m->heads), s);
         // pre = ctx Wo^T + bo + LN_in(xb)   (+ row statistics of pre)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
+        // (ring kernel, measured per GEMM inside the encoder at M = 64,000: the residual + statistics producers run faster on its 256-row
+        // tile - 181 us against 200 on the 128-row tile and 193 on the ping-pong kernel - QKV and FFN1, with their heavier epilogues,
+        // on the 128-row tile whose two workgroups per CU overlap epilogue and K loop: 248 / 341 us against 253 / 356)
+        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.ring_rows = producer_ring_rows();
+        g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
         g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
@@ -676,7 +708,8 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         if (e != hipSuccess) break;
         // xb = mid W2^T + b2 + LN1(pre)   (+ row statistics of xb)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
+        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.ring_rows = producer_ring_rows();
+        g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
         g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
@@ -950,6 +983,7 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
+  g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
   epilogue &= 0xff;
   if ((g.a_cm || g.out_cm) && (!pingpong_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
@@ -968,6 +1002,7 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
   g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
+  g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
   epilogue &= 0xff;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K))) return CAPAMD_ERR_ARG;
   if (ln_mu) {

@@ -94,6 +94,8 @@ struct GemmArgs {
   const float2* res_mr;                        // [M] (mu, rstd) of the rows of R
   const float* res_gamma;                      // [N]
   float* stat_part;     // [M][N / 64][2]: (sum, sum of squares) of the 64 output columns each wave column writes
+  int ring_rows;        // ring kernel: 256 = one workgroup per CU (128 x 128 wave tiles), 128 = two per CU; 0 = the library default
+  int ring_stagger;     // ring kernel, two workgroups per CU: blocks of the grid's second half start this many x 64 cycles late
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };
 
@@ -164,6 +166,7 @@ struct GemmKernel {
   static constexpr int kHalfBytes = kStageBytes / 2;            // one k-half (32 of the 64 k) of both operands
   static constexpr int kBurst = (BM + BN) * 64 / 1024 / kWaves; // global_load_lds instructions per wave per half-burst
   static constexpr bool kResid = (EPI == kEpiBiasResidBf16);
+  static constexpr bool kAccInAgprs = TN * TM * 16 > 128;        // one wave per SIMD, 256 accumulators: they live in AGPRs
   // epilogue rounds: one 32-row x 128-byte block per round = two 32x32 tiles in bf16, one in fp32 (residual sum)
   static constexpr int kStores = kResid ? TN * TM * 4 : TN * TM * 2;  // global store instructions per wave per tile
   static constexpr int kEpiLds = 4096;                                // wave-private staging bytes
@@ -428,6 +431,11 @@ struct GemmKernel {
           for (int cc = 0; cc < CP; ++cc) {
             const int cb = cp * CP + cc;
             const int i = TRANS ? rb : cb, j = TRANS ? cb : rb;
+            if (kAccInAgprs) {   // (see CmEpilogue::pin_acc: keep the tile in AGPRs until its round)
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("" : "+a"(acc[i][j]));
+              __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
               float v[4];
@@ -552,8 +560,20 @@ struct CmEpilogue {
   using Lane = typename G::Lane;
   using bf16x8 = typename Half<T>::x8;
   using bf16x4 = typename Half<T>::x4;
-  static constexpr int TN = G::TN, WNT = G::WNT, WMT = G::WMT;
-  static_assert(G::TM == 4 && TN % 2 == 0, "a wave owns 128 rows and whole 64-column statistic slots");
+  static constexpr int TN = G::TN, TM = G::TM, WNT = G::WNT, WMT = G::WMT;
+  // one wave per SIMD (the 256-row ring kernel: registers to spare, nobody to hide a wait): fetch a column group's operands one group
+  // ahead; with two waves per SIMD (the 8-wave kernel, the 128-row ring kernel) they stay inside the group
+  static constexpr bool kPipe = G::kAccInAgprs;
+  static_assert(TN % 2 == 0, "a wave owns whole 64-column statistic slots");
+
+  // The ring kernel's 256 accumulators live in AGPRs; VALU instructions cannot read those, and left alone the register allocator
+  // copies ALL of them to VGPRs at the K loop's exit (and spills what does not fit - scratch accesses are VMEM operations, each
+  // reload a full `vmcnt(0)` drain).  An empty asm with an AGPR constraint at the head of a column group keeps that group's four
+  // tiles in AGPRs up to that point, so the copies happen group by group.
+  static __device__ __forceinline__ void pin_acc(f32x16 (&row)[TM]) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(row[j]));
+  }
 
   // lanes 32..63 of x <-> lanes 0..31 of y
   // (inline asm: the compiler's hazard recogniser cannot see the cross-lane read, so the wait states a VALU-written
@@ -565,7 +585,7 @@ struct CmEpilogue {
   // Epilogue into a chunk-major output (cm_offset): bias (or the folded-LayerNorm form) (+ Q/8, + GELU) in registers, the
   // two lanes that share a row exchange their 8-byte halves (v_permlane32_swap) so each ends up with one whole 16-byte
   // chunk, and every store instruction writes 1 KiB contiguous (two adjacent chunks x 32 rows).  No LDS, no waits.
-  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][4]) {
+  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][TM]) {
     T* base = static_cast<T*>(a.out_bf16);
     int ncols = a.N, nloc = n0 + L.wn * WNT;
     float scale = 1.f;
@@ -575,20 +595,39 @@ struct CmEpilogue {
       else scale = 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in 16-bit)
     }
     const bool ln = a.ln_mu != nullptr;
-    float2 mr[4];
+    float2 mr[TM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      float4 b4[4], cs4[4];
+    for (int j = 0; j < TM; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
+    // The column vectors of 32-column group i+1 are fetched BEFORE the stores of group i are issued: VMEM operations retire in order,
+    // so a load issued behind 32 stores would wait for all of them (with one wave per SIMD - the ring kernel - nothing hides that).
+    float4 b4s[2][4], cs4s[2][4];
+    // (pipelined form: no branch on `ln` - without folded LayerNorm mu = 0, so any finite vector serves as cs, e.g. the bias itself;
+    // one straight-line block per column group, fenced by sched_barrier(0) so that the scheduler neither hoists all 256 accumulator
+    // reads to the top nor sinks the prefetch below the stores - both end in scratch spills, which are VMEM operations themselves)
+    const float* csp = ln ? a.ln_cs : a.bias;
+    auto load_cols = [&](int i, int buf) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int n = n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half;
-        b4[g4] = *reinterpret_cast<const float4*>(a.bias + n);
-        cs4[g4] = ln ? *reinterpret_cast<const float4*>(a.ln_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b4s[buf][g4] = *reinterpret_cast<const float4*>(a.bias + n);
+        if (kPipe) cs4s[buf][g4] = *reinterpret_cast<const float4*>(csp + n);
+        else cs4s[buf][g4] = ln ? *reinterpret_cast<const float4*>(a.ln_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    };
+    if (kPipe) load_cols(0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    for (int i = 0; i < TN; ++i) {
+      if (!kPipe) load_cols(i, i & 1);
+      else {
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < TN) load_cols(i + 1, (i + 1) & 1);
+        pin_acc(acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float4 (&b4)[4] = b4s[i & 1];
+      const float4 (&cs4)[4] = cs4s[i & 1];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
         const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
         const float mu = mr[j].x, rs = mr[j].y;
         unsigned pk[4][2];
@@ -628,30 +667,62 @@ struct CmEpilogue {
   //     stat_part[m][n0/64 + wn] = (sum_n P, sum_n P^2) over this wave's 64 columns, of the ROUNDED values the consumers
   //     will read.  fp32 sum, one rounding; the residual is read with coalesced 8-byte loads at the positions the lane's
   //     own values will occupy (chunk-major), so no LDS and no transposition is involved.
-  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][4]) {
+  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][TM]) {
     T* base = static_cast<T*>(a.out_bf16);
     const T* rsrc = static_cast<const T*>(a.res_src);
     const int nchunks = a.N >> 3, nloc = n0 + L.wn * WNT, nslot = a.N >> 6;
-    float2 mr[4];
-    float s1[TN / 2][4], s2[TN / 2][4];     // per 64-column slot of the wave's WNT columns
+    float2 mr[TM];
+    float s1[TN / 2][TM], s2[TN / 2][TM];     // per 64-column slot of the wave's WNT columns
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TM; ++j) {
       mr[j] = a.res_mr[m0 + L.wm * WMT + j * 32 + L.l31];
 #pragma unroll
       for (int sl = 0; sl < TN / 2; ++sl) s1[sl][j] = s2[sl][j] = 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
-      float4 bb[2][2], gg[2][2];
+    // Operands are fetched one step AHEAD of their use and before the stores of the step in between are issued (in-order retirement of
+    // VMEM operations, see epilogue_cm): the column vectors (bias', gamma) of 32-column group i+1 during group i, the residual chunks
+    // of row block (i, j+1) during (i, j).  kPipe = false (8-wave kernel): everything inside its own step, as before.
+    float4 bbs[2][2][2], ggs[2][2][2];
+    bf16x8 r8s[2][2];
+    auto load_cols = [&](int i, int buf) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int n = n0 + L.wn * WNT + i * 32 + (2 * p + L.half) * 8;
-        bb[p][0] = *reinterpret_cast<const float4*>(a.bias + n); bb[p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
-        gg[p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); gg[p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
+        bbs[buf][p][0] = *reinterpret_cast<const float4*>(a.bias + n); bbs[buf][p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        ggs[buf][p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); ggs[buf][p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
       }
+    };
+    auto load_res = [&](int t, int buf) {   // t = i * TM + j
+      const int i = t / TM, j = t % TM;
+      const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int p = 0; p < 2; ++p) {
+        const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
+        r8s[buf][p] = *reinterpret_cast<const bf16x8*>(rsrc + ((mblk * nchunks + chunk) * 32 + L.l31) * 8);
+      }
+    };
+    if (kPipe) { load_cols(0, 0); load_res(0, 0); }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      if (!kPipe) load_cols(i, i & 1);
+      else {
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < TN) load_cols(i + 1, (i + 1) & 1);
+        pin_acc(acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
+      const float4 (&bb)[2][2] = bbs[i & 1];
+      const float4 (&gg)[2][2] = ggs[i & 1];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int t = i * TM + j;
+        if (!kPipe) load_res(t, t & 1);
+        else {
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < TN * TM) load_res(t + 1, (t + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
         const float rmu = mr[j].x, rrs = mr[j].y;
 #pragma unroll
@@ -670,7 +741,7 @@ struct CmEpilogue {
           }
           const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
           const int64_t off = ((mblk * nchunks + chunk) * 32 + L.l31) * 8;
-          const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(rsrc + off);
+          const bf16x8 r8 = r8s[t & 1][p];
           const float bv[8] = {bb[p][0].x, bb[p][0].y, bb[p][0].z, bb[p][0].w, bb[p][1].x, bb[p][1].y, bb[p][1].z, bb[p][1].w};
           const float gv[8] = {gg[p][0].x, gg[p][0].y, gg[p][0].z, gg[p][0].w, gg[p][1].x, gg[p][1].y, gg[p][1].z, gg[p][1].w};
           bf16x8 o;
@@ -688,7 +759,7 @@ struct CmEpilogue {
 #pragma unroll
     for (int sl = 0; sl < TN / 2; ++sl)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < TM; ++j) {
         // the two lanes of a row hold its 2 x 32 columns: add them and let the lower lane write the wave's partial
         const float t1 = s1[sl][j] + __shfl_xor(s1[sl][j], 32, 64), t2 = s2[sl][j] + __shfl_xor(s2[sl][j], 32, 64);
         const int mrow = m0 + L.wm * WMT + j * 32 + L.l31;

@@ -1,29 +1,35 @@
-// 256 x 256 tile, four waves, k-slice ring: the encoder GEMM for shapes whose operands are BOTH chunk-major.
-//
-// Why a second kernel.  The 8-wave ping-pong kernel (bert_gemm.cuh) reads 192 KiB of LDS per K step (a 128 x 64 wave tile re-reads
-// every A fragment four times, every B fragment twice) and synchronises eight times per K step; on MI355X the matrix pipe is
-// POWER-limited long before it is issue-limited (the shader clock falls from 2.4 GHz to 1.3 - 1.9 GHz as the MFMA duty cycle
-// rises: measured in scripts/ubench/gemm4w2.hip with s_memtime against s_memrealtime), so what counts is work per MFMA.  One wave
-// per SIMD with a 128 x 128 wave tile (256 accumulator registers, in AGPRs) reads 128 KiB per K step, needs no LDS swizzle, and
-// the hardware has no second wave to arbitrate against.
+// BM x 256 tile, four waves, k-slice ring: the encoder GEMM for shapes whose operands are BOTH chunk-major.
 //
 // Layout.  Activations [M][K] and weights [N][K] are both chunk-major (cm_offset): [rows/32][K/8][32 rows][8 elements].  A 32-row x
 // 16-k "piece" (two adjacent chunks) is then 1 KiB CONTIGUOUS in memory: one LDS-DMA instruction (buffer_load_dwordx4 ... lds, lane l
 // reads bytes 16 l .. 16 l + 15) copies it unchanged into LDS, where lanes 0-31 / 32-63 of an MFMA fragment read (ds_read_b128) read
-// its first / second 512 bytes, row l31 at byte 16 l31: conflict-free without any XOR.  A k-slice (16 k of the whole 256 x 256 tile)
-// is 8 A pieces + 8 B pieces = 16 KiB = one ring SLOT; the ring has 8 slots (two K steps, 128 KiB).
+// its first / second 512 bytes, row l31 at byte 16 l31: conflict-free without any XOR.  A k-slice (16 k of the whole BM x 256 tile)
+// is BM/32 A pieces + 8 B pieces = one ring SLOT; the ring has kSlots of them.
 //
-// Schedule.  Consumption walks the slices in order; per slice and wave: 16 MFMAs (32x32x16), the 8 fragment reads of the NEXT slice,
-// the wave's 4 pieces of the slice 8 ahead (LDS-DMA into the slot of the slice everybody has just finished reading), ONE barrier:
-//     s_waitcnt vmcnt(24)   my pieces of slice t+1 have landed (the 6 x 4 pieces of slices t+2 .. t+7 may still fly)
-//     s_waitcnt lgkmcnt(0)  my fragments of slice t are in registers = I am done reading slot t
-//     s_barrier             => slice t+1 is complete in LDS, slot t is free
-//     8 x ds_read_b128 (slice t+1)  |  4 x LDS-DMA (slice t+8 -> slot t)  |  16 x MFMA (slice t)      interleaved by sched_group_barrier
-// The fill stream runs 8 slices (two K steps, ~1.5 us) ahead of consumption and straight on across the tile boundaries of the
-// persistent schedule: the last 8 slices of a tile fetch the first 8 of the block's next tile, and the epilogue runs with 28 pieces in
+// Schedule.  Consumption walks the slices in order; per slice and wave: TM x 4 MFMAs (32x32x16), the fragment reads of the NEXT slice,
+// the wave's P pieces of the slice kSlots ahead (LDS-DMA into the slot of the slice everybody has just finished reading), ONE barrier:
+//     s_waitcnt vmcnt((kSlots-2) P)  my pieces of slice t+1 have landed (those of slices t+2 .. t+kSlots-1 may still fly)
+//             & lgkmcnt(0)           my fragments of slice t are in registers = I am done reading slot t
+//     s_barrier                      => slice t+1 is complete in LDS, slot t is free
+//     M R M R ... | M M D ...        MFMAs of slice t, reads of slice t+1 first, LDS-DMAs of slice t+kSlots last; the order is pinned
+//                                    instruction by instruction (sched_barrier(0)): left alone the scheduler clusters the loads behind
+//                                    the MFMAs, where nothing covers their issue time
+// The fill stream runs kSlots slices ahead of consumption and straight on across the tile boundaries of the persistent schedule: the
+// last kSlots slices of a tile fetch the first kSlots of the block's next tile, and the epilogue runs with (kSlots-1) P pieces in
 // flight.  Past the block's last tile the LDS-DMA source lies beyond the buffer extent (reads as zeros) - the steady state is one basic
-// block with exact vmcnt arithmetic, no tail cases.  After an epilogue the first 8 slices allow 32 more outstanding operations
-// (the epilogue's stores are younger than the pieces they must not wait for; every epilogue issues at least 32 VMEM instructions).
+// block with exact vmcnt arithmetic, no tail cases.  After an epilogue, slices 0 .. kSlots-2 of the next tile allow kEpiVmem more
+// outstanding operations: the epilogue's VMEM operations are younger than the pieces those slices wait for (VMEM operations retire in
+// order) and every epilogue issues at least kEpiVmem of them.
+//
+// Two shapes of the same kernel:
+//   BM = 256  one workgroup per CU, one wave per SIMD, wave tile 128 x 128 (256 accumulators, in AGPRs), ring of 8 x 16 KiB.  Reads
+//             128 KiB of LDS per K step where the 8-wave ping-pong kernel (bert_gemm.cuh) reads 192 and synchronises once per 16 MFMAs,
+//             but nothing overlaps its epilogue, and one wave per SIMD gets through VALU work (GELU!) at about half the rate of two.
+//   BM = 128  TWO workgroups per CU (wave tile 64 x 128, 128 accumulators, ring of 5 x 12 KiB each): the two run unsynchronised, so one
+//             workgroup's epilogue overlaps the other's K loop - the matrix pipe always has a K loop to serve.
+// On MI355X the matrix pipe is POWER-limited long before it is issue-limited: back-to-back 32x32x16 fp16 MFMAs on random data sustain
+// 1.65 PFLOP/s at a clock that has fallen to 1.65 GHz (scripts/ubench/mfma_power.hip), so time saved in the K loop is partly paid back
+// as clock; what the epilogue costs, however, is paid in full.
 //
 // Accumulation order per output element is k ascending in slices of 16, exactly as in the ping-pong kernel: identical bits.
 #pragma once
@@ -32,30 +38,42 @@
 namespace capamd {
 
 #ifndef CAPAMD_RING_ABLATE
-#define CAPAMD_RING_ABLATE 0   // profiling builds only: 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no sched_group_barrier pattern
+#define CAPAMD_RING_ABLATE 0   // profiling builds only: 1 no LDS-DMA in the loop, 2 no fragment reads
 #endif
 
-template <int EPI, typename T>
+template <int EPI, typename T, int BM>
 struct GemmRing {
-  using G = GemmKernel<256, 256, 2, 2, EPI, T>;   // geometry (WMT = WNT = 128, TM = TN = 4), tile schedule, LDS-staged epilogues (V^T)
+  static_assert(BM == 256 || BM == 128, "tile rows");
+  using G = GemmKernel<BM, 256, 2, 2, EPI, T>;   // geometry (wave tile BM/2 x 128), tile schedule, LDS-staged epilogues (V^T)
   using CE = CmEpilogue<G, EPI, T>;
   using Lane = typename G::Lane;
   using x8 = typename Half<T>::x8;
-  using x4 = typename Half<T>::x4;
-  static constexpr int kSlot = 16 * 1024, kSlots = 8, kRing = kSlot * kSlots;
+  static constexpr int TM = G::TM;                       // 32-row MFMA tiles per wave: 4 / 2
+  static constexpr int kPiecesA = BM / 32, kPieces = kPiecesA + 8, P = kPieces / 4;   // 1-KiB pieces of a k-slice; per wave
+  static constexpr int kSlotA = kPiecesA * 1024, kSlot = kPieces * 1024;
+  static constexpr int kSlots = BM == 256 ? 8 : 5, kRing = kSlot * kSlots;
   static constexpr int kThreads = 256;
+  static constexpr int kWgPerCu = BM == 256 ? 1 : 2;
   static constexpr int kLdsBytes = kRing + 4 * G::kEpiLds;
-  static constexpr int kEpiVmem = 32;   // VMEM instructions every epilogue issues per wave, at least
+  static constexpr int kEpiVmem = 32;                    // VMEM instructions every epilogue issues per wave, at least
+  static constexpr int kVm = (kSlots - 2) * P;           // pieces that may stay in flight at the top of a slice
+  static constexpr int kHead = (kSlots - 1) & ~1;        // slices of a tile that may use kVm + kEpiVmem after an epilogue (<= kSlots - 1, even)
+  static_assert(kVm + kEpiVmem <= 63 && kLdsBytes * kWgPerCu <= 160 * 1024, "vmcnt immediate / LDS budget");
+  static_assert(kPiecesA % 4 == 0, "a wave's p-th piece is an A piece or a B piece for all four waves alike");
   static_assert(EPI != kEpiBiasResidBf16, "the row-major residual epilogue stays on the ping-pong / half-region kernels");
 
-  struct Bases { unsigned a[2], w[2]; };   // scalar byte offsets of this wave's pieces of k-slice 0 of a tile (a slice further: + 1024)
+  // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+  static constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
+  // scalar byte offsets of this wave's P pieces of k-slice 0 of a tile (a slice further: + 1024).  Piece q = wave + 4 p: the first
+  // BM/32 are A row blocks, the rest B row blocks
+  struct Bases { unsigned off[P]; };
   static __device__ __forceinline__ Bases bases_of(const GemmArgs& g, int m0, int n0, int wave) {
     Bases b;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      b.a[p] = (unsigned)(((m0 >> 5) + wave * 2 + p) * (g.K >> 3)) * 512u;
-      b.w[p] = (unsigned)(((n0 >> 5) + wave * 2 + p) * (g.K >> 3)) * 512u;
+    for (int p = 0; p < P; ++p) {
+      const int q = wave + 4 * p;
+      b.off[p] = 4 * p < kPiecesA ? (unsigned)(((m0 >> 5) + q) * (g.K >> 3)) * 512u : (unsigned)(((n0 >> 5) + q - kPiecesA) * (g.K >> 3)) * 512u;
     }
     return b;
   }
@@ -70,35 +88,40 @@ struct GemmRing {
 #define CAPAMD_STAMP() do { if (dbg && L.tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
     int m0, n0;
     if (!G::tile_of(g, 0, m0, n0)) return;
-    const int S = g.K >> 4;                          // k-slices per tile (>= 16: ring_shape)
+    const int S = g.K >> 4;                          // k-slices per tile (ring_shape: even, >= 16)
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)((size_t)g.M * g.K * 2), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, (int)((size_t)g.N * g.K * 2), 0x00020000);
     const int voff = L.lane * 16;
-    auto issue = [&](const Bases& b, int s, int slot_off) {
-      char* d = lds + slot_off;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int rb = L.wave * 2 + p;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(d + rb * 1024), 16, voff, (int)(b.a[p] + (unsigned)s * 1024u), 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(d + 8192 + rb * 1024), 16, voff, (int)(b.w[p] + (unsigned)s * 1024u), 0, 0);
-      }
+    // piece p of this wave: LDS-DMA of 1 KiB from byte offset `soff` of its operand into its place in the slot at `dst`
+    auto dma = [&](int p, char* dst, unsigned soff) {
+      const int q = L.wave + 4 * p;
+      if (4 * p < kPiecesA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(dst + q * 1024), 16, voff, (int)soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(dst + q * 1024), 16, voff, (int)soff, 0, 0);
     };
     // fragment of 32-row block rb of the A (m) / B (n) panel inside a slot: lane (l31, half) reads chunk `half`, row l31
-    const int a_base = L.wm * 4 * 1024 + L.half * 512 + L.l31 * 16;
-    const int b_base = 8192 + L.wn * 4 * 1024 + L.half * 512 + L.l31 * 16;
+    const int a_base = L.wm * TM * 1024 + L.half * 512 + L.l31 * 16;
+    const int b_base = kSlotA + L.wn * 4 * 1024 + L.half * 512 + L.l31 * 16;
 
     Bases cur = bases_of(g, m0, n0, L.wave);
+    // two workgroups per CU: the second half of the grid (the workgroups that land beside the first half) starts about half a tile
+    // late, so that the two K loops / epilogues of a CU alternate from the first tile on instead of coinciding
+    if (kWgPerCu == 2 && blockIdx.x >= (gridDim.x >> 1))
+      for (int i = 0; i < g.ring_stagger; ++i) __builtin_amdgcn_s_sleep(1);
     CAPAMD_STAMP();
 #pragma unroll 1
-    for (int i = 0; i < kSlots; ++i) issue(cur, i, i * kSlot);
-    x8 fa[2][4], fb[2][4];
-    wait_vmcnt<28>();
-    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < kSlots; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[0][i] = *reinterpret_cast<const x8*>(lds + a_base + i * 1024);
-      fb[0][i] = *reinterpret_cast<const x8*>(lds + b_base + i * 1024);
-    }
+      for (int p = 0; p < P; ++p) dma(p, lds + i * kSlot, cur.off[p] + (unsigned)i * 1024u);
+    x8 fa[2][TM], fb[2][4];
+    auto read_first = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[0][j] = *reinterpret_cast<const x8*>(lds + slot + a_base + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[0][i] = *reinterpret_cast<const x8*>(lds + slot + b_base + i * 1024);
+    };
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm((kSlots - 1) * P, 15));
+    __builtin_amdgcn_s_barrier();
+    read_first(0);
     int slot_off = 0;          // byte offset of the slot of the slice being consumed
     bool after_epilogue = false;
     for (int it = 0;; ++it) {
@@ -106,68 +129,80 @@ struct GemmRing {
       const bool more = G::tile_of(g, it + 1, m1, n1);
       if (!more) { m1 = g.M; n1 = g.N; }              // beyond both extents: the run-ahead LDS-DMAs read zeros
       const Bases nxt = bases_of(g, m1, n1, L.wave);
-      f32x16 acc[4][4];
+      f32x16 acc[4][TM];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       const bool trans = (EPI == kEpiQkv) && n0 >= 2 * g.H;
-      // one k-slice (see the header); U = which fragment set holds the slice, VM = outstanding VMEM operations allowed at its top
-      auto kslice = [&](auto u_c, auto vm_c, auto tr_c, const Bases& src, int fs) {
+      // one k-slice; U = which fragment set holds the slice, VM = outstanding VMEM operations allowed at its top; s = its index in the tile
+      auto kslice = [&](auto u_c, auto vm_c, auto tr_c, int s) {
         constexpr int cu = decltype(u_c)::value, nx = cu ^ 1, VM = decltype(vm_c)::value;
         constexpr bool TR = decltype(tr_c)::value;
-        wait_vmcnt<VM>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const char* stn = lds + ((slot_off + kSlot) & (kRing - 1));
-        if (!(CAPAMD_RING_ABLATE & 2)) {
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(VM, 0));   // (the builtin, not inline asm: the compiler's own waitcnt pass then knows the
+        __builtin_amdgcn_s_barrier();                      // fragment registers are ready and adds no waits of its own in the slice)
+        const int nslot = slot_off + kSlot == kRing ? 0 : slot_off + kSlot;
+        const char* stn = lds + nslot;
+        char* dst = lds + slot_off;
+        // the slice kSlots ahead: of this tile, or (the tile's last kSlots slices) of the block's next tile
+        const bool own = s + kSlots < S;
+        const unsigned so = (unsigned)(own ? s + kSlots : s + kSlots - S) * 1024u;
+        unsigned soff[P];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            fa[nx][i] = *reinterpret_cast<const x8*>(stn + a_base + i * 1024);
-            fb[nx][i] = *reinterpret_cast<const x8*>(stn + b_base + i * 1024);
+        for (int p = 0; p < P; ++p) soff[p] = (own ? cur.off[p] : nxt.off[p]) + so;
+        auto M = [&](int idx) {
+          const int i = idx / TM, j = idx % TM;
+          acc[i][j] = TR ? Half<T>::mfma(fa[cu][j], fb[cu][i], acc[i][j]) : Half<T>::mfma(fb[cu][i], fa[cu][j], acc[i][j]);
+        };
+        auto R = [&](int q) {
+          if (CAPAMD_RING_ABLATE & 2) return;
+          if (q < TM) fa[nx][q] = *reinterpret_cast<const x8*>(stn + a_base + q * 1024);
+          else fb[nx][q - TM] = *reinterpret_cast<const x8*>(stn + b_base + (q - TM) * 1024);
+        };
+        auto D = [&](int p) {
+          if (CAPAMD_RING_ABLATE & 1) return;
+          dma(p, dst, soff[p]);
+        };
+        constexpr int NM = 4 * TM, NR = TM + 4;           // 16 / 8 MFMAs, 8 / 6 fragment reads
+        constexpr int MPD = (NM - NR) / P;                 // MFMAs per LDS-DMA after the reads: 2 (BM = 256) / 0 (BM = 128: 2 MFMAs, 3 DMAs)
+#define CAPAMD_SB __builtin_amdgcn_sched_barrier(0)
+        CAPAMD_SB;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { M(q); CAPAMD_SB; R(q); CAPAMD_SB; }
+        if constexpr (MPD >= 1) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int k = 0; k < MPD; ++k) { M(NR + p * MPD + k); CAPAMD_SB; }
+            D(p); CAPAMD_SB;
           }
+#pragma unroll
+          for (int q = NR + P * MPD; q < NM; ++q) { M(q); CAPAMD_SB; }
+        } else {
+#pragma unroll
+          for (int q = NR; q < NM; ++q) { M(q); CAPAMD_SB; D(q - NR); CAPAMD_SB; }
+#pragma unroll
+          for (int p = NM - NR; p < P; ++p) { D(p); CAPAMD_SB; }
         }
-        if (!(CAPAMD_RING_ABLATE & 1)) issue(src, fs, slot_off);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = TR ? Half<T>::mfma(fa[cu][j], fb[cu][i], acc[i][j]) : Half<T>::mfma(fb[cu][i], fa[cu][j], acc[i][j]);
-#if !(CAPAMD_RING_ABLATE & 4)
-        // 16 MFMA | 8 DS read | 4 VMEM  ->  (M R M V M R M) x 4
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-#endif
-        slot_off = (slot_off + kSlot) & (kRing - 1);
+#undef CAPAMD_SB
+        slot_off = nslot;
       };
       using U0 = std::integral_constant<int, 0>;
       using U1 = std::integral_constant<int, 1>;
-      using V24 = std::integral_constant<int, 24>;
-      using VE = std::integral_constant<int, 24 + kEpiVmem>;
+      using VS = std::integral_constant<int, kVm>;
+      using VE = std::integral_constant<int, kVm + kEpiVmem>;
       auto tile_loop = [&](auto tr_c) {
-        // head: slices 0 .. 7 (refilled with 8 .. 15 of this tile); after an epilogue its VMEM operations are younger than the pieces
         if (after_epilogue) {
 #pragma unroll 1
-          for (int s = 0; s < 8; s += 2) { kslice(U0{}, VE{}, tr_c, cur, s + 8); kslice(U1{}, VE{}, tr_c, cur, s + 9); }
+          for (int s = 0; s < kHead; s += 2) { kslice(U0{}, VE{}, tr_c, s); kslice(U1{}, VE{}, tr_c, s + 1); }
         } else {
 #pragma unroll 1
-          for (int s = 0; s < 8; s += 2) { kslice(U0{}, V24{}, tr_c, cur, s + 8); kslice(U1{}, V24{}, tr_c, cur, s + 9); }
+          for (int s = 0; s < kHead; s += 2) { kslice(U0{}, VS{}, tr_c, s); kslice(U1{}, VS{}, tr_c, s + 1); }
         }
 #pragma unroll 1
-        for (int s = 8; s < S - 8; s += 2) { kslice(U0{}, V24{}, tr_c, cur, s + 8); kslice(U1{}, V24{}, tr_c, cur, s + 9); }
-        // tail: the last 8 slices fetch slices 0 .. 7 of the block's next tile
-#pragma unroll 1
-        for (int s = 0; s < 8; s += 2) { kslice(U0{}, V24{}, tr_c, nxt, s); kslice(U1{}, V24{}, tr_c, nxt, s + 1); }
+        for (int s = kHead; s < S; s += 2) { kslice(U0{}, VS{}, tr_c, s); kslice(U1{}, VS{}, tr_c, s + 1); }
       };
       if (trans) tile_loop(std::true_type{});
       else tile_loop(std::false_type{});
@@ -183,16 +218,19 @@ struct GemmRing {
       after_epilogue = true;
       cur = nxt;
       m0 = m1; n0 = n1;
+      // the next tile's first fragments are read again here (the copies the last slice fetched are dead across the epilogue: registers
+      // the epilogue needs more than the ~150 cycles this costs per tile)
+      read_first(slot_off);
     }
 #undef CAPAMD_STAMP
 #endif
   }
 };
 
-template <int EPI, typename T>
-__global__ __launch_bounds__(256, 1) void gemm_ring_kernel(GemmArgs a) {
+template <int EPI, typename T, int BM>
+__global__ __launch_bounds__(256, (BM == 256 ? 1 : 2)) void gemm_ring_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char gemm_ring_lds[];
-  GemmRing<EPI, T>::run(a, gemm_ring_lds);
+  GemmRing<EPI, T, BM>::run(a, gemm_ring_lds);
 }
 
 // [rows][K] row-major -> chunk-major (weights, once per model): one thread per 16-byte chunk

@@ -204,6 +204,7 @@ int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int
  * Its producers store straight from MFMA registers (no LDS regrouping), its consumers still fetch full 128-byte lines. */
 #define CAPAMD_GEMM_A_CHUNK_MAJOR 0x200   /* A is chunk-major */
 #define CAPAMD_GEMM_OUT_CHUNK_MAJOR 0x100 /* out is chunk-major */
+#define CAPAMD_GEMM_RING_256 0x800         /* with W chunk-major: the ring kernel's 256-row tile (one workgroup per CU) instead of its default 128-row tile (two per CU) */
 #define CAPAMD_GEMM_W_CHUNK_MAJOR 0x400   /* W is chunk-major too (with A chunk-major, M, N % 256 == 0, K % 32 == 0, K >= 256: the 4-wave ring kernel) */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
                      const void* resid, void* out, int dtype /* 0 bf16, 1 fp16 */, void* stream);

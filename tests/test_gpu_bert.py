@@ -460,8 +460,10 @@ def test_gemm_at_benchmark_scale(N, K, epi, dt):
     assert torch.equal(_from_cm(out_cm, M, N), out)
     # weights chunk-major too -> the 4-wave ring kernel (bert_gemm_ring.cuh): same accumulation order, identical bits
     out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(W)
-    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700, None, _p(out_ring), code, _stream()) == 0
-    assert torch.equal(out_ring, out_cm)
+    for rows256 in (0, 0x800):          # the 128-row tile (two workgroups per CU) and the 256-row tile (one)
+        out_ring.zero_()
+        assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700 | rows256, None, _p(out_ring), code, _stream()) == 0
+        assert torch.equal(out_ring, out_cm)
     out_ring_rm = torch.empty((M, N), dtype=tdt, device=DEV)      # ... and its row-major (LDS-staged) epilogue
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x600, None, _p(out_ring_rm), code, _stream()) == 0
     assert torch.equal(out_ring_rm, out)
@@ -495,9 +497,11 @@ def test_gemm_folded_layernorm_consumer_at_benchmark_scale(N, K, epi, dt):
         ref = torch.nn.functional.gelu(ref)
     _assert_close_big(_from_cm(out, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K}")
     out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(Ws)      # the ring kernel: identical bits
-    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0x700, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
-                                         _p(out_ring), code, _stream())
-    assert rc == 0 and torch.equal(out_ring, out)
+    for rows256 in (0, 0x800):
+        out_ring.zero_()
+        rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0x700 | rows256, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None,
+                                             None, _p(out_ring), code, _stream())
+        assert rc == 0 and torch.equal(out_ring, out)
 
 
 @pytest.mark.parametrize("N,K", [(768, 768), (768, 3072)])
@@ -525,23 +529,26 @@ def test_gemm_residual_stats_producer_at_benchmark_scale(N, K, dt):
     want = torch.stack([got.reshape(M, N // 64, 64).sum(2), (got * got).reshape(M, N // 64, 64).sum(2)], 2)
     torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-3)
     out_ring, part_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), torch.zeros((M, N // 64, 2), device=DEV), _to_cm(W)
-    rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0x700, None, None, None, None, _p(R_cm), _p(mr), _p(gamma), _p(part_ring),
-                                         _p(out_ring), code, _stream())
-    assert rc == 0 and torch.equal(out_ring, out) and torch.equal(part_ring, part)      # the ring kernel: identical bits
+    for rows256 in (0, 0x800):
+        out_ring.zero_(), part_ring.zero_()
+        rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0x700 | rows256, None, None, None, None, _p(R_cm), _p(mr), _p(gamma),
+                                             _p(part_ring), _p(out_ring), code, _stream())
+        assert rc == 0 and torch.equal(out_ring, out) and torch.equal(part_ring, part)      # the ring kernel: identical bits
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (512, 768, 512, 1), (768, 256, 1024, 0)])
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (512, 768, 512, 1), (768, 256, 1024, 0), (256, 256, 0x800 | 256, 0), (768, 512, 0x800 | 320, 1), (768, 512, 320, 1)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_ring_gemm_small_shapes(M, N, K, epi, dt):
     """The 4-wave ring kernel on a handful of tiles (fewer tiles than CUs, the minimum of 16 k-slices, a tile count that is not a
     multiple of 8) against fp32 torch."""
     tdt, code, rtol = TDT[dt]
+    rows256, K = K & 0x800, K & 0x7ff           # (the 256-row tile variant is encoded in the K parameter of the test id)
     g = torch.Generator(device=DEV).manual_seed(M + N + K + epi)
     A = (torch.randn((M, K), generator=g, device=DEV) * 0.5).to(tdt)
     W = (torch.randn((N, K), generator=g, device=DEV) * 0.05 + torch.arange(N, device=DEV)[:, None] * 1e-3).to(tdt)
     bias = torch.randn(N, generator=g, device=DEV)
     A_cm, W_cm, out = _to_cm(A), _to_cm(W), torch.empty(M * N, dtype=tdt, device=DEV)
-    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700, None, _p(out), code, _stream()) == 0
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700 | rows256, None, _p(out), code, _stream()) == 0
     ref = A.float() @ W.float().t() + bias
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
