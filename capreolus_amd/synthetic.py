@@ -134,7 +134,7 @@ def make_candidate_list_torch(
     return {"query": q.contiguous(), "posdoc": d.contiguous(), "query_idf": qidf.float().contiguous()}
 
 
-def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, empty_frac=0.15, same_query=True):
+def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, empty_frac=0.15, same_query=True, body_range=(40, 240)):
     """BertPassage-shaped inputs (bertpassage.py:268-284, 313-325): int64 [B, P, S] x3.
 
     `[CLS] q [SEP] psg [SEP] [PAD]...`; mask = 1 on non-pad; seg = 0 for len(q)+2 tokens then 1
@@ -158,7 +158,7 @@ def make_bert_passages(rs, n_docs, numpassages=4, maxseqlen=256, vocab=30522, em
             if rs.random_sample() < empty_frac and p > 0:
                 body = [PAD]
             else:
-                plo, phi = min(40, room), min(240, room)
+                plo, phi = min(body_range[0], room), min(body_range[1], room)
                 body = list(rs.randint(tlo, vocab, size=rs.randint(plo, phi + 1)))
             toks = head + body + [SEP]
             n = len(toks)

@@ -302,8 +302,9 @@ class PytorchTrainer:
         no per-batch host->device copy; one kernel launch per `evalbatch` pairs (0 -> the whole run in one launch)."""
         import torch.distributed as dist
 
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        rank = dist.get_rank() if world > 1 else 0
+        distributed = dist.is_available() and dist.is_initialized()      # (a process group of ONE rank still takes the collective path)
+        world = dist.get_world_size() if distributed else 1
+        rank = dist.get_rank() if distributed else 0
         reranker.model.to(store.device).eval()
         qids = list(qid_to_docids.keys())
         b = shard_bounds([len(qid_to_docids[q]) for q in qids], world)
@@ -313,7 +314,7 @@ class PytorchTrainer:
         with torch.no_grad():
             chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, len(keys), step)]
         local = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
-        if world > 1:
+        if distributed:
             counts = [sum(len(qid_to_docids[q]) for q in qids[b[r]:b[r + 1]]) for r in range(world)]
             width = max(counts)
             padded = torch.zeros(width, dtype=torch.float32, device=store.device)
@@ -359,8 +360,9 @@ class PytorchTrainer:
         writes the TREC run to `pred_fn` (rank 0)."""
         import torch.distributed as dist
 
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        rank = dist.get_rank() if world > 1 else 0
+        distributed = dist.is_available() and dist.is_initialized()      # (a process group of ONE rank still takes the collective path)
+        world = dist.get_world_size() if distributed else 1
+        rank = dist.get_rank() if distributed else 0
         if torch.cuda.is_available():
             self.device = torch.device("cuda", torch.cuda.current_device())
         else:
@@ -415,7 +417,7 @@ class PytorchTrainer:
         if local.numel() != count:
             raise RuntimeError(f"rank {rank} scored {local.numel()} pairs, expected {count}")
 
-        if world > 1:
+        if distributed:
             # every rank can derive every rank's (offset, count) from the sampler; only scores travel
             plan = [shard_pred_data(pred_data, r, world)[1:3] for r in range(world)]
             width = max(c for _, c in plan)

@@ -318,7 +318,7 @@ if __name__ == "__main__":
         gen_drmm(DRMM)
     if "drmmtks" in which:
         gen_drmmtks(TKS)
-    if "bert" in which:
+    if "bert" in which or any(w.startswith("bert:") for w in which):     # "bert:base_long" = only that case
         from make_golden_bert import gen_bert
 
-        gen_bert(MAXP)
+        gen_bert(MAXP, only={w[5:] for w in which if w.startswith("bert:")} or None)

@@ -17,13 +17,18 @@ CASES = {
     "mini": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=1000, max_pos=128, B=5, P=3, S=64, seed=11),
     "mini_s128": dict(hidden=192, layers=1, heads=3, ffn=256, vocab=1200, max_pos=128, B=3, P=2, S=128, seed=12),
     "base": dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, B=3, P=4, S=256, seed=13),
+    # a second draw of BERT-base: other weights, other queries per document, long passages only (200-240 tokens, none empty)
+    "base_long": dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_pos=512, B=4, P=4, S=256, seed=113, same_query=False,
+                      empty_frac=0.0, body_range=(200, 240)),
 }
 
 
-def gen_bert(MAXP):
+def gen_bert(MAXP, only=None):
     from transformers import AutoModelForSequenceClassification, BertConfig, BertForSequenceClassification
 
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         cfg = BertConfig(num_labels=2, hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
                          intermediate_size=c["ffn"], vocab_size=c["vocab"], max_position_embeddings=c["max_pos"])
         w = bert_port.random_weights(c["hidden"], c["layers"], c["heads"], c["ffn"], c["vocab"], c["max_pos"], seed=c["seed"])
@@ -32,7 +37,8 @@ def gen_bert(MAXP):
         try:
             out = {}
             rs = np.random.RandomState(c["seed"])
-            batch = synthetic.make_bert_passages(rs, c["B"], c["P"], c["S"], vocab=c["vocab"], same_query=True)
+            batch = synthetic.make_bert_passages(rs, c["B"], c["P"], c["S"], vocab=c["vocab"], same_query=c.get("same_query", True),
+                                                 empty_frac=c.get("empty_frac", 0.15), body_range=c.get("body_range", (40, 240)))
             ti = {k: torch.from_numpy(v) for k, v in batch.items()}
             for agg in ("max", "first", "sum", "avg"):
                 model = MAXP.PTBERTMaxP_Class(
@@ -47,6 +53,13 @@ def gen_bert(MAXP):
                         logits = model.bert(ti["pos_bert_input"].reshape(-1, c["S"]), attention_mask=ti["pos_mask"].reshape(-1, c["S"]),
                                             token_type_ids=ti["pos_seg"].reshape(-1, c["S"]))[0]
                         out["ref_passage_logits"] = logits.numpy().astype(np.float32)
+                        # the reference's OWN mixed-precision prediction mode (amp = pred / both wraps `reranker.test` in autocast,
+                        # trainer/pytorch.py:323-326, 343): the yardstick for what a 16-bit encoder may deviate from the fp32 result
+                        for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                            with torch.autocast("cpu", dtype=dt):
+                                amp = model.bert(ti["pos_bert_input"].reshape(-1, c["S"]), attention_mask=ti["pos_mask"].reshape(-1, c["S"]),
+                                                 token_type_ids=ti["pos_seg"].reshape(-1, c["S"]))[0]
+                            out["ref_passage_logits_amp_" + tag] = amp.float().numpy().astype(np.float32)
         finally:
             AutoModelForSequenceClassification.from_pretrained = orig
         np.savez_compressed(

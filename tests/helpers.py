@@ -48,7 +48,7 @@ def rank_order(scores_f16):
     s = np.asarray(scores_f16, dtype=np.float16).astype(np.float64)
     return np.argsort(-s, kind="stable")
 
-BERT_CASES = ["mini", "mini_s128", "base"]
+BERT_CASES = ["mini", "mini_s128", "base", "base_long"]
 
 
 def load_bert_case(name):

@@ -374,6 +374,65 @@ def test_predict_at_the_reference_default_evalbatch_coalesces_launches():
     assert (got == c["ref_scores_f16"]).mean() > 0.98        # (fp16 rounding-boundary flips only, as test_knrm_rank_order)
 
 
+def test_predict_over_rccl_single_rank(tmp_path):
+    """The multi-GPU path of `predict` / `predict_resident` with the real collective: a "nccl" (= RCCL) process group of one rank,
+    `all_gather_into_tensor` on device tensors, the padded `width` layout - same predictions as without a process group.  (The
+    world_size 2 / 3 logic runs on gloo in tests/test_trainer_cpu.py; the 8-GPU run is the driver's.)"""
+    import socket
+
+    import torch.distributed as dist
+
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "default")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+    q2d = {"11": [f"d{i}" for i in range(B // 3)], "4": [f"d{i}" for i in range(B // 3, B)]}      # ragged lists
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = q2d
+
+        def __iter__(self):
+            i = 0
+            for qid, docs in q2d.items():
+                for d in docs:
+                    yield {"qid": qid, "posdocid": d, "query": c["query"][i], "posdoc": c["posdoc"][i], "query_idf": c["query_idf"][i]}
+                    i += 1
+
+        def __len__(self):
+            return B
+
+        def get_qid_docid_pairs(self):
+            return ((q, d) for q, docs in q2d.items() for d in docs)
+
+    store = CandidateStore(DEV)
+    i = 0
+    for qid, docs in q2d.items():
+        for d in docs:
+            store.add_query(qid + ":" + d, c["query"][i], c["query_idf"][i])
+            store.add_doc(qid + ":" + d, c["posdoc"][i])
+            i += 1
+    store.finalize()
+    rq2d = {qid + ":" + d: [qid + ":" + d] for qid, docs in q2d.items() for d in docs}                # one (query row, doc row) per pair
+    t = PytorchTrainer({"batch": 7})
+    plain, plain_res = t.predict(r, Sampler()), t.predict_resident(r, store, rq2d)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        assert t.predict(r, Sampler(), tmp_path / "run.txt") == plain
+        assert t.predict_resident(r, store, rq2d) == plain_res
+        x = torch.arange(5, device=DEV, dtype=torch.float32)
+        out = torch.empty(5, device=DEV)
+        dist.all_gather_into_tensor(out, x)
+        assert torch.equal(out, x)
+    finally:
+        dist.destroy_process_group()
+    assert (tmp_path / "run.txt").exists()
+
+
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
 def test_resident_store_matches_extractor_layout(kind, tmp_path):
     """Row N1: int32 tables + index pairs give bit-identical scores to the int64 [B,Q]/[B,L] layout."""
