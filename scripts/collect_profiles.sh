@@ -1,21 +1,31 @@
 #!/bin/bash
-# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r01
+# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r02
 set -eu
-D=profiles/${1:-r01}
+D=profiles/${1:-r02}
 G=gpurun_out
 mkdir -p $D
-for f in bench_knrm bench_knrm_uniform bench_knrm_b1000 bench_drmm bench_bert bench_bert_skip_padding bench_drmmtks bench_pacrr bench_convknrm; do cp $G/$f.json $D/; done
-cp $G/bench_siblings.jsonl $D/
-cp $G/prof/knrm/knrm_kernel_stats.csv $D/knrm_bench_kernel_stats.csv
-cp $G/prof/drmm/drmm_kernel_stats.csv $D/drmm_bench_kernel_stats.csv
-cp $G/prof/bert/bert_kernel_stats.csv $D/bert_bench_kernel_stats.csv
-for m in drmmtks pacrr convknrm; do [ -f $G/prof/$m/${m}_kernel_stats.csv ] && cp $G/prof/$m/${m}_kernel_stats.csv $D/${m}_bench_kernel_stats.csv; done
-cp $G/prof/knrm_fetch/knrm_counter_collection.csv $D/knrm_fetch_counters.csv
-cp $G/prof/knrm_write/knrm_counter_collection.csv $D/knrm_write_counters.csv
-cp $G/prof/knrm_tcc/knrm_counter_collection.csv $D/knrm_tcc_counters.csv
-cp $G/prof/knrm_uni_fetch/knrm_counter_collection.csv $D/knrm_uni_fetch_counters.csv
-cp $G/prof/drmm_fetch/drmm_counter_collection.csv $D/drmm_fetch_counters.csv
-cp $G/prof/bert_mfma/bert_counter_collection.csv $D/bert_mfma_counters.csv
-cp $G/gemm_bench.txt $D/gemm_bench_vs_hipblaslt.txt
-cp $G/gemm_vs_vendor.txt $D/gemm_pmc_vs_hipblaslt.txt
-ls -la $D | tail -30
+for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_bf16 bert_pingpong drmmtks pacrr convknrm; do cp $G/bench_$f.json $D/; done
+for m in knrm knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm; do
+  f=$(ls $G/prof/$m/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${m}_bench_kernel_stats.csv
+done
+for m in knrm knrm_roofline_leg drmm drmm_roofline_leg; do for c in fetch write tcc; do
+  f=$(ls $G/prof/${m}_$c/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${m}_${c}_counters.csv
+done; done
+for m in bert_mfma bert_mfma_pingpong; do f=$(ls $G/prof/$m/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" "$D/${m}_counters_summary.csv" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,launches,counter,mean_per_launch\n")
+    for k, cs in acc.items():
+        for c, v in cs.items():
+            if len(v) >= 12:
+                f.write(f'"{k}",{len(v)},{c},{sum(v) / len(v):.1f}\n')
+PY
+done
+cp $G/knrm_hbm_traffic.json $G/drmm_hbm_traffic.json $D/
+cp $G/pmc_summary.txt $D/pmc_summary.txt
+cp $G/mfma_power.txt $D/mfma_power.txt
+cp $G/pytest_gpu.log $D/pytest_gpu.log
+ls -la $D | tail -40

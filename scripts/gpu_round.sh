@@ -1,33 +1,55 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench lines, rocprof kernel stats + PMC traffic.  Outputs under gpurun_out/.
+# One GPU-box session (round 2): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/.
 set -u
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/pytest_gpu.log; cat gpurun_out/pytest_gpu.log
-timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2
-timeout 300 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/bench_knrm.json; cut -c1-400 gpurun_out/bench_knrm.json
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --uniform-ids 2>/dev/null | tail -1 > gpurun_out/bench_knrm_uniform.json
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json
-timeout 300 python bench.py --steps 20 --warmup 3 --model drmm 2>/dev/null | tail -1 > gpurun_out/bench_drmm.json
-timeout 600 python bench.py --steps 3 --warmup 1 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
-timeout 600 python bench.py --steps 3 --warmup 1 --model bert --no-cpu-baseline --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
-for mdl in drmmtks pacrr convknrm; do timeout 300 python bench.py --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
-timeout 600 python scripts/sibling_bench.py 2>/dev/null | grep model > gpurun_out/bench_siblings.jsonl; cat gpurun_out/bench_siblings.jsonl
-for f in knrm_uniform knrm_b1000 drmm bert drmmtks pacrr convknrm; do python -c "import json;r=json.load(open('gpurun_out/bench_$f.json'));print('$f', round(r['value'],1), r['roofline']['frac'])"; done
+B="python $R/bench.py"
+( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
+# ---- bench lines -------------------------------------------------------------------------------------------------------
+timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json
+timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --bert-dtype bf16 2>/dev/null | tail -1 > gpurun_out/bench_bert_bf16.json
+CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
+for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
+python - <<'PY'
+import json
+for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_bf16", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):
+    try:
+        r = json.load(open(f"gpurun_out/bench_{f}.json")); ro = r["roofline"]
+        print(f"{f:20s} {r['value']:14.1f} {r['unit']}  ms/step {r['ms_per_step']:.3f}  roofline frac {ro.get('frac')}  {ro.get('whole_step_frac_nominal', '')}")
+        for leg in r.get("also", []):
+            print(f"   also: {leg.get('config', {}).get('workload', leg)[:60]} -> {leg.get('value')} frac {leg.get('roofline', {}).get('frac')}")
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
+# ---- rocprofv3 kernel stats of the same commands (one kernel of interest per run, so that the average is that kernel's) -------
 cd /tmp; P=/tmp/prof; rm -rf $P; mkdir -p $P
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/knrm -o knrm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/drmm -o drmm -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --model drmm > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/bert -o bert -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --model bert > /dev/null 2>&1
-for mdl in drmmtks pacrr convknrm; do timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$mdl -o $mdl -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/knrm_fetch -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/knrm_write -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/knrm_tcc -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/knrm_uni_fetch -o knrm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --uniform-ids > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/drmm_fetch -o drmm -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --model drmm > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/bert_mfma -o bert -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
+KS="rocprofv3 --kernel-trace --stats --output-format csv"
+timeout 300 $KS -d $P/knrm -o knrm -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-also --no-roofline-leg > /dev/null 2>&1
+timeout 300 $KS -d $P/knrm_roofline_leg -o knrm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-roofline-leg --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
+timeout 300 $KS -d $P/drmm -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm > /dev/null 2>&1
+timeout 300 $KS -d $P/drmm_roofline_leg -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
+timeout 300 $KS -d $P/bert -o bert -- $B --steps 3 --warmup 1 --no-cpu-baseline --model bert > /dev/null 2>&1
+timeout 300 $KS -d $P/default -o default -- $B --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+for mdl in drmmtks pacrr convknrm; do timeout 300 $KS -d $P/$mdl -o $mdl -- $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
+# ---- PMC passes (own runs, counters only): HBM traffic of the KNRM / DRMM headline and roofline legs, MFMA busy of the BERT GEMMs ------
+PM="rocprofv3 --output-format csv --pmc"
+for leg in "knrm:" "knrm_roofline_leg:--uniform-ids --vocab 4000001 --batches 2" "drmm:--model drmm" "drmm_roofline_leg:--model drmm --uniform-ids --vocab 4000001 --batches 2"; do
+  name=${leg%%:*}; extra=${leg#*:}
+  timeout 300 $PM FETCH_SIZE -d $P/${name}_fetch -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
+  timeout 300 $PM WRITE_SIZE -d $P/${name}_write -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
+  timeout 300 $PM TCC_HIT_sum TCC_MISS_sum -d $P/${name}_tcc -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
+done
+timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
+CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
 cd $R
-timeout 200 python scripts/gemm_bench.py 2>/dev/null | tail -5 > gpurun_out/gemm_bench.txt; cat gpurun_out/gemm_bench.txt
-bash scripts/pmc_gemm_vs_vendor.sh > /dev/null 2>&1; cat gpurun_out/gemm_vs_vendor.txt | cut -c1-220
-for f in $(find $P -name "*.csv" -size -3000k); do d=gpurun_out/prof/$(basename $(dirname $f)); mkdir -p $d; cp $f $d/; done
-ls gpurun_out/prof/*/ | head -40
+for f in $(find $P -name "*.csv" -size -4000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
+python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&1; cat gpurun_out/pmc_summary.txt
+timeout 200 ./scripts/ubench/mfma_power > gpurun_out/mfma_power.txt 2>&1; cat gpurun_out/mfma_power.txt
+ls gpurun_out/prof/
