@@ -15,7 +15,7 @@ for name, N, K, epi in [("ffn1 gelu", 3072, 768, 1), ("plain N=3072", 3072, 768,
     A = to_cm((torch.randn((M, K), device=dev) * 0.5).half()); W0 = (torch.randn((N, K), device=dev) * 0.05).half(); Wc = to_cm(W0)
     bias = torch.randn(N, device=dev)
     out = torch.empty(M * N, dtype=torch.float16, device=dev)
-    for flags, W, tag in ((0x300, W0, "pingpong"), (0x700, Wc, "ring")):
+    for flags, W, tag in ((0x300, W0, "pingpong"), (0x700, Wc, "ring128"), (0xF00, Wc, "ring256")):
         stamps = torch.zeros((256, 32), dtype=torch.int64, device=dev)
         ts = []
         for i in range(6):
