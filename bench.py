@@ -138,7 +138,7 @@ class Ctx:
             self.dist.destroy_process_group()
 
 
-def timed_loop(ctx, step, warmup, steps):
+def timed_loop(ctx, step, warmup, steps, drain=None):
     """W untimed steps, then exactly K steps between two fences (barrier + synchronize on both sides); wall clock = max over ranks.
     ONE HIP event pair on the launch stream brackets the K steps: (event time / K) is the per-step device time and can never
     exceed the wall-clock step.  (Event pairs around every single launch - what round 1 did - put a system-scope release /
@@ -146,12 +146,16 @@ def timed_loop(ctx, step, warmup, steps):
     slower than the back-to-back launches of the timed loop, hence a `kernel_ms` above `ms_per_step` in BENCH_r01.)"""
     for i in range(warmup):
         step(i)
+    if drain:
+        drain()
     ctx.fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(steps):
         step(warmup + i)
+    if drain:
+        drain()          # (inside the timed region: collectives still in flight are part of the K steps)
     ev1.record()
     ctx.fence()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
@@ -237,7 +241,12 @@ class InteractionLeg:
         from capreolus_amd import _lib
 
         _lib.load().capamd_set_concurrent_launches(1 if self.side else 0)
-        self.gathered = torch.empty(self.n_pairs * ctx.world, dtype=torch.float32, device=dev) if ctx.use_dist else None
+        # multi-GPU: the step's all-gather runs asynchronously on RCCL's stream from a snapshot of the scores, under the NEXT step's
+        # scoring (two snapshots / destinations in rotation); every gather is waited for before its buffers are reused and before the
+        # timed region closes
+        self.gathered = [torch.empty(self.n_pairs * ctx.world, dtype=torch.float32, device=dev) for _ in range(2)] if ctx.use_dist else None
+        self.snap = [torch.empty(self.n_pairs, dtype=torch.float32, device=dev) for _ in range(2)] if ctx.use_dist else None
+        self.pending = [None, None]
         self.last_batch = 0
 
     def capture(self):
@@ -261,8 +270,19 @@ class InteractionLeg:
         else:
             self._launch_all(bi)
         if self.ctx.use_dist:
-            self.ctx.dist.all_gather_into_tensor(self.gathered, self.out)
+            k = i & 1
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+            self.snap[k].copy_(self.out)
+            self.pending[k] = self.ctx.dist.all_gather_into_tensor(self.gathered[k], self.snap[k], async_op=True)
+            self.last_gather = k
         self.last_batch = bi
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
 
     def _launch_all(self, bi):
         if self.side:      # independent candidate lists: round-robin over side streams, joined before the step ends
@@ -282,12 +302,12 @@ class InteractionLeg:
         from capreolus_amd import engine
 
         self.capture()
-        elapsed, dev_s = timed_loop(self.ctx, self.step, warmup, steps)
+        elapsed, dev_s = timed_loop(self.ctx, self.step, warmup, steps, self.drain if self.ctx.use_dist else None)
         engine.status_word(self.ctx.dev).raise_if_set()
         assert torch.isfinite(self.out).all()
         if self.ctx.use_dist:
             r = self.ctx.rank
-            assert torch.equal(self.gathered[r * self.n_pairs:(r + 1) * self.n_pairs], self.out)
+            assert torch.equal(self.gathered[self.last_gather][r * self.n_pairs:(r + 1) * self.n_pairs], self.out)
         return elapsed, dev_s
 
     def bytes_requested_per_pair(self):
@@ -352,7 +372,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 "Zipf ids hit L2 / Infinity Cache, so neither is an HBM rate",
     }
     roof = None
-    if not args.no_roofline_leg and ctx.rank == 0:
+    if not args.no_roofline_leg and world == 1:       # (N > 1: every rank does the same work; the roofline leg is an N = 1 measurement)
         # HBM-bound leg: uniform ids over a table 20x the Infinity Cache -> (almost) every gathered row comes from HBM
         big = InteractionLeg(args, Ctx1(ctx), model, args.roofline_vocab, True, 64, 2, 77)
         _, big_s = big.run(2, max(5, min(steps, 10)))
@@ -395,7 +415,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                         f"{launches} launch(es) per step" + (f" round-robin over {len(leg.side)} HIP streams" if leg.side else "") + (", replayed as one captured HIP graph" if leg.graphs else "") +
                         f", {len(leg.batches)} distinct batches in rotation",
             "pairs_per_step_per_gpu": n_pairs,
-            "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU",
+            "parallelism": f"query-sharded x{world}, one all_gather of scores per step (asynchronous, under the next step's scoring)" if world > 1 else "single GPU",
         },
         "roofline": roof if roof is not None else {"bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": None, "peak": HBM_PEAK_GBS,
                                                    "unit": "GB/s", "frac": None, "traffic": None, "headline_leg": headline},
