@@ -27,7 +27,7 @@ class BertModel(ctypes.Structure):
 
     _fields_ = [(n, ctypes.c_int) for n in ("hidden", "layers", "heads", "ffn", "vocab", "max_pos", "type_vocab", "compute_dtype")] + [
         (n, ctypes.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "pooler_w", "pooler_b",
-                                       "cls_w", "cls_b", "blob", "layer_f32")]
+                                       "cls_w", "cls_b", "blob", "layer_f32")] + [("ln_eps", ctypes.c_float), ("pos_pad_id", ctypes.c_int)]
 
 
 _mp = ctypes.POINTER(BertModel)

@@ -21,7 +21,7 @@ using namespace capamd;
 
 namespace {
 
-constexpr float kLnEps = 1e-12f;  // BertConfig.layer_norm_eps
+constexpr float kLnEps = 1e-12f;  // BertConfig.layer_norm_eps (capamd_bert_model.ln_eps = 0)
 
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
                                                  const float* __restrict__ pos, const float* __restrict__ type, int vocab,
                                                  int type_vocab, int S, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, int64_t M, int H,
-                                                 T* xb, int* status, int out_cm) {
+                                                 T* xb, int* status, int out_cm, float eps, int pos_pad_id, int max_pos) {
   // one wave per token row, 8 elements (16 bytes of the 16-bit stream) per lane and step; H <= 1024
   using bf16x8 = typename Half<T>::x8;
   const int lane = threadIdx.x & 63;
@@ -65,8 +65,23 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
       id = 0;
       sg = 0;
     }
+    int64_t pidx = tok % S;
+    if (pos_pad_id >= 0) {
+      // RoBERTa: positions count the non-pad tokens of the passage up to and including this one (HF create_position_ids_from_input_ids)
+      const int64_t i = tok % S;
+      const int64_t* row = ids + (tok - i);
+      int cnt = 0;
+      for (int64_t j = lane; j <= i; j += 64) cnt += row[j] != pos_pad_id;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      pidx = id != pos_pad_id ? pos_pad_id + cnt : pos_pad_id;
+    }
+    if (pidx >= max_pos) {
+      if (lane == 0) atomicOr(status, 1);
+      pidx = 0;
+    }
     r0 = word + id * H;
-    r1 = pos + (tok % S) * H;
+    r1 = pos + pidx * H;
     r2 = type + sg * H;
   }
   float s = 0.f;
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
         q += (a * a + b * b) + (c * c + d * d);
       }
     }
-  const float rstd = rsqrtf(wave_sum64(q) / (float)H + kLnEps);
+  const float rstd = rsqrtf(wave_sum64(q) / (float)H + eps);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = lane + 64 * i;
@@ -232,7 +247,7 @@ struct Dims {
 bool dims_ok(const capamd_bert_model* m) {
   return m && m->hidden >= 64 && m->hidden <= 1024 && m->hidden % 64 == 0 && m->heads * 64 == m->hidden && m->layers >= 1 &&
          m->ffn >= 64 && m->ffn % 64 == 0 && m->vocab >= 1 && m->max_pos >= 1 && m->type_vocab >= 1 &&
-         (m->compute_dtype == 0 || m->compute_dtype == 1);
+         (m->compute_dtype == 0 || m->compute_dtype == 1) && m->ln_eps >= 0.f && m->pos_pad_id < m->vocab;
 }
 
 // LayerNorm folded into the GEMMs (bert_gemm.cuh) needs every encoder GEMM on the ping-pong kernel: N and K multiples of 256
@@ -487,7 +502,7 @@ __global__ void vec_add_kernel(const float* __restrict__ a, const float* __restr
 
 // row statistics of a pre-LayerNorm sum from the partials its producing GEMM wrote (kEpiResidStats), fixed order
 __global__ void ln_stats_kernel(const float* __restrict__ part, int nslot, int H, int64_t M, float* __restrict__ mu, float* __restrict__ rstd,
-                                float2* __restrict__ mr) {
+                                float2* __restrict__ mr, float eps) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   // every slot covers 64 columns: per-slot (mean, M2) merged pairwise-style (equal counts), so that a row whose mean is large
@@ -506,7 +521,7 @@ __global__ void ln_stats_kernel(const float* __restrict__ part, int nslot, int H
     between = __builtin_fmaf(d, d, between);
   }
   const float var = (m2 + 64.f * between) / (float)H;
-  const float r = rsqrtf(var + kLnEps);
+  const float r = rsqrtf(var + eps);
   mu[m] = mean;    // separate arrays: float4 loads of 4 consecutive rows (transposed V^T epilogue)
   rstd[m] = r;
   mr[m] = make_float2(mean, r);  // interleaved: one load per row where a lane owns a row
@@ -600,6 +615,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
                            const capamd_bert_model* m, const Workspace& w, int* status, hipStream_t s, const CedrTap* tap = nullptr) {
   const int H = m->hidden, F = m->ffn;
   const T* blob = (const T*)m->blob;
+  const float eps = m->ln_eps > 0.f ? m->ln_eps : kLnEps;
   hipError_t e = hipSuccess;
 
   for (int64_t p0 = 0; p0 < NP && e == hipSuccess; p0 += mb) {
@@ -618,7 +634,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     const bool fused = !tap && fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
                        pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
     hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M_real + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M_real, H, (T*)w.xb, status, fused ? 1 : 0);
+                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M_real, H, (T*)w.xb, status, fused ? 1 : 0, eps, m->pos_pad_id, m->max_pos);
     if (M > M_real) {   // (S % 32 == 0: the pad rows are whole 32-row groups, contiguous in the row-major and the chunk-major layout alike)
       (void)hipMemsetAsync(w.xb + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
       (void)hipMemsetAsync(w.ctx + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
@@ -673,7 +689,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
           e = launch_gemm<kEpiBiasBf16, T>(g, s);
           if (e != hipSuccess) break;
           hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, (const T*)pre_c, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             0, 0, 1, ln1g, ln1b, npad, H, x_c, status, 0);
+                             0, 0, 1, ln1g, ln1b, npad, H, x_c, status, 0, eps, -1, 0);
           g.N = F; g.K = H; g.A = x_c; g.W = w1; g.bias = b1; g.out_bf16 = mid_c;
           e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
           if (e != hipSuccess) break;
@@ -681,7 +697,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
           e = launch_gemm<kEpiBiasBf16, T>(g, s);
           if (e != hipSuccess) break;
           hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, (const T*)pre_c, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             0, 0, 1, ln2g, ln2b, npad, H, x_c, status, 0);
+                             0, 0, 1, ln2g, ln2b, npad, H, x_c, status, 0, eps, -1, 0);
           cls_done = true;
           cls_x = x_c;
           break;
@@ -697,7 +713,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_p, w.rstd_p, w.mr_p);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_p, w.rstd_p, w.mr_p, eps);
         // mid = gelu(LN1(pre) W1^T + b1)
         g = GemmArgs{};
         g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s + cmo; g.w_cm = ring; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
@@ -713,7 +729,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_x, w.rstd_x, w.mr_x);
+        hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_x, w.rstd_x, w.mr_x, eps);
         last_g = ln2g; last_b = ln2b;
       }
       if (e != hipSuccess) break;
@@ -750,7 +766,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       e = launch_gemm<kEpiBiasBf16, T>(g, s);
       if (e != hipSuccess) break;
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status, 0);
+                         0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status, 0, eps, -1, 0);
       // feed-forward: 768 -> 3072 (GELU) -> 768, residual + LayerNorm
       const bool cm = chunk_major_enabled() && pingpong_shape(M, F, H) && pingpong_shape(M, H, F);  // mid in the chunk-major layout (bert_gemm.cuh)
       g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid; g.out_cm = cm;
@@ -763,7 +779,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       g.a_cm = 0;
       if (e != hipSuccess) break;
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status, 0);
+                         0, 0, S, ln2g, ln2b, M, H, (T*)w.xb, status, 0, eps, -1, 0);
       if (tap) cedr_tap_layer<T>(*tap, l + 1, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s);
     }
     if (e != hipSuccess) break;

@@ -222,9 +222,12 @@ class BertEngine:
 
     COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
 
-    def __init__(self, params, heads, microbatch=256, compute_dtype="fp16", skip_padding=True):
+    def __init__(self, params, heads, microbatch=256, compute_dtype="fp16", skip_padding=True, ln_eps=0.0, pos_pad_id=-1):
+        """ln_eps / pos_pad_id: RoBERTa bodies (include/capreolus_amd.h: capamd_bert_model) - LayerNorm epsilon (0 = BERT's 1e-12) and the
+        padding id its position ids are counted around (-1 = BERT: position i)."""
         if compute_dtype not in self.COMPUTE_DTYPES:
             raise ValueError("compute_dtype must be 'bf16' or 'fp16'")
+        self.ln_eps, self.pos_pad_id = float(ln_eps), int(pos_pad_id)
         self.params = params
         self.heads = heads
         self.microbatch = microbatch
@@ -249,6 +252,7 @@ class BertEngine:
         m.max_pos = p["bert.embeddings.position_embeddings.weight"].shape[0]
         m.type_vocab = p["bert.embeddings.token_type_embeddings.weight"].shape[0]
         m.compute_dtype = self.COMPUTE_DTYPES[self.compute_dtype]
+        m.ln_eps, m.pos_pad_id = self.ln_eps, self.pos_pad_id
         return m
 
     def model(self):

@@ -4,8 +4,9 @@ gfx950 kernels in capreolus_amd/csrc/bert*.{hip,cuh} through the C ABI.
 The reference keeps a transformers `AutoModelForSequenceClassification` in ``self.bert``; here a bare
 parameter container with the same attribute tree (and therefore the same state_dict names:
 ``bert.bert.embeddings.*``, ``bert.bert.encoder.layer.N.*``, ``bert.bert.pooler.dense.*``,
-``bert.classifier.*``) holds the weights, so reference checkpoints load unchanged.  Only BERT-architecture
-checkpoints are supported (bert-base-uncased, Capreolus/bert-base-msmarco, ...).
+``bert.classifier.*``) holds the weights, so reference checkpoints load unchanged.  BERT-architecture checkpoints
+(bert-base-uncased, Capreolus/bert-base-msmarco, ...) and RoBERTa-architecture ones (``bert.roberta.*``, ``bert.classifier.dense|out_proj.*``;
+token types zeroed as ptBERTMaxP.py:57-58 does) are supported; the ELECTRA variants raise, as they do in the reference as written.
 """
 import torch
 from torch import nn
@@ -67,18 +68,34 @@ def bert_container(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, max_p
     return box
 
 
+def roberta_container(hidden=768, layers=12, heads=12, ffn=3072, vocab=50265, max_pos=514, type_vocab=1, pad_token_id=1, layer_norm_eps=1e-5):
+    """Parameter tree of transformers.RobertaForSequenceClassification(num_labels=2) (state_dict names as HF): the BERT encoder under the
+    attribute `roberta`, no pooler, a `dense -> tanh -> out_proj` head on the first token."""
+    body = bert_body(hidden, layers, heads, ffn, vocab, max_pos, type_vocab, pooler=False)
+    for ln in [body.embeddings.LayerNorm] + [m for lyr in body.encoder.layer for m in (lyr.attention.output.LayerNorm, lyr.output.LayerNorm)]:
+        ln.eps = layer_norm_eps
+    box = _Box(roberta=body, classifier=_Box(dense=nn.Linear(hidden, hidden), out_proj=nn.Linear(hidden, 2)))
+    box.num_attention_heads, box.pad_token_id, box.layer_norm_eps = heads, pad_token_id, layer_norm_eps
+    return box
+
+
 class PTBERTMaxP_Class(nn.Module):
     def __init__(self, extractor, config):
         super().__init__()
         self.extractor = extractor
         self.config = config
         pre = config["pretrained"]
+        self.is_roberta = False
         if isinstance(pre, dict):            # explicit geometry, weights loaded later with load_state_dict
-            self.bert = bert_container(**pre)
-        elif isinstance(pre, str) and ("electra" in pre or "roberta" in pre):
-            raise NotImplementedError(f"{pre}: only BERT-architecture sequence classifiers are scored by the MI355X engine")
+            pre = dict(pre)
+            self.is_roberta = pre.pop("arch", "bert") == "roberta"
+            self.bert = roberta_container(**pre) if self.is_roberta else bert_container(**pre)
+        elif isinstance(pre, str) and "electra" in pre:
+            # (the reference's ELECTRA head, ptBERTMaxP.py:14-26, defines `call` instead of `forward`: it raises in the reference too)
+            raise NotImplementedError(f"{pre}: only BERT- and RoBERTa-architecture sequence classifiers are scored by the MI355X engine")
         else:
             self.bert = self._from_hf(pre, config["hidden_dropout_prob"])
+            self.is_roberta = hasattr(self.bert, "roberta")
         self._engine = None
 
     @staticmethod
@@ -90,17 +107,28 @@ class PTBERTMaxP_Class(nn.Module):
             name = "Capreolus/bert-base-msmarco"
         hf = AutoModelForSequenceClassification.from_pretrained(name, hidden_dropout_prob=hidden_dropout_prob)
         c = hf.config
-        if c.model_type != "bert" or c.hidden_act != "gelu" or c.num_labels != 2:
+        if c.model_type not in ("bert", "roberta") or c.hidden_act != "gelu" or c.num_labels != 2:
             raise NotImplementedError(f"{name}: unsupported architecture {c.model_type}/{c.hidden_act}/{c.num_labels} labels")
-        box = bert_container(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size, c.vocab_size,
-                             c.max_position_embeddings, c.type_vocab_size)
+        if c.model_type == "roberta":
+            box = roberta_container(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size, c.vocab_size,
+                                    c.max_position_embeddings, c.type_vocab_size, c.pad_token_id, c.layer_norm_eps)
+        else:
+            box = bert_container(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size, c.vocab_size,
+                                 c.max_position_embeddings, c.type_vocab_size)
         missing = box.load_state_dict(hf.state_dict(), strict=False)
         if missing.missing_keys:
             raise RuntimeError(f"checkpoint lacks {missing.missing_keys}")
         return box
 
     def _params(self):
-        return {k: v for k, v in self.bert.state_dict(keep_vars=True).items() if not k.endswith("position_ids")}
+        p = {k: v for k, v in self.bert.state_dict(keep_vars=True).items() if not k.endswith("position_ids")}
+        if not self.is_roberta:
+            return p
+        # the engine addresses the encoder by the BERT names: same tensors, RoBERTa's head = pooler + classifier under other names
+        q = {"bert." + k[len("roberta."):]: v for k, v in p.items() if k.startswith("roberta.")}
+        q["bert.pooler.dense.weight"], q["bert.pooler.dense.bias"] = p["classifier.dense.weight"], p["classifier.dense.bias"]
+        q["classifier.weight"], q["classifier.bias"] = p["classifier.out_proj.weight"], p["classifier.out_proj.bias"]
+        return q
 
     def forward(self, doc_input, doc_mask, doc_seg):
         if self.training:
@@ -108,6 +136,9 @@ class PTBERTMaxP_Class(nn.Module):
                 "capreolus_amd scores with hand-written inference kernels; fine-tuning (ptBERTMaxP.py:60-61) is not part of "
                 "this engine. Call under model.eval() as PytorchTrainer.predict does."
             )
+        if self.is_roberta:
+            doc_seg = torch.zeros_like(doc_mask)  # "since roberta does not have segment input" (ptBERTMaxP.py:57-58); with it the
+            # passage mask of the sum / avg aggregations is all-False: sum scores 0, avg 0/0 = NaN - in the reference alike
         return self.predict_step(doc_input, doc_mask, doc_seg)
 
     def predict_step(self, doc_input, doc_mask, doc_seg):
@@ -117,7 +148,9 @@ class PTBERTMaxP_Class(nn.Module):
             self._engine = engine.BertEngine(self._params(), self.bert.num_attention_heads,
                                              microbatch=int(self.config.get("microbatch", 256)),
                                              compute_dtype=self.config.get("compute_dtype", "fp16"),
-                                             skip_padding=bool(self.config.get("skip_padding", True)))
+                                             skip_padding=bool(self.config.get("skip_padding", True)),
+                                             ln_eps=self.bert.layer_norm_eps if self.is_roberta else 0.0,
+                                             pos_pad_id=self.bert.pad_token_id if self.is_roberta else -1)
         else:
             self._engine.params = self._params()
         shape = (B, P, S)

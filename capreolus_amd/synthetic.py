@@ -204,3 +204,18 @@ def random_bert_weights(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522, 
             w[p + ln + ".weight"] = 1.0 + n(hidden, s=0.1)
             w[p + ln + ".bias"] = n(hidden, s=0.1)
     return w
+
+
+def random_roberta_weights(hidden=768, layers=12, heads=12, ffn=3072, vocab=50265, max_pos=514, seed=0, std=0.05):
+    """`random_bert_weights` under the HF state_dict names of a RobertaForSequenceClassification (one token type; the pooler / classifier
+    tensors become the head's `classifier.dense` / `classifier.out_proj`)."""
+    w = random_bert_weights(hidden, layers, heads, ffn, vocab, max_pos, type_vocab=1, seed=seed, std=std)
+    out = {}
+    for k, v in w.items():
+        if k.startswith("bert.pooler.dense."):
+            out["classifier.dense." + k.rsplit(".", 1)[1]] = v
+        elif k.startswith("classifier."):
+            out["classifier.out_proj." + k.rsplit(".", 1)[1]] = v
+        else:
+            out["roberta." + k[len("bert."):]] = v
+    return out

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAPAMD_VERSION 100
+#define CAPAMD_VERSION 200
 
 #define CAPAMD_OK 0
 #define CAPAMD_ERR_ARG 1       /* null pointer / bad size / unsupported configuration */
@@ -162,6 +162,14 @@ typedef struct capamd_bert_model {
   const float* cls_b;     /* [2] */
   const void* blob;       /* capamd_bert_blob_bytes(): per layer Wqkv[3H,H] | Wo[H,H] | W1[F,H] | W2[H,F] (+ gamma-scaled Wqkv, W1), 16-bit */
   const float* layer_f32; /* layers * capamd_bert_layer_f32_floats(): bqkv | bo | ln1.g | ln1.b | b1 | b2 | ln2.g | ln2.b | folded-LayerNorm vectors */
+  /* RoBERTa bodies (transformers.RobertaForSequenceClassification behind ptBERTMaxP.py:46-48, 57-58): the same encoder with
+   *   - position ids counted over the non-pad tokens: pad_id + #(ids[0..i] != pad_id) for a non-pad token, pad_id for a pad
+   *     (pos_pad_id >= 0; -1 = BERT: position i),
+   *   - its own LayerNorm epsilon (1e-5; 0 = BERT's 1e-12),
+   *   - a `dense -> tanh -> out_proj` head on the first token: the pooler / classifier arithmetic under other names
+   *     (pooler_w/b = classifier.dense, cls_w/b = classifier.out_proj) and a one-row token-type table. */
+  float ln_eps;
+  int pos_pad_id;
 } capamd_bert_model;
 
 int64_t capamd_bert_blob_bytes(const capamd_bert_model* m);        /* only the int fields are read */

@@ -28,23 +28,40 @@ def _ln(x, w, b, eps=1e-12):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def encode_passages(w, input_ids, attention_mask, token_type_ids, heads, layers):
+def roberta_as_bert(w):
+    """HF RobertaForSequenceClassification state_dict -> the BERT names this file reads: the same encoder under `roberta.`, and a
+    `dense -> tanh -> out_proj` head on the first token, which is the pooler / classifier arithmetic under other names."""
+    q = {"bert." + k[len("roberta."):]: v for k, v in w.items() if k.startswith("roberta.")}
+    q["bert.pooler.dense.weight"], q["bert.pooler.dense.bias"] = w["classifier.dense.weight"], w["classifier.dense.bias"]
+    q["classifier.weight"], q["classifier.bias"] = w["classifier.out_proj.weight"], w["classifier.out_proj.bias"]
+    return q
+
+
+def encode_passages(w, input_ids, attention_mask, token_type_ids, heads, layers, eps=1e-12, pos_pad_id=None):
     """[N, S] int64 x3 -> logits [N, 2] (BertForSequenceClassification.forward in eval mode)."""
-    x = encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers)[-1]
+    x = encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers, eps, pos_pad_id)[-1]
     pooled = torch.tanh(x[:, 0] @ w["bert.pooler.dense.weight"].t() + w["bert.pooler.dense.bias"])
     return pooled @ w["classifier.weight"].t() + w["classifier.bias"]
 
 
-def encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers):
+def encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers, eps=1e-12, pos_pad_id=None):
     """[N, S] int64 x3 -> the layers + 1 hidden states [N, S, H] (BertModel(output_hidden_states=True).hidden_states:
-    the embedding output, then every encoder layer's output)."""
+    the embedding output, then every encoder layer's output).  pos_pad_id (RoBERTa): position ids counted over the non-pad tokens,
+    `cumsum(ids != pad) * (ids != pad) + pad` (transformers create_position_ids_from_input_ids); eps: its LayerNorm epsilon."""
     N, S = input_ids.shape
     H = w["bert.embeddings.word_embeddings.weight"].shape[1]
     dh = H // heads
-    x = (w["bert.embeddings.word_embeddings.weight"][input_ids]
-         + w["bert.embeddings.position_embeddings.weight"][:S].unsqueeze(0)
+    if pos_pad_id is None:
+        pos = w["bert.embeddings.position_embeddings.weight"][:S].unsqueeze(0)
+    else:
+        nonpad = (input_ids != pos_pad_id).long()
+        pos = w["bert.embeddings.position_embeddings.weight"][torch.cumsum(nonpad, dim=1) * nonpad + pos_pad_id]
+    x = (w["bert.embeddings.word_embeddings.weight"][input_ids] + pos
          + w["bert.embeddings.token_type_embeddings.weight"][token_type_ids])
-    x = _ln(x, w["bert.embeddings.LayerNorm.weight"], w["bert.embeddings.LayerNorm.bias"])
+    def ln(t, g, b):  # (the model's epsilon everywhere below)
+        return _ln(t, g, b, eps)
+
+    x = ln(x, w["bert.embeddings.LayerNorm.weight"], w["bert.embeddings.LayerNorm.bias"])
     bias = (1.0 - attention_mask.float()).view(N, 1, 1, S) * torch.finfo(torch.float32).min
     hidden = [x]
     for i in range(layers):
@@ -58,16 +75,17 @@ def encode_hidden(w, input_ids, attention_mask, token_type_ids, heads, layers):
         v = lin("attention.self.value", x).view(N, S, heads, dh).transpose(1, 2)
         a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + bias, dim=-1)
         ctx = (a @ v).transpose(1, 2).reshape(N, S, H)
-        x = _ln(lin("attention.output.dense", ctx) + x, w[p + "attention.output.LayerNorm.weight"],
+        x = ln(lin("attention.output.dense", ctx) + x, w[p + "attention.output.LayerNorm.weight"],
                 w[p + "attention.output.LayerNorm.bias"])
         h = F.gelu(lin("intermediate.dense", x))  # erf GELU
-        x = _ln(lin("output.dense", h) + x, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"])
+        x = ln(lin("output.dense", h) + x, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"])
         hidden.append(x)
     return hidden
 
 
-def maxp(w, doc_input, doc_mask, doc_seg, heads, layers, aggregation="max", chunk=64):
-    """PTBERTMaxP_Class.predict_step (ptBERTMaxP.py:67-96): [B, P, S] int64 x3 -> [B] fp32."""
+def maxp(w, doc_input, doc_mask, doc_seg, heads, layers, aggregation="max", chunk=64, eps=1e-12, pos_pad_id=None):
+    """PTBERTMaxP_Class.predict_step (ptBERTMaxP.py:67-96): [B, P, S] int64 x3 -> [B] fp32.
+    RoBERTa (`roberta_as_bert(w)`, eps 1e-5, pos_pad_id 1): the caller zeroes doc_seg as ptBERTMaxP.py:57-58 does."""
     B, P, S = doc_input.shape
     passage_position = (doc_mask * doc_seg).sum(dim=-1)           # :75
     passage_mask = (passage_position > 5).long()                  # :76
@@ -75,7 +93,7 @@ def maxp(w, doc_input, doc_mask, doc_seg, heads, layers, aggregation="max", chun
     outs = []
     with torch.no_grad():
         for lo in range(0, B * P, chunk):
-            outs.append(encode_passages(w, flat[0][lo:lo + chunk], flat[1][lo:lo + chunk], flat[2][lo:lo + chunk], heads, layers)[:, 1])
+            outs.append(encode_passages(w, flat[0][lo:lo + chunk], flat[1][lo:lo + chunk], flat[2][lo:lo + chunk], heads, layers, eps, pos_pad_id)[:, 1])
     s = torch.cat(outs).reshape(B, P)                             # :82-83
     if aggregation == "max":
         return s.max(dim=1)[0]

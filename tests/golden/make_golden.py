@@ -318,6 +318,10 @@ if __name__ == "__main__":
         gen_drmm(DRMM)
     if "drmmtks" in which:
         gen_drmmtks(TKS)
+    if "roberta" in which or (which >= {"knrm", "bert", "cedr"}):
+        from make_golden_bert import gen_roberta
+
+        gen_roberta(MAXP)
     if "bert" in which or any(w.startswith("bert:") for w in which):     # "bert:base_long" = only that case
         from make_golden_bert import gen_bert
 

@@ -70,6 +70,58 @@ def gen_bert(MAXP, only=None):
         print("bert", name, {k: v[:3] for k, v in out.items() if k.startswith("ref_") and v.ndim == 1})
 
 
+ROBERTA_CASES = {
+    # the reference PTBERTMaxP_Class with a "roberta*" checkpoint name (ptBERTMaxP.py:46-48, 57-58) driving transformers' RobertaForSequenceClassification
+    "roberta_mini": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=1000, max_pos=130, B=5, P=3, S=64, seed=31),
+    # hidden 256 / ffn 512: every encoder GEMM on the chunk-major (folded-LayerNorm, ring kernel) path; S = 128 -> positions up to 129
+    "roberta_h256": dict(hidden=256, layers=3, heads=4, ffn=512, vocab=1200, max_pos=130, B=4, P=4, S=128, seed=32),
+}
+
+
+def gen_roberta(MAXP, only=None):
+    from transformers import AutoModelForSequenceClassification, RobertaConfig, RobertaForSequenceClassification
+
+    for name, c in ROBERTA_CASES.items():
+        if only and name not in only:
+            continue
+        cfg = RobertaConfig(num_labels=2, hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                            intermediate_size=c["ffn"], vocab_size=c["vocab"], max_position_embeddings=c["max_pos"], type_vocab_size=1,
+                            pad_token_id=1, layer_norm_eps=1e-5)
+        w = synthetic.random_roberta_weights(c["hidden"], c["layers"], c["heads"], c["ffn"], c["vocab"], c["max_pos"], seed=c["seed"])
+        orig = AutoModelForSequenceClassification.from_pretrained
+        AutoModelForSequenceClassification.from_pretrained = staticmethod(lambda *a, **k: RobertaForSequenceClassification(cfg))
+        try:
+            out = {}
+            rs = np.random.RandomState(c["seed"])
+            batch = synthetic.make_bert_passages(rs, c["B"], c["P"], c["S"], vocab=c["vocab"], same_query=False)
+            batch["pos_bert_input"] = np.where(batch["pos_bert_input"] == 0, 1, batch["pos_bert_input"])     # RoBERTa's <pad> is id 1
+            ti = {k: torch.from_numpy(v) for k, v in batch.items()}
+            for agg in ("max", "first", "sum", "avg"):
+                model = MAXP.PTBERTMaxP_Class(
+                    SimpleNamespace(config={"numpassages": c["P"], "maxseqlen": c["S"]}),
+                    {"pretrained": "roberta-base", "aggregation": agg, "hidden_dropout_prob": 0.1})
+                missing = model.bert.load_state_dict(w, strict=False)
+                assert not [k for k in missing.missing_keys if "position_ids" not in k] and not missing.unexpected_keys, missing
+                model.eval()
+                with torch.no_grad():
+                    out["ref_" + agg] = model(ti["pos_bert_input"], ti["pos_mask"], ti["pos_seg"]).view(-1).numpy().astype(np.float32)
+                    if agg == "max":
+                        flat = [ti[k].reshape(-1, c["S"]) for k in ("pos_bert_input", "pos_mask")]
+                        out["ref_passage_logits"] = model.bert(flat[0], attention_mask=flat[1], token_type_ids=torch.zeros_like(flat[1]))[0].numpy().astype(np.float32)
+                        for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                            with torch.autocast("cpu", dtype=dt):
+                                amp = model.bert(flat[0], attention_mask=flat[1], token_type_ids=torch.zeros_like(flat[1]))[0]
+                            out["ref_passage_logits_amp_" + tag] = amp.float().numpy().astype(np.float32)
+        finally:
+            AutoModelForSequenceClassification.from_pretrained = orig
+        np.savez_compressed(
+            os.path.join(HERE, f"bert_{name}.npz"), weight_seed=np.int64(c["seed"]),
+            dims=np.array([c["hidden"], c["layers"], c["heads"], c["ffn"], c["vocab"], c["max_pos"]], dtype=np.int64),
+            pos_bert_input=batch["pos_bert_input"].astype(np.int32), pos_mask=batch["pos_mask"].astype(np.int8),
+            pos_seg=batch["pos_seg"].astype(np.int8), **out)
+        print("bert", name, {k: v[:3] for k, v in out.items() if k.startswith("ref_") and v.ndim == 1})
+
+
 CEDR_CASES = {
     # name: encoder dims + inputs (as above), then the CEDR-KNRM options
     "mini": dict(hidden=128, layers=2, heads=2, ffn=512, vocab=1000, max_pos=128, B=5, P=3, S=64, seed=21,

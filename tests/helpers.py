@@ -51,6 +51,23 @@ def rank_order(scores_f16):
 BERT_CASES = ["mini", "mini_s128", "base", "base_long"]
 
 
+ROBERTA_CASES = ["roberta_mini", "roberta_h256"]
+
+
+def load_roberta_case(name):
+    """(fixture dict, HF-named RobertaForSequenceClassification weights)"""
+    import torch
+
+    z = np.load(os.path.join(GOLDEN, f"bert_{name}.npz"))
+    c = {k: z[k] for k in z.files}
+    hidden, layers, heads, ffn, vocab, max_pos = (int(x) for x in c["dims"])
+    c.update(hidden=hidden, layers=layers, heads=heads, ffn=ffn, vocab=vocab, max_pos=max_pos)
+    c["weights"] = synthetic.random_roberta_weights(hidden, layers, heads, ffn, vocab, max_pos, seed=int(c["weight_seed"]))
+    for k in ("pos_bert_input", "pos_mask", "pos_seg"):
+        c[k] = torch.from_numpy(c[k].astype(np.int64))
+    return c
+
+
 def load_bert_case(name):
     import torch
 

@@ -225,6 +225,46 @@ def test_bert_maxp_end_to_end(name, dt):
                 assert got_doc[i] > got_doc[j], (name, dt, i, j)
 
 
+@pytest.mark.parametrize("name", ["roberta_mini", "roberta_h256"])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_roberta_maxp_end_to_end(name, dt):
+    """A RoBERTa body behind PTBERTMaxP (reference ptBERTMaxP.py:46-48, 57-58; HF RobertaForSequenceClassification): pad-relative
+    position ids, LayerNorm eps 1e-5, the dense -> tanh -> out_proj head, token types zeroed.  Same yardstick as the BERT fixtures."""
+    from tests.helpers import load_roberta_case
+
+    c = load_roberta_case(name)
+    B, P, S = c["pos_bert_input"].shape
+    pre = dict(arch="roberta", hidden=c["hidden"], layers=c["layers"], heads=c["heads"], ffn=c["ffn"], vocab=c["vocab"], max_pos=c["max_pos"])
+    d = {k: c[k].to(DEV) for k in ("pos_bert_input", "pos_mask", "pos_seg")}
+    ref_l = c["ref_passage_logits"][:, 1]
+    amp_err = np.abs(c["ref_passage_logits_amp_" + dt][:, 1] - ref_l).max()
+    bound = (1.25 if dt == "fp16" else 1.5) * amp_err + 1e-4
+    for agg in ("max", "first", "sum", "avg"):
+        r = PTBERTMaxP({"pretrained": pre, "aggregation": agg, "compute_dtype": dt}, SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
+        m = r.build_model()
+        m.bert.load_state_dict(c["weights"], strict=True)       # the reference's checkpoint names
+        m.to(DEV).eval()
+        with torch.no_grad():
+            got = r.test(d).cpu().numpy()
+        if agg == "avg":
+            assert np.isnan(c["ref_avg"]).all() and np.isnan(got).all()        # 0 / 0 with zeroed token types, as the reference
+        elif agg == "sum":
+            assert (got == 0).all() and (c["ref_sum"] == 0).all()
+        else:
+            assert np.abs(got - c["ref_" + agg]).max() <= bound, (name, agg, dt, np.abs(got - c["ref_" + agg]).max(), bound)
+    with torch.no_grad():
+        for sp in (True, False):      # length buckets: pad-relative positions depend on the prefix only -> bit-identical
+            out, plog = m._engine.forward(d["pos_bert_input"], d["pos_mask"], torch.zeros_like(d["pos_seg"]), "max", return_passage_logits=True, skip_padding=sp)
+            err = np.abs(plog.cpu().numpy() - ref_l).max()
+            assert err <= bound, (name, dt, sp, err, amp_err)
+            if sp:
+                first = plog.clone()
+        assert torch.equal(first, plog)
+    print(f"{name} {dt}: max abs err on passage logits {err:.2e} (reference autocast {amp_err:.2e})")
+    with pytest.raises(NotImplementedError):
+        PTBERTMaxP({"pretrained": "google/electra-base-discriminator"}, SimpleNamespace(config={"numpassages": P, "maxseqlen": S})).build_model()
+
+
 @pytest.mark.parametrize("S,n_docs,P", [(64, 4, 4), (128, 4, 2), (192, 4, 1), (256, 3, 1), (256, 2, 3), (384, 2, 1), (512, 2, 2)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_fused_layernorm_path_other_geometries(S, n_docs, P, dt):

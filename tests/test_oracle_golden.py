@@ -170,6 +170,29 @@ def test_bert_port_matches_reference(name):
         assert rel_err(got, c["ref_" + agg][sl]).max() <= 2e-5, (name, agg)
 
 
+@pytest.mark.parametrize("name", ["roberta_mini", "roberta_h256"])
+def test_roberta_port_matches_reference(name):
+    """RoBERTa bodies behind ptBERTMaxP (ptBERTMaxP.py:46-48, 57-58): position ids counted over non-pad tokens, LayerNorm eps 1e-5, the
+    `dense -> tanh -> out_proj` head, token types zeroed - whence `sum` scores 0 and `avg` is 0/0 in the reference."""
+    import torch
+
+    from oracle import bert_port
+    from tests.helpers import load_roberta_case
+
+    c = load_roberta_case(name)
+    w = bert_port.roberta_as_bert(c["weights"])
+    zeros = torch.zeros_like(c["pos_seg"])
+    for agg in ("max", "first", "sum", "avg"):
+        got = bert_port.maxp(w, c["pos_bert_input"], c["pos_mask"], zeros, c["heads"], c["layers"], agg, eps=1e-5, pos_pad_id=1).numpy()
+        ref = c["ref_" + agg]
+        if agg == "avg":
+            assert np.isnan(ref).all() and np.isnan(got).all()
+        elif agg == "sum":
+            assert (ref == 0).all() and (got == 0).all()
+        else:
+            assert rel_err(got, ref).max() <= 2e-5, (name, agg)
+
+
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
 def test_ndcg20_parity_oracle_vs_reference(kind):
     """The metric's parity half (BASELINE.json: nDCG@20 parity vs ref) on the 200-document ranking lists."""
