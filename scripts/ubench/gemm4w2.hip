@@ -108,7 +108,23 @@ __global__ __launch_bounds__(256, 1) void gemm4w2(const _Float16* __restrict__ A
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][i], fa[cur][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+#if ABL & 8
+          // power experiment only (wrong arithmetic): the same FLOPs as four 16x16x32 MFMAs on the same operand registers
+          typedef __attribute__((ext_vector_type(4))) float f32x4;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 c0 = {acc[i][j][8 * h + 0], acc[i][j][8 * h + 1], acc[i][j][8 * h + 2], acc[i][j][8 * h + 3]};
+            f32x4 c1 = {acc[i][j][8 * h + 4], acc[i][j][8 * h + 5], acc[i][j][8 * h + 6], acc[i][j][8 * h + 7]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][i], fa[cur][j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][i], fa[cur][j], c1, 0, 0, 0);
+            acc[i][j][8 * h + 0] = c0[0]; acc[i][j][8 * h + 1] = c0[1]; acc[i][j][8 * h + 2] = c0[2]; acc[i][j][8 * h + 3] = c0[3];
+            acc[i][j][8 * h + 4] = c1[0]; acc[i][j][8 * h + 5] = c1[1]; acc[i][j][8 * h + 6] = c1[2]; acc[i][j][8 * h + 7] = c1[3];
+          }
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][i], fa[cur][j], acc[i][j], 0, 0, 0);
+#endif
+        }
 #if !(ABL & 4)
       // 16 MFMA | 8 DS read | 4 VMEM: M R M V M R M  x4
 #pragma unroll
