@@ -16,8 +16,9 @@
 //                                    the MFMAs, where nothing covers their issue time
 // The fill stream runs kSlots slices ahead of consumption and straight on across the tile boundaries of the persistent schedule: the
 // last kSlots slices of a tile fetch the first kSlots of the block's next tile, and the epilogue runs with (kSlots-1) P pieces in
-// flight.  Past the block's last tile the LDS-DMA source lies beyond the buffer extent (reads as zeros) - the steady state is one basic
-// block with exact vmcnt arithmetic, no tail cases.  After an epilogue, slices 0 .. kSlots-2 of the next tile allow kEpiVmem more
+// flight.  Past the block's last tile the fill stream simply re-reads the first slices of tile (0, 0) into slots nobody consumes (valid
+// memory: the scalar offset of a buffer load is not range-checked, so it must not point past the tensor) - the steady state is one
+// basic block with exact vmcnt arithmetic, no tail cases.  After an epilogue, slices 0 .. kSlots-2 of the next tile allow kEpiVmem more
 // outstanding operations: the epilogue's VMEM operations are younger than the pieces those slices wait for (VMEM operations retire in
 // order) and every epilogue issues at least kEpiVmem of them.
 //
@@ -127,7 +128,7 @@ struct GemmRing {
     for (int it = 0;; ++it) {
       int m1 = 0, n1 = 0;
       const bool more = G::tile_of(g, it + 1, m1, n1);
-      if (!more) { m1 = g.M; n1 = g.N; }              // beyond both extents: the run-ahead LDS-DMAs read zeros
+      if (!more) { m1 = 0; n1 = 0; }                  // nothing follows: the run-ahead LDS-DMAs re-read the first tile's slices (never consumed)
       const Bases nxt = bases_of(g, m1, n1, L.wave);
       f32x16 acc[4][TM];
 #pragma unroll

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w2(const _Float16* __restrict__ A
   int tile = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
   int m0 = (tile / tn) * 256, n0 = (tile % tn) * 256;
   // scalar byte offsets of this wave's pieces (row-blocks 2w, 2w+1 of the A and of the B panel) of k-slice 0 of a tile; a k-slice
-  // further is +1024 bytes.  Beyond the last tile the offsets lie outside the buffer extent: those LDS-DMAs read zeros.
+  // further is +1024 bytes.
   auto bases = [&](int t, unsigned (&sa)[2], unsigned (&sb)[2]) {
+    if (t >= ntiles) t = 0;     // nothing follows: re-read tile 0's slices into slots nobody consumes (the scalar offset is not range-checked)
     const int tm = (t / tn) * 256, tn0 = (t % tn) * 256;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
