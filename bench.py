@@ -312,10 +312,18 @@ class InteractionLeg:
 
     def bytes_requested_per_pair(self):
         """What the kernel asks the memory system for: the id rows (int64), one packed table row (row_stride floats: the embedding,
-        its norm, padding to whole 128-byte lines) per in-vocabulary document term and per query term, the score.  Pads and OOV
-        terms are scored in closed form without a gather."""
-        nonpad = float(sum(int((b["posdoc"] > 0).sum().item()) for b in self.batches)) / (len(self.batches) * self.n_pairs)
-        return self.L * 8 + self.Q * 8 + (nonpad + self.Q) * self.row_stride * 4 + 4 + (4 * self.Q if self.model == "drmm" else 0), nonpad
+        its norm, padding to whole 128-byte lines) per DISTINCT in-vocabulary document term and per query term, the score.  A term the
+        document repeats is gathered once and weighted by its count; pads and OOV terms are scored in closed form without a gather
+        (DESIGN.md §3.1).  Returns (bytes per pair, mean non-pad terms per document, mean distinct terms per document)."""
+        nonpad = distinct = 0
+        for b in self.batches:
+            srt = torch.sort(b["posdoc"], dim=1).values
+            nonpad += int((srt > 0).sum().item())
+            distinct += int((srt[:, 0] > 0).sum().item()) + int(((srt[:, 1:] != srt[:, :-1]) & (srt[:, 1:] > 0)).sum().item())
+        n = len(self.batches) * self.n_pairs
+        nonpad, distinct = nonpad / n, distinct / n
+        return (self.L * 8 + self.Q * 8 + (distinct + self.Q) * self.row_stride * 4 + 4 + (4 * self.Q if self.model == "drmm" else 0), nonpad,
+                distinct)
 
     def check_against_oracle(self, n):
         """The scores the timed loop left in `out` (its last step's batch) against the C oracle on the first n pairs; returns what the
@@ -358,15 +366,15 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     leg = InteractionLeg(args, ctx, model, args.vocab, args.uniform_ids, per_rank_q, max(1, args.batches), 1 + ctx.rank)
     elapsed, dev_s = leg.run(warmup, steps)
     n_pairs = leg.n_pairs
-    req_b, nonpad = leg.bytes_requested_per_pair()
+    req_b, nonpad, distinct = leg.bytes_requested_per_pair()
     abytes = algorithmic_bytes_per_pair(model, Q, L, D)
     launches = len(leg.slices)
     headline = {
         "ids": "uniform" if args.uniform_ids else "Zipf(1.1)", "vocab": args.vocab, "kernel_ms": dev_s * 1e3 / launches,
-        "pairs_per_launch": n_pairs / launches, "mean_nonpad_terms_per_doc": nonpad, "requested_bytes_per_pair": req_b,
+        "pairs_per_launch": n_pairs / launches, "mean_nonpad_terms_per_doc": nonpad, "mean_distinct_terms_per_doc": distinct, "requested_bytes_per_pair": req_b,
         "requested_GBps": n_pairs * req_b / dev_s / 1e9,
         "algorithmic_bytes_per_pair": abytes, "algorithmic_GBps": n_pairs * abytes / dev_s / 1e9,
-        "note": "cache-level rates of the headline leg: bytes the kernel requests (ids + one packed row per in-vocabulary term) and the "
+        "note": "cache-level rates of the headline leg: bytes the kernel requests (ids + one packed row per distinct in-vocabulary term of a document) and the "
                 "SURVEY §8(d) algorithmic bytes (all L positions x fp32 row - pads and OOV terms are scored in closed form, never gathered) "
                 "over the per-step device time (one HIP event pair around the timed steps; in a multi-GPU run it includes the all_gather). "
                 "Zipf ids hit L2 / Infinity Cache, so neither is an HBM rate",
@@ -376,7 +384,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         # HBM-bound leg: uniform ids over a table 20x the Infinity Cache -> (almost) every gathered row comes from HBM
         big = InteractionLeg(args, Ctx1(ctx), model, args.roofline_vocab, True, 64, 2, 77)
         _, big_s = big.run(2, max(5, min(steps, 10)))
-        big_req, big_nonpad = big.bytes_requested_per_pair()
+        big_req, big_nonpad, big_distinct = big.bytes_requested_per_pair()
         ach = big.n_pairs * big_req / big_s / 1e9
         roof = {
             "bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -386,8 +394,9 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             "leg": f"uniform term ids over a {args.roofline_vocab}-row table ({args.roofline_vocab * big.row_stride * 4 / 1e9:.1f} GB packed, 20x the 256 MB "
                    "Infinity Cache), 64 x 1000 pairs per launch, 2 alternating batches: HBM is the binding resource",
             "kernel_ms": big_s * 1e3, "pairs_per_launch": big.n_pairs, "requested_bytes_per_pair": big_req, "mean_nonpad_terms_per_doc": big_nonpad,
-            "definition": "achieved = bytes the kernel requests (int64 id rows + one packed 1280-byte table row per in-vocabulary document / query "
-                          "term + score) / per-launch device time (one HIP event pair around the timed launches); every requested row is a "
+            "mean_distinct_terms_per_doc": big_distinct,
+            "definition": "achieved = bytes the kernel requests (int64 id rows + one packed 1280-byte table row per distinct in-vocabulary document term "
+                          "and per query term + score) / per-launch device time (one HIP event pair around the timed launches); every requested row is a "
                           "distinct random row, so requested bytes = HBM bytes up to the <= 5 % the Infinity Cache can hold",
             "headline_leg": headline,
         }

@@ -72,8 +72,11 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   float* edges = reinterpret_cast<float*>(hist + kQT * kMaxBins);  // [kMaxBins]
   float* zlds = edges + kMaxBins;                              // [kMaxQ]
   float* glds = zlds + kMaxQ;                                  // [kMaxQ]
-  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [8]: 0..3 real counts, 4..7 oov counts
-  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);      // QLDS: [kQT][NV*16] float4
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [12] (+4 spare): distinct_terms' per-wave counts
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 16);     // QLDS: [kQT][NV*16] float4
+  int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);  // [tok_cap] multiplicity of tok[k]
+  int* hkey = mult + tok_cap;                                    // [kHashSlots] phase 1 only
+  int* hfirst = hkey + kHashSlots;                               // [kHashSlots] phase 1 only
 
   const int tid = threadIdx.x;
   const int lane16 = tid & 15;
@@ -86,30 +89,9 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
 
   if (tid < a.nbins) edges[tid] = a.edges[tid];
 
-  // ---- compact real document terms; count OOV terms --------------------------------------
-  int n_real = 0, n_oov = 0;
-  for (int base = 0; base < a.L; base += kThreads) {
-    const int j = base + tid;
-    int64_t did = (j < a.L) ? ids.d(j) : 0;
-    if (did >= a.V) {
-      atomicOr(a.status, kErrDocIdRange);
-      did = 0;
-    }
-    const bool real = did > 0;
-    const unsigned long long m = __ballot(real);
-    const unsigned long long mo = __ballot(did < 0);
-    if (lane == 0) {
-      wave_cnt[wave] = __popcll(m);
-      wave_cnt[4 + wave] = __popcll(mo);
-    }
-    __syncthreads();
-    int off = n_real;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (real) tok[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)did;
-    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
-    __syncthreads();
-  }
+  // ---- the document's distinct real terms with their multiplicities; OOV count (interaction.cuh) --------
+  const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
+  const int n_real = tl.n_unique, n_oov = tl.n_oov;
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
@@ -141,9 +123,10 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
 #pragma unroll
         for (int u = 0; u < U; ++u)
           if (has[u]) {
+            const int m = mult[t0 + u * kGroupsPerWG];     // how often the document repeats this term
             const int bu = bin_of(x[u], edges, a.nbins);
-            if (bu < a.nbins) atomicAdd(&h[bu], 1);
-            if (x[u] > 0.999f && x[u] < 1.001f) atomicAdd(&h[a.nbins], 1);
+            if (bu < a.nbins) atomicAdd(&h[bu], m);
+            if (x[u] > 0.999f && x[u] < 1.001f) atomicAdd(&h[a.nbins], m);
           }
       }
     }
@@ -226,7 +209,7 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   DrmmArgs a{ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 16 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
@@ -264,7 +247,7 @@ extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
              nullptr, nullptr, nullptr, nullptr, status, feat_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 8) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 16 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)

@@ -82,6 +82,101 @@ __device__ __forceinline__ PairIds pair_ids(const IdSource& s, int b, int Q, int
   return p;
 }
 
+// ---- phase 1 of the scoring kernels: the document's real terms, each DISTINCT id once, with its multiplicity ------------------------
+// A document repeats its frequent terms (Zipf-distributed ids, 300 real terms: 59 % distinct; natural text is no different), and a
+// repeated term has the same similarity to every query term - so its packed row is gathered ONCE and its contribution multiplied by
+// its count (kernel pooling: count x K(sim); matching histogram: bin += count, still exact integers).  The distinct ids come out in
+// the order of their FIRST occurrence in the document, which makes the list - and with it every floating-point sum over it - a
+// function of the id row alone, whatever order the hash insertions happened to race in:
+//   A  every real position inserts its id into an LDS hash set (linear probing, ds_cmpst) and atomic-mins its position into the slot
+//   B  the position that holds a slot's minimum is the id's owner: owners are compacted in document order (ballot + popcount, as
+//      before) into tok[]; the slot remembers the owner's dense index
+//   C  every real position adds 1 to mult[dense index of its slot]
+// Documents longer than kDedupMaxL positions (the API allows 32768) skip the hash and list every real term with multiplicity 1.
+constexpr int kHashSlots = 1024;
+constexpr int kDedupMaxL = 896;               // <= 4 positions per thread, load factor <= 0.875
+constexpr int kDedupPos = (kDedupMaxL + 255) / 256;
+
+struct TermList {
+  int n_unique;   // entries of tok[] / mult[]
+  int n_real;     // real (id > 0) positions, repeats included
+  int n_oov;      // negative ids
+};
+
+// tok, mult: [L rounded up to 4] ints; key, first: [kHashSlots] ints; wave_cnt: [12] ints.  All LDS.  256 threads.
+__device__ __forceinline__ TermList distinct_terms(const PairIds& ids, int L, int64_t V, int* status, int* tok, int* mult, int* key, int* first,
+                                                   int* wave_cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TermList r{0, 0, 0};
+  if (L > kDedupMaxL) {   // no hash: every real term, multiplicity 1
+    for (int base = 0; base < L; base += kThreads) {
+      const int j = base + tid;
+      int64_t did = (j < L) ? ids.d(j) : 0;
+      if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
+      const bool real = did > 0;
+      const unsigned long long m = __ballot(real), mo = __ballot(did < 0);
+      if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); }
+      __syncthreads();
+      int off = r.n_unique;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      if (real) { const int k = off + __popcll(m & ((1ull << lane) - 1ull)); tok[k] = (int)did; mult[k] = 1; }
+      r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+      __syncthreads();
+    }
+    r.n_real = r.n_unique;
+    return r;
+  }
+  for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
+  for (int i = tid; i < L; i += kThreads) mult[i] = 0;
+  __syncthreads();
+  int id_r[kDedupPos], slot_r[kDedupPos];
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // A
+    const int j = it * kThreads + tid;
+    int64_t did = (j < L) ? ids.d(j) : 0;
+    if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
+    id_r[it] = did < 0 ? -1 : (int)did;
+    slot_r[it] = -1;
+    if (did > 0) {
+      unsigned h = ((unsigned)did * 2654435761u) >> 22;
+      for (;;) {
+        const int old = atomicCAS(&key[h], 0, (int)did);
+        if (old == 0 || old == (int)did) break;
+        h = (h + 1) & (kHashSlots - 1);
+      }
+      slot_r[it] = (int)h;
+      atomicMin(&first[h], j);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // B (document order: it-major, then thread)
+    const int j = it * kThreads + tid;
+    const bool real = slot_r[it] >= 0;
+    const bool owner = real && first[slot_r[it]] == j;
+    const unsigned long long m = __ballot(owner), mr = __ballot(real), mo = __ballot(id_r[it] < 0);
+    if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); wave_cnt[8 + wave] = __popcll(mr); }
+    __syncthreads();   // (also: every comparison against first[] above is done before any slot is overwritten below)
+    int off = r.n_unique;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (owner) {
+      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+      tok[k] = id_r[it];
+      first[slot_r[it]] = -1 - k;       // negative: never equal to a position
+    }
+    r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+    r.n_real += wave_cnt[8] + wave_cnt[9] + wave_cnt[10] + wave_cnt[11];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it)              // C
+    if (slot_r[it] >= 0) atomicAdd(&mult[-1 - first[slot_r[it]]], 1);
+  __syncthreads();
+  return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

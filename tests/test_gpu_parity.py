@@ -269,6 +269,60 @@ def test_full_size_drmm_properties(full):
     assert rel_err(s[idx].cpu().numpy(), want).max() <= ORACLE_TOL
 
 
+def _repeated_term_docs(L, V, seed):
+    """Documents that stress the distinct-term pass (interaction.cuh: distinct_terms): one term repeated over the whole document,
+    terms that all land in one hash bucket (longest probe chains), heavy repetition with OOV terms and pads mixed in, no repetition."""
+    rng = np.random.default_rng(seed)
+    ids = np.arange(1, V, dtype=np.int64)
+    bucket = ((ids * 2654435761) & 0xFFFFFFFF) >> 22
+    same = ids[bucket == np.bincount(bucket).argmax()]          # every id of the fullest hash bucket
+    d = np.zeros((6, L), dtype=np.int64)
+    d[0, :] = 7
+    d[1, :] = rng.choice(same, L)
+    b0 = int(bucket[same[0] - 1])
+    d[2, :] = rng.choice(ids[(bucket >= b0) & (bucket < b0 + 24)], L)   # ~470 ids over 24 adjacent buckets: one long cluster
+    d[3, :] = rng.integers(1, 40, L)
+    d[3, rng.random(L) < 0.2] = -1
+    d[3, rng.random(L) < 0.2] = 0
+    d[4, :] = rng.permutation(V - 1)[:L] + 1
+    d[5, : L // 3] = rng.integers(1, V, L // 3)                 # short document, pads behind it
+    q = np.array([[7, int(same[0]), 3, 0]] * 6, dtype=np.int64)
+    return q, d
+
+
+@pytest.mark.parametrize("L", [800, 896, 897, 1024, 5])
+def test_repeated_document_terms(L):
+    V, D = 20000, 300
+    rng = np.random.default_rng(L)
+    emb = (rng.standard_normal((V, D)) * 0.4).astype(np.float32)
+    emb[0] = 0
+    q, d = _repeated_term_docs(L, V, L)
+    idf = rng.random((6, 4)).astype(np.float32)
+    packed = oracle.pack(emb)
+    batch = {"query": _t(q), "posdoc": _t(d), "query_idf": _t(idf)}
+    # KNRM: repeated terms are gathered once and weighted by their count; the oracle walks every position
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        s = r.test(batch).cpu().numpy()
+    mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+    want, _ = oracle.knrm(q, d, packed, D, mu, sigma, m.combine[0].weight.detach().cpu().numpy(), m.combine[0].bias.detach().cpu().numpy())
+    assert rel_err(s, want).max() <= ORACLE_TOL
+    # DRMM: the bin counts stay bit-exact
+    r = DRMM({}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        c0 = torch.empty((6, 4, 30), dtype=torch.int32, device=DEV)
+        s = m(batch["posdoc"], batch["query"], batch["query_idf"], counts_out=c0).view(-1).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    want, wcounts, err = oracle.drmm(q, d, idf, packed, D, torch.linspace(-1, 1, 30)[1:].numpy(), "LCH", "IDF", sd["gates.weight"], emb,
+                                     sd["ffw.0.weight"], sd["ffw.0.bias"], sd["ffw.2.weight"], sd["ffw.2.bias"], sd["output_layer.weight"],
+                                     sd["output_layer.bias"])
+    assert err == 0
+    assert np.array_equal(c0.cpu().numpy(), wcounts)
+    assert rel_err(s, want).max() <= ORACLE_TOL
+
+
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
 def test_ndcg20_parity_gpu_vs_reference(kind):
     from capreolus_amd import run_io
