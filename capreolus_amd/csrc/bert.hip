@@ -277,9 +277,22 @@ int num_cus() {
 template <typename T>
 void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
   if (S == 256) {
-    // persistent + double-buffered (bert_attn.cuh); CAPAMD_ATTN_ONESHOT=1 selects the one-shot kernel for A/B runs
-    static const bool oneshot = [] { const char* e = getenv("CAPAMD_ATTN_ONESHOT"); return e && e[0] == '1'; }();
-    if (oneshot) {
+    // two 4-wave workgroups per CU, 64 queries per wave (bert_attn.cuh: attention_s256_kernel); CAPAMD_ATTN=oneshot | persistent
+    // select the earlier kernels for A/B runs
+    static const int which = [] {
+      const char* e = getenv("CAPAMD_ATTN");
+      if (e && e[0] == 'o') return 1;
+      if (e && e[0] == 'p') return 2;
+      return 0;
+    }();
+    if (which == 0) {
+      const unsigned slots = 2u * (unsigned)num_cus();
+      const dim3 grid(nblk < slots ? nblk : slots), block(256);
+      if (at.qk_cm && at.ctx_cm) hipLaunchKernelGGL((attention_s256_kernel<T, true, true>), grid, block, 0, s, at, (int)nblk);
+      else if (at.qk_cm) hipLaunchKernelGGL((attention_s256_kernel<T, true, false>), grid, block, 0, s, at, (int)nblk);
+      else if (at.ctx_cm) hipLaunchKernelGGL((attention_s256_kernel<T, false, true>), grid, block, 0, s, at, (int)nblk);
+      else hipLaunchKernelGGL((attention_s256_kernel<T, false, false>), grid, block, 0, s, at, (int)nblk);
+    } else if (which == 1) {
       hipLaunchKernelGGL((attention_kernel<256, 8, T>), dim3(nblk), dim3(512), 0, s, at);
     } else {
       constexpr int kAttnLds = 2 * (256 * 128 + 64 * 256 * 2 + 256 * 4);

@@ -88,6 +88,70 @@ __device__ inline float softmax_inplace(f32x16 (&sc)[NT]) {
   return 1.f / sum;
 }
 
+// out * (1 / sum) rounded to the 16-bit type in two steps (fp32 product, then the conversion), in every kernel: under hipcc's default
+// -ffp-contract=fast the compiler may fuse the two into one v_fma_mixlo_f16 (a single rounding) in one kernel and not in another,
+// and the same passage would then score a 16-bit ulp differently depending on which kernel its length bucket selects.
+template <typename T>
+__device__ __forceinline__ T scale_round(float v, float inv) {
+#pragma clang fp contract(off)
+  float m = v * inv;
+  asm volatile("" : "+v"(m));
+  return (T)m;
+}
+
+// ---- the arithmetic every S <= 256 kernel below shares (so that a passage scores bit-identically whichever kernel its length
+//      bucket selects) ------------------------------------------------------------------------------------------------------
+// Key order: the A-operand row i of a 32-key score tile holds key i with bits 2 and 3 swapped (`key_of_row`), so that register r of
+// the tile is key 32 t + 16 (r >> 3) + 8 half + (r & 7): the 8 probabilities a lane feeds to one P V MFMA are 8 CONSECUTIVE keys
+// and the matching V^T fragment is 16 contiguous bytes.
+__device__ __forceinline__ int key_of_row(int l31) { return (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1); }
+
+template <int NT>
+__device__ inline f32x16 scores_init_permuted(const float* madd_t) {   // madd_t = madd + 32 t + 8 half; register r <- key 32t + 16(r>>3) + 8 half + (r&7)
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 ma = *reinterpret_cast<const float4*>(madd_t + 16 * (g >> 1) + 4 * (g & 1));
+    v[g * 4 + 0] = ma.x;
+    v[g * 4 + 1] = ma.y;
+    v[g * 4 + 2] = ma.z;
+    v[g * 4 + 3] = ma.w;
+  }
+  return v;
+}
+
+// exact softmax of one query row (a lane pair) over NT x 16 scores, probabilities rounded to the 16-bit type as they are produced
+// (half a tile at a time: 8 fp32 scores leave as 4 packed registers); returns 1 / sum
+template <int NT, typename T>
+__device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename Half<T>::x8 (&p)[NT][2]) {
+  float mx = -3.4028234663852886e38f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  constexpr float kLog2e = 1.4426950408889634f;
+  const float nb = -mx * kLog2e;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][8 * s2 + e], kLog2e, nb));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part[e & 3] += x[e];
+        p[t][s2][e] = (T)x[e];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  float sum = (part[0] + part[1]) + (part[2] + part[3]);
+  sum += __shfl_xor(sum, 32, 64);
+  return 1.f / sum;
+}
+
 // NW = waves per workgroup (each wave owns 32 queries); S/32/NW workgroups share one (passage, head) and each
 // stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V staged
 // once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us:
@@ -142,20 +206,25 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of K: hipcc does not wait for it at the barrier by itself
   __syncthreads();
 
-  // ---- scores^T tiles: lane <- query l31, keys 32t + 8*(r>>2) + 4*half + (r&3) ----
-  f32x16 sc[NT];
+  // ---- scores^T tiles: lane <- query l31, keys 32t + 16*(r>>3) + 8*half + (r&7) (key_of_row) ----
+  const int lperm = key_of_row(l31);
+  bf16x8 pf[NT][2];
+  float inv;
+  {
+    f32x16 sc[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    sc[t] = scores_init_from_mask(madd + t * 32 + 4 * half);
+    for (int t = 0; t < NT; ++t) {
+      sc[t] = scores_init_permuted<NT>(madd + t * 32 + 8 * half);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int row = t * 32 + l31;
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
-      sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = t * 32 + lperm;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
+        sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+      }
     }
+    // ---- exact softmax over the S keys of this lane's query ----
+    inv = softmax_pack<NT, T>(sc, pf);
   }
-  // ---- exact softmax over the S keys of this lane's query ----
-  const float inv = softmax_inplace<NT>(sc);
 
   // ---- ctx^T = V^T · P^T : out[dt] lane <- query l31, d = 32dt + 8*(r>>2) + 4*half + (r&3) ----
   f32x16 out[2];
@@ -167,18 +236,15 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pf;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pf[e] = (T)sc[t][8 * s2 + e];
-      const int kb = (32 * t + 16 * s2 + 4 * half) * 2;  // byte offset of keys {kb/2 .. +3}; second group +8 keys
+      const int kb = (32 * t + 16 * s2 + 8 * half) * 2;  // byte offset of keys 32t + 16 s2 + 8 half .. + 7 in a V^T row (8-byte aligned rows)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const char* vr = Vs + (dt * 32 + l31) * VROW + kb;
         const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
         const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
         const bf16x8 vf = __builtin_bit_cast(bf16x8, raw);
-        out[dt] = Half<T>::mfma(vf, pf, out[dt]);
+        out[dt] = Half<T>::mfma(vf, pf[t][s2], out[dt]);
       }
     }
   const int64_t ctok = tok0 + qwave * 32 + l31;
@@ -186,8 +252,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv),
-                  (T)(out[dt][g4 * 4 + 2] * inv), (T)(out[dt][g4 * 4 + 3] * inv)};
+      bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv),
+                  scale_round<T>(out[dt][g4 * 4 + 2], inv), scale_round<T>(out[dt][g4 * 4 + 3], inv)};
       *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
     }
 }
@@ -312,13 +378,197 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
-                      (T)(out[dt][g4 * 4 + 3] * inv)};
+          bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv), scale_round<T>(out[dt][g4 * 4 + 2], inv),
+                      scale_round<T>(out[dt][g4 * 4 + 3], inv)};
           *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
         }
     }
     if (!more) break;
     stores_pending = true;
+  }
+}
+
+// ---- S = 256, two independent 4-wave workgroups per CU (the default) ----------------------------------------------------------------
+// What bounds the 8-wave kernel above is not one resource but their SUM: its waves run in lockstep (one barrier per item), so
+// all of them read K fragments, then all of them do softmax VALU work, then all of them read V fragments - per item about 2 k
+// cycles of LDS reads for QK^T, 4.8 k of VALU, 4 k of LDS reads for P V (the b64 V reads are 2-way bank conflicted), MFMA pipe busy
+// 20 %.  This kernel is laid out so that the phases of different waves overlap instead:
+//   * 4 waves per workgroup, 2 workgroups per CU (64 KiB of LDS each, 256 registers per wave): the two workgroups share nothing
+//     and drift apart, so one's softmax sits beside the other's MFMAs / LDS reads;
+//   * a wave owns 64 queries as two 32-query blocks handled one after the other (scores -> softmax -> P V, twice): the registers of
+//     one block at a time (128 score registers) fit the 256-register budget of two waves per SIMD;
+//   * the key order inside a 32-key tile is permuted on the K side (A-operand row i holds key i with bits 2 and 3 swapped), so the
+//     8 probabilities a lane contributes to one P V MFMA are 8 CONSECUTIVE keys: the matching V^T fragment is one 16-byte chunk
+//     (ds_read_b128, conflict-free under the chunk swizzle) instead of two conflicted b64 halves;
+//   * K and V^T have one buffer each, refilled by LDS-DMA as soon as the workgroup is done with it: K(i+1) streams in under
+//     P V of block B of item i, V^T(i+1) under the scores of block A of item i+1.  Four barriers per item.
+// 16 bytes per lane from global memory straight into LDS (64 lanes -> 1 KiB at `lds_addr`, a wave-uniform LDS byte address), issued
+// from inline assembly on purpose: hipcc puts an `s_waitcnt vmcnt(0)` in front of the first LDS read after any LDS-DMA it has seen
+// issued (it cannot tell which LDS bytes are in flight), which turns a refill that should run under the next phase into a stall at
+// the top of it.  The kernel below waits for its DMAs explicitly where it needs them.  M0 is saved and restored around the issue.
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_addr) {
+  uint32_t saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved)
+               : "s"(lds_addr), "v"(gptr)
+               : "memory");
+}
+
+// QKCM / CTXCM: the activation layouts (AttnArgs::qk_cm, ctx_cm) as compile-time constants - as run-time flags every address
+// computation exists twice and the spare copies cost registers this kernel does not have
+template <typename T, bool QKCM, bool CTXCM>
+__global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int n_items) {
+  using bf16x8 = typename Half<T>::x8;
+  using bf16x4 = typename Half<T>::x4;
+  constexpr int S = 256, NT = 8, KBYTES = S * 128, VBYTES = 64 * S * 2;
+  __shared__ __attribute__((aligned(16))) char Ks[KBYTES];
+  __shared__ __attribute__((aligned(16))) char Vs[VBYTES];
+  __shared__ __attribute__((aligned(16))) float madd[S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int lperm = key_of_row(l31);
+  const int Hc = a.H >> 3;                                              // 16-byte chunks per activation row
+  const uint32_t ks_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)Ks), vs_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)Vs);
+
+  // byte offset of chunk `chunk` of local token row `row` (0..255) from the passage's first row, either activation layout
+  // (a passage starts on a multiple of 32 rows, so its chunk-major image starts at the same element offset tok0 * H)
+  auto row_off = [&](int row, int chunk) -> uint32_t {
+    return (uint32_t)(QKCM ? (((row >> 5) * Hc + chunk) * 32 + (row & 31)) * 16 : (row * Hc + chunk) * 16);
+  };
+  auto stage_k = [&](int item) {
+    const int psg = item / a.heads, head = item % a.heads;
+    const char* kb = static_cast<const char*>(a.K) + (int64_t)psg * S * a.H * 2;
+    const int r8 = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = (wave * 8 + t) * 8 + r8;
+      lds_dma16(kb + row_off(row, head * 8 + swz_chunk(row, p)), ks_addr + (wave * 8 + t) * 1024);
+    }
+  };
+  auto stage_v = [&](int item) {
+    const char* vb = static_cast<const char*>(a.Vt) + (int64_t)item * 64 * S * 2;
+    const int r2 = lane >> 5, pc = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int d = (wave * 8 + t) * 2 + r2;
+      lds_dma16(vb + (uint32_t)(d * (S * 2) + ((pc ^ (d & 31)) << 4)), vs_addr + (wave * 8 + t) * 1024);
+    }
+  };
+  auto load_q = [&](int item, bf16x8 (&qf)[2][4]) {
+    const int psg = item / a.heads, head = item % a.heads;
+    const char* qb = static_cast<const char*>(a.Q) + (int64_t)psg * S * a.H * 2;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[x][ks] = *reinterpret_cast<const bf16x8*>(qb + row_off(wave * 64 + x * 32 + l31, head * 8 + 2 * ks + half));
+  };
+  // scores^T of one 32-query block against all 256 keys, then the exact softmax, packed to the 16-bit type
+  auto scores_block = [&](const bf16x8 (&q)[4], bf16x8 (&p)[NT][2]) -> float {
+    f32x16 sc[NT];
+    int kbase = lperm * 128 + half * 16, ksw = ((lperm >> 1) & 7) << 4;   // K image: row * 128 + ((2 ks + half) ^ ((row >> 1) & 7)) * 16
+    asm volatile("" : "+v"(kbase), "+v"(ksw));                          // (re-derived per block: not hoisted out of the item loop)
+#pragma unroll
+    for (int t = 0; t < NT; t += 2) {
+      sc[t] = scores_init_permuted<NT>(madd + t * 32 + 8 * half);
+      sc[t + 1] = scores_init_permuted<NT>(madd + (t + 1) * 32 + 8 * half);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t + u) * 4096 + ((kbase + ks * 32) ^ ksw));
+          sc[t + u] = Half<T>::mfma(kf, q[ks], sc[t + u]);
+        }
+      }
+    }
+    return softmax_pack<NT, T>(sc, p);
+  };
+
+  // ctx^T = V^T . P^T of one query block: out[dt] lane <- query l31, d = 32 dt + 8 (r >> 2) + 4 half + (r & 3); scaled, rounded, stored
+  auto pv_block = [&](const bf16x8 (&p)[NT][2], float inv, int64_t ctok, int head) {
+    f32x16 out[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
+    int vbase = l31 * 512 + half * 16, vsw = l31 << 4;   // V^T image: d * 512 + ((4 t + 2 s2 + half) ^ (d & 31)) * 16
+    asm volatile("" : "+v"(vbase), "+v"(vsw));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int o = (vbase + (4 * t + 2 * s2) * 16) ^ vsw;
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(Vs + o);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vs + o + 32 * 512);
+        out[0] = Half<T>::mfma(v0, p[t][s2], out[0]);
+        out[1] = Half<T>::mfma(v1, p[t][s2], out[1]);
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv), scale_round<T>(out[dt][g4 * 4 + 2], inv), scale_round<T>(out[dt][g4 * 4 + 3], inv)};
+        T* c = static_cast<T*>(a.ctx);
+        if (CTXCM) c += (((ctok >> 5) * Hc + head * 8 + dt * 4 + g4) * 32 + (ctok & 31)) * 8 + 4 * half;   // ctx_slot, chunk-major
+        else c += ctok * a.H + head * 64 + dt * 32 + 8 * g4 + 4 * half;
+        *reinterpret_cast<bf16x4*>(c) = o;
+      }
+  };
+
+  // The compiler's own wait for the Q loads would sit at their first use - the top of the next item, AFTER the V^T DMAs have been
+  // issued behind them, where (the counter being in order) it would wait for those as well.  Using the registers right after the
+  // explicit wait pins the compiler's wait to that point, where it is free.
+  auto touch_q = [&](bf16x8 (&qf)[2][4]) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[x][ks]));
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  bf16x8 qf[2][4];
+  {
+    const int64_t mval = a.mask[(int64_t)(item / a.heads) * S + tid];
+    stage_k(item);
+    load_q(item, qf);
+    madd[tid] = mval != 0 ? 0.f : -3.4028234663852886e38f;   // HF: (1 - mask) * finfo.min
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    touch_q(qf);
+    stage_v(item);
+  }
+  for (;; item += gridDim.x) {
+    const int nxt = item + gridDim.x;
+    const bool more = nxt < n_items;
+    const int psg = item / a.heads, head = item % a.heads;
+    const int64_t ctok = (int64_t)psg * S + wave * 64 + l31;
+    // B0: K(item), Q(item) and madd(item) are in place (every wave waited for its own DMA slices before it issued V^T / wrote madd)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 p[NT][2];
+    float inv = scores_block(qf[0], p);
+    // B1: every wave's V^T(item) slices have landed (issued before the scores of block A)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    pv_block(p, inv, ctok, head);
+    __builtin_amdgcn_sched_barrier(0);
+    inv = scores_block(qf[1], p);
+    // B2: every wave is done with K and madd -> refill K; the next item's Q fragments and mask row travel with it
+    __builtin_amdgcn_s_barrier();
+    if (more) {
+      stage_k(nxt);
+      load_q(nxt, qf);
+    }
+    // kept raw (and loaded unconditionally, so that no select is formed here): converting it now would put a wait for everything
+    // just issued in front of the P V pass
+    const int64_t mnext = a.mask[(int64_t)((more ? nxt : item) / a.heads) * S + tid];
+    pv_block(p, inv, ctok + 32, head);
+    if (!more) break;
+    // B3: every wave is done with V^T; K(nxt), Q(nxt) and the mask row have landed (issued a whole P V pass ago)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    touch_q(qf);
+    __builtin_amdgcn_s_barrier();
+    madd[tid] = mnext != 0 ? 0.f : -3.4028234663852886e38f;
+    stage_v(nxt);
   }
 }
 
@@ -499,8 +749,8 @@ __global__ __launch_bounds__(S * 2) void attention_long_kernel(AttnArgs a) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      bf16x4 o = {(T)(out[dt][g4 * 4 + 0] * inv), (T)(out[dt][g4 * 4 + 1] * inv), (T)(out[dt][g4 * 4 + 2] * inv),
-                  (T)(out[dt][g4 * 4 + 3] * inv)};
+      bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv), scale_round<T>(out[dt][g4 * 4 + 2], inv),
+                  scale_round<T>(out[dt][g4 * 4 + 3], inv)};
       *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
     }
 }
