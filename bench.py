@@ -77,9 +77,11 @@ def parse():
     ap.add_argument("--bert-skip-padding", action="store_true",
                     help="BERT: encode passages in length buckets (multiples of 32 tokens) - identical scores, padded rows not computed. Off by "
                          "default here: the headline line times the reference's full 4 x 256-token computation")
-    ap.add_argument("--bert-two-streams", action="store_true",
-                    help="BERT, full-length mode: the engine's default of running two halves of a large batch on two streams (+2.6 %). "
-                         "Off here so that the dominant kernel's HIP-event duration in `roofline` is not inflated by a concurrent kernel")
+    ap.add_argument("--bert-microbatch", type=int, default=256, help="passages (of 256 tokens) per encoder micro-batch")
+    ap.add_argument("--bert-streams", type=int, default=2,
+                    help="BERT: slices of a step's passages encoded concurrently on their own HIP streams and workspaces (the engine's default is 2; "
+                         "1 = strictly serial kernels).  `roofline` times the dominant kernel in a separate serial step after the timed ones, so "
+                         "that its HIP-event duration is not inflated by a concurrent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the DRMM / BERT legs of the default invocation")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
@@ -642,7 +644,7 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
     d = bert_queries(args.docs, range(first_q, first_q + per_rank_q), P, S, VOCAB, dev)
     docs = args.docs * per_rank_q
     weights = synthetic.random_bert_weights(H, LAYERS, HEADS, F, VOCAB, 512, seed=0)
-    rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": 256,
+    rr = PTBERTMaxP({"pretrained": dict(hidden=H, layers=LAYERS, heads=HEADS, ffn=F, vocab=VOCAB, max_pos=512), "microbatch": args.bert_microbatch,
                      "compute_dtype": args.bert_dtype, "skip_padding": bool(args.bert_skip_padding)},
                     SimpleNamespace(config={"numpassages": P, "maxseqlen": S}))
     m = rr.build_model()
@@ -650,7 +652,7 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
     m.to(dev).eval()
     with torch.no_grad():
         rr.test({k: v[:8] for k, v in d.items()})   # builds the 16-bit blob
-    m._engine.two_streams = bool(args.bert_two_streams)
+    m._engine.n_streams = max(1, args.bert_streams)
     eng = m._engine
     gathered = torch.empty(docs * world, dtype=torch.float32, device=dev) if use_dist else None
     out = [None]
@@ -663,16 +665,30 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
     lib = _lib.load()
     for i in range(warmup):
         step(i)
-    lib.capamd_debug_ffn1_timing(1)  # HIP events around the dominant kernel's launches during the timed steps (read back below)
+    serial = eng.n_streams == 1
+    if serial:
+        lib.capamd_debug_ffn1_timing(1)  # HIP events around the dominant kernel's launches during the timed steps (read back below)
     elapsed, dev_s = timed_loop(ctx, step, 0, steps)
     engine.status_word(dev).raise_if_set()
     assert torch.isfinite(out[0]).all()
+    scores = out[0].clone()
 
     # dominant kernel: the FFN1 GEMM (folded LayerNorm + bias + GELU epilogue), timed by the library's HIP events around each of its
-    # launches on the bench stream during the timed steps (capamd_debug_ffn1_timing, include/capreolus_amd.h)
+    # launches (capamd_debug_ffn1_timing, include/capreolus_amd.h) - during the timed steps when they run on one stream, otherwise in
+    # one more step of the same batch run strictly serially (kernels of concurrent streams would stretch each other's durations)
+    if not serial:
+        eng.n_streams = 1
+        step(0)                       # (sizes the single-stream workspace)
+        torch.cuda.synchronize(dev)
+        lib.capamd_debug_ffn1_timing(1)
+        step(0)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out[0], scores), "the serial and the multi-stream step disagree"
+        eng.n_streams = max(1, args.bert_streams)
     tot_ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
     _lib.check(lib.capamd_debug_ffn1_timing_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(rows)), "ffn1 timing")
     lib.capamd_debug_ffn1_timing(0)
+    out[0] = scores
     gemm_s = tot_ms.value * 1e-3 / max(1, launches.value)
     gemm_tf = 2.0 * rows.value * F * H / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
     Mg = rows.value // max(1, launches.value)
@@ -687,9 +703,10 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
         "config": {"workload": f"BERT-base MaxP inference (BASELINE.json configs[{4 if strong else 3}]): {P} passages x {S} tokens per doc, {docs} docs per step "
                                f"per GPU ({per_rank_q} quer{'y' if per_rank_q == 1 else 'ies'} x {args.docs} candidates, generator seeded 1000 + qid), seeded "
                                f"random-init weights, {args.bert_dtype} MFMA operands and activations, fp32 accumulate/LayerNorm statistics/softmax",
-                   "passages_per_s": psg_per_s,
+                   "passages_per_s": psg_per_s, "streams": eng.n_streams,
                    "parallelism": f"queries in contiguous blocks over {world} ranks, one all_gather of document scores per step" if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": f"gemm_pingpong_kernel<bias+GELU> (FFN1: mean M={Mg} N={F} K={H}; {launches.value} launches in the timed steps)",
+        "roofline": {"bound": "mfma", "kernel": f"{'gemm_pingpong_kernel' if os.environ.get('CAPAMD_GEMM_RING') == '0' else 'gemm_ring_kernel'}<folded LayerNorm + bias + GELU> (FFN1: mean M={Mg} N={F} K={H}; {launches.value} launches "
+                               + ("in the timed steps)" if serial else "in one strictly serial step after the timed ones)"),
                      "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
                      "traffic": None, "kernel_ms": gemm_s * 1e3, "device_ms_per_step": dev_s * 1e3,
                      "whole_step_achieved": step_tf, "whole_step_frac": step_tf / MFMA_BF16_PEAK_TFLOPS,

@@ -122,8 +122,12 @@ __device__ inline f32x16 scores_init_permuted(const float* madd_t) {   // madd_t
 
 // exact softmax of one query row (a lane pair) over NT x 16 scores, probabilities rounded to the 16-bit type as they are produced
 // (half a tile at a time: 8 fp32 scores leave as 4 packed registers); returns 1 / sum
-template <int NT, typename T>
-__device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename Half<T>::x8 (&p)[NT][2]) {
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// hook(0 .. 2 NT - 1) runs after each half tile (the S = 256 kernel issues its refills there)
+template <int NT, typename T, typename Hook = NoHook>
+__device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename Half<T>::x8 (&p)[NT][2], Hook&& hook = Hook()) {
   float mx = -3.4028234663852886e38f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -145,6 +149,7 @@ __device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename H
         part[e & 3] += x[e];
         p[t][s2][e] = (T)x[e];
       }
+      hook(2 * t + s2);
       __builtin_amdgcn_sched_barrier(0);
     }
   float sum = (part[0] + part[1]) + (part[2] + part[3]);
@@ -401,18 +406,31 @@ __global__ __launch_bounds__(512) void attention_persistent_kernel(AttnArgs a, i
 //     8 probabilities a lane contributes to one P V MFMA are 8 CONSECUTIVE keys: the matching V^T fragment is one 16-byte chunk
 //     (ds_read_b128, conflict-free under the chunk swizzle) instead of two conflicted b64 halves;
 //   * K and V^T have one buffer each, refilled by LDS-DMA as soon as the workgroup is done with it: K(i+1) streams in under
-//     P V of block B of item i, V^T(i+1) under the scores of block A of item i+1.  Four barriers per item.
+//     P V of block B of item i, V^T(i+1) under the scores of block A of item i+1.  Three barriers per item.
 // 16 bytes per lane from global memory straight into LDS (64 lanes -> 1 KiB at `lds_addr`, a wave-uniform LDS byte address), issued
 // from inline assembly on purpose: hipcc puts an `s_waitcnt vmcnt(0)` in front of the first LDS read after any LDS-DMA it has seen
 // issued (it cannot tell which LDS bytes are in flight), which turns a refill that should run under the next phase into a stall at
 // the top of it.  The kernel below waits for its DMAs explicitly where it needs them.  M0 is saved and restored around the issue.
-__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_addr) {
+__device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint32_t lds_addr) {   // base: wave-uniform; voff: this lane's byte offset
   uint32_t saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // (uniform already; keeps the value in an SGPR whatever the compiler did with the arithmetic before)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(saved)
-               : "s"(lds_addr), "v"(gptr)
+               : "s"(lds_addr), "v"(voff), "s"(base)
                : "memory");
 }
+
+// builder-side phase timing (scripts/ubench/attn_trace.hip defines CAPAMD_ATTN_TRACE): thread 0 of every workgroup stamps s_memtime
+#ifdef CAPAMD_ATTN_TRACE
+__device__ unsigned long long* g_attn_trace;
+#define ATTN_STAMP_DECL int stamp_it = 0
+#define ATTN_STAMP(k) do { if (tid == 0 && stamp_it < 8) g_attn_trace[(blockIdx.x * 8 + stamp_it) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define ATTN_STAMP_NEXT ++stamp_it
+#else
+#define ATTN_STAMP_DECL
+#define ATTN_STAMP(k)
+#define ATTN_STAMP_NEXT
+#endif
 
 // QKCM / CTXCM: the activation layouts (AttnArgs::qk_cm, ctx_cm) as compile-time constants - as run-time flags every address
 // computation exists twice and the spare copies cost registers this kernel does not have
@@ -435,36 +453,26 @@ __global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int 
   auto row_off = [&](int row, int chunk) -> uint32_t {
     return (uint32_t)(QKCM ? (((row >> 5) * Hc + chunk) * 32 + (row & 31)) * 16 : (row * Hc + chunk) * 16);
   };
-  auto stage_k = [&](int item) {
-    const int psg = item / a.heads, head = item % a.heads;
+  // The refills are issued ONE instruction at a time between the MFMAs of the phase they hide behind (dma_k / dma_v / load_q1, t = 0..7
+  // per wave), not as a burst: a wave that issues 8 KiB of LDS-DMA back to back sits in the issue until the CU's ~20-25 B/clk fill
+  // path has taken it (measured: 1.5-2.5 k cycles per burst, 5.8 k of a 21.6 k-cycle item).
+  auto dma_k = [&](int psg, int head, int t) {   // 8 rows x 128 B of the K image: rows (wave * 8 + t) * 8 .. + 7
     const char* kb = static_cast<const char*>(a.K) + (int64_t)psg * S * a.H * 2;
-    const int r8 = lane >> 3, p = lane & 7;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int row = (wave * 8 + t) * 8 + r8;
-      lds_dma16(kb + row_off(row, head * 8 + swz_chunk(row, p)), ks_addr + (wave * 8 + t) * 1024);
-    }
+    const int row = (wave * 8 + t) * 8 + (lane >> 3);
+    lds_dma16(kb, row_off(row, head * 8 + swz_chunk(row, lane & 7)), ks_addr + (wave * 8 + t) * 1024);
   };
-  auto stage_v = [&](int item) {
+  auto dma_v = [&](int item, int t) {            // 2 rows x 512 B of the V^T image: d = (wave * 8 + t) * 2 + {0, 1}
     const char* vb = static_cast<const char*>(a.Vt) + (int64_t)item * 64 * S * 2;
-    const int r2 = lane >> 5, pc = lane & 31;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int d = (wave * 8 + t) * 2 + r2;
-      lds_dma16(vb + (uint32_t)(d * (S * 2) + ((pc ^ (d & 31)) << 4)), vs_addr + (wave * 8 + t) * 1024);
-    }
+    const int d = (wave * 8 + t) * 2 + half;
+    lds_dma16(vb, (uint32_t)(d * (S * 2) + ((l31 ^ (d & 31)) << 4)), vs_addr + (wave * 8 + t) * 1024);
   };
-  auto load_q = [&](int item, bf16x8 (&qf)[2][4]) {
-    const int psg = item / a.heads, head = item % a.heads;
+  auto load_q1 = [&](int psg, int head, bf16x8 (&qf)[2][4], int j) {   // Q fragment j = 4 x + ks of this wave's two query blocks
     const char* qb = static_cast<const char*>(a.Q) + (int64_t)psg * S * a.H * 2;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[x][ks] = *reinterpret_cast<const bf16x8*>(qb + row_off(wave * 64 + x * 32 + l31, head * 8 + 2 * ks + half));
+    const int x = j >> 2, ks = j & 3;
+    qf[x][ks] = *reinterpret_cast<const bf16x8*>(qb + row_off(wave * 64 + x * 32 + l31, head * 8 + 2 * ks + half));
   };
-  // scores^T of one 32-query block against all 256 keys, then the exact softmax, packed to the 16-bit type
-  auto scores_block = [&](const bf16x8 (&q)[4], bf16x8 (&p)[NT][2]) -> float {
-    f32x16 sc[NT];
+  // scores^T of one 32-query block against all 256 keys; hook(0..3) runs between the tile pairs
+  auto qk_block = [&](const bf16x8 (&q)[4], f32x16 (&sc)[NT], auto&& hook) {
     int kbase = lperm * 128 + half * 16, ksw = ((lperm >> 1) & 7) << 4;   // K image: row * 128 + ((2 ks + half) ^ ((row >> 1) & 7)) * 16
     asm volatile("" : "+v"(kbase), "+v"(ksw));                          // (re-derived per block: not hoisted out of the item loop)
 #pragma unroll
@@ -479,12 +487,12 @@ __global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int 
           sc[t + u] = Half<T>::mfma(kf, q[ks], sc[t + u]);
         }
       }
+      hook(t >> 1);
     }
-    return softmax_pack<NT, T>(sc, p);
   };
-
-  // ctx^T = V^T . P^T of one query block: out[dt] lane <- query l31, d = 32 dt + 8 (r >> 2) + 4 half + (r & 3); scaled, rounded, stored
-  auto pv_block = [&](const bf16x8 (&p)[NT][2], float inv, int64_t ctok, int head) {
+  // ctx^T = V^T . P^T of one query block: out[dt] lane <- query l31, d = 32 dt + 8 (r >> 2) + 4 half + (r & 3); scaled, rounded, stored;
+  // hook(0..15) runs between the (t, s2) steps
+  auto pv_block = [&](const bf16x8 (&p)[NT][2], float inv, int64_t ctok, int head, auto&& hook) {
     f32x16 out[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -501,19 +509,20 @@ __global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int 
         const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(Vs + o + 32 * 512);
         out[0] = Half<T>::mfma(v0, p[t][s2], out[0]);
         out[1] = Half<T>::mfma(v1, p[t][s2], out[1]);
+        hook(2 * t + s2);
       }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv), scale_round<T>(out[dt][g4 * 4 + 2], inv), scale_round<T>(out[dt][g4 * 4 + 3], inv)};
+        bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv), scale_round<T>(out[dt][g4 * 4 + 2], inv),
+                    scale_round<T>(out[dt][g4 * 4 + 3], inv)};
         T* c = static_cast<T*>(a.ctx);
         if (CTXCM) c += (((ctok >> 5) * Hc + head * 8 + dt * 4 + g4) * 32 + (ctok & 31)) * 8 + 4 * half;   // ctx_slot, chunk-major
         else c += ctok * a.H + head * 64 + dt * 32 + 8 * g4 + 4 * half;
         *reinterpret_cast<bf16x4*>(c) = o;
       }
   };
-
   // The compiler's own wait for the Q loads would sit at their first use - the top of the next item, AFTER the V^T DMAs have been
   // issued behind them, where (the counter being in order) it would wait for those as well.  Using the registers right after the
   // explicit wait pins the compiler's wait to that point, where it is free.
@@ -523,53 +532,89 @@ __global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int 
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[x][ks]));
   };
+  auto no_hook = [](int) {};
 
   int item = blockIdx.x;
   if (item >= n_items) return;
   bf16x8 qf[2][4];
   {
-    const int64_t mval = a.mask[(int64_t)(item / a.heads) * S + tid];
-    stage_k(item);
-    load_q(item, qf);
+    const int psg = item / a.heads, head = item % a.heads;
+    const int64_t mval = a.mask[(int64_t)psg * S + tid];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dma_k(psg, head, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_q1(psg, head, qf, j);
     madd[tid] = mval != 0 ? 0.f : -3.4028234663852886e38f;   // HF: (1 - mask) * finfo.min
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    touch_q(qf);
-    stage_v(item);
-  }
-  for (;; item += gridDim.x) {
-    const int nxt = item + gridDim.x;
-    const bool more = nxt < n_items;
-    const int psg = item / a.heads, head = item % a.heads;
-    const int64_t ctok = (int64_t)psg * S + wave * 64 + l31;
-    // B0: K(item), Q(item) and madd(item) are in place (every wave waited for its own DMA slices before it issued V^T / wrote madd)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[0][ks]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    bf16x8 p[NT][2];
-    float inv = scores_block(qf[0], p);
-    // B1: every wave's V^T(item) slices have landed (issued before the scores of block A)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    pv_block(p, inv, ctok, head);
-    __builtin_amdgcn_sched_barrier(0);
-    inv = scores_block(qf[1], p);
-    // B2: every wave is done with K and madd -> refill K; the next item's Q fragments and mask row travel with it
-    __builtin_amdgcn_s_barrier();
-    if (more) {
-      stage_k(nxt);
-      load_q(nxt, qf);
-    }
-    // kept raw (and loaded unconditionally, so that no select is formed here): converting it now would put a wait for everything
-    // just issued in front of the P V pass
-    const int64_t mnext = a.mask[(int64_t)((more ? nxt : item) / a.heads) * S + tid];
-    pv_block(p, inv, ctok + 32, head);
-    if (!more) break;
-    // B3: every wave is done with V^T; K(nxt), Q(nxt) and the mask row have landed (issued a whole P V pass ago)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    touch_q(qf);
-    __builtin_amdgcn_s_barrier();
-    madd[tid] = mnext != 0 ? 0.f : -3.4028234663852886e38f;
-    stage_v(nxt);
   }
+  ATTN_STAMP_DECL;
+  // One item; MORE (compile time): another item follows and its operands are fetched under this one's phases.  Where what streams in
+  // (each refill one instruction at a time between the instructions of the phase that covers it; the Q fragments, which occupy
+  // registers from the moment they are requested, only in the two P V passes, where 100 registers are free):
+  //     scores A + softmax A : V^T(item)            P V A : Q block B (item)
+  //     softmax B            : K(next)              P V B : Q block A (next)
+  auto do_item = [&](auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    // here: K(item), Q block A (item), madd(item) are in place for every wave; the V^T buffer is free
+    ATTN_STAMP(0);
+    const int nxt = MORE ? item + (int)gridDim.x : item;
+    const int psg = item / a.heads, head = item % a.heads;
+    const int npsg = nxt / a.heads, nhead = nxt % a.heads;
+    const int64_t ctok = (int64_t)psg * S + wave * 64 + l31;
+    int64_t mnext = 1;   // the next item's mask element, kept raw until the madd buffer is free
+    if (MORE) mnext = a.mask[(int64_t)npsg * S + tid];
+    bf16x8 p[NT][2];
+    float inv;
+    {
+      f32x16 sc[NT];
+      qk_block(qf[0], sc, [&](int i) { dma_v(item, i); });
+      inv = softmax_pack<NT, T>(sc, p, [&](int i) {
+        if ((i & 3) == 0) dma_v(item, 4 + (i >> 2));
+      });
+    }
+    ATTN_STAMP(1);
+    // B1: every wave's V^T(item) slices have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ATTN_STAMP(2);
+    pv_block(p, inv, ctok, head, [&](int i) {
+      if ((i & 3) == 1) load_q1(psg, head, qf, 4 + (i >> 2));
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(3);
+    {
+      f32x16 sc[NT];
+      qk_block(qf[1], sc, no_hook);
+      ATTN_STAMP(4);
+      // B2: every wave is done with K and madd -> the next item's mask row goes in, K(next) streams in under the softmax of block B
+      __builtin_amdgcn_s_barrier();
+      if (MORE) madd[tid] = mnext != 0 ? 0.f : -3.4028234663852886e38f;
+      inv = softmax_pack<NT, T>(sc, p, [&](int i) {
+        if (MORE && (i & 1) == 0) dma_k(npsg, nhead, i >> 1);
+      });
+    }
+    ATTN_STAMP(5);
+    pv_block(p, inv, ctok + 32, head, [&](int i) {
+      if (MORE && (i & 3) == 1) load_q1(npsg, nhead, qf, i >> 2);
+    });
+    ATTN_STAMP(6);
+    if (MORE) {
+      // B3: every wave is done with V^T; K(next) and Q block A (next) have landed (everything but this block's 8 ctx stores); madd(next) is written
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[0][ks]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    ATTN_STAMP(7);
+    ATTN_STAMP_NEXT;
+  };
+  for (; item + (int)gridDim.x < n_items; item += gridDim.x) do_item(std::true_type{});
+  do_item(std::false_type{});
 }
 
 // ---- last layer: attention for the [CLS] query only -----------------------------------------------------------------

@@ -237,7 +237,8 @@ class BertEngine:
         self._blob = self._lf32 = None
         self._wss = {}        # workspaces: None -> the full-length call, Sb -> the length bucket running on its own stream
         self._streams = {}
-        self.two_streams = os.environ.get("CAPAMD_BERT_TWO_STREAMS", "1") != "0"   # A/B switch of the full-length path
+        # the full-length path splits a large batch over this many HIP streams (own workspaces); 1 = strictly serial kernels
+        self.n_streams = max(1, int(os.environ.get("CAPAMD_BERT_STREAMS", "2")))
         self._model = None
         self._keep = None
 
@@ -334,19 +335,21 @@ class BertEngine:
         if not lengths:
             NP = B * P
             q = 256 // math.gcd(S, 256)                      # passages per whole 256-row GEMM tile
-            cut = (NP // 2 + q - 1) // q * q                 # first half of a two-stream split, in whole tiles
-            if NP < 2 * self.microbatch or not self.two_streams or cut >= NP:
+            ns = max(1, min(self.n_streams, NP // self.microbatch))
+            per = (NP // ns + q - 1) // q * q if ns > 1 else NP   # passages per stream, in whole tiles
+            cuts = [min(NP, k * per) for k in range(ns)] + [NP]
+            if ns < 2 or cuts[-2] >= NP:
                 plog = torch.empty(NP, dtype=torch.float32, device=ids.device) if return_passage_logits else None
                 self._encode(ids, mask, seg, B, P, S, aggregation, out, plog, check)
                 return (out, plog) if return_passage_logits else out
-            # full-length computation of a large batch: two halves on two streams (own workspaces) - the persistent GEMM
-            # kernels of one half start on the CUs the other half's last tiles and launch gaps leave idle
+            # full-length computation of a large batch: `ns` slices on as many streams (own workspaces) - the persistent GEMM kernels
+            # of one slice start on the CUs the others' last tiles, low-occupancy kernels and launch gaps leave idle
             fids, fmask, fseg = ids.view(NP, S), mask.view(NP, S), seg.view(NP, S)
             plog = torch.empty(NP, dtype=torch.float32, device=ids.device)
             self.model()
             main = torch.cuda.current_stream(ids.device)
             sides = []
-            for k, (a0, a1) in enumerate(((0, cut), (cut, NP))):
+            for k, (a0, a1) in enumerate(zip(cuts[:-1], cuts[1:])):
                 side = self._streams.get(("half", k))
                 if side is None:
                     side = self._streams[("half", k)] = torch.cuda.Stream(device=ids.device)

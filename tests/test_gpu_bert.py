@@ -670,7 +670,7 @@ def test_bert_base_benchmark_microbatch_matches_fixture_sized_runs(dt):
     with torch.no_grad():
         r.test({k: v[:B0] for k, v in d.items()})
         eng = r.model._engine
-        eng.two_streams = False
+        eng.n_streams = 1
         eng.microbatch = 256
         s256, pl256 = eng.forward(*eng_args, return_passage_logits=True, skip_padding=False)
         eng.microbatch = 12
@@ -678,12 +678,14 @@ def test_bert_base_benchmark_microbatch_matches_fixture_sized_runs(dt):
     assert torch.equal(pl256, pl12) and torch.equal(s256, s12)
     tol = BF16_E2E_TOL if dt == "bf16" else FP16_E2E_TOL
     assert rel_err(pl256[:B0 * P].cpu().numpy(), c["ref_passage_logits"][:, 1]).max() <= tol
-    # and 1,000 passages (four micro-batches, the last one ragged) through the two-stream path the engine uses by default
-    with torch.no_grad():
-        eng.microbatch, eng.two_streams = 256, True
-        big = {k: torch.cat([v] * 4)[:250] for k, v in d.items()}
-        sb, plb = eng.forward(big["pos_bert_input"], big["pos_mask"], big["pos_seg"], "max", return_passage_logits=True, skip_padding=False)
-    assert torch.equal(plb[:256], pl256) and torch.equal(plb[256:512], pl256) and torch.equal(plb[768:], pl256[:232])
+    # and 1,000 passages (four micro-batches, the last one ragged) through the multi-stream path the engine uses by default (2 slices) and
+    # the bench's (3): slices on their own streams and workspaces
+    big = {k: torch.cat([v] * 4)[:250] for k, v in d.items()}
+    for ns in (2, 3):
+        with torch.no_grad():
+            eng.microbatch, eng.n_streams = 256, ns
+            sb, plb = eng.forward(big["pos_bert_input"], big["pos_mask"], big["pos_seg"], "max", return_passage_logits=True, skip_padding=False)
+        assert torch.equal(plb[:256], pl256) and torch.equal(plb[256:512], pl256) and torch.equal(plb[768:], pl256[:232])
 
 
 @pytest.mark.parametrize("S,n_passages", [(32, 1), (32, 13), (96, 5), (160, 7), (224, 3), (64, 5), (128, 3)])
