@@ -73,7 +73,10 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank scores --queries queries per step; strong: the step's --queries queries are divided over the ranks")
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
-    ap.add_argument("--bert-dtype", default="fp16", choices=["bf16", "fp16"], help="16-bit operand type of the BERT encoder")
+    ap.add_argument("--bert-dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit operand type of the BERT encoder: bf16 is what BASELINE.json configs[3] names; fp16 is the engine's default outside the "
+                         "bench (three more mantissa bits: closer to the reference's fp32 scores, ~3 %% slower - more operand bits toggle per MFMA)")
+    ap.add_argument("--no-bert-other-dtype", action="store_true", help="BERT: skip the short run with the other 16-bit operand type")
     ap.add_argument("--bert-skip-padding", action="store_true",
                     help="BERT: encode passages in length buckets (multiples of 32 tokens) - identical scores, padded rows not computed. Off by "
                          "default here: the headline line times the reference's full 4 x 256-token computation")
@@ -716,6 +719,18 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
                      "note": "whole_step_* = executed FLOPs (last layer: [CLS] rows only after the QKV projection) / step time; *_nominal prices "
                              "every passage at SURVEY §8(d)'s 45.90 GFLOP"},
     }
+    if world == 1 and not args.no_bert_other_dtype and not args.bert_skip_padding:
+        # the same step with the other 16-bit operand type (short: 3 steps), so that one line carries both
+        import copy
+
+        other = copy.copy(args)
+        other.bert_dtype = "fp16" if args.bert_dtype == "bf16" else "bf16"
+        other.no_bert_other_dtype = True
+        del m, eng, rr
+        torch.cuda.empty_cache()
+        o = bench_bert(other, ctx, 3, 1, with_cpu=False)
+        rec["other_operand_type"] = {"dtype": other.bert_dtype, "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 3,
+                                     "whole_step_frac_nominal": o["roofline"]["whole_step_frac_nominal"], "ffn1_frac": o["roofline"]["frac"]}
     if args.bert_skip_padding:
         # the nominal FLOP count (every passage at S tokens) no longer describes the executed work: no whole-step MFMA figure
         rec["config"]["padding"] = "passages encoded in length buckets of 32 tokens (identical scores; rows beyond a passage's last token are not computed)"

@@ -142,11 +142,117 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
   }
 }
 
+// ln_kernel<0> for the chunk-major stream: a block takes one 32-token row group, whose chunk-major image is ONE contiguous run of
+// 32 H elements, builds it in LDS (a wave per token, eight tokens per wave) and copies it out linearly - a wave of ln_kernel writing
+// its token straight to the chunk-major layout touches 64 different 128-byte lines with 16 bytes each.  Same arithmetic as ln_kernel<0>.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_cm_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const float* __restrict__ word,
+                                                          const float* __restrict__ pos, const float* __restrict__ type, int vocab, int type_vocab, int S,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int H, T* xb, int* status,
+                                                          float eps, int pos_pad_id, int max_pos) {
+  using bf16x8 = typename Half<T>::x8;
+  extern __shared__ __attribute__((aligned(16))) char stage_raw[];
+  bf16x8* stage = reinterpret_cast<bf16x8*>(stage_raw);   // [32 tokens][H / 8 + 1] 16-byte pieces (token-major, rows padded by one piece: conflict-free
+                                                          // writes along a token, 2-way conflicts on the transposed read)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = H >> 3;
+  constexpr int TB = 4;   // tokens a wave works on at once: their gathers are all in flight before the first reduction (the kernel is latency bound)
+  for (int t0 = wave * 8; t0 < wave * 8 + 8; t0 += TB) {
+    const float4 *r0[TB], *r1[TB], *r2[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int64_t tok = (int64_t)blockIdx.x * 32 + t0 + u;
+      int64_t id = ids[tok], sg = seg[tok];
+      if (id < 0 || id >= vocab || sg < 0 || sg >= type_vocab) {
+        if (lane == 0) atomicOr(status, 1);
+        id = 0;
+        sg = 0;
+      }
+      int64_t pidx = tok % S;
+      if (pos_pad_id >= 0) {   // RoBERTa positions (see ln_kernel)
+        const int64_t i = tok % S;
+        const int64_t* row = ids + (tok - i);
+        int cnt = 0;
+        for (int64_t j = lane; j <= i; j += 64) cnt += row[j] != pos_pad_id;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        pidx = id != pos_pad_id ? pos_pad_id + cnt : pos_pad_id;
+      }
+      if (pidx >= max_pos) {
+        if (lane == 0) atomicOr(status, 1);
+        pidx = 0;
+      }
+      r0[u] = reinterpret_cast<const float4*>(word + id * H);
+      r1[u] = reinterpret_cast<const float4*>(pos + pidx * H);
+      r2[u] = reinterpret_cast<const float4*>(type + sg * H);
+    }
+    float v[TB][2][8];
+    float s[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      s[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 x = r0[u][2 * c + h], y = r1[u][2 * c + h], z = r2[u][2 * c + h];
+            v[u][i][4 * h + 0] = x.x + (y.x + z.x); v[u][i][4 * h + 1] = x.y + (y.y + z.y);
+            v[u][i][4 * h + 2] = x.z + (y.z + z.z); v[u][i][4 * h + 3] = x.w + (y.w + z.w);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) s[u] += (v[u][i][e] + v[u][i][e + 1]) + (v[u][i][e + 2] + v[u][i][e + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int tl = t0 + u;
+      const float mean = wave_sum64(s[u]) / (float)H;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            const float a = v[u][i][e] - mean, b = v[u][i][e + 1] - mean, c = v[u][i][e + 2] - mean, d = v[u][i][e + 3] - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+          }
+        }
+      const float rstd = rsqrtf(wave_sum64(q) / (float)H + eps);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+          bf16x8 ob;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[2 * c + h], b = reinterpret_cast<const float4*>(beta)[2 * c + h];
+            ob[4 * h + 0] = (T)((v[u][i][4 * h + 0] - mean) * rstd * g.x + b.x);
+            ob[4 * h + 1] = (T)((v[u][i][4 * h + 1] - mean) * rstd * g.y + b.y);
+            ob[4 * h + 2] = (T)((v[u][i][4 * h + 2] - mean) * rstd * g.z + b.z);
+            ob[4 * h + 3] = (T)((v[u][i][4 * h + 3] - mean) * rstd * g.w + b.w);
+          }
+          stage[tl * (nchunk + 1) + c] = ob;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  bf16x8* dst = reinterpret_cast<bf16x8*>(xb + (int64_t)blockIdx.x * 32 * H);
+  for (int i = threadIdx.x; i < nchunk * 32; i += 256) dst[i] = stage[(i & 31) * (nchunk + 1) + (i >> 5)];   // chunk-major: piece (chunk i >> 5, token i & 31)
+}
+
 // pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]).
-// grid (ceil(n_psg / kHeadPsg), H / 64): a block owns 64 pooler rows and kHeadPsg passages, so every pooler row is
-// fetched once per kHeadPsg passages; its partial sum over those 64 rows of cls_w[1][j] * tanh(pooler_j) goes to
-// part[psg][slice]; head_reduce_kernel adds the slices in fixed order (deterministic, no atomics).
-constexpr int kHeadPsg = 8;
+// grid (ceil(n_psg / kHeadPsg), H / kHeadRows): a block owns kHeadRows pooler rows (8 per wave) and kHeadPsg passages.  A lane holds
+// elements lane + 64 c of its wave's 8 weight rows (coalesced fp32 reads of the live parameters) and accumulates the 8 x 8 partial
+// dot products against the [CLS] rows staged in LDS; the 64 partials are then summed over the 64 lanes by ONE transposing butterfly
+// (step k keeps the half of the values the lane's bit 5-k selects and adds the partner's copy of them: 32+16+..+1 = 63 exchanges
+// instead of 64 x 6, and lane l ends up with the complete dot product of (row l >> 3, passage l & 7)), so tanh runs once per output
+// and not once per lane.  The partial sum over the block's rows of cls_w[1][j] * tanh(pooler_j) goes to part[psg][slice];
+// head_reduce_kernel adds the slices in fixed order (deterministic, no atomics; a passage's logit does not depend on its neighbours).
+constexpr int kHeadPsg = 8, kHeadRows = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int64_t n_psg, int S, int H,
                                                    const float* __restrict__ pw, const float* __restrict__ pb,
@@ -157,7 +263,7 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int
   __shared__ float wsum[4][kHeadPsg];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p0 = (int64_t)blockIdx.x * kHeadPsg;
-  const int nslice = gridDim.y, j0 = blockIdx.y * 64;
+  const int nslice = gridDim.y, j0 = blockIdx.y * kHeadRows + wave * 8;
 #pragma unroll
   for (int q = 0; q < kHeadPsg; ++q) {
     const int64_t psg = p0 + q < n_psg ? p0 + q : n_psg - 1;
@@ -171,30 +277,37 @@ __global__ __launch_bounds__(256) void head_kernel(const T* __restrict__ xf, int
     }
   }
   __syncthreads();
-  float acc[kHeadPsg];
+  float p[64];   // p[8 r + q]: this lane's share of <pooler row j0 + r, [CLS] of passage q>
 #pragma unroll
-  for (int q = 0; q < kHeadPsg; ++q) acc[q] = 0.f;
-  const int nc = (H + 63) >> 6;  // <= 16
-  for (int jj = wave; jj < 64; jj += 4) {
-    const int j = j0 + jj;
-    const float* w = pw + (int64_t)j * H;
-    float wr[16];
+  for (int i = 0; i < 64; ++i) p[i] = 0.f;
+  const int nc = H >> 6;  // <= 16
+  for (int c = 0; c < nc; ++c) {
+    float wr[8], xq[kHeadPsg];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) wr[c] = (c < nc && lane + 64 * c < H) ? w[lane + 64 * c] : 0.f;
-    const float bj = pb[j], cj = cw[H + j];
+    for (int r = 0; r < 8; ++r) wr[r] = pw[(int64_t)(j0 + r) * H + lane + 64 * c];
 #pragma unroll
-    for (int q = 0; q < kHeadPsg; ++q) {
-      float p = 0.f;
+    for (int q = 0; q < kHeadPsg; ++q) xq[q] = cls[q][lane + 64 * c];
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        if (c < nc) p = __builtin_fmaf(wr[c], cls[q][(lane + 64 * c) & 1023], p);
-      p = wave_sum64(p);
-      acc[q] = __builtin_fmaf(cj, tanhf(p + bj), acc[q]);
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int q = 0; q < kHeadPsg; ++q) p[8 * r + q] = __builtin_fmaf(wr[r], xq[q], p[8 * r + q]);
+  }
+  // transposing butterfly: 64 values x 64 lanes -> lane l holds the sum over all lanes of value l
+#pragma unroll
+  for (int half = 32; half >= 1; half >>= 1) {
+    const bool up = (lane & half) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float keep = up ? p[half + i] : p[i], send = up ? p[i] : p[half + i];
+      p[i] = keep + __shfl_xor(send, half, 64);
     }
   }
-  if (lane == 0)
-#pragma unroll
-    for (int q = 0; q < kHeadPsg; ++q) wsum[wave][q] = acc[q];
+  const int r = lane >> 3, q = lane & 7, j = j0 + r;
+  float contrib = cw[H + j] * tanhf(p[0] + pb[j]);
+  contrib += __shfl_xor(contrib, 8, 64);     // over the wave's 8 rows, fixed order
+  contrib += __shfl_xor(contrib, 16, 64);
+  contrib += __shfl_xor(contrib, 32, 64);
+  if (lane < kHeadPsg) wsum[wave][q] = contrib;
   __syncthreads();
   if (tid < kHeadPsg && p0 + tid < n_psg)
     part[(p0 + tid) * nslice + blockIdx.y] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
@@ -646,8 +759,14 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     // (a CEDR-KNRM call reads every layer's normalised output: it runs the path that materialises them)
     const bool fused = !tap && fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
                        pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
-    hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M_real + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
-                       m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M_real, H, (T*)w.xb, status, fused ? 1 : 0, eps, m->pos_pad_id, m->max_pos);
+    if (fused) {  // chunk-major stream: whole 32-token groups through LDS (S % 32 == 0, so M_real % 32 == 0)
+      const size_t lds = (size_t)32 * (H / 8 + 1) * 16;
+      if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_ln_cm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((embed_ln_cm_kernel<T>), dim3((unsigned)(M_real / 32)), dim3(256), lds, s, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+                         m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, H, (T*)w.xb, status, eps, m->pos_pad_id, m->max_pos);
+    } else
+      hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M_real + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+                         m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, M_real, H, (T*)w.xb, status, 0, eps, m->pos_pad_id, m->max_pos);
     if (M > M_real) {   // (S % 32 == 0: the pad rows are whole 32-row groups, contiguous in the row-major and the chunk-major layout alike)
       (void)hipMemsetAsync(w.xb + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
       (void)hipMemsetAsync(w.ctx + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
@@ -748,13 +867,13 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       if (e != hipSuccess) break;
       float* hpart = reinterpret_cast<float*>(cls_done ? w.ctx : w.pre);
       if (cls_done)   // compact, already normalised [CLS] rows: one row per passage
-        hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, cls_x, np, 1, H,
+        hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / kHeadRows)), dim3(256), 0, s, cls_x, np, 1, H,
                            m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr);
       else
-      hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
+      hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / kHeadRows)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
                          m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)w.mu_x, (const float*)w.rstd_x, last_g, last_b);
-      hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
+      hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / kHeadRows, m->cls_b, w.logits + p0);
       e = hipGetLastError();
       continue;
     }
@@ -803,10 +922,10 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     }
     // (the partial sums reuse the pre-LayerNorm buffer, which is dead after the last layer)
     float* hpart = reinterpret_cast<float*>(w.pre);
-    hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / 64)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
+    hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / kHeadRows)), dim3(256), 0, s, (const T*)w.xb, np, S, H,
                        m->pooler_w, m->pooler_b, m->cls_w, hpart, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr);
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / 64, m->cls_b, w.logits + p0);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, hpart, np, H / kHeadRows, m->cls_b, w.logits + p0);
     e = hipGetLastError();
   }
   return e;

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python $R/bench.py"
-( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
+( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
 # ---- bench lines -------------------------------------------------------------------------------------------------------
 timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json
@@ -13,13 +13,14 @@ timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1
 timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json
 timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json
 timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
-timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
-timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --bert-dtype bf16 2>/dev/null | tail -1 > gpurun_out/bench_bert_bf16.json
-CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json
+CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
 for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
 python - <<'PY'
 import json
-for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_bf16", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):
+for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):
     try:
         r = json.load(open(f"gpurun_out/bench_{f}.json")); ro = r["roofline"]
         print(f"{f:20s} {r['value']:14.1f} {r['unit']}  ms/step {r['ms_per_step']:.3f}  roofline frac {ro.get('frac')}  {ro.get('whole_step_frac_nominal', '')}")
@@ -35,7 +36,7 @@ timeout 300 $KS -d $P/knrm -o knrm -- $B --steps 20 --warmup 5 --no-cpu-baseline
 timeout 300 $KS -d $P/knrm_roofline_leg -o knrm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-roofline-leg --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
 timeout 300 $KS -d $P/drmm -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm > /dev/null 2>&1
 timeout 300 $KS -d $P/drmm_roofline_leg -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
-timeout 300 $KS -d $P/bert -o bert -- $B --steps 3 --warmup 1 --no-cpu-baseline --model bert > /dev/null 2>&1
+timeout 300 $KS -d $P/bert -o bert -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert > /dev/null 2>&1
 timeout 300 $KS -d $P/default -o default -- $B --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 for mdl in drmmtks pacrr convknrm; do timeout 300 $KS -d $P/$mdl -o $mdl -- $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
 # ---- PMC passes (own runs, counters only): HBM traffic of the KNRM / DRMM headline and roofline legs, MFMA busy of the BERT GEMMs ------
@@ -46,8 +47,8 @@ for leg in "knrm:" "knrm_roofline_leg:--uniform-ids --vocab 4000001 --batches 2"
   timeout 300 $PM WRITE_SIZE -d $P/${name}_write -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
   timeout 300 $PM TCC_HIT_sum TCC_MISS_sum -d $P/${name}_tcc -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
 done
-timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
-CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --model bert --docs 256 > /dev/null 2>&1
+timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
+CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 cd $R
 for f in $(find $P -name "*.csv" -size -4000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
 python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&1; cat gpurun_out/pmc_summary.txt
