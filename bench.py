@@ -18,10 +18,13 @@ What the line carries (N = 1, default model):
   value / ms_per_step  KNRM on Zipf(1.1) term ids (the headline leg), consecutive steps score DIFFERENT batches
   roofline             HBM fraction of the KNRM kernel, from a leg where HBM is the binding resource (uniform ids over a table
                        far larger than the 256 MB Infinity Cache): bytes the kernel REQUESTS / kernel time / 8 TB/s, <= 1 by
-                       construction.  The Zipf leg's cache-level rates are reported next to it (roofline.headline_leg)
+                       construction.  The Zipf leg's cache-level rates are reported next to it (roofline.headline_leg);
+                       roofline.traffic = HBM-side bytes per launch of that leg from the PMC counters, measured by two
+                       `rocprofv3 --pmc` child runs inside this invocation (FETCH_SIZE, WRITE_SIZE; --no-pmc-traffic skips them)
   cpu_baseline         C oracle (OpenMP) on the host cores + the reference's ATen op sequence swept over thread counts and
                        batch sizes (best reported) + the BASELINE configs[0] stand-in (16 training steps + 325 x 100 predict)
-  also                 DRMM (configs[2]) and BERT-base MaxP (configs[3]) legs with their own roofline / cpu_baseline
+  also                 DRMM (configs[2]) and BERT-base MaxP (configs[3]: bf16 operands, the step's passages in two slices on two
+                       streams; the fp16 figure under other_operand_type) legs with their own roofline / cpu_baseline
 """
 import argparse
 import ctypes
@@ -70,6 +73,8 @@ def parse():
     ap.add_argument("--roofline-vocab", type=int, default=4000001,
                     help="rows of the table of the HBM-bound roofline leg (uniform ids; 4,000,001 x 1280 B = 5.1 GB, 20x the Infinity Cache)")
     ap.add_argument("--no-roofline-leg", action="store_true")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (FETCH_SIZE / WRITE_SIZE of the HBM-bound leg)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank scores --queries queries per step; strong: the step's --queries queries are divided over the ranks")
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
@@ -360,6 +365,48 @@ class InteractionLeg:
         return run, (q, d, idf, emb_h, sd), err
 
 
+def pmc_traffic(args, model):
+    """roofline.traffic measured inside this invocation: HBM-side bytes per launch of the HBM-bound leg's kernel from the PMC counters,
+    collected as MI355X_MICROARCH.md (section HBM) prescribes - FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes (own child
+    runs of this script on the leg's configuration, counters only, no trace domains), bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: gfx950
+    tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B.  Returns (bytes per launch or None, how / why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if any(k.startswith(("ROCPROFILER", "ROCP_", "ROCTRACER")) for k in os.environ):
+        return None, "not measured: this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "not measured: rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--model", model, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-roofline-leg",
+             "--no-pmc-traffic", "--uniform-ids", "--vocab", str(args.roofline_vocab), "--batches", "2", "--dim", str(args.dim)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CAPAMD_FORCE_DIST")}
+    env["TMPDIR"] = "/tmp"
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            try:
+                subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "c", "--"] + child, cwd="/tmp", env=env, timeout=300,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"not measured: rocprofv3 --pmc {counter} failed ({type(e).__name__})"
+            vals = []
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "forward_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"not measured: the rocprofv3 --pmc {counter} pass returned no rows for the kernel"
+            kb[counter] = (sum(vals) / len(vals), len(vals))
+    return (kb["FETCH_SIZE"][0] * 2 + kb["WRITE_SIZE"][0]) * 1024, (
+        f"measured in this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of this leg ({kb['FETCH_SIZE'][1]} / {kb['WRITE_SIZE'][1]} launches "
+        f"sampled, {kb['FETCH_SIZE'][0]:.0f} / {kb['WRITE_SIZE'][0]:.0f} KB per launch); bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md section HBM "
+        "(gfx950 tallies 128-B requests of wide coalesced reads at 64 B); memory-side requests of the L2s, Infinity-Cache hits included: an upper bound on HBM bytes")
+
+
 def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     """One KNRM / DRMM measurement: headline leg + HBM roofline leg (+ CPU baseline on rank 0 at N = 1)."""
     Q, L, D = 4, 800, args.dim
@@ -394,7 +441,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         roof = {
             "bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": None,
-            "traffic_source": f"not measured in this run (PMC counters need rocprofv3): profiles/r02/{model}_hbm_traffic.json holds the builder-run "
+            "traffic_source": f"not measured in this run (--no-pmc-traffic): profiles/r02/{model}_hbm_traffic.json holds the builder-run "
                               "FETCH_SIZE x2 + WRITE_SIZE per launch of this leg and of the headline leg",
             "leg": f"uniform term ids over a {args.roofline_vocab}-row table ({args.roofline_vocab * big.row_stride * 4 / 1e9:.1f} GB packed, 20x the 256 MB "
                    "Infinity Cache), 64 x 1000 pairs per launch, 2 alternating batches: HBM is the binding resource",
@@ -408,6 +455,10 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         del big
         _tables.pop((ctx.dev.index, args.roofline_vocab, args.dim), None)
         torch.cuda.empty_cache()
+        if not args.no_pmc_traffic and ctx.rank == 0 and args.vocab <= 400001 and not args.uniform_ids:
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(args, model)
+            if roof["traffic"] is not None:
+                roof["traffic_over_requested"] = roof["traffic"] / (roof["pairs_per_launch"] * roof["requested_bytes_per_pair"])
     total_pairs = n_pairs * world
     rec = {
         "metric": "query-doc pairs scored/sec",

@@ -9,9 +9,9 @@ B="python $R/bench.py"
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
 # ---- bench lines -------------------------------------------------------------------------------------------------------
 timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-pmc-traffic --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json
 timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json
