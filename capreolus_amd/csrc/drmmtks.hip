@@ -51,33 +51,22 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
   float* lists = reinterpret_cast<float*>(tok + tok_cap);            // [16 groups][kQT][kMaxTopK]
   float* zlds = lists + kGroupsPerWG * kQT * kMaxTopK;               // [kMaxQ]
   float* glds = zlds + kMaxQ;                                        // [kMaxQ]
-  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);              // [4] (+4 spare)
-  int* n_one = wave_cnt + 8;                                         // [kQT] (+4 spare)
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);              // [12] (+4 spare)
+  int* n_one = wave_cnt + 16;                                        // [kQT] (+4 spare)
   float4* qlds = reinterpret_cast<float4*>(n_one + 8);               // [kQT][NV*16] float4
+  int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);      // [tok_cap] multiplicity of tok[k]
+  int* hkey = mult + tok_cap;                                        // [kHashSlots] phase 1 only
+  int* hfirst = hkey + kHashSlots;                                   // [kHashSlots] phase 1 only
 
   const int tid = threadIdx.x, lane16 = tid & 15, g = tid >> 4, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x, K = a.topk;
   const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
 
-  int n_real = 0;
-  for (int base = 0; base < a.L; base += kThreads) {
-    const int j = base + tid;
-    int64_t did = (j < a.L) ? ids.d(j) : 0;
-    if (did >= a.V) {
-      atomicOr(a.status, kErrDocIdRange);
-      did = 0;
-    }
-    const bool real = did > 0;
-    const unsigned long long m = __ballot(real);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = n_real;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (real) tok[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)did;
-    n_real += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
-  }
-  const int n_nonreal = a.L - n_real;
+  // the document's distinct real terms with their multiplicities (interaction.cuh: distinct_terms): a repeated term is gathered once
+  // and its similarity enters the top-k lists as many times as the document repeats it (at most k copies can matter)
+  const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
+  const int n_real = tl.n_unique;
+  const int n_nonreal = a.L - tl.n_real;
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     QueryPass<NV> qp;
@@ -117,12 +106,15 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
       rows_sim_my<NV, CAPAMD_TKS_U, true>(d, qp, qlds + qoff, lane16, x);
 #pragma unroll
       for (int u = 0; u < CAPAMD_TKS_U; ++u) {
-        float v = has[u] ? x[u] : -INFINITY;
+        const int copies = has[u] ? min(mult[t0 + u * kGroupsPerWG], K) : 0;   // uniform over the 16 lanes of the group
+        for (int c = 0; c < copies; ++c) {
+          float v = x[u];
 #pragma unroll
-        for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
-          const float hi = fmaxf(top[i], v);
-          v = fminf(top[i], v);
-          top[i] = hi;
+          for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
+            const float hi = fmaxf(top[i], v);
+            v = fminf(top[i], v);
+            top[i] = hi;
+          }
         }
       }
     }
@@ -191,7 +183,7 @@ extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids
   if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   TksArgs a{ids, idf, B, Q, L, packed, V, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out, status, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 16) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)
@@ -214,7 +206,7 @@ extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_id
   if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   TksArgs a{ids, nullptr, B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, features};
-  const size_t smem = (size_t)((L + 3) & ~3) * 4 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 16) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)

@@ -804,6 +804,29 @@ def test_drmmtks_scores(name):
         assert same.mean() > 0.98
 
 
+@pytest.mark.parametrize("L,topk", [(800, 10), (896, 16), (897, 3), (40, 16)])
+def test_drmmtks_repeated_document_terms(L, topk):
+    """The distinct-term pass in front of DRMM-TKS: a repeated term is gathered once and enters the top-k lists `count` times (capped at
+    k) - documents that are one term throughout, hash-bucket clusters, OOV / pad mixes, no repeats; both sides of the 896-position limit."""
+    from capreolus_amd.reranker import DRMMTKS
+
+    V, D = 20000, 300
+    rng = np.random.default_rng(L + topk)
+    emb = (rng.standard_normal((V, D)) * 0.4).astype(np.float32)
+    emb[0] = 0
+    q, d = _repeated_term_docs(L, V, L + topk)
+    idf = rng.random((6, 4)).astype(np.float32)
+    r = DRMMTKS({"topk": topk}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        got = r.test({"query": _t(q), "posdoc": _t(d), "query_idf": _t(idf)}).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    want, err = oracle.drmmtks(q, d, idf, oracle.pack(emb), D, topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"],
+                               sd["output_layer.weight"], sd["output_layer.bias"])
+    assert err == 0
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+
+
 def _pacrr_reranker(c):
     from capreolus_amd.reranker import PACRR
 
