@@ -142,7 +142,7 @@ def test_gemm_gelu_accuracy():
 
 
 @pytest.mark.parametrize("S,hidden,heads,npsg", [(32, 128, 2, 8), (64, 128, 2, 4), (96, 128, 2, 8), (128, 192, 3, 2), (160, 128, 2, 8), (192, 128, 2, 4),
-                                                 (224, 128, 2, 8), (256, 768, 12, 2), (256, 768, 12, 3), (384, 128, 2, 2), (512, 128, 2, 3)])
+                                                 (224, 128, 2, 8), (256, 768, 12, 2), (256, 768, 12, 3), (256, 128, 2, 5), (256, 1024, 16, 45), (384, 128, 2, 2), (512, 128, 2, 3)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qkv_attention_vs_torch(S, hidden, heads, npsg, dt):
     tdt, code, rtol = TDT[dt]
