@@ -323,6 +323,64 @@ def test_repeated_document_terms(L):
     assert rel_err(s, want).max() <= ORACLE_TOL
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometries_against_the_oracle(seed):
+    """Randomised sweep: document lengths 1..1100 (both sides of the distinct-term pass's 896-position limit), 1..12 query terms, embedding
+    widths that fill 1..5 packed-row vectors, vocabularies small enough that most terms repeat, pads / OOV terms sprinkled in, a few
+    all-pad documents - KNRM, DRMM (bin counts bit-exact) and DRMM-TKS against the C oracle."""
+    from capreolus_amd.reranker import DRMMTKS
+
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.choice([1, 7, 40, 255, 256, 300, 800, 895, 896, 897, 1000, 1100]))
+    Q = int(rng.integers(1, 13))
+    D = int(rng.choice([20, 50, 64, 100, 128, 200, 300, 319]))
+    V = int(rng.choice([8, 60, 500, 5000]))
+    B = 24
+    emb = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+    emb[0] = 0
+    d = rng.integers(1, V, (B, L))
+    d[rng.random((B, L)) < rng.choice([0.0, 0.1, 0.6])] = 0          # pads anywhere
+    d[rng.random((B, L)) < rng.choice([0.0, 0.05])] = -1             # OOV terms
+    lens = rng.integers(0, L + 1, B)
+    d[np.arange(L)[None, :] >= lens[:, None]] = 0                    # padded tails (some documents are all pads)
+    q = rng.integers(1, V, (B, Q))
+    q[np.arange(Q)[None, :] >= rng.integers(1, Q + 1, B)[:, None]] = 0
+    idf = rng.random((B, Q)).astype(np.float32)
+    packed = oracle.pack(emb)
+    batch = {"query": _t(q), "posdoc": _t(d), "query_idf": _t(idf)}
+
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        got = r.test(batch).cpu().numpy()
+    mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+    want, _ = oracle.knrm(q, d, packed, D, mu, sigma, m.combine[0].weight.detach().cpu().numpy(), m.combine[0].bias.detach().cpu().numpy())
+    assert rel_err(got, want).max() <= ORACLE_TOL, ("knrm", L, Q, D, V, rel_err(got, want).max())
+
+    r = DRMM({}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        c0 = torch.empty((B, Q, 30), dtype=torch.int32, device=DEV)
+        got = m(batch["posdoc"], batch["query"], batch["query_idf"], counts_out=c0).view(-1).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    want, wcounts, err = oracle.drmm(q, d, idf, packed, D, torch.linspace(-1, 1, 30)[1:].numpy(), "LCH", "IDF", sd["gates.weight"], emb, sd["ffw.0.weight"],
+                                     sd["ffw.0.bias"], sd["ffw.2.weight"], sd["ffw.2.bias"], sd["output_layer.weight"], sd["output_layer.bias"])
+    assert err == 0
+    assert np.array_equal(c0.cpu().numpy(), wcounts), ("drmm counts", L, Q, D, V)
+    assert rel_err(got, want).max() <= ORACLE_TOL, ("drmm", L, Q, D, V, rel_err(got, want).max())
+
+    topk = int(min(L, rng.integers(1, 17)))
+    r = DRMMTKS({"topk": topk}, SimpleNamespace(embeddings=emb))
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        got = r.test(batch).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    want, err = oracle.drmmtks(q, d, idf, packed, D, topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"], sd["output_layer.weight"],
+                               sd["output_layer.bias"])
+    assert err == 0
+    assert rel_err(got, want).max() <= ORACLE_TOL, ("drmmtks", L, Q, D, V, topk, rel_err(got, want).max())
+
+
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
 def test_ndcg20_parity_gpu_vs_reference(kind):
     from capreolus_amd import run_io
