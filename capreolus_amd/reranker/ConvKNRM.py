@@ -36,7 +36,7 @@ class ConvKNRM_class(nn.Module):
     def forward(self, sentence, query_sentence, query_idf=None):
         """[B, 1] scores.  query_idf is accepted and ignored, as in the reference (ConvKNRM.py:42)."""
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("the ConvKNRM training step is not part of the MI355X engine; score under model.eval()")
+            return self._forward_train(sentence, query_sentence)
         w = self.embeddings.weight
         tables = self._tables.get(w, [c[0].weight for c in self.convs], [c[0].bias for c in self.convs])
         mu, sigma = self.kernels.stacked()
@@ -47,6 +47,40 @@ class ConvKNRM_class(nn.Module):
         out = engine.convknrm_forward(query_sentence, sentence, tables, w.shape[0], self.p["maxngram"], self.p["filters"], self.p["crossmatch"],
                                       mu, sigma, lin1.weight.detach().contiguous(), lin1.bias.detach(), w2, b2, score_tanh=self.p["scoretanh"])
         return out.view(-1, 1)
+
+
+    def _forward_train(self, sentence, query_sentence):
+        """Training step (reference trainer/pytorch.py:96-99 -> ConvKNRM.score).  The trainable convolutions sit IN FRONT of the
+        similarity matrices, so the gradient has to flow through the cosine and the kernel pooling into them and the projection
+        tables of the scoring kernel (rebuilt from the weights, not differentiable) cannot be used: the step runs the reference's
+        arithmetic (ConvKNRM.py:42-77, common.py:195-221) as PyTorch-ROCm ATen ops under autograd, on the GPU, at training batch
+        sizes.  It is a functional drop-in for `score()` in train mode, not part of the measured HIP path; scoring under
+        `model.eval()` / `no_grad()` is the fused kernel."""
+        import torch.nn.functional as F
+
+        engine._need_gpu(sentence, query_sentence, self.embeddings.weight)
+        a_emb, b_emb = self.embeddings(query_sentence).permute(0, 2, 1), self.embeddings(sentence).permute(0, 2, 1)
+        a_reps, b_reps = [], []
+        for g, conv in enumerate(self.convs, start=1):
+            a_reps.append(conv[0](F.pad(a_emb, (0, g - 1))).permute(0, 2, 1))   # ConstantPad1d((0, g - 1), 0), ConvKNRM.py:27-28
+            b_reps.append(conv[0](F.pad(b_emb, (0, g - 1))).permute(0, 2, 1))
+        pairs = [(a, b) for a in a_reps for b in b_reps] if self.p["crossmatch"] else list(zip(a_reps, b_reps))
+        q_pad, d_pad = (query_sentence == 0)[:, :, None], (sentence == 0)[:, None, :]      # extractor.pad == 0
+        sims = []
+        for a, b in pairs:
+            den = (a.norm(p=2, dim=2)[:, :, None] + 1e-9) * (b.norm(p=2, dim=2)[:, None, :] + 1e-9)
+            sim = a.bmm(b.permute(0, 2, 1)) / den
+            sims.append(sim.masked_fill(q_pad, 0.0).masked_fill(d_pad, 0.0))
+        simmats = torch.stack(sims, dim=1)                                   # [B, VIEWS, Q, L]
+        mu = torch.stack([k.mu for k in self.kernels.kernels]).float()          # live parameters: gradkernels trains them (ConvKNRM.py:22)
+        sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
+        adj = simmats[:, None] - mu.view(1, -1, 1, 1, 1)
+        kernels = torch.exp(-0.5 * adj * adj / sigma.view(1, -1, 1, 1, 1) / sigma.view(1, -1, 1, 1, 1))   # [B, K, VIEWS, Q, L]
+        B, K, V, Q, L = kernels.shape
+        result = kernels.reshape(B, K * V, Q, L).sum(dim=3)
+        mask = (simmats.sum(dim=3) != 0.0)[:, None].expand(B, K, V, Q).reshape(B, K * V, Q)
+        result = torch.where(mask, (result + 1e-6).log(), mask.float()).sum(dim=2)
+        return self.combine(result)
 
 
 class ConvKNRM(Reranker):

@@ -1002,6 +1002,40 @@ def test_convknrm_scores(name):
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
 
 
+@pytest.mark.parametrize("name", CONVKNRM_CASES)
+def test_convknrm_training_step(name):
+    """ConvKNRM.score() in train mode (autograd through the convolutions, ConvKNRM.py:42-77): its scores reproduce the REFERENCE's on
+    the fixtures (1e-5) and the fused scoring kernel's; the loss reaches the convolutions, the kernels and the combine layer, and one
+    Adam step on a pairwise hinge loss lowers it."""
+    c = load_case("convknrm", name)
+    r = _convknrm_reranker(c)
+    m = r.model
+    b = _batch(c)
+    with torch.no_grad():
+        fused = r.test(b)
+    m.train()
+    pos, neg = r.score({**b, "negdoc": torch.roll(b["posdoc"], 1, 0)})
+    assert pos.requires_grad
+    assert rel_err(pos.detach().cpu().numpy(), c["ref_scores"]).max() <= 1e-5
+    assert rel_err(pos.detach().cpu().numpy(), fused.cpu().numpy()).max() <= 5e-5
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    loss0 = torch.clamp(1.0 - (pos - neg), min=0).mean()
+    loss0.backward()
+    for g in range(int(c["cfg.maxngram"])):
+        assert m.convs[g][0].weight.grad is not None and float(m.convs[g][0].weight.grad.abs().max()) > 0
+    assert m.combine[0].weight.grad is not None and m.embeddings.weight.grad is None
+    if bool(int(c["cfg.gradkernels"])):
+        assert m.kernels.kernels[3].mu.grad is not None
+    opt.step()
+    opt.zero_grad()
+    pos, neg = r.score({**b, "negdoc": torch.roll(b["posdoc"], 1, 0)})
+    assert float(torch.clamp(1.0 - (pos - neg), min=0).mean().detach()) < float(loss0.detach())
+    with pytest.raises(RuntimeError):   # no CPU path, in training either
+        m.cpu()
+        r.score({k: v.cpu() for k, v in {**b, "negdoc": b["posdoc"]}.items()})
+
+
 def test_convknrm_tables_match_direct_projection():
     rng = np.random.default_rng(3)
     V, D, F, G = 123, 77, 48, 3
