@@ -18,6 +18,10 @@
 
 using namespace capamd;
 
+#ifndef CAPAMD_DRMM_ABLATE
+#define CAPAMD_DRMM_ABLATE 0   // profiling builds only: 1 = no binning (the histogram stays empty), 2 = no feed-forward net / gate, 3 = both
+#endif
+
 namespace {
 
 constexpr int kMaxBins = 64;   // nbins + 1 <= 64
@@ -49,10 +53,15 @@ struct DrmmArgs {
   float* feat_out;  // optional [B, Q, nbins+1]: the histogram features after CH/NH/LCH (input of the feed-forward net)
 };
 
+// sum over the 64 lanes, every lane gets it: DPP all-reduce inside each 16-lane row (interaction.cuh), then the four row sums by
+// v_readlane - no LDS-pipe permutes (a __shfl_xor butterfly is six ds_bpermute round trips of ~100 cycles each, and the per-pair tail
+// of this kernel is a serial chain of such reductions)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = group_allreduce(v);
+  const int bits = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
@@ -88,10 +97,15 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
 
   if (tid < a.nbins) edges[tid] = a.edges[tid];
+  // the first feed-forward layer's weights go where the hash of the distinct-term pass was (dead after it), when they fit
+  float* w1lds = reinterpret_cast<float*>(hkey);
+  const bool w1_in_lds = a.out && a.nodes * NB <= 2 * kHashSlots;
 
   // ---- the document's distinct real terms with their multiplicities; OOV count (interaction.cuh) --------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
   const int n_real = tl.n_unique, n_oov = tl.n_oov;
+  if (w1_in_lds)
+    for (int i = tid; i < a.nodes * NB; i += kThreads) w1lds[i] = a.w1[i];   // (visible after the barrier that follows the histogram loop)
 
   for (int q0 = 0; q0 < a.Q; q0 += kQT) {
     // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
@@ -118,7 +132,12 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
       int qoff = 0;
       if (QLDS) asm volatile("" : "+v"(qoff));
       rows_sim_my<NV, U, QLDS>(d, qp, qlds + qoff, lane16, x);
-      if (lane16 < kQT) {
+      if (CAPAMD_DRMM_ABLATE & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) keep += x[u];
+        asm volatile("" ::"v"(keep));
+      } else if (lane16 < kQT) {
         int* h = hist + lane16 * kMaxBins;
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -150,20 +169,30 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
         hv = lane < NB ? logf(hv) : 0.f;
       }
       if (a.feat_out && lane < NB) a.feat_out[((int64_t)b * a.Q + q) * NB + lane] = hv;
+      if (CAPAMD_DRMM_ABLATE & 2) {   // profiling builds only: no feed-forward net / gate
+        if (lane == 0) { zlds[q] = hv; glds[q] = 0.f; }
+      } else
       if (a.out) {  // (feature call: the net / gate run under autograd on the host side -- training step, row N3)
-      // ffw (DRMM.py:25): lane n holds node n
-      float acc = lane < a.nodes ? a.b1[lane] : 0.f;
-      for (int i = 0; i < NB; ++i) {
-        const float hi = __shfl(hv, i, 64);
-        if (lane < a.nodes) acc = __builtin_fmaf(a.w1[lane * NB + i], hi, acc);
+      // ffw (DRMM.py:25): lane i holds histogram entry i; node n = one wave-wide dot product, kept by lane n.  (An earlier version
+      // broadcast the entries one by one - 30 dependent ds_bpermute round trips per query term - and the per-pair tail cost 23 %
+      // of the kernel.)
+      // (every small operand of the tail is requested up front, so that the serial chain below waits for memory once)
+      const float b1v = lane < a.nodes ? a.b1[lane] : 0.f, w2v = lane < a.nodes ? a.w2[lane] : 0.f, b2v = a.b2[0];
+      const int64_t qid = ids.q(q);
+      const float gate0 = a.gate_type == 0 ? a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q] : 0.f;
+      float acc = 0.f;
+      for (int n = 0; n < a.nodes; ++n) {
+        const float wv = lane < NB ? (w1_in_lds ? w1lds[n * NB + lane] : a.w1[n * NB + lane]) : 0.f;
+        const float sn = wave_sum(wv * hv);
+        if (lane == n) acc = sn;
       }
-      const float contrib = lane < a.nodes ? a.w2[lane] * tanhf(acc) : 0.f;
-      const float o = wave_sum(contrib) + a.b2[0];
+      acc += b1v;
+      const float contrib = lane < a.nodes ? w2v * tanhf(acc) : 0.f;
+      const float o = wave_sum(contrib) + b2v;
       // term gate logit (DRMM.py:83-95)
       float gl;
-      const int64_t qid = ids.q(q);
       if (a.gate_type == 0) {
-        gl = a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q];
+        gl = gate0;
       } else {
         const float* e = a.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * a.ld;
         float p = 0.f;

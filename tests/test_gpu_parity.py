@@ -193,10 +193,10 @@ def full():
 
 def test_full_size_knrm_properties(full):
     emb, batch = full
+    torch.manual_seed(0)      # (the combine layer's initial weights set the score scale the tolerances below are relative to)
     r = KNRM({}, SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32)))
     m = r.build_model().to(DEV).eval()
     m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
-    torch.manual_seed(0)
     with torch.no_grad():
         s = r.test(batch)
         assert s.shape == (2000,) and torch.isfinite(s).all()
@@ -230,6 +230,7 @@ def test_full_size_knrm_properties(full):
 
 def test_full_size_drmm_properties(full):
     emb, batch = full
+    torch.manual_seed(0)
     r = DRMM({}, SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32)))
     m = r.build_model().to(DEV).eval()
     m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
@@ -293,6 +294,7 @@ def _repeated_term_docs(L, V, seed):
 @pytest.mark.parametrize("L", [800, 896, 897, 1024, 5])
 def test_repeated_document_terms(L):
     V, D = 20000, 300
+    torch.manual_seed(L)
     rng = np.random.default_rng(L)
     emb = (rng.standard_normal((V, D)) * 0.4).astype(np.float32)
     emb[0] = 0
@@ -330,6 +332,7 @@ def test_random_geometries_against_the_oracle(seed):
     all-pad documents - KNRM, DRMM (bin counts bit-exact) and DRMM-TKS against the C oracle."""
     from capreolus_amd.reranker import DRMMTKS
 
+    torch.manual_seed(seed)          # (the models' initial weights)
     rng = np.random.default_rng(1000 + seed)
     L = int(rng.choice([1, 7, 40, 255, 256, 300, 800, 895, 896, 897, 1000, 1100]))
     Q = int(rng.integers(1, 13))
@@ -869,6 +872,7 @@ def test_drmmtks_repeated_document_terms(L, topk):
     from capreolus_amd.reranker import DRMMTKS
 
     V, D = 20000, 300
+    torch.manual_seed(L + topk)
     rng = np.random.default_rng(L + topk)
     emb = (rng.standard_normal((V, D)) * 0.4).astype(np.float32)
     emb[0] = 0
