@@ -53,16 +53,7 @@ struct DrmmArgs {
   float* feat_out;  // optional [B, Q, nbins+1]: the histogram features after CH/NH/LCH (input of the feed-forward net)
 };
 
-// sum over the 64 lanes, every lane gets it: DPP all-reduce inside each 16-lane row (interaction.cuh), then the four row sums by
-// v_readlane - no LDS-pipe permutes (a __shfl_xor butterfly is six ds_bpermute round trips of ~100 cycles each, and the per-pair tail
-// of this kernel is a serial chain of such reductions)
-__device__ __forceinline__ float wave_sum(float v) {
-  v = group_allreduce(v);
-  const int bits = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
-              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
-  return (r0 + r1) + (r2 + r3);
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce_sum(v); }   // (interaction.cuh: DPP + readlane, no LDS-pipe permutes)
 
 __device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
   int bi = (int)floorf((x + 1.f) * (0.5f * (float)nbins));

@@ -135,9 +135,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
         if (lane < kGroupsPerWG) cand = head < kMaxTopK ? lists[(lane * kQT + wave) * kMaxTopK + head] : -INFINITY;
         else if (lane == 16) cand = head < no ? 1.f : -INFINITY;
         else if (lane == 17) cand = head < nz ? 0.f : -INFINITY;
-        float best = cand;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+        const float best = wave_allreduce_max(cand);
         const unsigned long long who = __ballot(cand == best && best > -INFINITY);
         if (who == 0) break;  // fewer than k candidates (L < k): torch.topk would raise; the host checks L >= k
         const int winner = __ffsll((long long)who) - 1;

@@ -191,6 +191,27 @@ __device__ __forceinline__ float group_allreduce(float v) {
   return v;
 }
 
+// Reductions over the 64 lanes of a wave, every lane gets the result: DPP all-reduce inside each 16-lane row, then the four row values by
+// v_readlane.  No LDS-pipe permutes: a `__shfl_xor` butterfly is six ds_bpermute round trips (~100 cycles each), and the per-pair tails
+// of these kernels (feed-forward nets, top-k merges) are serial chains of such reductions during which the workgroup requests no rows.
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+  v = group_allreduce(v);
+  const int bits = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const int bits = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 template <int NV>
 struct RowRegs {
   float4 v[NV];

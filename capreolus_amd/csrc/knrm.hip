@@ -160,6 +160,13 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
         }
     }
 
+#ifndef CAPAMD_KNRM_ABLATE
+#define CAPAMD_KNRM_ABLATE 0   // profiling builds only: 1 = no reduction / log / combine tail
+#endif
+    if (CAPAMD_KNRM_ABLATE == 1) {
+      if (acc[0] + acc[1] + acc[2] + rowsum == 123.456f) a.out[b] = 1.f;
+      continue;
+    }
     // ---- phase 3: fixed-order cross-group reduction ---------------------------------------
     {
       float* pl = partial + (g * kGroup + lane16) * PS;

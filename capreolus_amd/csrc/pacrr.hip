@@ -141,9 +141,7 @@ __device__ __forceinline__ void pacrr_wave_topk(float (&top)[KM], int kmax, int 
 #pragma unroll
     for (int i = 0; i < KM; ++i)
       if (i == head) cand = top[i];
-    float bst = cand;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bst = fmaxf(bst, __shfl_xor(bst, o, 64));
+    const float bst = wave_allreduce_max(cand);
     const unsigned long long who = __ballot(cand == bst && bst > -INFINITY);
     if (who == 0) break;
     if (lane == __ffsll((long long)who) - 1) ++head;
