@@ -23,10 +23,21 @@ namespace {
 
 constexpr float kLnEps = 1e-12f;  // BertConfig.layer_norm_eps (capamd_bert_model.ln_eps = 0)
 
+// sum over the 64 lanes, every lane gets it: DPP all-reduce inside each 16-lane row, then the four row sums by v_readlane (a
+// __shfl_xor butterfly is six ds_bpermute round trips through the LDS pipe, ~100 cycles each, and a LayerNorm row needs two in series)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x141>(v);   // row_half_mirror
+  v += dpp_mov_f<0x140>(v);   // row_mirror
+  const int bits = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // ---- fp32 -> bf16 weight conversion (row-major copy into the blob) ----------------------------

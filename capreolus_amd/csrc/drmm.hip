@@ -58,8 +58,16 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce_sum(v
 __device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
   int bi = (int)floorf((x + 1.f) * (0.5f * (float)nbins));
   bi = bi < 0 ? 0 : (bi > nbins ? nbins : bi);
-  while (bi > 0 && x < edges[bi - 1]) --bi;
-  while (bi < nbins && !(x < edges[bi])) ++bi;
+  // the arithmetic guess is almost always right: both neighbouring edges are read at once (one LDS latency), the walks below run only
+  // when the guess is off; the result is the same exact `x < edge` classification either way
+  const float e_lo = edges[bi > 0 ? bi - 1 : 0], e_hi = edges[bi < nbins ? bi : nbins - 1];
+  if (bi > 0 && x < e_lo) {
+    --bi;
+    while (bi > 0 && x < edges[bi - 1]) --bi;
+  } else if (bi < nbins && !(x < e_hi)) {
+    ++bi;
+    while (bi < nbins && !(x < edges[bi])) ++bi;
+  }
   return bi;  // == nbins: at or above the last edge (1.0): no regular bin
 }
 
