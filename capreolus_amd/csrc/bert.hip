@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
 }
 
 // ln_kernel<0> for the chunk-major stream: a block takes one 32-token row group, whose chunk-major image is ONE contiguous run of
-// 32 H elements, builds it in LDS (a wave per token, eight tokens per wave) and copies it out linearly - a wave of ln_kernel writing
+// 32 H elements, builds it in LDS (eight waves, four tokens each, all four in flight at once) and copies it out linearly - a wave of ln_kernel writing
 // its token straight to the chunk-major layout touches 64 different 128-byte lines with 16 bytes each.  Same arithmetic as ln_kernel<0>.
 template <typename T>
-__global__ __launch_bounds__(256) void embed_ln_cm_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const float* __restrict__ word,
+__global__ __launch_bounds__(512) void embed_ln_cm_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg, const float* __restrict__ word,
                                                           const float* __restrict__ pos, const float* __restrict__ type, int vocab, int type_vocab, int S,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int H, T* xb, int* status,
                                                           float eps, int pos_pad_id, int max_pos) {
@@ -165,10 +165,11 @@ __global__ __launch_bounds__(256) void embed_ln_cm_kernel(const int64_t* __restr
   extern __shared__ __attribute__((aligned(16))) char stage_raw[];
   bf16x8* stage = reinterpret_cast<bf16x8*>(stage_raw);   // [32 tokens][H / 8 + 1] 16-byte pieces (token-major, rows padded by one piece: conflict-free
                                                           // writes along a token, 2-way conflicts on the transposed read)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunk = H >> 3;
+  const int pos0 = (int)(((int64_t)blockIdx.x * 32) % S);   // the block's 32 tokens lie inside one passage (S % 32 == 0): one division per block
   constexpr int TB = 4;   // tokens a wave works on at once: their gathers are all in flight before the first reduction (the kernel is latency bound)
-  for (int t0 = wave * 8; t0 < wave * 8 + 8; t0 += TB) {
+  for (int t0 = wave * 4; t0 < wave * 4 + 4; t0 += TB) {
     const float4 *r0[TB], *r1[TB], *r2[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
@@ -179,9 +180,9 @@ __global__ __launch_bounds__(256) void embed_ln_cm_kernel(const int64_t* __restr
         id = 0;
         sg = 0;
       }
-      int64_t pidx = tok % S;
+      int64_t pidx = pos0 + t0 + u;
       if (pos_pad_id >= 0) {   // RoBERTa positions (see ln_kernel)
-        const int64_t i = tok % S;
+        const int64_t i = pos0 + t0 + u;
         const int64_t* row = ids + (tok - i);
         int cnt = 0;
         for (int64_t j = lane; j <= i; j += 64) cnt += row[j] != pos_pad_id;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void embed_ln_cm_kernel(const int64_t* __restr
   }
   __syncthreads();
   bf16x8* dst = reinterpret_cast<bf16x8*>(xb + (int64_t)blockIdx.x * 32 * H);
-  for (int i = threadIdx.x; i < nchunk * 32; i += 256) dst[i] = stage[(i & 31) * (nchunk + 1) + (i >> 5)];   // chunk-major: piece (chunk i >> 5, token i & 31)
+  for (int i = threadIdx.x; i < nchunk * 32; i += 512) dst[i] = stage[(i & 31) * (nchunk + 1) + (i >> 5)];   // chunk-major: piece (chunk i >> 5, token i & 31)
 }
 
 // pooler tanh(Wp h_CLS + bp) and classifier logit 1 (ptBERTMaxP.py:82 takes [:, 1]).
@@ -773,7 +774,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     if (fused) {  // chunk-major stream: whole 32-token groups through LDS (S % 32 == 0, so M_real % 32 == 0)
       const size_t lds = (size_t)32 * (H / 8 + 1) * 16;
       if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_ln_cm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((embed_ln_cm_kernel<T>), dim3((unsigned)(M_real / 32)), dim3(256), lds, s, ids_mb, seg_mb, m->word_emb, m->pos_emb,
+      hipLaunchKernelGGL((embed_ln_cm_kernel<T>), dim3((unsigned)(M_real / 32)), dim3(512), lds, s, ids_mb, seg_mb, m->word_emb, m->pos_emb,
                          m->type_emb, m->vocab, m->type_vocab, S, m->emb_ln_g, m->emb_ln_b, H, (T*)w.xb, status, eps, m->pos_pad_id, m->max_pos);
     } else
       hipLaunchKernelGGL((ln_kernel<0, T>), dim3((unsigned)((M_real + 3) / 4)), dim3(256), 0, s, (const T*)nullptr, ids_mb, seg_mb, m->word_emb, m->pos_emb,
