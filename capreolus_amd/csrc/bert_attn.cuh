@@ -120,6 +120,16 @@ __device__ inline f32x16 scores_init_permuted(const float* madd_t) {   // madd_t
   return v;
 }
 
+// The value the partner lane (lane ^ 32) holds: v_permlane32_swap on two copies (x.hi <-> y.lo leaves x = [lo | lo], y = [hi | hi]) and a
+// select - a VALU exchange instead of the ds_bpermute round trip through the LDS pipe `__shfl_xor(v, 32)` compiles to; the softmax has two
+// of them in its serial chain (row maximum, row sum).  (Inline asm with the wait states a VALU-written operand needs before a
+// lane-crossing instruction, as in bert_gemm.cuh: swap32.)
+__device__ __forceinline__ float partner32(float v, int half) {
+  unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return __builtin_bit_cast(float, half ? x : y);   // lower half wants the upper value (now everywhere in y), upper half the lower (in x)
+}
+
 // exact softmax of one query row (a lane pair) over NT x 16 scores, probabilities rounded to the 16-bit type as they are produced
 // (half a tile at a time: 8 fp32 scores leave as 4 packed registers); returns 1 / sum
 struct NoHook {
@@ -133,7 +143,8 @@ __device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename H
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const int half = (int)(threadIdx.x & 32) >> 5;
+  mx = fmaxf(mx, partner32(mx, half));
   constexpr float kLog2e = 1.4426950408889634f;
   const float nb = -mx * kLog2e;
   float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -153,7 +164,7 @@ __device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename H
       __builtin_amdgcn_sched_barrier(0);
     }
   float sum = (part[0] + part[1]) + (part[2] + part[3]);
-  sum += __shfl_xor(sum, 32, 64);
+  sum += partner32(sum, half);
   return 1.f / sum;
 }
 
