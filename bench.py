@@ -568,7 +568,7 @@ def bench_sibling(args, ctx):
     status = engine.deferred_status(dev)              # the timed calls are queued back to back like the KNRM / DRMM launches
     status.__enter__()                                # (check=False there); the accumulated status bits are raised at the end
     elapsed, kern_s = timed_loop(ctx, step, args.warmup, args.steps)   # one scoring call = the model's kernel + a few tiny torch ops of the mirror
-    assert torch.isfinite(out[0]).all()
+    assert os.environ.get("CAPAMD_BENCH_NOCHECK") == "1" or torch.isfinite(out[0]).all()   # (the knob: profiling builds that drop a phase of the kernel)
     status.__exit__(None, None, None)
     nonpad = float((d_all > 0).sum().item()) / n_pairs
     if args.model == "convknrm":
