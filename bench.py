@@ -579,7 +579,7 @@ def bench_sibling(args, ctx):
     else:
         row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
         abytes = algorithmic_bytes_per_pair("knrm", Q, L, D) + 4 * Q
-        kname = {"drmmtks": "drmmtks_forward_kernel<5>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[args.model]
+        kname = {"drmmtks": "drmmtks_forward_kernel<5, 12>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[args.model]
     requested = n_pairs * (L * 8 + Q * 8 + (nonpad + Q) * row + 4) / kern_s / 1e9
     if rank != 0:
         return None

@@ -43,7 +43,8 @@ struct TksArgs {
 #define CAPAMD_TKS_WAVES 6   // measured per 64,000 pairs: 5 -> 2.20 ms, 6 -> 2.12 ms; two rows in flight per group (CAPAMD_TKS_U 2) spill and lose 2-5x
 #endif
 
-template <int NV>
+// KT = length of the per-lane sorted lists (>= topk, a multiple of 4): the compare-exchange chain of an insertion is KT steps long
+template <int NV, int KT>
 __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_kernel(TksArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* tok = reinterpret_cast<int*>(smem_raw);
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
         }
     }
     // sorted (descending) top-k of this lane's query term over the terms its group visits
-    float top[kMaxTopK];
+    float top[KT];
 #pragma unroll
-    for (int i = 0; i < kMaxTopK; ++i) top[i] = -INFINITY;
+    for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
     for (int t0 = g; t0 < n_real; t0 += CAPAMD_TKS_U * kGroupsPerWG) {   // CAPAMD_TKS_U rows in flight per 16-lane group
       RowRegs<NV> d[CAPAMD_TKS_U];
       bool has[CAPAMD_TKS_U];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
         for (int c = 0; c < copies; ++c) {
           float v = x[u];
 #pragma unroll
-          for (int i = 0; i < kMaxTopK; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
+          for (int i = 0; i < KT; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
             const float hi = fmaxf(top[i], v);
             v = fminf(top[i], v);
             top[i] = hi;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
     }
     if (lane16 < kQT) {
 #pragma unroll
-      for (int i = 0; i < kMaxTopK; ++i) lists[(g * kQT + lane16) * kMaxTopK + i] = top[i];
+      for (int i = 0; i < KT; ++i) lists[(g * kQT + lane16) * kMaxTopK + i] = top[i];
     }
     __syncthreads();
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
       float acc = a.feat ? 0.f : a.ffw_b[0];
       for (int r = 0; r < K; ++r) {
         float cand = -INFINITY;
-        if (lane < kGroupsPerWG) cand = head < kMaxTopK ? lists[(lane * kQT + wave) * kMaxTopK + head] : -INFINITY;
+        if (lane < kGroupsPerWG) cand = head < KT ? lists[(lane * kQT + wave) * kMaxTopK + head] : -INFINITY;
         else if (lane == 16) cand = head < no ? 1.f : -INFINITY;
         else if (lane == 17) cand = head < nz ? 0.f : -INFINITY;
         const float best = wave_allreduce_max(cand);
@@ -184,7 +185,13 @@ extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_)                                                                                                                   \
+  do {                                                                                                                                \
+    if (topk <= 4) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 4>), dim3(B), dim3(kThreads), smem, s, a);                          \
+    else if (topk <= 8) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 8>), dim3(B), dim3(kThreads), smem, s, a);                     \
+    else if (topk <= 12) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 12>), dim3(B), dim3(kThreads), smem, s, a);                   \
+    else hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 16>), dim3(B), dim3(kThreads), smem, s, a);                                   \
+  } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -207,7 +214,13 @@ extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_id
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_)                                                                                                                   \
+  do {                                                                                                                                \
+    if (topk <= 4) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 4>), dim3(B), dim3(kThreads), smem, s, a);                          \
+    else if (topk <= 8) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 8>), dim3(B), dim3(kThreads), smem, s, a);                     \
+    else if (topk <= 12) hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 12>), dim3(B), dim3(kThreads), smem, s, a);                   \
+    else hipLaunchKernelGGL((drmmtks_forward_kernel<NV_, 16>), dim3(B), dim3(kThreads), smem, s, a);                                   \
+  } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
