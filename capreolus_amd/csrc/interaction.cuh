@@ -177,6 +177,118 @@ __device__ __forceinline__ TermList distinct_terms(const PairIds& ids, int L, in
   return r;
 }
 
+// distinct_terms for kernels that need the POSITIONS of a term rather than its count (PACRR writes a similarity to every position of the
+// pair's matrix): tok[k] = the k-th distinct real term, plist[start[k] .. start[k + 1]) = its positions (any order).
+// tok: [L rounded up to 4] ints; start: [L + 1] and plist: [L] uint16 (L <= 65535); wave_cnt: [12] ints; scratch: `scratch_ints` ints that
+// may alias anything dead during the call (hash keys | first positions | per-term counters).  Without room for the hash, or beyond
+// kDedupMaxL positions, every real position is listed as its own term.  256 threads; ends on a barrier.
+__device__ __forceinline__ TermList distinct_terms_positions(const PairIds& ids, int L, int64_t V, int* status, int* tok, unsigned short* start,
+                                                             unsigned short* plist, int* scratch, int scratch_ints, int* wave_cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TermList r{0, 0, 0};
+  const int tok_cap = (L + 3) & ~3;
+  if (L > kDedupMaxL || scratch_ints < 2 * kHashSlots + tok_cap) {
+    for (int base = 0; base < L; base += kThreads) {
+      const int j = base + tid;
+      int64_t did = (j < L) ? ids.d(j) : 0;
+      if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
+      const bool real = did > 0;
+      const unsigned long long m = __ballot(real), mo = __ballot(did < 0);
+      if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); }
+      __syncthreads();
+      int off = r.n_unique;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      if (real) {
+        const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+        tok[k] = (int)did;
+        start[k] = (unsigned short)k;
+        plist[k] = (unsigned short)j;
+      }
+      r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+      __syncthreads();
+    }
+    if (tid == 0) start[r.n_unique] = (unsigned short)r.n_unique;
+    r.n_real = r.n_unique;
+    __syncthreads();
+    return r;
+  }
+  int *key = scratch, *first = scratch + kHashSlots, *cnt = scratch + 2 * kHashSlots;
+  for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
+  for (int i = tid; i < L; i += kThreads) cnt[i] = 0;
+  __syncthreads();
+  int id_r[kDedupPos], slot_r[kDedupPos];
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // A: hash insert, first position per term
+    const int j = it * kThreads + tid;
+    int64_t did = (j < L) ? ids.d(j) : 0;
+    if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
+    id_r[it] = did < 0 ? -1 : (int)did;
+    slot_r[it] = -1;
+    if (did > 0) {
+      unsigned h = ((unsigned)did * 2654435761u) >> 22;
+      for (;;) {
+        const int old = atomicCAS(&key[h], 0, (int)did);
+        if (old == 0 || old == (int)did) break;
+        h = (h + 1) & (kHashSlots - 1);
+      }
+      slot_r[it] = (int)h;
+      atomicMin(&first[h], j);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // B: owners compacted in document order
+    const int j = it * kThreads + tid;
+    const bool real = slot_r[it] >= 0;
+    const bool owner = real && first[slot_r[it]] == j;
+    const unsigned long long m = __ballot(owner), mr = __ballot(real), mo = __ballot(id_r[it] < 0);
+    if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); wave_cnt[8 + wave] = __popcll(mr); }
+    __syncthreads();
+    int off = r.n_unique;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (owner) {
+      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+      tok[k] = id_r[it];
+      first[slot_r[it]] = -1 - k;
+    }
+    r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
+    r.n_real += wave_cnt[8] + wave_cnt[9] + wave_cnt[10] + wave_cnt[11];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it)              // C: occurrences per term
+    if (slot_r[it] >= 0) atomicAdd(&cnt[-1 - first[slot_r[it]]], 1);
+  __syncthreads();
+  if (wave == 0) {                                    // exclusive prefix sum of the counts: one wave, a run of terms per lane
+    const int n = r.n_unique, chunk = (n + 63) >> 6, k0 = lane * chunk, k1 = min(n, k0 + chunk);
+    int sum = 0;
+    for (int k = k0; k < k1; ++k) sum += cnt[k];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    int run = incl - sum;
+    for (int k = k0; k < k1; ++k) {
+      start[k] = (unsigned short)run;
+      run += cnt[k];
+    }
+    if (lane == 63) start[n] = (unsigned short)incl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it)              // D: positions grouped by term
+    if (slot_r[it] >= 0) {
+      const int k = -1 - first[slot_r[it]];
+      plist[start[k] + atomicSub(&cnt[k], 1) - 1] = (unsigned short)(it * kThreads + tid);
+    }
+  __syncthreads();
+  return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

@@ -132,6 +132,54 @@ __device__ __forceinline__ void pacrr_similarities(const PacrrArgs& a, const Pai
   }
 }
 
+// The same over the pair's DISTINCT terms (interaction.cuh: distinct_terms_positions): a term the document repeats is gathered once and its
+// similarities are written to every position it occupies.
+template <int NV, int U, typename Put>
+__device__ __forceinline__ void pacrr_similarities_distinct(const PacrrArgs& a, const PairIds& ids, const int* tok, const unsigned short* start,
+                                                            const unsigned short* plist, int n_unique, float4* qlds, int tid, Put put) {
+  const int lane16 = tid & 15, g = tid >> 4;
+  for (int q0 = 0; q0 < a.Q; q0 += kQT) {
+    QueryPass<NV> qp;
+    load_query_pass_lds<NV>(a.packed, ids, a.Q, q0, a.V, tid, kThreads, lane16, qlds, qp, a.status);
+    __syncthreads();
+    {  // OOV exact matches (equal negative ids): 1.0 (common.py:155-158)
+      bool any_oov_q = false;
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) any_oov_q |= qp.id[t] < 0;
+      if (any_oov_q)
+        for (int j = tid; j < a.L; j += kThreads) {
+          const int64_t did = ids.d(j);
+          if (did < 0) {
+#pragma unroll
+            for (int t = 0; t < kQT; ++t)
+              if (qp.id[t] == (int)did && did > -2147483648LL) put(q0 + t, j, 1.f);
+          }
+        }
+    }
+    for (int t0 = g; t0 < n_unique; t0 += U * kGroupsPerWG) {   // U rows in flight per 16-lane group
+      RowRegs<NV> d[U];
+      bool has[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tu = t0 + u * kGroupsPerWG;
+        has[u] = tu < n_unique;
+        load_row<NV>(a.packed, has[u] ? tok[tu] : 0, lane16, d[u]);
+      }
+      float x[U];
+      int qoff = 0;
+      asm volatile("" : "+v"(qoff));
+      rows_sim_my<NV, U, true>(d, qp, qlds + qoff, lane16, x);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (has[u] && lane16 < kQT && q0 + lane16 < a.Q) {   // lane l owns query term l & 3
+          const int tu = t0 + u * kGroupsPerWG;
+          for (int i = start[tu], e = start[tu + 1]; i < e; ++i) put(q0 + lane16, (int)plist[i], x[u]);
+        }
+    }
+    __syncthreads();
+  }
+}
+
 // Per-lane sorted candidate lists -> the kmax largest of the wave, written to dst[0 .. kmax).
 template <int KM>
 __device__ __forceinline__ void pacrr_wave_topk(float (&top)[KM], int kmax, int lane, float* dst) {
@@ -349,7 +397,7 @@ __device__ __forceinline__ float pacrr_relu_max(const f32x16& c) {
 
 // bytes of the LDS region shared by the front end's term list and the back end's weights / head vectors
 __host__ __device__ inline int pacrr_mfma_region0(int L, int n_weights) {
-  const int front = ((L + 7) & ~7) * 6, back = (n_weights + kPacrrMaxFeat + 2 * kPacrrMaxC) * 4;
+  const int front = ((L + 7) & ~7) * 8 + 16, back = (n_weights + kPacrrMaxFeat + 2 * kPacrrMaxC) * 4;   // tok int32 | start uint16 (+1) | plist uint16
   return ((front > back ? front : back) + 15) & ~15;
 }
 
@@ -362,7 +410,8 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
   // region 0 is used twice: the compacted terms (front end), then the convolution weights and the head's vectors (back end)
   const int r0 = pacrr_mfma_region0(a.L, a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters);
   int* tok = reinterpret_cast<int*>(smem_raw);
-  unsigned short* pos = reinterpret_cast<unsigned short*>(tok + tok_cap);
+  unsigned short* start = reinterpret_cast<unsigned short*>(tok + tok_cap);   // [tok_cap + 8]
+  unsigned short* plist = start + tok_cap + 8;                                // [tok_cap]
   float* wts = reinterpret_cast<float*>(smem_raw);               // conv_w | conv_b   (after the front end)
   float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;
   float* h1 = feat + kPacrrMaxFeat;
@@ -377,6 +426,9 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
   const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
   const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
 
+  // distinct terms and their positions first: the hash of that pass borrows the (not yet initialised) matrix planes
+  const TermList tl = distinct_terms_positions(ids, a.L, a.V, a.status, tok, start, plist, reinterpret_cast<int*>(s_hi), LP * 8, wave_cnt);
+  int n_real = tl.n_unique;
   {
     u32x4 z = {0u, 0u, 0u, 0u}, one = {0u, 0u, 0u, 0x3C000000u};   // row 7 = 1.0
     for (int i = tid; i < LP; i += kThreads) {
@@ -384,9 +436,8 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
       reinterpret_cast<u32x4*>(s_lo)[i] = z;
     }
   }
-  int n_real = pacrr_compact(a, ids, tok, pos, wave_cnt, tid);
   if (CAPAMD_PACRR_ABLATE == 2) n_real = 0;
-  pacrr_similarities<NV, CAPAMD_PACRR_U>(a, ids, tok, pos, n_real, qlds, tid, [&](int row, int j, float x) {
+  pacrr_similarities_distinct<NV, CAPAMD_PACRR_U>(a, ids, tok, start, plist, n_real, qlds, tid, [&](int row, int j, float x) {
     const float h = f16_round(x);
     s_hi[j * 8 + row] = (_Float16)h;
     s_lo[j * 8 + row] = (_Float16)(x - h);

@@ -930,6 +930,10 @@ def test_pacrr_scores(name, valu, monkeypatch):
     (4, 65, 3, 3, 32, 2, False, "relu", 32),     # one position into the second step, trigrams only
     (6, 300, 1, 3, 32, 2, True, "relu", 32),     # one query row too many for it: general kernel
     (4, 300, 1, 3, 33, 2, True, "relu", 32),     # one filter too many for it: general kernel
+    (5, 896, 1, 3, 32, 4, True, "relu", 32),     # the longest document the distinct-term pass hashes (150-word vocabulary: every term repeats)
+    (4, 897, 1, 3, 32, 2, False, "relu", 32),    # one position more: every position listed on its own
+    (4, 320, 1, 3, 32, 2, True, "relu", 32),     # the shortest document whose matrix planes have room for the hash
+    (4, 288, 1, 3, 32, 2, True, "relu", 32),     # ... and one step below
 ])
 def test_pacrr_geometries_match_oracle(Q, L, lo, hi, nf, kmax, idf, nonlin, comb):
     rng = np.random.default_rng(Q * 1000 + L)
