@@ -80,8 +80,8 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   float* edges = reinterpret_cast<float*>(hist + kQT * kMaxBins);  // [kMaxBins]
   float* zlds = edges + kMaxBins;                              // [kMaxQ]
   float* glds = zlds + kMaxQ;                                  // [kMaxQ]
-  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [12] (+4 spare): distinct_terms' per-wave counts
-  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 16);     // QLDS: [kQT][NV*16] float4
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);        // [48]: distinct_terms' per-wave counts
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 48);     // QLDS: [kQT][NV*16] float4
   int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);  // [tok_cap] multiplicity of tok[k]
   int* hkey = mult + tok_cap;                                    // [kHashSlots] phase 1 only
   int* hfirst = hkey + kHashSlots;                               // [kHashSlots] phase 1 only
@@ -237,7 +237,7 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   DrmmArgs a{ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 16 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
@@ -275,7 +275,7 @@ extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
              nullptr, nullptr, nullptr, nullptr, status, feat_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 16 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)

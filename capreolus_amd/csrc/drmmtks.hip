@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
   float* lists = reinterpret_cast<float*>(tok + tok_cap);            // [16 groups][kQT][kMaxTopK]
   float* zlds = lists + kGroupsPerWG * kQT * kMaxTopK;               // [kMaxQ]
   float* glds = zlds + kMaxQ;                                        // [kMaxQ]
-  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);              // [12] (+4 spare)
-  int* n_one = wave_cnt + 16;                                        // [kQT] (+4 spare)
+  int* wave_cnt = reinterpret_cast<int*>(glds + kMaxQ);              // [48]: distinct_terms' per-wave counts
+  int* n_one = wave_cnt + 48;                                        // [kQT] (+4 spare)
   float4* qlds = reinterpret_cast<float4*>(n_one + 8);               // [kQT][NV*16] float4
   int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);      // [tok_cap] multiplicity of tok[k]
   int* hkey = mult + tok_cap;                                        // [kHashSlots] phase 1 only
@@ -182,7 +182,7 @@ extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids
   if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   TksArgs a{ids, idf, B, Q, L, packed, V, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out, status, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 56 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_)                                                                                                                   \
@@ -211,7 +211,7 @@ extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_id
   if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   TksArgs a{ids, nullptr, B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, features};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 24 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 56 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_)                                                                                                                   \

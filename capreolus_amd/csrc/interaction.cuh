@@ -103,7 +103,78 @@ struct TermList {
   int n_oov;      // negative ids
 };
 
-// tok, mult: [L rounded up to 4] ints; key, first: [kHashSlots] ints; wave_cnt: [12] ints.  All LDS.  256 threads.
+// The hash part of the distinct-term pass: tok[k] = the k-th distinct real term in order of first occurrence, first[slot] = -1 - k for
+// every used hash slot, and per thread the (term, slot) of its up to kDedupPos positions (position j = it * 256 + tid).  L <= kDedupMaxL.
+// key, first: [kHashSlots] ints; wave_cnt: [48] ints.  Five barriers in all for a caller that adds one counting pass: the ids of a
+// thread's positions are requested together, and the owners of all four position blocks are compacted behind ONE pair of barriers.
+struct DistinctCore {
+  int id_r[kDedupPos], slot_r[kDedupPos];
+  TermList r;
+};
+__device__ __forceinline__ void distinct_core(const PairIds& ids, int L, int64_t V, int* status, int* tok, int* key, int* first, int* wave_cnt,
+                                              DistinctCore& c) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
+  int64_t did[kDedupPos];
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {
+    const int j = it * kThreads + tid;
+    did[it] = (j < L) ? ids.d(j) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // A: hash insert, first position per term
+    const int j = it * kThreads + tid;
+    if (did[it] >= V) { atomicOr(status, kErrDocIdRange); did[it] = 0; }
+    c.id_r[it] = did[it] < 0 ? -1 : (int)did[it];
+    c.slot_r[it] = -1;
+    if (did[it] > 0) {
+      unsigned h = ((unsigned)did[it] * 2654435761u) >> 22;
+      for (;;) {
+        const int old = atomicCAS(&key[h], 0, (int)did[it]);
+        if (old == 0 || old == (int)did[it]) break;
+        h = (h + 1) & (kHashSlots - 1);
+      }
+      c.slot_r[it] = (int)h;
+      atomicMin(&first[h], j);
+    }
+  }
+  __syncthreads();
+  unsigned long long m_own[kDedupPos];
+  bool owner[kDedupPos];
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // B1: who owns a term (its first position), per-wave counts
+    const int j = it * kThreads + tid;
+    const bool real = c.slot_r[it] >= 0;
+    owner[it] = real && first[c.slot_r[it]] == j;
+    m_own[it] = __ballot(owner[it]);
+    const unsigned long long mr = __ballot(real), mo = __ballot(c.id_r[it] < 0);
+    if (lane == 0) {
+      wave_cnt[(it * 3 + 0) * 4 + wave] = __popcll(m_own[it]);
+      wave_cnt[(it * 3 + 1) * 4 + wave] = __popcll(mo);
+      wave_cnt[(it * 3 + 2) * 4 + wave] = __popcll(mr);
+    }
+  }
+  __syncthreads();   // (every comparison against first[] is done before any slot is overwritten below)
+  c.r = TermList{0, 0, 0};
+#pragma unroll
+  for (int it = 0; it < kDedupPos; ++it) {            // B2: owners compacted in document order (position block major, then thread)
+    const int* w0 = wave_cnt + (it * 3) * 4;
+    int off = c.r.n_unique;
+    for (int w = 0; w < wave; ++w) off += w0[w];
+    if (owner[it]) {
+      const int k = off + __popcll(m_own[it] & ((1ull << lane) - 1ull));
+      tok[k] = c.id_r[it];
+      first[c.slot_r[it]] = -1 - k;       // negative: never equal to a position
+    }
+    c.r.n_unique += w0[0] + w0[1] + w0[2] + w0[3];
+    c.r.n_oov += w0[4] + w0[5] + w0[6] + w0[7];
+    c.r.n_real += w0[8] + w0[9] + w0[10] + w0[11];
+  }
+  __syncthreads();
+}
+
+// tok, mult: [L rounded up to 4] ints; key, first: [kHashSlots] ints; wave_cnt: [48] ints.  All LDS.  256 threads.
 __device__ __forceinline__ TermList distinct_terms(const PairIds& ids, int L, int64_t V, int* status, int* tok, int* mult, int* key, int* first,
                                                    int* wave_cnt) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,59 +198,19 @@ __device__ __forceinline__ TermList distinct_terms(const PairIds& ids, int L, in
     r.n_real = r.n_unique;
     return r;
   }
-  for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
   for (int i = tid; i < L; i += kThreads) mult[i] = 0;
-  __syncthreads();
-  int id_r[kDedupPos], slot_r[kDedupPos];
+  DistinctCore c;
+  distinct_core(ids, L, V, status, tok, key, first, wave_cnt, c);
 #pragma unroll
-  for (int it = 0; it < kDedupPos; ++it) {            // A
-    const int j = it * kThreads + tid;
-    int64_t did = (j < L) ? ids.d(j) : 0;
-    if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
-    id_r[it] = did < 0 ? -1 : (int)did;
-    slot_r[it] = -1;
-    if (did > 0) {
-      unsigned h = ((unsigned)did * 2654435761u) >> 22;
-      for (;;) {
-        const int old = atomicCAS(&key[h], 0, (int)did);
-        if (old == 0 || old == (int)did) break;
-        h = (h + 1) & (kHashSlots - 1);
-      }
-      slot_r[it] = (int)h;
-      atomicMin(&first[h], j);
-    }
-  }
+  for (int it = 0; it < kDedupPos; ++it)              // occurrences per term
+    if (c.slot_r[it] >= 0) atomicAdd(&mult[-1 - first[c.slot_r[it]]], 1);
   __syncthreads();
-#pragma unroll
-  for (int it = 0; it < kDedupPos; ++it) {            // B (document order: it-major, then thread)
-    const int j = it * kThreads + tid;
-    const bool real = slot_r[it] >= 0;
-    const bool owner = real && first[slot_r[it]] == j;
-    const unsigned long long m = __ballot(owner), mr = __ballot(real), mo = __ballot(id_r[it] < 0);
-    if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); wave_cnt[8 + wave] = __popcll(mr); }
-    __syncthreads();   // (also: every comparison against first[] above is done before any slot is overwritten below)
-    int off = r.n_unique;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (owner) {
-      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
-      tok[k] = id_r[it];
-      first[slot_r[it]] = -1 - k;       // negative: never equal to a position
-    }
-    r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
-    r.n_real += wave_cnt[8] + wave_cnt[9] + wave_cnt[10] + wave_cnt[11];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int it = 0; it < kDedupPos; ++it)              // C
-    if (slot_r[it] >= 0) atomicAdd(&mult[-1 - first[slot_r[it]]], 1);
-  __syncthreads();
-  return r;
+  return c.r;
 }
 
 // distinct_terms for kernels that need the POSITIONS of a term rather than its count (PACRR writes a similarity to every position of the
 // pair's matrix): tok[k] = the k-th distinct real term, plist[start[k] .. start[k + 1]) = its positions (any order).
-// tok: [L rounded up to 4] ints; start: [L + 1] and plist: [L] uint16 (L <= 65535); wave_cnt: [12] ints; scratch: `scratch_ints` ints that
+// tok: [L rounded up to 4] ints; start: [L + 1] and plist: [L] uint16 (L <= 65535); wave_cnt: [48] ints; scratch: `scratch_ints` ints that
 // may alias anything dead during the call (hash keys | first positions | per-term counters).  Without room for the hash, or beyond
 // kDedupMaxL positions, every real position is listed as its own term.  256 threads; ends on a barrier.
 __device__ __forceinline__ TermList distinct_terms_positions(const PairIds& ids, int L, int64_t V, int* status, int* tok, unsigned short* start,
@@ -214,52 +245,13 @@ __device__ __forceinline__ TermList distinct_terms_positions(const PairIds& ids,
     return r;
   }
   int *key = scratch, *first = scratch + kHashSlots, *cnt = scratch + 2 * kHashSlots;
-  for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
   for (int i = tid; i < L; i += kThreads) cnt[i] = 0;
-  __syncthreads();
-  int id_r[kDedupPos], slot_r[kDedupPos];
+  DistinctCore c;
+  distinct_core(ids, L, V, status, tok, key, first, wave_cnt, c);
+  r = c.r;
 #pragma unroll
-  for (int it = 0; it < kDedupPos; ++it) {            // A: hash insert, first position per term
-    const int j = it * kThreads + tid;
-    int64_t did = (j < L) ? ids.d(j) : 0;
-    if (did >= V) { atomicOr(status, kErrDocIdRange); did = 0; }
-    id_r[it] = did < 0 ? -1 : (int)did;
-    slot_r[it] = -1;
-    if (did > 0) {
-      unsigned h = ((unsigned)did * 2654435761u) >> 22;
-      for (;;) {
-        const int old = atomicCAS(&key[h], 0, (int)did);
-        if (old == 0 || old == (int)did) break;
-        h = (h + 1) & (kHashSlots - 1);
-      }
-      slot_r[it] = (int)h;
-      atomicMin(&first[h], j);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < kDedupPos; ++it) {            // B: owners compacted in document order
-    const int j = it * kThreads + tid;
-    const bool real = slot_r[it] >= 0;
-    const bool owner = real && first[slot_r[it]] == j;
-    const unsigned long long m = __ballot(owner), mr = __ballot(real), mo = __ballot(id_r[it] < 0);
-    if (lane == 0) { wave_cnt[wave] = __popcll(m); wave_cnt[4 + wave] = __popcll(mo); wave_cnt[8 + wave] = __popcll(mr); }
-    __syncthreads();
-    int off = r.n_unique;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (owner) {
-      const int k = off + __popcll(m & ((1ull << lane) - 1ull));
-      tok[k] = id_r[it];
-      first[slot_r[it]] = -1 - k;
-    }
-    r.n_unique += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    r.n_oov += wave_cnt[4] + wave_cnt[5] + wave_cnt[6] + wave_cnt[7];
-    r.n_real += wave_cnt[8] + wave_cnt[9] + wave_cnt[10] + wave_cnt[11];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int it = 0; it < kDedupPos; ++it)              // C: occurrences per term
-    if (slot_r[it] >= 0) atomicAdd(&cnt[-1 - first[slot_r[it]]], 1);
+  for (int it = 0; it < kDedupPos; ++it)              // occurrences per term
+    if (c.slot_r[it] >= 0) atomicAdd(&cnt[-1 - first[c.slot_r[it]]], 1);
   __syncthreads();
   if (wave == 0) {                                    // exclusive prefix sum of the counts: one wave, a run of terms per lane
     const int n = r.n_unique, chunk = (n + 63) >> 6, k0 = lane * chunk, k1 = min(n, k0 + chunk);
@@ -281,8 +273,8 @@ __device__ __forceinline__ TermList distinct_terms_positions(const PairIds& ids,
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kDedupPos; ++it)              // D: positions grouped by term
-    if (slot_r[it] >= 0) {
-      const int k = -1 - first[slot_r[it]];
+    if (c.slot_r[it] >= 0) {
+      const int k = -1 - first[c.slot_r[it]];
       plist[start[k] + atomicSub(&cnt[k], 1) - 1] = (unsigned short)(it * kThreads + tid);
     }
   __syncthreads();

@@ -28,6 +28,10 @@
 
 using namespace capamd;
 
+#ifndef CAPAMD_KNRM_ABLATE
+#define CAPAMD_KNRM_ABLATE 0   // profiling builds only: 1 = no reduction / log / combine tail, 2 = no gather (phase 1 + tail only)
+#endif
+
 namespace {
 
 constexpr int kMaxK = 12;      // 3 kernel slots x 4 lane-rows
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   float* Rlds = partial + kGroupsPerWG * kGroup * PS;            // 48 (x3 with GRAD)
   float* Flds = Rlds + 48 * 3;                                   // kMaxK (+pad to 16) x3: f, df/dmu, df/dsigma
   float* Hlds = Flds + 48;                                       // kMaxHidden
-  int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // 12 (+4 spare)
-  int* n_one = wave_cnt + 16;                                    // kQT per pass (+4 spare)
+  int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // [48]: distinct_terms' per-wave counts
+  int* n_one = wave_cnt + 48;                                    // kQT per pass (+4 spare)
   float4* qlds = reinterpret_cast<float4*>(n_one + 8);           // QLDS: [kQT][NV*16] float4
   int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);  // [tok_cap] multiplicity of tok[k]
   int* hkey = mult + tok_cap;                                    // [kHashSlots] phase 1 only
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 
   // ---- phase 1: the document's distinct real terms with their multiplicities (interaction.cuh) ---------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
-  const int n_real = tl.n_unique;              // rows to gather
+  const int n_real = CAPAMD_KNRM_ABLATE == 2 ? 0 : tl.n_unique;   // rows to gather (profiling builds: 2 = none)
   const int n_nonreal = a.L - tl.n_real;       // pads + OOV positions (closed form below)
 
   // per-lane kernel constants: lane owns query term (lane16 & 3), kernels krow + 4*s
@@ -160,9 +164,6 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
         }
     }
 
-#ifndef CAPAMD_KNRM_ABLATE
-#define CAPAMD_KNRM_ABLATE 0   // profiling builds only: 1 = no reduction / log / combine tail
-#endif
     if (CAPAMD_KNRM_ABLATE == 1) {
       if (acc[0] + acc[1] + acc[2] + rowsum == 123.456f) a.out[b] = 1.f;
       continue;
@@ -271,7 +272,7 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, nullptr, nullptr, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 16 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 48 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
@@ -333,7 +334,7 @@ extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
              dfdsigma_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 16 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, 1, true, 4, true>), dim3(B), dim3(kThreads), smem, s, a)

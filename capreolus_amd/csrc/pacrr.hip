@@ -418,8 +418,8 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
   float* h2 = h1 + kPacrrMaxC;
   _Float16* s_hi = reinterpret_cast<_Float16*>(smem_raw + r0);   // [LP][8]: f16(sim[row][position]), row kBiasRow = 1
   _Float16* s_lo = s_hi + LP * 8;                                // [LP][8]: f16(sim - hi)
-  int* wave_cnt = reinterpret_cast<int*>(s_lo + LP * 8);
-  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 8);        // (32 bytes after a 16-byte aligned plane: aligned)
+  int* wave_cnt = reinterpret_cast<int*>(s_lo + LP * 8);         // [48]: distinct_terms_positions' per-wave counts
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 48);       // (192 bytes after a 16-byte aligned plane: aligned)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
@@ -547,7 +547,7 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
   const size_t tail = (size_t)(ncw + (maxgram - mingram + 1) * nfilters) * 4 + (size_t)(kPacrrMaxFeat + 2 * kPacrrMaxC + 8) * 4 + 16 +
                       (size_t)kQT * kMaxNV * 16 * 16;
   if (Q <= kMfmaMaxQ && nfilters <= 32 && !pacrr_force_valu()) {
-    const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 32 +
+    const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 192 +
                         (size_t)kQT * kMaxNV * 16 * 16;
 #define LAUNCH_M(NV_)                                                                                                           \
   do {                                                                                                                          \
