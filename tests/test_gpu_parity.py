@@ -325,7 +325,7 @@ def test_repeated_document_terms(L):
     assert rel_err(s, want).max() <= ORACLE_TOL
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_geometries_against_the_oracle(seed):
     """Randomised sweep: document lengths 1..1100 (both sides of the distinct-term pass's 896-position limit), 1..12 query terms, embedding
     widths that fill 1..5 packed-row vectors, vocabularies small enough that most terms repeat, pads / OOV terms sprinkled in, a few
@@ -357,8 +357,16 @@ def test_random_geometries_against_the_oracle(seed):
     with torch.no_grad():
         got = r.test(batch).cpu().numpy()
     mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
-    want, _ = oracle.knrm(q, d, packed, D, mu, sigma, m.combine[0].weight.detach().cpu().numpy(), m.combine[0].bias.detach().cpu().numpy())
-    assert rel_err(got, want).max() <= ORACLE_TOL, ("knrm", L, Q, D, V, rel_err(got, want).max())
+    w_c, b_c = m.combine[0].weight.detach().cpu().numpy(), m.combine[0].bias.detach().cpu().numpy()
+    want, _ = oracle.knrm(q, d, packed, D, mu, sigma, w_c, b_c)
+    # The score is a signed sum of 11 log-features: with random combine weights it can cancel to 1e-3 of its terms, and an element-wise
+    # relative bound then measures the cancellation, not the kernel.  Bound the error by the terms instead (features through an identity
+    # combine layer): 2e-5 of the score OR 1e-6 of sum |w_k f_k| + |b| (a dozen fp32 ulps of the largest term; observed < 1e-7).
+    feats = np.stack([oracle.knrm(q, d, packed, D, mu, sigma, np.eye(len(mu), dtype=np.float32)[k:k + 1], np.zeros(1, np.float32))[0]
+                      for k in range(len(mu))], 1)
+    terms = np.abs(w_c.ravel()[None, :] * feats).sum(1) + abs(float(b_c[0]))
+    err = np.abs(got - want)
+    assert ((err <= ORACLE_TOL * np.abs(want)) | (err <= 1e-6 * terms)).all(), ("knrm", L, Q, D, V, float((err / terms).max()))
 
     r = DRMM({}, SimpleNamespace(embeddings=emb))
     m = r.build_model().to(DEV).eval()
@@ -370,7 +378,10 @@ def test_random_geometries_against_the_oracle(seed):
                                      sd["ffw.0.bias"], sd["ffw.2.weight"], sd["ffw.2.bias"], sd["output_layer.weight"], sd["output_layer.bias"])
     assert err == 0
     assert np.array_equal(c0.cpu().numpy(), wcounts), ("drmm counts", L, Q, D, V)
-    assert rel_err(got, want).max() <= ORACLE_TOL, ("drmm", L, Q, D, V, rel_err(got, want).max())
+    # (same conditioning argument: the score is out_w * x + out_b with |x| <= 1, and the two can cancel to 1e-4 of either)
+    terms = np.abs(sd["output_layer.weight"]).sum() + np.abs(sd["output_layer.bias"]).sum()
+    err = np.abs(got - want)
+    assert ((err <= ORACLE_TOL * np.abs(want)) | (err <= 1e-6 * terms)).all(), ("drmm", L, Q, D, V, float(err.max() / terms))
 
     topk = int(min(L, rng.integers(1, 17)))
     r = DRMMTKS({"topk": topk}, SimpleNamespace(embeddings=emb))
@@ -381,7 +392,9 @@ def test_random_geometries_against_the_oracle(seed):
     want, err = oracle.drmmtks(q, d, idf, packed, D, topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"], sd["output_layer.weight"],
                                sd["output_layer.bias"])
     assert err == 0
-    assert rel_err(got, want).max() <= ORACLE_TOL, ("drmmtks", L, Q, D, V, topk, rel_err(got, want).max())
+    terms = np.abs(sd["output_layer.weight"]).sum() + np.abs(sd["output_layer.bias"]).sum()
+    err = np.abs(got - want)
+    assert ((err <= ORACLE_TOL * np.abs(want)) | (err <= 1e-6 * terms)).all(), ("drmmtks", L, Q, D, V, topk, float(err.max() / terms))
 
 
 @pytest.mark.parametrize("kind", ["knrm", "drmm"])
