@@ -199,6 +199,41 @@ def test_abi_header_and_library_agree():
     assert lib.capamd_packed_table_bytes(400001, 300) == 400001 * 320 * 4
 
 
+def test_abi_entries_reject_null_pointers():
+    """Error behaviour at the boundary: every status-returning entry answers CAPAMD_ERR_ARG to null pointers before it touches the
+    device (argument checks come first, so this runs without a GPU) - a caller's mistake is an error code, never a crash."""
+    import ctypes
+
+    from capreolus_amd import _lib
+
+    lib = _lib.load()
+
+    def is_ptr(t):
+        return t is ctypes.c_void_p or hasattr(t, "contents")
+
+    checked = 0
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        if restype is not ctypes.c_int or not any(is_ptr(t) for t in argtypes):
+            continue
+        args = [None if is_ptr(t) else 1 for t in argtypes]
+        assert getattr(lib, name)(*args) == _lib.ERR_ARG, name
+        checked += 1
+    assert checked >= 20
+
+    # geometry limits are refused the same way (device pointers are never dereferenced on the host: any aligned non-null value will do)
+    P = 0x10000
+    knrm = lambda Q=4, L=800, D=300, K=11, hidden=0, V=1000: lib.capamd_knrm_forward(P, P, 8, Q, L, P, V, D, P, P, K, P, P, hidden, P, P, 0, P, P, None)
+    for kw in ({"D": 320}, {"K": 13}, {"K": 0}, {"Q": 0}, {"L": 0}, {"L": 32769}, {"hidden": -1}, {"hidden": 10**6}, {"V": 0}, {"V": 2**31}):
+        assert knrm(**kw) == _lib.ERR_ARG, kw
+    pacrr = lambda Q=4, L=800, maxgram=3, kmax=2, nf=32, comb=32: lib.capamd_pacrr_forward(
+        P, P, P, 8, Q, L, P, 1000, 300, 1, maxgram, nf, kmax, P, P, 1, comb, 1, P, P, P, P, P, P, P, P, None)
+    for kw in ({"Q": 9}, {"L": 1025}, {"maxgram": 4}, {"kmax": 5}, {"nf": 257}, {"comb": 129}):
+        assert pacrr(**kw) == _lib.ERR_ARG, kw
+    assert lib.capamd_convknrm_table_bytes(1000, 4, 128) == -1 and lib.capamd_convknrm_table_bytes(1000, 3, 24) == -1
+    assert lib.capamd_convknrm_table_bytes(1000, 3, 128) == 1000 * 6 * 128 * 4
+    assert lib.capamd_pack_embeddings(P, 10, 300, 300, P + 16, None) == _lib.ERR_ALIGN       # packed rows are 256-byte aligned
+
+
 # ---- training control flow on the host (reference trainer/pytorch.py:47-122, 124-300; trainer/__init__.py:98-109) ----
 
 def test_build_checks_and_lr_schedule():
