@@ -505,6 +505,10 @@ bool fused_ln_enabled() {  // CAPAMD_BERT_FUSED_LN=0 keeps the separate residual
   static const bool on = [] { const char* e = getenv("CAPAMD_BERT_FUSED_LN"); return !(e && e[0] == '0'); }();
   return on;
 }
+bool cedr_fused_enabled() {  // CAPAMD_CEDR_FUSED=0: the tapped encoder on the separate-LayerNorm path (A/B runs)
+  static const bool on = [] { const char* e = getenv("CAPAMD_CEDR_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool small_tiles_enabled() {  // CAPAMD_GEMM_SMALL_TILES=0: A/B switch
   static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_SMALL_TILES"); return !(e && e[0] == '0'); }();
   return on;
@@ -768,9 +772,11 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     const int64_t* mask_mb = mask + p0 * S;
     const int64_t* seg_mb = seg + p0 * S;
     // LayerNorm folded into the GEMMs: every encoder GEMM of this microbatch must be a ping-pong shape
-    // (a CEDR-KNRM call reads every layer's normalised output: it runs the path that materialises them)
-    const bool fused = !tap && fused_ln_enabled() && fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) &&
-                       pingpong_shape(M, F, H) && pingpong_shape(M, H, F);
+    // (a CEDR-KNRM call reads every layer's normalised output: its tap applies the LayerNorm to the operand fragments it loads from
+    // the un-normalised stream, cedr_tap.cuh; CAPAMD_CEDR_FUSED=0 runs it on the path that materialises them instead)
+    const bool fused = (!tap || (cedr_fused_enabled() && S % 32 == 0 && cedr_pool_cm_smem(S, H, tap->A) <= 160 * 1024)) && fused_ln_enabled() &&
+                       fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) && pingpong_shape(M, F, H) &&
+                       pingpong_shape(M, H, F);
     if (fused) {  // chunk-major stream: whole 32-token groups through LDS (S % 32 == 0, so M_real % 32 == 0)
       const size_t lds = (size_t)32 * (H / 8 + 1) * 16;
       if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_ln_cm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -783,7 +789,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       (void)hipMemsetAsync(w.xb + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
       (void)hipMemsetAsync(w.ctx + M_real * H, 0, (size_t)(M - M_real) * H * 2, s);
     }
-    if (tap) cedr_tap_layer<T>(*tap, 0, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s);
+    if (tap) cedr_tap_layer<T>(*tap, 0, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s, fused);   // (normalised in either layout)
     if (fused) {
       // Activation stream: xb and pre hold UN-normalised pre-LayerNorm sums in the chunk-major layout, (mu, rstd) of
       // their rows next to them; no LayerNorm pass exists.  Consumers fold the normalisation into their epilogue
@@ -815,7 +821,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
         AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1, ring ? 1 : 0};
-        if (l == m->layers - 1 && cls_tail_enabled()) {
+        if (l == m->layers - 1 && cls_tail_enabled() && !tap) {   // (CEDR-KNRM pools every row of the last hidden state too)
           // Last layer: only the [CLS] row of every passage is read afterwards and everything after the attention is
           // row-wise - attention for that one query, then the output projection / LayerNorm / FFN / LayerNorm on n_psg
           // rows (padded to whole 256-row tiles) instead of n_psg * S, through the plain row-major kernels.
@@ -875,8 +881,15 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, w.part, H / 64, H, M, w.mu_x, w.rstd_x, w.mr_x, eps);
         last_g = ln2g; last_b = ln2b;
+        if (tap) cedr_tap_layer<T>(*tap, l + 1, (const T*)w.xb, mask_mb, seg_mb, p0, np, S, H, s, true, (const float2*)w.mr_x, ln2g, ln2b);
       }
       if (e != hipSuccess) break;
+      if (tap) {   // the [CLS] rows of the last hidden state (CEDRKNRM.py:160), LayerNorm applied on the way
+        hipLaunchKernelGGL(cedr_cls_rows_cm_kernel<T>, dim3((unsigned)np), dim3(256), 0, s, (const T*)w.xb, (const float2*)w.mr_x, last_g, last_b, S, H,
+                           tap->cls + p0 * H);
+        e = hipGetLastError();
+        continue;
+      }
       float* hpart = reinterpret_cast<float*>(cls_done ? w.ctx : w.pre);
       if (cls_done)   // compact, already normalised [CLS] rows: one row per passage
         hipLaunchKernelGGL(head_kernel<T>, dim3((unsigned)((np + kHeadPsg - 1) / kHeadPsg), (unsigned)(H / kHeadRows)), dim3(256), 0, s, cls_x, np, 1, H,
