@@ -18,6 +18,8 @@ timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-oth
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json
 CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
 for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
+PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cat gpurun_out/bench_cedrknrm.json
+CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
 python - <<'PY'
 import json
 for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):
@@ -39,6 +41,7 @@ timeout 300 $KS -d $P/drmm_roofline_leg -o drmm -- $B --steps 10 --warmup 2 --no
 timeout 300 $KS -d $P/bert -o bert -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert > /dev/null 2>&1
 timeout 300 $KS -d $P/default -o default -- $B --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 for mdl in drmmtks pacrr convknrm; do timeout 300 $KS -d $P/$mdl -o $mdl -- $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
+PYTHONPATH=$R timeout 300 $KS -d $P/cedrknrm -o cedrknrm -- python $R/scripts/sibling_bench.py --only CEDRKNRM > /dev/null 2>&1
 # ---- PMC passes (own runs, counters only): HBM traffic of the KNRM / DRMM headline and roofline legs, MFMA busy of the BERT GEMMs ------
 PM="rocprofv3 --output-format csv --pmc"
 for leg in "knrm:" "knrm_roofline_leg:--uniform-ids --vocab 4000001 --batches 2" "drmm:--model drmm" "drmm_roofline_leg:--model drmm --uniform-ids --vocab 4000001 --batches 2"; do
