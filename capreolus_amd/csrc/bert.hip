@@ -449,7 +449,9 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
       case 128: hipLaunchKernelGGL((attention_kernel<128, 4, T>), dim3(nblk), dim3(256), 0, s, at); break;
       case 160: hipLaunchKernelGGL((attention_kernel<160, 5, T>), dim3(nblk), dim3(320), 0, s, at); break;
       case 192: hipLaunchKernelGGL((attention_kernel<192, 6, T>), dim3(nblk), dim3(384), 0, s, at); break;
-      default: hipLaunchKernelGGL((attention_kernel<224, 7, T>), dim3(nblk), dim3(448), 0, s, at); break;
+      // (seven waves spread badly over four SIMDs: four waves of two query blocks each, 146 -> 126 us per 3072 blocks; the same form is
+      // slower at S = 160 / 192 - three waves, 70 -> 75 and 94 -> 137 us)
+      default: hipLaunchKernelGGL((attention_kernel<224, 4, T, 2>), dim3(nblk), dim3(256), 0, s, at); break;
     }
   }
 }

@@ -168,16 +168,21 @@ __device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename H
   return 1.f / sum;
 }
 
-// NW = waves per workgroup (each wave owns 32 queries); S/32/NW workgroups share one (passage, head) and each
-// stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V staged
-// once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us:
-// the kernel is bound by the L2->LDS fill, so the doubled staging costs more than the overlap buys.
-template <int S, int NW, typename T>
-__global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
+// NW = waves per workgroup, QPW = 32-query blocks per wave (handled one after the other); ceil(S/32 / (NW QPW)) workgroups share
+// one (passage, head) and each stages the whole K / V^T of it.  Measured at S = 256: NW = 8 (one workgroup per (passage, head), K/V
+// staged once) 131 us per 3072 blocks; NW = 4 (two resident workgroups per CU, staging overlapped but doubled) 147 us: the kernel is
+// bound by the L2->LDS fill, so the doubled staging costs more than the overlap buys.
+// These kernels move 4 x S x 128 bytes per (passage, head) - Q, K, V^T in, the context out - for work that grows with S^2: below
+// S = 256 they are bound by that traffic (per 256 passages x 12 heads: 12.5 / 23.4 / 35.6 / 49.8 us at S = 32 .. 128 = 4.0-4.2 TB/s;
+// without the softmax S = 128 still takes 46.9 us: profiling builds -DCAPAMD_ATTN1_ABLATE=1|2); S = 160 / 192 / 224 with their
+// 5 / 6 / 7 waves take 70 / 94 / 146 us, 1.4-2.1 x that bound.  QPW = 2 (four waves of two blocks) brings S = 224 to 126 us; on
+// three waves S = 160 / 192 get slower (75 / 137 us - the second block's latency chain is exposed), so they keep QPW = 1.
+template <int S, int NW, typename T, int QPW = 1>
+__global__ __launch_bounds__(64 * NW, QPW == 1 ? 1 : 2) void attention_kernel(AttnArgs a) {   // (QPW = 2: without a bound hipcc spends 330 registers on it - one wave per SIMD)
   using bf16x8 = typename Half<T>::x8;
   using bf16x4 = typename Half<T>::x4;
-  constexpr int NT = S / 32;            // key tiles
-  constexpr int QB = NT / NW;           // workgroups per (passage, head)
+  constexpr int NT = S / 32;                              // key tiles = 32-query blocks
+  constexpr int QB = (NT + NW * QPW - 1) / (NW * QPW);    // workgroups per (passage, head)
   constexpr int NTHR = 64 * NW;
   constexpr int VROW = S * 2 + 8;       // bytes per V^T row in LDS
   __shared__ __attribute__((aligned(16))) char lds[S * 128 + 64 * VROW + S * 4];
@@ -190,17 +195,16 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
   const int ph = blockIdx.x / QB, qb = blockIdx.x % QB;   // (passage, head) index, query block
   const int psg = ph / a.heads, head = ph % a.heads;
   const int64_t tok0 = (int64_t)psg * S;
-  const int qwave = qb * NW + wave;                       // which 32-query slice of the passage this wave owns
+  const int qwave0 = (qb * NW + wave) * QPW;              // the first 32-query slice of the passage this wave owns
 
   // ---- stage K (swizzled, via LDS-DMA), V^T (padded rows, via registers), additive mask ----
   {
     const int r8 = lane >> 3, p = lane & 7;
-    constexpr int INSTR = S * 8 / 64 / NW;
 #pragma unroll
-    for (int t = 0; t < INSTR; ++t) {
-      const int row = (wave * INSTR + t) * 8 + r8;
+    for (int c = wave; c < S / 8; c += NW) {              // 8 key rows (1 KiB) per instruction and wave
+      const int row = c * 8 + r8;
       const T* src = static_cast<const T*>(a.K) + qk_offset(a, tok0 + row, head * 8 + swz_chunk(row, p));
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + (wave * INSTR + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ks + c * 1024), 16, 0, 0);
     }
     const T* vsrc = static_cast<const T*>(a.Vt) + (int64_t)ph * 64 * S;
     for (int c = tid; c < 64 * S / 8; c += NTHR) {
@@ -213,65 +217,87 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(AttnArgs a) {
       madd[k] = a.mask[(int64_t)psg * S + k] != 0 ? 0.f : -3.4028234663852886e38f;  // HF: (1-mask) * finfo.min
   }
   // this wave's Q fragments (B operand): query = qwave*32 + l31, d = (2*ks+half)*8 ..+7
-  bf16x8 qf[4];
-  {
+  auto load_q = [&](bf16x8 (&q)[4], int qw) {
+    qw = qw < NT ? qw : NT - 1;                           // (a block beyond the passage: a valid row, never computed)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, tok0 + qwave * 32 + l31, head * 8 + 2 * ks + half));
-  }
+      q[ks] = *reinterpret_cast<const bf16x8*>(static_cast<const T*>(a.Q) + qk_offset(a, tok0 + qw * 32 + l31, head * 8 + 2 * ks + half));
+  };
+  bf16x8 qf[4];
+  load_q(qf, qwave0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of K: hipcc does not wait for it at the barrier by itself
   __syncthreads();
 
-  // ---- scores^T tiles: lane <- query l31, keys 32t + 16*(r>>3) + 8*half + (r&7) (key_of_row) ----
   const int lperm = key_of_row(l31);
-  bf16x8 pf[NT][2];
-  float inv;
-  {
-    f32x16 sc[NT];
+  // (one block after the other, not unrolled: interleaving two blocks doubles the live registers - 298 at S = 224 - and leaves one wave per SIMD)
+#pragma unroll 1
+  for (int j = 0; j < QPW; ++j) {
+    const int qwave = qwave0 + j;
+    if (qwave >= NT) break;                               // (wave-uniform; no barrier below)
+    bf16x8 qn[4];
+    if (QPW > 1) load_q(qn, qwave + 1);                   // the next block's fragments arrive under this block's work
+    // ---- scores^T tiles: lane <- query l31, keys 32t + 16*(r>>3) + 8*half + (r&7) (key_of_row) ----
+    bf16x8 pf[NT][2];
+    float inv;
+    {
+      f32x16 sc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      sc[t] = scores_init_permuted<NT>(madd + t * 32 + 8 * half);
+      for (int t = 0; t < NT; ++t) {
+        sc[t] = scores_init_permuted<NT>(madd + t * 32 + 8 * half);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int row = t * 32 + lperm;
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
-        sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+        for (int ks = 0; ks < 4; ++ks) {
+          const int row = t * 32 + lperm;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + swz_chunk(row, 2 * ks + half) * 16);
+          sc[t] = Half<T>::mfma(kf, qf[ks], sc[t]);
+        }
       }
+      // ---- exact softmax over the S keys of this lane's query ----
+#if defined(CAPAMD_ATTN1_ABLATE) && (CAPAMD_ATTN1_ABLATE & 2)   // profiling build: no softmax (plain conversion)
+      inv = 1.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pf[t][e >> 3][e & 7] = (T)sc[t][e];
+#else
+      inv = softmax_pack<NT, T>(sc, pf);
+#endif
     }
-    // ---- exact softmax over the S keys of this lane's query ----
-    inv = softmax_pack<NT, T>(sc, pf);
-  }
 
-  // ---- ctx^T = V^T · P^T : out[dt] lane <- query l31, d = 32dt + 8*(r>>2) + 4*half + (r&3) ----
-  f32x16 out[2];
+    // ---- ctx^T = V^T · P^T : out[dt] lane <- query l31, d = 32dt + 8*(r>>2) + 4*half + (r&3) ----
+    f32x16 out[2];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) out[dt][r] = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int kb = (32 * t + 16 * s2 + 8 * half) * 2;  // byte offset of keys 32t + 16 s2 + 8 half .. + 7 in a V^T row (8-byte aligned rows)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int kb = (32 * t + 16 * s2 + 8 * half) * 2;  // byte offset of keys 32t + 16 s2 + 8 half .. + 7 in a V^T row (8-byte aligned rows)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const char* vr = Vs + (dt * 32 + l31) * VROW + kb;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
-        const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, raw);
-        out[dt] = Half<T>::mfma(vf, pf[t][s2], out[dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vr = Vs + (dt * 32 + l31) * VROW + kb;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);
+          const uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, raw);
+          out[dt] = Half<T>::mfma(vf, pf[t][s2], out[dt]);
+        }
       }
-    }
-  const int64_t ctok = tok0 + qwave * 32 + l31;
+    const int64_t ctok = tok0 + qwave * 32 + l31;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv),
-                  scale_round<T>(out[dt][g4 * 4 + 2], inv), scale_round<T>(out[dt][g4 * 4 + 3], inv)};
-      *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o = {scale_round<T>(out[dt][g4 * 4 + 0], inv), scale_round<T>(out[dt][g4 * 4 + 1], inv),
+                    scale_round<T>(out[dt][g4 * 4 + 2], inv), scale_round<T>(out[dt][g4 * 4 + 3], inv)};
+        *reinterpret_cast<bf16x4*>(ctx_slot<T>(a, ctok, head, dt, g4, half)) = o;
+      }
+    if (QPW > 1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
     }
+  }
 }
 
 // ---- persistent, double-buffered variant for S = 256 ------------------------------------------------------------
