@@ -28,4 +28,5 @@ cp $G/knrm_hbm_traffic.json $G/drmm_hbm_traffic.json $D/
 cp $G/pmc_summary.txt $D/pmc_summary.txt
 cp $G/mfma_power.txt $D/mfma_power.txt
 cp $G/pytest_gpu.log $D/pytest_gpu.log
+[ -f $G/train_steps.jsonl ] && cp $G/train_steps.jsonl $D/train_steps.jsonl
 ls -la $D | tail -40

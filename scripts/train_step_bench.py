@@ -1,0 +1,57 @@
+"""Training-step rate of the trainable rerankers (row N3): `reranker.score()` on a (query, positive, negative) batch of the reference's
+default size (batch = 32, trainer/pytorch.py:24-27) -> pairwise hinge loss -> backward -> Adam step, on the GPU.  KNRM / DRMM / DRMM-TKS /
+PACRR run their [B, Q, L] part on HIP feature kernels, ConvKNRM the reference's ATen op sequence under autograd.
+Prints one JSON line per model; not part of bench.py's contract."""
+import argparse
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from capreolus_amd import synthetic  # noqa: E402
+from capreolus_amd.reranker import DRMM, DRMMTKS, KNRM, PACRR, ConvKNRM  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--vocab", type=int, default=400001)
+ap.add_argument("--dim", type=int, default=300)
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--only", default="", help="comma-separated model names")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+emb = synthetic.make_embeddings(args.vocab, args.dim, seed=0)
+cand = synthetic.make_candidate_list_torch(1, 2 * args.batch, args.vocab, dev)       # one query's candidates: the first half positives, the rest negatives
+ext = SimpleNamespace(embeddings=emb, config={"maxqlen": 4}, pad=0)
+B = args.batch
+for name, r in (("KNRM", KNRM({}, ext)), ("DRMM", DRMM({}, ext)), ("DRMMTKS", DRMMTKS({}, ext)), ("PACRR", PACRR({}, ext)), ("ConvKNRM", ConvKNRM({}, ext))):
+    if args.only and name not in args.only.split(","):
+        continue
+    fix = (lambda v: v.abs()) if name in ("ConvKNRM", "DRMM") else (lambda v: v)      # nn.Embedding ids only where the reference looks ids up unclamped
+    d = {"query": fix(cand["query"][:B]), "query_idf": cand["query_idf"][:B], "posdoc": fix(cand["posdoc"][:B]), "negdoc": fix(cand["posdoc"][B:])}
+    torch.manual_seed(0)
+    m = r.build_model().to(dev).train()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+
+    def step():
+        pos, neg = r.score(d)
+        loss = torch.clamp(1.0 - (pos - neg), min=0).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        loss0 = step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    print(json.dumps({"model": name, "train_steps_per_s": round(1e3 / ms, 1), "ms_per_step": round(ms, 3), "batch": B, "docs_scored_per_step": 2 * B,
+                      "loss_first": round(float(loss0.detach()), 5), "loss_last": round(float(loss.detach()), 5)}))
