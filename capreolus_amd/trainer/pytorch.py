@@ -248,7 +248,7 @@ class PytorchTrainer:
             self._train_autocast, self.scaler = contextlib.nullcontext, None
         self._set_lr(0)                      # LambdaLR's construction applies multiplier(0)
         self.loss = self.pair_softmax_loss if self.config["softmaxloss"] else self.pair_hinge_loss
-        loader = torch.utils.data.DataLoader(train_dataset, batch_size=self.config["batch"], pin_memory=self.device.type == "cuda",
+        loader = torch.utils.data.DataLoader(train_dataset, batch_size=self.config["batch"], pin_memory=False,   # (see predict)
                                              num_workers=1 if self.config["multithread"] else 0)
         train_output_path, dev_output_path = os.fspath(train_output_path), os.fspath(dev_output_path)
         best_fn, weights_path, loss_fn, metric_fn = self._early_stopping_paths(train_output_path, dev_output_path)
@@ -342,17 +342,25 @@ class PytorchTrainer:
         from .. import ranking
 
         reranker.model.to(store.device).eval()
-        keys, pq, pd = store.pairs(qid_to_docids)
-        step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(len(keys), 1)
+        # The index pairs and the judgment arrays depend only on (store, run, qrels, k): `train` evaluates the same dev set after every
+        # iteration, so they are built once (walking 64,000 dict entries costs 10x the scoring and ranking kernels) and kept while the
+        # caller holds the same objects.
+        key = (id(store), id(qid_to_docids), id(qrels), k)
+        plan = getattr(self, "_eval_plan", None)
+        if plan is None or plan[0] != key or plan[1] is not store or plan[2] is not qid_to_docids or plan[3] is not qrels:
+            keys, pq, pd = store.pairs(qid_to_docids)
+            rel, tie, idcg, offsets = ranking.eval_arrays(qid_to_docids, qrels, k, store.device)
+            judged = torch.tensor([q in qrels for q in qid_to_docids], dtype=torch.bool, device=store.device)
+            plan = self._eval_plan = (key, store, qid_to_docids, qrels, len(keys), pq, pd, rel, tie, idcg, offsets, judged)
+        n, pq, pd, rel, tie, idcg, offsets, judged = plan[4:]
+        step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(n, 1)
         with torch.no_grad():
-            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, len(keys), step)]
+            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]
         scores = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
-        rel, tie, idcg, offsets = ranking.eval_arrays(qid_to_docids, qrels, k, store.device)
         per_query = ranking.ndcg_cut(scores, offsets, rel, tie, idcg, k=k)
         from ..engine import status_word
 
         status_word(store.device).raise_if_set()
-        judged = torch.tensor([q in qrels for q in qid_to_docids], dtype=torch.bool, device=store.device)
         return float(per_query[judged].mean().item()) if bool(judged.any()) else 0.0
 
     def predict(self, reranker, pred_data, pred_fn=None):
@@ -375,7 +383,10 @@ class PytorchTrainer:
         workers = 1 if self.config["multithread"] else 0
         keys, chunks = [], []
         if count > 0:
-            loader = torch.utils.data.DataLoader(part, batch_size=evalbatch, pin_memory=self.device.type == "cuda",
+            # (no pin_memory, unlike trainer/pytorch.py:335: on ROCm the loader's pinning thread allocates a fresh pinned block for every
+            # batch of more than ~1 MB - measured 1.29 s against 0.08 s per 20,000 samples at evalbatch 256, scripts/dbg/pin_probe.py - and
+            # at the default 32 the pageable copy is faster too, 0.098 against 0.124 s)
+            loader = torch.utils.data.DataLoader(part, batch_size=evalbatch, pin_memory=False,
                                                  num_workers=workers)
             coalesce = self.config["coalesce"]
             pending, n_pending = [], 0

@@ -19,6 +19,7 @@ timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-oth
 CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
 for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cat gpurun_out/bench_cedrknrm.json
+PYTHONPATH=$R timeout 300 python $R/scripts/predict_e2e_bench.py 2>/dev/null | tail -1 > gpurun_out/predict_e2e.json; cat gpurun_out/predict_e2e.json
 PYTHONPATH=$R timeout 300 python $R/scripts/train_step_bench.py 2>/dev/null | grep "^{" > gpurun_out/train_steps.jsonl; cat gpurun_out/train_steps.jsonl
 CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
 python - <<'PY'

@@ -733,6 +733,11 @@ def test_evaluate_resident_equals_host_pipeline():
     got = tr.evaluate_resident(r, store, q2d, qrels, k=20)
     want = run_io.mean_ndcg_cut(qrels, tr.predict_resident(r, store, q2d), 20)
     assert abs(got - want) <= 1e-12
+    assert tr.evaluate_resident(r, store, q2d, qrels, k=20) == got          # second call: the cached index pairs / judgment arrays
+    qrels2 = {q: {d: 2 - g for d, g in ds.items()} for q, ds in qrels.items()}  # other judgments (another object): the plan is rebuilt
+    got2 = tr.evaluate_resident(r, store, q2d, qrels2, k=20)
+    assert abs(got2 - run_io.mean_ndcg_cut(qrels2, tr.predict_resident(r, store, q2d), 20)) <= 1e-12 and got2 != got
+    assert abs(tr.evaluate_resident(r, store, q2d, qrels, k=10) - run_io.mean_ndcg_cut(qrels, tr.predict_resident(r, store, q2d), 10)) <= 1e-12
 
 
 # ---- training step (row N3): HIP features + Jacobian diagonals vs autograd through the ATen port on CPU ----------
