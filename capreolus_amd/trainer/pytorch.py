@@ -22,6 +22,16 @@ import torch
 from ..run_io import write_trec_run
 
 
+def _preds_dict(keys, scores):
+    """{qid: {docid: score}} with the scores rounded to float16 - what the reference hands to pytrec_eval and to the run file
+    (trainer/pytorch.py:346-348).  One vectorised conversion: `score.astype(np.float16).item()` per pair was most of predict_resident's time."""
+    vals = np.asarray(scores).astype(np.float16).tolist()
+    preds = {}
+    for (qid, docid), v in zip(keys, vals):
+        preds.setdefault(qid, {})[docid] = v
+    return preds
+
+
 def shard_bounds(sizes, world):
     """Contiguous split of items with the given sizes into `world` blocks of near-equal total size.
     Returns world+1 boundaries (indices into the item list)."""
@@ -326,9 +336,7 @@ class PytorchTrainer:
             allkeys = [(q, d) for q in qids for d in qid_to_docids[q]]
         else:
             allkeys, allscores = keys, local.cpu().numpy()
-        preds = {}
-        for (qid, docid), score in zip(allkeys, allscores):
-            preds.setdefault(qid, {})[docid] = score.astype(np.float16).item()
+        preds = _preds_dict(allkeys, allscores)
         if pred_fn is not None and rank == 0:
             os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
             write_trec_run(preds, pred_fn)
@@ -449,10 +457,7 @@ class PytorchTrainer:
         else:
             allkeys, allscores = keys, local.cpu().numpy()
 
-        preds = {}
-        for (qid, docid), score in zip(allkeys, allscores):
-            # float16: what the reference hands to pytrec_eval (trainer/pytorch.py:346-348)
-            preds.setdefault(qid, {})[docid] = score.astype(np.float16).item()
+        preds = _preds_dict(allkeys, allscores)
         if pred_fn is not None and rank == 0:
             os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
             write_trec_run(preds, pred_fn)
