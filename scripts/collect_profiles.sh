@@ -27,6 +27,7 @@ done
 cp $G/knrm_hbm_traffic.json $G/drmm_hbm_traffic.json $D/
 cp $G/pmc_summary.txt $D/pmc_summary.txt
 cp $G/mfma_power.txt $D/mfma_power.txt
+[ -f $G/hbm_read.txt ] && cp $G/hbm_read.txt $D/hbm_read.txt
 cp $G/pytest_gpu.log $D/pytest_gpu.log
 [ -f $G/train_steps.jsonl ] && cp $G/train_steps.jsonl $D/train_steps.jsonl
 [ -f $G/predict_e2e.json ] && cp $G/predict_e2e.json $D/predict_e2e.json

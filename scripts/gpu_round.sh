@@ -58,4 +58,5 @@ cd $R
 for f in $(find $P -name "*.csv" -size -4000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
 python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&1; cat gpurun_out/pmc_summary.txt
 timeout 200 ./scripts/ubench/mfma_power > gpurun_out/mfma_power.txt 2>&1; cat gpurun_out/mfma_power.txt
+[ -x ./scripts/ubench/hbm_read ] && { timeout 200 ./scripts/ubench/hbm_read > gpurun_out/hbm_read.txt 2>&1; cat gpurun_out/hbm_read.txt; }
 ls gpurun_out/prof/
