@@ -451,6 +451,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                           "and per query term + score) / per-launch device time (one HIP event pair around the timed launches); every requested row is a "
                           "distinct random row, so requested bytes = HBM bytes up to the <= 5 % the Infinity Cache can hold",
             "headline_leg": headline,
+            "read_ceiling_note": "a kernel that only reads sustains 6.0-6.6 TB/s streaming 8 GiB and 6.3-6.4 TB/s on random 1280-byte rows of the same "
+                                 "5.1 GB table on this part (scripts/ubench/hbm_read.hip, profiles/r02/hbm_read.txt; builder-run, not measured in this invocation)",
         }
         del big
         _tables.pop((ctx.dev.index, args.roofline_vocab, args.dim), None)
