@@ -133,6 +133,8 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
     float acc[3] = {0.f, 0.f, 0.f};
     float acc1[3] = {0.f, 0.f, 0.f}, acc2[3] = {0.f, 0.f, 0.f};  // GRAD: sum K*adj, sum K*adj^2
     float rowsum = 0.f;
+    // (issuing a group's NEXT row before the current one is used - two rows in flight for one row's arithmetic registers - is slower
+    // at every occupancy: 45.6 / 44.7 / 43.4 M pairs/s at 5 / 4 / 6 waves per SIMD against 49.2 M; the loop is not waiting for memory)
     for (int t0 = g; t0 < n_real; t0 += U * kGroupsPerWG) {
       RowRegs<NV> d[U];
       bool has[U];

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
+#include <math.h>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int U>
@@ -88,6 +90,40 @@ int main() {
     float m4 = time_ms([&] { hipLaunchKernelGGL(row_gather<4>, dim3(grid), dim3(256), 0, 0, buf, d_rows, n_rows, out); }, 3);
     printf("random 1280-byte rows of a 5.1 GB table, %2d workgroups per CU: %.2f / %.2f / %.2f TB/s with 1 / 2 / 4 rows in flight per 16-lane group\n",
            wgs_per_cu, n_rows * 1280.0 / m1 / 1e9, n_rows * 1280.0 / m2 / 1e9, n_rows * 1280.0 / m4 / 1e9);
+  }
+  // (c) the headline leg's request stream: Zipf(1.1) term ids over a 400,001-row table (512 MB - twice the Infinity Cache), documents of 303
+  //     draws with repeats inside a document removed (what the distinct-term pass requests), documents handed to consecutive groups
+  {
+    const size_t Vz = 400001;
+    std::vector<double> cdf(Vz);
+    double z = 0;
+    for (size_t i = 1; i < Vz; ++i) { z += pow((double)i, -1.1); cdf[i] = z; }
+    std::vector<int> zr;
+    zr.reserve(n_rows + 512);
+    std::vector<int> doc;
+    while (zr.size() < n_rows) {
+      doc.clear();
+      for (int t = 0; t < 303; ++t) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = (double)(s >> 11) / 9007199254740992.0 * z;
+        doc.push_back((int)(std::lower_bound(cdf.begin() + 1, cdf.end(), u) - cdf.begin()));
+      }
+      std::sort(doc.begin(), doc.end());
+      doc.erase(std::unique(doc.begin(), doc.end()), doc.end());
+      // (original order does not matter to the memory system; shuffle lightly so that neighbours are not sorted by rank)
+      for (size_t i = doc.size(); i > 1; --i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; std::swap(doc[i - 1], doc[s % i]); }
+      zr.insert(zr.end(), doc.begin(), doc.end());
+    }
+    zr.resize(n_rows);
+    CK(hipMemcpy(d_rows, zr.data(), n_rows * 4, hipMemcpyHostToDevice));
+    for (int wgs_per_cu : {8, 16, 32}) {
+      const int grid = 256 * wgs_per_cu;
+      float m1 = time_ms([&] { hipLaunchKernelGGL(row_gather<1>, dim3(grid), dim3(256), 0, 0, buf, d_rows, n_rows, out); }, 3);
+      float m2 = time_ms([&] { hipLaunchKernelGGL(row_gather<2>, dim3(grid), dim3(256), 0, 0, buf, d_rows, n_rows, out); }, 3);
+      float m4 = time_ms([&] { hipLaunchKernelGGL(row_gather<4>, dim3(grid), dim3(256), 0, 0, buf, d_rows, n_rows, out); }, 3);
+      printf("Zipf(1.1) rows of a 512 MB table, distinct within 303-term documents, %2d workgroups per CU: %.2f / %.2f / %.2f TB/s with 1 / 2 / 4 rows in flight\n",
+             wgs_per_cu, n_rows * 1280.0 / m1 / 1e9, n_rows * 1280.0 / m2 / 1e9, n_rows * 1280.0 / m4 / 1e9);
+    }
   }
   return 0;
 }
