@@ -399,68 +399,38 @@ __device__ __forceinline__ float row_sim_my(const RowRegs<NV>& d, const QueryPas
 // ---- multi-term form used by the scoring kernels -------------------------------------------------
 // U document rows are gathered per group per iteration (U*NV float4 loads in flight per lane).  The
 // query rows come either from registers (QueryPass) or, when QLDS, from an LDS copy shared by the
-// workgroup (kQT*NV*16 float4, term pairs interleaved - see below -, den slot zeroed) which frees 16*NV VGPRs per wave for more rows in
+// workgroup ([kQT][NV*16] float4, den slot zeroed) which frees 16*NV VGPRs per wave for more rows in
 // flight; each query chunk read from LDS is reused for all U rows.  The fma order per (row, query
 // term) is unchanged (i ascending; x, y, z, w), so results are bit-identical across variants.
-// The LDS copy interleaves the query terms in PAIRS - per pair (2 tp, 2 tp + 1) and chunk i two float4:
-// (a.x, b.x, a.y, b.y), (a.z, b.z, a.w, b.w) - so that the two terms' partial dot products advance with ONE v_pk_fma_f32
-// (document value splatted by op_sel, the two query values and the two accumulators as 64-bit register pairs): the
-// headline KNRM kernel is bound by VALU issue, not by memory (a read-only gather of its request stream sustains 15.5 TB/s against the
-// kernel's 11.7, scripts/ubench/hbm_read.hip), and the 80 fp32 FMAs per 4 rows and wave were half of its instructions.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (Tried in round 2: the LDS copy interleaved in term PAIRS so that two terms' partial sums advance with one v_pk_fma_f32 - 40
+// instead of 80 FMA instructions per 4 rows, bit-identical sums.  Same-box A/B: KNRM headline 49.9 = 49.9 M pairs/s, its HBM-bound
+// leg 0.797 against 0.817; DRMM +2 %, DRMM-TKS -2 %, PACRR -2 %: the kernels are not bound by VALU issue.  Not kept.)
 template <int NV, int U, bool QLDS>
 __device__ __forceinline__ void rows_sim_my(const RowRegs<NV> (&d)[U], const QueryPass<NV>& qp, const float4* qlds, int lane16,
                                             float (&sim)[U]) {
   float p[U][kQT];
-  if (QLDS) {
-    static_assert(kQT == 4, "query terms are paired");
-    f32x2_t p2[U][2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) p2[u][0] = p2[u][1] = f32x2_t{0.f, 0.f};
+  for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
+    for (int t = 0; t < kQT; ++t) p[u][t] = 0.f;
 #pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
-        const float4 qa = qlds[((tp * NV + i) * 2 + 0) * 16 + lane16], qb = qlds[((tp * NV + i) * 2 + 1) * 16 + lane16];
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          f32x2_t a = p2[u][tp];
-          const float4 dv = d[u].v[i];
-          a = __builtin_elementwise_fma(f32x2_t{dv.x, dv.x}, f32x2_t{qa.x, qa.y}, a);
-          a = __builtin_elementwise_fma(f32x2_t{dv.y, dv.y}, f32x2_t{qa.z, qa.w}, a);
-          a = __builtin_elementwise_fma(f32x2_t{dv.z, dv.z}, f32x2_t{qb.x, qb.y}, a);
-          a = __builtin_elementwise_fma(f32x2_t{dv.w, dv.w}, f32x2_t{qb.z, qb.w}, a);
-          p2[u][tp] = a;
-        }
-        // keep at most one pair of query chunks in flight ahead of its use: otherwise the scheduler front-loads all
-        // kQT*NV LDS reads and the 16*NV VGPRs the LDS copy was meant to free are back
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < kQT; ++t) {
+      const float4 q = QLDS ? qlds[(t * NV + i) * 16 + lane16] : qp.row[t].v[i];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float a = p[u][t];
+        a = __builtin_fmaf(d[u].v[i].x, q.x, a);
+        a = __builtin_fmaf(d[u].v[i].y, q.y, a);
+        a = __builtin_fmaf(d[u].v[i].z, q.z, a);
+        a = __builtin_fmaf(d[u].v[i].w, q.w, a);
+        p[u][t] = a;
       }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      p[u][0] = p2[u][0].x; p[u][1] = p2[u][0].y; p[u][2] = p2[u][1].x; p[u][3] = p2[u][1].y;
+      // keep at most one query chunk in flight ahead of its use: otherwise the scheduler front-loads all
+      // kQT*NV LDS reads and the 16*NV VGPRs the LDS copy was meant to free are back
+      if (QLDS && (t & 1)) __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int t = 0; t < kQT; ++t) p[u][t] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-      for (int t = 0; t < kQT; ++t) {
-        const float4 q = qp.row[t].v[i];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          float a = p[u][t];
-          a = __builtin_fmaf(d[u].v[i].x, q.x, a);
-          a = __builtin_fmaf(d[u].v[i].y, q.y, a);
-          a = __builtin_fmaf(d[u].v[i].z, q.z, a);
-          a = __builtin_fmaf(d[u].v[i].w, q.w, a);
-          p[u][t] = a;
-        }
-      }
-  }
   const int myq = lane16 & 3;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -499,13 +469,7 @@ __device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ pa
     for (int c = tid; c < NV * 16; c += nthreads) {
       float4 v = reinterpret_cast<const float4*>(row)[c];
       if (c == NV * 16 - 1) v.w = 0.f;  // keep the den slot out of the dot product
-      // interleaved with the other term of the pair (rows_sim_my): (a.x, b.x, a.y, b.y), (a.z, b.z, a.w, b.w)
-      const int i = c >> 4, l = c & 15, tp = t >> 1, sl = t & 1;
-      float* dst = reinterpret_cast<float*>(qlds + ((tp * NV + i) * 2) * 16 + l);
-      dst[sl] = v.x;
-      dst[2 + sl] = v.y;
-      dst[64 + sl] = v.z;      // (+16 float4)
-      dst[64 + 2 + sl] = v.w;
+      qlds[t * NV * 16 + c] = v;
     }
   }
 }
