@@ -353,7 +353,10 @@ class PytorchTrainer:
         # The index pairs and the judgment arrays depend only on (store, run, qrels, k): `train` evaluates the same dev set after every
         # iteration, so they are built once (walking 64,000 dict entries costs 10x the scoring and ranking kernels) and kept while the
         # caller holds the same objects.
-        key = (id(store), id(qid_to_docids), id(qrels), k)
+        # (+ a cheap fingerprint of their sizes, so that a run or judgments grown / shrunk in place are noticed; values edited in place
+        # under an unchanged shape are not - hand in new objects then)
+        key = (id(store), id(qid_to_docids), id(qrels), k, len(qid_to_docids), sum(len(v) for v in qid_to_docids.values()),
+               len(qrels), sum(len(v) for v in qrels.values()))
         plan = getattr(self, "_eval_plan", None)
         if plan is None or plan[0] != key or plan[1] is not store or plan[2] is not qid_to_docids or plan[3] is not qrels:
             keys, pq, pd = store.pairs(qid_to_docids)
