@@ -116,10 +116,23 @@ __device__ __forceinline__ void distinct_core(const PairIds& ids, int L, int64_t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kHashSlots; i += kThreads) { key[i] = 0; first[i] = 0x7fffffff; }
   int64_t did[kDedupPos];
+  // (one branch on the id layout around all of a thread's loads, not one per load: inside `ids.d(j)` the int32 side's sign extension
+  // made hipcc wait for each load before it issued the next - four memory round trips per pair on the resident-store path)
+  if (ids.d32) {
+    int v[kDedupPos];
 #pragma unroll
-  for (int it = 0; it < kDedupPos; ++it) {
-    const int j = it * kThreads + tid;
-    did[it] = (j < L) ? ids.d(j) : 0;
+    for (int it = 0; it < kDedupPos; ++it) {
+      const int j = it * kThreads + tid;
+      v[it] = ids.d32[j < L ? j : L - 1];          // (unconditional: a load under its own exec mask is waited for at the join)
+    }
+#pragma unroll
+    for (int it = 0; it < kDedupPos; ++it) did[it] = (it * kThreads + tid < L) ? (int64_t)v[it] : 0;
+  } else {
+#pragma unroll
+    for (int it = 0; it < kDedupPos; ++it) {
+      const int j = it * kThreads + tid;
+      did[it] = (j < L) ? ids.d64[j] : 0;
+    }
   }
   __syncthreads();
 #pragma unroll
