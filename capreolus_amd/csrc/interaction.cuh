@@ -457,32 +457,56 @@ __device__ __forceinline__ void rows_sim_my(const RowRegs<NV> (&d)[U], const Que
   }
 }
 
-// query pass whose rows live in LDS: only ids / den of the owned term stay in registers
+// query pass whose rows live in LDS: only ids / den of the owned term stay in registers.  The loads are batched - the kQT ids together
+// (one branch on the id layout around them, indices clamped instead of predicated), then the kQT rows' chunks and norms together, then
+// the LDS writes: written term by term, hipcc waited for each id before it asked for that term's row and for each row before the next
+// id - eight memory round trips per pair in series where two do.  nthreads >= NV * 16 (one chunk per thread and row).
 template <int NV>
 __device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ packed, const PairIds& ids, int Q,
                                                     int q0, int64_t V, int tid, int nthreads, int lane16, float4* qlds,
                                                     QueryPass<NV>& qp, int* status) {
+  (void)nthreads;
   const int myq = lane16 & 3;
+  int64_t id[kQT];
+  if (ids.q32) {
+    int v[kQT];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) v[t] = ids.q32[q0 + t < Q ? q0 + t : Q - 1];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) id[t] = (q0 + t < Q) ? (int64_t)v[t] : 0;
+  } else {
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) id[t] = ids.q64[q0 + t < Q ? q0 + t : Q - 1];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) id[t] = (q0 + t < Q) ? id[t] : 0;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int t = 0; t < kQT; ++t)
+    if (id[t] >= V) { bad = true; id[t] = 0; }
+  if (bad && status) atomicOr(status, kErrQueryIdRange);
+  float den[kQT];
+  float4 v[kQT];
+  const int c = tid < NV * 16 ? tid : 0;
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    const float* row = packed + (id[t] > 0 ? id[t] : 0) * (int64_t)(64 * NV);
+    den[t] = row[64 * NV - 1];
+    v[t] = reinterpret_cast<const float4*>(row)[c];
+  }
   qp.den_my = 1e-9f;
   qp.id_my = 0;
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
-    int64_t id = (q0 + t < Q) ? ids.q(q0 + t) : 0;
-    if (id >= V) {
-      if (status) atomicOr(status, kErrQueryIdRange);
-      id = 0;
-    }
-    qp.id[t] = (int)id;
-    const float* row = packed + (id > 0 ? id : 0) * (int64_t)(64 * NV);
-    const float den = row[64 * NV - 1];
+    qp.id[t] = (int)id[t];
     if (myq == t) {
-      qp.den_my = den;
-      qp.id_my = (int)id;
+      qp.den_my = den[t];
+      qp.id_my = (int)id[t];
     }
-    for (int c = tid; c < NV * 16; c += nthreads) {
-      float4 v = reinterpret_cast<const float4*>(row)[c];
-      if (c == NV * 16 - 1) v.w = 0.f;  // keep the den slot out of the dot product
-      qlds[t * NV * 16 + c] = v;
+    if (tid < NV * 16) {
+      float4 w = v[t];
+      if (tid == NV * 16 - 1) w.w = 0.f;  // keep the den slot out of the dot product
+      qlds[t * NV * 16 + tid] = w;
     }
   }
 }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   float* Hlds = Flds + 48;                                       // kMaxHidden
   int* wave_cnt = reinterpret_cast<int*>(Hlds + kMaxHidden);     // [48]: distinct_terms' per-wave counts
   int* n_one = wave_cnt + 48;                                    // kQT per pass (+4 spare)
-  float4* qlds = reinterpret_cast<float4*>(n_one + 8);           // QLDS: [kQT][NV*16] float4
+  float* Clds = reinterpret_cast<float*>(n_one + 8);             // [64]: mu[16] | sigma[16] | w1[16] (single Linear) | b1[0]: the tail's constants
+  float4* qlds = reinterpret_cast<float4*>(Clds + 64);           // QLDS: [kQT][NV*16] float4
   int* mult = reinterpret_cast<int*>(qlds + kQT * kMaxNV * 16);  // [tok_cap] multiplicity of tok[k]
   int* hkey = mult + tok_cap;                                    // [kHashSlots] phase 1 only
   int* hfirst = hkey + kHashSlots;                               // [kHashSlots] phase 1 only
@@ -96,12 +97,31 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   // per-lane kernel constants: lane owns query term (lane16 & 3), kernels krow + 4*s
   const int krow = lane16 >> 2;
   float mu_s[3], c_s[3];
+  {
+    float sg_l[3], mu_l[3];   // (clamped index, not a predicated load: the six loads go out together - one memory round trip, not three)
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int k = krow + 4 * s;
-    const float sg = k < a.K ? a.sigma[k] : 1.f;
-    mu_s[s] = k < a.K ? a.mu[k] : 0.f;
-    c_s[s] = k < a.K ? (-0.5f * kLog2e) / (sg * sg) : 0.f;
+    for (int s = 0; s < 3; ++s) {
+      const int k = krow + 4 * s, kc = k < a.K ? k : a.K - 1;
+      sg_l[s] = a.sigma[kc];
+      mu_l[s] = a.mu[kc];
+    }
+    // ... and with them what the per-pair tail needs (kernel k's mu / sigma, the single Linear's weights): from LDS there instead of
+    // from global memory - thread 0's 11-term combine was four to five dependent memory round trips at the very end of every pair
+    if (tid < 16) {
+      const int kc = tid < a.K ? tid : a.K - 1;
+      // (the feature / gradient call has no combine layer: w1 and b1 are NULL there)
+      const float m = a.mu[kc], sg = a.sigma[kc], w = (a.out && a.hidden == 0) ? a.w1[kc] : 0.f, bb = a.out ? a.b1[0] : 0.f;
+      Clds[tid] = m;
+      Clds[16 + tid] = sg;
+      Clds[32 + tid] = w;
+      if (tid == 0) Clds[48] = bb;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int k = krow + 4 * s;
+      mu_s[s] = k < a.K ? mu_l[s] : 0.f;
+      c_s[s] = k < a.K ? (-0.5f * kLog2e) / (sg_l[s] * sg_l[s]) : 0.f;
+    }
   }
   if (tid < 48) Flds[tid] = 0.f;
 
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
       }
       float R = 0.f, Rmu = 0.f, Rsg = 0.f;
       if (kk < a.K) {
-        const float mk = a.mu[kk], sg = a.sigma[kk];
+        const float mk = Clds[kk], sg = Clds[16 + kk];
         const float ck = (-0.5f * kLog2e) / (sg * sg);
         const int no = n_one[q];
         const int nz = n_nonreal - no;
@@ -254,8 +274,8 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
       sc = a.b2[0];
       for (int j = 0; j < a.hidden; ++j) sc = __builtin_fmaf(a.w2[j], Hlds[j], sc);
     } else {
-      sc = a.b1[0];
-      for (int k = 0; k < a.K; ++k) sc = __builtin_fmaf(a.w1[k], Flds[k], sc);
+      sc = Clds[48];
+      for (int k = 0; k < a.K; ++k) sc = __builtin_fmaf(Clds[32 + k], Flds[k], sc);
     }
     if (a.scoretanh) sc = tanhf(sc);
     a.out[b] = sc;
@@ -274,7 +294,7 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, nullptr, nullptr, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 48 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 48 + 8 + 64 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
@@ -336,7 +356,7 @@ extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
              dfdsigma_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 64 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, 1, true, 4, true>), dim3(B), dim3(kThreads), smem, s, a)
