@@ -130,6 +130,11 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
     if (q < a.Q) {
       const int no = n_one[wave], nz = n_nonreal - no;
       int head = 0;
+      // (what the merge rounds and the gate need from global memory, requested together in front of them: the rounds used to load
+      // ffw_w[r] one by one - K dependent memory round trips per query term - and the gate its three operands after the last round)
+      const float ffw_l = (!a.feat && lane < K) ? a.ffw_w[lane] : 0.f;
+      const float gate_w0 = a.feat ? 0.f : a.gate_w[0], idf_q = a.feat ? 0.f : a.idf[(int64_t)ids.qrow * a.Q + q];
+      const bool q_pad = ids.q(q) == 0;
       float acc = a.feat ? 0.f : a.ffw_b[0];
       for (int r = 0; r < K; ++r) {
         float cand = -INFINITY;
@@ -144,13 +149,13 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
         if (a.feat) {
           if (lane == 0) a.feat[((int64_t)b * a.Q + q) * K + r] = best;
         } else {
-          acc = __builtin_fmaf(a.ffw_w[r], best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+          acc = __builtin_fmaf(__shfl(ffw_l, r, 64), best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
         }
       }
       if (lane == 0 && !a.feat) {
         zlds[q] = tanhf(acc);
-        float gl = a.gate_w[0] * a.idf[(int64_t)ids.qrow * a.Q + q];
-        if (ids.q(q) == 0) gl += -1e7f;   // DRMMTKS.py:38
+        float gl = gate_w0 * idf_q;
+        if (q_pad) gl += -1e7f;   // DRMMTKS.py:38
         glds[q] = gl;
       }
     }
