@@ -323,10 +323,13 @@ __global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmA
   // Only rows of real query terms are pooled (a pad term's row is all zero and masked at the end, ConvKNRM.py:72-73): with nq real
   // terms there are views * nq rows, each shared by as many threads as fit.
   int nq = 0, qreal[kCkMaxQ];
+  int64_t qid_l[kCkMaxQ];   // (the Q ids requested together - clamped index, unconditional: one memory round trip, not one per term)
+#pragma unroll
+  for (int q = 0; q < kCkMaxQ; ++q) qid_l[q] = qi[q < Q ? q : Q - 1];
 #pragma unroll
   for (int q = 0; q < kCkMaxQ; ++q) {
     qreal[q] = 0;
-    if (q < Q && qtok_early(qi, q, a.V) != 0) {
+    if (q < Q && !(qid_l[q] <= 0 || qid_l[q] >= a.V)) {
 #pragma unroll
       for (int j = 0; j < kCkMaxQ; ++j)
         if (j == nq) qreal[j] = q;
