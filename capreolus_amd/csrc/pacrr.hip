@@ -210,12 +210,21 @@ __device__ __forceinline__ void pacrr_insert(float (&top)[KM], float v) {
 // idf channel + the three linear layers (PACRR.py:48-55); feat = [Q][qts] in LDS
 __device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& ids, float* feat, float* h1, float* h2, int qts, int tid, int b) {
   if (a.use_idf && tid == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50)
-    const float* idf = a.idf + (int64_t)ids.qrow * a.Q;
+    const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
+    float idf[kPacrrMaxQ];   // (Q <= 8; requested together - clamped index - instead of one dependent load per use: three loops over Q by one thread)
+#pragma unroll
+    for (int q = 0; q < kPacrrMaxQ; ++q) idf[q] = idf_g[q < a.Q ? q : a.Q - 1];
     float m = idf[0];
-    for (int q = 1; q < a.Q; ++q) m = fmaxf(m, idf[q]);
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+      if (q < a.Q) m = fmaxf(m, idf[q]);
     float den = 0.f;
-    for (int q = 0; q < a.Q; ++q) den += expf(idf[q] - m);
-    for (int q = 0; q < a.Q; ++q) feat[q * qts + qts - 1] = expf(idf[q] - m) / den;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < a.Q) den += expf(idf[q] - m);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < a.Q) feat[q * qts + qts - 1] = expf(idf[q] - m) / den;
   }
   __syncthreads();
   const int nin = a.Q * qts;
