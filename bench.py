@@ -248,9 +248,6 @@ class InteractionLeg:
         self.launch_one = launch_one
         n_side = min(args.launch_streams, len(self.slices)) if len(self.slices) > 1 else 1
         self.side = [torch.cuda.Stream(device=dev) for _ in range(n_side)] if n_side > 1 else []
-        from capreolus_amd import _lib
-
-        _lib.load().capamd_set_concurrent_launches(1 if self.side else 0)
         # multi-GPU: the step's all-gather runs asynchronously on RCCL's stream from a snapshot of the scores, under the NEXT step's
         # scoring (two snapshots / destinations in rotation); every gather is waited for before its buffers are reused and before the
         # timed region closes
@@ -299,9 +296,12 @@ class InteractionLeg:
             main = torch.cuda.current_stream()
             for st in self.side:
                 st.wait_stream(main)
-            for k, (lo, hi) in enumerate(self.slices):
-                with torch.cuda.stream(self.side[k % len(self.side)]):
-                    self.launch_one(bi, lo, hi)
+            from capreolus_amd import engine
+
+            with engine.concurrent_launches():             # per-call flag: small launches share the chip, use the occupancy variant
+                for k, (lo, hi) in enumerate(self.slices):
+                    with torch.cuda.stream(self.side[k % len(self.side)]):
+                        self.launch_one(bi, lo, hi)
             for st in self.side:
                 main.wait_stream(st)
         else:
@@ -718,7 +718,7 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
         if use_dist:
             dist.all_gather_into_tensor(gathered, out[0])
 
-    lib = _lib.load()
+    lib = _lib.profiling()
     for i in range(warmup):
         step(i)
     serial = eng.n_streams == 1
@@ -730,7 +730,7 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
     scores = out[0].clone()
 
     # dominant kernel: the FFN1 GEMM (folded LayerNorm + bias + GELU epilogue), timed by the library's HIP events around each of its
-    # launches (capamd_debug_ffn1_timing, include/capreolus_amd.h) - during the timed steps when they run on one stream, otherwise in
+    # launches (capamd_debug_ffn1_timing, capreolus_amd/csrc/capamd_profiling.h) - during the timed steps when they run on one stream, otherwise in
     # one more step of the same batch run strictly serially (kernels of concurrent streams would stretch each other's durations)
     if not serial:
         eng.n_streams = 1

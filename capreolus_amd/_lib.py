@@ -16,9 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAPAMD_LIB_PATH") or os.path.join(_HERE, "csrc", "libcapreolus_amd.so")  # override: profiling builds only
 
 OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
+LAUNCH_CONCURRENT = 1
 STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV, STATUS_SCORE_NAN, STATUS_TIE_RANGE = 1, 2, 4, 8, 16
 
-_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_vp, _i, _i64, _sz, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint
 
 
 
@@ -36,12 +37,12 @@ _mp = ctypes.POINTER(BertModel)
 SIGNATURES = {
     "capamd_version": (_i, []),
     "capamd_arch": (ctypes.c_char_p, []),
-    "capamd_set_concurrent_launches": (_i, [_i]),
+    "capamd_interaction_workspace_bytes": (_sz, []),
     "capamd_packed_row_stride": (_i64, [_i]),
     "capamd_packed_table_bytes": (_i64, [_i64, _i]),
     "capamd_pack_embeddings": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),
     "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
-    "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u, _vp]),
     "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmmtks_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "capamd_pacrr_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -51,7 +52,8 @@ SIGNATURES = {
     "capamd_convknrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capamd_knrm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
-    "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u,
+                                         _vp]),
     "capamd_drmm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
@@ -68,10 +70,14 @@ SIGNATURES = {
     "capamd_bert_gemm_ln": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "capamd_rank_candidates": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "capamd_ndcg_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+}
+
+# builder-side profiling hooks (capreolus_amd/csrc/capamd_profiling.h): exported by the library, not declared in the public header
+PROFILING_SIGNATURES = {
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
     "capamd_debug_ffn1_timing": (None, [_i]),
     "capamd_debug_ffn1_timing_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 _lib = None
@@ -96,6 +102,15 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    return lib
+
+
+def profiling():
+    """The library with its profiling hooks bound (bench.py's roofline timing, scripts/ probes)."""
+    lib = load()
+    for name, (res, args) in PROFILING_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
     return lib
 
 

@@ -12,6 +12,7 @@
 #include "bert_gemm.cuh"
 #include "bert_gemm_ring.cuh"
 #include "capreolus_amd.h"
+#include "capamd_profiling.h"
 #include "cedr_tap.cuh"
 #include <stdlib.h>
 #include <utility>

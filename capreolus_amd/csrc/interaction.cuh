@@ -27,8 +27,6 @@
 
 namespace capamd {
 
-extern int g_concurrent_launches;  // capamd_set_concurrent_launches (defined in pack_simmat.hip)
-
 constexpr int kGroup = 16;        // lanes per doc term (one DPP row)
 constexpr int kThreads = 256;     // 4 waves per workgroup
 constexpr int kGroupsPerWG = kThreads / kGroup;

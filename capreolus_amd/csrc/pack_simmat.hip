@@ -5,10 +5,6 @@
 
 using namespace capamd;
 
-namespace capamd {
-int g_concurrent_launches = 0;   // capamd_set_concurrent_launches
-}
-
 namespace {
 
 // One 16-lane group per table row.  Writes the packed row and its den = |row|_2 + 1e-9f.
@@ -76,11 +72,7 @@ __global__ __launch_bounds__(kThreads) void simmat_kernel(const int64_t* __restr
 extern "C" {
 
 int capamd_version(void) { return CAPAMD_VERSION; }
-int capamd_set_concurrent_launches(int on) {
-  const int prev = capamd::g_concurrent_launches;
-  capamd::g_concurrent_launches = on ? 1 : 0;
-  return prev;
-}
+size_t capamd_interaction_workspace_bytes(void) { return 64; }
 const char* capamd_arch(void) { return "gfx950"; }
 
 int64_t capamd_packed_row_stride(int D) { return (D >= 1 && D <= 64 * kMaxNV - 1) ? row_stride_for_dim(D) : -1; }

@@ -9,6 +9,8 @@ import ctypes
 import math
 import os
 
+import threading
+
 import torch
 
 from . import _lib
@@ -101,17 +103,38 @@ def status_word(device):
     return _status_words[key]
 
 
+_launch_hint = threading.local()
+
+
 class concurrent_launches:
-    """Context: the caller keeps several scoring calls in flight on different streams (capamd_set_concurrent_launches), e.g.
-    one candidate list per launch round-robin over a few streams so that the tail of one list overlaps the next launch."""
+    """Context: the caller keeps several scoring calls in flight on different streams (the CAPAMD_LAUNCH_CONCURRENT flag of the
+    interaction entries), e.g. one candidate list per launch round-robin over a few streams so that the tail of one list overlaps
+    the next launch.  Per thread and nestable; the flag travels with each call, the library keeps no state."""
 
     def __enter__(self):
-        self.prev = _lib.load().capamd_set_concurrent_launches(1)
+        _launch_hint.depth = getattr(_launch_hint, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        _lib.load().capamd_set_concurrent_launches(self.prev)
+        _launch_hint.depth -= 1
         return False
+
+
+def _launch_flags():
+    return _lib.LAUNCH_CONCURRENT if getattr(_launch_hint, "depth", 0) else 0
+
+
+_workspaces = {}
+
+
+def _workspace(device):
+    """The few bytes of device memory an interaction call may use (capamd_interaction_workspace_bytes): one per (device, stream) -
+    calls on one stream run in order, calls on different streams must not share it."""
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = torch.zeros(max(16, int(_lib.load().capamd_interaction_workspace_bytes()) // 4), dtype=torch.int32, device=device)
+    return ws
 
 
 class PackedEmbedding:
@@ -168,10 +191,10 @@ def knrm_forward(query, doc, packed, V, D, mu, sigma, w1, b1, w2=None, b2=None, 
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=q.device)
     hidden = 0 if w2 is None else w1.shape[0]
-    st = status_word(q.device)
+    st, ws = status_word(q.device), _workspace(q.device)
     rc = _lib.load().capamd_knrm_forward(
         _ptr(q), _ptr(d), B, Q, L, _ptr(packed), V, D, _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), hidden,
-        _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _stream())
+        _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel() * 4, _launch_flags(), _stream())
     _lib.check(rc, "capamd_knrm_forward")
     if check:
         st.raise_if_set()
@@ -422,10 +445,10 @@ def knrm_forward_indexed(q_table, d_table, pair_q, pair_d, packed, V, D, mu, sig
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=pq.device)
     hidden = 0 if w2 is None else w1.shape[0]
-    st = status_word(pq.device)
+    st, ws = status_word(pq.device), _workspace(pq.device)
     rc = _lib.load().capamd_knrm_forward_indexed(
         _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), B, Q, L, _ptr(packed), V, D, _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1),
-        hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _stream())
+        hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel() * 4, _launch_flags(), _stream())
     _lib.check(rc, "capamd_knrm_forward_indexed")
     if check:
         st.raise_if_set()

@@ -88,6 +88,7 @@ class ConvKNRM(Reranker):
     (reference ConvKNRM.py:81-97)."""
 
     module_name = "ConvKNRM"
+    supports_resident = True   # term-id rows: served from a device-resident CandidateStore (Reranker.test_resident)
     config_spec = {"gradkernels": True, "maxngram": 3, "crossmatch": True, "filters": 128, "scoretanh": False, "singlefc": True}
 
     def build_model(self):

@@ -91,6 +91,7 @@ class DRMM(Reranker):
     """Guo et al., A Deep Relevance Matching Model for Ad-hoc Retrieval, CIKM'16 (reference DRMM.py:119-133)."""
 
     module_name = "DRMM"
+    supports_resident = True   # term-id rows: served from a device-resident CandidateStore (Reranker.test_resident)
     config_spec = {"nbins": 29, "nodes": 5, "histType": "LCH", "gateType": "IDF"}
 
     def build_model(self):

@@ -59,6 +59,7 @@ class DRMMTKS(Reranker):
     """Guo et al., CIKM'16, MatchZoo's top-k variant (reference DRMMTKS.py:68-80)."""
 
     module_name = "DRMMTKS"
+    supports_resident = True   # term-id rows: served from a device-resident CandidateStore (Reranker.test_resident)
     config_spec = {"topk": 10, "gateType": "IDF", "freezeemb": True}
 
     def build_model(self):

@@ -101,6 +101,7 @@ class KNRM(Reranker):
     """Xiong et al., End-to-End Neural Ad-hoc Ranking with Kernel Pooling, SIGIR'17 (reference KNRM.py:58-69)."""
 
     module_name = "KNRM"
+    supports_resident = True   # term-id rows: served from a device-resident CandidateStore (Reranker.test_resident)
     config_spec = {"gradkernels": True, "scoretanh": False, "singlefc": True, "finetune": False}
 
     def build_model(self):

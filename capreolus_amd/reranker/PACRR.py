@@ -80,6 +80,7 @@ class PACRR(Reranker):
     (reference PACRR.py:81-98)."""
 
     module_name = "PACRR"
+    supports_resident = True   # term-id rows: served from a device-resident CandidateStore (Reranker.test_resident)
     config_spec = {"mingram": 1, "maxgram": 3, "nfilters": 32, "idf": True, "kmax": 2, "combine": 32, "nonlinearity": "relu"}
 
     def build_model(self):

@@ -27,6 +27,13 @@ class Reranker:
         self.extractor = extractor
         self.trainer = trainer
 
+    # `supports_resident`: `test_resident` is meaningful (an interaction model over term-id rows; the BERT rerankers' inputs are
+    # per (query, passage)).  `batch_coupled`: a pair's score depends on what else is in the batch (never true for the interaction
+    # models; ptBERTMaxP with aggregation = avg, reference ptBERTMaxP.py:92) - `PytorchTrainer.predict` then keeps the DataLoader's
+    # batches as they are.
+    supports_resident = False
+    batch_coupled = False
+
     def build_model(self):
         raise NotImplementedError
 

@@ -171,6 +171,12 @@ class PTBERTMaxP(Reranker):
     config_spec = {"pretrained": "bert-base-uncased", "aggregation": "max", "hidden_dropout_prob": 0.1, "microbatch": 256,
                    "compute_dtype": "fp16", "skip_padding": True}
 
+    @property
+    def batch_coupled(self):
+        """aggregation = avg divides every document's passage sum by the BATCH-wide passage count (reference ptBERTMaxP.py:92): the
+        scores depend on the batch composition, so `PytorchTrainer.predict` must not merge DataLoader batches for it."""
+        return self.config["aggregation"] == "avg"
+
     def build_model(self):
         self.model = PTBERTMaxP_Class(self.extractor, self.config)
         return self.model

@@ -89,8 +89,16 @@ class PytorchTrainer:
         "decay": 0.0, "decayiters": 3, "decaytype": None, "amp": None, "seed": 123,
         # this engine's own: `predict` hands the scorer one batch per `coalesce` pairs instead of one per DataLoader batch (the
         # reference default evalbatch = batch = 32 would be 32-workgroup launches on a 256-CU chip); 0 = one call per DataLoader
-        # batch with the reference's fill-by-repetition of the last one.  The scores do not depend on it (pairs are independent).
-        "coalesce": 16384,
+        # batch with the reference's fill-by-repetition of the last one.  Pairs are scored independently, so the scores do not depend
+        # on it - except for rerankers that say `batch_coupled` (ptBERTMaxP aggregation = avg divides by a batch-wide count,
+        # ptBERTMaxP.py:92): those are never coalesced.  A merged batch is also capped at `coalesce_bytes` of input tensors.
+        "coalesce": 16384, "coalesce_bytes": 256 << 20,
+        # `resident` (default on): a sampler with the PredSampler contract scored by a reranker that can read a device-resident
+        # candidate store is tokenised ONCE - the first `predict` of a sampler walks it like the DataLoader would and uploads the
+        # distinct query / document id rows as int32 tables (capreolus_amd.feeder.CandidateStore); that call and every later one on the
+        # same sampler (the dev set after every training iteration, RerankTask's repeated predict) score it by index pairs without
+        # touching the host per sample (SURVEY.md row N1 through the reference's own call site, trainer/pytorch.py:310-353).
+        "resident": True,
     }
     # amp = "pred" / "both" at prediction time (reference :323-326, 343: autocast around `reranker.test`) selects nothing here: the
     # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
@@ -135,16 +143,16 @@ class PytorchTrainer:
         return (self.config["itersize"] // self.config["batch"]) or 1     # reference trainer/__init__.py:74-76
 
     def lr_multiplier(self, step):
-        """Warm-up, then exponential / linear decay per optimisation step (reference trainer/__init__.py:98-109)."""
-        c = self.config
-        warmup_steps = c["warmupiters"] * self.n_batch_per_iter
-        if warmup_steps and step <= warmup_steps:
-            return min((step + 1) / warmup_steps, 1)
-        if c["decaytype"] == "exponential":
-            return c["decay"] ** ((step - warmup_steps) / (c["decayiters"] * self.n_batch_per_iter))
-        if c["decaytype"] == "linear":
-            return 1 / (1 + c["decay"] * ((step - warmup_steps) / self.n_batch_per_iter))
-        return 1
+        """Learning-rate factor of optimisation step `step`: linear ramp over the warm-up steps, then the configured decay measured
+        in iterations since the end of the warm-up (same schedule as the reference's LambdaLR, trainer/__init__.py:98-109)."""
+        c, per_iter = self.config, self.n_batch_per_iter
+        ramp = c["warmupiters"] * per_iter
+        if ramp > 0 and step <= ramp:
+            return min(1, (step + 1) / ramp)
+        iters_after = (step - ramp) / per_iter
+        decay = {"exponential": lambda: c["decay"] ** (iters_after / c["decayiters"]),
+                 "linear": lambda: 1 / (1 + c["decay"] * iters_after)}.get(c["decaytype"])
+        return decay() if decay else 1
 
     def _set_lr(self, step):
         # what `LambdaLR.step(epoch=step)` leaves behind in the reference (:118-120): lr = base lr x multiplier(step)
@@ -202,18 +210,14 @@ class PytorchTrainer:
 
     @staticmethod
     def load_loss_file(fn):
-        """reference trainer/__init__.py:22-48: `<iteration> <loss>` lines, iterations consecutive from 0."""
-        loss = []
+        """The per-iteration mean losses of `info/loss.txt` (one `<iteration> <loss>` record per line, iteration numbers 0, 1, 2, ...
+        - the layout the reference writes, trainer/__init__.py:22-48).  A gap or repeat in the numbering means two runs wrote to the
+        same directory: IOError."""
         with open(fn, "rt") as f:
-            for lineidx, line in enumerate(f):
-                line = line.strip()
-                if not line:
-                    continue
-                iteridx, iterloss = line.rstrip().split()
-                if int(iteridx) != lineidx:
-                    raise IOError(f"malformed loss file {fn} ... did two processes write to it?")
-                loss.append(float(iterloss))
-        return loss
+            records = [ln.split() for ln in f if ln.strip()]
+        if [int(r[0]) for r in records] != list(range(len(records))):
+            raise IOError(f"{fn}: iteration numbers are not 0..{len(records) - 1} in order (two writers?)")
+        return [float(r[1]) for r in records]
 
     def fastforward_training(self, reranker, weights_path, loss_fn, metric_fn):
         """Resume from the last iteration whose weights were saved (reference :76-122 of trainer/pytorch.py `fastforward_training`):
@@ -307,6 +311,66 @@ class PytorchTrainer:
 
         return {k: pad(v) for k, v in batch.items()}
 
+    # ---- the resident route of `predict` ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _sampler_fingerprint(pred_data):
+        """What identifies a prediction sampler's content cheaply: per query its id, the number of candidates and the first / last
+        docid (None for samplers without `qid_to_docids`, which take the DataLoader route)."""
+        q2d = getattr(pred_data, "qid_to_docids", None)
+        if not isinstance(q2d, dict) or not q2d:
+            return None
+        try:
+            return (len(q2d), hash(tuple((q, len(d), d[0], d[-1]) if len(d) else (q, 0) for q, d in q2d.items())))
+        except TypeError:
+            return None
+
+    def _resident_plan(self, pred_data, part, rank, world):
+        """(store, pair_q, pair_d, groups) for this rank's part of `pred_data`, built on the first call for a sampler and kept for
+        the next ones; None when the samples are not interaction-model id rows or a docid's row depends on the query it comes with."""
+        from ..feeder import CandidateStore
+
+        fp = self._sampler_fingerprint(pred_data)
+        if fp is None:
+            return None
+        plans = self.__dict__.setdefault("_resident_plans", {})
+        key = (id(pred_data), rank, world, str(self.device))
+        hit = plans.get(key)
+        if hit is not None and hit[0] == fp and hit[1]() is pred_data:
+            return hit[2]
+        store, pq, pd, groups = CandidateStore(self.device), [], [], []
+        for sample in part:           # the same walk the DataLoader would do - once
+            if not all(k in sample for k in ("qid", "posdocid", "query", "posdoc")):
+                return None
+            qid, docid = sample["qid"], sample["posdocid"]
+            qrow = store.qrow.get(qid)
+            if qrow is None:
+                qrow = store.add_query(qid, sample["query"], sample.get("query_idf"))
+            drow = store.drow.get(docid)
+            if drow is None:
+                drow = store.add_doc(docid, sample["posdoc"])
+            elif not np.array_equal(store._d[drow], np.asarray(sample["posdoc"])):
+                return None       # this extractor's document row depends on the query: not a candidate-store sampler
+            if not groups or groups[-1][0] != qid:
+                groups.append([qid, [], len(pq)])
+            groups[-1][1].append(docid)
+            pq.append(qrow)
+            pd.append(drow)
+        if not pq:
+            return None
+        store.finalize()
+        import weakref
+
+        plan = (store, torch.as_tensor(np.asarray(pq, dtype=np.int32)).to(self.device), torch.as_tensor(np.asarray(pd, dtype=np.int32)).to(self.device),
+                [(q, ds, lo) for q, ds, lo in groups])
+        try:
+            ref = weakref.ref(pred_data)
+        except TypeError:
+            ref = (lambda obj: (lambda: obj))(pred_data)
+        while len(plans) >= 4:          # a dev set and a test set per rank; old samplers' tables are dropped
+            plans.pop(next(iter(plans)))
+        plans[key] = (fp, ref, plan)
+        return plan
+
     def predict_resident(self, reranker, store, qid_to_docids, pred_fn=None):
         """`predict` over a device-resident `capreolus_amd.feeder.CandidateStore`: no DataLoader,
         no per-batch host->device copy; one kernel launch per `evalbatch` pairs (0 -> the whole run in one launch)."""
@@ -393,14 +457,35 @@ class PytorchTrainer:
         evalbatch = self.config["evalbatch"] if self.config["evalbatch"] > 0 else self.config["batch"]
         workers = 1 if self.config["multithread"] else 0
         keys, chunks = [], []
-        if count > 0:
+        plan = None
+        if count > 0 and self.config["resident"] and self.device.type == "cuda" and getattr(reranker, "supports_resident", False):
+            plan = self._resident_plan(pred_data, part, rank, world)
+        if plan is not None:
+            store, pq, pd, groups = plan
+            step = max(evalbatch, self.config["coalesce"])
+            with torch.no_grad():
+                chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, pq.numel(), step)]
+            if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
+                vals = torch.cat(chunks).cpu().numpy().astype(np.float16).tolist()      # (trainer/pytorch.py:346-348)
+                if len(vals) != count:
+                    raise RuntimeError(f"rank {rank} scored {len(vals)} pairs, expected {count}")
+                preds = {}
+                for qid, docids, lo in groups:
+                    preds.setdefault(qid, {}).update(zip(docids, vals[lo:lo + len(docids)]))
+                if pred_fn is not None:
+                    os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
+                    write_trec_run(preds, pred_fn)
+                return preds
+            keys = [(q, d) for q, ds, _ in groups for d in ds]
+        elif count > 0:
             # (no pin_memory, unlike trainer/pytorch.py:335: on ROCm the loader's pinning thread allocates a fresh pinned block for every
             # batch of more than ~1 MB - measured 1.29 s against 0.08 s per 20,000 samples at evalbatch 256, scripts/dbg/pin_probe.py - and
             # at the default 32 the pageable copy is faster too, 0.098 against 0.124 s)
             loader = torch.utils.data.DataLoader(part, batch_size=evalbatch, pin_memory=False,
                                                  num_workers=workers)
-            coalesce = self.config["coalesce"]
+            coalesce = 0 if getattr(reranker, "batch_coupled", False) else self.config["coalesce"]
             pending, n_pending = [], 0
+            byte_cap = [None]       # pairs per merged batch allowed by `coalesce_bytes`, known after the first batch
 
             def score(batch, n):
                 dbatch = {k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in batch.items()}
@@ -425,9 +510,12 @@ class PytorchTrainer:
                 for batch in loader:
                     n = len(batch["qid"])
                     if coalesce > 0:
+                        if byte_cap[0] is None:
+                            per_pair = sum(v.numel() * v.element_size() for v in batch.values() if torch.is_tensor(v)) / max(n, 1)
+                            byte_cap[0] = max(evalbatch, int(self.config["coalesce_bytes"] // max(per_pair, 1)))
                         pending.append(batch)
                         n_pending += n
-                        if n_pending >= coalesce:
+                        if n_pending >= min(coalesce, byte_cap[0]):
                             flush()
                             n_pending = 0
                         continue

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAPAMD_VERSION 200
+#define CAPAMD_VERSION 300
 
 #define CAPAMD_OK 0
 #define CAPAMD_ERR_ARG 1       /* null pointer / bad size / unsupported configuration */
@@ -48,11 +48,18 @@ extern "C" {
 int capamd_version(void);
 const char* capamd_arch(void); /* "gfx950" */
 
-/* Launch hint (process-wide; returns the previous value).  on = 1: the caller keeps several scoring calls in flight on different
- * streams (one candidate list per launch, the reference's PytorchTrainer.predict loop at small evalbatch, trainer/pytorch.py:334-348),
- * so a small launch no longer has the chip to itself: the interaction kernels then use their occupancy-oriented variant at every
- * batch size instead of the latency-oriented one they pick for a lone launch of <= 1536 pairs.  Scores are bit-identical either way. */
-int capamd_set_concurrent_launches(int on);
+/* Per-call launch flags of the interaction scoring entries (`flags` argument; no process-wide state).
+ * CAPAMD_LAUNCH_CONCURRENT: the caller keeps several scoring calls in flight on different streams (one candidate list per launch,
+ * the reference's PytorchTrainer.predict loop at small evalbatch, trainer/pytorch.py:334-348), so a small launch no longer has the
+ * chip to itself: the kernels then use their occupancy-oriented variant at every batch size instead of the latency-oriented one
+ * they pick for a lone launch of <= 1536 pairs.  Scores are bit-identical either way. */
+#define CAPAMD_LAUNCH_CONCURRENT 1u
+
+/* Workspace of the interaction scoring entries (`workspace`, `workspace_bytes`): a few bytes of device memory the caller owns (any
+ * contents; 4-byte aligned; one per call in flight).  Launches that outnumber the workgroups the chip holds run persistent
+ * workgroups that draw their pairs from a ticket counter kept there (zeroed by the call, on `stream`).  NULL / too small: allowed,
+ * every launch then runs one workgroup per pair.  Scores do not depend on it beyond the last bits of fp32 rounding. */
+size_t capamd_interaction_workspace_bytes(void);
 
 /* ---- embedding table ------------------------------------------------------------------------
  * Replaces create_emb_layer + nn.Embedding lookup (capreolus/reranker/common.py:279-288, :161).
@@ -74,11 +81,11 @@ int capamd_similarity_matrix(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_id
  * combine (KNRM.py:27-34): hidden == 0 -> score = w1[0,:K]·f + b1[0]            ("singlefc")
  *                          hidden  > 0 -> score = w2[0,:hidden]·tanh(w1·f + b1) + b2[0]
  *                          scoretanh != 0 applies a final tanh.
- * out fp32 [B].  No workspace. */
+ * out fp32 [B].  workspace / flags: see CAPAMD_LAUNCH_* and capamd_interaction_workspace_bytes above. */
 int capamd_knrm_forward(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_ids /*[B,L]*/, int B, int Q, int L,
                         const float* packed, int64_t V, int D, const float* mu, const float* sigma, int K,
                         const float* w1, const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
-                        float* out, int* status, void* stream);
+                        float* out, int* status, void* workspace, size_t workspace_bytes, unsigned flags, void* stream);
 
 /* Forward half of the training step (reference trainer/pytorch.py:96-99 -> KNRM.score):
  * the kernel-pooling features f[b][k] = sum_q mask_q log(sum_j K_k(sim_qj) + 1e-6) (KNRM.py:50-53) that feed `combine`,
@@ -96,7 +103,8 @@ int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int 
 int capamd_knrm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
                                 const int32_t* pair_d, int B, int Q, int L, const float* packed, int64_t V, int D,
                                 const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden,
-                                const float* w2, const float* b2, int scoretanh, float* out, int* status, void* stream);
+                                const float* w2, const float* b2, int scoretanh, float* out, int* status, void* workspace,
+                                size_t workspace_bytes, unsigned flags, void* stream);
 
 /* ---- DRMM_class.forward (capreolus/reranker/DRMM.py:101-116) behind DRMM.test (DRMM.py:150-155)
  * idf fp32 [B,Q]; edges fp32 [nbins] = torch.linspace(-1,1,nbins+1)[1:] (DRMM.py:63);
@@ -308,17 +316,6 @@ int capamd_rank_candidates(const float* scores, const int64_t* offsets, int n_qu
                            int32_t* out_idx, uint16_t* out_f16, int* status, void* stream);
 int capamd_ndcg_cut(const float* scores, const int64_t* offsets, const int32_t* rel, const int32_t* tie, const double* idcg,
                     int n_queries, int max_candidates, int k, double* out, int* status, void* stream);
-
-/* ---- profiling hooks (off by default; not part of the scoring interface) -----------------------------------
- * capamd_debug_set_gemm_stamps: when non-NULL, capamd_bert_gemm blocks write up to 32 s_memtime stamps each into
- * stamps[block][32] (uint64, device memory).  Pass NULL to switch it off.
- * capamd_debug_ffn1_timing (used by bench.py's `roofline` object): while enabled, capamd_bert_maxp_forward brackets
- * every launch of its dominant kernel (the FFN1 GEMM, bias + GELU) with HIP events on the caller's stream;
- * capamd_debug_ffn1_timing_read synchronises those events, returns the summed duration in milliseconds, the number of
- * launches and the summed GEMM rows since the last read, and clears the list. */
-void capamd_debug_set_gemm_stamps(void* stamps);
-void capamd_debug_ffn1_timing(int enable);
-int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows);
 
 #ifdef __cplusplus
 }
