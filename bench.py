@@ -172,6 +172,28 @@ def timed_loop(ctx, step, warmup, steps, drain=None):
     return elapsed, ev0.elapsed_time(ev1) * 1e-3 / steps
 
 
+def collective_info(ctx, floats_per_rank):
+    """What the N > 1 line says about its one collective: the backend and the number of ranks the process group really has (so that a
+    SCALE record proves N ranks took part), the bytes one step gathers, and the duration of that all_gather on its own (10 blocking
+    repetitions after a fence; inside the timed steps it runs asynchronously under the next step's scoring)."""
+    if not ctx.use_dist:
+        return None
+    dist, dev = ctx.dist, ctx.dev
+    world = dist.get_world_size()
+    src = torch.zeros(floats_per_rank, dtype=torch.float32, device=dev)
+    dst = torch.empty(floats_per_rank * world, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        dist.all_gather_into_tensor(dst, src)
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dist.all_gather_into_tensor(dst, src)
+    torch.cuda.synchronize()
+    ms = ctx.max_over_ranks(time.perf_counter() - t0) * 100.0
+    return {"backend": dist.get_backend(), "rccl_ranks": world, "collective": "all_gather_into_tensor (fp32 scores)", "gathered_bytes_per_step": floats_per_rank * world * 4,
+            "gather_ms": ms}
+
+
 _tables = {}
 
 
@@ -361,7 +383,8 @@ class InteractionLeg:
         want = run()
         got = self.out[:n].cpu().numpy()
         err = float(np.abs(got - want).max() / max(1e-6, np.abs(want).max()))
-        assert err <= 2e-5, f"{self.model}: the timed scores differ from the oracle's by {err}"
+        # (CAPAMD_BENCH_NO_CHECK: ablation builds of the library, scripts/build_variant_obj.sh - their scores are wrong on purpose)
+        assert err <= 2e-5 or os.environ.get("CAPAMD_BENCH_NO_CHECK"), f"{self.model}: the timed scores differ from the oracle's by {err}"
         return run, (q, d, idf, emb_h, sd), err
 
 
@@ -487,6 +510,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         "roofline": roof if roof is not None else {"bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": None, "peak": HBM_PEAK_GBS,
                                                    "unit": "GB/s", "frac": None, "traffic": None, "headline_leg": headline},
     }
+    if ctx.use_dist:
+        rec["collective"] = collective_info(ctx, n_pairs)
     if with_cpu and world == 1:
         rec["cpu_baseline"] = cpu_baseline(args, model, leg.check_against_oracle, leg)
     return rec
@@ -520,8 +545,12 @@ def main():
             short = max(5, min(args.steps, 10))
             torch.cuda.empty_cache()
             rec["also"] = []
+            # ... and the row-N4 siblings (short legs: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)
             for leg in (lambda: interaction_record(args, ctx, "drmm", short, 2, 64, with_cpu=not args.no_cpu_baseline),
-                        lambda: bench_bert(args, ctx, 5, 2, with_cpu=not args.no_cpu_baseline)):
+                        lambda: bench_bert(args, ctx, 5, 2, with_cpu=not args.no_cpu_baseline),
+                        lambda: bench_sibling(args, ctx, "drmmtks", 5, 2, with_cpu=False),
+                        lambda: bench_sibling(args, ctx, "pacrr", 5, 2, with_cpu=False),
+                        lambda: bench_sibling(args, ctx, "convknrm", 5, 2, with_cpu=False)):
                 try:
                     rec["also"].append(leg())
                 except Exception as e:  # noqa: BLE001  a failing secondary leg must not take the headline line with it
@@ -533,27 +562,27 @@ def main():
         emit(rec)
 
 
-def bench_sibling(args, ctx):
-    """Row N4 models on the KNRM benchmark's candidate lists: DRMM-TKS, PACRR (KNRM's gather; same algorithmic bytes) and
-    ConvKNRM (per position 6 projection-table parts of `filters` floats instead of one embedding row)."""
+def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
+    """One timed leg of a row-N4 model on candidate lists of the KNRM benchmark's shape: (reranker module, batch, last scores, wall
+    seconds, per-step device seconds, bytes of one gathered row, mean non-pad terms per document)."""
     from types import SimpleNamespace
 
     from capreolus_amd import engine, synthetic
     from capreolus_amd.reranker import DRMMTKS, PACRR, ConvKNRM
 
-    world, rank, dev, use_dist, dist = ctx.world, ctx.rank, ctx.dev, ctx.use_dist, ctx.dist
-    Q, L, V, D = 4, 800, args.vocab, args.dim
+    world, dev, use_dist, dist = ctx.world, ctx.dev, ctx.use_dist, ctx.dist
+    Q, L, D = 4, 800, args.dim
     n_queries = args.queries or 64
     n_pairs = n_queries * args.docs
     emb = table(dev, V, D)
-    batch = synthetic.make_candidate_list_torch(n_queries, args.docs, V, dev, seed=1 + rank, maxqlen=Q, maxdoclen=L, uniform_ids=args.uniform_ids)
-    if args.model == "convknrm":      # nn.Embedding ids only (the slowembedtext extractor has no negative OOV ids)
+    batch = synthetic.make_candidate_list_torch(n_queries, args.docs, V, dev, seed=seed, maxqlen=Q, maxdoclen=L, uniform_ids=uniform)
+    if model == "convknrm":      # nn.Embedding ids only (the slowembedtext extractor has no negative OOV ids)
         batch = {k: (v.abs() if v.dtype == torch.int64 else v) for k, v in batch.items()}
     torch.manual_seed(0)
     stub = SimpleNamespace(embeddings=np.zeros((2, D), dtype=np.float32), config={"maxqlen": Q}, pad=0)
-    rr = {"drmmtks": DRMMTKS, "pacrr": PACRR, "convknrm": ConvKNRM}[args.model]({}, stub)
+    rr = {"drmmtks": DRMMTKS, "pacrr": PACRR, "convknrm": ConvKNRM}[model]({}, stub)
     m = rr.build_model().to(dev).eval()
-    name = "embeddings" if args.model == "convknrm" else "embedding"
+    name = "embeddings" if model == "convknrm" else "embedding"
     setattr(m, name, torch.nn.Embedding.from_pretrained(emb, freeze=True))
     q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
     gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if use_dist else None
@@ -569,74 +598,111 @@ def bench_sibling(args, ctx):
         m(d_all[:8], q_all[:8], idf_all[:8])          # packs the tables and checks the status word once, synchronously
     status = engine.deferred_status(dev)              # the timed calls are queued back to back like the KNRM / DRMM launches
     status.__enter__()                                # (check=False there); the accumulated status bits are raised at the end
-    elapsed, kern_s = timed_loop(ctx, step, args.warmup, args.steps)   # one scoring call = the model's kernel + a few tiny torch ops of the mirror
+    elapsed, kern_s = timed_loop(ctx, step, warmup, steps)   # one scoring call = the model's kernel + a few tiny torch ops of the mirror
     assert os.environ.get("CAPAMD_BENCH_NOCHECK") == "1" or torch.isfinite(out[0]).all()   # (the knob: profiling builds that drop a phase of the kernel)
     status.__exit__(None, None, None)
     nonpad = float((d_all > 0).sum().item()) / n_pairs
-    if args.model == "convknrm":
+    if model == "convknrm":
         G, F = m.p["maxngram"], m.p["filters"]
         row = G * (G + 1) // 2 * F * 4
+    else:
+        row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
+    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad
+
+
+def sibling_oracle(model, m, D, q, d, idf, emb_h):
+    """The C oracle's scorer of a row-N4 model on host arrays (checker of the timed scores and the `cpu_baseline` port)."""
+    from oracle import cpu as oracle
+
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
+    if model == "drmmtks":
+        packed = oracle.pack(emb_h)
+        return lambda: oracle.drmmtks(q, d, idf, packed, D, m.topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"],
+                                      sd["output_layer.weight"], sd["output_layer.bias"])
+    if model == "pacrr":
+        packed = oracle.pack(emb_h)
+        p = m.p
+        n_ng = p["maxgram"] - p["mingram"] + 1
+        return lambda: oracle.pacrr(q, d, idf, packed, D, p["mingram"], p["maxgram"], p["nfilters"], p["kmax"],
+                                    [sd[f"ngrams.{i}.conv.weight"] for i in range(n_ng)], [sd[f"ngrams.{i}.conv.bias"] for i in range(n_ng)], p["idf"],
+                                    sd["linear1.weight"], sd["linear1.bias"], sd["linear2.weight"], sd["linear2.bias"], sd["linear3.weight"],
+                                    sd["linear3.bias"], p["nonlinearity"])
+    p = m.p
+    mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+    return lambda: oracle.convknrm(q, d, emb_h, [sd[f"convs.{i}.0.weight"] for i in range(p["maxngram"])],
+                                   [sd[f"convs.{i}.0.bias"] for i in range(p["maxngram"])], p["crossmatch"], mu, sigma, sd["combine.0.weight"],
+                                   sd["combine.0.bias"])
+
+
+def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None, check_pairs=256):
+    """Row N4 models on the KNRM benchmark's candidate lists: DRMM-TKS, PACRR (KNRM's gather; same algorithmic bytes) and
+    ConvKNRM (per position 6 projection-table parts of `filters` floats instead of one embedding row).  The timed
+    scores of the first `check_pairs` pairs are checked against the C oracle in every run; `roofline.frac` comes from a second leg
+    on uniform ids over the `--roofline-vocab` table (where HBM binds), like the KNRM / DRMM lines."""
+    model = model or args.model
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    with_cpu = (not args.no_cpu_baseline) if with_cpu is None else with_cpu
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
+    Q, L, V, D = 4, 800, args.vocab, args.dim
+    n_queries = args.queries or 64
+    n_pairs = n_queries * args.docs
+    rr, m, batch, scores, elapsed, kern_s, row, nonpad = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
+    q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
+    emb = table(dev, V, D)
+    if model == "convknrm":
         abytes = L * (8 + row) + Q * (8 + row) + 4
         kname = "convknrm_forward_kernel<2>"
     else:
-        row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
         abytes = algorithmic_bytes_per_pair("knrm", Q, L, D) + 4 * Q
-        kname = {"drmmtks": "drmmtks_forward_kernel<5, 12>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[args.model]
+        kname = {"drmmtks": "drmmtks_forward_kernel<5, 12>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[model]
     requested = n_pairs * (L * 8 + Q * 8 + (nonpad + Q) * row + 4) / kern_s / 1e9
     if rank != 0:
         return None
+    # the timed scores are the oracle's (a bounded sample; oracle/ is the checker here, never the thing measured)
+    emb_h = emb.cpu().numpy() if V <= 400001 else None
+    oracle_err = None
+    if emb_h is not None and os.environ.get("CAPAMD_BENCH_NOCHECK") != "1":
+        nchk = min(check_pairs, n_pairs)
+        want, err = sibling_oracle(model, m, D, *(t[:nchk].cpu().numpy() for t in (q_all, d_all, idf_all)), emb_h)()
+        assert err == 0
+        oracle_err = float(np.abs(scores[:nchk].cpu().numpy() - want).max() / max(1.0, np.abs(want).max()))
+        assert oracle_err <= 1e-3, f"{model}: the timed scores differ from the oracle's by {oracle_err}"
+    hbm = None
+    if not args.no_roofline_leg and world == 1 and not args.uniform_ids and args.roofline_vocab > V:
+        del batch, scores
+        big = sibling_leg(args, Ctx1(ctx), model, args.roofline_vocab, True, max(3, min(steps, 5)), 1, 77)
+        b_s, b_row, b_nonpad = big[5], big[6], big[7]
+        ach = n_pairs * (L * 8 + Q * 8 + (b_nonpad + Q) * b_row + 4) / b_s / 1e9
+        hbm = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel_ms": b_s * 1e3, "mean_nonpad_terms_per_doc": b_nonpad,
+               "leg": f"uniform term ids over a {args.roofline_vocab}-row table ({args.roofline_vocab * b_row / 1e9:.1f} GB of gathered rows), "
+                      f"{n_queries} x {args.docs} pairs per launch: HBM is the binding resource"}
+        del big
+        _tables.pop((dev.index, args.roofline_vocab, D), None)
+        torch.cuda.empty_cache()
     rec = {
-        "metric": "query-doc pairs scored/sec", "value": n_pairs * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "metric": "query-doc pairs scored/sec", "value": n_pairs * world * steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{rr.module_name} inference (SURVEY.md §8f row N4) on the KNRM benchmark's lists: qlen={Q} dlen={L} embed={D} vocab={V}, "
                                f"{args.docs} docs/query x {n_queries} queries per step per GPU, {'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, "
                                "reference default model options",
                    "pairs_per_step_per_gpu": n_pairs, "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU"},
-        # an HBM fraction only where HBM binds (uniform ids: --uniform-ids --vocab 4000001); on Zipf ids the rate is a cache-level rate
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": requested if args.uniform_ids else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": requested / HBM_PEAK_GBS if args.uniform_ids else None, "traffic": None, "kernel_ms": kern_s * 1e3, "pairs_per_launch": n_pairs,
+        # `frac`: the HBM-bound leg (uniform ids over the --roofline-vocab table); on the Zipf ids of the headline leg the rate is a cache-level rate
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": hbm["achieved"] if hbm else (requested if args.uniform_ids else None), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": hbm["frac"] if hbm else (requested / HBM_PEAK_GBS if args.uniform_ids else None), "traffic": None,
+                     "hbm_leg": hbm, "kernel_ms": kern_s * 1e3, "pairs_per_launch": n_pairs,
                      "requested_GBps": requested, "algorithmic_bytes_per_pair": abytes, "algorithmic_GBps": n_pairs * abytes / kern_s / 1e9,
                      "mean_nonpad_terms_per_doc": nonpad,
                      "note": "requested = int64 ids + one gathered row per in-vocabulary term / device time of one scoring call (one HIP event pair "
                              "around the timed steps); algorithmic = all L positions (pads are scored in closed form without a gather)"},
+        "oracle_check": {"pairs": min(check_pairs, n_pairs), "max_err_of_scale": oracle_err},
     }
-    if not args.no_cpu_baseline and world == 1:
-        from oracle import cpu as oracle   # the CPU leg only
-
+    if with_cpu and world == 1 and emb_h is not None:
         cores = os.cpu_count() or 1
-        n = args.cpu_pairs or (2000 if args.model == "convknrm" else min(n_pairs, 2000 * max(1, cores // 4)))
-        q, d, idf = (t[:n].cpu().numpy() for t in (q_all, d_all, idf_all))
-        emb_h = emb.cpu().numpy()
-        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if "embedding" not in k}
-        if args.model == "drmmtks":
-            packed = oracle.pack(emb_h)
-
-            def run():
-                return oracle.drmmtks(q, d, idf, packed, D, m.topk, sd["gates.weight"], sd["ffw.0.weight"], sd["ffw.0.bias"],
-                                      sd["output_layer.weight"], sd["output_layer.bias"])
-        elif args.model == "pacrr":
-            packed = oracle.pack(emb_h)
-            p = m.p
-            n_ng = p["maxgram"] - p["mingram"] + 1
-
-            def run():
-                return oracle.pacrr(q, d, idf, packed, D, p["mingram"], p["maxgram"], p["nfilters"], p["kmax"],
-                                    [sd[f"ngrams.{i}.conv.weight"] for i in range(n_ng)], [sd[f"ngrams.{i}.conv.bias"] for i in range(n_ng)], p["idf"],
-                                    sd["linear1.weight"], sd["linear1.bias"], sd["linear2.weight"], sd["linear2.bias"], sd["linear3.weight"],
-                                    sd["linear3.bias"], p["nonlinearity"])
-        else:
-            p = m.p
-            mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
-
-            def run():
-                return oracle.convknrm(q, d, emb_h, [sd[f"convs.{i}.0.weight"] for i in range(p["maxngram"])],
-                                       [sd[f"convs.{i}.0.bias"] for i in range(p["maxngram"])], p["crossmatch"], mu, sigma, sd["combine.0.weight"],
-                                       sd["combine.0.bias"])
-        want, err = run()
-        assert err == 0
-        got = out[0][:n].cpu().numpy()
-        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max()), np.abs(got - want).max()   # the timed scores are the oracle's
+        n = args.cpu_pairs or (2000 if model == "convknrm" else min(n_pairs, 2000 * max(1, cores // 4)))
+        run = sibling_oracle(model, m, D, *(t[:n].cpu().numpy() for t in (q_all, d_all, idf_all)), emb_h)
+        run()
         t0 = time.perf_counter()
         reps = 0
         while True:
@@ -748,6 +814,7 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
     gemm_s = tot_ms.value * 1e-3 / max(1, launches.value)
     gemm_tf = 2.0 * rows.value * F * H / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
     Mg = rows.value // max(1, launches.value)
+    coll = collective_info(ctx, docs)       # (every rank takes part)
     if rank != 0:
         return None
     psg_per_s = docs * P * world * steps / elapsed
@@ -772,6 +839,8 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
                      "note": "whole_step_* = executed FLOPs (last layer: [CLS] rows only after the QKV projection) / step time; *_nominal prices "
                              "every passage at SURVEY §8(d)'s 45.90 GFLOP"},
     }
+    if coll is not None:
+        rec["collective"] = coll
     if world == 1 and not args.no_bert_other_dtype and not args.bert_skip_padding:
         # the same step with the other 16-bit operand type (short: 3 steps), so that one line carries both
         import copy
@@ -801,6 +870,9 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
         # (a sanity bound on one document's MaxP score under wide random weights - the parity tests proper are tests/test_gpu_bert.py)
         err = float((out[0][:n].cpu() - want).abs().max() / max(1.0, float(want.abs().max())))
         assert err <= (5e-2 if args.bert_dtype == "bf16" else 1e-2), f"BERT: the timed scores differ from the fp32 port's by {err}"
+        rec["parity"] = {"dtype": args.bert_dtype, "documents": n, "max_score_error_of_scale_vs_fp32_port": err,
+                         "note": "the timed scores of the step's first document(s) against oracle/bert_port.py (fp32) under these wide random-init weights; "
+                                 "the parity tests proper (reference fixtures, both dtypes) are tests/test_gpu_bert.py"}
         rec["cpu_baseline"] = {"value": n / dt, "unit": "pairs/s", "cores": min(cores, 64), "kind": "port",
                                "sample": f"{n} document(s) ({n * P} passages) through oracle/bert_port.py (fp32 ATen ops, {min(cores, 64)} threads); the timed "
                                          f"GPU scores of these documents agree with it to {err:.1e}"}

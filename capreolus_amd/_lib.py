@@ -55,9 +55,9 @@ SIGNATURES = {
     "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u,
                                          _vp]),
     "capamd_drmm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
-                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _u, _vp]),
     "capamd_drmm_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _u, _vp]),
     "capamd_bert_blob_bytes": (_i64, [_mp]),
     "capamd_bert_layer_f32_floats": (_i64, [_mp]),
     "capamd_bert_pack_layer": (_i, [_mp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp]),

@@ -15,6 +15,8 @@
 //     are skipped; OOV document terms (id < 0) have sim exactly 0 -> added to bin(0) in closed form.
 #include "capreolus_amd.h"
 #include "interaction.cuh"
+#include "interaction_stream.cuh"
+#include <stdlib.h>
 
 using namespace capamd;
 
@@ -221,6 +223,129 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   }
 }
 
+
+// =====================================================================================================================================
+// Streaming form (interaction_stream.cuh): persistent five-wave workgroups, the model's part as a policy.
+//   gathering waves: bin every gathered similarity into hist[buf][query term][bin] (LDS atomics, integers: order independent)
+//   list wave:       OOV document terms in closed form, then per query term CH / NH / LCH -> feed-forward net -> gate logit, the softmax
+//                    gate and the output layer (DRMM.py:71-116) - the tail that cost the one-pair-per-workgroup kernel 23 % of its
+//                    time (a workgroup in its tail requests no rows) now runs beside the next pair's gather.
+struct DrmmStream {
+  using Args = DrmmArgs;
+  struct Gather {};
+  static constexpr int kW1Lds = 512;   // floats of the first layer kept in LDS (nodes x (nbins + 1); the reference's 5 x 30 = 150)
+  // hist[2][kQT][kMaxBins] | edges[kMaxBins] | w1[kW1Lds]
+  __host__ __device__ static size_t lds_bytes(const Args&) { return (2 * kQT * kMaxBins + kMaxBins + kW1Lds) * 4; }
+  __device__ static int* hist(char* lds, int buf) { return reinterpret_cast<int*>(lds) + buf * kQT * kMaxBins; }
+  __device__ static float* edges(char* lds) { return reinterpret_cast<float*>(lds) + 2 * kQT * kMaxBins; }
+  __device__ static float* w1(char* lds) { return edges(lds) + kMaxBins; }
+
+  __device__ static void list_init(const Args& a, char* lds, int lane) {
+    if (lane < a.nbins) edges(lds)[lane] = a.edges[lane];
+    const int NB = a.nbins + 1;
+    if (a.nodes * NB <= kW1Lds)
+      for (int i = lane; i < a.nodes * NB; i += 64) w1(lds)[i] = a.w1[i];
+    wave_fence();
+  }
+  __device__ static void prepare(const Args&, char* lds, int buf, int lane) {
+    reinterpret_cast<int4*>(hist(lds, buf))[lane] = make_int4(0, 0, 0, 0);     // kQT * kMaxBins = 256 ints
+  }
+
+  __device__ static void finish(const Args& a, const StreamSrc& src, char* lds, int buf, const StreamMeta* meta, int lane) {
+    int* H = hist(lds, buf);
+    const float* E = edges(lds);
+    const int NB = a.nbins + 1;
+    const int b = meta->pair;
+    const int n_oov = meta->n_oov;
+    if (lane < kQT && n_oov > 0) {  // OOV document terms: sim == 0 exactly
+      const int bz = bin_of(0.f, E, a.nbins);
+      if (bz < a.nbins) H[lane * kMaxBins + bz] += n_oov;
+    }
+    // DRMM cannot score an OOV query term: the reference indexes the embedding un-clamped (DRMM.py:109)
+    if (lane < src.Q && lane < kQT && meta->qid[lane] < 0) atomicOr(src.status, kErrQueryOOV);
+    wave_fence();
+    const bool w1_in_lds = a.nodes * NB <= kW1Lds;
+    const int qrow = src.ids.q32 ? src.ids.pair_q[b] : b;
+    // (every small operand of the tail is requested up front, so that the serial chain below waits for memory once)
+    const float b1v = lane < a.nodes ? a.b1[lane] : 0.f, w2v = lane < a.nodes ? a.w2[lane] : 0.f, b2v = a.b2[0];
+    const float gw0 = a.gate_type == 0 ? a.gate_w[0] : 0.f;
+    const float idfv = (a.gate_type == 0 && lane < src.Q) ? a.idf[(int64_t)qrow * src.Q + lane] : 0.f;
+    const float ow = a.out_w[0], ob = a.out_b[0];
+    float z[kQT], gl[kQT];
+#pragma unroll
+    for (int q = 0; q < kQT; ++q) {
+      z[q] = 0.f;
+      gl[q] = -3.0e38f;
+      if (q < src.Q) {
+        const int* h = H + q * kMaxBins;
+        if (a.counts_out && lane < NB) a.counts_out[((int64_t)b * src.Q + q) * NB + lane] = h[lane];
+        float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;  // DRMM.py:71
+        if (a.hist_type == 1) {                              // NH (DRMM.py:72-74)
+          const float hs = wave_sum(hv);
+          hv = hv / hs;
+        } else if (a.hist_type == 2) {                       // LCH (DRMM.py:75-76)
+          hv = lane < NB ? logf(hv) : 0.f;
+        }
+        // ffw (DRMM.py:25): lane i holds histogram entry i; node n = one wave-wide dot product, kept by lane n
+        float acc = 0.f;
+        for (int n = 0; n < a.nodes; ++n) {
+          const float wv = lane < NB ? (w1_in_lds ? w1(lds)[n * NB + lane] : a.w1[n * NB + lane]) : 0.f;
+          const float sn = wave_sum(wv * hv);
+          if (lane == n) acc = sn;
+        }
+        acc += b1v;
+        const float contrib = lane < a.nodes ? w2v * tanhf(acc) : 0.f;
+        const float o = wave_sum(contrib) + b2v;
+        // term gate logit (DRMM.py:83-95)
+        const int qid = meta->qid[q];
+        float g;
+        if (a.gate_type == 0) {
+          g = gw0 * __shfl(idfv, q, 64);
+        } else {
+          const float* e = a.emb_raw + (qid > 0 && qid < src.V ? qid : 0) * a.ld;
+          float p = 0.f;
+          for (int c = lane; c < a.D; c += 64) p = __builtin_fmaf(a.gate_w[c], e[c], p);
+          g = wave_sum(p);
+        }
+        if (qid == 0) g += -1e7f;
+        z[q] = tanhf(o);
+        gl[q] = g;
+      }
+    }
+    // softmax gate + output layer (DRMM.py:97-98, :112-114): the same fixed order as the one-pair-per-workgroup kernel
+    float m = gl[0];
+#pragma unroll
+    for (int q = 1; q < kQT; ++q)
+      if (q < src.Q) m = fmaxf(m, gl[q]);
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int q = 0; q < kQT; ++q)
+      if (q < src.Q) {
+        const float e = expf(gl[q] - m);
+        den += e;
+        num = __builtin_fmaf(e, z[q], num);
+      }
+    if (lane == 0) a.out[b] = __builtin_fmaf(ow, num / den, ob);
+    wave_fence();
+  }
+
+  __device__ static void gather_init(const Args&, Gather&, int) {}
+  template <int NV>
+  __device__ static void pair_begin(const Args&, Gather&, QueryPass<NV>& qp, const StreamMeta*, int) {
+    if (qp.id_my < 0) qp.id_my = 0;      // an OOV query term matches nothing here (and is reported through the status word)
+  }
+  __device__ static void row(const Args& a, Gather&, float x, unsigned entry, char* lds, int buf, int lane16) {
+    if (lane16 < kQT) {
+      int* h = hist(lds, buf) + lane16 * kMaxBins;
+      const int m = (int)(entry >> kIdBits);           // how often the document repeats this term (0: a filler beyond the list)
+      const int bu = bin_of(x, edges(lds), a.nbins);
+      if (m > 0 && bu < a.nbins) atomicAdd(&h[bu], m);
+      if (m > 0 && x > 0.999f && x < 1.001f) atomicAdd(&h[a.nbins], m);
+    }
+  }
+  __device__ static void pair_end(const Args&, Gather&, char*, int, int, int) {}
+};
+
 }  // namespace
 
 namespace {
@@ -228,7 +353,9 @@ namespace {
 int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, const float* packed, int64_t V, int D,
                 const float* edges, int nbins, int hist_type, int gate_type, const float* gate_w, const float* emb_raw, int64_t ld,
                 const float* w1, const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
-                const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+                const float* out_b, float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes, unsigned flags,
+                void* stream) {
+  (void)flags;   // (CAPAMD_LAUNCH_CONCURRENT: this kernel uses its occupancy-oriented variant at every batch size already)
   if (!idf || !packed || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out || !status) return CAPAMD_ERR_ARG;
   if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   if (nbins < 1 || nbins + 1 > kMaxBins || nodes < 1 || nodes > kMaxNodes) return CAPAMD_ERR_ARG;
@@ -240,6 +367,17 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
+  // Launches that outnumber the workgroups the chip holds run the streaming kernel (interaction_stream.cuh; needs the caller's workspace
+  // word, <= kQT query terms, L <= kDedupMaxL, ids < 2^22).  CAPAMD_DRMM_STREAM (profiling): 0 = never, 2 = whenever the geometry allows.
+  static const int stream_mode = [] {
+    const char* e = getenv("CAPAMD_DRMM_STREAM");
+    return e ? atoi(e) : 1;
+  }();
+  if (stream_mode && (B > 3072 || stream_mode == 2)) {
+    const StreamSrc src{ids, B, Q, L, packed, V, status};
+    int rc = CAPAMD_OK;
+    if (stream_launch<DrmmStream>(src, a, D, workspace, workspace_bytes, s, &rc)) return rc;
+  }
 #define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1, 2, false, 3); break;
@@ -258,12 +396,13 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
                                    const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type,
                                    int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
                                    const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
-                                   const float* out_b, float* out, int32_t* counts_out, int* status, void* stream) {
+                                   const float* out_b, float* out, int32_t* counts_out, int* status, void* workspace,
+                                   size_t workspace_bytes, unsigned flags, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!q_ids || !d_ids) return CAPAMD_ERR_ARG;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   return drmm_launch(ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld, w1, b1, nodes, w2,
-                     b2, out_w, out_b, out, counts_out, status, stream);
+                     b2, out_w, out_b, out, counts_out, status, workspace, workspace_bytes, flags, stream);
 }
 
 extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
@@ -295,10 +434,11 @@ extern "C" int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t
                                            int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type,
                                            const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1,
                                            int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
-                                           float* out, int32_t* counts_out, int* status, void* stream) {
+                                           float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes,
+                                           unsigned flags, void* stream) {
   if (B == 0) return CAPAMD_OK;
   if (!q_table || !d_table || !pair_q || !pair_d) return CAPAMD_ERR_ARG;
   const IdSource ids{nullptr, nullptr, q_table, d_table, pair_q, pair_d};
   return drmm_launch(ids, idf_table, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld, w1, b1, nodes,
-                     w2, b2, out_w, out_b, out, counts_out, status, stream);
+                     w2, b2, out_w, out_b, out, counts_out, status, workspace, workspace_bytes, flags, stream);
 }

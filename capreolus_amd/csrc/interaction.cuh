@@ -455,6 +455,61 @@ __device__ __forceinline__ void rows_sim_my(const RowRegs<NV> (&d)[U], const Que
   }
 }
 
+// The two halves of rows_sim_my<NV, 1, true> for callers that put something between them (the streaming kernels request the group's next
+// row as soon as the dot products are formed): same fma order, same reduction, same divide - bit-identical similarities.
+template <int NV>
+__device__ __forceinline__ void rows_dot(const RowRegs<NV>& d, const float4* qlds, int lane16, float (&p)[kQT]) {
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) p[t] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) {
+      const float4 q = qlds[(t * NV + i) * 16 + lane16];
+      float a = p[t];
+      a = __builtin_fmaf(d.v[i].x, q.x, a);
+      a = __builtin_fmaf(d.v[i].y, q.y, a);
+      a = __builtin_fmaf(d.v[i].z, q.z, a);
+      a = __builtin_fmaf(d.v[i].w, q.w, a);
+      p[t] = a;
+      if (t & 1) __builtin_amdgcn_sched_barrier(0);   // (as in rows_sim_my: at most one query chunk ahead of its use)
+    }
+}
+// two rows against one pass over the LDS query copy (each query chunk read once for both rows; per row the same fma order as rows_dot)
+template <int NV>
+__device__ __forceinline__ void rows_dot2(const RowRegs<NV>& d0, const RowRegs<NV>& d1, const float4* qlds, int lane16, float (&p0)[kQT], float (&p1)[kQT]) {
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) p0[t] = p1[t] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) {
+      const float4 q = qlds[(t * NV + i) * 16 + lane16];
+      float a = p0[t], b = p1[t];
+      a = __builtin_fmaf(d0.v[i].x, q.x, a);
+      b = __builtin_fmaf(d1.v[i].x, q.x, b);
+      a = __builtin_fmaf(d0.v[i].y, q.y, a);
+      b = __builtin_fmaf(d1.v[i].y, q.y, b);
+      a = __builtin_fmaf(d0.v[i].z, q.z, a);
+      b = __builtin_fmaf(d1.v[i].z, q.z, b);
+      a = __builtin_fmaf(d0.v[i].w, q.w, a);
+      b = __builtin_fmaf(d1.v[i].w, q.w, b);
+      p0[t] = a;
+      p1[t] = b;
+      if (t & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NV>
+__device__ __forceinline__ float sim_from_dots(const float (&p)[kQT], float dden, const QueryPass<NV>& qp, int lane16) {
+  float r[kQT];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) r[t] = group_allreduce(p[t]);
+  const int myq = lane16 & 3;
+  const float pm = myq == 0 ? r[0] : myq == 1 ? r[1] : myq == 2 ? r[2] : r[3];
+  const float s = pm / (qp.den_my * dden);
+  return qp.id_my > 0 ? s : 0.f;
+}
+
 // query pass whose rows live in LDS: only ids / den of the owned term stay in registers.  The loads are batched - the kQT ids together
 // (one branch on the id layout around them, indices clamped instead of predicated), then the kQT rows' chunks and norms together, then
 // the LDS writes: written term by term, hipcc waited for each id before it asked for that term's row and for each row before the next

@@ -210,12 +210,12 @@ def drmm_forward(query, doc, idf, packed, V, D, edges, hist_type, gate_type, gat
     L = d.shape[1]
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=q.device)
-    st = status_word(q.device)
+    st, ws = status_word(q.device), _workspace(q.device)
     ld = emb_raw.stride(0) if emb_raw is not None else 0
     rc = _lib.load().capamd_drmm_forward(
         _ptr(q), _ptr(d), _ptr(idf), B, Q, L, _ptr(packed), V, D, _ptr(edges), edges.numel(), HIST_TYPES[hist_type],
         GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0], _ptr(w2), _ptr(b2),
-        _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(counts_out), _ptr(st.t), _stream())
+        _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(counts_out), _ptr(st.t), _ptr(ws), ws.numel() * 4, _launch_flags(), _stream())
     _lib.check(rc, "capamd_drmm_forward")
     if check:
         st.raise_if_set()
@@ -463,12 +463,12 @@ def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V,
     B, Q, L = pq.numel(), qt.shape[1], dt.shape[1]
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=pq.device)
-    st = status_word(pq.device)
+    st, ws = status_word(pq.device), _workspace(pq.device)
     ld = emb_raw.stride(0) if emb_raw is not None else 0
     rc = _lib.load().capamd_drmm_forward_indexed(
         _ptr(qt), _ptr(dt), _ptr(idf), _ptr(pq), _ptr(pd), B, Q, L, _ptr(packed), V, D, _ptr(edges), edges.numel(),
         HIST_TYPES[hist_type], GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0], _ptr(w2),
-        _ptr(b2), _ptr(out_w), _ptr(out_b), _ptr(out), None, _ptr(st.t), _stream())
+        _ptr(b2), _ptr(out_w), _ptr(out_b), _ptr(out), None, _ptr(st.t), _ptr(ws), ws.numel() * 4, _launch_flags(), _stream())
     _lib.check(rc, "capamd_drmm_forward_indexed")
     if check:
         st.raise_if_set()

@@ -345,6 +345,9 @@ class PytorchTrainer:
             qrow = store.qrow.get(qid)
             if qrow is None:
                 qrow = store.add_query(qid, sample["query"], sample.get("query_idf"))
+            elif not (np.array_equal(store._q[qrow], np.asarray(sample["query"])) and
+                      (sample.get("query_idf") is None or np.array_equal(store._idf[qrow], np.asarray(sample["query_idf"], np.float32)))):
+                return None       # a qid whose query row changes from sample to sample: not a candidate-store sampler
             drow = store.drow.get(docid)
             if drow is None:
                 drow = store.add_doc(docid, sample["posdoc"])

@@ -117,7 +117,8 @@ int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float*
                         const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type,
                         int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
                         const float* b1, int nodes, const float* w2, const float* b2, const float* out_w,
-                        const float* out_b, float* out, int32_t* counts_out, int* status, void* stream);
+                        const float* out_b, float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes,
+                        unsigned flags, void* stream);
 
 /* Training-step forward half for DRMM: feat_out fp32 [B, Q, nbins+1] = the matching histogram after CH/NH/LCH
  * (DRMM._hist_map, DRMM.py:41-81; it has no trainable inputs, the embedding is frozen at DRMM.py:22); the
@@ -131,7 +132,8 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
                                 int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type,
                                 const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1,
                                 int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
-                                float* out, int32_t* counts_out, int* status, void* stream);
+                                float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes, unsigned flags,
+                                void* stream);
 
 /* ---- DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64) behind DRMMTKS.test (:105-110) ------------------
  * A sibling of DRMM on the same fused front end: per query term the top-k similarities over all

@@ -1,0 +1,106 @@
+"""Gradient fixtures: `.grad` of every trainable parameter of the REFERENCE nn.Modules after one pairwise training
+loss, for the cases whose inputs and weights are already in tests/golden/<model>_<case>.npz.  Called from make_golden_extra.py
+(build container only; the reference tree does not travel).
+
+The loss is the reference trainer's own pairwise hinge loss (reranker/common.py:101-103, called at trainer/pytorch.py:99) on
+(posdoc, negdoc) = (the case's documents, the same documents rolled by one pair), plus 0.01 x the sum of the positive scores so that
+every pair contributes a gradient even where the hinge is inactive - the same objective the GPU tests of the HIP training kernels use.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from capreolus_amd import synthetic  # noqa: E402
+
+
+def _load(name):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _set_weights(model, fx):
+    sd = model.state_dict()
+    n = 0
+    for k in list(sd):
+        if "sd." + k in fx:
+            sd[k] = torch.from_numpy(np.asarray(fx["sd." + k])).reshape(sd[k].shape)
+            n += 1
+    assert n > 0
+    model.load_state_dict(sd)
+
+
+def _grads(common, model, fx, name, idf_wrap=None):
+    q = torch.from_numpy(fx["query"].astype(np.int64))
+    d = torch.from_numpy(fx["posdoc"].astype(np.int64))
+    neg = d.roll(1, 0)
+    idf = torch.from_numpy(fx["query_idf"])
+    wrap = idf_wrap or (lambda t: t)
+    model.eval()
+    with torch.no_grad():      # the module rebuilt from the fixture IS the module that made the fixture
+        again = model(d, q, wrap(idf)).view(-1).numpy()
+    assert np.array_equal(again.astype(np.float32), fx["ref_scores"]), (name, np.abs(again - fx["ref_scores"]).max())
+    model.train()
+    pos_s = model(d, q, wrap(idf)).view(-1)
+    neg_s = model(neg, q, wrap(idf)).view(-1)
+    loss = common.pair_hinge_loss([pos_s, neg_s]) + 0.01 * pos_s.sum()
+    loss.backward()
+    out = {"ref_loss": np.float64(loss.item()), "ref_pos_scores": pos_s.detach().numpy().astype(np.float32),
+           "ref_neg_scores": neg_s.detach().numpy().astype(np.float32)}
+    for k, p in model.named_parameters():
+        if p.requires_grad and "embedding" not in k:
+            assert p.grad is not None, k
+            out["ref_grad." + k] = p.grad.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), {k[9:]: float(np.abs(v).max()) for k, v in out.items() if k.startswith("ref_grad.")})
+
+
+def gen_grads(common, KNRM, DRMM, TKS, PACRR, CONVKNRM):
+    from make_golden import _IdfTensor
+    from tests.helpers import convknrm_conv_weights
+
+    for case in ("default", "twolayer_tanh"):
+        fx = _load("knrm_" + case)
+        emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+        cfg = dict(gradkernels=True, finetune=False, singlefc=bool(fx["singlefc"]), scoretanh=bool(fx["scoretanh"]))
+        m = KNRM.KNRM_class(SimpleNamespace(embeddings=emb), cfg)
+        _set_weights(m, fx)
+        _grads(common, m, fx, "knrm_grad_" + case)
+    for case in ("zero_idf",):           # (a case on which the reference's bin counts and this build's agree: no coin flip inside the gradient)
+        fx = _load("drmm_" + case)
+        emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+        cfg = dict(nbins=int(fx["nbins"]), nodes=int(fx["nodes"]), histType=str(fx["histType"]), gateType=str(fx["gateType"]))
+        m = DRMM.DRMM_class(SimpleNamespace(embeddings=emb), cfg)
+        _set_weights(m, fx)
+        _grads(common, m, fx, "drmm_grad_" + case)
+    for case in ("default",):
+        fx = _load("drmmtks_" + case)
+        emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+        m = TKS.DRMMTKS_class(SimpleNamespace(embeddings=emb), dict(topk=int(fx["topk"]), gateType="IDF", freezeemb=True))
+        _set_weights(m, fx)
+        _grads(common, m, fx, "drmmtks_grad_" + case)
+    for case in ("default", "tanh_noidf_short"):
+        fx = _load("pacrr_" + case)
+        emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+        cfg = {k[4:]: (bool(v) if k == "cfg.idf" else int(v)) for k, v in fx.items() if k.startswith("cfg.")}
+        cfg["nonlinearity"] = str(fx["nonlinearity"])
+        ext = SimpleNamespace(embeddings=emb, config={"maxqlen": fx["query"].shape[1]})
+        m = PACRR.PACRR_class(ext, cfg)
+        _set_weights(m, fx)
+        _grads(common, m, fx, "pacrr_grad_" + case, idf_wrap=_IdfTensor)
+    for case in ("default", "nocross_2fc_short"):
+        fx = _load("convknrm_" + case)
+        emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+        cfg = {k[4:]: (int(v) if k in ("cfg.maxngram", "cfg.filters") else bool(v)) for k, v in fx.items() if k.startswith("cfg.")}
+        m = CONVKNRM.ConvKNRM_class(SimpleNamespace(embeddings=emb, pad=0), cfg)
+        ws, bs = convknrm_conv_weights(int(fx["conv_seed"]), cfg["filters"], int(fx["D"]), cfg["maxngram"])
+        with torch.no_grad():
+            for g, (w, b) in enumerate(zip(ws, bs)):
+                m.convs[g][0].weight.copy_(torch.from_numpy(w))
+                m.convs[g][0].bias.copy_(torch.from_numpy(b))
+        _set_weights(m, fx)
+        _grads(common, m, fx, "convknrm_grad_" + case)

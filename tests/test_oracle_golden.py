@@ -27,11 +27,10 @@ def test_knrm_oracle_rank_order_matches_reference():
     packed = oracle.pack(c["emb"])
     mu, sigma, w1, b1, w2, b2 = knrm_weights(c)
     got, _ = oracle.knrm(c["query"], c["posdoc"], packed, int(c["D"]), mu, sigma, w1, b1, w2, b2, bool(c["scoretanh"]))
-    assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98  # fp16 rounding boundary flips only
-    ours, ref = rank_order(got.astype(np.float16)), rank_order(c["ref_scores_f16"])
-    same = got.astype(np.float16) == c["ref_scores_f16"]
-    if same.all():
-        assert (ours == ref).all()
+    # all 200 fp16 scores are the reference's bit for bit (its scores sit >= 6.9e-6 relative from an fp16 rounding boundary, the
+    # oracle within 5e-7 of them): the same run order, outright
+    assert np.array_equal(got.astype(np.float16), c["ref_scores_f16"])
+    assert np.array_equal(rank_order(got.astype(np.float16)), rank_order(c["ref_scores_f16"]))
 
 
 def _drmm_run(c):
@@ -113,6 +112,39 @@ def test_drmm_coin_flip_statistics(name):
     b = DRMM_COIN_FLIP_BOUNDS[name]
     assert stats["pairs_moved"] <= b["pairs_moved"] and stats["counts_moved"] <= b["counts_moved"], stats
     assert stats["max_delta"] <= b["max_delta"] and stats["frac_over"] <= b["frac_over"], stats
+
+
+@pytest.mark.parametrize("name", ["default", "ranklist", "tv_nh", "ch"])
+def test_drmm_coin_flip_is_the_references_own_noise(name):
+    """The reference against ITSELF (tests/golden/make_golden_extra.py: the same module, weights and inputs scored one pair per call
+    instead of in one batch - another bmm blocking) moves the `sim < 1.0` counts of DRMM.py:62-66 at least as much as this build's
+    documented summation order does against the fixture: the oracle's (= the GPU kernel's: counts are asserted bit-exact between them)
+    distance to the reference is bounded by the reference's distance to its own second run, measure by measure.  Where the reference
+    agrees with itself (no identical in-vocabulary terms flip: `tv_nh`, `ch` under these blockings) only the frozen bounds of
+    test_drmm_coin_flip_statistics apply."""
+    import os
+
+    from tests.helpers import GOLDEN
+
+    c = load_case("drmm", name)
+    alt = np.load(os.path.join(GOLDEN, f"drmm_{name}_alt.npz"))
+    assert bool(alt["regenerates_fixture"])            # the generator reproduced drmm_<name>.npz before it varied the blocking
+    got, counts, _ = _drmm_run(c)
+
+    def distance(scores, cnt):
+        d = np.abs(cnt.astype(np.int64) - c["ref_counts"].astype(np.int64))
+        e = rel_err(scores, c["ref_scores"])
+        return dict(pairs_moved=int((d.sum(axis=(1, 2)) > 0).sum()), counts_moved=int(d.sum()), max_delta=float(e.max()),
+                    frac_over=float((e > REL_TOL).mean()))
+
+    ours = distance(got, counts)
+    ref_self = {k: distance(alt[k + "_scores"], alt[k + "_counts"]) for k in ("one_thread", "batch1", "reversed")}
+    worst = {m: max(v[m] for v in ref_self.values()) for m in ours}
+    print("DRMM reference vs itself", name, ref_self, "this build", ours)
+    if worst["pairs_moved"] == 0:
+        pytest.skip("the reference agrees with itself on this case under the three blockings tried")
+    assert ours["pairs_moved"] <= worst["pairs_moved"] and ours["counts_moved"] <= worst["counts_moved"], (ours, worst)
+    assert ours["max_delta"] <= worst["max_delta"] * 1.05 and ours["frac_over"] <= worst["frac_over"], (ours, worst)
 
 
 def test_drmm_oracle_rejects_oov_query():
