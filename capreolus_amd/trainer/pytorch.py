@@ -99,6 +99,10 @@ class PytorchTrainer:
         # same sampler (the dev set after every training iteration, RerankTask's repeated predict) score it by index pairs without
         # touching the host per sample (SURVEY.md row N1 through the reference's own call site, trainer/pytorch.py:310-353).
         "resident": True,
+        # `graph` (default on): a training step - score() on positives and negatives, loss, backward, Adam - is captured ONCE as a HIP
+        # graph and replayed per batch (at batch 32 a step is ~40 launches of microsecond kernels, i.e. host time).
+        # Needs a GPU, gradacc = 1 and no loss scaling (amp = train / both); anything else, and batches of another shape, run eagerly.
+        "graph": True,
     }
     # amp = "pred" / "both" at prediction time (reference :323-326, 343: autocast around `reranker.test`) selects nothing here: the
     # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
@@ -157,7 +161,11 @@ class PytorchTrainer:
     def _set_lr(self, step):
         # what `LambdaLR.step(epoch=step)` leaves behind in the reference (:118-120): lr = base lr x multiplier(step)
         for group in self.optimizer.param_groups:
-            group["lr"] = self.config["lr"] * self.lr_multiplier(step)
+            lr = self.config["lr"] * self.lr_multiplier(step)
+            if torch.is_tensor(group["lr"]):
+                group["lr"].fill_(lr)        # (capturable Adam: the captured step reads the learning rate from this device scalar)
+            else:
+                group["lr"] = lr
 
     # ---- training (reference trainer/pytorch.py:76-122, 189-300) -------------------------
     @staticmethod
@@ -172,6 +180,78 @@ class PytorchTrainer:
         scores = torch.stack(pos_neg_scores, dim=1)
         return torch.mean(1.0 - scores.softmax(dim=1)[:, 0])
 
+    # ---- one training step as one HIP graph -------------------------------------------------------------------------------------
+    def _graph_allowed(self):
+        return bool(self.config["graph"]) and self.device.type == "cuda" and self.config["gradacc"] == 1 and self.scaler is None and \
+            not getattr(self, "_graph_failed", False)
+
+    def _capture_train_step(self, reranker, tens, other, sig):
+        """Captures score -> loss -> backward -> optimizer step on static copies of one batch's tensors.  The eager warm-up the capture
+        needs (lazy optimizer state, library handles, autotuned convolutions) runs on a side stream and is then UNDONE - parameters and
+        Adam moments are put back in place - so that training takes exactly the steps it would take eagerly."""
+        from .. import engine
+
+        static = {k: v.to(self.device).clone() for k, v in tens.items()}
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        snap_p = [p.detach().clone() for p in params]
+        snap_s = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state.get(p, {}).items()} for p in params}
+
+        def step():
+            loss = self.loss(reranker.score({**other, **static}))
+            loss.backward()
+            self.optimizer.step()
+            return loss
+
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), engine.deferred_status(self.device):
+            for _ in range(2):
+                self.optimizer.zero_grad(set_to_none=True)
+                step()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        with torch.no_grad():
+            for p, sp in zip(params, snap_p):
+                p.copy_(sp)
+            for p in params:
+                for k, v in self.optimizer.state[p].items():
+                    if torch.is_tensor(v):
+                        old = snap_s[p].get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with engine.deferred_status(self.device), torch.cuda.graph(graph):
+            loss = step()
+        return {"sig": sig, "reranker": reranker, "static": static, "graph": graph, "loss": loss}
+
+    def _graphed_step(self, reranker, batch):
+        """Replays the captured step on `batch`; None when this batch cannot take the graph (another shape: the short last batch)."""
+        from .. import engine
+
+        tens = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        other = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tens.items()))
+        gs = getattr(self, "_train_graph", None)
+        if gs is not None and (gs["reranker"] is not reranker or gs["optimizer"] is not self.optimizer):
+            gs = self._train_graph = None
+        if gs is None:
+            try:
+                gs = self._capture_train_step(reranker, tens, other, sig)
+            except RuntimeError:
+                self._graph_failed = True        # something in this model's step cannot be captured: eager from here on
+                torch.cuda.synchronize(self.device)
+                return None
+            gs["optimizer"] = self.optimizer
+            self._train_graph = gs
+        elif gs["sig"] != sig:
+            return None
+        for k, v in tens.items():
+            gs["static"][k].copy_(v, non_blocking=True)
+        with engine.deferred_status(self.device):
+            gs["graph"].replay()
+        return gs["loss"].detach().clone()
+
     def single_train_iteration(self, reranker, train_dataloader, cur_iter=1):
         """`itersize // batch` batches with gradient accumulation, the per-step learning-rate schedule and (amp = train / both,
         on a GPU) autocast + loss scaling around the small trainable layers (reference :76-122).  The interaction kernels
@@ -179,21 +259,26 @@ class PytorchTrainer:
         n_batch_per_iter = self.n_batch_per_iter
         cur_step = cur_iter * n_batch_per_iter
         losses, since_update = [], 0
+        graphed = self._graph_allowed()
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
-            with self._train_autocast():
-                loss = self.loss(reranker.score(batch))
-            losses.append(loss.detach())
-            (self.scaler.scale(loss) if self.scaler else loss).backward()
-            since_update += 1
-            if since_update == self.config["gradacc"]:
-                since_update = 0
-                if self.scaler:
-                    self.scaler.step(self.optimizer)
-                    self.scaler.update()
-                else:
-                    self.optimizer.step()
-                self.optimizer.zero_grad()
+            done = self._graphed_step(reranker, batch) if graphed else None
+            if done is not None:
+                losses.append(done)
+            else:
+                with self._train_autocast():
+                    loss = self.loss(reranker.score(batch))
+                losses.append(loss.detach())
+                (self.scaler.scale(loss) if self.scaler else loss).backward()
+                since_update += 1
+                if since_update == self.config["gradacc"]:
+                    since_update = 0
+                    if self.scaler:
+                        self.scaler.step(self.optimizer)
+                        self.scaler.update()
+                    else:
+                        self.optimizer.step()
+                    self.optimizer.zero_grad()
             if (bi + 1) % n_batch_per_iter == 0:
                 break
             self._set_lr(cur_step)
@@ -254,12 +339,17 @@ class PytorchTrainer:
         k = int(metric.rsplit("_", 1)[1])
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         model = reranker.model.to(self.device)
-        self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=self.config["lr"])
         if self.config["amp"] in ("both", "train") and self.device.type == "cuda":
             self._train_autocast = lambda: torch.autocast("cuda", dtype=torch.float16)
             self.scaler = torch.amp.GradScaler("cuda")
         else:
             self._train_autocast, self.scaler = contextlib.nullcontext, None
+        self._train_graph, self._graph_failed = None, False
+        if self._graph_allowed():      # the captured step needs Adam's device-side step count and a device scalar as the learning rate
+            self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()),
+                                              lr=torch.tensor(float(self.config["lr"]), device=self.device), capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=self.config["lr"])
         self._set_lr(0)                      # LambdaLR's construction applies multiplier(0)
         self.loss = self.pair_softmax_loss if self.config["softmaxloss"] else self.pair_hinge_loss
         loader = torch.utils.data.DataLoader(train_dataset, batch_size=self.config["batch"], pin_memory=False,   # (see predict)

@@ -67,11 +67,23 @@ def timed(fn, reps=2):
     return (time.perf_counter() - t) / reps, res
 
 
-for eb in (32, 1000):
-    tr = PytorchTrainer({"evalbatch": eb})
+for eb in (32, 1000):      # the reference's route, kept selectable: DataLoader -> .to(device) -> test() per (coalesced) batch
+    tr = PytorchTrainer({"evalbatch": eb, "resident": False})
     tr.build()
     s, preds_a = timed(lambda: tr.predict(r, PredData()), reps=1)
-    out[f"predict_evalbatch{eb}_s"] = round(s, 3)
+    out[f"predict_dataloader_route_evalbatch{eb}_s"] = round(s, 3)
+# the default route: the first predict() of a sampler walks it once and uploads its id rows, later calls score by index pairs
+tr = PytorchTrainer({"evalbatch": 32})
+tr.build()
+sampler = PredData()
+t0 = time.perf_counter()
+preds_first = tr.predict(r, sampler)
+torch.cuda.synchronize()
+out["predict_first_call_s"] = round(time.perf_counter() - t0, 3)
+s, preds_again = timed(lambda: tr.predict(r, sampler), reps=3)
+out["predict_later_calls_s"] = round(s, 4)
+out["predict_later_calls_pairs_per_s"] = round(NQ * ND / s)
+out["predict_same_as_dataloader_route"] = preds_first == preds_a and preds_again == preds_a
 t0 = time.perf_counter()
 store = CandidateStore.from_id2vec(dev, qid_to_docids, id2vec)
 out["store_upload_s"] = round(time.perf_counter() - t0, 3)

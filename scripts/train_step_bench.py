@@ -6,6 +6,7 @@ import argparse
 import json
 import os
 import sys
+import time
 from types import SimpleNamespace
 
 import torch
@@ -13,6 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from capreolus_amd import synthetic  # noqa: E402
 from capreolus_amd.reranker import DRMM, DRMMTKS, KNRM, PACRR, ConvKNRM  # noqa: E402
+from capreolus_amd.trainer.pytorch import PytorchTrainer  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
@@ -43,15 +45,35 @@ for name, r in (("KNRM", KNRM({}, ext)), ("DRMM", DRMM({}, ext)), ("DRMMTKS", DR
         opt.step()
         return loss
 
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            last = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.steps, (time.perf_counter() - t0) * 1e3 / args.steps, last
+
     for _ in range(3):
         loss0 = step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(args.steps):
-        loss = step()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.steps
-    print(json.dumps({"model": name, "train_steps_per_s": round(1e3 / ms, 1), "ms_per_step": round(ms, 3), "batch": B, "docs_scored_per_step": 2 * B,
-                      "loss_first": round(float(loss0.detach()), 5), "loss_last": round(float(loss.detach()), 5)}))
+    eager_ms, eager_wall, loss = timed(step)
+    rec = {"model": name, "batch": B, "docs_scored_per_step": 2 * B, "eager_ms_per_step": round(eager_ms, 3), "loss_first": round(float(loss0.detach()), 5),
+           "loss_last_eager": round(float(loss.detach()), 5)}
+    # the same step through the trainer's captured HIP graph (PytorchTrainer.single_train_iteration's route: one replay per batch)
+    tr = PytorchTrainer({"batch": B, "itersize": B})
+    tr.device, tr.scaler, tr.loss = dev, None, tr.pair_hinge_loss
+    tr._train_graph, tr._graph_failed = None, False
+    torch.manual_seed(0)
+    m = r.build_model().to(dev).train()
+    tr.optimizer = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=torch.tensor(1e-3, device=dev), capturable=True)
+    first = tr._graphed_step(r, d)
+    if first is None:
+        rec["graph"] = "this model's step could not be captured"
+    else:
+        for _ in range(2):
+            tr._graphed_step(r, d)
+        g_ms, g_wall, gl = timed(lambda: tr._graphed_step(r, d))
+        rec.update(ms_per_step=round(g_ms, 3), wall_ms_per_step=round(g_wall, 3), train_steps_per_s=round(1e3 / g_ms, 1), loss_last_graph=round(float(gl), 5))
+    print(json.dumps(rec))

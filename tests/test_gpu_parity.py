@@ -1361,6 +1361,12 @@ def test_training_gradients_match_the_reference(kind, name, build):
         assert p.grad is not None, key
         got = p.grad.detach().cpu().numpy().reshape(want.shape)
         scale = float(np.abs(want).max())
+        if key.startswith("ref_grad.kernels.kernels.") and float(c["sd." + key[9:].rsplit(".", 1)[0] + ".sigma"]) < 0.01:
+            # the exact-match kernel (mu = 1, sigma = 0.001): dK/dmu = K (s - mu) / sigma^2 with s - mu = a few ulp of cos(a, a) - the
+            # reference's own value is 1e6 x its rounding noise (the DRMM coin flip in another guise), so only its magnitude is checked
+            assert float(np.abs(got).max()) <= max(20.0 * scale, 5e-3), (key, float(np.abs(got).max()), scale)
+            checked += 1
+            continue
         if scale == 0.0:
             assert float(np.abs(got).max()) <= 1e-7, key
         else:
@@ -1427,3 +1433,50 @@ def test_predict_builds_its_candidate_store_on_first_use():
 
     cs = Coupled()
     assert PytorchTrainer({"batch": 32}).predict(r, cs) == PytorchTrainer({"batch": 32, "resident": False}).predict(r, cs)
+
+
+@pytest.mark.parametrize("kind,name,build", [("knrm", "twolayer_tanh", _knrm_model), ("drmm", "zero_idf", _drmm_model), ("convknrm", "nocross_2fc_short", _convknrm_reranker)],
+                         ids=["knrm", "drmm", "convknrm"])
+def test_graphed_training_steps_equal_eager_steps(kind, name, build):
+    """Row N3: `PytorchTrainer.single_train_iteration` replays ONE captured HIP graph per batch (score on positives and negatives, loss,
+    backward, Adam).  Five steps through the graph leave the parameters where five eager steps leave them (the capture's warm-up steps
+    are undone), with the per-step learning-rate schedule applied through the device scalar the captured Adam reads."""
+    import contextlib
+
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case(kind, name)
+    B = c["query"].shape[0]
+    rs = np.random.RandomState(5)
+    batches = []
+    for _ in range(5):
+        perm = rs.permutation(B)
+        batches.append({"qid": [str(i) for i in range(B)], "query": torch.as_tensor(c["query"]), "query_idf": torch.as_tensor(c["query_idf"]),
+                        "posdoc": torch.as_tensor(c["posdoc"]), "negdoc": torch.as_tensor(c["posdoc"][perm])})
+
+    def run(graph):
+        r = build(c)
+        m = r.model
+        m.train()
+        t = PytorchTrainer({"batch": B, "itersize": 5 * B, "lr": 0.01, "warmupiters": 1, "decay": 0.5, "decaytype": "linear", "graph": graph})
+        t.device, t.scaler, t._train_autocast, t.loss = torch.device(DEV), None, contextlib.nullcontext, t.pair_hinge_loss
+        t._train_graph, t._graph_failed = None, False
+        params = [p for p in m.parameters() if p.requires_grad]
+        if graph:
+            t.optimizer = torch.optim.Adam(params, lr=torch.tensor(0.01, device=DEV), capturable=True)
+        else:
+            t.optimizer = torch.optim.Adam(params, lr=0.01)
+        t._set_lr(0)
+        loss = t.single_train_iteration(r, batches, cur_iter=1)
+        assert (t._train_graph is not None) == graph
+        return float(loss), {k: v.detach().cpu().clone() for k, v in m.named_parameters() if v.requires_grad}
+
+    loss_e, eager = run(False)
+    loss_g, graphed = run(True)
+    assert abs(loss_e - loss_g) <= 1e-5 * max(1.0, abs(loss_e))
+    moved = 0.0
+    for k, v in eager.items():
+        scale = float(v.abs().max()) + 1e-6
+        assert float((graphed[k] - v).abs().max()) <= 2e-4 * scale, (k, float((graphed[k] - v).abs().max()), scale)
+        moved = max(moved, float((v - torch.as_tensor(np.asarray(c["sd." + k])).reshape(v.shape)).abs().max()) if ("sd." + k) in c else 1.0)
+    assert moved > 1e-3          # the five steps did train something
