@@ -42,6 +42,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (guides: MI355X_MICROARCH.md "HBM3E peak BW")
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA")
 KERNEL_VARIANT = {"knrm": "knrm_forward_kernel<5, 1, true, 6, false>", "drmm": "drmm_forward_kernel<5, 1, true, 6, false>"}
+# launches of more than 3072 pairs over a table the cache hierarchy can hold run the persistent streaming kernels (interaction_stream.cuh)
+STREAM_VARIANT = {"knrm": "stream_kernel<5, false, KnrmStream>", "drmm": "stream_kernel<5, false, DrmmStream>"}
+
+
+def kernel_of(model, pairs_per_launch, vocab, row_stride_floats, resident=False):
+    """The kernel the library picks for a launch (knrm.hip / drmm.hip: knrm_launch, drmm_launch)."""
+    streaming = pairs_per_launch > 3072 and vocab * row_stride_floats * 4 <= (1 << 30) and vocab <= (1 << 22) and os.environ.get(
+        f"CAPAMD_{model.upper()}_STREAM", "1") != "0"
+    name = STREAM_VARIANT[model] if streaming else KERNEL_VARIANT[model]
+    return name.replace("false,", "true,") if (streaming and resident) else name
 
 
 def algorithmic_bytes_per_pair(model, Q, L, D):
@@ -445,7 +455,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     abytes = algorithmic_bytes_per_pair(model, Q, L, D)
     launches = len(leg.slices)
     headline = {
-        "ids": "uniform" if args.uniform_ids else "Zipf(1.1)", "vocab": args.vocab, "kernel_ms": dev_s * 1e3 / launches,
+        "ids": "uniform" if args.uniform_ids else "Zipf(1.1)", "vocab": args.vocab, "kernel": kernel_of(model, n_pairs // launches, args.vocab, leg.row_stride, args.resident),
+        "kernel_ms": dev_s * 1e3 / launches,
         "pairs_per_launch": n_pairs / launches, "mean_nonpad_terms_per_doc": nonpad, "mean_distinct_terms_per_doc": distinct, "requested_bytes_per_pair": req_b,
         "requested_GBps": n_pairs * req_b / dev_s / 1e9,
         "algorithmic_bytes_per_pair": abytes, "algorithmic_GBps": n_pairs * abytes / dev_s / 1e9,
@@ -462,7 +473,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         big_req, big_nonpad, big_distinct = big.bytes_requested_per_pair()
         ach = big.n_pairs * big_req / big_s / 1e9
         roof = {
-            "bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": kernel_of(model, big.n_pairs, args.roofline_vocab, big.row_stride), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS,
             "traffic": None,
             "traffic_source": f"not measured in this run (--no-pmc-traffic): profiles/r02/{model}_hbm_traffic.json holds the builder-run "
                               "FETCH_SIZE x2 + WRITE_SIZE per launch of this leg and of the headline leg",

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   if (tid < a.nbins) edges[tid] = a.edges[tid];
   // the first feed-forward layer's weights go where the hash of the distinct-term pass was (dead after it), when they fit
   float* w1lds = reinterpret_cast<float*>(hkey);
-  const bool w1_in_lds = a.out && a.nodes * NB <= 2 * kHashSlots;
+  const bool w1_in_lds = a.out && a.L <= kDedupMaxL && a.nodes * NB <= 2 * kHashSlots;   // (longer documents: no hash region in the carve-out)
 
   // ---- the document's distinct real terms with their multiplicities; OOV count (interaction.cuh) --------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
@@ -364,7 +364,7 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   DrmmArgs a{ids, idf, B, Q, L, packed, V, D, edges, nbins, hist_type, gate_type, gate_w, emb_raw, ld,
              w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out, status, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Launches that outnumber the workgroups the chip holds run the streaming kernel (interaction_stream.cuh; needs the caller's workspace
@@ -373,12 +373,18 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
     const char* e = getenv("CAPAMD_DRMM_STREAM");
     return e ? atoi(e) : 1;
   }();
-  if (stream_mode && (B > 3072 || stream_mode == 2)) {
+  const bool cacheable = (int64_t)V * row_stride_for_dim(D) * 4 <= (1LL << 30);   // (see knrm.hip: HBM-bound tables keep the one-pair-per-workgroup kernel)
+  if (stream_mode && ((B > 3072 && cacheable) || stream_mode == 2)) {
     const StreamSrc src{ids, B, Q, L, packed, V, status};
     int rc = CAPAMD_OK;
     if (stream_launch<DrmmStream>(src, a, D, workspace, workspace_bytes, s, &rc)) return rc;
   }
-#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_, U_, QL_, W_)                                                     \
+  do {                                                                               \
+    auto kern = drmm_forward_kernel<NV_, U_, QL_, W_>;                               \
+    if (const int bad = lds_budget(kern, smem)) return bad;                          \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
+  } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1, 2, false, 3); break;
     case 2: LAUNCH(2, 2, false, 3); break;
@@ -414,10 +420,15 @@ extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
              nullptr, nullptr, nullptr, nullptr, status, feat_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((drmm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_, U_, QL_, W_)                                                     \
+  do {                                                                               \
+    auto kern = drmm_forward_kernel<NV_, U_, QL_, W_>;                               \
+    if (const int bad = lds_budget(kern, smem)) return bad;                          \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
+  } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1, 2, false, 3); break;
     case 2: LAUNCH(2, 2, false, 3); break;

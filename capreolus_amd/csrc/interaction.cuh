@@ -292,6 +292,19 @@ __device__ __forceinline__ TermList distinct_terms_positions(const PairIds& ids,
   return r;
 }
 
+// Dynamic LDS of a one-pair-per-workgroup kernel: refused (CAPAMD_ERR_ARG = 1) beyond the 160 KiB a gfx950 workgroup can have, and the
+// kernel's limit raised where it is above the 64 KiB default.  (The term list and its multiplicities are 8 bytes per document
+// position: with the kernels' fixed parts that puts the longest document at ~19,000 positions; the distinct-term hash - 8 KiB -
+// exists only up to kDedupMaxL positions.)
+constexpr size_t kMaxLds = 160 * 1024;
+__host__ inline size_t dedup_hash_bytes(int L) { return L <= kDedupMaxL ? (size_t)2 * kHashSlots * 4 : 0; }
+template <class K>
+__host__ inline int lds_budget(K kernel, size_t smem) {
+  if (smem > kMaxLds) return 1;
+  if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 3;
+  return 0;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

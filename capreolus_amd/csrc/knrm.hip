@@ -413,7 +413,7 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
   if (hidden > 0 && (!w2 || !b2)) return CAPAMD_ERR_ARG;
   if (capamd_packed_row_stride(D) < 0 || L > 32768 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out, status, nullptr, nullptr, nullptr};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 48 + 8 + 64 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (1024 + 144 + 48 + kMaxHidden + 48 + 8 + 64) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   // Variant = how many rows each 16-lane group keeps in flight (U), where the query rows live (registers or a
@@ -430,12 +430,21 @@ int knrm_launch(const IdSource& ids, int B, int Q, int L, const float* packed, i
     const char* e = getenv("CAPAMD_KNRM_STREAM");   // profiling: 0 = never, 2 = whenever the geometry allows
     return e ? atoi(e) : 1;
   }();
-  if (stream_mode && !variant && (B > 3072 || stream_mode == 2)) {
+  // ... and a table the cache hierarchy can help with: over a table several times the 256 MB Infinity Cache (measured: 5.1 GB, uniform
+  // ids) every row comes from HBM, the one-pair-per-workgroup kernel already sits at the read ceiling (0.81-0.82 of 8 TB/s) and the
+  // streaming kernel's barrier per pair costs 2-4 % there (0.78-0.805; profiles/r03/stream_ab.txt)
+  const bool cacheable = (int64_t)V * row_stride_for_dim(D) * 4 <= (1LL << 30);
+  if (stream_mode && !variant && ((B > 3072 && cacheable) || stream_mode == 2)) {
     const StreamSrc src{ids, B, Q, L, packed, V, status};
     int rc = CAPAMD_OK;
     if (stream_launch<KnrmStream>(src, a, D, workspace, workspace_bytes, s, &rc)) return rc;
   }
-#define LAUNCH(NV_, U_, QL_, W_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, U_, QL_, W_>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_, U_, QL_, W_)                                                     \
+  do {                                                                               \
+    auto kern = knrm_forward_kernel<NV_, U_, QL_, W_>;                               \
+    if (const int bad = lds_budget(kern, smem)) return bad;                          \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
+  } while (0)
   // One candidate list per launch (B <= the 1536 workgroups the chip holds at once): the launch is as long as its longest
   // document, so four rows in flight per 16-lane group (U = 4) beat occupancy - 62 vs 77 us at B = 1000; from B = 2000 on
   // the 6-waves-per-SIMD variant wins again (96 vs 100 us; 33.0 vs 25.6 M pairs/s at B = 16000).  Same summation order.
@@ -487,10 +496,15 @@ extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, 
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
              dfdsigma_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 64 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
+  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 64) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-#define LAUNCH(NV_) hipLaunchKernelGGL((knrm_forward_kernel<NV_, 1, true, 4, true>), dim3(B), dim3(kThreads), smem, s, a)
+#define LAUNCH(NV_)                                                                  \
+  do {                                                                               \
+    auto kern = knrm_forward_kernel<NV_, 1, true, 4, true>;                          \
+    if (const int bad = lds_budget(kern, smem)) return bad;                          \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
+  } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;

@@ -515,6 +515,82 @@ class KnrmFeatures(torch.autograd.Function):
         return (g * dmu).sum(0), (g * dsg).sum(0), None, None, None, None, None
 
 
+class KernelPool(torch.autograd.Function):
+    """Cosine similarity + RBF kernel pooling over dense n-gram views, differentiable in both operands and in (mu, sigma)
+    (capamd_kernel_pool_forward / _backward): ConvKNRM's training step between its convolutions and `combine`.
+    qrep [B, GQ, Q, F], drep [B, GD, L, F] -> features [B, K V] in the reference's order (ConvKNRM.py:66-75)."""
+
+    @staticmethod
+    def forward(ctx, qrep, drep, q_ids, d_ids, mu, sigma, crossmatch):
+        _need_gpu(qrep, drep, q_ids, d_ids, mu, sigma)
+        qr, dr, qi, di = _f32(qrep.detach()), _f32(drep.detach()), _i64(q_ids), _i64(d_ids)
+        m, sg = _f32(mu.detach()), _f32(sigma.detach())
+        B, GQ, Q, F = qr.shape
+        GD, L = dr.shape[1], dr.shape[2]
+        K = m.numel()
+        V = GQ * GD if crossmatch else GD
+        T = (GQ if crossmatch else 1) * Q
+        feat = torch.empty((B, K * V), dtype=torch.float32, device=qr.device)
+        ksum = torch.empty((B, GD, T, K), dtype=torch.float32, device=qr.device)
+        rowsum = torch.empty((B, GD, T), dtype=torch.float32, device=qr.device)
+        rc = _lib.load().capamd_kernel_pool_forward(_ptr(qr), _ptr(dr), _ptr(qi), _ptr(di), B, GQ, GD, Q, L, F, int(bool(crossmatch)), _ptr(m), _ptr(sg), K,
+                                                    _ptr(feat), _ptr(ksum), _ptr(rowsum), _stream())
+        _lib.check(rc, "capamd_kernel_pool_forward")
+        ctx.save_for_backward(qr, dr, qi, di, m, sg, ksum, rowsum)
+        ctx.crossmatch = bool(crossmatch)
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        qr, dr, qi, di, m, sg, ksum, rowsum = ctx.saved_tensors
+        B, GQ, Q, F = qr.shape
+        GD, L = dr.shape[1], dr.shape[2]
+        K, T = m.numel(), ksum.shape[2]
+        dq_part = torch.empty((B, GD, T, F), dtype=torch.float32, device=qr.device)
+        dd = torch.empty_like(dr)
+        dmu = torch.empty((B * GD, K), dtype=torch.float32, device=qr.device)
+        dsg = torch.empty_like(dmu)
+        rc = _lib.load().capamd_kernel_pool_backward(_ptr(qr), _ptr(dr), _ptr(qi), _ptr(di), B, GQ, GD, Q, L, F, int(ctx.crossmatch), _ptr(m), _ptr(sg), K,
+                                                     _ptr(_f32(g)), _ptr(ksum), _ptr(rowsum), _ptr(dq_part), _ptr(dd), _ptr(dmu), _ptr(dsg), _stream())
+        _lib.check(rc, "capamd_kernel_pool_backward")
+        dq = dq_part.view(B, GD, GQ, Q, F).sum(1) if ctx.crossmatch else dq_part     # (without crossmatch block gd holds query view gd: T = Q)
+        return dq, dd, None, None, dmu.sum(0), dsg.sum(0), None
+
+
+class PacrrConvMax(torch.autograd.Function):
+    """PACRR's n-gram Conv2d -> ReLU -> max over filters -> k-max over the document on a [B, Q, L] similarity matrix, with the
+    gradient into the convolution weights (capamd_pacrr_convmax_forward / _backward; PACRR.py:68-78).  No gradient into `sim`:
+    the embedding table behind it is frozen (PACRR.py:26)."""
+
+    @staticmethod
+    def forward(ctx, sim, conv_w, conv_b, mingram, maxgram, nfilters, kmax):
+        _need_gpu(sim, conv_w, conv_b)
+        x, w, b = _f32(sim.detach()), _f32(conv_w.detach()), _f32(conv_b.detach())
+        B, Q, L = x.shape
+        n = (maxgram - mingram + 1) * kmax
+        top = torch.empty((B, Q, n), dtype=torch.float32, device=x.device)
+        pos = torch.empty((B, Q, n), dtype=torch.int32, device=x.device)
+        filt = torch.empty_like(pos)
+        rc = _lib.load().capamd_pacrr_convmax_forward(_ptr(x), B, Q, L, mingram, maxgram, nfilters, kmax, _ptr(w), _ptr(b), _ptr(top), _ptr(pos), _ptr(filt),
+                                                      _stream())
+        _lib.check(rc, "capamd_pacrr_convmax_forward")
+        ctx.save_for_backward(x, pos, filt)
+        ctx.geom = (mingram, maxgram, nfilters, kmax, w.numel(), b.numel())
+        return top
+
+    @staticmethod
+    def backward(ctx, g):
+        x, pos, filt = ctx.saved_tensors
+        mingram, maxgram, nfilters, kmax, nw, nb = ctx.geom
+        B, Q, L = x.shape
+        dw = torch.empty(nw, dtype=torch.float32, device=x.device)
+        db = torch.empty(nb, dtype=torch.float32, device=x.device)
+        rc = _lib.load().capamd_pacrr_convmax_backward(_ptr(x), B, Q, L, mingram, maxgram, nfilters, kmax, _ptr(_f32(g)), _ptr(pos), _ptr(filt), _ptr(dw),
+                                                       _ptr(db), _stream())
+        _lib.check(rc, "capamd_pacrr_convmax_backward")
+        return None, dw, db, None, None, None, None
+
+
 def drmm_features(query, doc, packed, V, D, edges, hist_type, check=True):
     """capamd_drmm_features: matching-histogram features [B, Q, nbins+1] (no trainable inputs)."""
     _need_gpu(query, doc, packed, edges)

@@ -51,18 +51,40 @@ class ConvKNRM_class(nn.Module):
 
     def _forward_train(self, sentence, query_sentence):
         """Training step (reference trainer/pytorch.py:96-99 -> ConvKNRM.score).  The trainable convolutions sit IN FRONT of the
-        similarity matrices, so the gradient has to flow through the cosine and the kernel pooling into them and the projection
-        tables of the scoring kernel (rebuilt from the weights, not differentiable) cannot be used: the step runs the reference's
-        arithmetic (ConvKNRM.py:42-77, common.py:195-221) as PyTorch-ROCm ATen ops under autograd, on the GPU, at training batch
-        sizes.  It is a functional drop-in for `score()` in train mode, not part of the measured HIP path; scoring under
-        `model.eval()` / `no_grad()` is the fused kernel."""
+        similarity matrices, so the projection tables of the scoring kernel (rebuilt from the weights, not differentiable) cannot be
+        used: the n-gram convolutions run as Conv1d on the GPU (MIOpen, a library convolution), and everything behind them - cosine
+        similarity of every (query view, document view) pair, pad masks, RBF kernel pooling, log / mask / sum - is ONE HIP kernel
+        forward and one backward (capreolus_amd/csrc/kernel_pool.hip through `engine.KernelPool`), which hands the gradient back to
+        both convolution outputs and to the kernels' mu / sigma.  Geometries outside that kernel's limits (filters > 256, more than
+        24 query vectors per document view) keep the reference's op sequence under autograd (`_forward_train_aten`)."""
+        import torch.nn.functional as F
+
+        engine._need_gpu(sentence, query_sentence, self.embeddings.weight)
+        G, Q = len(self.convs), query_sentence.shape[1]
+        nf = self.p["filters"]
+        if nf % 4 or nf > 256 or (G if self.p["crossmatch"] else 1) * Q > 24 or self.kernels.count() > 16:
+            return self._forward_train_aten(sentence, query_sentence)
+        a_emb, b_emb = self.embeddings(query_sentence).permute(0, 2, 1), self.embeddings(sentence).permute(0, 2, 1)
+        a_reps, b_reps = [], []
+        for g, conv in enumerate(self.convs, start=1):
+            a_reps.append(conv[0](F.pad(a_emb, (0, g - 1))).permute(0, 2, 1))   # ConstantPad1d((0, g - 1), 0), ConvKNRM.py:27-28
+            b_reps.append(conv[0](F.pad(b_emb, (0, g - 1))).permute(0, 2, 1))
+        mu = torch.stack([k.mu for k in self.kernels.kernels]).float()          # live parameters: gradkernels trains them (ConvKNRM.py:22)
+        sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
+        feats = engine.KernelPool.apply(torch.stack(a_reps, dim=1), torch.stack(b_reps, dim=1), query_sentence, sentence, mu, sigma,
+                                        bool(self.p["crossmatch"]))
+        return self.combine(feats)
+
+    def _forward_train_aten(self, sentence, query_sentence):
+        """The reference's arithmetic (ConvKNRM.py:42-77, common.py:195-221) as ATen ops under autograd: the checker of the HIP
+        training path in the tests, and the route of geometries the kernel-pooling kernel does not take."""
         import torch.nn.functional as F
 
         engine._need_gpu(sentence, query_sentence, self.embeddings.weight)
         a_emb, b_emb = self.embeddings(query_sentence).permute(0, 2, 1), self.embeddings(sentence).permute(0, 2, 1)
         a_reps, b_reps = [], []
         for g, conv in enumerate(self.convs, start=1):
-            a_reps.append(conv[0](F.pad(a_emb, (0, g - 1))).permute(0, 2, 1))   # ConstantPad1d((0, g - 1), 0), ConvKNRM.py:27-28
+            a_reps.append(conv[0](F.pad(a_emb, (0, g - 1))).permute(0, 2, 1))
             b_reps.append(conv[0](F.pad(b_emb, (0, g - 1))).permute(0, 2, 1))
         pairs = [(a, b) for a in a_reps for b in b_reps] if self.p["crossmatch"] else list(zip(a_reps, b_reps))
         q_pad, d_pad = (query_sentence == 0)[:, :, None], (sentence == 0)[:, None, :]      # extractor.pad == 0
@@ -72,7 +94,7 @@ class ConvKNRM_class(nn.Module):
             sim = a.bmm(b.permute(0, 2, 1)) / den
             sims.append(sim.masked_fill(q_pad, 0.0).masked_fill(d_pad, 0.0))
         simmats = torch.stack(sims, dim=1)                                   # [B, VIEWS, Q, L]
-        mu = torch.stack([k.mu for k in self.kernels.kernels]).float()          # live parameters: gradkernels trains them (ConvKNRM.py:22)
+        mu = torch.stack([k.mu for k in self.kernels.kernels]).float()
         sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
         adj = simmats[:, None] - mu.view(1, -1, 1, 1, 1)
         kernels = torch.exp(-0.5 * adj * adj / sigma.view(1, -1, 1, 1, 1) / sigma.view(1, -1, 1, 1, 1))   # [B, K, VIEWS, Q, L]
@@ -97,8 +119,7 @@ class ConvKNRM(Reranker):
         return self.model
 
     def score(self, d):
-        q, idf = d["query"], d["query_idf"]
-        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+        return self._score_pos_neg(d)
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

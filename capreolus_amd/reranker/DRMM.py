@@ -63,7 +63,9 @@ class DRMM_class(nn.Module):
         trainable inputs (DRMM.py:22 freezes the embedding); the 30 -> 5 -> 1 net, the gate and the output layer --
         a few hundred flops per pair -- stay under autograd (DRMM.py:106-114)."""
         w = self.embedding.weight
-        if (query_sentence < 0).any():
+        # (inside a HIP graph capture - PytorchTrainer's captured training step - a device -> host read is not allowed: there the
+        # kernel's status word carries the same error, raised when the trainer reads it at the end of the iteration)
+        if not torch.cuda.is_current_stream_capturing() and (query_sentence < 0).any():
             raise IndexError("index out of range in self: DRMM cannot score an OOV (negative) query term id")
         feats = engine.drmm_features(query_sentence, sentence, self._packed.get(w), w.shape[0], w.shape[1], self._bin_edges(w.device),
                                      self.hist_type)
@@ -100,8 +102,7 @@ class DRMM(Reranker):
         return self.model
 
     def score(self, d):
-        q, idf = d["query"], d["query_idf"]
-        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+        return self._score_pos_neg(d)
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

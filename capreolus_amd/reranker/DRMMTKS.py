@@ -68,8 +68,7 @@ class DRMMTKS(Reranker):
         return self.model
 
     def score(self, d):
-        q, idf = d["query"], d["query_idf"]
-        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+        return self._score_pos_neg(d)
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

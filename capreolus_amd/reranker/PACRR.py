@@ -54,10 +54,31 @@ class PACRR_class(nn.Module):
 
 
     def _forward_train(self, doc, query, query_idf):
-        """Training step (reference trainer/pytorch.py:96-99 -> PACRR.score): the part that touches the embedding table - the
-        [B, Q, L] similarity matrix - is the HIP kernel (capamd_similarity_matrix; the table is frozen, no gradient flows
-        through it); the trainable part (PACRR.py:68-78: zero padding, the n-gram Conv2d, ReLU, max over filters, k-max over
-        the document; :46-54: idf softmax, combine) runs under autograd on that matrix, at training batch sizes."""
+        """Training step (reference trainer/pytorch.py:96-99 -> PACRR.score), on HIP kernels end to end up to the three small linear
+        layers: the [B, Q, L] similarity matrix (capamd_similarity_matrix; the table is frozen, no gradient flows through it), then
+        the trainable stage of PACRR.py:68-78 - zero padding, the n-gram Conv2d, ReLU, max over filters, k-max over the document -
+        forward with the winners' coordinates and backward into the convolution weights (pacrr_train.hip through
+        `engine.PacrrConvMax`).  The idf softmax and `combine` (:46-54) run under autograd on the [B, Q, n] features.  Geometries
+        beyond that kernel's limits keep the reference's op sequence (`_forward_train_aten`)."""
+        import torch.nn.functional as F
+
+        w = self.embedding.weight
+        sim = engine.similarity_matrix(query, doc, self._packed.get(w), w.shape[0], w.shape[1])
+        B, Q, L = sim.shape
+        p = self.p
+        if Q > 8 or L > 1024 or p["maxgram"] > 3 or p["kmax"] > 4 or p["nfilters"] > 256 or L < p["kmax"]:
+            return self._forward_train_aten(doc, query, query_idf)
+        conv_w = torch.cat([m.conv.weight.reshape(-1) for m in self.ngrams])
+        conv_b = torch.cat([m.conv.bias.reshape(-1) for m in self.ngrams])
+        feats = [engine.PacrrConvMax.apply(sim, conv_w, conv_b, p["mingram"], p["maxgram"], p["nfilters"], p["kmax"])]
+        if p["idf"]:
+            feats.append(F.softmax(query_idf.float(), dim=1).view(B, Q, 1))
+        scores = torch.cat(feats, dim=2).reshape(B, -1)
+        return self.combine(scores)
+
+    def _forward_train_aten(self, doc, query, query_idf):
+        """The trainable stage as the reference's ATen op sequence under autograd on the HIP similarity matrix: the checker of the
+        HIP training path in the tests, and the route of geometries `engine.PacrrConvMax` does not take."""
         import torch.nn.functional as F
 
         w = self.embedding.weight
@@ -89,8 +110,7 @@ class PACRR(Reranker):
         return self.model
 
     def score(self, d):
-        q, idf = d["query"], d["query_idf"]
-        return [self.model(d["posdoc"], q, idf).view(-1), self.model(d["negdoc"], q, idf).view(-1)]
+        return self._score_pos_neg(d)
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)

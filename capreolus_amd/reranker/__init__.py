@@ -43,6 +43,16 @@ class Reranker:
     def test(self, d):
         raise NotImplementedError
 
+    def _score_pos_neg(self, d):
+        """`score(d)` of the interaction models (reference e.g. KNRM.py:87-94): the positive and the negative document of every training
+        pair through ONE model call - documents are independent rows, so the scores are those of two calls, at half the launches of a
+        training step (a batch-32 step is launch-bound: PytorchTrainer replays it as one HIP graph, this halves its nodes)."""
+        import torch
+
+        q, idf, pos = d["query"], d["query_idf"], d["posdoc"]
+        both = self.model(torch.cat([pos, d["negdoc"]]), torch.cat([q, q]), torch.cat([idf, idf])).view(-1)
+        return [both[: pos.shape[0]], both[pos.shape[0]:]]
+
     def test_resident(self, store, pair_q, pair_d):
         """Scores (query row, document row) pairs of a device-resident `capreolus_amd.feeder.CandidateStore`.
         Default for the interaction models: the id rows are gathered ON THE DEVICE from the store's int32 tables (no host

@@ -248,8 +248,7 @@ class PytorchTrainer:
             return None
         for k, v in tens.items():
             gs["static"][k].copy_(v, non_blocking=True)
-        with engine.deferred_status(self.device):
-            gs["graph"].replay()
+        gs["graph"].replay()       # (the kernels' status word is read once per iteration, by single_train_iteration)
         return gs["loss"].detach().clone()
 
     def single_train_iteration(self, reranker, train_dataloader, cur_iter=1):
@@ -258,8 +257,16 @@ class PytorchTrainer:
         compute in fp32 whatever `amp` says."""
         n_batch_per_iter = self.n_batch_per_iter
         cur_step = cur_iter * n_batch_per_iter
-        losses, since_update = [], 0
         graphed = self._graph_allowed()
+        if graphed:      # no device -> host read inside the iteration: data-dependent errors of the kernels are raised once, after it
+            from .. import engine
+
+            with engine.deferred_status(self.device):
+                return self._train_batches(reranker, train_dataloader, n_batch_per_iter, cur_step, True)
+        return self._train_batches(reranker, train_dataloader, n_batch_per_iter, cur_step, False)
+
+    def _train_batches(self, reranker, train_dataloader, n_batch_per_iter, cur_step, graphed):
+        losses, since_update = [], 0
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
             done = self._graphed_step(reranker, batch) if graphed else None

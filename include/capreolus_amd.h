@@ -81,7 +81,9 @@ int capamd_similarity_matrix(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_id
  * combine (KNRM.py:27-34): hidden == 0 -> score = w1[0,:K]·f + b1[0]            ("singlefc")
  *                          hidden  > 0 -> score = w2[0,:hidden]·tanh(w1·f + b1) + b2[0]
  *                          scoretanh != 0 applies a final tanh.
- * out fp32 [B].  workspace / flags: see CAPAMD_LAUNCH_* and capamd_interaction_workspace_bytes above. */
+ * out fp32 [B].  workspace / flags: see CAPAMD_LAUNCH_* and capamd_interaction_workspace_bytes above.
+ * L: the document's term list lives in LDS (8 bytes per position beside ~11 KiB of fixed parts): documents beyond ~19,000 positions
+ * do not fit the 160 KiB of a workgroup and are refused with CAPAMD_ERR_ARG (DRMM alike). */
 int capamd_knrm_forward(const int64_t* q_ids /*[B,Q]*/, const int64_t* d_ids /*[B,L]*/, int B, int Q, int L,
                         const float* packed, int64_t V, int D, const float* mu, const float* sigma, int K,
                         const float* w1, const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
@@ -299,6 +301,38 @@ int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, const float
                          const float* conv_b, int use_idf, int combine, int nonlinearity, const float* w1, const float* b1,
                          const float* w2, const float* b2, const float* w3, const float* b3, float* out, int* status,
                          void* stream);
+
+/* ---- differentiable kernel pooling over dense n-gram representations (ConvKNRM's training step) ---------
+ * The part of ConvKNRM_class.forward between its trainable n-gram convolutions and `combine`, capreolus/reranker/ConvKNRM.py:53-76
+ * (StackedSimilarityMatrix common.py:195-221 + RbfKernelBank common.py:224-250), forward and backward - so that the reference
+ * trainer's loss.backward() (trainer/pytorch.py:96-107) reaches the convolutions through HIP kernels, not ATen ops.
+ * qrep fp32 [B, GQ, Q, F] / drep fp32 [B, GD, L, F]: the GQ / GD n-gram views of query and document (F % 4 == 0, F <= 256);
+ * q_ids / d_ids: the token ids (pad = 0: masked positions); crossmatch != 0: every (query view, document view) pair, V = GQ GD
+ * views (v = gq GD + gd), else the matching ones (GQ == GD, V = GD).  (crossmatch ? GQ : 1) * Q <= 24, K <= 16.
+ * forward:  feat fp32 [B, K V] (feature k V + v, the reference's kernels.reshape(B, K V, Q, L) order); ksum fp32 [B, GD, T, K] and
+ *           rowsum fp32 [B, GD, T] (T = (crossmatch ? GQ : 1) Q) are what the backward needs of it.
+ * backward: gfeat fp32 [B, K V] -> dq_part fp32 [B, GD, T, F] (the caller sums over GD the blocks that share a query view: with
+ *           crossmatch view gq = t / Q of every gd; without, block gd holds query view gd), dd fp32 [B, GD, L, F],
+ *           dmu_part / dsigma_part fp32 [B GD, K] (summed over their first axis by the caller). */
+int capamd_kernel_pool_forward(const float* qrep, const float* drep, const int64_t* q_ids, const int64_t* d_ids, int B, int GQ, int GD, int Q,
+                               int L, int F, int crossmatch, const float* mu, const float* sigma, int K, float* feat, float* ksum,
+                               float* rowsum, void* stream);
+int capamd_kernel_pool_backward(const float* qrep, const float* drep, const int64_t* q_ids, const int64_t* d_ids, int B, int GQ, int GD, int Q,
+                                int L, int F, int crossmatch, const float* mu, const float* sigma, int K, const float* gfeat,
+                                const float* ksum, const float* rowsum, float* dq_part, float* dd, float* dmu_part, float* dsigma_part,
+                                void* stream);
+
+/* ---- PACRR's trainable convolution stage with its gradient (PACRR's training step) --------------------------
+ * PACRRConvMax2dModule.forward, capreolus/reranker/PACRR.py:68-78, for every n-gram size mingram..maxgram at once: zero padding,
+ * Conv2d(1 -> nfilters, ng x ng) over the similarity matrix sim fp32 [B, Q, L] (capamd_similarity_matrix), ReLU, max over the
+ * filters, the kmax largest values over the document - and, for the reference trainer's loss.backward() (trainer/pytorch.py:96-107),
+ * the coordinates of every value.  conv_w / conv_b as in capamd_pacrr_forward.  Q <= 8, L <= 1024, maxgram <= 3, kmax <= 4.
+ * forward:  top fp32 / pos int32 / filt int32 [B, Q, n_ngrams * kmax]: value, document position, filter (-1: a ReLU zero).
+ * backward: gtop fp32 [B, Q, n_ngrams * kmax] -> dconv_w, dconv_b (laid out like conv_w / conv_b; summed in a fixed order). */
+int capamd_pacrr_convmax_forward(const float* sim, int B, int Q, int L, int mingram, int maxgram, int nfilters, int kmax, const float* conv_w,
+                                 const float* conv_b, float* top, int32_t* pos, int32_t* filt, void* stream);
+int capamd_pacrr_convmax_backward(const float* sim, int B, int Q, int L, int mingram, int maxgram, int nfilters, int kmax, const float* gtop,
+                                  const int32_t* pos, const int32_t* filt, float* dconv_w, float* dconv_b, void* stream);
 
 /* ---- ranking of scored candidate lists ---------------------------------------------
  * What follows the scoring call in the reference, kept on the device:

@@ -61,6 +61,11 @@ for name, r in (("KNRM", KNRM({}, ext)), ("DRMM", DRMM({}, ext)), ("DRMMTKS", DR
     eager_ms, eager_wall, loss = timed(step)
     rec = {"model": name, "batch": B, "docs_scored_per_step": 2 * B, "eager_ms_per_step": round(eager_ms, 3), "loss_first": round(float(loss0.detach()), 5),
            "loss_last_eager": round(float(loss.detach()), 5)}
+    # (the eager steps' autograd graphs must be gone before a capture: their AccumulateGrad nodes belong to the default stream)
+    del loss, loss0
+    opt.zero_grad(set_to_none=True)
+    del opt, m
+    r = type(r)({}, ext)
     # the same step through the trainer's captured HIP graph (PytorchTrainer.single_train_iteration's route: one replay per batch)
     tr = PytorchTrainer({"batch": B, "itersize": B})
     tr.device, tr.scaler, tr.loss = dev, None, tr.pair_hinge_loss

@@ -214,9 +214,13 @@ def test_bert_maxp_end_to_end(name, dt):
     print(f"{name} {dt}: max abs err on passage logits {err:.2e} (reference autocast {amp_err:.2e}); relative to the logit scale {err / scale:.2e}, "
           f"element-wise {rel_err(plog.cpu().numpy(), ref_l).max():.2e}")
     assert err <= bound, (name, dt, err, amp_err)
-    # the north-star 1e-3 holds where the logits are of the size the `base` fixture has
-    if name == "base" and dt == "fp16":
-        assert rel_err(plog.cpu().numpy(), ref_l).max() <= FP16_E2E_TOL
+    # ... and, whatever the reference's autocast does on a fixture, a FIXED absolute bound on the passage logit per operand type
+    # (observed: fp16 <= 1.2e-2, bf16 <= 1.1e-1 on the four fixtures): a regression in the attention / ring / folded-LayerNorm kernels
+    # cannot hide behind a generous yardstick
+    assert err <= (1.6e-2 if dt == "fp16" else 1.5e-1), (name, dt, err)
+    # the north-star 1e-3 relative (fp16; 2e-2 with bf16 operands, 8 mantissa bits) on every fixture whose logits are of order 1 or more
+    if scale >= 1.0:
+        assert rel_err(plog.cpu().numpy(), ref_l).max() <= (FP16_E2E_TOL if dt == "fp16" else BF16_E2E_TOL), (name, dt)
     # rank order of the documents by MaxP score: wherever two reference scores are further apart than twice the error bound
     got_doc, ref_doc = eng_out.cpu().numpy(), c["ref_max"]
     for i in range(B):

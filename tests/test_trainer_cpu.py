@@ -223,7 +223,8 @@ def test_abi_entries_reject_null_pointers():
     # geometry limits are refused the same way (device pointers are never dereferenced on the host: any aligned non-null value will do)
     P = 0x10000
     knrm = lambda Q=4, L=800, D=300, K=11, hidden=0, V=1000: lib.capamd_knrm_forward(P, P, 8, Q, L, P, V, D, P, P, K, P, P, hidden, P, P, 0, P, P, None, 0, 0, None)
-    for kw in ({"D": 320}, {"K": 13}, {"K": 0}, {"Q": 0}, {"L": 0}, {"L": 32769}, {"hidden": -1}, {"hidden": 10**6}, {"V": 0}, {"V": 2**31}):
+    # ({"L": 24000}: the term list of such a document does not fit the 160 KiB of LDS a workgroup can have - refused, not mis-launched)
+    for kw in ({"D": 320}, {"K": 13}, {"K": 0}, {"Q": 0}, {"L": 0}, {"L": 32769}, {"L": 24000}, {"hidden": -1}, {"hidden": 10**6}, {"V": 0}, {"V": 2**31}):
         assert knrm(**kw) == _lib.ERR_ARG, kw
     pacrr = lambda Q=4, L=800, maxgram=3, kmax=2, nf=32, comb=32: lib.capamd_pacrr_forward(
         P, P, P, 8, Q, L, P, 1000, 300, 1, maxgram, nf, kmax, P, P, 1, comb, 1, P, P, P, P, P, P, P, P, None)
