@@ -429,7 +429,7 @@ def pmc_traffic(args, model):
             vals = []
             for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "forward_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    if ("forward_kernel" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None, f"not measured: the rocprofv3 --pmc {counter} pass returned no rows for the kernel"
@@ -476,7 +476,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             "bound": "hbm", "kernel": kernel_of(model, big.n_pairs, args.roofline_vocab, big.row_stride), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS,
             "traffic": None,
-            "traffic_source": f"not measured in this run (--no-pmc-traffic): profiles/r02/{model}_hbm_traffic.json holds the builder-run "
+            "traffic_source": f"not measured in this run (--no-pmc-traffic): profiles/r03/{model}_hbm_traffic.json holds the builder-run "
                               "FETCH_SIZE x2 + WRITE_SIZE per launch of this leg and of the headline leg",
             "leg": f"uniform term ids over a {args.roofline_vocab}-row table ({args.roofline_vocab * big.row_stride * 4 / 1e9:.1f} GB packed, 20x the 256 MB "
                    "Infinity Cache), 64 x 1000 pairs per launch, 2 alternating batches: HBM is the binding resource",

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r02
+# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r03
 set -eu
-D=profiles/${1:-r02}
+D=profiles/${1:-r03}
 G=gpurun_out
 mkdir -p $D
 for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_pingpong drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; done
@@ -31,4 +31,5 @@ cp $G/mfma_power.txt $D/mfma_power.txt
 cp $G/pytest_gpu.log $D/pytest_gpu.log
 [ -f $G/train_steps.jsonl ] && cp $G/train_steps.jsonl $D/train_steps.jsonl
 [ -f $G/predict_e2e.json ] && cp $G/predict_e2e.json $D/predict_e2e.json
+[ -f $G/knrm_pipes.txt ] && cp $G/knrm_pipes.txt $D/knrm_pipes.txt
 ls -la $D | tail -40

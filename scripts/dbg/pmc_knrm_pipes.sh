@@ -8,7 +8,7 @@ import csv, glob, collections
 f = glob.glob("/tmp/pk/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f[0])) if f else []:
-    if "knrm_forward" in r["Kernel_Name"] or "drmm_forward" in r["Kernel_Name"]:
+    if "knrm_forward" in r["Kernel_Name"] or "drmm_forward" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print({k: round(sum(v) / len(v)) for k, v in acc.items()}, "launches", max([len(v) for v in acc.values()] or [0]))
 PY

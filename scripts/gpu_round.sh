@@ -1,5 +1,6 @@
 #!/bin/bash
-# One GPU-box session (round 2): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/.
+# One GPU-box session (round 3): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
+# (scripts/collect_profiles.sh r03 copies what is kept into profiles/r03/).
 set -u
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
@@ -17,7 +18,7 @@ timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-oth
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json
 CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
-for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
+for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cat gpurun_out/bench_cedrknrm.json
 PYTHONPATH=$R timeout 300 python $R/scripts/predict_e2e_bench.py 2>/dev/null | tail -1 > gpurun_out/predict_e2e.json; cat gpurun_out/predict_e2e.json
 PYTHONPATH=$R timeout 300 python $R/scripts/train_step_bench.py 2>/dev/null | grep "^{" > gpurun_out/train_steps.jsonl; cat gpurun_out/train_steps.jsonl
@@ -60,3 +61,5 @@ python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&
 timeout 200 ./scripts/ubench/mfma_power > gpurun_out/mfma_power.txt 2>&1; cat gpurun_out/mfma_power.txt
 [ -x ./scripts/ubench/hbm_read ] && { timeout 200 ./scripts/ubench/hbm_read > gpurun_out/hbm_read.txt 2>&1; cat gpurun_out/hbm_read.txt; }
 ls gpurun_out/prof/
+# which pipe binds the KNRM headline kernel (streaming kernel): LDS-array cycles, VALU / LDS issue activity, wait buckets
+cd $R; bash scripts/dbg/pmc_knrm_pipes.sh > gpurun_out/knrm_pipes.txt 2>&1; cat gpurun_out/knrm_pipes.txt

@@ -1,4 +1,4 @@
-"""Turns the rocprofv3 --pmc CSVs of scripts/gpu_round.sh into the per-launch figures quoted in DESIGN.md and profiles/r02/*.json:
+"""Turns the rocprofv3 --pmc CSVs of scripts/gpu_round.sh into the per-launch figures quoted in DESIGN.md and profiles/<round>/*.json:
 HBM-side traffic of the KNRM / DRMM kernels (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), L2 hit rates, and the MFMA
 duty cycle of the BERT GEMM kernels."""
 import collections
@@ -15,7 +15,7 @@ def counters(sub, match):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(root, sub, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if match in r["Kernel_Name"]:
+            if any(m in r["Kernel_Name"] for m in match):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
@@ -25,9 +25,9 @@ for model in ("knrm", "drmm"):
     rec = {}
     for leg in ("", "_roofline_leg"):
         name = model + leg
-        f = counters(name + "_fetch", "forward_kernel").get("FETCH_SIZE")
-        w = counters(name + "_write", "forward_kernel").get("WRITE_SIZE")
-        t = counters(name + "_tcc", "forward_kernel")
+        f = counters(name + "_fetch", ("forward_kernel", "stream_kernel")).get("FETCH_SIZE")
+        w = counters(name + "_write", ("forward_kernel", "stream_kernel")).get("WRITE_SIZE")
+        t = counters(name + "_tcc", ("forward_kernel", "stream_kernel"))
         if not f or not w:
             continue
         hit, miss = t.get("TCC_HIT_sum", (0, 0))[0], t.get("TCC_MISS_sum", (0, 0))[0]
@@ -42,8 +42,8 @@ for model in ("knrm", "drmm"):
     print(model, json.dumps(rec, indent=1)[:1500])
 for sub in ("bert_mfma", "bert_mfma_pingpong"):
     for kern in ("gemm_ring_kernelILi1", "gemm_ring_kernelILi3", "gemm_ring_kernelILi5", "gemm_pingpong_kernelILi1", "gemm_pingpong_kernelILi3", "gemm_pingpong_kernelILi5",
-                 "attention_persistent"):
-        c = counters(sub, kern)
+                 "attention_persistent", "attention_s256"):
+        c = counters(sub, (kern,))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
             busy, active = c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / 1024.0, c["GRBM_GUI_ACTIVE"][0] / 8.0
