@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank scores --queries queries per step; strong: the step's --queries queries are divided over the ranks")
     ap.add_argument("--resident", action="store_true", help="score through the device-resident int32 candidate store (row N1)")
+    ap.add_argument("--per-pair", action="store_true",
+                    help="KNRM / DRMM: score the step with the per-pair kernels (one fused kernel, every pair on its own) instead of as whole candidate lists")
     ap.add_argument("--bert-dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit operand type of the BERT encoder: bf16 is what BASELINE.json configs[3] names; fp16 is the engine's default outside the "
                          "bench (three more mantissa bits: closer to the reference's fp32 scores, ~3 %% slower - more operand bits toggle per MFMA)")
@@ -251,6 +253,9 @@ class InteractionLeg:
         self.out = out = torch.empty(self.n_pairs, dtype=torch.float32, device=dev)
         launch = args.launch_docs or self.n_pairs
         self.slices = [(i, min(i + launch, self.n_pairs)) for i in range(0, self.n_pairs, launch)]
+        # whole candidate lists (csrc/lists.hip) unless asked otherwise; launches of single lists, the resident store and the HBM-bound
+        # leg (uniform ids: a list's documents share almost no vocabulary) stay on the per-pair kernels
+        self.lists = not args.per_pair and not args.resident and not uniform and launch % args.docs == 0 and launch >= 4 * args.docs
         D = self.D
         if model == "knrm":
             mu, sigma = m.kernels.stacked()
@@ -262,6 +267,11 @@ class InteractionLeg:
 
                 def launch_one(bi, lo, hi):
                     engine.knrm_forward_indexed(tabs[bi][0], tabs[bi][1], pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+            elif self.lists:
+                def launch_one(bi, lo, hi):      # the step's candidate lists (args.docs documents per query) as lists
+                    b = self.batches[bi]
+                    engine.knrm_forward_lists(np.arange(0, hi - lo + 1, args.docs), packed, V, D, mu, sigma, w1, b1, query=b["query"][lo:hi],
+                                              doc=b["posdoc"][lo:hi], out=out[lo:hi], check=False)
             else:
                 def launch_one(bi, lo, hi):
                     b = self.batches[bi]
@@ -275,8 +285,12 @@ class InteractionLeg:
 
             def launch_one(bi, lo, hi):
                 b = self.batches[bi]
-                engine.drmm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
-                                    f2w, f2b, ow, ob, out=out[lo:hi], check=False)
+                if self.lists:
+                    engine.drmm_forward_lists(np.arange(0, hi - lo + 1, args.docs), b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
+                                              f2w, f2b, ow, ob, query=b["query"][lo:hi], doc=b["posdoc"][lo:hi], out=out[lo:hi], check=False)
+                else:
+                    engine.drmm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
+                                        f2w, f2b, ow, ob, out=out[lo:hi], check=False)
         self.launch_one = launch_one
         n_side = min(args.launch_streams, len(self.slices)) if len(self.slices) > 1 else 1
         self.side = [torch.cuda.Stream(device=dev) for _ in range(n_side)] if n_side > 1 else []
@@ -367,6 +381,20 @@ class InteractionLeg:
         return (self.L * 8 + self.Q * 8 + (distinct + self.Q) * self.row_stride * 4 + 4 + (4 * self.Q if self.model == "drmm" else 0), nonpad,
                 distinct)
 
+    def bytes_requested_per_pair_lists(self):
+        """The whole-list route's requests per pair (csrc/lists.hip): the id row twice (mark pass, pooling pass), one byte-map store and one
+        16-byte table lookup per real position, and the list's distinct terms' packed rows (gathered once per LIST) spread over its documents."""
+        docs = self.args.docs
+        nonpad = rows = 0
+        for b in self.batches:
+            d = b["posdoc"].view(-1, docs * self.L)
+            nonpad += int((d > 0).sum().item())
+            for i in range(d.shape[0]):
+                u = torch.unique(d[i])
+                rows += int((u > 0).sum().item())
+        n = len(self.batches) * self.n_pairs
+        return 2 * self.L * 8 + self.Q * 8 + (nonpad / n) * 17 + (rows / n) * self.row_stride * 4 + 4, rows / (n / docs)
+
     def check_against_oracle(self, n):
         """The scores the timed loop left in `out` (its last step's batch) against the C oracle on the first n pairs; returns what the
         CPU baseline needs to time the same sample."""
@@ -454,6 +482,8 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     req_b, nonpad, distinct = leg.bytes_requested_per_pair()
     abytes = algorithmic_bytes_per_pair(model, Q, L, D)
     launches = len(leg.slices)
+    if leg.lists:
+        req_lists, distinct_per_list = leg.bytes_requested_per_pair_lists()
     headline = {
         "ids": "uniform" if args.uniform_ids else "Zipf(1.1)", "vocab": args.vocab, "kernel": kernel_of(model, n_pairs // launches, args.vocab, leg.row_stride, args.resident),
         "kernel_ms": dev_s * 1e3 / launches,
@@ -465,6 +495,14 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 "over the per-step device time (one HIP event pair around the timed steps; in a multi-GPU run it includes the all_gather). "
                 "Zipf ids hit L2 / Infinity Cache, so neither is an HBM rate",
     }
+    if leg.lists:
+        headline.update({
+            "route": f"whole candidate lists (capamd_{model}_forward_lists): per list every distinct term's row gathered once, documents pooled from 16-byte lookups",
+            "kernel": f"lists_mark_kernel + lists_sims_kernel<5> + lists_{model}_pool_kernel", "mean_distinct_terms_per_list": distinct_per_list,
+            "requested_bytes_per_pair": req_lists, "requested_GBps": n_pairs * req_lists / dev_s / 1e9,
+            "per_pair_kernel_requested_bytes_per_pair": req_b,
+            "note": headline["note"] + "; on this route the rows of a LIST's distinct terms are gathered once (requested_bytes_per_pair counts them spread over the "
+                                       "list's documents; per_pair_kernel_requested_bytes_per_pair is what the per-pair kernels - bench.py --per-pair - ask for)"})
     roof = None
     if not args.no_roofline_leg and world == 1:       # (N > 1: every rank does the same work; the roofline leg is an N = 1 measurement)
         # HBM-bound leg: uniform ids over a table 20x the Infinity Cache -> (almost) every gathered row comes from HBM
@@ -514,6 +552,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             "workload": f"{model.upper()} inference (BASELINE.json configs[{1 if model == 'knrm' else 2}]): qlen={Q} dlen={L} "
                         f"embed={D} vocab={args.vocab}, {args.docs} docs/query x {per_rank_q} queries per step per GPU, "
                         f"{'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, lognormal doc lengths, "
+                        + ("scored as whole candidate lists, " if leg.lists else "") +
                         f"{launches} launch(es) per step" + (f" round-robin over {len(leg.side)} HIP streams" if leg.side else "") + (", replayed as one captured HIP graph" if leg.graphs else "") +
                         f", {len(leg.batches)} distinct batches in rotation",
             "pairs_per_step_per_gpu": n_pairs,
@@ -558,7 +597,7 @@ def main():
             torch.cuda.empty_cache()
             rec["also"] = []
             # ... and the row-N4 siblings (short legs: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)
-            for leg in (lambda: interaction_record(args, ctx, "drmm", short, 2, 64, with_cpu=not args.no_cpu_baseline),
+            for leg in (lambda: interaction_record(args, ctx, "drmm", args.steps, 3, 64, with_cpu=not args.no_cpu_baseline),     # (a 1.3 ms step: as many as the headline)
                         lambda: bench_bert(args, ctx, 5, 2, with_cpu=not args.no_cpu_baseline),
                         lambda: bench_sibling(args, ctx, "drmmtks", 5, 2, with_cpu=False),
                         lambda: bench_sibling(args, ctx, "pacrr", 5, 2, with_cpu=False),

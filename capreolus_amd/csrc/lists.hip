@@ -1,0 +1,549 @@
+// KNRM / DRMM over whole CANDIDATE LISTS (one query, its first-stage documents) for gfx950 - what PytorchTrainer.predict scores
+// (reference capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query lists, sampler/__init__.py:222-233; RerankTask hands it
+// up to 1000 documents per query, task/rerank.py:22-23).
+//
+// The per-pair kernels (knrm.hip, drmm.hip, interaction_stream.cuh) gather one packed row per distinct term of every DOCUMENT: 179 rows
+// = 229 KB per pair on the benchmark's lists, 14.7 GB per 64,000 pairs - and that gather is what they are bound by.  But the similarity
+// of a document term to the query depends on (query, term) only, and the 1000 documents of a list share their vocabulary: a list's
+// 303,000 tokens are ~50,000 distinct terms.  So per list:
+//   1  mark    every document of the list flags its real term ids in a byte map over the vocabulary (plain byte stores: racing writers
+//              write the same value; a flag already set is not written again)
+//   2  sims    per (list, block of 512 vocabulary ids): collect the flagged ids and for every one of them gather its packed row ONCE,
+//              the four similarities to the list's query by the SAME arithmetic as the per-pair kernels (rows_dot / sim_from_dots:
+//              bit-identical values) -> table[id]: KNRM the four floats, DRMM the four histogram bins (a byte each: bin | exact-match
+//              bit) - the binning is done once per distinct term, not once per position.  Workgroups are numbered so that an XCD
+//              works on ONE id block of ALL lists at a time (workgroup i runs on XCD i % 8): the lists share most of a block's rows,
+//              so the rows come from that XCD's L2.
+//   3  pool    every document: its ids are requested together, then their table entries (two memory round trips per document - the
+//              per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a lane per (position, query term), K exponentials
+//              into per-lane sums; DRMM: a lane per position, four integer bin counts.  Passes of padding only (a document's tail) are
+//              skipped after the id load.  Then the models' per-pair tails.  An XCD works on one list at a time: the hot part of the
+//              list's table sits in its L2 (DRMM's 1.6 MB table all of it).
+// Rows gathered: 4.1 GB instead of 14.7, most of them L2 hits.
+// DRMM's bin counts are integers of bit-identical similarities: bit-exact with the per-pair kernels.  KNRM sums the same kernel values
+// in another order (per lane over its positions, then over the lanes): equal to fp32 rounding of the sums (1e-6 relative).
+// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V = 400,001);
+// lists are processed in chunks of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits as the per-pair entries.
+#include "capreolus_amd.h"
+#include "interaction.cuh"
+
+using namespace capamd;
+
+namespace {
+
+constexpr int kListChunk = 64;            // lists per launch group (their start / length travel as kernel arguments)
+constexpr int kSimsIds = 512;             // vocabulary ids one workgroup of the sims pass scans
+constexpr int kMaxK = 12, kMaxHidden = 64, kMaxBins = 64, kMaxNodes = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct ListGeom {
+  int start[kListChunk];   // first pair of the list
+  int len[kListChunk];     // its documents
+};
+
+struct ListsArgs {
+  IdSource ids;
+  int Q, L;
+  const float* packed;
+  int64_t V, Vp;           // Vp: V rounded up to kSimsIds (row stride of flags / table / idlist)
+  uint8_t* flags;          // [lists][Vp]
+  float4* table;           // [lists][Vp] entry of a flagged id (written for flagged ids only): KNRM 4 floats, DRMM 4 bytes (at 4 B stride)
+  int* status;
+  int nl, longest;         // lists in this launch group, documents of the longest
+  const float* edges;      // DRMM: histogram bin edges
+  int nbins;
+};
+
+// workgroup -> (list, document) of the mark / pool launches.  With 8 or more lists, XCD x (workgroups i % 8 == x) takes the lists
+// 8 k + x, one at a time: what a list's documents share (flags; rank map and table) stays in that XCD's L2.
+__device__ __forceinline__ bool list_doc_of(const ListsArgs& a, int& l, int& doc) {
+  const int bid = blockIdx.x;
+  if (a.nl >= 8) {
+    const int k = bid >> 3;
+    doc = k % a.longest;
+    l = (k / a.longest) * 8 + (bid & 7);
+  } else {
+    doc = bid % a.longest;
+    l = bid / a.longest;
+  }
+  return l < a.nl;
+}
+unsigned list_doc_grid(int nl, int longest) { return (unsigned)((nl >= 8 ? (nl + 7) / 8 * 8 : nl) * longest); }
+
+__device__ __forceinline__ int64_t doc_id_at(const PairIds& ids, int j) { return ids.d32 ? (int64_t)ids.d32[j] : ids.d64[j]; }
+
+// ---- 1: mark -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g) {
+  int l, doc;
+  if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
+  const PairIds ids = pair_ids(a.ids, g.start[l] + doc, a.Q, a.L);
+  uint8_t* f = a.flags + (int64_t)l * a.Vp;
+  bool bad = false;
+  for (int j = threadIdx.x; j < a.L; j += 256) {
+    const int64_t id = doc_id_at(ids, j);
+    if (id >= a.V) bad = true;
+    else if (id > 0 && !f[id]) f[id] = 1;
+  }
+  if (bad) atomicOr(a.status, kErrDocIdRange);
+}
+
+// ---- 2: sims -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int list_bin_of(float x, const float* edges, int nbins) {   // as drmm.hip: exactly the reference's `x < edge`
+  int bi = (int)floorf((x + 1.f) * (0.5f * (float)nbins));
+  bi = bi < 0 ? 0 : (bi > nbins ? nbins : bi);
+  const float e_lo = edges[bi > 0 ? bi - 1 : 0], e_hi = edges[bi < nbins ? bi : nbins - 1];
+  if (bi > 0 && x < e_lo) {
+    --bi;
+    while (bi > 0 && x < edges[bi - 1]) --bi;
+  } else if (bi < nbins && !(x < e_hi)) {
+    ++bi;
+    while (bi < nbins && !(x < edges[bi])) ++bi;
+  }
+  return bi;
+}
+constexpr unsigned kBinExact = 0x80;      // entry byte: bin (nbins = above the last edge) | kBinExact when 0.999 < s < 1.001 (drmm.hip's exact-match bin)
+
+template <int NV, bool BINS>
+__global__ __launch_bounds__(256) void lists_sims_kernel(ListsArgs a, ListGeom g) {
+  __shared__ __attribute__((aligned(16))) float4 qlds[kQT * kMaxNV * 16];
+  __shared__ int lst[kSimsIds];
+  __shared__ int wave_cnt[4];
+  __shared__ float edges[kMaxBins];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane16 = tid & 15, grp = tid >> 4;
+  // XCD x takes the id blocks 8 k + x, each for all lists back to back
+  const int k = blockIdx.x >> 3, l = k % a.nl, blk = (k / a.nl) * 8 + (blockIdx.x & 7);
+  if ((int64_t)blk * kSimsIds >= a.Vp) return;
+  const int id0 = blk * kSimsIds;
+  const uint32_t f2 = *reinterpret_cast<const uint16_t*>(a.flags + (int64_t)l * a.Vp + id0 + tid * 2);   // 2 ids per thread
+  // the list's query rows (LDS copy, den slot zeroed) - the same staging as the per-pair kernels
+  const PairIds ids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  QueryPass<NV> qp;
+  load_query_pass_lds<NV>(a.packed, ids, a.Q, 0, a.V, tid, 256, lane16, qlds, qp, blk == 0 ? a.status : nullptr);
+  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
+  const int n0 = (f2 & 0xff) ? 1 : 0, n1 = (f2 >> 8) ? 1 : 0;
+  int incl = n0 + n1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wave_cnt[wave] = incl;
+  __syncthreads();
+  const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  if (total == 0) return;
+  {
+    int pos = incl - n0 - n1;
+    for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+    if (n0) lst[pos++] = tid * 2;
+    if (n1) lst[pos] = tid * 2 + 1;
+  }
+  __syncthreads();
+  float* tab = reinterpret_cast<float*>(a.table + (int64_t)l * a.Vp);
+  uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
+  for (int e = grp; e < total; e += kGroupsPerWG) {
+    const int id = id0 + lst[e];
+    RowRegs<NV> d;
+    load_row<NV>(a.packed, id, lane16, d);
+    float p[kQT];
+    int qoff = 0;
+    asm volatile("" : "+v"(qoff));
+    rows_dot<NV>(d, qlds + qoff, lane16, p);
+    const float sm = sim_from_dots<NV>(p, row_den<NV>(d), qp, lane16);   // lane l: the similarity of query term l & 3
+    if (lane16 < kQT) {
+      if (BINS) {
+        const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
+        tabb[(int64_t)id * 4 + lane16] = (uint8_t)bin;
+      } else {
+        tab[(int64_t)id * 4 + lane16] = sm;
+      }
+    }
+  }
+}
+
+// ---- 3a: KNRM pooling ----------------------------------------------------------------------------------------------------------
+struct KnrmPoolArgs {
+  const float* mu;
+  const float* sigma;
+  int K;
+  const float* w1;
+  const float* b1;
+  int hidden;
+  const float* w2;
+  const float* b2;
+  int scoretanh;
+  float* out;
+};
+
+// A lane is (position slot, query term): row t of a wave (its lanes 16 t .. 16 t + 15) holds query term t of 16 positions, the four
+// waves hold 64 consecutive positions ("a trip").  A document is walked in passes of kPoolTrips trips: every id of the pass is
+// requested first, then every table entry, then the arithmetic; a pass without a real or OOV term (padding) stops after the ids.
+#ifndef CAPAMD_LISTS_TRIPS
+#define CAPAMD_LISTS_TRIPS 8
+#endif
+constexpr int kPoolTrips = CAPAMD_LISTS_TRIPS;     // 64 positions each
+
+__global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+  __shared__ float red[4][kQT][kMaxK + 2];         // per wave and query term: S[k], row sum, exact matches
+  __shared__ int n_real_s[4];
+  __shared__ float F[kMaxK];
+  int l, doc;
+  if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = wave * 16 + (lane & 15);
+  const int b = g.start[l] + doc;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
+  int64_t qid = t < a.Q ? qids.q(t) : 0;
+  if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
+  float mu[kMaxK], ck[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    const int kc = k < m.K ? k : m.K - 1;
+    const float sg = m.sigma[kc];
+    mu[k] = m.mu[kc];
+    ck[k] = (-0.5f * kLog2e) / (sg * sg);
+  }
+  float acc[kMaxK], rs = 0.f;
+  int n_one = 0, n_real = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
+  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
+  for (int j0 = 0; j0 < a.L; j0 += 64 * kPoolTrips) {
+    int id[kPoolTrips];
+    if (ids.d32) {
+#pragma unroll
+      for (int u = 0; u < kPoolTrips; ++u) {
+        const int j = j0 + u * 64 + ps;
+        id[u] = ids.d32[j < a.L ? j : a.L - 1];
+      }
+    } else {
+      int64_t w[kPoolTrips];
+#pragma unroll
+      for (int u = 0; u < kPoolTrips; ++u) {
+        const int j = j0 + u * 64 + ps;
+        w[u] = ids.d64[j < a.L ? j : a.L - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kPoolTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
+    }
+    int live = 0;
+#pragma unroll
+    for (int u = 0; u < kPoolTrips; ++u) {
+      if (j0 + u * 64 + ps >= a.L || id[u] >= a.V) id[u] = 0;
+      live |= id[u];
+    }
+    if (!__any(live != 0)) continue;         // padding only (wave-uniform)
+    float s[kPoolTrips];
+#pragma unroll
+    for (int u = 0; u < kPoolTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kPoolTrips; ++u) {
+      if (!__any(id[u] != 0)) continue;
+      if (id[u] > 0) {
+        ++n_real;
+        rs += s[u];
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) {
+          const float adj = s[u] - mu[k];
+          acc[k] += __builtin_amdgcn_exp2f(adj * adj * ck[k]);
+        }
+      } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
+        ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)
+      }
+    }
+  }
+  // the 16 lanes of a row (one query term) -> wave -> workgroup (fixed order)
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    const float v = group_allreduce(acc[k]);
+    if ((lane & 15) == 0) red[wave][t][k] = v;
+  }
+  {
+    const float r = group_allreduce(rs), no = group_allreduce((float)n_one);
+    if ((lane & 15) == 0) { red[wave][t][kMaxK] = r; red[wave][t][kMaxK + 1] = no; }
+    const float nr = group_allreduce((float)n_real);     // (every term's lanes count the same positions)
+    if (lane == 0) n_real_s[wave] = (int)nr;
+  }
+  __syncthreads();
+  if (tid < kMaxK) {
+    const int k = tid;
+    float f = 0.f;
+    if (k < m.K) {
+      const float sg = m.sigma[k], mk = m.mu[k], c = (-0.5f * kLog2e) / (sg * sg);
+      const float k0 = __builtin_amdgcn_exp2f(mk * mk * c), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
+      const int nreal = n_real_s[0] + n_real_s[1] + n_real_s[2] + n_real_s[3];
+      for (int q = 0; q < a.Q && q < kQT; ++q) {
+        float S = ((red[0][q][k] + red[1][q][k]) + red[2][q][k]) + red[3][q][k];
+        float R = ((red[0][q][kMaxK] + red[1][q][kMaxK]) + red[2][q][kMaxK]) + red[3][q][kMaxK];
+        const int no = (int)(((red[0][q][kMaxK + 1] + red[1][q][kMaxK + 1]) + red[2][q][kMaxK + 1]) + red[3][q][kMaxK + 1]);
+        const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
+        // (a pad / OOV QUERY term has similarity 0 everywhere: its real positions were looked up as 0 and are in S as K_k(0) already)
+        S += (float)nz * k0;
+        S += (float)no * k1;
+        R += (float)no;
+        f += R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
+      }
+    }
+    F[k] = f;
+  }
+  __syncthreads();
+  if (m.hidden > 0) {
+    float h = 0.f;
+    if (tid < m.hidden) {
+      h = m.b1[tid];
+      for (int k = 0; k < m.K; ++k) h = __builtin_fmaf(m.w1[tid * m.K + k], F[k], h);
+      h = m.w2[tid] * tanhf(h);
+    }
+    if (wave == 0) {
+      float sc = wave_allreduce_sum(h) + m.b2[0];
+      if (m.scoretanh) sc = tanhf(sc);
+      if (lane == 0) m.out[b] = sc;
+    }
+  } else if (tid == 0) {
+    float sc = m.b1[0];
+    for (int k = 0; k < m.K; ++k) sc = __builtin_fmaf(m.w1[k], F[k], sc);
+    if (m.scoretanh) sc = tanhf(sc);
+    m.out[b] = sc;
+  }
+}
+
+// ---- 3b: DRMM pooling ----------------------------------------------------------------------------------------------------------
+struct DrmmPoolArgs {
+  const float* idf;   // [B, Q] or the query table's [NQ, Q] in indexed mode
+  const float* edges;
+  int nbins, hist_type, gate_type, D;
+  const float* gate_w;
+  const float* emb_raw;
+  int64_t ld;
+  const float* w1;
+  const float* b1;
+  int nodes;
+  const float* w2;
+  const float* b2;
+  const float* out_w;
+  const float* out_b;
+  float* out;
+  int32_t* counts_out;
+};
+
+// A lane is a position: 256 consecutive positions per trip, kDrmmTrips trips per pass (ids first, then the 4-byte entries, then the
+// counts).  Counts go to one of 16 copies of the histograms (by lane & 15: at most 4 lanes of a wave meet on an address).
+constexpr int kDrmmTrips = 4, kHistCopies = 16;
+
+__global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
+  __shared__ int hist[kQT][kMaxBins];
+  __shared__ int hrep[kHistCopies][kQT * kMaxBins + 1];
+  __shared__ float zs[kQT], gs[kQT];
+  int l, doc;
+  if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = g.start[l] + doc, NB = m.nbins + 1;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  for (int i = tid; i < kHistCopies * (kQT * kMaxBins + 1); i += 256) (&hrep[0][0])[i] = 0;
+  __syncthreads();
+  int* myh = hrep[lane & (kHistCopies - 1)];
+  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
+  int n_oov = 0;
+  for (int j0 = 0; j0 < a.L; j0 += 256 * kDrmmTrips) {
+    int id[kDrmmTrips];
+    if (ids.d32) {
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        const int j = j0 + u * 256 + tid;
+        id[u] = ids.d32[j < a.L ? j : a.L - 1];
+      }
+    } else {
+      int64_t w[kDrmmTrips];
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        const int j = j0 + u * 256 + tid;
+        w[u] = ids.d64[j < a.L ? j : a.L - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? -1 : (int)w[u];
+    }
+    int live = 0;
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) {
+      if (j0 + u * 256 + tid >= a.L || id[u] >= a.V) id[u] = 0;
+      live |= id[u];
+    }
+    if (!__any(live != 0)) continue;         // padding only (wave-uniform)
+    uint32_t e[kDrmmTrips];
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) {
+      if (id[u] > 0) {
+#pragma unroll
+        for (int q = 0; q < kQT; ++q) {
+          if (q < a.Q) {
+            const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
+            if ((int)bin < m.nbins) atomicAdd(&myh[q * kMaxBins + bin], 1);
+            if (by & kBinExact) atomicAdd(&myh[q * kMaxBins + m.nbins], 1);
+          }
+        }
+      } else if (id[u] < 0) {
+        ++n_oov;       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_oov += __shfl_xor(n_oov, o, 64);
+  if (lane == 0 && n_oov > 0) {
+    const int bz = list_bin_of(0.f, m.edges, m.nbins);
+    if (bz < m.nbins)
+      for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&hrep[0][q * kMaxBins + bz], n_oov);
+  }
+  __syncthreads();
+  {
+    int h = 0;
+#pragma unroll
+    for (int c = 0; c < kHistCopies; ++c) h += hrep[c][tid];
+    hist[tid >> 6][tid & 63] = h;
+  }
+  // per query term (one wave each): histogram transform + feed-forward net + gate logit - the tail of drmm.hip
+  const int q = wave;
+  if (q < a.Q) {
+    const int64_t qid = qids.q(q);
+    if (lane == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
+    const int* h = hist[q];
+    if (m.counts_out && lane < NB) m.counts_out[((int64_t)b * a.Q + q) * NB + lane] = h[lane];
+    float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;
+    if (m.hist_type == 1) hv = hv / wave_allreduce_sum(hv);
+    else if (m.hist_type == 2) hv = lane < NB ? logf(hv) : 0.f;
+    const float b1v = lane < m.nodes ? m.b1[lane] : 0.f, w2v = lane < m.nodes ? m.w2[lane] : 0.f, b2v = m.b2[0];
+    const float gate0 = m.gate_type == 0 ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
+    float acc = 0.f;
+    for (int n = 0; n < m.nodes; ++n) {
+      const float wv = lane < NB ? m.w1[n * NB + lane] : 0.f;
+      const float sn = wave_allreduce_sum(wv * hv);
+      if (lane == n) acc = sn;
+    }
+    acc += b1v;
+    const float o = wave_allreduce_sum(lane < m.nodes ? w2v * tanhf(acc) : 0.f) + b2v;
+    float gl;
+    if (m.gate_type == 0) {
+      gl = gate0;
+    } else {
+      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
+      float p = 0.f;
+      for (int c = lane; c < m.D; c += 64) p = __builtin_fmaf(m.gate_w[c], e[c], p);
+      gl = wave_allreduce_sum(p);
+    }
+    if (qid == 0) gl += -1e7f;
+    if (lane == 0) { zs[q] = tanhf(o); gs[q] = gl; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = gs[0];
+    for (int t = 1; t < a.Q; ++t) mx = fmaxf(mx, gs[t]);
+    float den = 0.f, num = 0.f;
+    for (int t = 0; t < a.Q; ++t) {
+      const float e = expf(gs[t] - mx);
+      den += e;
+      num = __builtin_fmaf(e, zs[t], num);
+    }
+    m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
+
+// runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
+template <class Pool>
+int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V, int D, int* status,
+              void* workspace, size_t workspace_bytes, hipStream_t s, const float* edges, int nbins, Pool pool) {
+  if (!offsets_host || !packed || !status || !workspace) return CAPAMD_ERR_ARG;
+  if (n_lists < 0 || Q < 1 || Q > kQT || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return CAPAMD_ERR_ALIGN;
+  const int64_t Vp = lists_vp(V);
+  const size_t per_list = (size_t)Vp * 17;
+  int cap = (int)(workspace_bytes / per_list < (size_t)kListChunk ? workspace_bytes / per_list : (size_t)kListChunk);
+  if (cap < 1) return CAPAMD_ERR_WORKSPACE;
+  if (cap > kListChunk) cap = kListChunk;
+  for (int l = 0; l < n_lists; ++l)
+    if (offsets_host[l + 1] < offsets_host[l] || offsets_host[l + 1] > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  (void)hipGetLastError();
+  for (int l0 = 0; l0 < n_lists; l0 += cap) {
+    const int nl = n_lists - l0 < cap ? n_lists - l0 : cap;
+    ListGeom g{};
+    int longest = 0;
+    for (int i = 0; i < nl; ++i) {
+      g.start[i] = (int)offsets_host[l0 + i];
+      g.len[i] = (int)(offsets_host[l0 + i + 1] - offsets_host[l0 + i]);
+      if (g.len[i] > longest) longest = g.len[i];
+    }
+    if (longest == 0) continue;
+    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp]
+    char* ws = static_cast<char*>(workspace);
+    float4* table = reinterpret_cast<float4*>(ws);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
+    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins};
+    if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
+    hipLaunchKernelGGL(lists_mark_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g);
+    const dim3 sg((unsigned)((Vp / kSimsIds + 7) / 8 * 8 * nl));
+#define CAPAMD_SIMS(NV)                                                                                         \
+  if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true>), sg, dim3(256), 0, s, a, g);                      \
+  else hipLaunchKernelGGL((lists_sims_kernel<NV, false>), sg, dim3(256), 0, s, a, g)
+    switch (nv_for_dim(D)) {
+      case 1: CAPAMD_SIMS(1); break;
+      case 2: CAPAMD_SIMS(2); break;
+      case 3: CAPAMD_SIMS(3); break;
+      case 4: CAPAMD_SIMS(4); break;
+      default: CAPAMD_SIMS(5); break;
+    }
+#undef CAPAMD_SIMS
+    pool(a, g, nl, longest);
+    if (hipGetLastError() != hipSuccess) return CAPAMD_ERR_LAUNCH;
+  }
+  return CAPAMD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
+  if (n_lists < 1 || V < 1) return 0;
+  const int n = n_lists < kListChunk ? n_lists : kListChunk;
+  return (size_t)n * (size_t)lists_vp(V) * 17;
+}
+
+extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
+                                         const int32_t* pair_q, const int32_t* pair_d, const int64_t* list_offsets_host, int n_lists, int Q,
+                                         int L, const float* packed, int64_t V, int D, const float* mu, const float* sigma, int K,
+                                         const float* w1, const float* b1, int hidden, const float* w2, const float* b2, int scoretanh,
+                                         float* out, int* status, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_lists == 0) return CAPAMD_OK;
+  const bool indexed = q_table != nullptr;
+  if (indexed ? (!d_table || !pair_q || !pair_d) : (!q_ids || !d_ids)) return CAPAMD_ERR_ARG;
+  if (!mu || !sigma || !w1 || !b1 || !out || K < 1 || K > kMaxK || hidden < 0 || hidden > kMaxHidden || (hidden > 0 && (!w2 || !b2))) return CAPAMD_ERR_ARG;
+  const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  const KnrmPoolArgs m{mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out};
+  hipStream_t s = (hipStream_t)stream;
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0,
+                   [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
+                     hipLaunchKernelGGL(lists_knrm_pool_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g, m);
+                   });
+}
+
+extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
+                                         const int32_t* pair_q, const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host,
+                                         int n_lists, int Q, int L, const float* packed, int64_t V, int D, const float* edges, int nbins,
+                                         int hist_type, int gate_type, const float* gate_w, const float* emb_raw, int64_t ld, const float* w1,
+                                         const float* b1, int nodes, const float* w2, const float* b2, const float* out_w, const float* out_b,
+                                         float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_lists == 0) return CAPAMD_OK;
+  const bool indexed = q_table != nullptr;
+  if (indexed ? (!d_table || !pair_q || !pair_d) : (!q_ids || !d_ids)) return CAPAMD_ERR_ARG;
+  if (!idf || !edges || !gate_w || !w1 || !b1 || !w2 || !b2 || !out_w || !out_b || !out) return CAPAMD_ERR_ARG;
+  if (nbins < 1 || nbins + 1 > kMaxBins || nodes < 1 || nodes > kMaxNodes || hist_type < 0 || hist_type > 2 || gate_type < 0 || gate_type > 1) return CAPAMD_ERR_ARG;
+  if (gate_type == 1 && (!emb_raw || ld < D)) return CAPAMD_ERR_ARG;
+  const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  const DrmmPoolArgs m{idf, edges, nbins, hist_type, gate_type, D, gate_w, emb_raw, ld, w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out};
+  hipStream_t s = (hipStream_t)stream;
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins,
+                   [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
+                     hipLaunchKernelGGL(lists_drmm_pool_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g, m);
+                   });
+}

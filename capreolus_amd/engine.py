@@ -475,6 +475,83 @@ def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V,
     return out
 
 
+# ---- whole candidate lists (capamd_*_forward_lists) ------------------------------------------------------------------------------
+_list_workspaces = {}
+
+
+def _lists_workspace(device, n_lists, V):
+    nbytes = int(_lib.load().capamd_lists_workspace_bytes(int(n_lists), int(V)))
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _list_workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _list_workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _list_offsets(offsets):
+    """host int64 array of n_lists + 1 pair offsets (kept alive by the caller's frame during the call)"""
+    import numpy as np
+
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.int64))
+    if off.ndim != 1 or off.size < 1 or off[0] != 0 or (np.diff(off) < 0).any():
+        raise ValueError("list offsets must start at 0 and be non-decreasing")
+    return off
+
+
+def _lists_ids(query, doc, store, pair_q, pair_d):
+    """(q64, d64, q32, d32, pq, pd, B, Q, L, device): one of the two id layouts"""
+    if store is not None:
+        qt, dt, pq, pd = _i32(store.q_table), _i32(store.d_table), _i32(pair_q), _i32(pair_d)
+        return None, None, qt, dt, pq, pd, pq.numel(), qt.shape[1], dt.shape[1], pq.device
+    q, d = _i64(query), _i64(doc)
+    return q, d, None, None, None, None, q.shape[0], q.shape[1], d.shape[1], q.device
+
+
+def knrm_forward_lists(offsets, packed, V, D, mu, sigma, w1, b1, w2=None, b2=None, scoretanh=False, query=None, doc=None, store=None, pair_q=None,
+                       pair_d=None, out=None, check=True):
+    """KNRM over whole candidate lists (capamd_knrm_forward_lists): pairs laid out list after list, `offsets` their n_lists + 1
+    boundaries on the host; ids as [B, Q] / [B, L] tensors or through a CandidateStore (store, pair_q, pair_d)."""
+    q, d, qt, dt, pq, pd, B, Q, L, dev = _lists_ids(query, doc, store, pair_q, pair_d)
+    _need_gpu(packed, mu, sigma, w1, b1, w2, b2)
+    off = _list_offsets(offsets)
+    if int(off[-1]) != B:
+        raise ValueError("the last list offset must be the number of pairs")
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+    hidden = 0 if w2 is None else w1.shape[0]
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    rc = _lib.load().capamd_knrm_forward_lists(
+        _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D, _ptr(mu),
+        _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "capamd_knrm_forward_lists")
+    if check:
+        st.raise_if_set()
+    return out
+
+
+def drmm_forward_lists(offsets, idf, packed, V, D, edges, hist_type, gate_type, gate_w, emb_raw, w1, b1, w2, b2, out_w, out_b, query=None, doc=None,
+                       store=None, pair_q=None, pair_d=None, out=None, counts_out=None, check=True):
+    """DRMM over whole candidate lists (capamd_drmm_forward_lists); `idf`: [B, Q] per pair, or the store's [NQ, Q] table in indexed mode."""
+    q, d, qt, dt, pq, pd, B, Q, L, dev = _lists_ids(query, doc, store, pair_q, pair_d)
+    _need_gpu(packed, edges, gate_w, w1, b1, w2, b2, out_w, out_b)
+    off = _list_offsets(offsets)
+    if int(off[-1]) != B:
+        raise ValueError("the last list offset must be the number of pairs")
+    idf = _f32(idf)
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+    ld = emb_raw.stride(0) if emb_raw is not None else 0
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    rc = _lib.load().capamd_drmm_forward_lists(
+        _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
+        _ptr(edges), edges.numel(), HIST_TYPES[hist_type], GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0],
+        _ptr(w2), _ptr(b2), _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(counts_out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "capamd_drmm_forward_lists")
+    if check:
+        st.raise_if_set()
+    return out
+
+
 def knrm_features(query, doc, packed, V, D, mu, sigma, need_grad=True, check=True):
     """capamd_knrm_features: kernel-pooling features [B, K] and d f/d mu, d f/d sigma [B, K] (None when not needed)."""
     _need_gpu(query, doc, packed, mu, sigma)

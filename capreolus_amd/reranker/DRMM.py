@@ -89,6 +89,17 @@ class DRMM_class(nn.Module):
             self.ffw[2].bias.detach(), self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach())
 
 
+    def forward_lists(self, offsets, query=None, doc=None, idf=None, store=None, pair_q=None, pair_d=None):
+        """Whole candidate lists through capamd_drmm_forward_lists -> [B] (see KNRM_class.forward_lists); a list takes the idf row of
+        its first pair."""
+        w = self.embedding.weight
+        return engine.drmm_forward_lists(
+            offsets, store.idf_table if store is not None else idf, self._packed.get(w), w.shape[0], w.shape[1], self._bin_edges(w.device), self.hist_type,
+            self.gate_type, self.gates.weight.detach().contiguous().view(-1), w.detach(), self.ffw[0].weight.detach().contiguous(),
+            self.ffw[0].bias.detach(), self.ffw[2].weight.detach().contiguous().view(-1), self.ffw[2].bias.detach(),
+            self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), query=query, doc=doc, store=store, pair_q=pair_q, pair_d=pair_d)
+
+
 class DRMM(Reranker):
     """Guo et al., A Deep Relevance Matching Model for Ad-hoc Retrieval, CIKM'16 (reference DRMM.py:119-133)."""
 
@@ -109,3 +120,11 @@ class DRMM(Reranker):
 
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)
+
+    supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmm_forward_lists)
+
+    def test_lists(self, d, offsets):
+        return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"], idf=d["query_idf"])
+
+    def test_resident_lists(self, store, pair_q, pair_d, offsets):
+        return self.model.forward_lists(offsets, store=store, pair_q=pair_q, pair_d=pair_d)

@@ -97,6 +97,20 @@ class KNRM_class(nn.Module):
                                            lin1.weight.detach().contiguous(), lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"])
 
 
+    def forward_lists(self, offsets, query=None, doc=None, store=None, pair_q=None, pair_d=None):
+        """Whole candidate lists (pairs laid out list after list, `offsets` their boundaries on the host; every list scored against
+        its first pair's query) through capamd_knrm_forward_lists -> [B]."""
+        w = self.embedding.weight
+        mu, sigma = self.kernels.stacked()
+        lin1 = self.combine[0]
+        w2 = b2 = None
+        if not self.p["singlefc"]:
+            w2, b2 = self.combine[2].weight.detach(), self.combine[2].bias.detach()
+        return engine.knrm_forward_lists(offsets, self._packed.get(w), w.shape[0], w.shape[1], mu, sigma, lin1.weight.detach().contiguous(),
+                                         lin1.bias.detach(), w2, b2, scoretanh=self.p["scoretanh"], query=query, doc=doc, store=store,
+                                         pair_q=pair_q, pair_d=pair_d)
+
+
 class KNRM(Reranker):
     """Xiong et al., End-to-End Neural Ad-hoc Ranking with Kernel Pooling, SIGIR'17 (reference KNRM.py:58-69)."""
 
@@ -117,3 +131,11 @@ class KNRM(Reranker):
 
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)
+
+    supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_knrm_forward_lists)
+
+    def test_lists(self, d, offsets):
+        return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"])
+
+    def test_resident_lists(self, store, pair_q, pair_d, offsets):
+        return self.model.forward_lists(offsets, store=store, pair_q=pair_q, pair_d=pair_d)

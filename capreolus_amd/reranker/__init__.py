@@ -33,6 +33,10 @@ class Reranker:
     # batches as they are.
     supports_resident = False
     batch_coupled = False
+    # `supports_lists`: `test_lists(d, offsets)` / `test_resident_lists(store, pair_q, pair_d, offsets)` score whole candidate lists (pairs
+    # laid out list after list, every list against its first pair's query) - KNRM and DRMM, whose kernels then gather every distinct
+    # term of a LIST once instead of every distinct term of every document (csrc/lists.hip)
+    supports_lists = False
 
     def build_model(self):
         raise NotImplementedError

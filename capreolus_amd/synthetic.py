@@ -128,6 +128,8 @@ def make_candidate_list_torch(
     d = torch.where(torch.arange(L, device=device)[None, :] < dlen, d, torch.zeros_like(d))
     if idf:
         qidf = torch.rand((N, Q), generator=g, device=device) * 7.5 + 0.5
+        # (an idf vector is a property of the QUERY, embedtext.py:131-135: every candidate of a query carries the query's - its first draw)
+        qidf = qidf.view(n_queries, docs_per_query, Q)[:, :1].expand(n_queries, docs_per_query, Q).reshape(N, Q)
         qidf = torch.where(q != 0, qidf, torch.zeros_like(qidf))
     else:
         qidf = torch.zeros((N, Q), device=device)

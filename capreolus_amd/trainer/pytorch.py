@@ -564,7 +564,13 @@ class PytorchTrainer:
             store, pq, pd, groups = plan
             step = max(evalbatch, self.config["coalesce"])
             with torch.no_grad():
-                chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, pq.numel(), step)]
+                if getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and pq.numel() >= 8 * len(groups):
+                    # whole candidate lists (a run of one qid = one list; its query row is the same for every pair, checked when the
+                    # plan was built): every distinct term of a LIST is gathered once
+                    offsets = [lo for _, _, lo in groups] + [pq.numel()]
+                    chunks = [reranker.test_resident_lists(store, pq, pd, offsets).float()]
+                else:
+                    chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, pq.numel(), step)]
             if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
                 vals = torch.cat(chunks).cpu().numpy().astype(np.float16).tolist()      # (trainer/pytorch.py:346-348)
                 if len(vals) != count:

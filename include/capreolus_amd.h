@@ -137,6 +137,29 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
                                 float* out, int32_t* counts_out, int* status, void* workspace, size_t workspace_bytes, unsigned flags,
                                 void* stream);
 
+/* ---- KNRM / DRMM over whole candidate lists (what PytorchTrainer.predict scores: one query, its first-stage documents;
+ * capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query lists, sampler/__init__.py:222-233) ------------------------
+ * The similarity of a document term to the query depends on (query, term) only, and the documents of a list share their vocabulary:
+ * per list every distinct term's packed row is gathered ONCE (same arithmetic as the per-pair entries: bit-identical similarities)
+ * into a float4 table over the vocabulary, and every document is pooled from 16-byte lookups.  DRMM's scores are bit-identical to
+ * capamd_drmm_forward's, KNRM's equal to fp32 rounding of the pooling sums (another summation order).
+ * Pairs are laid out list after list: list l owns pairs list_offsets_host[l] .. list_offsets_host[l+1] (a HOST array of n_lists + 1
+ * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row).  Ids either as [B,Q] / [B,L] int64
+ * (q_ids, d_ids; the table arguments NULL) or through a candidate store (q_table, d_table, pair_q, pair_d; q_ids / d_ids NULL).
+ * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V) bytes (16-byte aligned; any
+ * contents; 17 B x V per list in flight, at most 64 lists at a time - fewer if the buffer is smaller, CAPAMD_ERR_WORKSPACE below one). */
+size_t capamd_lists_workspace_bytes(int n_lists, int64_t V);
+int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                              const int32_t* pair_d, const int64_t* list_offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V,
+                              int D, const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden, const float* w2,
+                              const float* b2, int scoretanh, float* out, int* status, void* workspace, size_t workspace_bytes, void* stream);
+int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                              const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host, int n_lists, int Q, int L,
+                              const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type, int gate_type,
+                              const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1, int nodes, const float* w2,
+                              const float* b2, const float* out_w, const float* out_b, float* out, int32_t* counts_out, int* status,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64) behind DRMMTKS.test (:105-110) ------------------
  * A sibling of DRMM on the same fused front end: per query term the top-k similarities over all
  * L positions -> Linear(topk, 1) + tanh (ffw_w fp32 [topk], ffw_b [1]) -> IDF gate (gate_w [1]) -> output layer.

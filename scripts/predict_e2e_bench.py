@@ -23,8 +23,6 @@ NQ, ND, V = 64, 1000, 400001
 dev = torch.device("cuda:0")
 emb = synthetic.make_embeddings(V, 300, seed=0)
 cand = {k: v.cpu().numpy() for k, v in synthetic.make_candidate_list_torch(NQ, ND, V, dev).items()}
-# (a query's idf vector is a property of the query - embedtext.py:131-135 - the generator draws one per pair: keep the query's first)
-cand["query_idf"] = np.repeat(cand["query_idf"].reshape(NQ, ND, -1)[:, :1], ND, axis=1).reshape(NQ * ND, -1)
 qid_to_docids = {str(q): [f"d{q}_{i}" for i in range(ND)] for q in range(NQ)}
 row = {(str(q), f"d{q}_{i}"): q * ND + i for q in range(NQ) for i in range(ND)}
 

@@ -1541,3 +1541,123 @@ def test_pacrr_hip_convmax_matches_autograd_through_aten(name):
     for k, want in ga.items():
         scale = float(np.abs(want).max())
         assert float(np.abs(gh[k] - want).max()) <= 1e-3 * scale + 1e-7, (k, float(np.abs(gh[k] - want).max()), scale)
+
+
+# ---- whole candidate lists (csrc/lists.hip): every distinct term of a LIST gathered once ----------------------------------------------
+def _lists_batch(n_lists, docs, V, seed, Q=4, L=800):
+    rs = np.random.RandomState(seed)
+    parts = [synthetic.make_candidate_list(rs, int(n), V, Q, L, same_query=True, oov_range=30, query_oov_frac=0.3) for n in docs]
+    b = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    for k in ("query_idf",):       # a list's idf row is its query's
+        off = 0
+        for n in docs:
+            b[k][off:off + n] = b[k][off]
+            off += n
+    return b, np.concatenate([[0], np.cumsum(docs)]).astype(np.int64)
+
+
+def test_knrm_lists_match_the_per_pair_kernels():
+    """capamd_knrm_forward_lists (mark -> one gather per distinct term of a list -> 16-byte lookups) against the per-pair kernel and the
+    C oracle: ragged lists (1 .. 700 documents), OOV query terms with exact matches in the documents, pads, an all-pad document."""
+    V, D = 3000, 300
+    emb = synthetic.make_embeddings(V, D, seed=5)
+    docs = [700, 1, 3, 64, 250]
+    b, off = _lists_batch(len(docs), docs, V, 17)
+    b["posdoc"][5] = 0
+    b["posdoc"][9, 3] = b["query"][9, 0] if b["query"][9, 0] < 0 else -4     # an OOV document term (equal to the query's if that is OOV)
+    r = KNRM({"singlefc": False, "scoretanh": True}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(3)
+    m = r.build_model().to(DEV).eval()
+    d = {k: _t(v) for k, v in b.items()}
+    with torch.no_grad():
+        pairwise = r.test(d).cpu().numpy()
+        lists = r.test_lists(d, off).cpu().numpy()
+    # (the pooling sums are formed in another order: features of size ~50 move by their fp32 rounding, ~5e-6, and a random two-layer tanh
+    # combine can cancel them to a score a hundred times smaller - the error is bounded against the scores' scale, as in the geometry sweep)
+    scale = float(np.abs(pairwise).max())
+    assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (np.abs(lists - pairwise).max(), scale)
+    assert np.median(rel_err(lists, pairwise)) <= 1e-6
+    mu, sigma = (x.cpu().numpy() for x in m.kernels.stacked())
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want, err = oracle.knrm(b["query"], b["posdoc"], oracle.pack(emb), D, mu, sigma, sd["combine.0.weight"], sd["combine.0.bias"], sd["combine.2.weight"],
+                            sd["combine.2.bias"], True)
+    assert err == 0 and np.abs(lists - want).max() <= ORACLE_TOL * scale
+    # the same through a candidate store (int32 tables + pair rows), lists in another order than the tables' rows
+    from capreolus_amd.feeder import CandidateStore
+
+    store = CandidateStore(DEV)
+    for i in range(len(off) - 1):
+        store.add_query(f"q{i}", b["query"][off[i]], b["query_idf"][off[i]])
+    for j in range(b["posdoc"].shape[0]):
+        store.add_doc(f"d{j}", b["posdoc"][j])
+    store.finalize()
+    pq = _t(np.repeat(np.arange(len(docs)), docs).astype(np.int32))
+    pd = _t(np.arange(b["posdoc"].shape[0], dtype=np.int32))
+    with torch.no_grad():
+        via_store = r.test_resident_lists(store, pq, pd, off).cpu().numpy()
+    assert np.array_equal(via_store, lists)
+    # error behaviour: an id beyond the table is flagged, more than four query terms are refused
+    bad = {k: v.clone() for k, v in d.items()}
+    bad["posdoc"][2, 1] = V + 5
+    with pytest.raises(IndexError):
+        r.test_lists(bad, off)
+    with pytest.raises(EngineError):
+        r.test_lists({**d, "query": torch.cat([d["query"], d["query"]], dim=1)}, off)
+
+
+def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
+    """DRMM over whole lists: the similarities are computed by the same arithmetic and the bin counts are integers - scores, counts and
+    fp16 rank order equal capamd_drmm_forward's bit for bit."""
+    V, D = 3000, 300
+    emb = synthetic.make_embeddings(V, D, seed=6)
+    docs = [300, 2, 90, 1, 120]
+    rs = np.random.RandomState(23)
+    parts = [synthetic.make_candidate_list(rs, int(n), V, 4, 800, same_query=True, oov_range=30, query_oov_frac=0.0) for n in docs]
+    b = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    off = np.concatenate([[0], np.cumsum(docs)]).astype(np.int64)
+    for i in range(len(docs)):
+        b["query_idf"][off[i]:off[i + 1]] = b["query_idf"][off[i]]
+    b["posdoc"][4] = 0
+    for hist, gate in (("LCH", "IDF"), ("NH", "TV"), ("CH", "IDF")):
+        r = DRMM({"histType": hist, "gateType": gate}, SimpleNamespace(embeddings=emb))
+        torch.manual_seed(1)
+        m = r.build_model().to(DEV).eval()
+        with torch.no_grad():
+            m.gates.weight.mul_(30.0)
+            m.ffw[0].weight.mul_(4.0)
+        d = {k: _t(v) for k, v in b.items()}
+        with torch.no_grad():
+            pairwise = r.test(d)
+            lists = r.test_lists(d, off)
+        assert torch.equal(lists, pairwise), (hist, gate, float((lists - pairwise).abs().max()))
+
+
+def test_predict_scores_whole_lists_where_the_reranker_can():
+    """`PytorchTrainer.predict` on its resident route hands KNRM / DRMM whole candidate lists: same predictions as the per-pair route."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", "ranklist")
+    r = _knrm_model(c)
+    B = c["query"].shape[0]
+    q2d = {"5": [f"d{i}" for i in range(0, 120)], "6": [f"d{i}" for i in range(120, B)]}
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = q2d
+
+        def __iter__(self):
+            for qid, docs in q2d.items():
+                for dd in docs:
+                    yield {"qid": qid, "posdocid": dd, "query": c["query"][0], "posdoc": c["posdoc"][int(dd[1:])], "query_idf": c["query_idf"][0]}
+
+        def __len__(self):
+            return B
+
+        def get_qid_docid_pairs(self):
+            return ((q, dd) for q, docs in q2d.items() for dd in docs)
+
+    s = Sampler()
+    got = PytorchTrainer({"batch": 32}).predict(r, s)
+    want = PytorchTrainer({"batch": 32, "resident": False}).predict(r, s)
+    assert got == want
+    flat = np.array([got[q][dd] for q, docs in q2d.items() for dd in docs], dtype=np.float16)
+    assert np.array_equal(flat, c["ref_scores_f16"])
