@@ -383,7 +383,8 @@ class InteractionLeg:
 
     def bytes_requested_per_pair_lists(self):
         """The whole-list route's requests per pair (csrc/lists.hip): the id row twice (mark pass, pooling pass), one byte-map store and one
-        16-byte table lookup per real position, and the list's distinct terms' packed rows (gathered once per LIST) spread over its documents."""
+        table lookup per real position (KNRM: the four similarities, 16 B; DRMM: the four bins, 4 B), and the list's distinct terms' packed
+        rows (gathered once per LIST) spread over its documents."""
         docs = self.args.docs
         nonpad = rows = 0
         for b in self.batches:
@@ -393,7 +394,8 @@ class InteractionLeg:
                 u = torch.unique(d[i])
                 rows += int((u > 0).sum().item())
         n = len(self.batches) * self.n_pairs
-        return 2 * self.L * 8 + self.Q * 8 + (nonpad / n) * 17 + (rows / n) * self.row_stride * 4 + 4, rows / (n / docs)
+        entry = 16 if self.model == "knrm" else 4
+        return 2 * self.L * 8 + self.Q * 8 + (nonpad / n) * (1 + entry) + (rows / n) * (self.row_stride * 4 + entry) + 4, rows / (n / docs)
 
     def check_against_oracle(self, n):
         """The scores the timed loop left in `out` (its last step's batch) against the C oracle on the first n pairs; returns what the
@@ -497,8 +499,10 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     }
     if leg.lists:
         headline.update({
-            "route": f"whole candidate lists (capamd_{model}_forward_lists): per list every distinct term's row gathered once, documents pooled from 16-byte lookups",
-            "kernel": f"lists_mark_kernel + lists_sims_kernel<5> + lists_{model}_pool_kernel", "mean_distinct_terms_per_list": distinct_per_list,
+            "route": f"whole candidate lists (capamd_{model}_forward_lists): per list every distinct term's row gathered once "
+                     + ("(its four similarities kept), documents pooled from 16-byte lookups" if model == "knrm" else "(its four histogram bins kept), documents pooled from 4-byte lookups"),
+            "kernel": f"lists_mark_kernel + lists_query_kernel<5> + lists_sims_kernel<5, {'false' if model == 'knrm' else 'true'}> + lists_{model}_pool_kernel",
+            "mean_distinct_terms_per_list": distinct_per_list,
             "requested_bytes_per_pair": req_lists, "requested_GBps": n_pairs * req_lists / dev_s / 1e9,
             "per_pair_kernel_requested_bytes_per_pair": req_b,
             "note": headline["note"] + "; on this route the rows of a LIST's distinct terms are gathered once (requested_bytes_per_pair counts them spread over the "

@@ -509,8 +509,65 @@ __device__ __forceinline__ void rows_dot2(const RowRegs<NV>& d0, const RowRegs<N
       b = __builtin_fmaf(d1.v[i].w, q.w, b);
       p0[t] = a;
       p1[t] = b;
-      if (t & 1) __builtin_amdgcn_sched_barrier(0);
+      if (t & 1) {
+        // both rows' chains are tied to this point: left alone, hipcc runs row 0's chain through all the chunks first and keeps the
+        // whole query copy (NV x kQT float4) in registers for row 1's
+        asm volatile("" : "+v"(p0[t - 1]), "+v"(p0[t]), "+v"(p1[t - 1]), "+v"(p1[t]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+}
+// rows_dot / rows_dot2 on packed fp32 (v_pk_fma_f32: two fmas per lane and instruction): the two lanes of an instruction are two QUERY
+// TERMS' chains, each with exactly the operands and the order of rows_dot - bit-identical dot products at half the fma instructions.
+// The LDS copy is the PAIRED layout of load_query_pass_lds: per pair of terms (2P, 2P + 1), chunk i and half h a float4
+// {q[2P].c, q[2P+1].c, q[2P].c', q[2P+1].c'} with (c, c') = (x, y) for h = 0 and (z, w) for h = 1, at ((P * NV + i) * 2 + h) * 16 + lane16.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NV>
+__device__ __forceinline__ void rows_dot_pk(const RowRegs<NV>& d, const float4* qlds, int lane16, float (&p)[kQT]) {
+  f32x2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const float4 qa = qlds[((P * NV + i) * 2 + 0) * 16 + lane16], qb = qlds[((P * NV + i) * 2 + 1) * 16 + lane16];
+      f32x2 a = acc[P];
+      a = __builtin_elementwise_fma((f32x2){d.v[i].x, d.v[i].x}, (f32x2){qa.x, qa.y}, a);
+      a = __builtin_elementwise_fma((f32x2){d.v[i].y, d.v[i].y}, (f32x2){qa.z, qa.w}, a);
+      a = __builtin_elementwise_fma((f32x2){d.v[i].z, d.v[i].z}, (f32x2){qb.x, qb.y}, a);
+      a = __builtin_elementwise_fma((f32x2){d.v[i].w, d.v[i].w}, (f32x2){qb.z, qb.w}, a);
+      acc[P] = a;
+    }
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));      // (one chunk at a time: see rows_dot2)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  p[0] = acc[0].x; p[1] = acc[0].y; p[2] = acc[1].x; p[3] = acc[1].y;
+}
+template <int NV>
+__device__ __forceinline__ void rows_dot2_pk(const RowRegs<NV>& d0, const RowRegs<NV>& d1, const float4* qlds, int lane16, float (&p0)[kQT],
+                                             float (&p1)[kQT]) {
+  f32x2 acc0[2] = {{0.f, 0.f}, {0.f, 0.f}}, acc1[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const float4 qa = qlds[((P * NV + i) * 2 + 0) * 16 + lane16], qb = qlds[((P * NV + i) * 2 + 1) * 16 + lane16];
+      f32x2 a = acc0[P], b = acc1[P];
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].x, d0.v[i].x}, (f32x2){qa.x, qa.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].x, d1.v[i].x}, (f32x2){qa.x, qa.y}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].y, d0.v[i].y}, (f32x2){qa.z, qa.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].y, d1.v[i].y}, (f32x2){qa.z, qa.w}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].z, d0.v[i].z}, (f32x2){qb.x, qb.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].z, d1.v[i].z}, (f32x2){qb.x, qb.y}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].w, d0.v[i].w}, (f32x2){qb.z, qb.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].w, d1.v[i].w}, (f32x2){qb.z, qb.w}, b);
+      acc0[P] = a;
+      acc1[P] = b;
+    }
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc1[0]), "+v"(acc1[1]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  p0[0] = acc0[0].x; p0[1] = acc0[0].y; p0[2] = acc0[1].x; p0[3] = acc0[1].y;
+  p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
 }
 template <int NV>
 __device__ __forceinline__ float sim_from_dots(const float (&p)[kQT], float dden, const QueryPass<NV>& qp, int lane16) {
@@ -527,7 +584,8 @@ __device__ __forceinline__ float sim_from_dots(const float (&p)[kQT], float dden
 // (one branch on the id layout around them, indices clamped instead of predicated), then the kQT rows' chunks and norms together, then
 // the LDS writes: written term by term, hipcc waited for each id before it asked for that term's row and for each row before the next
 // id - eight memory round trips per pair in series where two do.  nthreads >= NV * 16 (one chunk per thread and row).
-template <int NV>
+// PAIRED: the LDS copy interleaves the query terms in pairs for rows_dot_pk (see there) instead of term after term.
+template <int NV, bool PAIRED = false>
 __device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ packed, const PairIds& ids, int Q,
                                                     int q0, int64_t V, int tid, int nthreads, int lane16, float4* qlds,
                                                     QueryPass<NV>& qp, int* status) {
@@ -569,10 +627,17 @@ __device__ __forceinline__ void load_query_pass_lds(const float* __restrict__ pa
       qp.den_my = den[t];
       qp.id_my = (int)id[t];
     }
-    if (tid < NV * 16) {
-      float4 w = v[t];
-      if (tid == NV * 16 - 1) w.w = 0.f;  // keep the den slot out of the dot product
-      qlds[t * NV * 16 + tid] = w;
+    if (tid == NV * 16 - 1) v[t].w = 0.f;  // keep the den slot out of the dot product
+    if (!PAIRED && tid < NV * 16) qlds[t * NV * 16 + tid] = v[t];
+  }
+  if (PAIRED && tid < NV * 16) {
+    static_assert(kQT == 4, "two pairs of query terms");
+    const int i = tid >> 4, ln = tid & 15;
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const float4 a = v[2 * P], b = v[2 * P + 1];
+      qlds[((P * NV + i) * 2 + 0) * 16 + ln] = make_float4(a.x, b.x, a.y, b.y);
+      qlds[((P * NV + i) * 2 + 1) * 16 + ln] = make_float4(a.z, b.z, a.w, b.w);
     }
   }
 }

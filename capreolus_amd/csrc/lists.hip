@@ -7,7 +7,7 @@
 // of a document term to the query depends on (query, term) only, and the 1000 documents of a list share their vocabulary: a list's
 // 303,000 tokens are ~50,000 distinct terms.  So per list:
 //   1  mark    every document of the list flags its real term ids in a byte map over the vocabulary (plain byte stores: racing writers
-//              write the same value; a flag already set is not written again)
+//              write the same value)
 //   2  sims    per (list, block of 512 vocabulary ids): collect the flagged ids and for every one of them gather its packed row ONCE,
 //              the four similarities to the list's query by the SAME arithmetic as the per-pair kernels (rows_dot / sim_from_dots:
 //              bit-identical values) -> table[id]: KNRM the four floats, DRMM the four histogram bins (a byte each: bin | exact-match
@@ -15,24 +15,28 @@
 //              works on ONE id block of ALL lists at a time (workgroup i runs on XCD i % 8): the lists share most of a block's rows,
 //              so the rows come from that XCD's L2.
 //   3  pool    every document: its ids are requested together, then their table entries (two memory round trips per document - the
-//              per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a lane per (position, query term), K exponentials
-//              into per-lane sums; DRMM: a lane per position, four integer bin counts.  Passes of padding only (a document's tail) are
+//              per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a wave per document, a lane per (position, query
+//              term), K exponentials into per-lane sums; DRMM: a workgroup per document, a lane per position, four integer bin counts.  Passes of padding only (a document's tail) are
 //              skipped after the id load.  Then the models' per-pair tails.  An XCD works on one list at a time: the hot part of the
 //              list's table sits in its L2 (DRMM's 1.6 MB table all of it).
 // Rows gathered: 4.1 GB instead of 14.7, most of them L2 hits.
 // DRMM's bin counts are integers of bit-identical similarities: bit-exact with the per-pair kernels.  KNRM sums the same kernel values
 // in another order (per lane over its positions, then over the lanes): equal to fp32 rounding of the sums (1e-6 relative).
-// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V = 400,001);
+// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V = 400,001) + 5 KB for its query;
 // lists are processed in chunks of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits as the per-pair entries.
 #include "capreolus_amd.h"
 #include "interaction.cuh"
+#include <stdlib.h>
 
 using namespace capamd;
 
 namespace {
 
 constexpr int kListChunk = 64;            // lists per launch group (their start / length travel as kernel arguments)
-constexpr int kSimsIds = 512;             // vocabulary ids one workgroup of the sims pass scans
+#ifndef CAPAMD_LISTS_SIMS_IDS
+#define CAPAMD_LISTS_SIMS_IDS 1024
+#endif
+constexpr int kSimsIds = CAPAMD_LISTS_SIMS_IDS;             // vocabulary ids one workgroup of the sims pass scans
 constexpr int kMaxK = 12, kMaxHidden = 64, kMaxBins = 64, kMaxNodes = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -41,6 +45,7 @@ struct ListGeom {
   int len[kListChunk];     // its documents
 };
 
+struct ListQuery;
 struct ListsArgs {
   IdSource ids;
   int Q, L;
@@ -52,23 +57,30 @@ struct ListsArgs {
   int nl, longest;         // lists in this launch group, documents of the longest
   const float* edges;      // DRMM: histogram bin edges
   int nbins;
+  float4* qimg;            // [lists][kQueryImage] the list's query rows as the sims pass wants them in LDS
+  struct ListQuery* qmeta; // [lists]
 };
 
-// workgroup -> (list, document) of the mark / pool launches.  With 8 or more lists, XCD x (workgroups i % 8 == x) takes the lists
-// 8 k + x, one at a time: what a list's documents share (flags; rank map and table) stays in that XCD's L2.
+constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
+struct ListQuery {
+  int id[kQT];             // query term ids (0: pad or beyond Q)
+  float den[kQT];          // their rows' norms
+};
+
+// workgroup -> (list, document) of the mark / pool launches.  With 8 or more lists, XCD x (workgroups whose linear index is x mod 8:
+// blockIdx.x = 8 * document + x, the grid's x extent a multiple of 8) takes the lists 8 k + x, one at a time: what a list's documents
+// share (flags; table) stays in that XCD's L2.
 __device__ __forceinline__ bool list_doc_of(const ListsArgs& a, int& l, int& doc) {
-  const int bid = blockIdx.x;
   if (a.nl >= 8) {
-    const int k = bid >> 3;
-    doc = k % a.longest;
-    l = (k / a.longest) * 8 + (bid & 7);
+    doc = blockIdx.x >> 3;
+    l = blockIdx.y * 8 + (blockIdx.x & 7);
   } else {
-    doc = bid % a.longest;
-    l = bid / a.longest;
+    doc = blockIdx.x;
+    l = blockIdx.y;
   }
   return l < a.nl;
 }
-unsigned list_doc_grid(int nl, int longest) { return (unsigned)((nl >= 8 ? (nl + 7) / 8 * 8 : nl) * longest); }
+dim3 list_doc_grid(int nl, int longest) { return nl >= 8 ? dim3((unsigned)longest * 8, (unsigned)(nl + 7) / 8) : dim3((unsigned)longest, (unsigned)nl); }
 
 __device__ __forceinline__ int64_t doc_id_at(const PairIds& ids, int j) { return ids.d32 ? (int64_t)ids.d32[j] : ids.d64[j]; }
 
@@ -79,10 +91,18 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
   const PairIds ids = pair_ids(a.ids, g.start[l] + doc, a.Q, a.L);
   uint8_t* f = a.flags + (int64_t)l * a.Vp;
   bool bad = false;
-  for (int j = threadIdx.x; j < a.L; j += 256) {
-    const int64_t id = doc_id_at(ids, j);
-    if (id >= a.V) bad = true;
-    else if (id > 0 && !f[id]) f[id] = 1;
+  for (int j0 = 0; j0 < a.L; j0 += 256 * 4) {
+    int64_t id[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 256 + (int)threadIdx.x;
+      id[u] = j < a.L ? doc_id_at(ids, j) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (id[u] >= a.V) bad = true;
+      else if (id[u] > 0) f[id[u]] = 1;        // (unconditional: a check of the flag first puts a load in front of every store and measures the same)
+    }
   }
   if (bad) atomicOr(a.status, kErrDocIdRange);
 }
@@ -103,52 +123,71 @@ __device__ __forceinline__ int list_bin_of(float x, const float* edges, int nbin
 }
 constexpr unsigned kBinExact = 0x80;      // entry byte: bin (nbins = above the last edge) | kBinExact when 0.999 < s < 1.001 (drmm.hip's exact-match bin)
 
+// the query of every list once: its packed rows in the PAIRED LDS layout of rows_dot_pk, its ids and norms
+template <int NV>
+__global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom g) {
+  __shared__ __attribute__((aligned(16))) float4 qlds[kQueryImage];
+  const int l = blockIdx.x, tid = threadIdx.x, lane16 = tid & 15;
+  const PairIds ids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  QueryPass<NV> qp;
+  load_query_pass_lds<NV, true>(a.packed, ids, a.Q, 0, a.V, tid, 128, lane16, qlds, qp, a.status);
+  __syncthreads();
+  float4* img = a.qimg + (int64_t)l * kQueryImage;
+  for (int i = tid; i < kQT * NV * 16; i += 128) img[i] = qlds[i];
+  if (tid < kQT) {           // lane16 = tid: the term this lane "owns" in QueryPass
+    a.qmeta[l].id[tid] = qp.id_my;
+    a.qmeta[l].den[tid] = qp.den_my;
+  }
+}
+
+#ifndef CAPAMD_LISTS_SIMS_WAVES
+#define CAPAMD_LISTS_SIMS_WAVES 1
+#endif
 template <int NV, bool BINS>
-__global__ __launch_bounds__(256) void lists_sims_kernel(ListsArgs a, ListGeom g) {
+__global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kernel(ListsArgs a, ListGeom g) {
   __shared__ __attribute__((aligned(16))) float4 qlds[kQT * kMaxNV * 16];
   __shared__ int lst[kSimsIds];
   __shared__ int wave_cnt[4];
   __shared__ float edges[kMaxBins];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane16 = tid & 15, grp = tid >> 4;
-  // XCD x takes the id blocks 8 k + x, each for all lists back to back
-  const int k = blockIdx.x >> 3, l = k % a.nl, blk = (k / a.nl) * 8 + (blockIdx.x & 7);
+  // XCD x (workgroups whose linear index is x mod 8: blockIdx.x = 8 * list + x) takes the id blocks 8 k + x, each for all lists back to back
+  const int l = blockIdx.x >> 3, blk = blockIdx.y * 8 + (blockIdx.x & 7);
   if ((int64_t)blk * kSimsIds >= a.Vp) return;
   const int id0 = blk * kSimsIds;
-  const uint32_t f2 = *reinterpret_cast<const uint16_t*>(a.flags + (int64_t)l * a.Vp + id0 + tid * 2);   // 2 ids per thread
-  // the list's query rows (LDS copy, den slot zeroed) - the same staging as the per-pair kernels
-  const PairIds ids = pair_ids(a.ids, g.start[l], a.Q, a.L);
-  QueryPass<NV> qp;
-  load_query_pass_lds<NV>(a.packed, ids, a.Q, 0, a.V, tid, 256, lane16, qlds, qp, blk == 0 ? a.status : nullptr);
-  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
-  const int n0 = (f2 & 0xff) ? 1 : 0, n1 = (f2 >> 8) ? 1 : 0;
-  int incl = n0 + n1;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += up;
-  }
-  if (lane == 63) wave_cnt[wave] = incl;
-  __syncthreads();
-  const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-  if (total == 0) return;
+  constexpr int kPer = kSimsIds / 256;      // ids per thread: their flag bytes in one load
+  static_assert(kPer == 2 || kPer == 4, "kSimsIds is 512 or 1024");
+  const uint8_t* fp = a.flags + (int64_t)l * a.Vp + id0 + tid * kPer;
+  const uint32_t fw = kPer == 2 ? (uint32_t)*reinterpret_cast<const uint16_t*>(fp) : *reinterpret_cast<const uint32_t*>(fp);
+  // the list's query rows: the LDS image lists_query_kernel left (built here, from the ids, it is five dependent loads per workgroup)
   {
-    int pos = incl - n0 - n1;
-    for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
-    if (n0) lst[pos++] = tid * 2;
-    if (n1) lst[pos] = tid * 2 + 1;
+    const float4* img = a.qimg + (int64_t)l * kQueryImage;
+    for (int i = tid; i < kQT * NV * 16; i += 256) qlds[i] = img[i];
   }
+  QueryPass<NV> qp;
+  qp.den_my = a.qmeta[l].den[lane16 & 3];
+  qp.id_my = a.qmeta[l].id[lane16 & 3];
+  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
+  // the flagged ids, dense, in LDS (any order): per flag byte one ballot, the lane's slot = the set lanes below it
+  int slot[kPer], mine = 0;
+#pragma unroll
+  for (int c = 0; c < kPer; ++c) {
+    const uint64_t set = __ballot(((fw >> (8 * c)) & 0xffu) != 0);
+    slot[c] = mine + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u));
+    mine += __builtin_popcountll(set);       // (wave-uniform from here: the wave's count so far)
+  }
+  if (lane == 0) wave_cnt[wave] = mine;
+  __syncthreads();
+  const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+  const int total = c0 + c1 + c2 + c3;
+  if (total == 0) return;
+  const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+#pragma unroll
+  for (int c = 0; c < kPer; ++c)
+    if ((fw >> (8 * c)) & 0xffu) lst[base + slot[c]] = tid * kPer + c;
   __syncthreads();
   float* tab = reinterpret_cast<float*>(a.table + (int64_t)l * a.Vp);
   uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
-  for (int e = grp; e < total; e += kGroupsPerWG) {
-    const int id = id0 + lst[e];
-    RowRegs<NV> d;
-    load_row<NV>(a.packed, id, lane16, d);
-    float p[kQT];
-    int qoff = 0;
-    asm volatile("" : "+v"(qoff));
-    rows_dot<NV>(d, qlds + qoff, lane16, p);
-    const float sm = sim_from_dots<NV>(p, row_den<NV>(d), qp, lane16);   // lane l: the similarity of query term l & 3
+  auto put = [&](int id, float sm) {        // lane l: the similarity of query term l & 3
     if (lane16 < kQT) {
       if (BINS) {
         const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
@@ -157,6 +196,26 @@ __global__ __launch_bounds__(256) void lists_sims_kernel(ListsArgs a, ListGeom g
         tab[(int64_t)id * 4 + lane16] = sm;
       }
     }
+  };
+  // two rows per group and trip: the LDS query copy is read once for both; packed fmas (rows_dot2_pk: per row and term the fma order of rows_dot)
+#pragma clang loop unroll(disable)
+  for (int e = grp; e < total; e += 2 * kGroupsPerWG) {
+    const int ida = id0 + lst[e], idb = id0 + lst[e + kGroupsPerWG < total ? e + kGroupsPerWG : e];
+    RowRegs<NV> da, db;
+#ifdef CAPAMD_LISTS_ABL_HOTROWS      // ablation: every row load hits one of 16 rows (what the pass costs without its gather)
+    load_row<NV>(a.packed, 1 + (ida & 15), lane16, da);
+    load_row<NV>(a.packed, 1 + (idb & 15), lane16, db);
+#else
+    load_row<NV>(a.packed, ida, lane16, da);
+    load_row<NV>(a.packed, idb, lane16, db);
+#endif
+    float pa[kQT], pb[kQT];
+    int qoff = 0;
+    asm volatile("" : "+v"(qoff));
+    rows_dot2_pk<NV>(da, db, qlds + qoff, lane16, pa, pb);
+    put(ida, sim_from_dots<NV>(pa, row_den<NV>(da), qp, lane16));
+    put(idb, sim_from_dots<NV>(pb, row_den<NV>(db), qp, lane16));    // (an odd last row is done twice: a branch here makes hipcc sink row b's
+                                                                     //  fma chain into it and keep the whole query copy in registers for that)
   }
 }
 
@@ -174,21 +233,22 @@ struct KnrmPoolArgs {
   float* out;
 };
 
-// A lane is (position slot, query term): row t of a wave (its lanes 16 t .. 16 t + 15) holds query term t of 16 positions, the four
-// waves hold 64 consecutive positions ("a trip").  A document is walked in passes of kPoolTrips trips: every id of the pass is
-// requested first, then every table entry, then the arithmetic; a pass without a real or OOV term (padding) stops after the ids.
-#ifndef CAPAMD_LISTS_TRIPS
-#define CAPAMD_LISTS_TRIPS 8
-#endif
-constexpr int kPoolTrips = CAPAMD_LISTS_TRIPS;     // 64 positions each
+// A WAVE per document (four documents per workgroup), a lane per (position slot, query term): row t of the wave (its lanes 16 t ..
+// 16 t + 15) holds query term t of 16 positions ("a trip").  A document is walked in passes of kWaveTrips trips: every id of the pass
+// is requested first, then every table entry, then the arithmetic; a pass without a real or OOV term (padding) stops after the ids.
+// No LDS and no barrier: the row reduction is DPP, the per-kernel logs run in lanes (query term, kernel), the read-out takes the
+// kernels' features by readlane.  (A workgroup per document - four waves sharing its positions, LDS reduction, one lane per kernel for
+// the logs - measured 465 us per 64,000 documents against this form's 352.)
+constexpr int kWaveTrips = 8;      // 128 positions per pass
+
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
 __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
-  __shared__ float red[4][kQT][kMaxK + 2];         // per wave and query term: S[k], row sum, exact matches
-  __shared__ int n_real_s[4];
-  __shared__ float F[kMaxK];
-  int l, doc;
-  if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = wave * 16 + (lane & 15);
+  int l, dq;
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
   const int b = g.start[l] + doc;
   const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
@@ -207,40 +267,41 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
-  for (int j0 = 0; j0 < a.L; j0 += 64 * kPoolTrips) {
-    int id[kPoolTrips];
+  for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
+    int id[kWaveTrips];
     if (ids.d32) {
 #pragma unroll
-      for (int u = 0; u < kPoolTrips; ++u) {
-        const int j = j0 + u * 64 + ps;
+      for (int u = 0; u < kWaveTrips; ++u) {
+        const int j = j0 + u * 16 + ps;
         id[u] = ids.d32[j < a.L ? j : a.L - 1];
       }
     } else {
-      int64_t w[kPoolTrips];
+      int64_t w[kWaveTrips];
 #pragma unroll
-      for (int u = 0; u < kPoolTrips; ++u) {
-        const int j = j0 + u * 64 + ps;
+      for (int u = 0; u < kWaveTrips; ++u) {
+        const int j = j0 + u * 16 + ps;
         w[u] = ids.d64[j < a.L ? j : a.L - 1];
       }
 #pragma unroll
-      for (int u = 0; u < kPoolTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
+      for (int u = 0; u < kWaveTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
     }
     int live = 0;
 #pragma unroll
-    for (int u = 0; u < kPoolTrips; ++u) {
-      if (j0 + u * 64 + ps >= a.L || id[u] >= a.V) id[u] = 0;
+    for (int u = 0; u < kWaveTrips; ++u) {
+      if (j0 + u * 16 + ps >= a.L || id[u] >= a.V) id[u] = 0;
       live |= id[u];
     }
     if (!__any(live != 0)) continue;         // padding only (wave-uniform)
-    float s[kPoolTrips];
+    float s[kWaveTrips];
 #pragma unroll
-    for (int u = 0; u < kPoolTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+    for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
 #pragma unroll
-    for (int u = 0; u < kPoolTrips; ++u) {
+    for (int u = 0; u < kWaveTrips; ++u) {
       if (!__any(id[u] != 0)) continue;
       if (id[u] > 0) {
         ++n_real;
         rs += s[u];
+        // (the kernels in pairs on packed fp32 - v_pk_add / v_pk_mul, 36 instructions per trip for 60 - measure the same: 358 us for 352)
 #pragma unroll
         for (int k = 0; k < kMaxK; ++k) {
           const float adj = s[u] - mu[k];
@@ -251,58 +312,46 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
       }
     }
   }
-  // the 16 lanes of a row (one query term) -> wave -> workgroup (fixed order)
+  // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
+  const int k = lane & 15;
+  float S = 0.f;
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) {
-    const float v = group_allreduce(acc[k]);
-    if ((lane & 15) == 0) red[wave][t][k] = v;
+  for (int kk = 0; kk < kMaxK; ++kk) {
+    const float v = group_allreduce(acc[kk]);
+    S = k == kk ? v : S;
   }
-  {
-    const float r = group_allreduce(rs), no = group_allreduce((float)n_one);
-    if ((lane & 15) == 0) { red[wave][t][kMaxK] = r; red[wave][t][kMaxK + 1] = no; }
-    const float nr = group_allreduce((float)n_real);     // (every term's lanes count the same positions)
-    if (lane == 0) n_real_s[wave] = (int)nr;
+  const float R0 = group_allreduce(rs);
+  const int no = (int)group_allreduce((float)n_one), nreal = (int)group_allreduce((float)n_real);
+  float f = 0.f;
+  if (k < m.K && t < a.Q) {
+    const float sg = m.sigma[k], mk = m.mu[k], c = (-0.5f * kLog2e) / (sg * sg);
+    const float k0 = __builtin_amdgcn_exp2f(mk * mk * c), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
+    const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
+    S += (float)nz * k0;
+    S += (float)no * k1;
+    const float R = R0 + (float)no;
+    f = R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
   }
-  __syncthreads();
-  if (tid < kMaxK) {
-    const int k = tid;
-    float f = 0.f;
-    if (k < m.K) {
-      const float sg = m.sigma[k], mk = m.mu[k], c = (-0.5f * kLog2e) / (sg * sg);
-      const float k0 = __builtin_amdgcn_exp2f(mk * mk * c), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
-      const int nreal = n_real_s[0] + n_real_s[1] + n_real_s[2] + n_real_s[3];
-      for (int q = 0; q < a.Q && q < kQT; ++q) {
-        float S = ((red[0][q][k] + red[1][q][k]) + red[2][q][k]) + red[3][q][k];
-        float R = ((red[0][q][kMaxK] + red[1][q][kMaxK]) + red[2][q][kMaxK]) + red[3][q][kMaxK];
-        const int no = (int)(((red[0][q][kMaxK + 1] + red[1][q][kMaxK + 1]) + red[2][q][kMaxK + 1]) + red[3][q][kMaxK + 1]);
-        const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
-        // (a pad / OOV QUERY term has similarity 0 everywhere: its real positions were looked up as 0 and are in S as K_k(0) already)
-        S += (float)nz * k0;
-        S += (float)no * k1;
-        R += (float)no;
-        f += R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
-      }
-    }
-    F[k] = f;
-  }
-  __syncthreads();
+  // over the query terms, in their order
+  const float F = ((__shfl(f, k, 64) + __shfl(f, 16 + k, 64)) + __shfl(f, 32 + k, 64)) + __shfl(f, 48 + k, 64);
   if (m.hidden > 0) {
     float h = 0.f;
-    if (tid < m.hidden) {
-      h = m.b1[tid];
-      for (int k = 0; k < m.K; ++k) h = __builtin_fmaf(m.w1[tid * m.K + k], F[k], h);
-      h = m.w2[tid] * tanhf(h);
-    }
-    if (wave == 0) {
-      float sc = wave_allreduce_sum(h) + m.b2[0];
-      if (m.scoretanh) sc = tanhf(sc);
-      if (lane == 0) m.out[b] = sc;
-    }
-  } else if (tid == 0) {
-    float sc = m.b1[0];
-    for (int k = 0; k < m.K; ++k) sc = __builtin_fmaf(m.w1[k], F[k], sc);
+    const int n = lane < m.hidden ? lane : 0;
+    h = m.b1[n];
+#pragma unroll
+    for (int kk = 0; kk < kMaxK; ++kk)
+      if (kk < m.K) h = __builtin_fmaf(m.w1[n * m.K + kk], lane_bcast(F, kk), h);
+    h = lane < m.hidden ? m.w2[n] * tanhf(h) : 0.f;
+    float sc = wave_allreduce_sum(h) + m.b2[0];
     if (m.scoretanh) sc = tanhf(sc);
-    m.out[b] = sc;
+    if (lane == 0) m.out[b] = sc;
+  } else {
+    float sc = m.b1[0];
+#pragma unroll
+    for (int kk = 0; kk < kMaxK; ++kk)
+      if (kk < m.K) sc = __builtin_fmaf(m.w1[kk], lane_bcast(F, kk), sc);
+    if (m.scoretanh) sc = tanhf(sc);
+    if (lane == 0) m.out[b] = sc;
   }
 }
 
@@ -449,6 +498,7 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
+constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
@@ -459,7 +509,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
   if (n_lists < 0 || Q < 1 || Q > kQT || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return CAPAMD_ERR_ALIGN;
   const int64_t Vp = lists_vp(V);
-  const size_t per_list = (size_t)Vp * 17;
+  const size_t per_list = (size_t)Vp * 17 + kListQueryBytes;
   int cap = (int)(workspace_bytes / per_list < (size_t)kListChunk ? workspace_bytes / per_list : (size_t)kListChunk);
   if (cap < 1) return CAPAMD_ERR_WORKSPACE;
   if (cap > kListChunk) cap = kListChunk;
@@ -476,15 +526,18 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       if (g.len[i] > longest) longest = g.len[i];
     }
     if (longest == 0) continue;
-    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp]
+    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap]
     char* ws = static_cast<char*>(workspace);
     float4* table = reinterpret_cast<float4*>(ws);
     uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
-    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins};
+    float4* qimg = reinterpret_cast<float4*>(ws + (size_t)cap * Vp * 17);
+    ListQuery* qmeta = reinterpret_cast<ListQuery*>(qimg + (size_t)cap * kQueryImage);
+    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta};
     if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
-    hipLaunchKernelGGL(lists_mark_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g);
-    const dim3 sg((unsigned)((Vp / kSimsIds + 7) / 8 * 8 * nl));
+    hipLaunchKernelGGL(lists_mark_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g);
+    const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
 #define CAPAMD_SIMS(NV)                                                                                         \
+  hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl), dim3(128), 0, s, a, g);                                  \
   if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true>), sg, dim3(256), 0, s, a, g);                      \
   else hipLaunchKernelGGL((lists_sims_kernel<NV, false>), sg, dim3(256), 0, s, a, g)
     switch (nv_for_dim(D)) {
@@ -506,7 +559,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
 extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
   if (n_lists < 1 || V < 1) return 0;
   const int n = n_lists < kListChunk ? n_lists : kListChunk;
-  return (size_t)n * (size_t)lists_vp(V) * 17;
+  return (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes);
 }
 
 extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
@@ -523,7 +576,9 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
   hipStream_t s = (hipStream_t)stream;
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
-                     hipLaunchKernelGGL(lists_knrm_pool_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g, m);
+                     ListsArgs aq = a;
+                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                     hipLaunchKernelGGL(lists_knrm_pool_kernel, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                    });
 }
 
@@ -544,6 +599,6 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   hipStream_t s = (hipStream_t)stream;
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
-                     hipLaunchKernelGGL(lists_drmm_pool_kernel, dim3(list_doc_grid(nl, longest)), dim3(256), 0, s, a, g, m);
+                     hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
                    });
 }

@@ -147,7 +147,7 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row).  Ids either as [B,Q] / [B,L] int64
  * (q_ids, d_ids; the table arguments NULL) or through a candidate store (q_table, d_table, pair_q, pair_d; q_ids / d_ids NULL).
  * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V) bytes (16-byte aligned; any
- * contents; 17 B x V per list in flight, at most 64 lists at a time - fewer if the buffer is smaller, CAPAMD_ERR_WORKSPACE below one). */
+ * contents; 17 B x V + 5 KB per list in flight, at most 64 lists at a time - fewer if the buffer is smaller, CAPAMD_ERR_WORKSPACE below one). */
 size_t capamd_lists_workspace_bytes(int n_lists, int64_t V);
 int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
                               const int32_t* pair_d, const int64_t* list_offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V,
