@@ -322,8 +322,14 @@ __device__ __forceinline__ float group_allreduce(float v) {
 // Reductions over the 64 lanes of a wave, every lane gets the result: DPP all-reduce inside each 16-lane row, then the four row values by
 // v_readlane.  No LDS-pipe permutes: a `__shfl_xor` butterfly is six ds_bpermute round trips (~100 cycles each), and the per-pair tails
 // of these kernels (feed-forward nets, top-k merges) are serial chains of such reductions during which the workgroup requests no rows.
+// `unfused`: the value as computed - a product handed to a reduction is not contracted into the reduction's first add (hipcc's default
+// -ffp-contract=fast would, or would not, depending on the code around it: two spellings of one tail must round alike).
+__device__ __forceinline__ float unfused(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
-  v = group_allreduce(v);
+  v = group_allreduce(unfused(v));
   const int bits = __builtin_bit_cast(int, v);
   const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16)),
               r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));

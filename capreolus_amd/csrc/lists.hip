@@ -59,6 +59,11 @@ struct ListsArgs {
   int nbins;
   float4* qimg;            // [lists][kQueryImage] the list's query rows as the sims pass wants them in LDS
   struct ListQuery* qmeta; // [lists]
+  const float* kn_mu;      // KNRM: the kernels' parameters (null for DRMM) ...
+  const float* kn_sigma;
+  int kn_K;
+  float* kn_consts;        // ... and what the pooling pass needs of them, computed once per call: [4][kMaxK] mu, c = -log2(e) / (2 sigma^2),
+                           //     K(0) = 2^(c mu^2), K(1) = 2^(c (1 - mu)^2)   (slots beyond K repeat the last kernel)
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
@@ -137,6 +142,14 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
   if (tid < kQT) {           // lane16 = tid: the term this lane "owns" in QueryPass
     a.qmeta[l].id[tid] = qp.id_my;
     a.qmeta[l].den[tid] = qp.den_my;
+  }
+  if (l == 0 && a.kn_consts && tid < kMaxK) {
+    const int kc = tid < a.kn_K ? tid : a.kn_K - 1;
+    const float sg = a.kn_sigma[kc], mk = a.kn_mu[kc], c = (-0.5f * kLog2e) / (sg * sg);
+    a.kn_consts[tid] = mk;
+    a.kn_consts[kMaxK + tid] = c;
+    a.kn_consts[2 * kMaxK + tid] = __builtin_amdgcn_exp2f(mk * mk * c);
+    a.kn_consts[3 * kMaxK + tid] = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
   }
 }
 
@@ -257,10 +270,8 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   float mu[kMaxK], ck[kMaxK];
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
-    const int kc = k < m.K ? k : m.K - 1;
-    const float sg = m.sigma[kc];
-    mu[k] = m.mu[kc];
-    ck[k] = (-0.5f * kLog2e) / (sg * sg);
+    mu[k] = a.kn_consts[k];
+    ck[k] = a.kn_consts[kMaxK + k];
   }
   float acc[kMaxK], rs = 0.f;
   int n_one = 0, n_real = 0;
@@ -268,30 +279,32 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
   for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
+    // a pass of padding only - the tail of most documents - is recognised on the raw ids (wave-uniform), before anything is done with them
     int id[kWaveTrips];
     if (ids.d32) {
+      int live = 0;
 #pragma unroll
       for (int u = 0; u < kWaveTrips; ++u) {
         const int j = j0 + u * 16 + ps;
         id[u] = ids.d32[j < a.L ? j : a.L - 1];
+        live |= id[u];
       }
+      if (!__any(live != 0)) continue;
     } else {
-      int64_t w[kWaveTrips];
+      int64_t w[kWaveTrips], live = 0;
 #pragma unroll
       for (int u = 0; u < kWaveTrips; ++u) {
         const int j = j0 + u * 16 + ps;
         w[u] = ids.d64[j < a.L ? j : a.L - 1];
+        live |= w[u];
       }
+      if (!__any(live != 0)) continue;
 #pragma unroll
       for (int u = 0; u < kWaveTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
     }
-    int live = 0;
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) {
+    for (int u = 0; u < kWaveTrips; ++u)
       if (j0 + u * 16 + ps >= a.L || id[u] >= a.V) id[u] = 0;
-      live |= id[u];
-    }
-    if (!__any(live != 0)) continue;         // padding only (wave-uniform)
     float s[kWaveTrips];
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
@@ -324,8 +337,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   const int no = (int)group_allreduce((float)n_one), nreal = (int)group_allreduce((float)n_real);
   float f = 0.f;
   if (k < m.K && t < a.Q) {
-    const float sg = m.sigma[k], mk = m.mu[k], c = (-0.5f * kLog2e) / (sg * sg);
-    const float k0 = __builtin_amdgcn_exp2f(mk * mk * c), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
+    const float k0 = a.kn_consts[2 * kMaxK + k], k1 = a.kn_consts[3 * kMaxK + k];
     const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
     S += (float)nz * k0;
     S += (float)no * k1;
@@ -393,7 +405,10 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
   int* myh = hrep[lane & (kHistCopies - 1)];
   const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
   int n_oov = 0;
-  for (int j0 = 0; j0 < a.L; j0 += 256 * kDrmmTrips) {
+#ifndef CAPAMD_LISTS_DRMM_ABL
+#define CAPAMD_LISTS_DRMM_ABL 0
+#endif
+  for (int j0 = 0; j0 < (CAPAMD_LISTS_DRMM_ABL == 1 ? 0 : a.L); j0 += 256 * kDrmmTrips) {
     int id[kDrmmTrips];
     if (ids.d32) {
 #pragma unroll
@@ -451,7 +466,77 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
     for (int c = 0; c < kHistCopies; ++c) h += hrep[c][tid];
     hist[tid >> 6][tid & 63] = h;
   }
-  // per query term (one wave each): histogram transform + feed-forward net + gate logit - the tail of drmm.hip
+  // per query term: histogram transform + feed-forward net + gate logit - the tail of drmm.hip
+#if CAPAMD_LISTS_DRMM_ABL == 2
+  __syncthreads();
+  if (tid == 0) m.out[b] = (float)(hist[0][0] + hist[1][1] + hist[2][2] + hist[3][3]);
+  return;
+#endif
+  if (NB <= 32 && m.nodes <= 16) {
+    // ONE wave for the four terms (the other three leave): row q of the wave (lanes 16 q .. 16 q + 15) stands for the 64 lanes the per-pair
+    // tail gives term q - lane j for its lanes j and j + 16 - and reduces as that tail does, (row 0 + row 1) + (row 2 + row 3) with the
+    // rows beyond the bins / nodes all zero: the same sums in the same order, bit-identical scores, a quarter of the instructions.
+    __syncthreads();
+    if (wave != 0) return;
+    const int q = lane >> 4, j = lane & 15;
+    const bool on = q < a.Q;
+    const int64_t qid = on ? qids.q(q) : 0;
+    if (on && j == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
+    const bool ina = j < NB, inb = j + 16 < NB;
+    const int ha = hist[q][j], hb = hist[q][j + 16];
+    if (m.counts_out && on) {
+      int32_t* co = m.counts_out + ((int64_t)b * a.Q + q) * NB;
+      if (ina) co[j] = ha;
+      if (inb) co[j + 16] = hb;
+    }
+    float va = ina ? (float)(ha + 1) : 0.f, vb = inb ? (float)(hb + 1) : 0.f;
+    if (m.hist_type == 1) {
+      const float tot = group_allreduce(unfused(va)) + group_allreduce(unfused(vb));
+      va = va / tot;
+      vb = vb / tot;
+    } else if (m.hist_type == 2) {
+      va = ina ? logf(va) : 0.f;
+      vb = inb ? logf(vb) : 0.f;
+    }
+    float acc = 0.f;
+    for (int n = 0; n < m.nodes; ++n) {
+      const float wa = ina ? m.w1[n * NB + j] : 0.f, wb = inb ? m.w1[n * NB + j + 16] : 0.f;
+      const float sn = group_allreduce(unfused(wa * va)) + group_allreduce(unfused(wb * vb));
+      if (j == n) acc = sn;
+    }
+    acc += j < m.nodes ? m.b1[j] : 0.f;
+    const float o = group_allreduce(unfused(j < m.nodes ? m.w2[j] * tanhf(acc) : 0.f)) + m.b2[0];
+    float gl;
+    if (m.gate_type == 0) {
+      gl = on ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
+    } else {
+      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = 0.f;
+        for (int c = j + 16 * r; c < m.D; c += 64) p[r] = __builtin_fmaf(m.gate_w[c], e[c], p[r]);
+        p[r] = group_allreduce(unfused(p[r]));
+      }
+      gl = (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    if (qid == 0) gl += -1e7f;
+    const float z = tanhf(o);
+    float mx = lane_bcast(gl, 0);
+    for (int t = 1; t < a.Q && t < kQT; ++t) mx = fmaxf(mx, lane_bcast(gl, 16 * t));
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) {
+      if (t < a.Q) {
+        const float e = expf(lane_bcast(gl, 16 * t) - mx);
+        den += e;
+        num = __builtin_fmaf(e, lane_bcast(z, 16 * t), num);
+      }
+    }
+    if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+    return;
+  }
+  // more than 32 bins or 16 nodes: a wave per query term, as the per-pair kernels
   const int q = wave;
   if (q < a.Q) {
     const int64_t qid = qids.q(q);
@@ -498,19 +583,22 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
-constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery);
+constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 4 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
 template <class Pool>
 int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V, int D, int* status,
-              void* workspace, size_t workspace_bytes, hipStream_t s, const float* edges, int nbins, Pool pool) {
+              void* workspace, size_t workspace_bytes, hipStream_t s, const float* edges, int nbins, const float* kn_mu, const float* kn_sigma, int kn_K,
+              Pool pool) {
   if (!offsets_host || !packed || !status || !workspace) return CAPAMD_ERR_ARG;
   if (n_lists < 0 || Q < 1 || Q > kQT || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return CAPAMD_ERR_ALIGN;
   const int64_t Vp = lists_vp(V);
   const size_t per_list = (size_t)Vp * 17 + kListQueryBytes;
-  int cap = (int)(workspace_bytes / per_list < (size_t)kListChunk ? workspace_bytes / per_list : (size_t)kListChunk);
+  if (workspace_bytes < kListConstBytes) return CAPAMD_ERR_WORKSPACE;
+  const size_t fit = (workspace_bytes - kListConstBytes) / per_list;
+  int cap = (int)(fit < (size_t)kListChunk ? fit : (size_t)kListChunk);
   if (cap < 1) return CAPAMD_ERR_WORKSPACE;
   if (cap > kListChunk) cap = kListChunk;
   for (int l = 0; l < n_lists; ++l)
@@ -526,13 +614,14 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       if (g.len[i] > longest) longest = g.len[i];
     }
     if (longest == 0) continue;
-    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap]
+    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap] | KNRM kernel constants
     char* ws = static_cast<char*>(workspace);
     float4* table = reinterpret_cast<float4*>(ws);
     uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
     float4* qimg = reinterpret_cast<float4*>(ws + (size_t)cap * Vp * 17);
     ListQuery* qmeta = reinterpret_cast<ListQuery*>(qimg + (size_t)cap * kQueryImage);
-    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta};
+    float* kn_consts = kn_mu ? reinterpret_cast<float*>(qmeta + cap) : nullptr;
+    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, kn_consts};
     if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
     hipLaunchKernelGGL(lists_mark_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g);
     const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
@@ -559,7 +648,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
 extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
   if (n_lists < 1 || V < 1) return 0;
   const int n = n_lists < kListChunk ? n_lists : kListChunk;
-  return (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes);
+  return (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes) + kListConstBytes;
 }
 
 extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
@@ -574,7 +663,7 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const KnrmPoolArgs m{mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
                      aq.longest = (longest + 3) / 4;       // four documents per workgroup
@@ -597,7 +686,7 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const DrmmPoolArgs m{idf, edges, nbins, hist_type, gate_type, D, gate_w, emb_raw, ld, w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
                    });

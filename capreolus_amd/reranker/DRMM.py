@@ -122,6 +122,7 @@ class DRMM(Reranker):
         return self.model.forward_indexed(store, pair_q, pair_d)
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmm_forward_lists)
+    lists_bit_identical = True # (integer bin counts of bit-identical similarities)
 
     def test_lists(self, d, offsets):
         return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"], idf=d["query_idf"])

@@ -37,6 +37,8 @@ class Reranker:
     # laid out list after list, every list against its first pair's query) - KNRM and DRMM, whose kernels then gather every distinct
     # term of a LIST once instead of every distinct term of every document (csrc/lists.hip)
     supports_lists = False
+    # `lists_bit_identical`: the list route's scores equal the per-pair route's bit for bit (what PytorchTrainer's `lists` = "exact" asks)
+    lists_bit_identical = False
 
     def build_model(self):
         raise NotImplementedError

@@ -99,6 +99,12 @@ class PytorchTrainer:
         # same sampler (the dev set after every training iteration, RerankTask's repeated predict) score it by index pairs without
         # touching the host per sample (SURVEY.md row N1 through the reference's own call site, trainer/pytorch.py:310-353).
         "resident": True,
+        # `lists`: which rerankers the resident route scores as whole candidate lists (csrc/lists.hip: every distinct term of a LIST
+        # gathered once).  "exact" (default): those whose list scores equal their per-pair scores bit for bit (DRMM: integer counts of
+        # bit-identical similarities), so that `predict` returns the same dict by either route; "always": also KNRM, whose pooling sums
+        # then run in another order (1e-6 relative: an fp16-rounded prediction can land on the other side of a rounding boundary);
+        # "never": per-pair kernels only.
+        "lists": "exact",
         # `graph` (default on): a training step - score() on positives and negatives, loss, backward, Adam - is captured ONCE as a HIP
         # graph and replayed per batch (at batch 32 a step is ~40 launches of microsecond kernels, i.e. host time).
         # Needs a GPU, gradacc = 1 and no loss scaling (amp = train / both); anything else, and batches of another shape, run eagerly.
@@ -564,7 +570,8 @@ class PytorchTrainer:
             store, pq, pd, groups = plan
             step = max(evalbatch, self.config["coalesce"])
             with torch.no_grad():
-                if getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and pq.numel() >= 8 * len(groups):
+                as_lists = {"never": False, "exact": getattr(reranker, "lists_bit_identical", False), "always": True}[self.config["lists"]]
+                if as_lists and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and pq.numel() >= 8 * len(groups):
                     # whole candidate lists (a run of one qid = one list; its query row is the same for every pair, checked when the
                     # plan was built): every distinct term of a LIST is gathered once
                     offsets = [lo for _, _, lo in groups] + [pq.numel()]

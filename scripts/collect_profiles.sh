@@ -32,4 +32,5 @@ cp $G/pytest_gpu.log $D/pytest_gpu.log
 [ -f $G/train_steps.jsonl ] && cp $G/train_steps.jsonl $D/train_steps.jsonl
 [ -f $G/predict_e2e.json ] && cp $G/predict_e2e.json $D/predict_e2e.json
 [ -f $G/knrm_pipes.txt ] && cp $G/knrm_pipes.txt $D/knrm_pipes.txt
+for f in pmc_lists_knrm.txt pmc_lists_drmm.txt lists_ab.txt; do [ -f $G/$f ] && cp $G/$f $D/$f; done
 ls -la $D | tail -40

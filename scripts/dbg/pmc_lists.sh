@@ -12,7 +12,7 @@ for spec in "$@"; do
   case "$spec" in *:*) envs=${spec#*:}; envs=${envs%%@*}; envs=${envs//,/ };; esac
   libenv="X=1"; [ -n "$lib" ] && libenv="CAPAMD_LIB_PATH=$R/capreolus_amd/csrc/ablate/libcapreolus_amd_$lib.so"
   echo "== $model $name"
-  for grp in "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_EA_RDREQ_sum" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
+  for grp in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE TCP_TCC_READ_REQ_sum" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
     rm -rf /tmp/pk; env $envs $libenv CAPAMD_BENCH_NO_CHECK=1 timeout 300 rocprofv3 --output-format csv --pmc $grp -d /tmp/pk -o c -- $B > /dev/null 2>&1
     python3 - <<PY
 import csv, glob, collections

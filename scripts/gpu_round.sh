@@ -56,10 +56,12 @@ done
 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 cd $R
-for f in $(find $P -name "*.csv" -size -4000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
+for f in $(find $P -name "*.csv" -size -12000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
 python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&1; cat gpurun_out/pmc_summary.txt
 timeout 200 ./scripts/ubench/mfma_power > gpurun_out/mfma_power.txt 2>&1; cat gpurun_out/mfma_power.txt
 [ -x ./scripts/ubench/hbm_read ] && { timeout 200 ./scripts/ubench/hbm_read > gpurun_out/hbm_read.txt 2>&1; cat gpurun_out/hbm_read.txt; }
 ls gpurun_out/prof/
-# which pipe binds the KNRM headline kernel (streaming kernel): LDS-array cycles, VALU / LDS issue activity, wait buckets
-cd $R; bash scripts/dbg/pmc_knrm_pipes.sh > gpurun_out/knrm_pipes.txt 2>&1; cat gpurun_out/knrm_pipes.txt
+# which pipe binds the per-pair streaming kernel (bench.py --per-pair) and the kernels of the whole-list route: issue activity, wait buckets
+cd $R; bash scripts/dbg/pmc_knrm_pipes.sh --per-pair > gpurun_out/knrm_pipes.txt 2>&1; cat gpurun_out/knrm_pipes.txt
+bash scripts/dbg/pmc_lists.sh knrm base > /dev/null 2>&1; bash scripts/dbg/pmc_lists.sh drmm base > /dev/null 2>&1; cat gpurun_out/pmc_lists_knrm.txt gpurun_out/pmc_lists_drmm.txt
+bash scripts/dbg/lists_variants.sh base pairs > gpurun_out/lists_ab.txt 2>&1; cat gpurun_out/lists_ab.txt

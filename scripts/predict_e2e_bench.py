@@ -84,6 +84,17 @@ s, preds_again = timed(lambda: tr.predict(r, sampler), reps=3)
 out["predict_later_calls_s"] = round(s, 4)
 out["predict_later_calls_pairs_per_s"] = round(NQ * ND / s)
 out["predict_same_as_dataloader_route"] = preds_first == preds_a and preds_again == preds_a
+# `lists` = "always": KNRM as whole candidate lists too (its pooling sums in another order: 1e-6 relative, so an fp16-rounded prediction
+# can land on the other side of a rounding boundary)
+tr = PytorchTrainer({"evalbatch": 32, "lists": "always"})
+tr.build()
+preds_l = tr.predict(r, sampler)
+s, preds_l = timed(lambda: tr.predict(r, sampler), reps=3)
+out["predict_lists_always_s"] = round(s, 4)
+out["predict_lists_always_pairs_per_s"] = round(NQ * ND / s)
+diff = [(abs(preds_l[q][d] - preds_a[q][d]), abs(preds_a[q][d])) for q in preds_a for d in preds_a[q] if preds_l[q][d] != preds_a[q][d]]
+out["predict_lists_always_differing_fp16_predictions"] = len(diff)
+out["predict_lists_always_max_rel_diff"] = max((x / max(y, 1e-6) for x, y in diff), default=0.0)
 t0 = time.perf_counter()
 store = CandidateStore.from_id2vec(dev, qid_to_docids, id2vec)
 out["store_upload_s"] = round(time.perf_counter() - t0, 3)

@@ -1618,8 +1618,9 @@ def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
     for i in range(len(docs)):
         b["query_idf"][off[i]:off[i + 1]] = b["query_idf"][off[i]]
     b["posdoc"][4] = 0
-    for hist, gate in (("LCH", "IDF"), ("NH", "TV"), ("CH", "IDF")):
-        r = DRMM({"histType": hist, "gateType": gate}, SimpleNamespace(embeddings=emb))
+    # (29 bins / 5 nodes: the single-wave tail of the list kernel; 40 bins or 20 nodes: its wave-per-term tail)
+    for hist, gate, extra in (("LCH", "IDF", {}), ("NH", "TV", {}), ("CH", "IDF", {}), ("LCH", "TV", {"nbins": 40}), ("NH", "IDF", {"nodes": 20})):
+        r = DRMM({"histType": hist, "gateType": gate, **extra}, SimpleNamespace(embeddings=emb))
         torch.manual_seed(1)
         m = r.build_model().to(DEV).eval()
         with torch.no_grad():
@@ -1629,15 +1630,18 @@ def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
         with torch.no_grad():
             pairwise = r.test(d)
             lists = r.test_lists(d, off)
-        assert torch.equal(lists, pairwise), (hist, gate, float((lists - pairwise).abs().max()))
+        assert torch.equal(lists, pairwise), (hist, gate, extra, float((lists - pairwise).abs().max()))
 
 
-def test_predict_scores_whole_lists_where_the_reranker_can():
-    """`PytorchTrainer.predict` on its resident route hands KNRM / DRMM whole candidate lists: same predictions as the per-pair route."""
+@pytest.mark.parametrize("model", ["knrm", "drmm"])
+def test_predict_scores_whole_lists_where_the_reranker_can(model, monkeypatch):
+    """`PytorchTrainer.predict` on its resident route hands whole candidate lists to the rerankers whose list scores equal their per-pair
+    scores bit for bit (DRMM; `lists` = "exact", the default) or to every reranker that takes lists (`lists` = "always": KNRM too): same
+    predictions as the DataLoader route on the reference's 200-candidate ranking list."""
     from capreolus_amd.trainer import PytorchTrainer
 
-    c = load_case("knrm", "ranklist")
-    r = _knrm_model(c)
+    c = load_case(model, "ranklist")
+    r = _knrm_model(c) if model == "knrm" else _drmm_model(c)
     B = c["query"].shape[0]
     q2d = {"5": [f"d{i}" for i in range(0, 120)], "6": [f"d{i}" for i in range(120, B)]}
 
@@ -1655,9 +1659,17 @@ def test_predict_scores_whole_lists_where_the_reranker_can():
         def get_qid_docid_pairs(self):
             return ((q, dd) for q, docs in q2d.items() for dd in docs)
 
+    calls = []
+    real = type(r).test_resident_lists
+    monkeypatch.setattr(type(r), "test_resident_lists", lambda self, *a: calls.append(1) or real(self, *a))
     s = Sampler()
-    got = PytorchTrainer({"batch": 32}).predict(r, s)
     want = PytorchTrainer({"batch": 32, "resident": False}).predict(r, s)
-    assert got == want
-    flat = np.array([got[q][dd] for q, docs in q2d.items() for dd in docs], dtype=np.float16)
-    assert np.array_equal(flat, c["ref_scores_f16"])
+    got = PytorchTrainer({"batch": 32}).predict(r, s)
+    assert got == want and len(calls) == (1 if model == "drmm" else 0)       # "exact": DRMM as lists, KNRM through the per-pair kernel
+    got = PytorchTrainer({"batch": 32, "lists": "always"}).predict(r, s)
+    assert len(calls) == (2 if model == "drmm" else 1)
+    assert got == want       # (KNRM: equal on this list - its scores sit >= 6.9e-6 from an fp16 rounding boundary - not by construction)
+    assert PytorchTrainer({"batch": 32, "lists": "never"}).predict(r, s) == want and len(calls) == (2 if model == "drmm" else 1)
+    if model == "knrm":
+        flat = np.array([got[q][dd] for q, docs in q2d.items() for dd in docs], dtype=np.float16)
+        assert np.array_equal(flat, c["ref_scores_f16"])
