@@ -386,8 +386,9 @@ struct DrmmPoolArgs {
   int32_t* counts_out;
 };
 
-// A lane is a position: 256 consecutive positions per trip, kDrmmTrips trips per pass (ids first, then the 4-byte entries, then the
-// counts).  Counts go to one of 16 copies of the histograms (by lane & 15: at most 4 lanes of a wave meet on an address).
+// The general form (more than 32 bins or 16 nodes; otherwise lists_drmm_pool_wave_kernel below): a workgroup per document, a lane per
+// position: 256 consecutive positions per trip, kDrmmTrips trips per pass (ids first, then the 4-byte entries, then the counts).
+// Counts go to one of 16 copies of the histograms (by lane & 15: at most 4 lanes of a wave meet on an address).
 constexpr int kDrmmTrips = 4, kHistCopies = 16;
 
 __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
@@ -405,10 +406,7 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
   int* myh = hrep[lane & (kHistCopies - 1)];
   const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
   int n_oov = 0;
-#ifndef CAPAMD_LISTS_DRMM_ABL
-#define CAPAMD_LISTS_DRMM_ABL 0
-#endif
-  for (int j0 = 0; j0 < (CAPAMD_LISTS_DRMM_ABL == 1 ? 0 : a.L); j0 += 256 * kDrmmTrips) {
+  for (int j0 = 0; j0 < a.L; j0 += 256 * kDrmmTrips) {
     int id[kDrmmTrips];
     if (ids.d32) {
 #pragma unroll
@@ -467,23 +465,141 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
     hist[tid >> 6][tid & 63] = h;
   }
   // per query term: histogram transform + feed-forward net + gate logit - the tail of drmm.hip
-#if CAPAMD_LISTS_DRMM_ABL == 2
+  // a wave per query term, as the per-pair kernels
+  const int q = wave;
+  if (q < a.Q) {
+    const int64_t qid = qids.q(q);
+    if (lane == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
+    const int* h = hist[q];
+    if (m.counts_out && lane < NB) m.counts_out[((int64_t)b * a.Q + q) * NB + lane] = h[lane];
+    float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;
+    if (m.hist_type == 1) hv = hv / wave_allreduce_sum(hv);
+    else if (m.hist_type == 2) hv = lane < NB ? logf(hv) : 0.f;
+    const float b1v = lane < m.nodes ? m.b1[lane] : 0.f, w2v = lane < m.nodes ? m.w2[lane] : 0.f, b2v = m.b2[0];
+    const float gate0 = m.gate_type == 0 ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
+    float acc = 0.f;
+    for (int n = 0; n < m.nodes; ++n) {
+      const float wv = lane < NB ? m.w1[n * NB + lane] : 0.f;
+      const float sn = wave_allreduce_sum(wv * hv);
+      if (lane == n) acc = sn;
+    }
+    acc += b1v;
+    const float o = wave_allreduce_sum(lane < m.nodes ? w2v * tanhf(acc) : 0.f) + b2v;
+    float gl;
+    if (m.gate_type == 0) {
+      gl = gate0;
+    } else {
+      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
+      float p = 0.f;
+      for (int c = lane; c < m.D; c += 64) p = __builtin_fmaf(m.gate_w[c], e[c], p);
+      gl = wave_allreduce_sum(p);
+    }
+    if (qid == 0) gl += -1e7f;
+    if (lane == 0) { zs[q] = tanhf(o); gs[q] = gl; }
+  }
   __syncthreads();
-  if (tid == 0) m.out[b] = (float)(hist[0][0] + hist[1][1] + hist[2][2] + hist[3][3]);
-  return;
-#endif
-  if (NB <= 32 && m.nodes <= 16) {
-    // ONE wave for the four terms (the other three leave): row q of the wave (lanes 16 q .. 16 q + 15) stands for the 64 lanes the per-pair
-    // tail gives term q - lane j for its lanes j and j + 16 - and reduces as that tail does, (row 0 + row 1) + (row 2 + row 3) with the
-    // rows beyond the bins / nodes all zero: the same sums in the same order, bit-identical scores, a quarter of the instructions.
-    __syncthreads();
-    if (wave != 0) return;
+  if (tid == 0) {
+    float mx = gs[0];
+    for (int t = 1; t < a.Q; ++t) mx = fmaxf(mx, gs[t]);
+    float den = 0.f, num = 0.f;
+    for (int t = 0; t < a.Q; ++t) {
+      const float e = expf(gs[t] - mx);
+      den += e;
+      num = __builtin_fmaf(e, zs[t], num);
+    }
+    m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+  }
+}
+
+// Up to 32 bins and 16 nodes (the model's defaults: 30 and 5): a WAVE per document, four documents per workgroup, no barrier.  A lane
+// is a position (64 per trip); the counts go to one of 8 copies of the wave's own histograms; then ONE wave does the four terms' tails:
+// row q of the wave (lanes 16 q .. 16 q + 15) stands for the 64 lanes the per-pair tail gives term q - lane j for its lanes j and
+// j + 16 - and reduces as that tail does, (row 0 + row 1) + (row 2 + row 3) with the rows beyond the bins / nodes all zero: the same
+// sums in the same order, bit-identical scores.  (Workgroup per document with a wave per term for the tail: 277 us per 64,000
+// documents, of which the tails 104 and the counting 144; with the single-wave tail 245.)
+constexpr int kWaveCopies = 8, kWaveBins = 32, kWaveStride = kQT * kWaveBins + 1;
+
+__global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
+  __shared__ int hrep[4][kWaveCopies * kWaveStride];
+  int l, dq;
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
+  const int b = g.start[l] + doc, NB = m.nbins + 1;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  int* H = hrep[wave];
+  for (int i = lane; i < kWaveCopies * kWaveStride; i += 64) H[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
+  int* myh = H + (lane & (kWaveCopies - 1)) * kWaveStride;
+  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
+  int n_oov = 0;
+  for (int j0 = 0; j0 < a.L; j0 += 64 * kDrmmTrips) {
+    int id[kDrmmTrips];
+    if (ids.d32) {
+      int live = 0;
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        const int j = j0 + u * 64 + lane;
+        id[u] = ids.d32[j < a.L ? j : a.L - 1];
+        live |= id[u];
+      }
+      if (!__any(live != 0)) continue;         // padding only (wave-uniform)
+    } else {
+      int64_t w[kDrmmTrips], live = 0;
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        const int j = j0 + u * 64 + lane;
+        w[u] = ids.d64[j < a.L ? j : a.L - 1];
+        live |= w[u];
+      }
+      if (!__any(live != 0)) continue;
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? -1 : (int)w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u)
+      if (j0 + u * 64 + lane >= a.L || id[u] >= a.V) id[u] = 0;
+    uint32_t e[kDrmmTrips];
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) {
+      if (id[u] > 0) {
+#pragma unroll
+        for (int q = 0; q < kQT; ++q) {
+          if (q < a.Q) {
+            const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
+            if ((int)bin < m.nbins) atomicAdd(&myh[q * kWaveBins + bin], 1);
+            if (by & kBinExact) atomicAdd(&myh[q * kWaveBins + m.nbins], 1);
+          }
+        }
+      } else if (id[u] < 0) {
+        ++n_oov;       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_oov += __shfl_xor(n_oov, o, 64);
+  if (lane == 0 && n_oov > 0) {
+    const int bz = list_bin_of(0.f, m.edges, m.nbins);
+    if (bz < m.nbins)
+      for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&H[q * kWaveBins + bz], n_oov);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  {
     const int q = lane >> 4, j = lane & 15;
     const bool on = q < a.Q;
     const int64_t qid = on ? qids.q(q) : 0;
     if (on && j == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
     const bool ina = j < NB, inb = j + 16 < NB;
-    const int ha = hist[q][j], hb = hist[q][j + 16];
+    int ha = 0, hb = 0;
+#pragma unroll
+    for (int c = 0; c < kWaveCopies; ++c) {
+      ha += H[c * kWaveStride + q * kWaveBins + j];
+      hb += H[c * kWaveStride + q * kWaveBins + j + 16];
+    }
     if (m.counts_out && on) {
       int32_t* co = m.counts_out + ((int64_t)b * a.Q + q) * NB;
       if (ina) co[j] = ha;
@@ -534,51 +650,6 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
       }
     }
     if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
-    return;
-  }
-  // more than 32 bins or 16 nodes: a wave per query term, as the per-pair kernels
-  const int q = wave;
-  if (q < a.Q) {
-    const int64_t qid = qids.q(q);
-    if (lane == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
-    const int* h = hist[q];
-    if (m.counts_out && lane < NB) m.counts_out[((int64_t)b * a.Q + q) * NB + lane] = h[lane];
-    float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;
-    if (m.hist_type == 1) hv = hv / wave_allreduce_sum(hv);
-    else if (m.hist_type == 2) hv = lane < NB ? logf(hv) : 0.f;
-    const float b1v = lane < m.nodes ? m.b1[lane] : 0.f, w2v = lane < m.nodes ? m.w2[lane] : 0.f, b2v = m.b2[0];
-    const float gate0 = m.gate_type == 0 ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
-    float acc = 0.f;
-    for (int n = 0; n < m.nodes; ++n) {
-      const float wv = lane < NB ? m.w1[n * NB + lane] : 0.f;
-      const float sn = wave_allreduce_sum(wv * hv);
-      if (lane == n) acc = sn;
-    }
-    acc += b1v;
-    const float o = wave_allreduce_sum(lane < m.nodes ? w2v * tanhf(acc) : 0.f) + b2v;
-    float gl;
-    if (m.gate_type == 0) {
-      gl = gate0;
-    } else {
-      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
-      float p = 0.f;
-      for (int c = lane; c < m.D; c += 64) p = __builtin_fmaf(m.gate_w[c], e[c], p);
-      gl = wave_allreduce_sum(p);
-    }
-    if (qid == 0) gl += -1e7f;
-    if (lane == 0) { zs[q] = tanhf(o); gs[q] = gl; }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float mx = gs[0];
-    for (int t = 1; t < a.Q; ++t) mx = fmaxf(mx, gs[t]);
-    float den = 0.f, num = 0.f;
-    for (int t = 0; t < a.Q; ++t) {
-      const float e = expf(gs[t] - mx);
-      den += e;
-      num = __builtin_fmaf(e, zs[t], num);
-    }
-    m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
   }
 }
 
@@ -688,6 +759,12 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   hipStream_t s = (hipStream_t)stream;
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
-                     hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
+                     if (nbins + 1 <= kWaveBins && nodes <= 16) {
+                       ListsArgs aq = a;
+                       aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                       hipLaunchKernelGGL(lists_drmm_pool_wave_kernel, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     } else {
+                       hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
+                     }
                    });
 }
