@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (id[u] >= a.V) bad = true;
-      else if (id[u] > 0) f[id[u]] = 1;        // (unconditional: a check of the flag first puts a load in front of every store and measures the same)
+      else if (id[u] > 0) f[id[u]] = 1;        // (unconditional: a check of the flag first puts a load in front of every store and measures the same;
+                                               //  so does an LDS bit map of the terms a workgroup of 16 documents has stored already: 123-142 us for 114)
     }
   }
   if (bad) atomicOr(a.status, kErrDocIdRange);

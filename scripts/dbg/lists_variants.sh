@@ -39,7 +39,7 @@ for spec in "$@"; do
 import csv,glob
 f=glob.glob("/tmp/p/**/*kernel_stats.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-print("== $name $model", "  ".join("%s %.1f" % (r["Name"].split("lists_")[-1][:14] if "lists_" in r["Name"] else r["Name"][:14], float(r["AverageNs"])/1e3) for r in rows[:12] if int(r["Calls"]) >= 10))
+print("== $name $model", "  ".join("%s %.1f" % (r["Name"].split("lists_")[-1][:14] if "lists_" in r["Name"] else r["Name"][:14], float(r["AverageNs"])/1e3) for r in rows[:14] if int(r["Calls"]) >= 10 and "lists_" in r["Name"]))
 PY
   done
-done 2>&1 | tee -a gpurun_out/lists_variants.txt
+done 2>&1 | tee -a $R/gpurun_out/lists_variants.txt

@@ -2,7 +2,7 @@
 # One GPU-box session (round 3): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
 # (scripts/collect_profiles.sh r03 copies what is kept into profiles/r03/).
 set -u
-mkdir -p gpurun_out/prof
+rm -rf gpurun_out/prof gpurun_out/ab_*.json; mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python $R/bench.py"
@@ -56,7 +56,30 @@ done
 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 cd $R
-for f in $(find $P -name "*.csv" -size -12000k); do d=gpurun_out/prof/$(basename $(dirname $f)); case $(basename $(dirname $(dirname $f))) in prof) ;; *) d=gpurun_out/prof/$(basename $(dirname $(dirname $f)));; esac; mkdir -p $d; cp $f $d/; done
+# what travels back (gpurun_out/ is capped at 64 MiB): the kernel statistics and agent info as they are; of the counter files only the rows of this
+# library's kernels; no kernel traces
+python3 - $P gpurun_out/prof <<'PY'
+import csv, os, shutil, sys
+src, dst = sys.argv[1:3]
+for root, _, files in os.walk(src):
+    for f in files:
+        if not f.endswith(".csv") or f.endswith("kernel_trace.csv"):
+            continue
+        rel = os.path.relpath(root, src).split(os.sep)[0]
+        os.makedirs(os.path.join(dst, rel), exist_ok=True)
+        out = os.path.join(dst, rel, f)
+        if f.endswith("counter_collection.csv"):
+            with open(os.path.join(root, f)) as fi, open(out, "w", newline="") as fo:
+                r = csv.DictReader(fi)
+                w = csv.DictWriter(fo, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
+                w.writeheader()
+                for row in r:
+                    k = row["Kernel_Name"]
+                    if any(t in k for t in ("capamd", "lists_", "forward_kernel", "stream_kernel", "gemm_", "attention_")):
+                        w.writerow({"Kernel_Name": k[:120], "Counter_Name": row["Counter_Name"], "Counter_Value": row["Counter_Value"]})
+        elif os.path.getsize(os.path.join(root, f)) < 4000 * 1024:
+            shutil.copy(os.path.join(root, f), out)
+PY
 python scripts/summarize_pmc.py gpurun_out/prof > gpurun_out/pmc_summary.txt 2>&1; cat gpurun_out/pmc_summary.txt
 timeout 200 ./scripts/ubench/mfma_power > gpurun_out/mfma_power.txt 2>&1; cat gpurun_out/mfma_power.txt
 [ -x ./scripts/ubench/hbm_read ] && { timeout 200 ./scripts/ubench/hbm_read > gpurun_out/hbm_read.txt 2>&1; cat gpurun_out/hbm_read.txt; }

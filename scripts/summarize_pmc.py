@@ -43,9 +43,9 @@ for model in ("knrm", "drmm"):
         t = counters(name + "_tcc", ("forward_kernel", "stream_kernel"))
         route = "per-pair kernel"
         if not f or not w:      # the headline leg scored as whole candidate lists: mark + query + sims + pool per call
-            f = counters_per_call(name + "_fetch", "lists_", "_pool_kernel").get("FETCH_SIZE")
-            w = counters_per_call(name + "_write", "lists_", "_pool_kernel").get("WRITE_SIZE")
-            t = counters_per_call(name + "_tcc", "lists_", "_pool_kernel")
+            f = counters_per_call(name + "_fetch", "lists_", "_pool_").get("FETCH_SIZE")
+            w = counters_per_call(name + "_write", "lists_", "_pool_").get("WRITE_SIZE")
+            t = counters_per_call(name + "_tcc", "lists_", "_pool_")
             route = "whole candidate lists: sums over lists_mark / lists_query / lists_sims / lists_*_pool per call"
         if not f or not w:
             continue
