@@ -1633,6 +1633,34 @@ def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
         assert torch.equal(lists, pairwise), (hist, gate, extra, float((lists - pairwise).abs().max()))
 
 
+@pytest.mark.parametrize("D,Q,L,V,docs", [
+    (50, 3, 37, 700, [5, 1, 40]),                       # one float4 chunk per lane, three query terms, a short odd document length
+    (100, 1, 130, 1500, [9] * 11),                      # one query term; more than 8 lists (the XCD-aware numbering)
+    (200, 4, 1000, 2100, [2, 300]),                     # documents longer than the benchmark's; ids beyond one 1024-id block
+    (300, 2, 64, 1030, [3] * 70),                       # more lists than one launch group holds (64)
+])
+def test_lists_random_geometries(D, Q, L, V, docs):
+    """The list route over the shapes the per-pair sweep covers: embedding widths of 1-5 float4 chunks per lane, 1-4 query terms, short /
+    long documents, fewer and more lists than an XCD group and than a launch group - KNRM against the per-pair kernel to fp32 rounding
+    of its sums, DRMM bit for bit."""
+    emb = synthetic.make_embeddings(V, D, seed=D + Q)
+    b, off = _lists_batch(len(docs), docs, V, 100 + L, Q=Q, L=L)
+    d = {k: _t(v) for k, v in b.items()}
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(L)
+    r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        pairwise, lists = r.test(d).cpu().numpy(), r.test_lists(d, off).cpu().numpy()
+    scale = float(np.abs(pairwise).max())
+    assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (np.abs(lists - pairwise).max(), scale)
+    no_oov = {**d, "query": d["query"].clamp(min=0)}      # (DRMM refuses OOV query terms)
+    r = DRMM({}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(L)
+    r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(r.test_lists(no_oov, off), r.test(no_oov))
+
+
 @pytest.mark.parametrize("model", ["knrm", "drmm"])
 def test_predict_scores_whole_lists_where_the_reranker_can(model, monkeypatch):
     """`PytorchTrainer.predict` on its resident route hands whole candidate lists to the rerankers whose list scores equal their per-pair
