@@ -643,9 +643,13 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
     gathered = torch.empty(n_pairs * world, dtype=torch.float32, device=dev) if use_dist else None
     out = [None]
 
+    # whole candidate lists (csrc/lists.hip) where the model takes them, unless asked otherwise or on the uniform-id leg (lists share nothing there)
+    as_lists = bool(getattr(rr, "supports_lists", False)) and not args.per_pair and not uniform and n_queries >= 4
+    offsets = np.arange(0, n_pairs + 1, args.docs, dtype=np.int64)
+
     def step(_):
         with torch.no_grad():
-            out[0] = m(d_all, q_all, idf_all).view(-1)
+            out[0] = m.forward_lists(offsets, query=q_all, doc=d_all, idf=idf_all).view(-1) if as_lists else m(d_all, q_all, idf_all).view(-1)
         if use_dist:
             dist.all_gather_into_tensor(gathered, out[0])
 
@@ -662,7 +666,7 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
         row = G * (G + 1) // 2 * F * 4
     else:
         row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
-    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad
+    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad, as_lists
 
 
 def sibling_oracle(model, m, D, q, d, idf, emb_h):
@@ -702,7 +706,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
     Q, L, V, D = 4, 800, args.vocab, args.dim
     n_queries = args.queries or 64
     n_pairs = n_queries * args.docs
-    rr, m, batch, scores, elapsed, kern_s, row, nonpad = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
+    rr, m, batch, scores, elapsed, kern_s, row, nonpad, as_lists = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
     q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
     emb = table(dev, V, D)
     if model == "convknrm":
@@ -711,6 +715,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
     else:
         abytes = algorithmic_bytes_per_pair("knrm", Q, L, D) + 4 * Q
         kname = {"drmmtks": "drmmtks_forward_kernel<5, 12>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[model]
+    headline_kernel = "lists_mark_kernel + lists_query_kernel<5> + lists_sims_kernel<5, false> + lists_tks_pool_kernel<12>" if as_lists else kname
     requested = n_pairs * (L * 8 + Q * 8 + (nonpad + Q) * row + 4) / kern_s / 1e9
     if rank != 0:
         return None
@@ -741,12 +746,14 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{rr.module_name} inference (SURVEY.md §8f row N4) on the KNRM benchmark's lists: qlen={Q} dlen={L} embed={D} vocab={V}, "
                                f"{args.docs} docs/query x {n_queries} queries per step per GPU, {'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, "
-                               "reference default model options",
+                               + ("scored as whole candidate lists, " if as_lists else "") + "reference default model options",
                    "pairs_per_step_per_gpu": n_pairs, "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU"},
         # `frac`: the HBM-bound leg (uniform ids over the --roofline-vocab table); on the Zipf ids of the headline leg the rate is a cache-level rate
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": hbm["achieved"] if hbm else (requested if args.uniform_ids else None), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": hbm["frac"] if hbm else (requested / HBM_PEAK_GBS if args.uniform_ids else None), "traffic": None,
-                     "hbm_leg": hbm, "kernel_ms": kern_s * 1e3, "pairs_per_launch": n_pairs,
+                     "hbm_leg": hbm, "headline_kernel": headline_kernel,
+                     "headline_route": "whole candidate lists (csrc/lists.hip); `kernel` / `frac` are the HBM-bound leg's per-pair kernel" if as_lists else "per-pair kernel",
+                     "kernel_ms": kern_s * 1e3, "pairs_per_launch": n_pairs,
                      "requested_GBps": requested, "algorithmic_bytes_per_pair": abytes, "algorithmic_GBps": n_pairs * abytes / kern_s / 1e9,
                      "mean_nonpad_terms_per_doc": nonpad,
                      "note": "requested = int64 ids + one gathered row per in-vocabulary term / device time of one scoring call (one HIP event pair "

@@ -47,6 +47,8 @@ SIGNATURES = {
     "capamd_knrm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "capamd_drmm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "capamd_drmmtks_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                          _vp]),
     "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmmtks_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "capamd_pacrr_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

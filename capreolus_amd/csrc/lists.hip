@@ -654,6 +654,138 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
   }
 }
 
+// ---- 3c: DRMM-TKS pooling -------------------------------------------------------------------------------------------------------
+//   The KNRM form of the sims pass (four floats per term), then per document the top-k similarities of
+// every query term over ALL positions (reference DRMMTKS.py:55-56; pads and unmatched OOV terms contribute their 0, OOV exact matches
+// their 1) -> Linear(k, 1) + tanh -> idf gate -> output layer, as drmmtks.hip.  A wave per document, a lane per (position slot, query
+// term) as in the KNRM pooling: every lane keeps a sorted top-KT of the similarities it meets (compare-exchange chain in registers),
+// the 16 lists of a row are merged in k rounds of a row-wide maximum over the list heads (LDS) and the closed-form candidates.  The
+// values are selections of bit-identical similarities and enter the Linear in the same order: the scores equal capamd_drmmtks_forward's.
+struct TksPoolArgs {
+  const float* idf;      // [B, Q] or the query table's [NQ, Q] in indexed mode
+  int topk;
+  const float* gate_w;   // [1]
+  const float* ffw_w;    // [topk]
+  const float* ffw_b;    // [1]
+  const float* out_w;
+  const float* out_b;
+  float* out;
+};
+constexpr int kMaxTopK = 16;
+
+__device__ __forceinline__ float group_allreduce_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGeom g, TksPoolArgs m) {
+  __shared__ float heads[4][KT][64];        // [wave][list entry][lane]
+  int l, dq;
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
+  const int b = g.start[l] + doc, K = m.topk;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
+  int64_t qid = t < a.Q ? qids.q(t) : 0;
+  if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
+  const float ffw_l = lane < K ? m.ffw_w[lane] : 0.f;
+  const float gl0 = t < a.Q ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + t] : 0.f;
+  float top[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
+  int n_one = 0, n_real = 0;
+  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
+  for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
+    int id[kWaveTrips];
+    if (ids.d32) {
+      int live = 0;
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) {
+        const int j = j0 + u * 16 + ps;
+        id[u] = ids.d32[j < a.L ? j : a.L - 1];
+        live |= id[u];
+      }
+      if (!__any(live != 0)) continue;
+    } else {
+      int64_t w[kWaveTrips], live = 0;
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) {
+        const int j = j0 + u * 16 + ps;
+        w[u] = ids.d64[j < a.L ? j : a.L - 1];
+        live |= w[u];
+      }
+      if (!__any(live != 0)) continue;
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u)
+      if (j0 + u * 16 + ps >= a.L || id[u] >= a.V) id[u] = 0;
+    float s[kWaveTrips];
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) {
+      if (!__any(id[u] != 0)) continue;
+      if (id[u] > 0) {
+        ++n_real;
+        float v = s[u];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {     // compare-exchange chain: top[] stays sorted, v carries the displaced value
+          const float hi = fmaxf(top[i], v);
+          v = fminf(top[i], v);
+          top[i] = hi;
+        }
+      } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
+        ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KT; ++i) heads[wave][i][lane] = top[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
+  const int no = (int)group_allreduce((float)n_one), nreal = (int)group_allreduce((float)n_real);
+  const int nz = a.L - nreal - no;          // pads and OOV terms without a match: similarity 0
+  int head = 0, used1 = 0, used0 = 0;
+  float acc = m.ffw_b[0];
+  for (int r = 0; r < K; ++r) {
+    const float cand = head < KT ? heads[wave][head][lane] : -INFINITY;
+    const float from_lists = group_allreduce_max(cand);
+    const float c1 = used1 < no ? 1.f : -INFINITY, c0 = used0 < nz ? 0.f : -INFINITY;
+    const float best = fmaxf(from_lists, fmaxf(c1, c0));
+    const unsigned row = (unsigned)(__ballot(cand == best && best > -INFINITY) >> (16 * t)) & 0xffffu;
+    if (row) {
+      if (ps == __ffs((int)row) - 1) ++head;          // one list of the row advances
+    } else if (c1 == best) {
+      ++used1;
+    } else {
+      ++used0;
+    }
+    if (best > -INFINITY) acc = __builtin_fmaf(lane_bcast(ffw_l, r), best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+  }
+  const float z = tanhf(acc);
+  float gl = gl0;
+  if (qid == 0) gl += -1e7f;   // DRMMTKS.py:38
+  float mx = lane_bcast(gl, 0);
+  for (int q = 1; q < a.Q && q < kQT; ++q) mx = fmaxf(mx, lane_bcast(gl, 16 * q));
+  float den = 0.f, num = 0.f;
+#pragma unroll
+  for (int q = 0; q < kQT; ++q) {
+    if (q < a.Q) {
+      const float e = expf(lane_bcast(gl, 16 * q) - mx);
+      den += e;
+      num = __builtin_fmaf(e, lane_bcast(z, 16 * q), num);
+    }
+  }
+  if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 4 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
@@ -767,5 +899,29 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
                      } else {
                        hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
                      }
+                   });
+}
+
+extern "C" int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
+                                            const int32_t* pair_q, const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host,
+                                            int n_lists, int Q, int L, const float* packed, int64_t V, int D, int topk, const float* gate_w,
+                                            const float* ffw_w, const float* ffw_b, const float* out_w, const float* out_b, float* out, int* status,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_lists == 0) return CAPAMD_OK;
+  const bool indexed = q_table != nullptr;
+  if (indexed ? (!d_table || !pair_q || !pair_d) : (!q_ids || !d_ids)) return CAPAMD_ERR_ARG;
+  if (!idf || !gate_w || !ffw_w || !ffw_b || !out_w || !out_b || !out || topk < 1 || topk > kMaxTopK || topk > L) return CAPAMD_ERR_ARG;
+  const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  const TksPoolArgs m{idf, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out};
+  hipStream_t s = (hipStream_t)stream;
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0,
+                   [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
+                     ListsArgs aq = a;
+                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                     const dim3 grid = list_doc_grid(nl, aq.longest);
+                     if (topk <= 4) hipLaunchKernelGGL(lists_tks_pool_kernel<4>, grid, dim3(256), 0, s, aq, g, m);
+                     else if (topk <= 8) hipLaunchKernelGGL(lists_tks_pool_kernel<8>, grid, dim3(256), 0, s, aq, g, m);
+                     else if (topk <= 12) hipLaunchKernelGGL(lists_tks_pool_kernel<12>, grid, dim3(256), 0, s, aq, g, m);
+                     else hipLaunchKernelGGL(lists_tks_pool_kernel<16>, grid, dim3(256), 0, s, aq, g, m);
                    });
 }

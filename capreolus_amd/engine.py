@@ -702,6 +702,29 @@ def drmmtks_forward(query, doc, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b, o
     return out
 
 
+def drmmtks_forward_lists(offsets, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b, out_w, out_b, query=None, doc=None, store=None, pair_q=None,
+                          pair_d=None, out=None, check=True):
+    """DRMM-TKS over whole candidate lists (capamd_drmmtks_forward_lists); `idf`: [B, Q] per pair, or the store's [NQ, Q] table."""
+    q, d, qt, dt, pq, pd, B, Q, L, dev = _lists_ids(query, doc, store, pair_q, pair_d)
+    _need_gpu(packed, gate_w, ffw_w, ffw_b, out_w, out_b)
+    off = _list_offsets(offsets)
+    if int(off[-1]) != B:
+        raise ValueError("the last list offset must be the number of pairs")
+    if topk > L:
+        raise RuntimeError("selected index k out of range")  # what torch.topk raises at DRMMTKS.py:56
+    idf = _f32(idf)
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    rc = _lib.load().capamd_drmmtks_forward_lists(
+        _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
+        int(topk), _ptr(gate_w), _ptr(ffw_w), _ptr(ffw_b), _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "capamd_drmmtks_forward_lists")
+    if check:
+        st.raise_if_set()
+    return out
+
+
 def drmmtks_features(query, doc, packed, V, D, topk, check=True):
     """The sorted top-k similarities of every query term (DRMMTKS.py:55-56): fp32 [B, Q, topk] (capamd_drmmtks_features)."""
     _need_gpu(query, doc, packed)

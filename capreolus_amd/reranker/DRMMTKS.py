@@ -40,6 +40,15 @@ class DRMMTKS_class(nn.Module):
         return out.view(-1, 1)
 
 
+    def forward_lists(self, offsets, query=None, doc=None, idf=None, store=None, pair_q=None, pair_d=None):
+        """Whole candidate lists through capamd_drmmtks_forward_lists -> [B] (see KNRM_class.forward_lists); a list takes the idf row of
+        its first pair."""
+        w = self.embedding.weight
+        return engine.drmmtks_forward_lists(
+            offsets, store.idf_table if store is not None else idf, self._packed.get(w), w.shape[0], w.shape[1], self.topk,
+            self.gates.weight.detach().view(-1), self.ffw[0].weight.detach().contiguous().view(-1), self.ffw[0].bias.detach(),
+            self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), query=query, doc=doc, store=store, pair_q=pair_q, pair_d=pair_d)
+
     def _forward_train(self, doc, query, query_idf):
         """Training step (reference trainer/pytorch.py:96-99 -> DRMMTKS.score): the gather / similarity / top-k - everything that
         touches the [B, Q, L] tensors - is the HIP kernel (capamd_drmmtks_features); the embedding table is frozen, so no
@@ -72,3 +81,12 @@ class DRMMTKS(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmmtks_forward_lists)
+    lists_bit_identical = True # (top-k selections of bit-identical similarities, fed to the Linear in the same order)
+
+    def test_lists(self, d, offsets):
+        return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"], idf=d["query_idf"])
+
+    def test_resident_lists(self, store, pair_q, pair_d, offsets):
+        return self.model.forward_lists(offsets, store=store, pair_q=pair_q, pair_d=pair_d)

@@ -159,6 +159,13 @@ int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const 
                               const float* gate_w, const float* emb_raw, int64_t ld, const float* w1, const float* b1, int nodes, const float* w2,
                               const float* b2, const float* out_w, const float* out_b, float* out, int32_t* counts_out, int* status,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* DRMM-TKS the same way (the float form of the table, then per document the top-k of every query term's lookups): scores bit-identical
+ * to capamd_drmmtks_forward's (selections of bit-identical similarities, fed to the Linear in the same order).  IDF gate; Q <= 4. */
+int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                                 const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host, int n_lists, int Q, int L,
+                                 const float* packed, int64_t V, int D, int topk, const float* gate_w, const float* ffw_w, const float* ffw_b,
+                                 const float* out_w, const float* out_b, float* out, int* status, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* ---- DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64) behind DRMMTKS.test (:105-110) ------------------
  * A sibling of DRMM on the same fused front end: per query term the top-k similarities over all

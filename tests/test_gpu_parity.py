@@ -1633,6 +1633,44 @@ def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
         assert torch.equal(lists, pairwise), (hist, gate, extra, float((lists - pairwise).abs().max()))
 
 
+@pytest.mark.parametrize("topk", [10, 3, 16])
+def test_drmmtks_lists_are_bit_identical_to_the_per_pair_kernel(topk):
+    """DRMM-TKS over whole lists (capamd_drmmtks_forward_lists): top-k selections of bit-identical similarities, fed to the Linear in the
+    same order - the scores equal capamd_drmmtks_forward's bit for bit; ragged lists, OOV query terms with exact matches in the
+    documents, an all-pad document, a document of fewer real terms than k; ids as rows and through a candidate store."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.reranker import DRMMTKS
+
+    V, D = 3000, 300
+    emb = synthetic.make_embeddings(V, D, seed=8)
+    docs = [300, 1, 17, 90]
+    b, off = _lists_batch(len(docs), docs, V, 31)
+    b["posdoc"][7] = 0
+    b["posdoc"][8, 5:] = 0
+    b["posdoc"][9, 3] = b["query"][9, 0] if b["query"][9, 0] < 0 else -4
+    r = DRMMTKS({"topk": topk}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(2)
+    m = r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        m.gates.weight.mul_(40.0)
+        m.ffw[0].weight.mul_(6.0)
+    d = {k: _t(v) for k, v in b.items()}
+    with torch.no_grad():
+        pairwise = r.test(d)
+        lists = r.test_lists(d, off)
+    assert torch.equal(lists, pairwise), float((lists - pairwise).abs().max())
+    store = CandidateStore(DEV)
+    for i in range(len(off) - 1):
+        store.add_query(f"q{i}", b["query"][off[i]], b["query_idf"][off[i]])
+    for j in range(b["posdoc"].shape[0]):
+        store.add_doc(f"d{j}", b["posdoc"][j])
+    store.finalize()
+    pq = _t(np.repeat(np.arange(len(docs)), docs).astype(np.int32))
+    pd = _t(np.arange(b["posdoc"].shape[0], dtype=np.int32))
+    with torch.no_grad():
+        assert torch.equal(r.test_resident_lists(store, pq, pd, off), pairwise)
+
+
 @pytest.mark.parametrize("D,Q,L,V,docs", [
     (50, 3, 37, 700, [5, 1, 40]),                       # one float4 chunk per lane, three query terms, a short odd document length
     (100, 1, 130, 1500, [9] * 11),                      # one query term; more than 8 lists (the XCD-aware numbering)
