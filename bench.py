@@ -366,6 +366,28 @@ class InteractionLeg:
             assert torch.equal(self.gathered[self.last_gather][r * self.n_pairs:(r + 1) * self.n_pairs], self.out)
         return elapsed, dev_s
 
+    def lists_pass_times(self, steps=5):
+        """The passes of the whole-list route one by one: HIP events on the stream the kernels run on, recorded by the library between the
+        passes of `steps` more steps after the timed loop (csrc/capamd_profiling.h: capamd_debug_lists_timing; the events sit between
+        launches, so a pass's figure includes its launch gap - the five add up to the step).  Returns ms per step of
+        (memset, mark, query, sims, pool)."""
+        import ctypes
+
+        from capreolus_amd import _lib
+
+        lib = _lib.profiling()
+        lib.capamd_debug_lists_timing(1)
+        try:
+            for i in range(steps):
+                for lo, hi in self.slices:
+                    self.launch_one(i % len(self.batches), lo, hi)
+            ms = (ctypes.c_double * 5)()
+            groups = lib.capamd_debug_lists_timing_read(ms)
+        finally:
+            lib.capamd_debug_lists_timing(0)
+        torch.cuda.synchronize()
+        return [m / steps for m in ms] if groups else None
+
     def bytes_requested_per_pair(self):
         """What the kernel asks the memory system for: the id rows (int64), one packed table row (row_stride floats: the embedding,
         its norm, padding to whole 128-byte lines) per DISTINCT in-vocabulary document term and per query term, the score.  A term the
@@ -498,6 +520,27 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 "Zipf ids hit L2 / Infinity Cache, so neither is an HBM rate",
     }
     if leg.lists:
+        passes = leg.lists_pass_times() if len(leg.slices) == 1 else None
+        if passes:
+            # what each pass does per step (the figures DESIGN.md section 3.5 prices the passes with) over its own duration
+            rows = distinct_per_list * (n_pairs / args.docs)
+            tokens = nonpad * n_pairs
+            K = 11
+            names = ["hipMemsetAsync (byte maps)", "lists_mark_kernel", "lists_query_kernel<5>", f"lists_sims_kernel<5, {'false' if model == 'knrm' else 'true'}>",
+                     "lists_knrm_pool_kernel" if model == "knrm" else "lists_drmm_pool_wave_kernel"]
+            work = [
+                {"bytes_cleared": (n_pairs / args.docs) * ((args.vocab + 1023) // 1024 * 1024)},
+                {"id_row_bytes": n_pairs * L * 8, "byte_stores": tokens, "GBps_of_id_rows": n_pairs * L * 8 / (passes[1] * 1e-3) / 1e9},
+                {"lists": n_pairs / args.docs},
+                {"rows_gathered": rows, "row_bytes": rows * leg.row_stride * 4, "row_GBps": rows * leg.row_stride * 4 / (passes[3] * 1e-3) / 1e9,
+                 "fp32_fma": rows * Q * leg.row_stride, "fp32_TFLOPs": 2 * rows * Q * leg.row_stride / (passes[3] * 1e-3) / 1e12,
+                 "fp32_valu_peak_TFLOPs": 78.6, "note": "256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, one fma per lane and cycle (packed fp32 issues no faster here: DESIGN.md 3.5)"},
+                ({"id_row_bytes": n_pairs * L * 8, "table_lookups": tokens, "exponentials": tokens * Q * K, "Gexp_per_s": tokens * Q * K / (passes[4] * 1e-3) / 1e9}
+                 if model == "knrm" else {"id_row_bytes": n_pairs * L * 8, "table_lookups": tokens, "lds_increments": tokens * Q}),
+            ]
+            headline["passes"] = [{"pass": nm, "ms": ms, **w} for nm, ms, w in zip(names, passes, work)]
+            headline["passes_note"] = ("HIP events recorded by the library on the launch stream between the passes of 5 more steps after the timed loop "
+                                       "(csrc/capamd_profiling.h: capamd_debug_lists_timing); a pass's ms includes its launch gap, the five add up to the step")
         headline.update({
             "route": f"whole candidate lists (capamd_{model}_forward_lists): per list every distinct term's row gathered once "
                      + ("(its four similarities kept), documents pooled from 16-byte lookups" if model == "knrm" else "(its four histogram bins kept), documents pooled from 4-byte lookups"),

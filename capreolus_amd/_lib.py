@@ -88,6 +88,8 @@ PROFILING_SIGNATURES = {
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
     "capamd_debug_ffn1_timing": (None, [_i]),
     "capamd_debug_ffn1_timing_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "capamd_debug_lists_timing": (None, [_i]),
+    "capamd_debug_lists_timing_read": (_i, [ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

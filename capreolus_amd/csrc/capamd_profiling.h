@@ -15,6 +15,12 @@ extern "C" {
  * capamd_debug_ffn1_timing_read synchronises those events, returns the summed duration in milliseconds, the number of
  * launches and the summed GEMM rows since the last read, and clears the list. */
 void capamd_debug_set_gemm_stamps(void* stamps);
+/* capamd_debug_lists_timing (bench.py's headline leg): while enabled, the whole-list entries (capamd_*_forward_lists) record a HIP event
+ * on the caller's stream after each of their passes - memset, mark, query, sims, pool - of every launch group;
+ * capamd_debug_lists_timing_read synchronises them, adds the five durations in milliseconds to ms[0..4], returns the number of launch
+ * groups since the last read and clears the list. */
+void capamd_debug_lists_timing(int enable);
+int capamd_debug_lists_timing_read(double* ms);
 void capamd_debug_ffn1_timing(int enable);
 int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows);
 

@@ -26,7 +26,9 @@
 // lists are processed in chunks of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits as the per-pair entries.
 #include "capreolus_amd.h"
 #include "interaction.cuh"
+#include "capamd_profiling.h"
 #include <stdlib.h>
+#include <vector>
 
 using namespace capamd;
 
@@ -790,6 +792,17 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
 constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 4 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 
+// capamd_debug_lists_timing: six events per launch group while enabled (profiling only: not thread-safe, off by default)
+bool g_lists_timing = false;
+std::vector<hipEvent_t> g_lists_events;
+void lists_stamp(hipStream_t s) {
+  if (!g_lists_timing) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_lists_events.push_back(e);
+}
+
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
 template <class Pool>
 int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V, int D, int* status,
@@ -826,11 +839,15 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     ListQuery* qmeta = reinterpret_cast<ListQuery*>(qimg + (size_t)cap * kQueryImage);
     float* kn_consts = kn_mu ? reinterpret_cast<float*>(qmeta + cap) : nullptr;
     ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, kn_consts};
+    lists_stamp(s);
     if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
+    lists_stamp(s);
     hipLaunchKernelGGL(lists_mark_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g);
+    lists_stamp(s);
     const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl), dim3(128), 0, s, a, g);                                  \
+  lists_stamp(s);                                                                                               \
   if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true>), sg, dim3(256), 0, s, a, g);                      \
   else hipLaunchKernelGGL((lists_sims_kernel<NV, false>), sg, dim3(256), 0, s, a, g)
     switch (nv_for_dim(D)) {
@@ -841,13 +858,35 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       default: CAPAMD_SIMS(5); break;
     }
 #undef CAPAMD_SIMS
+    lists_stamp(s);
     pool(a, g, nl, longest);
+    lists_stamp(s);
     if (hipGetLastError() != hipSuccess) return CAPAMD_ERR_LAUNCH;
   }
   return CAPAMD_OK;
 }
 
 }  // namespace
+
+extern "C" void capamd_debug_lists_timing(int enable) {
+  g_lists_timing = enable != 0;
+  for (hipEvent_t e : g_lists_events) (void)hipEventDestroy(e);
+  g_lists_events.clear();
+}
+
+extern "C" int capamd_debug_lists_timing_read(double* ms) {
+  const size_t groups = g_lists_events.size() / 6;
+  for (size_t i = 0; i < groups; ++i) {
+    (void)hipEventSynchronize(g_lists_events[6 * i + 5]);
+    for (int k = 0; k < 5; ++k) {
+      float t = 0.f;
+      if (ms && hipEventElapsedTime(&t, g_lists_events[6 * i + k], g_lists_events[6 * i + k + 1]) == hipSuccess) ms[k] += t;
+    }
+  }
+  for (hipEvent_t e : g_lists_events) (void)hipEventDestroy(e);
+  g_lists_events.clear();
+  return (int)groups;
+}
 
 extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
   if (n_lists < 1 || V < 1) return 0;
