@@ -758,7 +758,8 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
     else:
         abytes = algorithmic_bytes_per_pair("knrm", Q, L, D) + 4 * Q
         kname = {"drmmtks": "drmmtks_forward_kernel<5, 12>", "pacrr": "pacrr_mfma_kernel<5, 2>"}[model]
-    headline_kernel = "lists_mark_kernel + lists_query_kernel<5> + lists_sims_kernel<5, false> + lists_tks_pool_kernel<12>" if as_lists else kname
+    headline_kernel = ("lists_mark_kernel + lists_query_kernel<5> + lists_sims_kernel<5, false> + "
+                       + {"drmmtks": "lists_tks_pool_kernel<12>", "pacrr": "pacrr_mfma_lists_kernel<5, 2>"}.get(model, "")) if as_lists else kname
     requested = n_pairs * (L * 8 + Q * 8 + (nonpad + Q) * row + 4) / kern_s / 1e9
     if rank != 0:
         return None

@@ -51,6 +51,8 @@ SIGNATURES = {
                                           _vp]),
     "capamd_drmmtks_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmmtks_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "capamd_pacrr_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "capamd_pacrr_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
     "capamd_convknrm_table_bytes": (_i64, [_i64, _i, _i]),

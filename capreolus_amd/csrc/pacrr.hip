@@ -28,6 +28,7 @@
 //                (Most K slots multiply zeros - 3 of 16 carry weights - and the matrix pipe is still ~9x the VALU form.)
 #include "capreolus_amd.h"
 #include "interaction.cuh"
+#include "lists.cuh"
 
 using namespace capamd;
 
@@ -411,8 +412,11 @@ __host__ __device__ inline int pacrr_mfma_region0(int L, int n_weights) {
 }
 
 // KM = length of the per-lane candidate lists (>= kmax)
+// `table` != nullptr: the whole-list route (lists.cuh) - the pair's list has its terms' four similarities in table[id] already, and the
+// front end is a lookup per position instead of the distinct-term pass and the gather (same values: the matrix, and with it the score,
+// is bit-identical).
 template <int NV, int KM>
-__global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kernel(PacrrArgs a) {
+__device__ __forceinline__ void pacrr_mfma_body(const PacrrArgs& a, const int b, const float4* table) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tok_cap = (a.L + 7) & ~7;
   const int LP = ((a.L + 63) & ~63) + 4;                         // positions in the LDS image (zero tail = right padding)
@@ -431,13 +435,15 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
   float4* qlds = reinterpret_cast<float4*>(wave_cnt + 48);       // (192 bytes after a 16-byte aligned plane: aligned)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x;
   const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
   const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
 
   // distinct terms and their positions first: the hash of that pass borrows the (not yet initialised) matrix planes
-  const TermList tl = distinct_terms_positions(ids, a.L, a.V, a.status, tok, start, plist, reinterpret_cast<int*>(s_hi), LP * 8, wave_cnt);
-  int n_real = tl.n_unique;
+  int n_real = 0;
+  if (!table) {
+    const TermList tl = distinct_terms_positions(ids, a.L, a.V, a.status, tok, start, plist, reinterpret_cast<int*>(s_hi), LP * 8, wave_cnt);
+    n_real = tl.n_unique;
+  }
   {
     u32x4 z = {0u, 0u, 0u, 0u}, one = {0u, 0u, 0u, 0x3C000000u};   // row 7 = 1.0
     for (int i = tid; i < LP; i += kThreads) {
@@ -446,11 +452,34 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
     }
   }
   if (CAPAMD_PACRR_ABLATE == 2) n_real = 0;
-  pacrr_similarities_distinct<NV, CAPAMD_PACRR_U>(a, ids, tok, start, plist, n_real, qlds, tid, [&](int row, int j, float x) {
+  auto put = [&](int row, int j, float x) {
     const float h = f16_round(x);
     s_hi[j * 8 + row] = (_Float16)h;
     s_lo[j * 8 + row] = (_Float16)(x - h);
-  });
+  };
+  if (table) {
+    int64_t qid[kQT];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) qid[t] = t < a.Q ? ids.q(t) : 0;
+    __syncthreads();        // (the planes are initialised)
+    for (int j = tid; j < a.L; j += kThreads) {
+      const int64_t did = ids.d(j);
+      if (did > 0 && did < a.V) {        // (an id beyond the table was flagged by the mark pass)
+        const float4 x = table[did];
+        put(0, j, x.x);
+        if (a.Q > 1) put(1, j, x.y);
+        if (a.Q > 2) put(2, j, x.z);
+        if (a.Q > 3) put(3, j, x.w);
+      } else if (did < 0 && did > -2147483648LL) {   // OOV exact matches (equal negative ids): 1.0 (common.py:155-158)
+#pragma unroll
+        for (int t = 0; t < kQT; ++t)
+          if (qid[t] < 0 && (int)qid[t] == (int)did) put(t, j, 1.f);
+      }
+    }
+    __syncthreads();
+  } else {
+    pacrr_similarities_distinct<NV, CAPAMD_PACRR_U>(a, ids, tok, start, plist, n_real, qlds, tid, put);
+  }
   // (the front end ended on a barrier: tok / pos are dead, region 0 now takes the weights)
   for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
   for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
@@ -527,6 +556,19 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kerne
   pacrr_head(a, ids, feat, h1, h2, qts, tid, b);
 }
 
+template <int NV, int KM>
+__global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kernel(PacrrArgs a) {
+  pacrr_mfma_body<NV, KM>(a, blockIdx.x, nullptr);
+}
+
+// whole candidate lists: a workgroup per (list, document) in the XCD-aware numbering of lists.cuh
+template <int NV, int KM>
+__global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_lists_kernel(PacrrArgs a, ListsArgs la, ListGeom g) {
+  int l, doc;
+  if (!list_doc_of(la, l, doc) || doc >= g.len[l]) return;
+  pacrr_mfma_body<NV, KM>(a, g.start[l] + doc, la.table + (int64_t)l * la.Vp);
+}
+
 }  // namespace
 
 static bool pacrr_force_valu() {   // CAPAMD_PACRR_VALU=1: the general kernel for every geometry (A/B measurements, tests)
@@ -600,4 +642,48 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
 #undef LAUNCH_P
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+/* PACRR over whole candidate lists (lists.cuh): mark -> sims (every distinct term of a list gathered once) -> the MFMA kernel with a
+ * table lookup per position as its front end.  Q <= 4, nfilters <= 32 (the MFMA kernel's geometry); scores bit-identical to
+ * capamd_pacrr_forward's. */
+extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
+                                          const int32_t* pair_q, const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host,
+                                          int n_lists, int Q, int L, const float* packed, int64_t V, int D, int mingram, int maxgram, int nfilters,
+                                          int kmax, const float* conv_w, const float* conv_b, int use_idf, int combine, int nonlinearity,
+                                          const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                                          float* out, int* status, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_lists == 0) return CAPAMD_OK;
+  const bool indexed = q_table != nullptr;
+  if (indexed ? (!d_table || !pair_q || !pair_d) : (!q_ids || !d_ids)) return CAPAMD_ERR_ARG;
+  if (!packed || !conv_w || !conv_b || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || !status) return CAPAMD_ERR_ARG;
+  if (use_idf && !idf) return CAPAMD_ERR_ARG;
+  if (Q < 1 || Q > kQT || L < 1 || L > 1024 || nfilters < 1 || nfilters > 32) return CAPAMD_ERR_ARG;
+  if (mingram < 1 || maxgram < mingram || maxgram > kPacrrMaxGram) return CAPAMD_ERR_ARG;
+  if (kmax < 1 || kmax > kPacrrMaxK || kmax > L || combine < 1 || combine > kPacrrMaxC || nonlinearity < 0 || nonlinearity > 2) return CAPAMD_ERR_ARG;
+  int ncw = 0;
+  for (int ng = mingram; ng <= maxgram; ++ng) ncw += nfilters * ng * ng;
+  const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  PacrrArgs a{ids, idf, 0, Q, L, packed, V, mingram, maxgram, nfilters, kmax, conv_w, conv_b, ncw, use_idf ? 1 : 0, combine, nonlinearity,
+              w1, b1, w2, b2, w3, b3, out, status};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 192 +
+                      (size_t)kQT * kMaxNV * 16 * 16;
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0,
+                   [&](const ListsArgs& la, const ListGeom& g, int nl, int longest) {
+#define LAUNCH_L(NV_)                                                                                                           \
+  do {                                                                                                                          \
+    auto k = kmax <= 2 ? pacrr_mfma_lists_kernel<NV_, 2> : pacrr_mfma_lists_kernel<NV_, kPacrrMaxK>;                           \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(k, list_doc_grid(nl, longest), dim3(kThreads), smem, s, a, la, g);                                       \
+  } while (0)
+                     switch (nv_for_dim(D)) {
+                       case 1: LAUNCH_L(1); break;
+                       case 2: LAUNCH_L(2); break;
+                       case 3: LAUNCH_L(3); break;
+                       case 4: LAUNCH_L(4); break;
+                       default: LAUNCH_L(5); break;
+                     }
+#undef LAUNCH_L
+                   });
 }

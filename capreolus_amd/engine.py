@@ -767,6 +767,30 @@ def pacrr_forward(query, doc, idf, packed, V, D, mingram, maxgram, nfilters, kma
     return out
 
 
+def pacrr_forward_lists(offsets, idf, packed, V, D, mingram, maxgram, nfilters, kmax, conv_w, conv_b, use_idf, nonlinearity, w1, b1, w2, b2, w3, b3,
+                        query=None, doc=None, store=None, pair_q=None, pair_d=None, out=None, check=True):
+    """PACRR over whole candidate lists (capamd_pacrr_forward_lists); `idf`: [B, Q] per pair, or the store's [NQ, Q] table."""
+    q, d, qt, dt, pq, pd, B, Q, L, dev = _lists_ids(query, doc, store, pair_q, pair_d)
+    _need_gpu(packed, conv_w, conv_b, w1, b1, w2, b2, w3, b3)
+    off = _list_offsets(offsets)
+    if int(off[-1]) != B:
+        raise ValueError("the last list offset must be the number of pairs")
+    if kmax > L:
+        raise RuntimeError("selected index k out of range")  # what torch.topk raises at PACRR.py:74
+    idf = _f32(idf)
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    rc = _lib.load().capamd_pacrr_forward_lists(
+        _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
+        int(mingram), int(maxgram), int(nfilters), int(kmax), _ptr(conv_w), _ptr(conv_b), int(bool(use_idf)), w1.shape[0], NONLINEARITIES[nonlinearity],
+        _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "capamd_pacrr_forward_lists")
+    if check:
+        st.raise_if_set()
+    return out
+
+
 class ConvProjectionTables:
     """ConvKNRM's Conv1d layers folded into per-token projection tables (capamd_convknrm_pack_tables).  Rebuilt whenever the
     embedding table or any convolution parameter changes (version counters + storage pointers)."""

@@ -52,6 +52,18 @@ class PACRR_class(nn.Module):
                                    self.linear3.weight.detach().contiguous().view(-1), self.linear3.bias.detach())
         return out.view(-1, 1)
 
+    def forward_lists(self, offsets, query=None, doc=None, idf=None, store=None, pair_q=None, pair_d=None):
+        """Whole candidate lists through capamd_pacrr_forward_lists -> [B] (see KNRM_class.forward_lists).  Up to four query terms and
+        32 filters (the MFMA kernel's geometry)."""
+        w = self.embedding.weight
+        conv_w = torch.cat([m.conv.weight.detach().reshape(-1) for m in self.ngrams]).contiguous()
+        conv_b = torch.cat([m.conv.bias.detach().reshape(-1) for m in self.ngrams]).contiguous()
+        p = self.p
+        return engine.pacrr_forward_lists(
+            offsets, store.idf_table if store is not None else idf, self._packed.get(w), w.shape[0], w.shape[1], p["mingram"], p["maxgram"], p["nfilters"],
+            p["kmax"], conv_w, conv_b, p["idf"], p["nonlinearity"], self.linear1.weight.detach().contiguous(), self.linear1.bias.detach(),
+            self.linear2.weight.detach().contiguous(), self.linear2.bias.detach(), self.linear3.weight.detach().contiguous().view(-1),
+            self.linear3.bias.detach(), query=query, doc=doc, store=store, pair_q=pair_q, pair_d=pair_d)
 
     def _forward_train(self, doc, query, query_idf):
         """Training step (reference trainer/pytorch.py:96-99 -> PACRR.score), on HIP kernels end to end up to the three small linear
@@ -114,3 +126,15 @@ class PACRR(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    lists_bit_identical = True # (the similarity matrix is the same: lookups of bit-identical similarities)
+
+    @property
+    def supports_lists(self):      # whole candidate lists (capamd_pacrr_forward_lists): the MFMA kernel's geometry only
+        return self.model.p["nfilters"] <= 32 and self.model.p["maxgram"] <= 3
+
+    def test_lists(self, d, offsets):
+        return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"], idf=d["query_idf"])
+
+    def test_resident_lists(self, store, pair_q, pair_d, offsets):
+        return self.model.forward_lists(offsets, store=store, pair_q=pair_q, pair_d=pair_d)

@@ -167,6 +167,15 @@ int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t* d_ids, con
                                  const float* out_w, const float* out_b, float* out, int* status, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* PACRR the same way (the float form of the table, then capamd_pacrr_forward's MFMA kernel with a table lookup per position as its front
+ * end): scores bit-identical to capamd_pacrr_forward's.  Q <= 4, nfilters <= 32, maxgram <= 3, L <= 1024. */
+int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
+                               const int32_t* pair_d, const float* idf, const int64_t* list_offsets_host, int n_lists, int Q, int L,
+                               const float* packed, int64_t V, int D, int mingram, int maxgram, int nfilters, int kmax, const float* conv_w,
+                               const float* conv_b, int use_idf, int combine, int nonlinearity, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* w3, const float* b3, float* out, int* status, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- DRMMTKS_class.forward (capreolus/reranker/DRMMTKS.py:50-64) behind DRMMTKS.test (:105-110) ------------------
  * A sibling of DRMM on the same fused front end: per query term the top-k similarities over all
  * L positions -> Linear(topk, 1) + tanh (ffw_w fp32 [topk], ffw_b [1]) -> IDF gate (gate_w [1]) -> output layer.

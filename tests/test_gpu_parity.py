@@ -1671,6 +1671,41 @@ def test_drmmtks_lists_are_bit_identical_to_the_per_pair_kernel(topk):
         assert torch.equal(r.test_resident_lists(store, pq, pd, off), pairwise)
 
 
+@pytest.mark.parametrize("cfg", [{}, {"kmax": 4, "nfilters": 16, "idf": False, "nonlinearity": "tanh"}, {"mingram": 2, "maxgram": 2}])
+def test_pacrr_lists_are_bit_identical_to_the_per_pair_kernel(cfg):
+    """PACRR over whole lists (capamd_pacrr_forward_lists): the MFMA kernel with a table lookup per position as its front end - the
+    similarity matrix, and with it the score, equals capamd_pacrr_forward's bit for bit; ragged lists, OOV query terms with exact matches
+    in the documents, an all-pad document; ids as rows and through a candidate store."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.reranker import PACRR
+
+    V, D = 3000, 300
+    emb = synthetic.make_embeddings(V, D, seed=9)
+    docs = [200, 1, 9, 70]
+    b, off = _lists_batch(len(docs), docs, V, 41)
+    b["posdoc"][7] = 0
+    b["posdoc"][9, 3] = b["query"][9, 0] if b["query"][9, 0] < 0 else -4
+    r = PACRR(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": 4}, pad=0))
+    torch.manual_seed(4)
+    r.build_model().to(DEV).eval()
+    assert r.supports_lists
+    d = {k: _t(v) for k, v in b.items()}
+    with torch.no_grad():
+        pairwise = r.test(d)
+        lists = r.test_lists(d, off)
+    assert torch.equal(lists, pairwise), float((lists - pairwise).abs().max())
+    store = CandidateStore(DEV)
+    for i in range(len(off) - 1):
+        store.add_query(f"q{i}", b["query"][off[i]], b["query_idf"][off[i]])
+    for j in range(b["posdoc"].shape[0]):
+        store.add_doc(f"d{j}", b["posdoc"][j])
+    store.finalize()
+    pq = _t(np.repeat(np.arange(len(docs)), docs).astype(np.int32))
+    pd = _t(np.arange(b["posdoc"].shape[0], dtype=np.int32))
+    with torch.no_grad():
+        assert torch.equal(r.test_resident_lists(store, pq, pd, off), pairwise)
+
+
 @pytest.mark.parametrize("D,Q,L,V,docs", [
     (50, 3, 37, 700, [5, 1, 40]),                       # one float4 chunk per lane, three query terms, a short odd document length
     (100, 1, 130, 1500, [9] * 11),                      # one query term; more than 8 lists (the XCD-aware numbering)
