@@ -67,6 +67,8 @@ constexpr int kWaveTrips = 8;      // 128 positions per pass
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
+// KK: kernels the loops run over (11 - the model's default bank - or kMaxK, slots beyond K repeating the last kernel)
+template <int KK>
 __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
   int l, dq;
   if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
@@ -78,16 +80,16 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
   int64_t qid = t < a.Q ? qids.q(t) : 0;
   if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
-  float mu[kMaxK], ck[kMaxK];
+  float mu[KK], ck[KK];
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) {
+  for (int k = 0; k < KK; ++k) {
     mu[k] = a.kn_consts[k];
     ck[k] = a.kn_consts[kMaxK + k];
   }
-  float acc[kMaxK], rs = 0.f;
+  float acc[KK], rs = 0.f;
   int n_one = 0, n_real = 0;
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
+  for (int k = 0; k < KK; ++k) acc[k] = 0.f;
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
   for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
     // a pass of padding only - the tail of most documents - is recognised on the raw ids (wave-uniform), before anything is done with them
@@ -119,6 +121,9 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     float s[kWaveTrips];
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+    // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) {
       if (!__any(id[u] != 0)) continue;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
         rs += s[u];
         // (the kernels in pairs on packed fp32 - v_pk_add / v_pk_mul, 36 instructions per trip for 60 - measure the same: 358 us for 352)
 #pragma unroll
-        for (int k = 0; k < kMaxK; ++k) {
+        for (int k = 0; k < KK; ++k) {
           const float adj = s[u] - mu[k];
           acc[k] += __builtin_amdgcn_exp2f(adj * adj * ck[k]);
         }
@@ -136,11 +141,18 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
       }
     }
   }
+  // the read-out's weights, requested together now (asked for one by one inside the fma chain they are K dependent round trips)
+  const int hn = lane < m.hidden ? lane : 0;
+  float w1v[kMaxK];
+#pragma unroll
+  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
+#pragma unroll
+  for (int kk = 0; kk < kMaxK; ++kk) asm volatile("" : "+v"(w1v[kk]));
   // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
   const int k = lane & 15;
   float S = 0.f;
 #pragma unroll
-  for (int kk = 0; kk < kMaxK; ++kk) {
+  for (int kk = 0; kk < KK; ++kk) {
     const float v = group_allreduce(acc[kk]);
     S = k == kk ? v : S;
   }
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     h = m.b1[n];
 #pragma unroll
     for (int kk = 0; kk < kMaxK; ++kk)
-      if (kk < m.K) h = __builtin_fmaf(m.w1[n * m.K + kk], lane_bcast(F, kk), h);
+      if (kk < m.K) h = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), h);
     h = lane < m.hidden ? m.w2[n] * tanhf(h) : 0.f;
     float sc = wave_allreduce_sum(h) + m.b2[0];
     if (m.scoretanh) sc = tanhf(sc);
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     float sc = m.b1[0];
 #pragma unroll
     for (int kk = 0; kk < kMaxK; ++kk)
-      if (kk < m.K) sc = __builtin_fmaf(m.w1[kk], lane_bcast(F, kk), sc);
+      if (kk < m.K) sc = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), sc);
     if (m.scoretanh) sc = tanhf(sc);
     if (lane == 0) m.out[b] = sc;
   }
@@ -245,6 +257,8 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
     uint32_t e[kDrmmTrips];
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) {
       if (id[u] > 0) {
@@ -375,6 +389,8 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
     uint32_t e[kDrmmTrips];
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+#pragma unroll
+    for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) {
       if (id[u] > 0) {
@@ -540,6 +556,9 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
     float s[kWaveTrips];
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+    // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) {
       if (!__any(id[u] != 0)) continue;
@@ -640,7 +659,8 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
                      aq.longest = (longest + 3) / 4;       // four documents per workgroup
-                     hipLaunchKernelGGL(lists_knrm_pool_kernel, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     if (K == 11) hipLaunchKernelGGL(lists_knrm_pool_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     else hipLaunchKernelGGL(lists_knrm_pool_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                    });
 }
 
