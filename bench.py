@@ -381,6 +381,7 @@ class InteractionLeg:
             for i in range(steps):
                 for lo, hi in self.slices:
                     self.launch_one(i % len(self.batches), lo, hi)
+                self.last_batch = i % len(self.batches)       # (`out` now holds this batch's scores: what check_against_oracle compares)
             ms = (ctypes.c_double * 5)()
             groups = lib.capamd_debug_lists_timing_read(ms)
         finally:

@@ -30,7 +30,7 @@ for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "b
         r = json.load(open(f"gpurun_out/bench_{f}.json")); ro = r["roofline"]
         print(f"{f:20s} {r['value']:14.1f} {r['unit']}  ms/step {r['ms_per_step']:.3f}  roofline frac {ro.get('frac')}  {ro.get('whole_step_frac_nominal', '')}")
         for leg in r.get("also", []):
-            print(f"   also: {leg.get('config', {}).get('workload', leg)[:60]} -> {leg.get('value')} frac {leg.get('roofline', {}).get('frac')}")
+            print(f"   also: {str(leg.get('config', {}).get('workload', leg))[:60]} -> {leg.get('value')} frac {leg.get('roofline', {}).get('frac')}")
     except Exception as e:
         print(f, "FAILED", e)
 PY
