@@ -18,7 +18,7 @@ def stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(HERE, "*.cuh")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    deps = sources() + glob.glob(os.path.join(HERE, "*.cuh")) + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -152,9 +152,10 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
   if ((int64_t)blk * kSimsIds >= a.Vp) return;
   const int id0 = blk * kSimsIds;
   constexpr int kPer = kSimsIds / 256;      // ids per thread: their flag bytes in one load
-  static_assert(kPer == 2 || kPer == 4, "kSimsIds is 512 or 1024");
+  static_assert(kPer == 2 || kPer == 4 || kPer == 8, "kSimsIds is 512, 1024 or 2048");
   const uint8_t* fp = a.flags + (int64_t)l * a.Vp + id0 + tid * kPer;
-  const uint32_t fw = kPer == 2 ? (uint32_t)*reinterpret_cast<const uint16_t*>(fp) : *reinterpret_cast<const uint32_t*>(fp);
+  const uint64_t fw = kPer == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(fp) : kPer == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(fp)
+                                                                                               : *reinterpret_cast<const uint64_t*>(fp);
   // the list's query rows: the LDS image lists_query_kernel left (built here, from the ids, it is five dependent loads per workgroup)
   {
     const float4* img = a.qimg + (int64_t)l * kQueryImage;
