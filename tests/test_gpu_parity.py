@@ -1633,6 +1633,34 @@ def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
         assert torch.equal(lists, pairwise), (hist, gate, extra, float((lists - pairwise).abs().max()))
 
 
+@pytest.mark.parametrize("K", [5, 12])
+def test_knrm_lists_with_other_kernel_banks(K):
+    """The KNRM list pooling is specialised for the reference's 11-kernel bank; any other number of kernels (the C ABI takes up to 12)
+    runs its general form - compared with the per-pair kernel through the engine calls, one- and two-layer read-out."""
+    from capreolus_amd import engine
+
+    V, D = 2000, 300
+    emb = synthetic.make_embeddings(V, D, seed=12)
+    docs = [40, 9, 130]
+    b, off = _lists_batch(len(docs), docs, V, 50 + K)
+    q, d = _t(b["query"]), _t(b["posdoc"])
+    w = _t(emb)
+    packed = engine.PackedEmbedding().get(w)
+    g = torch.Generator().manual_seed(K)
+    mu = _t(np.linspace(-0.9, 1.0, K).astype(np.float32))
+    sigma = _t(np.r_[np.full(K - 1, 0.1), 0.001].astype(np.float32))
+    for hidden in (0, 7):
+        w1 = (torch.randn((hidden or 1), K, generator=g) * 0.3).to(DEV).contiguous()
+        b1 = (torch.randn(hidden or 1, generator=g) * 0.1).to(DEV)
+        w2 = (torch.randn(hidden, generator=g) * 0.5).to(DEV) if hidden else None
+        b2 = (torch.randn(1, generator=g) * 0.1).to(DEV) if hidden else None
+        a1 = w1 if hidden else w1.view(-1)
+        pairwise = engine.knrm_forward(q, d, packed, V, D, mu, sigma, a1, b1, w2, b2, scoretanh=bool(hidden)).cpu().numpy()
+        lists = engine.knrm_forward_lists(off, packed, V, D, mu, sigma, a1, b1, w2, b2, scoretanh=bool(hidden), query=q, doc=d).cpu().numpy()
+        scale = float(np.abs(pairwise).max())
+        assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (K, hidden, np.abs(lists - pairwise).max(), scale)
+
+
 @pytest.mark.parametrize("topk", [10, 3, 16])
 def test_drmmtks_lists_are_bit_identical_to_the_per_pair_kernel(topk):
     """DRMM-TKS over whole lists (capamd_drmmtks_forward_lists): top-k selections of bit-identical similarities, fed to the Linear in the
