@@ -1,29 +1,32 @@
-// KNRM / DRMM over whole CANDIDATE LISTS (one query, its first-stage documents) for gfx950 - what PytorchTrainer.predict scores
-// (reference capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query lists, sampler/__init__.py:222-233; RerankTask hands it
-// up to 1000 documents per query, task/rerank.py:22-23).
+// KNRM / DRMM / DRMM-TKS over whole CANDIDATE LISTS (one query, its first-stage documents) for gfx950 - what PytorchTrainer.predict
+// scores (reference capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query lists, sampler/__init__.py:222-233; RerankTask
+// hands it up to 1000 documents per query, task/rerank.py:22-23).  PACRR's list entry is in pacrr.hip; the shared passes in lists.cuh.
 //
 // The per-pair kernels (knrm.hip, drmm.hip, interaction_stream.cuh) gather one packed row per distinct term of every DOCUMENT: 179 rows
 // = 229 KB per pair on the benchmark's lists, 14.7 GB per 64,000 pairs - and that gather is what they are bound by.  But the similarity
 // of a document term to the query depends on (query, term) only, and the 1000 documents of a list share their vocabulary: a list's
 // 303,000 tokens are ~50,000 distinct terms.  So per list:
 //   1  mark    every document of the list flags its real term ids in a byte map over the vocabulary (plain byte stores: racing writers
-//              write the same value)
-//   2  sims    per (list, block of 512 vocabulary ids): collect the flagged ids and for every one of them gather its packed row ONCE,
-//              the four similarities to the list's query by the SAME arithmetic as the per-pair kernels (rows_dot / sim_from_dots:
-//              bit-identical values) -> table[id]: KNRM the four floats, DRMM the four histogram bins (a byte each: bin | exact-match
-//              bit) - the binning is done once per distinct term, not once per position.  Workgroups are numbered so that an XCD
-//              works on ONE id block of ALL lists at a time (workgroup i runs on XCD i % 8): the lists share most of a block's rows,
-//              so the rows come from that XCD's L2.
-//   3  pool    every document: its ids are requested together, then their table entries (two memory round trips per document - the
-//              per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a wave per document, a lane per (position, query
-//              term), K exponentials into per-lane sums; DRMM: a workgroup per document, a lane per position, four integer bin counts.  Passes of padding only (a document's tail) are
-//              skipped after the id load.  Then the models' per-pair tails.  An XCD works on one list at a time: the hot part of the
-//              list's table sits in its L2 (DRMM's 1.6 MB table all of it).
+//              write the same value)                                                                                    [lists.cuh]
+//   2  sims    per (list, block of 1024 vocabulary ids): collect the flagged ids and for every one of them gather its packed row
+//              ONCE, the four similarities to the list's query by the SAME arithmetic as the per-pair kernels (rows_dot2_pk /
+//              sim_from_dots: bit-identical values) -> table[id]: the four floats, or DRMM's four histogram bins (a byte each: bin |
+//              exact-match bit) - the binning is done once per distinct term, not once per position.  Workgroups are numbered so
+//              that an XCD works on ONE id block of ALL lists at a time: the lists share most of a block's rows, so the rows come
+//              from that XCD's L2.                                                                                       [lists.cuh]
+//   3  pool    every document, a WAVE each: its ids are requested together, then their table entries (two memory round trips per
+//              document - the per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a lane per (position, query term), K
+//              exponentials into per-lane sums; DRMM: a lane per position, four integer bin counts; DRMM-TKS: a lane per (position,
+//              query term) keeping a sorted top-k.  Passes of padding only (a document's tail) stop after the id load.  Then the
+//              models' per-pair tails, in the same wave.  An XCD works on one list at a time: the hot part of the list's table
+//              sits in its L2 (DRMM's 1.6 MB table all of it).                                                          [this file]
 // Rows gathered: 4.1 GB instead of 14.7, most of them L2 hits.
-// DRMM's bin counts are integers of bit-identical similarities: bit-exact with the per-pair kernels.  KNRM sums the same kernel values
-// in another order (per lane over its positions, then over the lanes): equal to fp32 rounding of the sums (1e-6 relative).
-// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V = 400,001) + 5 KB for its query;
-// lists are processed in chunks of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits as the per-pair entries.
+// DRMM's bin counts are integers of bit-identical similarities and DRMM-TKS's top-k are selections of them: scores bit-exact with the
+// per-pair kernels.  KNRM sums the same kernel values in another order (per lane over its positions, then over the lanes): equal to
+// fp32 rounding of the sums (1e-6 relative).
+// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V =
+// 400,001) + 5 KB for its query; lists are processed in groups of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits
+// as the per-pair entries.
 #include "lists.cuh"
 #include "capamd_profiling.h"
 #include <vector>
