@@ -477,6 +477,19 @@ class PytorchTrainer:
         plans[key] = (fp, ref, plan)
         return plan
 
+    def _score_store(self, reranker, store, pq, pd, counts, step):
+        """Scores index pairs of a candidate store laid out query after query (`counts` documents each) -> fp32 [n].  Rerankers that
+        take whole candidate lists get them as lists where the `lists` option allows (every distinct term of a LIST is gathered once:
+        csrc/lists.hip); otherwise one launch per `step` pairs."""
+        n = int(pq.numel())
+        as_lists = {"never": False, "exact": getattr(reranker, "lists_bit_identical", False), "always": True}[self.config["lists"]]
+        with torch.no_grad():
+            if as_lists and n > 0 and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and n >= 8 * len(counts):
+                offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+                return reranker.test_resident_lists(store, pq, pd, offsets).float()
+            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]
+        return torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
+
     def predict_resident(self, reranker, store, qid_to_docids, pred_fn=None):
         """`predict` over a device-resident `capreolus_amd.feeder.CandidateStore`: no DataLoader,
         no per-batch host->device copy; one kernel launch per `evalbatch` pairs (0 -> the whole run in one launch)."""
@@ -491,9 +504,7 @@ class PytorchTrainer:
         mine = {q: qid_to_docids[q] for q in qids[b[rank]:b[rank + 1]]}
         keys, pq, pd = store.pairs(mine)
         step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(len(keys), 1)
-        with torch.no_grad():
-            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, len(keys), step)]
-        local = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
+        local = self._score_store(reranker, store, pq, pd, [len(v) for v in mine.values()], step)
         if distributed:
             counts = [sum(len(qid_to_docids[q]) for q in qids[b[r]:b[r + 1]]) for r in range(world)]
             width = max(counts)
@@ -532,12 +543,11 @@ class PytorchTrainer:
             keys, pq, pd = store.pairs(qid_to_docids)
             rel, tie, idcg, offsets = ranking.eval_arrays(qid_to_docids, qrels, k, store.device)
             judged = torch.tensor([q in qrels for q in qid_to_docids], dtype=torch.bool, device=store.device)
-            plan = self._eval_plan = (key, store, qid_to_docids, qrels, len(keys), pq, pd, rel, tie, idcg, offsets, judged)
-        n, pq, pd, rel, tie, idcg, offsets, judged = plan[4:]
+            counts = [len(v) for v in qid_to_docids.values()]
+            plan = self._eval_plan = (key, store, qid_to_docids, qrels, len(keys), pq, pd, rel, tie, idcg, offsets, judged, counts)
+        n, pq, pd, rel, tie, idcg, offsets, judged, counts = plan[4:]
         step = self.config["evalbatch"] if self.config["evalbatch"] > 0 else max(n, 1)
-        with torch.no_grad():
-            chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]
-        scores = torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
+        scores = self._score_store(reranker, store, pq, pd, counts, step)
         per_query = ranking.ndcg_cut(scores, offsets, rel, tie, idcg, k=k)
         from ..engine import status_word
 
@@ -569,15 +579,8 @@ class PytorchTrainer:
         if plan is not None:
             store, pq, pd, groups = plan
             step = max(evalbatch, self.config["coalesce"])
-            with torch.no_grad():
-                as_lists = {"never": False, "exact": getattr(reranker, "lists_bit_identical", False), "always": True}[self.config["lists"]]
-                if as_lists and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and pq.numel() >= 8 * len(groups):
-                    # whole candidate lists (a run of one qid = one list; its query row is the same for every pair, checked when the
-                    # plan was built): every distinct term of a LIST is gathered once
-                    offsets = [lo for _, _, lo in groups] + [pq.numel()]
-                    chunks = [reranker.test_resident_lists(store, pq, pd, offsets).float()]
-                else:
-                    chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, pq.numel(), step)]
+            # (a run of one qid = one list; its query row is the same for every pair, checked when the plan was built)
+            chunks = [self._score_store(reranker, store, pq, pd, [len(docids) for _, docids, _ in groups], step)]
             if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
                 vals = torch.cat(chunks).cpu().numpy().astype(np.float16).tolist()      # (trainer/pytorch.py:346-348)
                 if len(vals) != count:
