@@ -341,3 +341,51 @@ def pickle_load(fn):
 
     with open(fn, "rb") as f:
         return pickle.load(f)
+
+
+@pytest.mark.parametrize("mode,exact,expect_lists", [("exact", True, True), ("exact", False, False), ("always", False, True), ("never", True, False)])
+def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
+    """`PytorchTrainer._score_store` (predict / predict_resident / evaluate_resident on a candidate store): whole candidate lists for the
+    rerankers the `lists` option admits - "exact": only those whose list scores equal their per-pair scores bit for bit - with the
+    lists' offsets handed over as a host array; the per-pair route in `evalbatch` steps otherwise, for more than four query terms, and
+    for runs of fewer than eight candidates per query."""
+    calls = []
+
+    class Store:
+        device = torch.device("cpu")
+        q_table = torch.zeros(3, 4, dtype=torch.int32)
+
+    class Fake:
+        supports_lists = True
+        lists_bit_identical = exact
+
+        def test_resident_lists(self, store, pq, pd, offsets):
+            calls.append(("lists", np.asarray(offsets).tolist()))
+            return torch.arange(pq.numel(), dtype=torch.float32)
+
+        def test_resident(self, store, pq, pd):
+            calls.append(("pairs", int(pq.numel())))
+            return pd.float()
+
+    counts = [20, 9, 11]
+    n = sum(counts)
+    pq = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(counts))
+    pd = torch.arange(n, dtype=torch.int32)
+    tr = PytorchTrainer({"lists": mode})
+    out = tr._score_store(Fake(), Store(), pq, pd, counts, 16)
+    assert out.dtype == torch.float32 and out.numel() == n and torch.equal(out, torch.arange(n, dtype=torch.float32))
+    if expect_lists:
+        assert calls == [("lists", [0, 20, 29, 40])]
+    else:
+        assert calls == [("pairs", 16), ("pairs", 16), ("pairs", 8)]
+    # more than four query terms, or short lists: always pair by pair
+    calls.clear()
+    wide = Store()
+    wide.q_table = torch.zeros(3, 6, dtype=torch.int32)
+    tr._score_store(Fake(), wide, pq, pd, counts, 64)
+    assert calls == [("pairs", n)]
+    calls.clear()
+    tr._score_store(Fake(), Store(), pq[:6], pd[:6], [2, 2, 2], 64)
+    assert calls == [("pairs", 6)]
+    with pytest.raises(KeyError):
+        PytorchTrainer({"lists": "sometimes"})._score_store(Fake(), Store(), pq, pd, counts, 16)
