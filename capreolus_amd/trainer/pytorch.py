@@ -144,6 +144,8 @@ class PytorchTrainer:
             raise ValueError("amp must be one of: None, train, pred, both")
         if c["decaytype"] not in (None, "exponential", "linear"):
             raise ValueError("decaytype must be one of: None, exponential, linear")
+        if c["lists"] not in ("exact", "always", "never"):
+            raise ValueError("lists must be one of: exact, always, never")
         torch.manual_seed(c["seed"])
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(c["seed"])

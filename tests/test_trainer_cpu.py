@@ -387,5 +387,5 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     calls.clear()
     tr._score_store(Fake(), Store(), pq[:6], pd[:6], [2, 2, 2], 64)
     assert calls == [("pairs", 6)]
-    with pytest.raises(KeyError):
-        PytorchTrainer({"lists": "sometimes"})._score_store(Fake(), Store(), pq, pd, counts, 16)
+    with pytest.raises(ValueError):
+        PytorchTrainer({"lists": "sometimes"}).build()
