@@ -1661,6 +1661,48 @@ def test_knrm_lists_with_other_kernel_banks(K):
         assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (K, hidden, np.abs(lists - pairwise).max(), scale)
 
 
+@pytest.mark.parametrize("kind", ["knrm", "drmm", "drmmtks", "pacrr"])
+def test_full_size_list_properties(kind):
+    """The list route at BASELINE.json's geometry (vocabulary 400,001 x 300, 800-term documents, 16 queries x 1000 candidates): a
+    document's score does not depend on where it stands in its list or on how the query's documents are cut into lists (both bit for
+    bit: the table of a (query, term) pair holds the same four similarities whichever list computes it, and a document is pooled alone),
+    and the scores equal the per-pair kernels' - bit for bit for DRMM / DRMM-TKS / PACRR, to fp32 rounding of the sums for KNRM."""
+    from capreolus_amd.reranker import DRMMTKS, PACRR
+
+    V, D, NQ, ND = 400001, 300, 16, 1000
+    g = torch.Generator(device=DEV)
+    g.manual_seed(0)
+    emb = torch.randn((V, D), generator=g, device=DEV) * 0.4
+    emb[0] = 0
+    batch = synthetic.make_candidate_list_torch(NQ, ND, V, DEV, seed=5)
+    if kind != "knrm":
+        batch = {**batch, "query": batch["query"].clamp(min=0)}
+    torch.manual_seed(1)
+    ext = SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32), config={"maxqlen": 4}, pad=0)
+    r = {"knrm": KNRM, "drmm": DRMM, "drmmtks": DRMMTKS, "pacrr": PACRR}[kind]({}, ext)
+    m = r.build_model().to(DEV).eval()
+    m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
+    off = np.arange(0, NQ * ND + 1, ND, dtype=np.int64)
+    with torch.no_grad():
+        s = r.test_lists(batch, off)
+        assert s.shape == (NQ * ND,) and torch.isfinite(s).all()
+        pairwise = r.test(batch)
+        if kind == "knrm":
+            assert (s - pairwise).abs().max() <= 2e-5 * pairwise.abs().max()
+        else:
+            assert torch.equal(s, pairwise)
+        # (a) the documents of every list in another order
+        perm = torch.cat([q * ND + torch.randperm(ND, device=DEV) for q in range(NQ)])
+        assert torch.equal(r.test_lists({k: v[perm] for k, v in batch.items()}, off), s[perm])
+        # (b) every query's documents cut into three lists of unequal length (48 lists: one launch group), and the whole run in groups
+        #     of 5 lists per call (the last call has one list)
+        cuts = np.sort(np.concatenate([off, off[:-1] + 1, off[:-1] + 377]))
+        assert torch.equal(r.test_lists(batch, cuts), s)
+        parts = [r.test_lists({k: v[lo * ND:hi * ND] for k, v in batch.items()}, off[: hi - lo + 1]) for lo, hi in
+                 [(i, min(i + 5, NQ)) for i in range(0, NQ, 5)]]
+        assert torch.equal(torch.cat(parts), s)
+
+
 @pytest.mark.parametrize("topk", [10, 3, 16])
 def test_drmmtks_lists_are_bit_identical_to_the_per_pair_kernel(topk):
     """DRMM-TKS over whole lists (capamd_drmmtks_forward_lists): top-k selections of bit-identical similarities, fed to the Linear in the
