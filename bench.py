@@ -255,7 +255,7 @@ class InteractionLeg:
         self.slices = [(i, min(i + launch, self.n_pairs)) for i in range(0, self.n_pairs, launch)]
         # whole candidate lists (csrc/lists.hip) unless asked otherwise; launches of single lists, the resident store and the HBM-bound
         # leg (uniform ids: a list's documents share almost no vocabulary) stay on the per-pair kernels
-        self.lists = not args.per_pair and not args.resident and not uniform and launch % args.docs == 0 and launch >= 4 * args.docs
+        self.lists = not args.per_pair and not uniform and launch % args.docs == 0 and launch >= 4 * args.docs
         D = self.D
         if model == "knrm":
             mu, sigma = m.kernels.stacked()
@@ -265,8 +265,14 @@ class InteractionLeg:
                 pq = torch.arange(self.n_pairs, device=dev, dtype=torch.int32) // args.docs
                 pd = torch.arange(self.n_pairs, device=dev, dtype=torch.int32)
 
+                stores = [SimpleNamespace(q_table=t[0], d_table=t[1]) for t in tabs]
+
                 def launch_one(bi, lo, hi):
-                    engine.knrm_forward_indexed(tabs[bi][0], tabs[bi][1], pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+                    if self.lists:      # the store's lists as lists (index pairs into the int32 tables)
+                        engine.knrm_forward_lists(np.arange(0, hi - lo + 1, args.docs), packed, V, D, mu, sigma, w1, b1, store=stores[bi], pair_q=pq[lo:hi],
+                                                  pair_d=pd[lo:hi], out=out[lo:hi], check=False)
+                    else:
+                        engine.knrm_forward_indexed(tabs[bi][0], tabs[bi][1], pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
             elif self.lists:
                 def launch_one(bi, lo, hi):      # the step's candidate lists (args.docs documents per query) as lists
                     b = self.batches[bi]
@@ -527,17 +533,18 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             rows = distinct_per_list * (n_pairs / args.docs)
             tokens = nonpad * n_pairs
             K = 11
+            idb = 4 if (args.resident and model == "knrm") else 8       # bytes per id: the candidate store's tables are int32
             names = ["hipMemsetAsync (byte maps)", "lists_mark_kernel", "lists_query_kernel<5>", f"lists_sims_kernel<5, {'false' if model == 'knrm' else 'true'}>",
                      "lists_knrm_pool_kernel" if model == "knrm" else "lists_drmm_pool_wave_kernel"]
             work = [
                 {"bytes_cleared": (n_pairs / args.docs) * ((args.vocab + 1023) // 1024 * 1024)},
-                {"id_row_bytes": n_pairs * L * 8, "byte_stores": tokens, "GBps_of_id_rows": n_pairs * L * 8 / (passes[1] * 1e-3) / 1e9},
+                {"id_row_bytes": n_pairs * L * idb, "byte_stores": tokens, "GBps_of_id_rows": n_pairs * L * idb / (passes[1] * 1e-3) / 1e9},
                 {"lists": n_pairs / args.docs},
                 {"rows_gathered": rows, "row_bytes": rows * leg.row_stride * 4, "row_GBps": rows * leg.row_stride * 4 / (passes[3] * 1e-3) / 1e9,
                  "fp32_fma": rows * Q * leg.row_stride, "fp32_TFLOPs": 2 * rows * Q * leg.row_stride / (passes[3] * 1e-3) / 1e12,
                  "fp32_valu_peak_TFLOPs": 78.6, "note": "256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, one fma per lane and cycle (packed fp32 issues no faster here: DESIGN.md 3.5)"},
-                ({"id_row_bytes": n_pairs * L * 8, "table_lookups": tokens, "exponentials": tokens * Q * K, "Gexp_per_s": tokens * Q * K / (passes[4] * 1e-3) / 1e9}
-                 if model == "knrm" else {"id_row_bytes": n_pairs * L * 8, "table_lookups": tokens, "lds_increments": tokens * Q}),
+                ({"id_row_bytes": n_pairs * L * idb, "table_lookups": tokens, "exponentials": tokens * Q * K, "Gexp_per_s": tokens * Q * K / (passes[4] * 1e-3) / 1e9}
+                 if model == "knrm" else {"id_row_bytes": n_pairs * L * idb, "table_lookups": tokens, "lds_increments": tokens * Q}),
             ]
             headline["passes"] = [{"pass": nm, "ms": ms, **w} for nm, ms, w in zip(names, passes, work)]
             headline["passes_note"] = ("HIP events recorded by the library on the launch stream between the passes of 5 more steps after the timed loop "
