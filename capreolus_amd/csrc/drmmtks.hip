@@ -6,7 +6,7 @@
 //
 // Same work layout as knrm.hip / drmm.hip (one workgroup per pair, 16 lanes per document term, real terms compacted in
 // LDS, query rows in an LDS copy).  Back end: every lane keeps a sorted top-k of the similarities of the query term it
-// owns (compare-exchange chain in registers); the 16 groups' lists are merged by one wave per query term (k rounds of
+// owns (sorted_insert in registers: one v_med3_f32 per element); the 16 groups' lists are merged by one wave per query term (k rounds of
 // a wave-wide arg-max over the list heads), together with the closed-form candidates of the terms that were never
 // gathered: n1 ones (OOV exact matches) and n0 zeros (pads and other OOV terms).
 #include "capreolus_amd.h"
@@ -43,7 +43,7 @@ struct TksArgs {
 #define CAPAMD_TKS_WAVES 6   // measured per 64,000 pairs: 5 -> 2.20 ms, 6 -> 2.12 ms; two rows in flight per group (CAPAMD_TKS_U 2) spill and lose 2-5x
 #endif
 
-// KT = length of the per-lane sorted lists (>= topk, a multiple of 4): the compare-exchange chain of an insertion is KT steps long
+// KT = length of the per-lane sorted lists (>= topk, a multiple of 4): an insertion is KT independent v_med3_f32
 template <int NV, int KT>
 __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_kernel(TksArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -109,13 +109,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
       for (int u = 0; u < CAPAMD_TKS_U; ++u) {
         const int copies = has[u] ? min(mult[t0 + u * kGroupsPerWG], K) : 0;   // uniform over the 16 lanes of the group
         for (int c = 0; c < copies; ++c) {
-          float v = x[u];
-#pragma unroll
-          for (int i = 0; i < KT; ++i) {  // compare-exchange chain: top[] stays sorted, v carries the displaced value
-            const float hi = fmaxf(top[i], v);
-            v = fminf(top[i], v);
-            top[i] = hi;
-          }
+          sorted_insert<KT>(top, x[u]);
         }
       }
     }

@@ -322,6 +322,16 @@ __device__ __forceinline__ float group_allreduce(float v) {
 // Reductions over the 64 lanes of a wave, every lane gets the result: DPP all-reduce inside each 16-lane row, then the four row values by
 // v_readlane.  No LDS-pipe permutes: a `__shfl_xor` butterfly is six ds_bpermute round trips (~100 cycles each), and the per-pair tails
 // of these kernels (feed-forward nets, top-k merges) are serial chains of such reductions during which the workgroup requests no rows.
+// Insertion into a descending sorted list in registers: new top[i] = median(top[i-1], top[i], v) - the element above if v passed it, v if
+// it lands here, the old one otherwise - one v_med3_f32 per element and no carried value (a compare-exchange chain is a v_max and a v_min
+// per element, each waiting for the one before).
+template <int K>
+__device__ __forceinline__ void sorted_insert(float (&top)[K], float v) {
+#pragma unroll
+  for (int i = K - 1; i >= 1; --i) top[i] = __builtin_amdgcn_fmed3f(top[i - 1], top[i], v);
+  top[0] = fmaxf(top[0], v);
+}
+
 // `unfused`: the value as computed - a product handed to a reduction is not contracted into the reduction's first add (hipcc's default
 // -ffp-contract=fast would, or would not, depending on the code around it: two spellings of one tail must round alike).
 __device__ __forceinline__ float unfused(float v) {

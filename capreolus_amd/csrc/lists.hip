@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
 //   The KNRM form of the sims pass (four floats per term), then per document the top-k similarities of
 // every query term over ALL positions (reference DRMMTKS.py:55-56; pads and unmatched OOV terms contribute their 0, OOV exact matches
 // their 1) -> Linear(k, 1) + tanh -> idf gate -> output layer, as drmmtks.hip.  A wave per document, a lane per (position slot, query
-// term) as in the KNRM pooling: every lane keeps a sorted top-KT of the similarities it meets (compare-exchange chain in registers),
+// term) as in the KNRM pooling: every lane keeps a sorted top-KT of the similarities it meets (sorted_insert: one v_med3_f32 per element),
 // the 16 lists of a row are merged in k rounds of a row-wide maximum over the list heads (LDS) and the closed-form candidates.  The
 // values are selections of bit-identical similarities and enter the Linear in the same order: the scores equal capamd_drmmtks_forward's.
 struct TksPoolArgs {
@@ -567,13 +567,7 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
       if (!__any(id[u] != 0)) continue;
       if (id[u] > 0) {
         ++n_real;
-        float v = s[u];
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {     // compare-exchange chain: top[] stays sorted, v carries the displaced value
-          const float hi = fmaxf(top[i], v);
-          v = fminf(top[i], v);
-          top[i] = hi;
-        }
+        sorted_insert<KT>(top, s[u]);
       } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
         ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)
       }

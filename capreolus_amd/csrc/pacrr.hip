@@ -200,12 +200,7 @@ __device__ __forceinline__ void pacrr_wave_topk(float (&top)[KM], int kmax, int 
 
 template <int KM>
 __device__ __forceinline__ void pacrr_insert(float (&top)[KM], float v) {
-#pragma unroll
-  for (int i = 0; i < KM; ++i) {
-    const float hi = fmaxf(top[i], v);
-    v = fminf(top[i], v);
-    top[i] = hi;
-  }
+  sorted_insert<KM>(top, v);
 }
 
 // idf channel + the three linear layers (PACRR.py:48-55); feat = [Q][qts] in LDS
