@@ -46,6 +46,61 @@ void capamd::lists_stamp(hipStream_t s) {
 }
 namespace {
 
+// The ids of one pass of a pooling kernel - TRIPS trips of STRIDE consecutive positions, this lane's slot `ps` - as int: 0 = pad (or beyond
+// the table: flagged by the mark pass), > 0 a term, < 0 an OOV term (KEEP_OOV: its own id, INT_MIN where that does not fit; otherwise
+// -1).  Returns false for a pass of padding only (wave-uniform), recognised on the raw ids before anything is done with them - the
+// tail of most documents.  A pass that lies inside the document reads base + constant offsets; only the last one predicates.
+template <int TRIPS, int STRIDE, bool KEEP_OOV>
+__device__ __forceinline__ bool load_pass_ids(const PairIds& ids, int j0, int ps, int L, int64_t V, int (&id)[TRIPS]) {
+  const bool full = j0 + TRIPS * STRIDE <= L;
+  if (ids.d32) {
+    int live = 0;
+    if (full) {
+      const int* p = ids.d32 + j0 + ps;
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        id[u] = p[u * STRIDE];
+        live |= id[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int j = j0 + u * STRIDE + ps;
+        id[u] = j < L ? ids.d32[j] : 0;
+        live |= id[u];
+      }
+    }
+    if (!__any(live != 0)) return false;
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) {
+      if (id[u] >= V) id[u] = 0;
+      if (!KEEP_OOV && id[u] < 0) id[u] = -1;
+    }
+  } else {
+    int64_t w[TRIPS], live = 0;
+    if (full) {
+      const int64_t* p = ids.d64 + j0 + ps;
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        w[u] = p[u * STRIDE];
+        live |= w[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int j = j0 + u * STRIDE + ps;
+        w[u] = j < L ? ids.d64[j] : 0;
+        live |= w[u];
+      }
+    }
+    if (!__any(live != 0)) return false;
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u)
+      id[u] = w[u] >= V ? 0 : w[u] < 0 ? (KEEP_OOV ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : -1) : (int)w[u];
+  }
+  return true;
+}
+
 // ---- 3a: KNRM pooling ----------------------------------------------------------------------------------------------------------
 struct KnrmPoolArgs {
   const float* mu;
@@ -95,32 +150,8 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   for (int k = 0; k < KK; ++k) acc[k] = 0.f;
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
   for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
-    // a pass of padding only - the tail of most documents - is recognised on the raw ids (wave-uniform), before anything is done with them
     int id[kWaveTrips];
-    if (ids.d32) {
-      int live = 0;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) {
-        const int j = j0 + u * 16 + ps;
-        id[u] = ids.d32[j < a.L ? j : a.L - 1];
-        live |= id[u];
-      }
-      if (!__any(live != 0)) continue;
-    } else {
-      int64_t w[kWaveTrips], live = 0;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) {
-        const int j = j0 + u * 16 + ps;
-        w[u] = ids.d64[j < a.L ? j : a.L - 1];
-        live |= w[u];
-      }
-      if (!__any(live != 0)) continue;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u)
-      if (j0 + u * 16 + ps >= a.L || id[u] >= a.V) id[u] = 0;
+    if (!load_pass_ids<kWaveTrips, 16, true>(ids, j0, ps, a.L, a.V, id)) continue;
     float s[kWaveTrips];
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
@@ -365,30 +396,7 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
   int n_oov = 0;
   for (int j0 = 0; j0 < a.L; j0 += 64 * kDrmmTrips) {
     int id[kDrmmTrips];
-    if (ids.d32) {
-      int live = 0;
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) {
-        const int j = j0 + u * 64 + lane;
-        id[u] = ids.d32[j < a.L ? j : a.L - 1];
-        live |= id[u];
-      }
-      if (!__any(live != 0)) continue;         // padding only (wave-uniform)
-    } else {
-      int64_t w[kDrmmTrips], live = 0;
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) {
-        const int j = j0 + u * 64 + lane;
-        w[u] = ids.d64[j < a.L ? j : a.L - 1];
-        live |= w[u];
-      }
-      if (!__any(live != 0)) continue;
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? -1 : (int)w[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u)
-      if (j0 + u * 64 + lane >= a.L || id[u] >= a.V) id[u] = 0;
+    if (!load_pass_ids<kDrmmTrips, 64, false>(ids, j0, lane, a.L, a.V, id)) continue;
     uint32_t e[kDrmmTrips];
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
@@ -532,30 +540,7 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
   for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
-    if (ids.d32) {
-      int live = 0;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) {
-        const int j = j0 + u * 16 + ps;
-        id[u] = ids.d32[j < a.L ? j : a.L - 1];
-        live |= id[u];
-      }
-      if (!__any(live != 0)) continue;
-    } else {
-      int64_t w[kWaveTrips], live = 0;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) {
-        const int j = j0 + u * 16 + ps;
-        w[u] = ids.d64[j < a.L ? j : a.L - 1];
-        live |= w[u];
-      }
-      if (!__any(live != 0)) continue;
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : (int)w[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u)
-      if (j0 + u * 16 + ps >= a.L || id[u] >= a.V) id[u] = 0;
+    if (!load_pass_ids<kWaveTrips, 16, true>(ids, j0, ps, a.L, a.V, id)) continue;
     float s[kWaveTrips];
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
