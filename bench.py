@@ -253,9 +253,10 @@ class InteractionLeg:
         self.out = out = torch.empty(self.n_pairs, dtype=torch.float32, device=dev)
         launch = args.launch_docs or self.n_pairs
         self.slices = [(i, min(i + launch, self.n_pairs)) for i in range(0, self.n_pairs, launch)]
-        # whole candidate lists (csrc/lists.hip) unless asked otherwise; launches of single lists, the resident store and the HBM-bound
-        # leg (uniform ids: a list's documents share almost no vocabulary) stay on the per-pair kernels
-        self.lists = not args.per_pair and not uniform and launch % args.docs == 0 and launch >= 4 * args.docs
+        # whole candidate lists (csrc/lists.hip) unless asked otherwise; launches of single lists (38.6 M pairs/s as a list against 48.6 M
+        # pair by pair; two lists per launch: 54.3 against 49.3) and the HBM-bound leg (uniform ids: a list's documents share almost no
+        # vocabulary) stay on the per-pair kernels
+        self.lists = not args.per_pair and not uniform and launch % args.docs == 0 and launch >= 2 * args.docs
         D = self.D
         if model == "knrm":
             mu, sigma = m.kernels.stacked()
@@ -695,7 +696,7 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
     out = [None]
 
     # whole candidate lists (csrc/lists.hip) where the model takes them, unless asked otherwise or on the uniform-id leg (lists share nothing there)
-    as_lists = bool(getattr(rr, "supports_lists", False)) and not args.per_pair and not uniform and n_queries >= 4
+    as_lists = bool(getattr(rr, "supports_lists", False)) and not args.per_pair and not uniform and n_queries >= 2
     offsets = np.arange(0, n_pairs + 1, args.docs, dtype=np.int64)
 
     def step(_):

@@ -486,7 +486,8 @@ class PytorchTrainer:
         n = int(pq.numel())
         as_lists = {"never": False, "exact": getattr(reranker, "lists_bit_identical", False), "always": True}[self.config["lists"]]
         with torch.no_grad():
-            if as_lists and n > 0 and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and n >= 8 * len(counts):
+            # (a single list keeps the per-pair kernels: its 1000 workgroups fill the chip better than one list's passes do)
+            if as_lists and len(counts) >= 2 and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and n >= 8 * len(counts):
                 offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
                 return reranker.test_resident_lists(store, pq, pd, offsets).float()
             chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]

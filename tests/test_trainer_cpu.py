@@ -347,8 +347,8 @@ def pickle_load(fn):
 def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     """`PytorchTrainer._score_store` (predict / predict_resident / evaluate_resident on a candidate store): whole candidate lists for the
     rerankers the `lists` option admits - "exact": only those whose list scores equal their per-pair scores bit for bit - with the
-    lists' offsets handed over as a host array; the per-pair route in `evalbatch` steps otherwise, for more than four query terms, and
-    for runs of fewer than eight candidates per query."""
+    lists' offsets handed over as a host array; the per-pair route in `evalbatch` steps otherwise, for more than four query terms, for
+    runs of fewer than eight candidates per query and for a single list."""
     calls = []
 
     class Store:
@@ -387,5 +387,8 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     calls.clear()
     tr._score_store(Fake(), Store(), pq[:6], pd[:6], [2, 2, 2], 64)
     assert calls == [("pairs", 6)]
+    calls.clear()
+    tr._score_store(Fake(), Store(), pq[:20], pd[:20], [20], 64)       # a single list: the per-pair kernels fill the chip better
+    assert calls == [("pairs", 20)]
     with pytest.raises(ValueError):
         PytorchTrainer({"lists": "sometimes"}).build()
