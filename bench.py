@@ -102,21 +102,123 @@ def parse():
                     help="BERT: slices of a step's passages encoded concurrently on their own HIP streams and workspaces (the engine's default is 2; "
                          "1 = strictly serial kernels).  `roofline` times the dominant kernel in a separate serial step after the timed ones, so "
                          "that its HIP-event duration is not inflated by a concurrent kernel")
+    ap.add_argument("--no-pass-times", action="store_true", help="list route: skip the per-pass HIP-event leg (it binds the -DCAPAMD_PROFILING build of the library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the DRMM / BERT legs of the default invocation")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
 
+COMPACT_LIMIT = 4000      # bytes of the ONE stdout line (BENCH_r03: the driver could not parse a 22 KB line)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def _round(x):
+    """floats to 6 significant digits (the stdout line only; bench_full.json keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.6g}")
+    if isinstance(x, dict):
+        return {k: _round(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_round(v) for v in x]
+    return x
+
+
+def compact_roofline(r, depth=0):
+    """The roofline object of the stdout line: the contract's keys, the per-pass table of the list route and the per-pair HBM-bound leg,
+    each cut down to numbers + kernel names (the notes / definitions stay in bench_full.json)."""
+    if not isinstance(r, dict):
+        return r
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "compulsory_bytes", "traffic_over_compulsory", "traffic_over_requested", "kernel_ms",
+                    "call_ms", "whole_step_frac", "whole_step_frac_nominal", "device_ms_per_step"))
+    out.setdefault("traffic", r.get("traffic"))
+    if "kernel" in r:
+        out["kernel"] = _short(r["kernel"], 110 if depth == 0 else 70)
+    if isinstance(r.get("passes"), list):
+        out["passes"] = [{**_pick(q, ("ms", "bound", "achieved", "peak", "unit", "frac")), "kernel": _short(q.get("kernel", ""), 44)} for q in r["passes"]]
+    if isinstance(r.get("per_pair_hbm_leg"), dict) and depth == 0:
+        out["per_pair_hbm_leg"] = compact_roofline(r["per_pair_hbm_leg"], 1)
+    return out
+
+
+def compact(rec, full_path):
+    """What the driver parses: the contract's keys + config + roofline + cpu_baseline of the headline, and one short entry per `also` leg."""
+    out = _pick(rec, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    out["vs_baseline"] = rec.get("vs_baseline")
+    cfg = rec.get("config", {})
+    out["config"] = {**_pick(cfg, ("pairs_per_step_per_gpu", "passages_per_s", "streams", "parallelism")), "workload": _short(cfg.get("workload", ""), 330)}
+    out["roofline"] = compact_roofline(rec.get("roofline"))
+    cb = rec.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "aten_port_value", "aten_port_threads", "aten_port_batch", "aten_port_reference_default",
+                                              "config0_s", "config0_gpu_s")), "sample": _short(cb.get("sample", ""), 150)}
+    if isinstance(rec.get("collective"), dict):
+        out["collective"] = _pick(rec["collective"], ("backend", "rccl_ranks", "gathered_bytes_per_step", "gather_ms"))
+    if isinstance(rec.get("oracle_check"), dict):
+        out["oracle_check"] = rec["oracle_check"]
+    if isinstance(rec.get("parity"), dict):
+        out["parity"] = _pick(rec["parity"], ("dtype", "documents", "max_score_error_of_scale_vs_fp32_port"))
+    if isinstance(rec.get("other_operand_type"), dict):
+        out["other_operand_type"] = _pick(rec["other_operand_type"], ("dtype", "value", "ms_per_step", "whole_step_frac", "whole_step_frac_nominal"))
+    also = []
+    for a in rec.get("also", []) or []:
+        if not isinstance(a, dict) or "error" in a:
+            also.append(a if isinstance(a, dict) else {"error": str(a)})
+            continue
+        e = {"workload": " ".join(str(a.get("config", {}).get("workload", "")).split()[:2]), **_pick(a, ("value", "unit", "ms_per_step", "steps", "dtype"))}
+        r = a.get("roofline") or {}
+        e["roofline"] = {**_pick(r, ("bound", "frac", "whole_step_frac", "whole_step_frac_nominal")), "kernel": _short(r.get("kernel", ""), 40)}
+        if isinstance(r.get("per_pair_hbm_leg"), dict):
+            e["roofline"]["per_pair_hbm_leg_frac"] = r["per_pair_hbm_leg"].get("frac")
+        if isinstance(a.get("cpu_baseline"), dict):
+            e["cpu_baseline"] = _pick(a["cpu_baseline"], ("value", "cores", "kind"))
+        if isinstance(a.get("oracle_check"), dict):
+            e["oracle_err"] = a["oracle_check"].get("max_err_of_scale")
+        if isinstance(a.get("other_operand_type"), dict):
+            e["other_operand_type"] = _pick(a["other_operand_type"], ("dtype", "value", "whole_step_frac", "whole_step_frac_nominal"))
+        also.append(e)
+    if also:
+        out["also"] = also
+    out["full_record"] = full_path
+    out = _round(out)
+    line = json.dumps(out, separators=(",", ":"))
+    for victim in ("also", "other_operand_type", "parity"):        # (never reached with the default legs: a guard, not a plan)
+        if len(line) <= COMPACT_LIMIT:
+            break
+        if victim == "also" and "also" in out:
+            out["also"] = [{k: v for k, v in e.items() if k in ("workload", "value", "ms_per_step", "error")} for e in out["also"]]
+        else:
+            out.pop(victim, None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
 def emit(rec):
-    """The ONE JSON line, and the last line of stdout: RCCL prints a version banner through C stdio, which would otherwise
-    be flushed at process exit, after Python's own line."""
+    """The whole record goes to bench_full.json (next to this file; `also` legs in full, CPU sweeps, per-pass work figures, notes) and to
+    stderr; stdout gets ONE compact JSON line (<= 4 KB) - the last line of stdout: RCCL prints a version banner through C stdio, which
+    would otherwise be flushed at process exit, after Python's own line."""
+    full_path = os.path.join(ROOT, "bench_full.json")
+    try:
+        with open(full_path, "w") as f:
+            json.dump(rec, f, indent=1)
+        shown = "bench_full.json"
+    except OSError as e:
+        shown = f"not written ({type(e).__name__})"
+    print(json.dumps(rec), file=sys.stderr, flush=True)
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
     sys.stdout.flush()
-    print(json.dumps(rec), flush=True)
+    print(compact(rec, shown), flush=True)
 
 
 class Ctx:
@@ -378,23 +480,24 @@ class InteractionLeg:
         passes of `steps` more steps after the timed loop (csrc/capamd_profiling.h: capamd_debug_lists_timing; the events sit between
         launches, so a pass's figure includes its launch gap - the five add up to the step).  Returns ms per step of
         (memset, mark, query, sims, pool)."""
-        import ctypes
-
         from capreolus_amd import _lib
 
-        lib = _lib.profiling()
-        lib.capamd_debug_lists_timing(1)
-        try:
-            for i in range(steps):
-                for lo, hi in self.slices:
-                    self.launch_one(i % len(self.batches), lo, hi)
-                self.last_batch = i % len(self.batches)       # (`out` now holds this batch's scores: what check_against_oracle compares)
-            ms = (ctypes.c_double * 5)()
-            groups = lib.capamd_debug_lists_timing_read(ms)
-        finally:
-            lib.capamd_debug_lists_timing(0)
-        torch.cuda.synchronize()
-        return [m / steps for m in ms] if groups else None
+        with _lib.profiling_build() as lib:      # the -DCAPAMD_PROFILING build of the same kernels: the product library has no hooks
+            for lo, hi in self.slices:
+                self.launch_one(0, lo, hi)       # (module load of the second library)
+            torch.cuda.synchronize()
+            lib.capamd_debug_lists_timing(1)
+            try:
+                for i in range(steps):
+                    for lo, hi in self.slices:
+                        self.launch_one(i % len(self.batches), lo, hi)
+                    self.last_batch = i % len(self.batches)       # (`out` now holds this batch's scores: what check_against_oracle compares)
+                ms = (ctypes.c_double * 8)()
+                groups = lib.capamd_debug_lists_timing_read(ms)
+            finally:
+                lib.capamd_debug_lists_timing(0)
+            torch.cuda.synchronize()
+        return [m / steps for m in ms][:5] if groups else None
 
     def bytes_requested_per_pair(self):
         """What the kernel asks the memory system for: the id rows (int64), one packed table row (row_stride floats: the embedding,
@@ -458,11 +561,14 @@ class InteractionLeg:
         return run, (q, d, idf, emb_h, sd), err
 
 
-def pmc_traffic(args, model):
-    """roofline.traffic measured inside this invocation: HBM-side bytes per launch of the HBM-bound leg's kernel from the PMC counters,
-    collected as MI355X_MICROARCH.md (section HBM) prescribes - FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes (own child
-    runs of this script on the leg's configuration, counters only, no trace domains), bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: gfx950
-    tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B.  Returns (bytes per launch or None, how / why not)."""
+def pmc_traffic(args, model, route="per_pair_hbm"):
+    """HBM-side bytes from the PMC counters, measured inside this invocation and collected as MI355X_MICROARCH.md (section HBM) prescribes -
+    FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes (own child runs of this script, counters only, no trace domains),
+    bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: gfx950 tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B.
+      route "per_pair_hbm": per launch of the per-pair kernel on the HBM-bound leg (uniform ids over the --roofline-vocab table)
+      route "lists":        per CALL of the whole-list route on the headline configuration: every kernel of the call summed (the byte-map
+                            memset, lists_mark, lists_query, lists_sims, the pooling kernel)
+    Returns (bytes or None, how / why not)."""
     import csv
     import glob
     import shutil
@@ -475,7 +581,23 @@ def pmc_traffic(args, model):
     if exe is None:
         return None, "not measured: rocprofv3 not found"
     child = [sys.executable, os.path.abspath(__file__), "--model", model, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-roofline-leg",
-             "--no-pmc-traffic", "--uniform-ids", "--vocab", str(args.roofline_vocab), "--batches", "2", "--dim", str(args.dim)]
+             "--no-pmc-traffic", "--batches", "2", "--dim", str(args.dim)]
+    if route == "per_pair_hbm":
+        child += ["--uniform-ids", "--vocab", str(args.roofline_vocab)]
+
+        def mine(name):
+            return "forward_kernel" in name or "stream_kernel" in name
+
+        def unit(name):
+            return mine(name)
+    else:
+        child += ["--vocab", str(args.vocab), "--queries", str(args.queries or 64), "--docs", str(args.docs), "--no-pass-times"]
+
+        def mine(name):
+            return name.startswith("lists_") or "pacrr_mfma_lists" in name or "fillBuffer" in name
+
+        def unit(name):
+            return name.startswith("lists_mark_kernel")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CAPAMD_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     kb = {}
@@ -486,18 +608,73 @@ def pmc_traffic(args, model):
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
             except (OSError, subprocess.TimeoutExpired) as e:
                 return None, f"not measured: rocprofv3 --pmc {counter} failed ({type(e).__name__})"
-            vals = []
+            total, units = 0.0, 0
             for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if ("forward_kernel" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
+                    if r["Counter_Name"] != counter:
+                        continue
+                    if mine(r["Kernel_Name"]):
+                        total += float(r["Counter_Value"])
+                    if unit(r["Kernel_Name"]):
+                        units += 1
+            if not units:
                 return None, f"not measured: the rocprofv3 --pmc {counter} pass returned no rows for the kernel"
-            kb[counter] = (sum(vals) / len(vals), len(vals))
+            kb[counter] = (total / units, units)
+    what = "launches of the per-pair kernel" if route == "per_pair_hbm" else "calls of the list route (all its kernels summed)"
     return (kb["FETCH_SIZE"][0] * 2 + kb["WRITE_SIZE"][0]) * 1024, (
-        f"measured in this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs of this leg ({kb['FETCH_SIZE'][1]} / {kb['WRITE_SIZE'][1]} launches "
-        f"sampled, {kb['FETCH_SIZE'][0]:.0f} / {kb['WRITE_SIZE'][0]:.0f} KB per launch); bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md section HBM "
+        f"measured in this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child runs ({kb['FETCH_SIZE'][1]} / {kb['WRITE_SIZE'][1]} {what} "
+        f"sampled, {kb['FETCH_SIZE'][0]:.0f} / {kb['WRITE_SIZE'][0]:.0f} KB each); bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md section HBM "
         "(gfx950 tallies 128-B requests of wide coalesced reads at 64 B); memory-side requests of the L2s, Infinity-Cache hits included: an upper bound on HBM bytes")
+
+
+# What bounds each pass of the whole-list route and the peak it is priced against:
+F32_PEAK_TFLOPS = 157.3        # fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md "Peak FP32 (vector)" / "(matrix)")
+# RBF kernel evaluations per second the VALUs sustain when they do nothing else: scripts/ubench/valu_rates.hip's loop of the pooling
+# kernel's evaluation (v_fma, v_mul, v_exp_f32, v_add per value), every SIMD busy; profiles/r04/valu_rates.txt
+KERNEL_EVAL_PEAK_G = 2340.0
+SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("mfma" once they are v_mfma_f32_4x4x1_16b_f32)
+
+
+def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic, traffic_src):
+    """`roofline` of a line whose timed steps run the whole-list route: one entry per pass (what binds it, its rate against that peak), the
+    top-level keys = the longest pass, the call's PMC traffic against its compulsory bytes, and the per-pair kernel's HBM-bound leg kept as
+    a clearly labelled secondary."""
+    rows = []
+    for q in headline.get("passes") or []:
+        ms = q["ms"]
+        e = {"kernel": q["pass"], "ms": ms}
+        if "bytes_cleared" in q:
+            e.update(bound="hbm", achieved=q["bytes_cleared"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif "fp32_fma" in q:
+            e.update(bound=q.get("pipe", "valu"), achieved=2 * q["fp32_fma"] / (ms * 1e-3) / 1e12, peak=F32_PEAK_TFLOPS, unit="TFLOP/s")
+        elif "exponentials" in q:
+            e.update(bound="valu", achieved=q["exponentials"] / (ms * 1e-3) / 1e9, peak=KERNEL_EVAL_PEAK_G, unit="G kernel evaluations/s")
+        elif "id_row_bytes" in q:
+            e.update(bound="hbm", achieved=(q["id_row_bytes"] + q.get("bytes_written", 0)) / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        if "achieved" in e:
+            e["frac"] = e["achieved"] / e["peak"]
+        rows.append(e)
+    top = max((r for r in rows if "frac" in r), key=lambda r: r["ms"], default=None)
+    out = {"bound": top["bound"] if top else "valu", "kernel": (top["kernel"] if top else headline.get("kernel")) + " (the longest pass of the timed call; all passes below)",
+           "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else None, "unit": top["unit"] if top else None,
+           "frac": top["frac"] if top else None, "kernel_ms": top["ms"] if top else None,
+           "traffic": traffic, "traffic_source": traffic_src, "compulsory_bytes": compulsory,
+           "traffic_over_compulsory": (traffic / compulsory) if traffic else None, "call_ms": dev_s * 1e3,
+           "call_compulsory_GBps": compulsory / dev_s / 1e9, "call_hbm_frac_on_compulsory_bytes": compulsory / dev_s / 1e9 / HBM_PEAK_GBS,
+           "passes": rows,
+           "note": "the timed steps run the whole-list route (csrc/lists.hip): its passes bind on different resources, so every pass is priced against "
+                   "its own peak (bound = hbm: bytes / 8 TB/s; mfma: fp32 MFMA flops / 157.3 TF; valu: RBF kernel evaluations / the rate of a VALU-only "
+                   "loop of the same evaluation) and the top-level keys repeat the longest pass; compulsory_bytes = the id rows once + one packed row per "
+                   "distinct term of a list + the scores; traffic = PMC bytes of ALL the call's kernels.  SURVEY 8(d)'s algorithmic bytes (every "
+                   "position x a fp32 row) do not describe this route: it gathers a term once per LIST (roofline.headline_leg.algorithmic_GBps is kept "
+                   "for reference and exceeds the HBM peak)",
+           "headline_leg": headline}
+    if hbm_leg is not None:
+        out["per_pair_hbm_leg"] = {k: v for k, v in hbm_leg.items() if k != "headline_leg"}
+        out["per_pair_hbm_leg"]["what"] = ("SECONDARY, not what the timed steps launch: the one-pair-per-workgroup kernel on uniform ids over a table 20x the "
+                                            "Infinity Cache, where lists share nothing and HBM binds (launches that are not whole lists, training batches and huge "
+                                            "tables run this kernel)")
+    return out
 
 
 def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
@@ -528,7 +705,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 "Zipf ids hit L2 / Infinity Cache, so neither is an HBM rate",
     }
     if leg.lists:
-        passes = leg.lists_pass_times() if len(leg.slices) == 1 else None
+        passes = leg.lists_pass_times() if (len(leg.slices) == 1 and not args.no_pass_times) else None
         if passes:
             # what each pass does per step (the figures DESIGN.md section 3.5 prices the passes with) over its own duration
             rows = distinct_per_list * (n_pairs / args.docs)
@@ -542,8 +719,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 {"id_row_bytes": n_pairs * L * idb, "byte_stores": tokens, "GBps_of_id_rows": n_pairs * L * idb / (passes[1] * 1e-3) / 1e9},
                 {"lists": n_pairs / args.docs},
                 {"rows_gathered": rows, "row_bytes": rows * leg.row_stride * 4, "row_GBps": rows * leg.row_stride * 4 / (passes[3] * 1e-3) / 1e9,
-                 "fp32_fma": rows * Q * leg.row_stride, "fp32_TFLOPs": 2 * rows * Q * leg.row_stride / (passes[3] * 1e-3) / 1e12,
-                 "fp32_valu_peak_TFLOPs": 78.6, "note": "256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, one fma per lane and cycle (packed fp32 issues no faster here: DESIGN.md 3.5)"},
+                 "fp32_fma": rows * Q * leg.row_stride, "fp32_TFLOPs": 2 * rows * Q * leg.row_stride / (passes[3] * 1e-3) / 1e12, "pipe": SIMS_PIPE},
                 ({"id_row_bytes": n_pairs * L * idb, "table_lookups": tokens, "exponentials": tokens * Q * K, "Gexp_per_s": tokens * Q * K / (passes[4] * 1e-3) / 1e9}
                  if model == "knrm" else {"id_row_bytes": n_pairs * L * idb, "table_lookups": tokens, "lds_increments": tokens * Q}),
             ]
@@ -590,6 +766,13 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             roof["traffic"], roof["traffic_source"] = pmc_traffic(args, model)
             if roof["traffic"] is not None:
                 roof["traffic_over_requested"] = roof["traffic"] / (roof["pairs_per_launch"] * roof["requested_bytes_per_pair"])
+    if leg.lists and world == 1:
+        # the line's roofline describes what its timed steps launch: the list route's passes (the per-pair HBM-bound leg stays as a secondary)
+        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / args.docs) * (Q * 8 + (distinct_per_list + Q) * leg.row_stride * 4)
+        traffic, traffic_src = None, "not measured in this run (--no-pmc-traffic)"
+        if not args.no_pmc_traffic and ctx.rank == 0 and not args.uniform_ids:
+            traffic, traffic_src = pmc_traffic(args, model, "lists")
+        roof = lists_roofline(model, headline, roof, n_pairs, dev_s, compulsory, traffic, traffic_src)
     total_pairs = n_pairs * world
     rec = {
         "metric": "query-doc pairs scored/sec",
@@ -713,12 +896,29 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
     assert os.environ.get("CAPAMD_BENCH_NOCHECK") == "1" or torch.isfinite(out[0]).all()   # (the knob: profiling builds that drop a phase of the kernel)
     status.__exit__(None, None, None)
     nonpad = float((d_all > 0).sum().item()) / n_pairs
+    passes = None
+    if as_lists and not args.no_pass_times:       # the route's passes, HIP events between them (the -DCAPAMD_PROFILING build of the same kernels)
+        from capreolus_amd import _lib
+
+        with _lib.profiling_build() as lib, torch.no_grad():
+            step(0)
+            torch.cuda.synchronize()
+            lib.capamd_debug_lists_timing(1)
+            try:
+                for _ in range(3):
+                    step(0)
+                ms = (ctypes.c_double * 8)()
+                groups = lib.capamd_debug_lists_timing_read(ms)
+            finally:
+                lib.capamd_debug_lists_timing(0)
+            torch.cuda.synchronize()
+        passes = [x / 3 for x in ms][:5] if groups else None
     if model == "convknrm":
         G, F = m.p["maxngram"], m.p["filters"]
         row = G * (G + 1) // 2 * F * 4
     else:
         row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
-    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad, as_lists
+    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad, as_lists, passes
 
 
 def sibling_oracle(model, m, D, q, d, idf, emb_h):
@@ -758,7 +958,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
     Q, L, V, D = 4, 800, args.vocab, args.dim
     n_queries = args.queries or 64
     n_pairs = n_queries * args.docs
-    rr, m, batch, scores, elapsed, kern_s, row, nonpad, as_lists = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
+    rr, m, batch, scores, elapsed, kern_s, row, nonpad, as_lists, passes = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
     q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
     emb = table(dev, V, D)
     if model == "convknrm":
@@ -793,6 +993,25 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
         del big
         _tables.pop((dev.index, args.roofline_vocab, D), None)
         torch.cuda.empty_cache()
+    lists_view = None
+    if as_lists and passes and world == 1:
+        # the timed steps run the list route: its passes, each against the resource that binds it (lists_roofline); the pooling kernels of these
+        # two models (per-lane top-k lists / MFMA convolutions + k-max) have no single-resource peak: their entry carries ms only
+        docs = args.docs
+        d2 = d_all.view(-1, docs * L)
+        rows = float(sum(int((torch.unique(d2[i]) > 0).sum().item()) for i in range(d2.shape[0])))
+        rstride = row // 4
+        tokens = nonpad * n_pairs
+        pool_name = {"drmmtks": "lists_tks_pool_kernel<12>", "pacrr": "pacrr_mfma_lists_kernel<5, 2>"}[model]
+        ptab = [{"pass": "hipMemsetAsync (byte maps)", "ms": passes[0], "bytes_cleared": (n_pairs / docs) * ((V + 1023) // 1024 * 1024)},
+                {"pass": "lists_mark_kernel", "ms": passes[1], "id_row_bytes": n_pairs * L * 8, "byte_stores": tokens},
+                {"pass": "lists_query_kernel<5>", "ms": passes[2]},
+                {"pass": "lists_sims_kernel<5, false>", "ms": passes[3], "rows_gathered": rows, "fp32_fma": rows * Q * rstride, "pipe": SIMS_PIPE},
+                {"pass": pool_name, "ms": passes[4]}]
+        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / docs) * (Q * 8 + (rows / (n_pairs / docs) + Q) * row)
+        lists_view = lists_roofline(model, {"passes": ptab, "kernel": headline_kernel}, None, n_pairs, kern_s, compulsory, None,
+                                    "not measured for this leg (the KNRM / DRMM lines measure the shared passes)")
+        lists_view.pop("headline_leg", None)
     rec = {
         "metric": "query-doc pairs scored/sec", "value": n_pairs * world * steps / elapsed, "unit": "pairs/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
@@ -813,6 +1032,11 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
                              "around the timed steps); algorithmic = all L positions (pads are scored in closed form without a gather)"},
         "oracle_check": {"pairs": min(check_pairs, n_pairs), "max_err_of_scale": oracle_err},
     }
+    if lists_view is not None:      # the line's roofline = what its timed steps launch; the per-pair kernel's HBM-bound leg as the labelled secondary
+        per_pair = rec["roofline"]
+        per_pair["what"] = "SECONDARY, not what the timed steps launch: the one-pair-per-workgroup kernel on uniform ids over the --roofline-vocab table"
+        lists_view["per_pair_hbm_leg"] = per_pair
+        rec["roofline"] = lists_view
     if with_cpu and world == 1 and emb_h is not None:
         cores = os.cpu_count() or 1
         n = args.cpu_pairs or (2000 if model == "convknrm" else min(n_pairs, 2000 * max(1, cores // 4)))
@@ -899,32 +1123,31 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
         if use_dist:
             dist.all_gather_into_tensor(gathered, out[0])
 
-    lib = _lib.profiling()
     for i in range(warmup):
         step(i)
     serial = eng.n_streams == 1
-    if serial:
-        lib.capamd_debug_ffn1_timing(1)  # HIP events around the dominant kernel's launches during the timed steps (read back below)
     elapsed, dev_s = timed_loop(ctx, step, 0, steps)
     engine.status_word(dev).raise_if_set()
     assert torch.isfinite(out[0]).all()
     scores = out[0].clone()
 
-    # dominant kernel: the FFN1 GEMM (folded LayerNorm + bias + GELU epilogue), timed by the library's HIP events around each of its
-    # launches (capamd_debug_ffn1_timing, capreolus_amd/csrc/capamd_profiling.h) - during the timed steps when they run on one stream, otherwise in
-    # one more step of the same batch run strictly serially (kernels of concurrent streams would stretch each other's durations)
-    if not serial:
+    # dominant kernel: the FFN1 GEMM (folded LayerNorm + bias + GELU epilogue), timed by HIP events around each of its launches
+    # (capamd_debug_ffn1_timing, capreolus_amd/csrc/capamd_profiling.h - a hook of the -DCAPAMD_PROFILING build of the library only, so
+    # the timed steps above ran the product library) in one more step of the same batch, run strictly serially (kernels of concurrent
+    # streams would stretch each other's durations)
+    tot_ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    with _lib.profiling_build() as lib:
         eng.n_streams = 1
-        step(0)                       # (sizes the single-stream workspace)
+        step(0)                       # (sizes the single-stream workspace; module load of the second library)
         torch.cuda.synchronize(dev)
         lib.capamd_debug_ffn1_timing(1)
         step(0)
         torch.cuda.synchronize(dev)
         assert torch.equal(out[0], scores), "the serial and the multi-stream step disagree"
         eng.n_streams = max(1, args.bert_streams)
-    tot_ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    _lib.check(lib.capamd_debug_ffn1_timing_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(rows)), "ffn1 timing")
-    lib.capamd_debug_ffn1_timing(0)
+        _lib.check(lib.capamd_debug_ffn1_timing_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(rows)), "ffn1 timing")
+        lib.capamd_debug_ffn1_timing(0)
+    serial = False
     out[0] = scores
     gemm_s = tot_ms.value * 1e-3 / max(1, launches.value)
     gemm_tf = 2.0 * rows.value * F * H / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
@@ -967,7 +1190,8 @@ def bench_bert(args, ctx, steps, warmup, with_cpu):
         torch.cuda.empty_cache()
         o = bench_bert(other, ctx, 3, 1, with_cpu=False)
         rec["other_operand_type"] = {"dtype": other.bert_dtype, "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": 3,
-                                     "whole_step_frac_nominal": o["roofline"]["whole_step_frac_nominal"], "ffn1_frac": o["roofline"]["frac"]}
+                                     "whole_step_frac": o["roofline"]["whole_step_frac"], "whole_step_frac_nominal": o["roofline"]["whole_step_frac_nominal"],
+                                     "ffn1_frac": o["roofline"]["frac"]}
     if args.bert_skip_padding:
         # the nominal FLOP count (every passage at S tokens) no longer describes the executed work: no whole-step MFMA figure
         rec["config"]["padding"] = "passages encoded in length buckets of 32 tokens (identical scores; rows beyond a passage's last token are not computed)"

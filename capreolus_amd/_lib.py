@@ -85,7 +85,9 @@ SIGNATURES = {
     "capamd_bert_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
-# builder-side profiling hooks (capreolus_amd/csrc/capamd_profiling.h): exported by the library, not declared in the public header
+# builder-side profiling hooks (capreolus_amd/csrc/capamd_profiling.h): exported ONLY by the -DCAPAMD_PROFILING build of the library
+# (csrc/libcapreolus_amd_prof.so), never by the product library - see profiling_build()
+PROF_LIB_PATH = os.path.join(_HERE, "csrc", "libcapreolus_amd_prof.so")
 PROFILING_SIGNATURES = {
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
     "capamd_debug_ffn1_timing": (None, [_i]),
@@ -119,13 +121,32 @@ def load():
     return lib
 
 
-def profiling():
-    """The library with its profiling hooks bound (bench.py's roofline timing, scripts/ probes)."""
-    lib = load()
-    for name, (res, args) in PROFILING_SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
-    return lib
+_prof = None
+
+
+class profiling_build:
+    """`with _lib.profiling_build() as lib:` - inside the block every engine call goes to the -DCAPAMD_PROFILING build of the library
+    (the same kernels plus the event hooks of csrc/capamd_profiling.h); `lib` has the hooks bound.  For bench.py's per-pass timing
+    legs and the scripts/ probes: the product library has no such hooks and no mutable global state."""
+
+    def __enter__(self):
+        global _lib, _prof
+        load()
+        if _prof is None:
+            if not os.path.exists(PROF_LIB_PATH):
+                raise ImportError(f"{PROF_LIB_PATH} is missing (capreolus_amd/csrc/build.py builds it next to the product library)")
+            lib = ctypes.CDLL(PROF_LIB_PATH)
+            for name, (res, args) in list(SIGNATURES.items()) + list(PROFILING_SIGNATURES.items()):
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _prof = lib
+        self.saved, _lib = _lib, _prof
+        return _prof
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 _ERR_NAMES = {ERR_ARG: "CAPAMD_ERR_ARG", ERR_ALIGN: "CAPAMD_ERR_ALIGN", ERR_LAUNCH: "CAPAMD_ERR_LAUNCH",

@@ -689,7 +689,9 @@ __global__ void neutral_stats_kernel(int64_t M, float* __restrict__ mu, float* _
   }
 }
 
-// profiling hook (capamd_debug_ffn1_timing): HIP events around the FFN1 launches of the timed forward passes
+// profiling hook (capamd_debug_ffn1_timing): HIP events around the FFN1 launches of the timed forward passes.  Exists only in the
+// -DCAPAMD_PROFILING build (libcapreolus_amd_prof.so, bench.py / scripts): the product library carries no mutable global state.
+#ifdef CAPAMD_PROFILING
 struct Ffn1Timing {
   static inline bool on = false;
   static inline std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -707,6 +709,12 @@ struct Ffn1Timing {
     rows += m;
   }
 };
+#else
+struct Ffn1Timing {
+  static void begin(hipStream_t) {}
+  static void end(hipStream_t, int64_t) {}
+};
+#endif
 
 struct Workspace {
   uint16_t* xb;   // [M, H] activation / residual stream      (16-bit type T of the model: bf16 or fp16)
@@ -1131,6 +1139,7 @@ int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const 
 }
 
 /* building blocks, exported for unit tests and for callers that want the encoder pieces */
+#ifdef CAPAMD_PROFILING
 void capamd_debug_ffn1_timing(int enable) { Ffn1Timing::on = enable != 0; }
 int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* rows) {
   if (!total_ms || !launches || !rows) return CAPAMD_ERR_ARG;
@@ -1147,6 +1156,9 @@ int capamd_debug_ffn1_timing_read(double* total_ms, int64_t* launches, int64_t* 
 }
 static unsigned long long* g_gemm_dbg = nullptr;
 void capamd_debug_set_gemm_stamps(void* p) { g_gemm_dbg = (unsigned long long*)p; }  /* profiling hook (scripts/gemm_timeline.py) */
+#else
+static constexpr unsigned long long* g_gemm_dbg = nullptr;
+#endif
 
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue, const void* resid,
                      void* out, int dtype, void* stream) {

@@ -1,4 +1,12 @@
-"""Builds capreolus_amd/csrc/libcapreolus_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Builds the C-ABI libraries for gfx950 with hipcc (cross-compiles without a GPU):
+
+    libcapreolus_amd.so        the product library (include/capreolus_amd.h; no profiling hooks, no mutable global state)
+    libcapreolus_amd_prof.so   the same objects, with the sources that carry profiling hooks (csrc/capamd_profiling.h) compiled
+                               once more with -DCAPAMD_PROFILING - bound by bench.py's per-pass timing legs and scripts/ only
+                               (capreolus_amd._lib.profiling_build())
+
+Incremental: an object is rebuilt when its source or anything in its depfile (-MMD) is newer than it.
+"""
 import glob
 import os
 import subprocess
@@ -7,41 +15,70 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libcapreolus_amd.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + HERE]
+OUT_PROF = os.path.join(HERE, "libcapreolus_amd_prof.so")
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + HERE]
+PROF_SOURCES = ("bert.hip", "lists.hip", "pacrr.hip")     # sources whose code differs under -DCAPAMD_PROFILING
 
 
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
 
-def stale():
-    if not os.path.exists(OUT):
+def _deps(obj, src):
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return None
+    words = open(d).read().replace("\\\n", " ").split()
+    return [w for w in words[1:] if w != src] + [src]
+
+
+def _obj_stale(obj, src):
+    if not os.path.exists(obj):
         return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(HERE, "*.cuh")) + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    deps = _deps(obj, src)
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _jobs():
+    """[(source, object, extra flags)]: every source for the product library, PROF_SOURCES once more for the profiling one"""
+    jobs = []
+    for src in sources():
+        jobs.append((src, src[:-4] + ".o", []))
+        if os.path.basename(src) in PROF_SOURCES:
+            jobs.append((src, src[:-4] + ".prof.o", ["-DCAPAMD_PROFILING"]))
+    return jobs
+
+
+def stale():
+    return (not os.path.exists(OUT)) or (not os.path.exists(OUT_PROF)) or any(_obj_stale(o, s) for s, o, _ in _jobs()) or any(
+        os.path.getmtime(o) > min(os.path.getmtime(OUT), os.path.getmtime(OUT_PROF)) for _, o, _ in _jobs() if os.path.exists(o))
 
 
 def build(force=False, verbose=False):
     if not force and not stale():
         return OUT
-    objs = []
     procs = []
-    for src in sources():
-        obj = src[:-4] + ".o"
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-I" + os.path.join(ROOT, "include"),
-               "-I" + HERE, src, "-o", obj]
+    for src, obj, extra in _jobs():
+        if not force and not _obj_stale(obj, src):
+            continue
+        cmd = ["hipcc"] + CFLAGS + extra + ["-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objs = [o for _, o, extra in _jobs() if not extra]
+    prof = {s: o for s, o, extra in _jobs() if extra}
+    prof_objs = [prof.get(s, o) for s, o, extra in _jobs() if not extra]
+    for out, ol in ((OUT, objs), (OUT_PROF, prof_objs)):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + ol
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return OUT
 
 

@@ -8,7 +8,12 @@
 #include <stdlib.h>
 
 namespace capamd {
+constexpr int kListStamps = 6;        // stamps per launch group: before the memset and after each of memset, mark, query, sims, pool
+#ifdef CAPAMD_PROFILING
 void lists_stamp(hipStream_t s);      // lists.hip: records an event between passes while capamd_debug_lists_timing is on
+#else
+inline void lists_stamp(hipStream_t) {}
+#endif
 }
 
 using namespace capamd;

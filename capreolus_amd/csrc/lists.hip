@@ -31,9 +31,10 @@
 #include "capamd_profiling.h"
 #include <vector>
 
+// capamd_debug_lists_timing: an event after every pass of a launch group while enabled.  Exists only in the -DCAPAMD_PROFILING build
+// (libcapreolus_amd_prof.so, bench.py / scripts; not thread-safe): the product library carries no mutable global state.
+#ifdef CAPAMD_PROFILING
 namespace {
-
-// capamd_debug_lists_timing: six events per launch group while enabled (profiling only: not thread-safe, off by default)
 bool g_lists_timing = false;
 std::vector<hipEvent_t> g_lists_events;
 }  // namespace
@@ -44,6 +45,7 @@ void capamd::lists_stamp(hipStream_t s) {
   (void)hipEventRecord(e, s);
   g_lists_events.push_back(e);
 }
+#endif
 namespace {
 
 // The ids of one pass of a pooling kernel - TRIPS trips of STRIDE consecutive positions, this lane's slot `ps` - as int: 0 = pad (or beyond
@@ -599,25 +601,29 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
 
 }  // namespace
 
+#ifdef CAPAMD_PROFILING
 extern "C" void capamd_debug_lists_timing(int enable) {
   g_lists_timing = enable != 0;
   for (hipEvent_t e : g_lists_events) (void)hipEventDestroy(e);
   g_lists_events.clear();
 }
 
+// adds the durations of the passes (kListPasses of them per launch group) to ms[0 .. kListPasses), returns the launch groups seen
 extern "C" int capamd_debug_lists_timing_read(double* ms) {
-  const size_t groups = g_lists_events.size() / 6;
+  constexpr int per = capamd::kListStamps;
+  const size_t groups = g_lists_events.size() / per;
   for (size_t i = 0; i < groups; ++i) {
-    (void)hipEventSynchronize(g_lists_events[6 * i + 5]);
-    for (int k = 0; k < 5; ++k) {
+    (void)hipEventSynchronize(g_lists_events[per * i + per - 1]);
+    for (int k = 0; k + 1 < per; ++k) {
       float t = 0.f;
-      if (ms && hipEventElapsedTime(&t, g_lists_events[6 * i + k], g_lists_events[6 * i + k + 1]) == hipSuccess) ms[k] += t;
+      if (ms && hipEventElapsedTime(&t, g_lists_events[per * i + k], g_lists_events[per * i + k + 1]) == hipSuccess) ms[k] += t;
     }
   }
   for (hipEvent_t e : g_lists_events) (void)hipEventDestroy(e);
   g_lists_events.clear();
   return (int)groups;
 }
+#endif
 
 extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
   if (n_lists < 1 || V < 1) return 0;

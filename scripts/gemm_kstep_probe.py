@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from capreolus_amd import _lib
-lib = _lib.profiling(); dev = "cuda:0"
+lib = _lib.profiling_build().__enter__(); dev = "cuda:0"   # (the -DCAPAMD_PROFILING build for the whole script)
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, M, N, K in [("M=2048  N=2304 (72 tiles, A 3 MB)", 2048, 2304, 768), ("M=8192  N=2304 (288 tiles)", 8192, 2304, 768),

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from capreolus_amd import _lib
-lib = _lib.profiling(); dev = "cuda:0"
+lib = _lib.profiling_build().__enter__(); dev = "cuda:0"   # (the -DCAPAMD_PROFILING build for the whole script)
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = 65536
