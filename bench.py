@@ -594,10 +594,10 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
         child += ["--vocab", str(args.vocab), "--queries", str(args.queries or 64), "--docs", str(args.docs), "--no-pass-times"]
 
         def mine(name):
-            return name.startswith("lists_") or "pacrr_mfma_lists" in name or "fillBuffer" in name
+            return "lists_" in name or "fillBuffer" in name
 
         def unit(name):
-            return name.startswith("lists_mark_kernel")
+            return "lists_mark_kernel" in name
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CAPAMD_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     kb = {}
@@ -631,7 +631,7 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
 F32_PEAK_TFLOPS = 157.3        # fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md "Peak FP32 (vector)" / "(matrix)")
 # RBF kernel evaluations per second the VALUs sustain when they do nothing else: scripts/ubench/valu_rates.hip's loop of the pooling
 # kernel's evaluation (v_fma, v_mul, v_exp_f32, v_add per value), every SIMD busy; profiles/r04/valu_rates.txt
-KERNEL_EVAL_PEAK_G = 2340.0
+KERNEL_EVAL_PEAK_G = 7150.0
 SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("mfma" once they are v_mfma_f32_4x4x1_16b_f32)
 
 
@@ -665,7 +665,7 @@ def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic
            "note": "the timed steps run the whole-list route (csrc/lists.hip): its passes bind on different resources, so every pass is priced against "
                    "its own peak (bound = hbm: bytes / 8 TB/s; mfma: fp32 MFMA flops / 157.3 TF; valu: RBF kernel evaluations / the rate of a VALU-only "
                    "loop of the same evaluation) and the top-level keys repeat the longest pass; compulsory_bytes = the id rows once + one packed row per "
-                   "distinct term of a list + the scores; traffic = PMC bytes of ALL the call's kernels.  SURVEY 8(d)'s algorithmic bytes (every "
+                   "distinct term of the STEP (rows that lists share are compulsory once) + the scores; traffic = PMC bytes of ALL the call's kernels.  SURVEY 8(d)'s algorithmic bytes (every "
                    "position x a fp32 row) do not describe this route: it gathers a term once per LIST (roofline.headline_leg.algorithmic_GBps is kept "
                    "for reference and exceeds the HBM peak)",
            "headline_leg": headline}
@@ -768,7 +768,10 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                 roof["traffic_over_requested"] = roof["traffic"] / (roof["pairs_per_launch"] * roof["requested_bytes_per_pair"])
     if leg.lists and world == 1:
         # the line's roofline describes what its timed steps launch: the list route's passes (the per-pair HBM-bound leg stays as a secondary)
-        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / args.docs) * (Q * 8 + (distinct_per_list + Q) * leg.row_stride * 4)
+        # compulsory HBM bytes of a call: the id rows once, every table row the step's lists touch once (shared rows come from cache), the scores
+        union_rows = float(np.mean([int((torch.unique(b["posdoc"]) > 0).sum().item()) for b in leg.batches]))
+        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / args.docs) * Q * (8 + leg.row_stride * 4) + union_rows * leg.row_stride * 4
+        headline["distinct_terms_per_step"] = union_rows
         traffic, traffic_src = None, "not measured in this run (--no-pmc-traffic)"
         if not args.no_pmc_traffic and ctx.rank == 0 and not args.uniform_ids:
             traffic, traffic_src = pmc_traffic(args, model, "lists")
@@ -822,6 +825,8 @@ class Ctx1:
 
 def main():
     args = parse()
+    if os.environ.get("CAPAMD_LIB_PATH"):       # an A/B build of the library (scripts/build_variant*.sh): it has no profiling twin
+        args.no_pass_times = True
     ctx = Ctx(args)
     if args.model == "bert":
         rec = bench_bert(args, ctx, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)
@@ -1008,7 +1013,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
                 {"pass": "lists_query_kernel<5>", "ms": passes[2]},
                 {"pass": "lists_sims_kernel<5, false>", "ms": passes[3], "rows_gathered": rows, "fp32_fma": rows * Q * rstride, "pipe": SIMS_PIPE},
                 {"pass": pool_name, "ms": passes[4]}]
-        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / docs) * (Q * 8 + (rows / (n_pairs / docs) + Q) * row)
+        compulsory = n_pairs * (L * 8 + 4) + (n_pairs / docs) * Q * (8 + row) + int((torch.unique(d_all) > 0).sum().item()) * row
         lists_view = lists_roofline(model, {"passes": ptab, "kernel": headline_kernel}, None, n_pairs, kern_s, compulsory, None,
                                     "not measured for this leg (the KNRM / DRMM lines measure the shared passes)")
         lists_view.pop("headline_leg", None)

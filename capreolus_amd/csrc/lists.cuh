@@ -50,8 +50,8 @@ struct ListsArgs {
   const float* kn_mu;      // KNRM: the kernels' parameters (null for DRMM) ...
   const float* kn_sigma;
   int kn_K;
-  float* kn_consts;        // ... and what the pooling pass needs of them, computed once per call: [4][kMaxK] mu, c = -log2(e) / (2 sigma^2),
-                           //     K(0) = 2^(c mu^2), K(1) = 2^(c (1 - mu)^2)   (slots beyond K repeat the last kernel)
+  float* kn_consts;        // ... and what the pooling pass needs of them, computed once per call: [6][kMaxK] mu, c = -log2(e) / (2 sigma^2),
+                           //     K(0) = 2^(c mu^2), K(1) = 2^(c (1 - mu)^2), A = sqrt(-c), B = -A mu   (slots beyond K repeat the last kernel)
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
@@ -118,13 +118,21 @@ __device__ __forceinline__ int list_bin_of(float x, const float* edges, int nbin
 constexpr unsigned kBinExact = 0x80;      // entry byte: bin (nbins = above the last edge) | kBinExact when 0.999 < s < 1.001 (drmm.hip's exact-match bin)
 
 // the query of every list once: its packed rows in the PAIRED LDS layout of rows_dot_pk, its ids and norms
+#ifdef CAPAMD_LISTS_SIMS_VALU      // A/B builds: the round-3 sims pass on the fp32 VALU (lists_sims_kernel); its query image is the paired layout
+constexpr bool kSimsOnMfma = false;
+#define CAPAMD_SIMS_KERNEL lists_sims_kernel
+#else
+constexpr bool kSimsOnMfma = true;
+#define CAPAMD_SIMS_KERNEL lists_sims_mfma_kernel
+#endif
 template <int NV>
 __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom g) {
   __shared__ __attribute__((aligned(16))) float4 qlds[kQueryImage];
   const int l = blockIdx.x, tid = threadIdx.x, lane16 = tid & 15;
   const PairIds ids = pair_ids(a.ids, g.start[l], a.Q, a.L);
   QueryPass<NV> qp;
-  load_query_pass_lds<NV, true>(a.packed, ids, a.Q, 0, a.V, tid, 128, lane16, qlds, qp, a.status);
+  // (the MFMA sims pass reads the plain layout [(term * NV + chunk) * 16 + piece]; the VALU one the paired layout of rows_dot_pk)
+  load_query_pass_lds<NV, !kSimsOnMfma>(a.packed, ids, a.Q, 0, a.V, tid, 128, lane16, qlds, qp, a.status);
   __syncthreads();
   float4* img = a.qimg + (int64_t)l * kQueryImage;
   for (int i = tid; i < kQT * NV * 16; i += 128) img[i] = qlds[i];
@@ -139,9 +147,15 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
     a.kn_consts[kMaxK + tid] = c;
     a.kn_consts[2 * kMaxK + tid] = __builtin_amdgcn_exp2f(mk * mk * c);
     a.kn_consts[3 * kMaxK + tid] = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * c);
+    // the evaluation as K(s) = 2^-(A s + B)^2 with A = sqrt(-c), B = -A mu: fma, mul, exp, add - one VALU instruction fewer per value than
+    // (s - mu)^2 c (scripts/ubench/valu_rates.hip: 8.7 against 7.2 T evaluations/s)
+    const float A = sqrtf(-c);
+    a.kn_consts[4 * kMaxK + tid] = A;
+    a.kn_consts[5 * kMaxK + tid] = -A * mk;
   }
 }
 
+#ifdef CAPAMD_LISTS_SIMS_VALU      // (A/B builds only: the round-3 pass on the fp32 VALU)
 #ifndef CAPAMD_LISTS_SIMS_WAVES
 #define CAPAMD_LISTS_SIMS_WAVES 1
 #endif
@@ -223,8 +237,186 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
   // (one row per trip with the NEXT row requested before the current one is used - a software pipeline - is 4-5 % slower end to end)
 }
 
+#endif
+
+// ---- 2': sims on the matrix pipe ------------------------------------------------------------------------------------------------
+// The same dot products - per (row, query term) the 16 lane-partial fma chains of rows_dot and their balanced tree, bit for bit - with
+// the chains on v_mfma_f32_4x4x1_16b_f32 instead of the fp32 VALU.  That instruction is 16 independent 4 x 4 outer products, K = 1:
+// D_b[i][j] += A_b[i] * B_b[j] for blocks b = 0..15, lane 4 b + i supplying A_b[i], lane 4 b + j supplying B_b[j] and keeping column j of
+// D_b in its four result registers; and an fp32 MFMA accumulates as a k-ordered fmaf chain, bit for bit (MI355X_MICROARCH.md, checked by
+// scripts/ubench/valu_rates.hip).  So: block b IS lane-partial b of the VALU form (the chain over floats 64 c + 4 b + e, c ascending, e =
+// x, y, z, w), i = one of FOUR table rows, j = one of the four query terms: 20 instructions (NV = 5) give four rows' 16 x 4 partial
+// chains at twice the VALU's fma rate, the VALU left to the reductions - 3 DPP adds per result register for the in-row levels of the tree
+// (partials b ^ 1, b ^ 2) and a reduce-scatter over the wave's four rows for the last two (b ^ 4, b ^ 8), after which row R of the wave
+// holds the finished dot products of the R-th four-row group of a 16-row batch: 12 shuffles per 16 rows where the VALU form spends 64
+// DPP adds per ROW.  What the MFMA wants - lane = (partial, row), i.e. four different rows in every quad of lanes - is not what a gather
+// can deliver (a quad of lanes on four rows is four cache lines per request): rows are fetched as before, a 16-lane group per row, and
+// turned through a wave-private LDS stage (ds_write_b128 at slot 4 p + i, then one LINEAR ds_read_b128 per chunk: conflict-free).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lane_xor4(float v) {        // the value of lane ^ 4: quad reversed, then the 8-lane half mirrored
+  return dpp_mov<0x141>(dpp_mov<0x1B>(v));
+}
+
+template <int NV, bool BINS>
+__global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, ListGeom g) {
+  __shared__ int lst[kSimsIds];
+  static_assert(kSimsIds <= 4096, "16 flag bytes per thread at most");
+  __shared__ int wave_cnt[4];
+  __shared__ float edges[kMaxBins];
+  __shared__ __attribute__((aligned(16))) f32x4v stage[4][2][NV * 64];     // [wave][buffer][chunk * 64 + 4 * piece + row of the group]
+  __shared__ __attribute__((aligned(16))) float dens[4][16];              // [wave][row of the batch] the rows' norms
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = tid & 15, grp = lane >> 4;
+  // XCD x (workgroups whose linear index is x mod 8: blockIdx.x = 8 * list + x) takes the id blocks 8 k + x, each for all lists back to back
+  const int l = blockIdx.x >> 3, blk = blockIdx.y * 8 + (blockIdx.x & 7);
+  if ((int64_t)blk * kSimsIds >= a.Vp) return;
+  const int id0 = blk * kSimsIds;
+  constexpr int kPer = kSimsIds / 256;      // ids per thread: their flag bytes in one load
+  static_assert(kPer == 2 || kPer == 4 || kPer == 8 || kPer == 16, "kSimsIds is 512, 1024, 2048 or 4096");
+  const uint8_t* fp = a.flags + (int64_t)l * a.Vp + id0 + tid * kPer;
+  uint64_t fw, fw2 = 0;
+  if (kPer == 16) {
+    const uint4 w = *reinterpret_cast<const uint4*>(fp);
+    fw = (uint64_t)w.x | ((uint64_t)w.y << 32);
+    fw2 = (uint64_t)w.z | ((uint64_t)w.w << 32);
+  } else {
+    fw = kPer == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(fp) : kPer == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(fp)
+                                                                                   : *reinterpret_cast<const uint64_t*>(fp);
+  }
+  auto flag_of = [&](int c) { return (unsigned)(((c < 8 ? fw : fw2) >> (8 * (c & 7))) & 0xffu); };
+  // this lane's B operands: query term j = lane & 3, the pieces of partial chain b = lane >> 2 (requested now, used after the compaction)
+  const int j = lane & 3, b = lane >> 2;
+  f32x4v qreg[NV];
+  {
+    const f32x4v* img = reinterpret_cast<const f32x4v*>(a.qimg + (int64_t)l * kQueryImage);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) qreg[c] = img[(j * NV + c) * 16 + b];
+  }
+  const float qden = a.qmeta[l].den[j];
+  const int qid = a.qmeta[l].id[j];
+  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
+  // the flagged ids, dense, in LDS (any order): per flag byte one ballot, the lane's slot = the set lanes below it
+  int slot[kPer], mine = 0;
+#pragma unroll
+  for (int c = 0; c < kPer; ++c) {
+    const uint64_t set = __ballot(flag_of(c) != 0);
+    slot[c] = mine + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u));
+    mine += __builtin_popcountll(set);       // (wave-uniform from here: the wave's count so far)
+  }
+  if (lane == 0) wave_cnt[wave] = mine;
+  __syncthreads();
+  const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+  const int total = c0 + c1 + c2 + c3;
+  if (total == 0) return;
+  const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+#pragma unroll
+  for (int c = 0; c < kPer; ++c)
+    if (flag_of(c)) lst[base + slot[c]] = tid * kPer + c;
+  __syncthreads();
+  float* tab = reinterpret_cast<float*>(a.table + (int64_t)l * a.Vp);
+  uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
+  // batches of 16 rows (four groups of four), dealt to the waves round robin; no barrier from here on: every wave has its own stage
+  const int nb = (total + 15) >> 4;
+  auto row_id = [&](int batch, int G) {       // the table row this lane's 16-lane group fetches for group G of a batch (the tail repeats the last row)
+    const int e = batch * 16 + G * 4 + grp;
+    return id0 + lst[e < total ? e : total - 1];
+  };
+  // (native vectors, not float4 structs: a struct copied whole from memory to LDS stays a memcpy through a stack slot)
+  auto fetch = [&](int id, f32x4v (&r)[NV]) {
+    const f32x4v* p = reinterpret_cast<const f32x4v*>(a.packed + (int64_t)id * (64 * NV)) + pl;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) r[c] = p[c * 16];
+  };
+  f32x4v rr[4][NV];
+  int bt = wave;
+  if (bt >= nb) return;                       // (no barrier below)
+#pragma unroll
+  for (int G = 0; G < 4; ++G) fetch(row_id(bt, G), rr[G]);
+  for (; bt < nb; bt += 4) {
+    const int next = bt + 4 < nb ? bt + 4 : bt;       // (the last batch is requested twice: a load under a condition makes its destination a merge
+                                                      //  point, which hipcc resolves through scratch memory)
+    f32x4v acc[4];
+    f32x4v nx[4][NV];
+    // two groups at a time, one per stage buffer: their two accumulator chains alternate on the matrix pipe (an MFMA that waits for the
+    // one before it - the chain of a single group - issues at about half the rate)
+#pragma unroll
+    for (int H = 0; H < 2; ++H) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int G = 2 * H + h;
+        f32x4v* st = stage[wave][h];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) st[c * 64 + 4 * pl + grp] = rr[G][c];
+        if (pl == 15) dens[wave][G * 4 + grp] = rr[G][NV - 1].w;
+        fetch(row_id(next, G), nx[G]);                  // the same group of this wave's next batch (the registers just stored are free)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // (one wave: LDS program order is the synchronisation)
+      f32x4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const f32x4v a0 = stage[wave][0][c * 64 + lane], a1 = stage[wave][1][c * 64 + lane];
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, qreg[c].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, qreg[c].x, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, qreg[c].y, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, qreg[c].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, qreg[c].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, qreg[c].z, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, qreg[c].w, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, qreg[c].w, d1, 0, 0, 0);
+      }
+      acc[2 * H] = d0;
+      acc[2 * H + 1] = d1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // levels 1, 2 of the tree (partials b ^ 1, b ^ 2: inside the 16-lane row): every lane of a row ends with the row's sum for its term
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[G][i];
+        v += lane_xor4(v);
+        v += dpp_mov<0x128>(v);            // row_ror:8 = lane ^ 8
+        acc[G][i] = v;
+      }
+    // levels 3, 4 (b ^ 4, b ^ 8: the wave's rows R = lane >> 4) as a reduce-scatter: row R ends with the sums of group R
+    const bool odd = (grp & 1) != 0, hi = (grp & 2) != 0;
+    float fin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float keep = odd ? acc[2 * k + 1][i] : acc[2 * k][i], give = odd ? acc[2 * k][i] : acc[2 * k + 1][i];
+        t[k] = keep + __shfl_xor(give, 16, 64);
+      }
+      const float keep = hi ? t[1] : t[0], give = hi ? t[0] : t[1];
+      fin[i] = keep + __shfl_xor(give, 32, 64);
+    }
+    // lane (R, r, j): row r of group R against query term j
+    const int r = (lane >> 2) & 3, e = bt * 16 + grp * 4 + r;
+    const float dot = r == 0 ? fin[0] : r == 1 ? fin[1] : r == 2 ? fin[2] : fin[3];
+    const float dden = dens[wave][grp * 4 + r];
+    const float sdiv = dot / (qden * dden);
+    const float sm = qid > 0 ? sdiv : 0.f;
+    if (e < total && j < kQT) {
+      const int id = id0 + lst[e];
+      if (BINS) {
+        const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
+        tabb[(int64_t)id * 4 + j] = (uint8_t)bin;
+      } else {
+        tab[(int64_t)id * 4 + j] = sm;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (dens is rewritten by the next batch)
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) rr[G][c] = nx[G][c];
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------------
-constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 4 * kMaxK * sizeof(float);
+constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 6 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
@@ -272,8 +464,8 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl), dim3(128), 0, s, a, g);                                  \
   lists_stamp(s);                                                                                               \
-  if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true>), sg, dim3(256), 0, s, a, g);                      \
-  else hipLaunchKernelGGL((lists_sims_kernel<NV, false>), sg, dim3(256), 0, s, a, g)
+  if (edges) hipLaunchKernelGGL((CAPAMD_SIMS_KERNEL<NV, true>), sg, dim3(256), 0, s, a, g);                     \
+  else hipLaunchKernelGGL((CAPAMD_SIMS_KERNEL<NV, false>), sg, dim3(256), 0, s, a, g)
     switch (nv_for_dim(D)) {
       case 1: CAPAMD_SIMS(1); break;
       case 2: CAPAMD_SIMS(2); break;

@@ -140,11 +140,11 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
   int64_t qid = t < a.Q ? qids.q(t) : 0;
   if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
-  float mu[KK], ck[KK];
+  float ka[KK], kb[KK];      // K_k(s) = 2^-(ka s + kb)^2
 #pragma unroll
   for (int k = 0; k < KK; ++k) {
-    mu[k] = a.kn_consts[k];
-    ck[k] = a.kn_consts[kMaxK + k];
+    ka[k] = a.kn_consts[4 * kMaxK + k];
+    kb[k] = a.kn_consts[5 * kMaxK + k];
   }
   float acc[KK], rs = 0.f;
   int n_one = 0, n_real = 0;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
         // (the kernels in pairs on packed fp32 - v_pk_add / v_pk_mul, 36 instructions per trip for 60 - measure the same: 358 us for 352)
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
-          const float adj = s[u] - mu[k];
-          acc[k] += __builtin_amdgcn_exp2f(adj * adj * ck[k]);
+          const float tk = __builtin_fmaf(s[u], ka[k], kb[k]);
+          acc[k] += __builtin_amdgcn_exp2f(-tk * tk);
         }
       } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
         ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)

@@ -77,15 +77,36 @@ class Reranker:
     def _saved_keys(state_dict):
         return {k: v for k, v in state_dict.items() if "embedding.weight" not in k and "_nosave_" not in k}
 
+    @staticmethod
+    def _portable_optimizer_state(optimizer):
+        """The optimizer's state_dict as the reference's plain Adam would have written it: a graphed training step runs
+        Adam(capturable=True, lr=<device scalar>) (PytorchTrainer `graph`), whose state_dict would otherwise carry a CUDA `lr` tensor,
+        `capturable = True` and device-side step counters - a checkpoint the reference (or an eager run here) could not resume from."""
+        import torch
+
+        sd = optimizer.state_dict()
+        groups = []
+        for g in sd["param_groups"]:
+            g = dict(g)
+            if torch.is_tensor(g.get("lr")):
+                g["lr"] = float(g["lr"])
+            if g.get("capturable"):
+                g["capturable"] = False
+            groups.append(g)
+        state = {k: {n: (v.detach().cpu() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()}
+        return {"state": state, "param_groups": groups}
+
     def save_weights(self, weights_fn, optimizer):
         weights_fn = os.fspath(weights_fn)
         os.makedirs(os.path.dirname(weights_fn) or ".", exist_ok=True)
         with open(weights_fn, "wb") as outf:
             pickle.dump(self._saved_keys(self.model.state_dict()), outf, protocol=-1)
         with open(weights_fn + ".optimizer", "wb") as outf:
-            pickle.dump(optimizer.state_dict(), outf, protocol=-1)
+            pickle.dump(self._portable_optimizer_state(optimizer), outf, protocol=-1)
 
     def load_weights(self, weights_fn, optimizer):
+        import torch
+
         weights_fn = os.fspath(weights_fn)
         with open(weights_fn, "rb") as f:
             d = pickle.load(f)
@@ -94,8 +115,20 @@ class Reranker:
         if missing:
             raise RuntimeError("loading state_dict with keys that do not match current model: %s" % missing)
         self.model.load_state_dict(d, strict=False)
+        # what kind of Adam the caller runs (a captured training step needs capturable = True and a device scalar as the learning rate)
+        # survives the load: the checkpoint is the plain kind whoever wrote it
+        kinds = [(bool(g.get("capturable")), g["lr"].device if torch.is_tensor(g.get("lr")) else None) for g in optimizer.param_groups]
         with open(weights_fn + ".optimizer", "rb") as f:
             optimizer.load_state_dict(pickle.load(f))
+        for g, (capturable, lr_dev) in zip(optimizer.param_groups, kinds):
+            if lr_dev is not None and not torch.is_tensor(g["lr"]):
+                g["lr"] = torch.tensor(float(g["lr"]), device=lr_dev)
+            if capturable:
+                g["capturable"] = True
+                for p in g["params"]:
+                    st = optimizer.state.get(p)
+                    if st and "step" in st:
+                        st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(p.device)
 
 
 from .KNRM import KNRM, KNRM_class  # noqa: E402,F401

@@ -98,13 +98,14 @@ class PytorchTrainer:
         # distinct query / document id rows as int32 tables (capreolus_amd.feeder.CandidateStore); that call and every later one on the
         # same sampler (the dev set after every training iteration, RerankTask's repeated predict) score it by index pairs without
         # touching the host per sample (SURVEY.md row N1 through the reference's own call site, trainer/pytorch.py:310-353).
-        "resident": True,
+        "resident": True, "resident_verify": "sampled",
         # `lists`: which rerankers the resident route scores as whole candidate lists (csrc/lists.hip: every distinct term of a LIST
-        # gathered once).  "exact" (default): those whose list scores equal their per-pair scores bit for bit (DRMM: integer counts of
-        # bit-identical similarities), so that `predict` returns the same dict by either route; "always": also KNRM, whose pooling sums
-        # then run in another order (1e-6 relative: an fp16-rounded prediction can land on the other side of a rounding boundary);
-        # "never": per-pair kernels only.
-        "lists": "exact",
+        # gathered once).  "always" (default): every reranker that takes lists - KNRM, DRMM, DRMM-TKS, PACRR; this is the route
+        # `bench.py` times.  DRMM / DRMM-TKS / PACRR list scores equal their per-pair scores bit for bit; KNRM's pooling sums run in
+        # another order (1e-6 relative) - BOTH of its routes are pinned on the reference's fp16 predictions and run order over a
+        # multi-query run (tests/golden/knrm_multiquery.npz).  "exact": only the bit-identical ones (KNRM pair by pair); "never": per-pair
+        # kernels only.
+        "lists": "always",
         # `graph` (default on): a training step - score() on positives and negatives, loss, backward, Adam - is captured ONCE as a HIP
         # graph and replayed per batch (at batch 32 a step is ~40 launches of microsecond kernels, i.e. host time).
         # Needs a GPU, gradacc = 1 and no loss scaling (amp = train / both); anything else, and batches of another shape, run eagerly.
@@ -144,6 +145,8 @@ class PytorchTrainer:
             raise ValueError("amp must be one of: None, train, pred, both")
         if c["decaytype"] not in (None, "exponential", "linear"):
             raise ValueError("decaytype must be one of: None, exponential, linear")
+        if c["resident_verify"] not in ("sampled", "full"):
+            raise ValueError("resident_verify must be one of: sampled, full")
         if c["lists"] not in ("exact", "always", "never"):
             raise ValueError("lists must be one of: exact, always, never")
         torch.manual_seed(c["seed"])
@@ -212,21 +215,28 @@ class PytorchTrainer:
 
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), engine.deferred_status(self.device):
-            for _ in range(2):
-                self.optimizer.zero_grad(set_to_none=True)
-                step()
-        cur.wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        with torch.no_grad():
-            for p, sp in zip(params, snap_p):
-                p.copy_(sp)
-            for p in params:
-                for k, v in self.optimizer.state[p].items():
-                    if torch.is_tensor(v):
-                        old = snap_s[p].get(k)
-                        v.copy_(old) if old is not None else v.zero_()
+        rng = torch.cuda.get_rng_state(self.device)
+        try:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), engine.deferred_status(self.device):
+                for _ in range(2):
+                    self.optimizer.zero_grad(set_to_none=True)
+                    step()
+            cur.wait_stream(side)
+        finally:
+            # whatever the warm-up did - or failed half-way through (the caller then trains eagerly) - training continues from where it
+            # stood: parameters, Adam state and the device RNG (dropout) are put back
+            torch.cuda.synchronize(self.device)
+            with torch.no_grad():
+                for p, sp in zip(params, snap_p):
+                    p.copy_(sp)
+                for p in params:
+                    for k, v in self.optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            old = snap_s[p].get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+            torch.cuda.set_rng_state(rng, self.device)
+            self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         with engine.deferred_status(self.device), torch.cuda.graph(graph):
@@ -274,13 +284,18 @@ class PytorchTrainer:
         return self._train_batches(reranker, train_dataloader, n_batch_per_iter, cur_step, False)
 
     def _train_batches(self, reranker, train_dataloader, n_batch_per_iter, cur_step, graphed):
-        losses, since_update = [], 0
+        losses, since_update, replayed = [], 0, False
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
             done = self._graphed_step(reranker, batch) if graphed else None
             if done is not None:
                 losses.append(done)
+                replayed = True
             else:
+                if graphed and since_update == 0:
+                    # a batch the graph cannot take (another shape): after a replay every p.grad IS the graph's static gradient tensor,
+                    # still holding the previous step's values - backward() would add to them
+                    self.optimizer.zero_grad(set_to_none=True)
                 with self._train_autocast():
                     loss = self.loss(reranker.score(batch))
                 losses.append(loss.detach())
@@ -298,7 +313,17 @@ class PytorchTrainer:
                 break
             self._set_lr(cur_step)
             cur_step += 1
+        if replayed:
+            self._mark_parameters_changed()
         return torch.stack(losses).mean()
+
+    def _mark_parameters_changed(self):
+        """A graph replay updates the parameters behind autograd's back: `tensor._version` - what the engine's weight-derived caches
+        (PackedEmbedding, ConvKNRM's projection tables, the BERT blob) are keyed on - does not move.  An exact in-place no-op (x * 1)
+        on every trained parameter bumps it, so that the next predict() rebuilds what was derived from the old weights."""
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        with torch.no_grad():
+            torch._foreach_mul_(params, 1.0)
 
     @staticmethod
     def _early_stopping_paths(train_output_path, dev_output_path):
@@ -417,17 +442,25 @@ class PytorchTrainer:
         return {k: pad(v) for k, v in batch.items()}
 
     # ---- the resident route of `predict` ---------------------------------------------------------------------------------------
-    @staticmethod
-    def _sampler_fingerprint(pred_data):
-        """What identifies a prediction sampler's content cheaply: per query its id, the number of candidates and the first / last
-        docid (None for samplers without `qid_to_docids`, which take the DataLoader route)."""
+    def _sampler_fingerprint(self, pred_data):
+        """What identifies a prediction sampler's content: per query its id and candidate count plus - `resident_verify` = "sampled", the
+        default - the docid list object and eight evenly spaced docids of it, or - "full" - every docid (64,000 docids hash in ~3 ms, more
+        than the scoring takes).  None for samplers without `qid_to_docids`, which take the DataLoader route.  A list edited in place
+        between the sampled positions is the one change "sampled" cannot see: call `forget_candidate_stores()` (or use "full") then."""
         q2d = getattr(pred_data, "qid_to_docids", None)
         if not isinstance(q2d, dict) or not q2d:
             return None
         try:
-            return (len(q2d), hash(tuple((q, len(d), d[0], d[-1]) if len(d) else (q, 0) for q, d in q2d.items())))
+            if self.config["resident_verify"] == "full":
+                return (len(q2d), hash(tuple((q, tuple(d)) for q, d in q2d.items())))
+            return (len(q2d), hash(tuple((q, len(d), id(d)) + tuple(d[:: max(1, (len(d) - 1) // 7)]) + (d[-1],) if len(d) else (q, 0) for q, d in q2d.items())))
         except TypeError:
             return None
+
+    def forget_candidate_stores(self):
+        """Drops the device-resident candidate stores `predict` built (the next call on a sampler tokenises and uploads it again)."""
+        self.__dict__.pop("_resident_plans", None)
+        self.__dict__.pop("_eval_plan", None)
 
     def _resident_plan(self, pred_data, part, rank, world):
         """(store, pair_q, pair_d, groups) for this rank's part of `pred_data`, built on the first call for a sampler and kept for

@@ -6,6 +6,6 @@ src=$1; name=$2; shift 2
 C=capreolus_amd/csrc
 mkdir -p $C/ablate
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Iinclude -I$C "$@" $C/$src.hip -o $C/ablate/${src}_$name.o
-objs=$(ls $C/*.o | grep -v "/$src.o")
+objs=$(ls $C/*.o | grep -v "/$src.o" | grep -v "\.prof\.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $C/ablate/libcapreolus_amd_$name.so $C/ablate/${src}_$name.o $objs
 echo built $C/ablate/libcapreolus_amd_$name.so

@@ -61,7 +61,7 @@ def _edge_cases(rs, batch, vocab):
     return batch
 
 
-def gen_knrm(KNRM):
+def gen_knrm(KNRM, only=None):
     cases = {
         # name: (V, D, B, Q, L, config, seeds, perturb kernels?)
         "default": dict(V=5000, D=300, B=24, Q=4, L=800, cfg=dict(singlefc=True, scoretanh=False), pert=False),
@@ -69,14 +69,30 @@ def gen_knrm(KNRM):
         "glove50_short": dict(V=800, D=50, B=16, Q=3, L=100, cfg=dict(singlefc=True, scoretanh=True), pert=True),
         "dim100_q8": dict(V=1200, D=100, B=10, Q=8, L=230, cfg=dict(singlefc=False, scoretanh=False), pert=False),
         "ranklist": dict(V=20000, D=300, B=200, Q=4, L=800, cfg=dict(singlefc=True, scoretanh=False), pert=True, same_query=True),
+        # what `predict` scores: several queries' candidate lists in one run (8 queries x 150 candidates; one query with an OOV term that
+        # some of its candidates contain, one padded to a single term) - the fixture both scoring routes (per pair, whole lists) are
+        # pinned on: the reference's fp16 scores and run order per query
+        "multiquery": dict(V=20000, D=300, B=1200, Q=4, L=800, cfg=dict(singlefc=True, scoretanh=False), pert=True, same_query=True, lists=8),
     }
     for name, c in cases.items():
+        if only and name not in only:
+            continue
         seed = 100 + len(name)
         rs = np.random.RandomState(seed)
         emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
         same = c.get("same_query", False)
-        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same,
-                                              oov_range=40, query_oov_frac=0.0 if same else 0.1)
+        n_lists = c.get("lists", 1)
+        if n_lists > 1:
+            per = c["B"] // n_lists
+            parts = [synthetic.make_candidate_list(rs, per, c["V"], c["Q"], c["L"], same_query=True, oov_range=40, query_oov_frac=0.0) for _ in range(n_lists)]
+            parts[2]["query"][:, 1] = -11                       # an OOV query term ...
+            parts[2]["posdoc"][::7, 13] = -11                   # ... that every seventh candidate of that list contains (exact match, common.py:155-158)
+            parts[5]["query"][:, 1:] = 0                        # a one-term query
+            parts[5]["query_idf"][:, 1:] = 0
+            batch = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        else:
+            batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same,
+                                                  oov_range=40, query_oov_frac=0.0 if same else 0.1)
         if not same:
             batch = _edge_cases(rs, batch, c["V"])
         cfg = dict(gradkernels=True, finetune=False, **c["cfg"])
@@ -99,6 +115,8 @@ def gen_knrm(KNRM):
             query_idf=batch["query_idf"], ref_scores=scores.astype(np.float32),
             ref_scores_f16=scores.astype(np.float16), ref_sim_rowsum=sim.sum(axis=2).astype(np.float32),
         )
+        if n_lists > 1:
+            out["list_offsets"] = np.arange(0, c["B"] + 1, c["B"] // n_lists, dtype=np.int64)
         for k, v in sd.items():
             out["sd." + k] = v
         np.savez_compressed(os.path.join(HERE, f"knrm_{name}.npz"), **out)
@@ -312,8 +330,8 @@ if __name__ == "__main__":
         gen_convknrm(CONVKNRM)
     if "pacrr" in which:
         gen_pacrr(PACRR)
-    if "knrm" in which:
-        gen_knrm(KNRM)
+    if "knrm" in which or any(w.startswith("knrm:") for w in which):     # "knrm:multiquery" = only that case
+        gen_knrm(KNRM, only={w[5:] for w in which if w.startswith("knrm:")} or None)
     if "drmm" in which:
         gen_drmm(DRMM)
     if "drmmtks" in which:

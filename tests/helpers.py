@@ -7,7 +7,7 @@ from capreolus_amd import synthetic
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist"]
+KNRM_CASES = ["default", "twolayer_tanh", "glove50_short", "dim100_q8", "ranklist", "multiquery"]
 DRMM_CASES = ["default", "zero_idf", "tv_nh", "ch", "ranklist"]
 DRMMTKS_CASES = ["default", "top3_short", "ranklist"]
 CONVKNRM_CASES = ["default", "nocross_2fc_short", "ranklist"]

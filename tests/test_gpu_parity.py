@@ -95,6 +95,31 @@ def test_knrm_rank_order():
     assert np.array_equal(rank_order(got), rank_order(c["ref_scores_f16"]))
 
 
+@pytest.mark.parametrize("route", ["per_pair", "lists"])
+def test_knrm_multiquery_run_matches_the_reference_by_either_route(route):
+    """What `predict` scores - several queries' candidate lists in one run (8 x 150, one query with an OOV term some candidates contain,
+    one of a single term) - against the REFERENCE's scores: both scoring routes of this engine, the per-pair kernels and the whole-list
+    route (csrc/lists.hip, the trainer's default), reproduce the reference's fp16 predictions (`score.astype(np.float16)`,
+    trainer/pytorch.py:346-348) and with them every query's run order.  A prediction may differ only where the reference's own fp32 score
+    sits within 2e-6 (relative) of an fp16 rounding boundary - the closest one in this fixture is 5.2e-7 away - and then by one fp16 ulp."""
+    c = load_case("knrm", "multiquery")
+    r = _knrm_model(c)
+    off = c["list_offsets"]
+    with torch.no_grad():
+        got = (r.test(_batch(c)) if route == "per_pair" else r.test_lists(_batch(c), off)).cpu().numpy()
+    assert rel_err(got, c["ref_scores"]).max() <= 2e-5
+    g16, r16 = got.astype(np.float16), c["ref_scores_f16"]
+    bad = np.nonzero(g16 != r16)[0]
+    ref = c["ref_scores"].astype(np.float64)
+    for i in bad:        # only a reference score ON a rounding boundary (to 2e-6) may land on its other side
+        mid = (g16[i].astype(np.float64) + r16[i].astype(np.float64)) / 2
+        assert abs(ref[i] - mid) <= 2e-6 * abs(ref[i]) and abs(g16[i].view(np.int16).astype(int) - r16[i].view(np.int16).astype(int)) == 1, (i, got[i], ref[i])
+    assert len(bad) <= 2, bad
+    for a, b in zip(off[:-1], off[1:]):
+        if not np.isin(bad, np.arange(a, b)).any():
+            assert np.array_equal(rank_order(g16[a:b]), rank_order(r16[a:b]))
+
+
 def test_knrm_score_pair_interface():
     c = load_case("knrm", "default")
     r = _knrm_model(c)
@@ -1485,6 +1510,106 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
     assert moved > 1e-3          # the five steps did train something
 
 
+def _graph_trainer(r, B, n_batches, graph):
+    import contextlib
+
+    from capreolus_amd.trainer import PytorchTrainer
+
+    t = PytorchTrainer({"batch": B, "itersize": n_batches * B, "lr": 0.01, "graph": graph})
+    t.device, t.scaler, t._train_autocast, t.loss = torch.device(DEV), None, contextlib.nullcontext, t.pair_hinge_loss
+    t._train_graph, t._graph_failed = None, False
+    t.optimizer = torch.optim.Adam([p for p in r.model.parameters() if p.requires_grad], lr=torch.tensor(0.01, device=DEV), capturable=True)
+    t._set_lr(0)
+    return t
+
+
+def test_predict_after_graphed_iterations_uses_the_trained_weights():
+    """A graph replay updates the parameters without moving `tensor._version`, which is what ConvKNRM's folded projection tables (and
+    every other weight-derived cache of the engine) are keyed on: after graphed iterations `test()` must score with the CURRENT
+    convolutions - equal to a freshly built model loaded with the same weights - not with tables folded before the training."""
+    c = load_case("convknrm", "nocross_2fc_short")
+    B = c["query"].shape[0]
+    rs = np.random.RandomState(9)
+    batch = lambda: {"qid": [str(i) for i in range(B)], "query": torch.as_tensor(c["query"]), "query_idf": torch.as_tensor(c["query_idf"]),  # noqa: E731
+                     "posdoc": torch.as_tensor(c["posdoc"]), "negdoc": torch.as_tensor(c["posdoc"][rs.permutation(B)])}
+    r = _convknrm_reranker(c)
+    d = _batch(c)
+    r.model.eval()
+    with torch.no_grad():
+        before = r.test(d).clone()           # folds the projection tables from the initial weights
+    t = _graph_trainer(r, B, 3, True)
+    for it in (1, 2):
+        r.model.train()
+        t.single_train_iteration(r, [batch() for _ in range(3)], cur_iter=it)
+        assert t._train_graph is not None
+        r.model.eval()
+        with torch.no_grad():
+            got = r.test(d).clone()
+        fresh = _convknrm_reranker(c)
+        fresh.model.load_state_dict({k: v for k, v in r.model.state_dict().items() if "embedding" not in k}, strict=False)
+        fresh.model.eval()
+        with torch.no_grad():
+            want = fresh.test(d)
+        assert torch.equal(got, want), float((got - want).abs().max())
+        assert float((got - before).abs().max()) > 1e-4          # ... and the training did move the scores
+
+
+@pytest.mark.parametrize("kind,name,build", [("knrm", "twolayer_tanh", _knrm_model), ("drmm", "zero_idf", _drmm_model)], ids=["knrm", "drmm"])
+def test_short_batch_after_graph_replays_takes_a_clean_eager_step(kind, name, build):
+    """A batch of another shape (the short last batch) runs eagerly between replays: its backward must not add to the graph's static
+    gradient tensors, which still hold the previous replay's gradients - full, full, short, full equals the same four eager steps."""
+    c = load_case(kind, name)
+    B = c["query"].shape[0]
+    rs = np.random.RandomState(6)
+
+    def mk(n):
+        perm = rs.permutation(B)[:n]
+        return {"qid": [str(i) for i in range(n)], "query": torch.as_tensor(c["query"][:n]), "query_idf": torch.as_tensor(c["query_idf"][:n]),
+                "posdoc": torch.as_tensor(c["posdoc"][:n]), "negdoc": torch.as_tensor(c["posdoc"][perm])}
+
+    batches = [mk(B), mk(B), mk(max(2, B // 2)), mk(B)]
+    out = {}
+    for graph in (False, True):
+        r = build(c)
+        r.model.train()
+        t = _graph_trainer(r, B, len(batches), graph)
+        t.single_train_iteration(r, batches, cur_iter=1)
+        assert (t._train_graph is not None) == graph
+        out[graph] = {k: v.detach().cpu().clone() for k, v in r.model.named_parameters() if v.requires_grad}
+    for k, v in out[False].items():
+        scale = float(v.abs().max()) + 1e-6
+        assert float((out[True][k] - v).abs().max()) <= 2e-4 * scale, (k, float((out[True][k] - v).abs().max()), scale)
+
+
+def test_optimizer_checkpoint_is_the_plain_kind_and_resumes_a_graphed_run(tmp_path):
+    """`save_weights` writes the optimizer state as the reference's plain Adam would (float lr, capturable off, host step counters) even
+    when the run trains through the captured step; `load_weights` puts it back into whichever Adam the caller runs."""
+    c = load_case("knrm", "twolayer_tanh")
+    r = _knrm_model(c)
+    params = [p for p in r.model.parameters() if p.requires_grad]
+    cap = torch.optim.Adam(params, lr=torch.tensor(0.01, device=DEV), capturable=True)
+    loss = sum(p.sum() for p in params)
+    loss.backward()
+    cap.step()
+    fn = tmp_path / "w.p"
+    r.save_weights(fn, cap)
+    import pickle
+
+    sd = pickle.load(open(str(fn) + ".optimizer", "rb"))
+    assert all(isinstance(g["lr"], float) and not g.get("capturable") for g in sd["param_groups"])
+    assert all(st["step"].device.type == "cpu" for st in sd["state"].values())
+    plain = torch.optim.Adam(params, lr=0.5)
+    r.load_weights(fn, plain)                       # an eager run (or the reference) resumes from it
+    assert plain.param_groups[0]["lr"] == pytest.approx(0.01) and not plain.param_groups[0]["capturable"]
+    cap2 = torch.optim.Adam(params, lr=torch.tensor(0.5, device=DEV), capturable=True)
+    r.load_weights(fn, cap2)                        # ... and so does a graphed one: still capturable, device lr and step
+    g = cap2.param_groups[0]
+    assert g["capturable"] and torch.is_tensor(g["lr"]) and g["lr"].is_cuda and float(g["lr"]) == pytest.approx(0.01)
+    assert all(st["step"].is_cuda and float(st["step"]) == 1.0 for st in cap2.state.values())
+    for p in params:
+        assert torch.equal(cap2.state[p]["exp_avg"], cap.state[p]["exp_avg"])
+
+
 @pytest.mark.parametrize("name", ["default", "nocross_2fc_short"])
 def test_convknrm_hip_kernel_pooling_matches_autograd_through_aten(name):
     """ConvKNRM's training step behind its convolutions - cosine of every n-gram view pair, pad masks, RBF kernel pooling, log / mask /
@@ -1806,8 +1931,8 @@ def test_lists_random_geometries(D, Q, L, V, docs):
 
 @pytest.mark.parametrize("model", ["knrm", "drmm"])
 def test_predict_scores_whole_lists_where_the_reranker_can(model, monkeypatch):
-    """`PytorchTrainer.predict` on its resident route hands whole candidate lists to the rerankers whose list scores equal their per-pair
-    scores bit for bit (DRMM; `lists` = "exact", the default) or to every reranker that takes lists (`lists` = "always": KNRM too): same
+    """`PytorchTrainer.predict` on its resident route hands whole candidate lists to every reranker that takes them (`lists` = "always", the
+    default) or only to those whose list scores equal their per-pair scores bit for bit (`lists` = "exact": DRMM, not KNRM): same
     predictions as the DataLoader route on the reference's 200-candidate ranking list."""
     from capreolus_amd.trainer import PytorchTrainer
 
@@ -1835,9 +1960,9 @@ def test_predict_scores_whole_lists_where_the_reranker_can(model, monkeypatch):
     monkeypatch.setattr(type(r), "test_resident_lists", lambda self, *a: calls.append(1) or real(self, *a))
     s = Sampler()
     want = PytorchTrainer({"batch": 32, "resident": False}).predict(r, s)
-    got = PytorchTrainer({"batch": 32}).predict(r, s)
+    got = PytorchTrainer({"batch": 32, "lists": "exact"}).predict(r, s)
     assert got == want and len(calls) == (1 if model == "drmm" else 0)       # "exact": DRMM as lists, KNRM through the per-pair kernel
-    got = PytorchTrainer({"batch": 32, "lists": "always"}).predict(r, s)
+    got = PytorchTrainer({"batch": 32}).predict(r, s)                        # the default: "always"
     assert len(calls) == (2 if model == "drmm" else 1)
     assert got == want       # (KNRM: equal on this list - its scores sit >= 6.9e-6 from an fp16 rounding boundary - not by construction)
     assert PytorchTrainer({"batch": 32, "lists": "never"}).predict(r, s) == want and len(calls) == (2 if model == "drmm" else 1)
