@@ -317,9 +317,13 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
   uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
   // batches of 16 rows (four groups of four), dealt to the waves round robin; no barrier from here on: every wave has its own stage
   const int nb = (total + 15) >> 4;
+#ifndef CAPAMD_SIMS_ABL
+#define CAPAMD_SIMS_ABL 0      // profiling builds: 1 = every row load hits one of 16 rows, 2 = no MFMAs, 4 = no cross-lane reductions
+#endif
   auto row_id = [&](int batch, int G) {       // the table row this lane's 16-lane group fetches for group G of a batch (the tail repeats the last row)
     const int e = batch * 16 + G * 4 + grp;
-    return id0 + lst[e < total ? e : total - 1];
+    const int id = id0 + lst[e < total ? e : total - 1];
+    return (CAPAMD_SIMS_ABL & 1) ? 1 + (id & 15) : id;
   };
   // (native vectors, not float4 structs: a struct copied whole from memory to LDS stays a memcpy through a stack slot)
   auto fetch = [&](int id, f32x4v (&r)[NV]) {
@@ -327,16 +331,14 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
 #pragma unroll
     for (int c = 0; c < NV; ++c) r[c] = p[c * 16];
   };
-  f32x4v rr[4][NV];
-  int bt = wave;
-  if (bt >= nb) return;                       // (no barrier below)
-#pragma unroll
-  for (int G = 0; G < 4; ++G) fetch(row_id(bt, G), rr[G]);
-  for (; bt < nb; bt += 4) {
+  // Two register sets in turn: a batch is computed from one while the wave's NEXT batch lands in the other (group by group, each right
+  // after the LDS store that frees its registers' counterpart).  Written as two calls of one body so that the sets are named registers
+  // (an array indexed by the batch's parity would live in scratch memory), and without a copy between them: a register move waits for its
+  // load, i.e. a copy at the end of a batch waits for the whole prefetch it has just issued.
+  auto batch = [&](f32x4v (&rr)[4][NV], f32x4v (&nx)[4][NV], const int bt) {
     const int next = bt + 4 < nb ? bt + 4 : bt;       // (the last batch is requested twice: a load under a condition makes its destination a merge
                                                       //  point, which hipcc resolves through scratch memory)
     f32x4v acc[4];
-    f32x4v nx[4][NV];
     // two groups at a time, one per stage buffer: their two accumulator chains alternate on the matrix pipe (an MFMA that waits for the
     // one before it - the chain of a single group - issues at about half the rate)
 #pragma unroll
@@ -348,13 +350,18 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
 #pragma unroll
         for (int c = 0; c < NV; ++c) st[c * 64 + 4 * pl + grp] = rr[G][c];
         if (pl == 15) dens[wave][G * 4 + grp] = rr[G][NV - 1].w;
-        fetch(row_id(next, G), nx[G]);                  // the same group of this wave's next batch (the registers just stored are free)
+        fetch(row_id(next, G), nx[G]);                  // the same group of this wave's next batch
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // (one wave: LDS program order is the synchronisation)
       f32x4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         const f32x4v a0 = stage[wave][0][c * 64 + lane], a1 = stage[wave][1][c * 64 + lane];
+        if (CAPAMD_SIMS_ABL & 2) {
+          d0 += a0;
+          d1 += a1;
+          continue;
+        }
         d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, qreg[c].x, d0, 0, 0, 0);
         d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, qreg[c].x, d1, 0, 0, 0);
         d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, qreg[c].y, d0, 0, 0, 0);
@@ -369,20 +376,26 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // levels 1, 2 of the tree (partials b ^ 1, b ^ 2: inside the 16-lane row): every lane of a row ends with the row's sum for its term
+    if (!(CAPAMD_SIMS_ABL & 4)) {
 #pragma unroll
-    for (int G = 0; G < 4; ++G)
+      for (int G = 0; G < 4; ++G)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = acc[G][i];
-        v += lane_xor4(v);
-        v += dpp_mov<0x128>(v);            // row_ror:8 = lane ^ 8
-        acc[G][i] = v;
-      }
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[G][i];
+          v += lane_xor4(v);
+          v += dpp_mov<0x128>(v);            // row_ror:8 = lane ^ 8
+          acc[G][i] = v;
+        }
+    }
     // levels 3, 4 (b ^ 4, b ^ 8: the wave's rows R = lane >> 4) as a reduce-scatter: row R ends with the sums of group R
     const bool odd = (grp & 1) != 0, hi = (grp & 2) != 0;
     float fin[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (CAPAMD_SIMS_ABL & 4) {
+        fin[i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        continue;
+      }
       float t[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -408,10 +421,19 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (dens is rewritten by the next batch)
+  };
+  f32x4v ra[4][NV], rb[4][NV];
+  int bt = wave;
+  if (bt >= nb) return;                       // (no barrier below)
 #pragma unroll
-    for (int G = 0; G < 4; ++G)
-#pragma unroll
-      for (int c = 0; c < NV; ++c) rr[G][c] = nx[G][c];
+  for (int G = 0; G < 4; ++G) fetch(row_id(bt, G), ra[G]);
+  for (;;) {
+    batch(ra, rb, bt);
+    bt += 4;
+    if (bt >= nb) break;
+    batch(rb, ra, bt);
+    bt += 4;
+    if (bt >= nb) break;
   }
 }
 

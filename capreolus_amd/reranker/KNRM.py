@@ -32,10 +32,16 @@ class _RbfBank(nn.Module):
         return len(self.kernels)
 
     def stacked(self):
-        """(mu[K], sigma[K]) as contiguous device vectors, re-read from the live parameters."""
-        mu = torch.stack([k.mu.detach() for k in self.kernels]).float()
-        sigma = torch.stack([k.sigma.detach() for k in self.kernels]).float()
-        return mu, sigma
+        """(mu[K], sigma[K]) as contiguous device vectors, re-read from the live parameters (one scalar nn.Parameter per kernel and
+        quantity, as the reference's state_dict names them: common.py:229-230) - kept until a parameter changes (storage or version
+        counter; PytorchTrainer bumps the counters after graph replays, which update parameters behind autograd's back)."""
+        key = tuple((p.data_ptr(), p._version) for k in self.kernels for p in (k.mu, k.sigma))
+        hit = self.__dict__.get("_stacked")
+        if hit is None or hit[0] != key or torch.is_grad_enabled():
+            mu = torch.stack([k.mu.detach() for k in self.kernels]).float()
+            sigma = torch.stack([k.sigma.detach() for k in self.kernels]).float()
+            hit = self.__dict__["_stacked"] = (key, mu, sigma)
+        return hit[1], hit[2]
 
 
 class KNRM_class(nn.Module):

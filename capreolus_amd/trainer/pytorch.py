@@ -501,8 +501,13 @@ class PytorchTrainer:
         store.finalize()
         import weakref
 
+        counts = [len(ds) for _, ds, _ in groups]
         plan = (store, torch.as_tensor(np.asarray(pq, dtype=np.int32)).to(self.device), torch.as_tensor(np.asarray(pd, dtype=np.int32)).to(self.device),
-                [(q, ds, lo) for q, ds, lo in groups])
+                [(q, tuple(ds), lo) for q, ds, lo in groups],
+                # what every later call would otherwise recompute: the lists' sizes and offsets, and whether every qid is ONE run of
+                # samples (then the predictions are one dict(zip(...)) per query)
+                {"counts": counts, "offsets": np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))]).astype(np.int64),
+                 "one_run_per_qid": len({q for q, _, _ in groups}) == len(groups)})
         try:
             ref = weakref.ref(pred_data)
         except TypeError:
@@ -512,7 +517,7 @@ class PytorchTrainer:
         plans[key] = (fp, ref, plan)
         return plan
 
-    def _score_store(self, reranker, store, pq, pd, counts, step):
+    def _score_store(self, reranker, store, pq, pd, counts, step, offsets=None):
         """Scores index pairs of a candidate store laid out query after query (`counts` documents each) -> fp32 [n].  Rerankers that
         take whole candidate lists get them as lists where the `lists` option allows (every distinct term of a LIST is gathered once:
         csrc/lists.hip); otherwise one launch per `step` pairs."""
@@ -521,7 +526,8 @@ class PytorchTrainer:
         with torch.no_grad():
             # (a single list keeps the per-pair kernels: its 1000 workgroups fill the chip better than one list's passes do)
             if as_lists and len(counts) >= 2 and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and n >= 8 * len(counts):
-                offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+                if offsets is None:
+                    offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
                 return reranker.test_resident_lists(store, pq, pd, offsets).float()
             chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]
         return torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
@@ -602,8 +608,12 @@ class PytorchTrainer:
             self.device = torch.device("cuda", torch.cuda.current_device())
         else:
             self.device = torch.device("cpu")
-        model = reranker.model.to(self.device)
-        model.eval()
+        model = reranker.model
+        first = next(model.parameters(), None)
+        if first is None or first.device != self.device:      # (nn.Module.to walks every parameter even when there is nothing to move)
+            model = model.to(self.device)
+        if model.training:
+            model.eval()
 
         part, offset, count, total = shard_pred_data(pred_data, rank, world)
         evalbatch = self.config["evalbatch"] if self.config["evalbatch"] > 0 else self.config["batch"]
@@ -613,17 +623,27 @@ class PytorchTrainer:
         if count > 0 and self.config["resident"] and self.device.type == "cuda" and getattr(reranker, "supports_resident", False):
             plan = self._resident_plan(pred_data, part, rank, world)
         if plan is not None:
-            store, pq, pd, groups = plan
+            from .. import engine
+
+            store, pq, pd, groups, extra = plan
             step = max(evalbatch, self.config["coalesce"])
             # (a run of one qid = one list; its query row is the same for every pair, checked when the plan was built)
-            chunks = [self._score_store(reranker, store, pq, pd, [len(docids) for _, docids, _ in groups], step)]
-            if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
-                vals = torch.cat(chunks).cpu().numpy().astype(np.float16).tolist()      # (trainer/pytorch.py:346-348)
+            # One synchronisation per call: the kernels' status word is read after the scores have come back (deferred_status), and the
+            # reference's `score.astype(np.float16)` (trainer/pytorch.py:346-348; round to nearest even) runs on the device, so that the
+            # copy is 2 bytes per pair and `tolist` is all the host still does per score.
+            with engine.deferred_status(self.device):
+                chunks = [self._score_store(reranker, store, pq, pd, extra["counts"], step, extra["offsets"])]
+                if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
+                    vals = chunks[0].to(torch.float16).cpu().numpy().tolist()
+            if not distributed:
                 if len(vals) != count:
                     raise RuntimeError(f"rank {rank} scored {len(vals)} pairs, expected {count}")
-                preds = {}
-                for qid, docids, lo in groups:
-                    preds.setdefault(qid, {}).update(zip(docids, vals[lo:lo + len(docids)]))
+                if extra["one_run_per_qid"]:
+                    preds = {qid: dict(zip(docids, vals[lo:lo + len(docids)])) for qid, docids, lo in groups}
+                else:
+                    preds = {}
+                    for qid, docids, lo in groups:
+                        preds.setdefault(qid, {}).update(zip(docids, vals[lo:lo + len(docids)]))
                 if pred_fn is not None:
                     os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
                     write_trec_run(preds, pred_fn)

@@ -73,8 +73,23 @@ def gen_drmm_alt(DRMM):
         # (c) the batch reversed
         s, c = _drmm_run(model, q.flip(0), d.flip(0), idf.flip(0))
         out["reversed_scores"], out["reversed_counts"] = s[::-1].copy(), c[::-1].copy()
+        # (d) round 4: more blockings - the batch in chunks of 2 / 4 / 8 / 32 pairs, 2 and 4 threads, denormals flushed
+        for bs in (2, 4, 8, 32):
+            ss, cc = zip(*[_drmm_run(model, q[i:i + bs], d[i:i + bs], idf[i:i + bs]) for i in range(0, q.shape[0], bs)])
+            out[f"batch{bs}_scores"], out[f"batch{bs}_counts"] = np.concatenate(ss), np.concatenate(cc)
+        for nt in (2, 4):
+            torch.set_num_threads(nt)
+            s, c = _drmm_run(model, q, d, idf)
+            out[f"threads{nt}_scores"], out[f"threads{nt}_counts"] = s, c
+        torch.set_num_threads(n_thr)
+        flushed = torch.set_flush_denormal(True)
+        s, c = _drmm_run(model, q, d, idf)
+        torch.set_flush_denormal(False)
+        if flushed:
+            out["flush_denormal_scores"], out["flush_denormal_counts"] = s, c
         # (tried and left out: oneDNN disabled - ATen's other bmm path gives the same bits as the base run on all four cases)
-        for k in ("one_thread", "batch1", "reversed"):
+        out["variants"] = np.array(sorted(k[:-7] for k in out if k.endswith("_scores")))
+        for k in out["variants"]:
             moved = (out[k + "_counts"] != base_c).any(axis=(1, 2))
             rel = np.abs(out[k + "_scores"] - base_s) / np.maximum(np.abs(base_s), 1e-6)
             print(f"drmm_{name}_alt {k:10s}: pairs with moved counts {int(moved.sum())} of {len(moved)}, counts moved "
