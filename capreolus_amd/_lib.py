@@ -19,7 +19,7 @@ OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
 LAUNCH_CONCURRENT = 1
 STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV, STATUS_SCORE_NAN, STATUS_TIE_RANGE = 1, 2, 4, 8, 16
 
-_vp, _i, _i64, _sz, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint
+_vp, _i, _i64, _sz, _u, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint, ctypes.c_float
 
 
 
@@ -43,7 +43,7 @@ SIGNATURES = {
     "capamd_pack_embeddings": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),
     "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u, _vp]),
-    "capamd_lists_workspace_bytes": (_sz, [_i, _i64]),
+    "capamd_lists_workspace_bytes": (_sz, [_i, _i64, _i64, _i]),
     "capamd_knrm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "capamd_drmm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -59,6 +59,8 @@ SIGNATURES = {
     "capamd_convknrm_pack_tables": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "capamd_convknrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "capamd_knrm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "capamd_knrm_train_step_workspace_floats": (_sz, [_i, _i]),
+    "capamd_knrm_train_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _sz, _vp, _vp]),
     "capamd_drmm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward_indexed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u,
                                          _vp]),

@@ -516,6 +516,133 @@ extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, 
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
+// ---- one KNRM training step without a host round trip (reference trainer/pytorch.py:93-108) -----------------------
+// score() on the positive and the negative documents -> pairwise hinge (reranker/common.py:101-103) or softmax (:96-98) loss -> backward
+// through `combine` (a single Linear, KNRM.py:27-34, optionally under tanh) and the RBF kernels' mu / sigma -> torch.optim.Adam's update
+// (no weight decay, no amsgrad; bias corrections computed by the caller in double, as the plain Adam of the reference does), all on the
+// device: the two feature launches above (values + d f / d mu, d f / d sigma per document), a gather of the 2 K scalar parameters, and ONE
+// workgroup for everything that is per batch.  Parameters and Adam moments are updated IN PLACE through a table of device pointers
+// (the reference's state_dict names one scalar nn.Parameter per kernel and quantity, common.py:229-230):
+//   ptrs[0 .. P)  the parameters, [P .. 2 P) their exp_avg, [2 P .. 3 P) their exp_avg_sq;  P = 2 K + 2:  mu_0 .. mu_{K-1}, sigma_0 .. sigma_{K-1},
+//   the Linear's weight [K], its bias [1]
+constexpr int kMaxStepBatch = 1024;
+
+struct KnrmStepArgs {
+  const float* f[2];      // [B, K] features of the positive / negative documents
+  const float* dmu[2];    // [B, K] d f_k / d mu_k
+  const float* dsg[2];    // [B, K] d f_k / d sigma_k
+  int B, K;
+  float* const* ptrs;
+  int train_kernels, scoretanh, loss_type;
+  float step_size, one_minus_beta1, beta2, eps, bc2_sqrt;
+  float* loss_out;
+};
+
+__global__ void knrm_stack_kernel(float* const* ptrs, int K, float* mu, float* sigma) {
+  const int t = threadIdx.x;
+  if (t < K) {
+    mu[t] = *ptrs[t];
+    sigma[t] = *ptrs[K + t];
+  }
+}
+
+__global__ __launch_bounds__(256) void knrm_step_kernel(KnrmStepArgs a) {
+  __shared__ float W[kMaxK + 4], gsc[2][kMaxStepBatch], lsum[kMaxStepBatch];
+  const int tid = threadIdx.x, K = a.K, P = 2 * K + 2;
+  if (tid < K) W[tid] = a.ptrs[2 * K][tid];
+  if (tid == K) W[K] = a.ptrs[2 * K + 1][0];
+  __syncthreads();
+  const float inv_b = 1.f / (float)a.B;
+  for (int i = tid; i < a.B; i += 256) {
+    float sc[2], dt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v = W[K];
+      for (int k = 0; k < K; ++k) v = __builtin_fmaf(W[k], a.f[h][(int64_t)i * K + k], v);     // (the scoring kernels' order)
+      dt[h] = 1.f;
+      if (a.scoretanh) {
+        v = tanhf(v);
+        dt[h] = 1.f - v * v;
+      }
+      sc[h] = v;
+    }
+    float li, gp, gn;      // loss of the pair, d loss / d score of its positive / negative document
+    if (a.loss_type == 0) {
+      const float mrg = 1.f - (sc[0] - sc[1]);
+      li = fmaxf(mrg, 0.f);
+      const float on = mrg >= 0.f ? inv_b : 0.f;      // (torch.clamp's backward passes the gradient at the boundary)
+      gp = -on;
+      gn = on;
+    } else {
+      const float mx = fmaxf(sc[0], sc[1]), e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx), p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+      li = 1.f - p0;
+      gp = -p0 * p1 * inv_b;
+      gn = p0 * p1 * inv_b;
+    }
+    gsc[0][i] = gp * dt[0];
+    gsc[1][i] = gn * dt[1];
+    lsum[i] = li;
+  }
+  __syncthreads();
+  // one thread per parameter element (and one for the loss): its gradient summed over the batch in pair order, then Adam's update
+  const int j = tid;
+  if (j > 3 * K + 1) return;
+  if (j == 3 * K + 1) {
+    float l = 0.f;
+    for (int i = 0; i < a.B; ++i) l += lsum[i];
+    a.loss_out[0] = l * inv_b;
+    return;
+  }
+  if (j < 2 * K && !a.train_kernels) return;
+  float g = 0.f;
+  if (j < 2 * K) {
+    const int k = j < K ? j : j - K;
+    const float* const* d = j < K ? a.dmu : a.dsg;
+    for (int i = 0; i < a.B; ++i) g += gsc[0][i] * d[0][(int64_t)i * K + k] + gsc[1][i] * d[1][(int64_t)i * K + k];
+    g *= W[k];
+  } else if (j < 3 * K) {
+    const int k = j - 2 * K;
+    for (int i = 0; i < a.B; ++i) g += gsc[0][i] * a.f[0][(int64_t)i * K + k] + gsc[1][i] * a.f[1][(int64_t)i * K + k];
+  } else {
+    for (int i = 0; i < a.B; ++i) g += gsc[0][i] + gsc[1][i];
+  }
+  const int slot = j < 2 * K ? j : (j < 3 * K ? 2 * K : 2 * K + 1), el = (j >= 2 * K && j < 3 * K) ? j - 2 * K : 0;
+  float* pp = a.ptrs[slot] + el;
+  float* pm = a.ptrs[P + slot] + el;
+  float* pv = a.ptrs[2 * P + slot] + el;
+  float m = *pm, v = *pv;
+  m = m + (g - m) * a.one_minus_beta1;                       // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.beta2 + (1.f - a.beta2) * (g * g);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+  *pm = m;
+  *pv = v;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  *pp = *pp - a.step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+}
+
+extern "C" size_t capamd_knrm_train_step_workspace_floats(int B, int K) { return B > 0 && K > 0 ? (size_t)32 + (size_t)6 * B * K : 0; }
+
+extern "C" int capamd_knrm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, int B, int Q, int L, const float* packed,
+                                      int64_t V, int D, int K, float* const* ptrs, int train_kernels, int scoretanh, int loss_type, float step_size,
+                                      float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace,
+                                      size_t workspace_floats, int* status, void* stream) {
+  if (!q_ids || !pos_ids || !neg_ids || !packed || !ptrs || !loss_out || !workspace || !status) return CAPAMD_ERR_ARG;
+  if (B < 1 || B > kMaxStepBatch || K < 1 || K > kMaxK || loss_type < 0 || loss_type > 1 || !(bc2_sqrt > 0.f)) return CAPAMD_ERR_ARG;
+  if (workspace_floats < capamd_knrm_train_step_workspace_floats(B, K)) return CAPAMD_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float *mu = workspace, *sigma = workspace + 16, *w = workspace + 32;
+  const size_t n = (size_t)B * K;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(knrm_stack_kernel, dim3(1), dim3(64), 0, s, ptrs, K, mu, sigma);
+  int rc = capamd_knrm_features(q_ids, pos_ids, B, Q, L, packed, V, D, mu, sigma, K, w, w + n, w + 2 * n, status, stream);
+  if (rc != CAPAMD_OK) return rc;
+  rc = capamd_knrm_features(q_ids, neg_ids, B, Q, L, packed, V, D, mu, sigma, K, w + 3 * n, w + 4 * n, w + 5 * n, status, stream);
+  if (rc != CAPAMD_OK) return rc;
+  KnrmStepArgs a{{w, w + 3 * n}, {w + n, w + 4 * n}, {w + 2 * n, w + 5 * n}, B, K, ptrs, train_kernels, scoretanh, loss_type, step_size,
+                 one_minus_beta1, beta2, eps, bc2_sqrt, loss_out};
+  hipLaunchKernelGGL(knrm_step_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
 extern "C" int capamd_knrm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
                                            const int32_t* pair_d, int B, int Q, int L, const float* packed, int64_t V, int D,
                                            const float* mu, const float* sigma, int K, const float* w1, const float* b1,

@@ -50,11 +50,15 @@ struct ListsArgs {
   const float* kn_mu;      // KNRM: the kernels' parameters (null for DRMM) ...
   const float* kn_sigma;
   int kn_K;
+  int32_t* cid;            // [pairs][cid_stride] every document's REAL terms (0 < id < V), dense, in document order - written by the mark pass
+  int32_t* meta;           // [pairs][kDocMeta] n_real, n_oov, n_one[kQT] (OOV terms equal to the list's OOV query term t)
+  int cid_stride;
   float* kn_consts;        // ... and what the pooling pass needs of them, computed once per call: [6][kMaxK] mu, c = -log2(e) / (2 sigma^2),
                            //     K(0) = 2^(c mu^2), K(1) = 2^(c (1 - mu)^2), A = sqrt(-c), B = -A mu   (slots beyond K repeat the last kernel)
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
+constexpr int kDocMeta = 8;                          // ints of per-document metadata the mark pass leaves for the pooling pass
 struct ListQuery {
   int id[kQT];             // query term ids (0: pad or beyond Q)
   float den[kQT];          // their rows' norms
@@ -78,27 +82,117 @@ dim3 list_doc_grid(int nl, int longest) { return nl >= 8 ? dim3((unsigned)longes
 __device__ __forceinline__ int64_t doc_id_at(const PairIds& ids, int j) { return ids.d32 ? (int64_t)ids.d32[j] : ids.d64[j]; }
 
 // ---- 1: mark -------------------------------------------------------------------------------------------------------------------
+// A wave per document (four per workgroup): every real term id (0 < id < V) flags its byte of the list's map AND is appended to the
+// document's compact id row - int32, pads / OOV terms dropped - which is what the pooling pass reads instead of the [L] int64 row (303
+// real terms of 800 positions on the benchmark's lists: 78 MB written here, 330 MB not read there); the OOV terms are counted, those
+// equal to one of the list's OOV query terms per term (their similarity is exactly 1, common.py:155-158; everything else without a row
+// is exactly 0: the pooling pass adds both in closed form).  EMIT = false (PACRR: its kernel needs positions) only flags.
+#ifndef CAPAMD_MARK_TRIPS
+#define CAPAMD_MARK_TRIPS 13
+#endif
+constexpr int kMarkTrips = CAPAMD_MARK_TRIPS;     // 832 positions per pass, their ids requested together (the reference's documents are 800 positions)
+
+template <bool EMIT>
 __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g) {
-  int l, doc;
-  if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
-  const PairIds ids = pair_ids(a.ids, g.start[l] + doc, a.Q, a.L);
-  uint8_t* f = a.flags + (int64_t)l * a.Vp;
-  bool bad = false;
-  for (int j0 = 0; j0 < a.L; j0 += 256 * 4) {
-    int64_t id[4];
+  int l, dq;
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
+  const int b = g.start[l] + doc;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
+  int qo[kQT];                // the list's OOV query terms (0: not an OOV term)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * 256 + (int)threadIdx.x;
-      id[u] = j < a.L ? doc_id_at(ids, j) : 0;
+  for (int t = 0; t < kQT; ++t) {
+    const int64_t q = t < a.Q ? qids.q(t) : 0;
+    qo[t] = (q < 0 && q > -2147483648LL) ? (int)q : 0;
+  }
+  uint8_t* f = a.flags + (int64_t)l * a.Vp;
+  int32_t* out = EMIT ? a.cid + (int64_t)b * a.cid_stride : nullptr;
+  int n_real = 0, c_oov = 0, c_one[kQT] = {0, 0, 0, 0};
+  bool bad = false;
+  for (int j0 = 0; j0 < a.L; j0 += 64 * kMarkTrips) {
+    int64_t id[kMarkTrips];
+    const bool full = j0 + 64 * kMarkTrips <= a.L;
+    if (ids.d32) {
+      int v[kMarkTrips];
+      if (full) {
+        const int* p = ids.d32 + j0 + lane;
+#pragma unroll
+        for (int u = 0; u < kMarkTrips; ++u) v[u] = p[u * 64];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kMarkTrips; ++u) {
+          const int j = j0 + u * 64 + lane;
+          v[u] = ids.d32[j < a.L ? j : a.L - 1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kMarkTrips; ++u) id[u] = (j0 + u * 64 + lane < a.L) ? (int64_t)v[u] : 0;
+    } else if (full) {
+      const int64_t* p = ids.d64 + j0 + lane;
+#pragma unroll
+      for (int u = 0; u < kMarkTrips; ++u) id[u] = __builtin_nontemporal_load(p + u * 64);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kMarkTrips; ++u) {
+        const int j = j0 + u * 64 + lane;
+        id[u] = __builtin_nontemporal_load(ids.d64 + (j < a.L ? j : a.L - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < kMarkTrips; ++u) id[u] = (j0 + u * 64 + lane < a.L) ? id[u] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (id[u] >= a.V) bad = true;
-      else if (id[u] > 0) f[id[u]] = 1;        // (unconditional: a check of the flag first puts a load in front of every store and measures the same;
-                                               //  so does an LDS bit map of the terms a workgroup of 16 documents has stored already: 123-142 us for 114)
+    for (int u = 0; u < kMarkTrips; ++u) {
+      const int64_t v = id[u];
+      if (!__any(v != 0)) continue;          // padding only (wave-uniform): the tail of most documents
+      const bool real = v > 0 && v < a.V;
+      if (v >= a.V) bad = true;
+      if (real) f[v] = 1;                    // (unconditional: a check of the flag first puts a load in front of every store and measures the same)
+      if (EMIT) {
+        const uint64_t set = __ballot(real);
+        if (real) out[n_real + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = (int)v;
+        n_real += __builtin_popcountll(set);
+        const uint64_t neg = __ballot(v < 0);       // (counts as wave-uniform scalars: no cross-lane reduction at the end of the document)
+        if (neg) {
+          c_oov += __builtin_popcountll(neg);
+          const int vi = (v < 0 && v > -2147483648LL) ? (int)v : 0;
+#pragma unroll
+          for (int t = 0; t < kQT; ++t)
+            if (qo[t] != 0) c_one[t] += __builtin_popcountll(__ballot(vi == qo[t]));
+        }
+      }
     }
   }
   if (bad) atomicOr(a.status, kErrDocIdRange);
+  if (EMIT) {
+    if (lane == 0) {
+      int32_t* m = a.meta + (int64_t)b * kDocMeta;
+      m[0] = n_real;
+      m[1] = c_oov;
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) m[2 + t] = c_one[t];
+    }
+  }
+}
+
+// the compact ids of one pass of a pooling kernel - TRIPS trips of STRIDE consecutive entries, this lane's slot `ps`; 0 beyond the row's n
+template <int TRIPS, int STRIDE>
+__device__ __forceinline__ void load_pass_cids(const int32_t* row, int j0, int ps, int n, int (&id)[TRIPS]) {
+  if (j0 + TRIPS * STRIDE <= n) {
+    const int32_t* p = row + j0 + ps;
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) id[u] = __builtin_nontemporal_load(p + u * STRIDE);
+  } else {
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) {
+      const int j = j0 + u * STRIDE + ps;
+      id[u] = __builtin_nontemporal_load(row + (j < n ? j : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) id[u] = (j0 + u * STRIDE + ps < n) ? id[u] : 0;
+  }
 }
 
 // ---- 2: sims -------------------------------------------------------------------------------------------------------------------
@@ -118,12 +212,14 @@ __device__ __forceinline__ int list_bin_of(float x, const float* edges, int nbin
 constexpr unsigned kBinExact = 0x80;      // entry byte: bin (nbins = above the last edge) | kBinExact when 0.999 < s < 1.001 (drmm.hip's exact-match bin)
 
 // the query of every list once: its packed rows in the PAIRED LDS layout of rows_dot_pk, its ids and norms
-#ifdef CAPAMD_LISTS_SIMS_VALU      // A/B builds: the round-3 sims pass on the fp32 VALU (lists_sims_kernel); its query image is the paired layout
-constexpr bool kSimsOnMfma = false;
-#define CAPAMD_SIMS_KERNEL lists_sims_kernel
-#else
+// The sims pass runs on the fp32 VALU (lists_sims_kernel).  -DCAPAMD_LISTS_SIMS_MFMA builds the round-4 experiment instead - the same
+// partial chains on v_mfma_f32_4x4x1_16b_f32, bit-identical, measured SLOWER (see lists_sims_mfma_kernel) - with its plain query image.
+#ifdef CAPAMD_LISTS_SIMS_MFMA
 constexpr bool kSimsOnMfma = true;
 #define CAPAMD_SIMS_KERNEL lists_sims_mfma_kernel
+#else
+constexpr bool kSimsOnMfma = false;
+#define CAPAMD_SIMS_KERNEL lists_sims_kernel
 #endif
 template <int NV>
 __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom g) {
@@ -155,7 +251,7 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
   }
 }
 
-#ifdef CAPAMD_LISTS_SIMS_VALU      // (A/B builds only: the round-3 pass on the fp32 VALU)
+#ifndef CAPAMD_LISTS_SIMS_MFMA
 #ifndef CAPAMD_LISTS_SIMS_WAVES
 #define CAPAMD_LISTS_SIMS_WAVES 1
 #endif
@@ -239,7 +335,8 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
 
 #endif
 
-// ---- 2': sims on the matrix pipe ------------------------------------------------------------------------------------------------
+// ---- 2': sims on the matrix pipe (round-4 experiment, not the default: -DCAPAMD_LISTS_SIMS_MFMA) --------------------------------------
+#ifdef CAPAMD_LISTS_SIMS_MFMA
 // The same dot products - per (row, query term) the 16 lane-partial fma chains of rows_dot and their balanced tree, bit for bit - with
 // the chains on v_mfma_f32_4x4x1_16b_f32 instead of the fp32 VALU.  That instruction is 16 independent 4 x 4 outer products, K = 1:
 // D_b[i][j] += A_b[i] * B_b[j] for blocks b = 0..15, lane 4 b + i supplying A_b[i], lane 4 b + j supplying B_b[j] and keeping column j of
@@ -253,19 +350,22 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
 // can deliver (a quad of lanes on four rows is four cache lines per request): rows are fetched as before, a 16-lane group per row, and
 // turned through a wave-private LDS stage (ds_write_b128 at slot 4 p + i, then one LINEAR ds_read_b128 per chunk: conflict-free).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef CAPAMD_SIMS_MFMA_BLOCKS
+#define CAPAMD_SIMS_MFMA_BLOCKS 5      // workgroups per CU the register budget is set for (<= 96 registers)
+#endif
 
 __device__ __forceinline__ float lane_xor4(float v) {        // the value of lane ^ 4: quad reversed, then the 8-lane half mirrored
   return dpp_mov<0x141>(dpp_mov<0x1B>(v));
 }
 
 template <int NV, bool BINS>
-__global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, ListGeom g) {
+__global__ __launch_bounds__(256, CAPAMD_SIMS_MFMA_BLOCKS) void lists_sims_mfma_kernel(ListsArgs a, ListGeom g) {
   __shared__ int lst[kSimsIds];
   static_assert(kSimsIds <= 4096, "16 flag bytes per thread at most");
   __shared__ int wave_cnt[4];
   __shared__ float edges[kMaxBins];
-  __shared__ __attribute__((aligned(16))) f32x4v stage[4][2][NV * 64];     // [wave][buffer][chunk * 64 + 4 * piece + row of the group]
-  __shared__ __attribute__((aligned(16))) float dens[4][16];              // [wave][row of the batch] the rows' norms
+  __shared__ __attribute__((aligned(16))) f32x4v stage[4][NV * 64];        // [wave][chunk * 64 + 4 * piece + row of the group]
+  __shared__ __attribute__((aligned(16))) float dens[4][8];               // [wave][row of the batch] the rows' norms
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pl = tid & 15, grp = lane >> 4;
   // XCD x (workgroups whose linear index is x mod 8: blockIdx.x = 8 * list + x) takes the id blocks 8 k + x, each for all lists back to back
   const int l = blockIdx.x >> 3, blk = blockIdx.y * 8 + (blockIdx.x & 7);
@@ -315,103 +415,85 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
   __syncthreads();
   float* tab = reinterpret_cast<float*>(a.table + (int64_t)l * a.Vp);
   uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
-  // batches of 16 rows (four groups of four), dealt to the waves round robin; no barrier from here on: every wave has its own stage
-  const int nb = (total + 15) >> 4;
 #ifndef CAPAMD_SIMS_ABL
-#define CAPAMD_SIMS_ABL 0      // profiling builds: 1 = every row load hits one of 16 rows, 2 = no MFMAs, 4 = no cross-lane reductions
+#define CAPAMD_SIMS_ABL 0      // profiling builds: 1 = every row load hits one of 16 rows, 2 = no MFMAs
 #endif
-  auto row_id = [&](int batch, int G) {       // the table row this lane's 16-lane group fetches for group G of a batch (the tail repeats the last row)
-    const int e = batch * 16 + G * 4 + grp;
-    const int id = id0 + lst[e < total ? e : total - 1];
-    return (CAPAMD_SIMS_ABL & 1) ? 1 + (id & 15) : id;
-  };
   // (native vectors, not float4 structs: a struct copied whole from memory to LDS stays a memcpy through a stack slot)
   auto fetch = [&](int id, f32x4v (&r)[NV]) {
     const f32x4v* p = reinterpret_cast<const f32x4v*>(a.packed + (int64_t)id * (64 * NV)) + pl;
 #pragma unroll
     for (int c = 0; c < NV; ++c) r[c] = p[c * 16];
   };
-  // Two register sets in turn: a batch is computed from one while the wave's NEXT batch lands in the other (group by group, each right
-  // after the LDS store that frees its registers' counterpart).  Written as two calls of one body so that the sets are named registers
-  // (an array indexed by the batch's parity would live in scratch memory), and without a copy between them: a register move waits for its
-  // load, i.e. a copy at the end of a batch waits for the whole prefetch it has just issued.
-  auto batch = [&](f32x4v (&rr)[4][NV], f32x4v (&nx)[4][NV], const int bt) {
-    const int next = bt + 4 < nb ? bt + 4 : bt;       // (the last batch is requested twice: a load under a condition makes its destination a merge
+  // Batches of EIGHT rows (two groups of four) per wave: what bounds this pass is how many row requests a CU keeps in flight while each
+  // wave walks its chain request -> LDS turn -> MFMA chain -> reduction, i.e. the number of resident waves: 16-row batches with a second
+  // register set for the next batch (200 registers, 8 waves per CU) measured 470 us per call, the fp32-VALU form 285.  A group's registers
+  // are re-requested (the same group of the wave's next batch) right after the LDS store that frees them.
+  auto fetch2 = [&](int batch, int G, f32x4v (&r)[NV]) {
+    const int e = batch * 8 + G * 4 + grp;
+    const int id = id0 + lst[e < total ? e : total - 1];
+    fetch((CAPAMD_SIMS_ABL & 1) ? 1 + (id & 15) : id, r);
+  };
+  const int nb8 = (total + 7) >> 3;
+  f32x4v* st = stage[wave];
+  f32x4v rr[2][NV];
+  int bt = wave;
+  if (bt >= nb8) return;                      // (no barrier below)
+  fetch2(bt, 0, rr[0]);
+  fetch2(bt, 1, rr[1]);
+  for (; bt < nb8; bt += 4) {
+    const int next = bt + 4 < nb8 ? bt + 4 : bt;      // (the last batch is requested twice: a load under a condition makes its destination a merge
                                                       //  point, which hipcc resolves through scratch memory)
-    f32x4v acc[4];
-    // two groups at a time, one per stage buffer: their two accumulator chains alternate on the matrix pipe (an MFMA that waits for the
-    // one before it - the chain of a single group - issues at about half the rate)
+    f32x4v acc[2];
 #pragma unroll
-    for (int H = 0; H < 2; ++H) {
+    for (int G = 0; G < 2; ++G) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int G = 2 * H + h;
-        f32x4v* st = stage[wave][h];
-#pragma unroll
-        for (int c = 0; c < NV; ++c) st[c * 64 + 4 * pl + grp] = rr[G][c];
-        if (pl == 15) dens[wave][G * 4 + grp] = rr[G][NV - 1].w;
-        fetch(row_id(next, G), nx[G]);                  // the same group of this wave's next batch
-      }
+      for (int c = 0; c < NV; ++c) st[c * 64 + 4 * pl + grp] = rr[G][c];
+      if (pl == 15) dens[wave][G * 4 + grp] = rr[G][NV - 1].w;
+      fetch2(next, G, rr[G]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");              // (one wave: LDS program order is the synchronisation)
-      f32x4v d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      f32x4v d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        const f32x4v a0 = stage[wave][0][c * 64 + lane], a1 = stage[wave][1][c * 64 + lane];
+        const f32x4v av = st[c * 64 + lane];
         if (CAPAMD_SIMS_ABL & 2) {
-          d0 += a0;
-          d1 += a1;
+          d += av;
           continue;
         }
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, qreg[c].x, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, qreg[c].x, d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, qreg[c].y, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, qreg[c].y, d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, qreg[c].z, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, qreg[c].z, d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, qreg[c].w, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, qreg[c].w, d1, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, qreg[c].x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, qreg[c].y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, qreg[c].z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, qreg[c].w, d, 0, 0, 0);
       }
-      acc[2 * H] = d0;
-      acc[2 * H + 1] = d1;
+      acc[G] = d;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // levels 1, 2 of the tree (partials b ^ 1, b ^ 2: inside the 16-lane row): every lane of a row ends with the row's sum for its term
-    if (!(CAPAMD_SIMS_ABL & 4)) {
 #pragma unroll
-      for (int G = 0; G < 4; ++G)
+    for (int G = 0; G < 2; ++G)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = acc[G][i];
-          v += lane_xor4(v);
-          v += dpp_mov<0x128>(v);            // row_ror:8 = lane ^ 8
-          acc[G][i] = v;
-        }
-    }
-    // levels 3, 4 (b ^ 4, b ^ 8: the wave's rows R = lane >> 4) as a reduce-scatter: row R ends with the sums of group R
-    const bool odd = (grp & 1) != 0, hi = (grp & 2) != 0;
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[G][i];
+        v += lane_xor4(v);
+        v += dpp_mov<0x128>(v);            // row_ror:8 = lane ^ 8
+        acc[G][i] = v;
+      }
+    // levels 3, 4 (b ^ 4, b ^ 8: the wave's rows R = lane >> 4): rows R and R ^ 1 exchange the group they do not keep, then R and R ^ 2
+    // add what they hold of the same group - (R0 + R1) + (R2 + R3): rows 0 and 2 end with group 0, rows 1 and 3 with group 1
+    const bool odd = (grp & 1) != 0;
     float fin[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (CAPAMD_SIMS_ABL & 4) {
-        fin[i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
-        continue;
-      }
-      float t[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float keep = odd ? acc[2 * k + 1][i] : acc[2 * k][i], give = odd ? acc[2 * k][i] : acc[2 * k + 1][i];
-        t[k] = keep + __shfl_xor(give, 16, 64);
-      }
-      const float keep = hi ? t[1] : t[0], give = hi ? t[0] : t[1];
-      fin[i] = keep + __shfl_xor(give, 32, 64);
+      const float keep = odd ? acc[1][i] : acc[0][i], give = odd ? acc[0][i] : acc[1][i];
+      const float t = keep + __shfl_xor(give, 16, 64);
+      fin[i] = t + __shfl_xor(t, 32, 64);
     }
-    // lane (R, r, j): row r of group R against query term j
-    const int r = (lane >> 2) & 3, e = bt * 16 + grp * 4 + r;
+    // lane (R < 2, r, j): row r of group R against query term j
+    const int r = (lane >> 2) & 3, e = bt * 8 + (grp & 1) * 4 + r;
     const float dot = r == 0 ? fin[0] : r == 1 ? fin[1] : r == 2 ? fin[2] : fin[3];
-    const float dden = dens[wave][grp * 4 + r];
+    const float dden = dens[wave][(grp & 1) * 4 + r];
     const float sdiv = dot / (qden * dden);
     const float sm = qid > 0 ? sdiv : 0.f;
-    if (e < total && j < kQT) {
+    if (e < total && grp < 2) {
       const int id = id0 + lst[e];
       if (BINS) {
         const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
@@ -421,38 +503,32 @@ __global__ __launch_bounds__(256, 2) void lists_sims_mfma_kernel(ListsArgs a, Li
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (dens is rewritten by the next batch)
-  };
-  f32x4v ra[4][NV], rb[4][NV];
-  int bt = wave;
-  if (bt >= nb) return;                       // (no barrier below)
-#pragma unroll
-  for (int G = 0; G < 4; ++G) fetch(row_id(bt, G), ra[G]);
-  for (;;) {
-    batch(ra, rb, bt);
-    bt += 4;
-    if (bt >= nb) break;
-    batch(rb, ra, bt);
-    bt += 4;
-    if (bt >= nb) break;
   }
 }
+#endif   // CAPAMD_LISTS_SIMS_MFMA
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 6 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
+int lists_cid_stride(int L) { return (L + 3) & ~3; }
+size_t lists_pair_bytes(int64_t n_pairs, int L) { return (size_t)n_pairs * ((size_t)lists_cid_stride(L) * 4 + kDocMeta * 4); }
 
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
 template <class Pool>
 int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V, int D, int* status,
               void* workspace, size_t workspace_bytes, hipStream_t s, const float* edges, int nbins, const float* kn_mu, const float* kn_sigma, int kn_K,
-              Pool pool) {
+              bool emit, Pool pool) {
   if (!offsets_host || !packed || !status || !workspace) return CAPAMD_ERR_ARG;
   if (n_lists < 0 || Q < 1 || Q > kQT || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return CAPAMD_ERR_ALIGN;
   const int64_t Vp = lists_vp(V);
   const size_t per_list = (size_t)Vp * 17 + kListQueryBytes;
-  if (workspace_bytes < kListConstBytes) return CAPAMD_ERR_WORKSPACE;
-  const size_t fit = (workspace_bytes - kListConstBytes) / per_list;
+  // workspace: [compact id rows + document metadata of ALL the call's pairs] [per list in flight: table, byte map, query image] [KNRM constants]
+  const int64_t n_pairs = n_lists > 0 ? offsets_host[n_lists] : 0;
+  if (n_pairs < 0 || n_pairs > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  const size_t pair_bytes = emit ? lists_pair_bytes(n_pairs, L) : 0;
+  if (workspace_bytes < kListConstBytes + pair_bytes) return CAPAMD_ERR_WORKSPACE;
+  const size_t fit = (workspace_bytes - kListConstBytes - pair_bytes) / per_list;
   int cap = (int)(fit < (size_t)kListChunk ? fit : (size_t)kListChunk);
   if (cap < 1) return CAPAMD_ERR_WORKSPACE;
   if (cap > kListChunk) cap = kListChunk;
@@ -469,18 +545,26 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       if (g.len[i] > longest) longest = g.len[i];
     }
     if (longest == 0) continue;
-    // workspace: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap] | KNRM kernel constants
-    char* ws = static_cast<char*>(workspace);
+    // per-list part: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap] | KNRM kernel constants
+    char* ws = static_cast<char*>(workspace) + pair_bytes;
+    int32_t* cid = emit ? reinterpret_cast<int32_t*>(workspace) : nullptr;
+    int32_t* meta = emit ? cid + (size_t)n_pairs * lists_cid_stride(L) : nullptr;
     float4* table = reinterpret_cast<float4*>(ws);
     uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
     float4* qimg = reinterpret_cast<float4*>(ws + (size_t)cap * Vp * 17);
     ListQuery* qmeta = reinterpret_cast<ListQuery*>(qimg + (size_t)cap * kQueryImage);
     float* kn_consts = kn_mu ? reinterpret_cast<float*>(qmeta + cap) : nullptr;
-    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, kn_consts};
+    ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, cid, meta, lists_cid_stride(L),
+                kn_consts};
     lists_stamp(s);
     if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
     lists_stamp(s);
-    hipLaunchKernelGGL(lists_mark_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g);
+    {
+      ListsArgs am = a;
+      am.longest = (longest + 3) / 4;       // four documents per workgroup
+      if (emit) hipLaunchKernelGGL(lists_mark_kernel<true>, list_doc_grid(nl, am.longest), dim3(256), 0, s, am, g);
+      else hipLaunchKernelGGL(lists_mark_kernel<false>, list_doc_grid(nl, am.longest), dim3(256), 0, s, am, g);
+    }
     lists_stamp(s);
     const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
 #define CAPAMD_SIMS(NV)                                                                                         \

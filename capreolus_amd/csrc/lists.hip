@@ -48,61 +48,6 @@ void capamd::lists_stamp(hipStream_t s) {
 #endif
 namespace {
 
-// The ids of one pass of a pooling kernel - TRIPS trips of STRIDE consecutive positions, this lane's slot `ps` - as int: 0 = pad (or beyond
-// the table: flagged by the mark pass), > 0 a term, < 0 an OOV term (KEEP_OOV: its own id, INT_MIN where that does not fit; otherwise
-// -1).  Returns false for a pass of padding only (wave-uniform), recognised on the raw ids before anything is done with them - the
-// tail of most documents.  A pass that lies inside the document reads base + constant offsets; only the last one predicates.
-template <int TRIPS, int STRIDE, bool KEEP_OOV>
-__device__ __forceinline__ bool load_pass_ids(const PairIds& ids, int j0, int ps, int L, int64_t V, int (&id)[TRIPS]) {
-  const bool full = j0 + TRIPS * STRIDE <= L;
-  if (ids.d32) {
-    int live = 0;
-    if (full) {
-      const int* p = ids.d32 + j0 + ps;
-#pragma unroll
-      for (int u = 0; u < TRIPS; ++u) {
-        id[u] = p[u * STRIDE];
-        live |= id[u];
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < TRIPS; ++u) {
-        const int j = j0 + u * STRIDE + ps;
-        id[u] = j < L ? ids.d32[j] : 0;
-        live |= id[u];
-      }
-    }
-    if (!__any(live != 0)) return false;
-#pragma unroll
-    for (int u = 0; u < TRIPS; ++u) {
-      if (id[u] >= V) id[u] = 0;
-      if (!KEEP_OOV && id[u] < 0) id[u] = -1;
-    }
-  } else {
-    int64_t w[TRIPS], live = 0;
-    if (full) {
-      const int64_t* p = ids.d64 + j0 + ps;
-#pragma unroll
-      for (int u = 0; u < TRIPS; ++u) {
-        w[u] = p[u * STRIDE];
-        live |= w[u];
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < TRIPS; ++u) {
-        const int j = j0 + u * STRIDE + ps;
-        w[u] = j < L ? ids.d64[j] : 0;
-        live |= w[u];
-      }
-    }
-    if (!__any(live != 0)) return false;
-#pragma unroll
-    for (int u = 0; u < TRIPS; ++u)
-      id[u] = w[u] >= V ? 0 : w[u] < 0 ? (KEEP_OOV ? (w[u] > -2147483648LL ? (int)w[u] : (int)0x80000000) : -1) : (int)w[u];
-  }
-  return true;
-}
-
 // ---- 3a: KNRM pooling ----------------------------------------------------------------------------------------------------------
 struct KnrmPoolArgs {
   const float* mu;
@@ -128,62 +73,95 @@ constexpr int kWaveTrips = 8;      // 128 positions per pass
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
 // KK: kernels the loops run over (11 - the model's default bank - or kMaxK, slots beyond K repeating the last kernel)
+// Two variants measured in round 4 and NOT kept (profiles/r04/lists_pool_variants.txt), selectable for A/B builds:
+//   -DCAPAMD_POOL_HOT=2048 / -DCAPAMD_POOL_HOT_BINS=8192   the entries of the frequent terms (ids below the bound: ids are frequency ranks in
+//       GloVe-style vocabularies and in the benchmark's Zipf(1.1) ids - 75 % of all document terms have an id below 2048) staged in LDS per
+//       workgroup, so that three of four lookups are an LDS read instead of a 16-byte entry pulled out of L2 by a whole line: the random
+//       ds_read_b32 addresses of 64 lanes conflict on the banks - KNRM pooling 227 -> 281 us per call (388 with 4096 entries)
+//   -DCAPAMD_POOL_DOCS=8   a workgroup walking 8 documents per wave (what the staging needs to pay for itself): 227 -> 261 us without the
+//       table - fewer, longer waves balance the documents' 40x length spread worse
+#ifndef CAPAMD_POOL_HOT
+#define CAPAMD_POOL_HOT 0
+#endif
+#ifndef CAPAMD_POOL_DOCS
+#define CAPAMD_POOL_DOCS 1
+#endif
+#ifndef CAPAMD_POOL_HOT_BINS
+#define CAPAMD_POOL_HOT_BINS 0
+#endif
+constexpr int kPoolHot = CAPAMD_POOL_HOT, kPoolDocs = CAPAMD_POOL_DOCS, kPoolHotBins = CAPAMD_POOL_HOT_BINS;
+
 template <int KK>
 __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+  __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];
   int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
-  const int doc = dq * 4 + wave;
-  if (doc >= g.len[l]) return;
-  const int b = g.start[l] + doc;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
-  const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
-  int64_t qid = t < a.Q ? qids.q(t) : 0;
-  if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
+  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
+  if (kPoolHot > 0) {
+    const float4* src = a.table + (int64_t)l * a.Vp;
+    const int nh = a.Vp < kPoolHot ? (int)a.Vp : kPoolHot;
+    for (int i = tid; i < nh; i += 256) hot[i] = src[i];
+    __syncthreads();
+  }
+  const float* hotf = reinterpret_cast<const float*>(hot) + t;
   float ka[KK], kb[KK];      // K_k(s) = 2^-(ka s + kb)^2
 #pragma unroll
   for (int k = 0; k < KK; ++k) {
     ka[k] = a.kn_consts[4 * kMaxK + k];
     kb[k] = a.kn_consts[5 * kMaxK + k];
   }
+  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
+  // the read-out's weights: the same for every document
+  const int hn = lane < m.hidden ? lane : 0;
+  float w1v[kMaxK];
+#pragma unroll
+  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
+  const int kq = lane & 15;
+  const float k0c = (kq < m.K) ? a.kn_consts[2 * kMaxK + kq] : 0.f, k1c = (kq < m.K) ? a.kn_consts[3 * kMaxK + kq] : 0.f;
+  for (int di = 0; di < kPoolDocs; ++di) {
+  const int doc = (dq * kPoolDocs + di) * 4 + wave;
+  if (doc >= g.len[l]) break;
+  const int b = g.start[l] + doc;
+  // what the mark pass left: the document's real terms, dense (int32), and its counts
+  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
+  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
+  const int n = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
   float acc[KK], rs = 0.f;
-  int n_one = 0, n_real = 0;
 #pragma unroll
   for (int k = 0; k < KK; ++k) acc[k] = 0.f;
-  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
-  for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
+  for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
-    if (!load_pass_ids<kWaveTrips, 16, true>(ids, j0, ps, a.L, a.V, id)) continue;
+    load_pass_cids<kWaveTrips, 16>(row, j0, ps, n, id);
     float s[kWaveTrips];
+    if (kPoolHot > 0) {
+      float sg[kWaveTrips], sl[kWaveTrips];
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+      for (int u = 0; u < kWaveTrips; ++u) sg[u] = tab[(int64_t)(id[u] >= kPoolHot ? id[u] : 0) * 4];   // (entry 0: one shared line for the hot ones)
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) sl[u] = hotf[(id[u] < kPoolHot ? id[u] : 0) * 4];
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+    }
     // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) {
-      if (!__any(id[u] != 0)) continue;
+      if (j0 + u * 16 >= n) continue;          // (wave-uniform)
       if (id[u] > 0) {
-        ++n_real;
         rs += s[u];
-        // (the kernels in pairs on packed fp32 - v_pk_add / v_pk_mul, 36 instructions per trip for 60 - measure the same: 358 us for 352)
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
           const float tk = __builtin_fmaf(s[u], ka[k], kb[k]);
           acc[k] += __builtin_amdgcn_exp2f(-tk * tk);
         }
-      } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
-        ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)
       }
     }
   }
-  // the read-out's weights, requested together now (asked for one by one inside the fma chain they are K dependent round trips)
-  const int hn = lane < m.hidden ? lane : 0;
-  float w1v[kMaxK];
-#pragma unroll
-  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
-#pragma unroll
-  for (int kk = 0; kk < kMaxK; ++kk) asm volatile("" : "+v"(w1v[kk]));
   // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
   const int k = lane & 15;
   float S = 0.f;
@@ -193,10 +171,10 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     S = k == kk ? v : S;
   }
   const float R0 = group_allreduce(rs);
-  const int no = (int)group_allreduce((float)n_one), nreal = (int)group_allreduce((float)n_real);
+  const int no = n_one_t, nreal = n;
   float f = 0.f;
   if (k < m.K && t < a.Q) {
-    const float k0 = a.kn_consts[2 * kMaxK + k], k1 = a.kn_consts[3 * kMaxK + k];
+    const float k0 = k0c, k1 = k1c;
     const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
     S += (float)nz * k0;
     S += (float)no * k1;
@@ -224,6 +202,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     if (m.scoretanh) sc = tanhf(sc);
     if (lane == 0) m.out[b] = sc;
   }
+  }   // documents of this wave
 }
 
 // ---- 3b: DRMM pooling ----------------------------------------------------------------------------------------------------------
@@ -258,41 +237,20 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
   if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = g.start[l] + doc, NB = m.nbins + 1;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
+  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
+  const int n = dm[0], n_oov = dm[1];
   for (int i = tid; i < kHistCopies * (kQT * kMaxBins + 1); i += 256) (&hrep[0][0])[i] = 0;
   __syncthreads();
   int* myh = hrep[lane & (kHistCopies - 1)];
   const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
-  int n_oov = 0;
-  for (int j0 = 0; j0 < a.L; j0 += 256 * kDrmmTrips) {
+  for (int j0 = 0; j0 < n; j0 += 256 * kDrmmTrips) {
     int id[kDrmmTrips];
-    if (ids.d32) {
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) {
-        const int j = j0 + u * 256 + tid;
-        id[u] = ids.d32[j < a.L ? j : a.L - 1];
-      }
-    } else {
-      int64_t w[kDrmmTrips];
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) {
-        const int j = j0 + u * 256 + tid;
-        w[u] = ids.d64[j < a.L ? j : a.L - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) id[u] = w[u] >= a.V ? 0 : w[u] < 0 ? -1 : (int)w[u];
-    }
-    int live = 0;
-#pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) {
-      if (j0 + u * 256 + tid >= a.L || id[u] >= a.V) id[u] = 0;
-      live |= id[u];
-    }
-    if (!__any(live != 0)) continue;         // padding only (wave-uniform)
+    load_pass_cids<kDrmmTrips, 256>(row, j0, tid, n, id);
     uint32_t e[kDrmmTrips];
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u]];        // (entry 0 is never written and never used)
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
@@ -306,14 +264,10 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
             if (by & kBinExact) atomicAdd(&myh[q * kMaxBins + m.nbins], 1);
           }
         }
-      } else if (id[u] < 0) {
-        ++n_oov;       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n_oov += __shfl_xor(n_oov, o, 64);
-  if (lane == 0 && n_oov > 0) {
+  if (tid == 0 && n_oov > 0) {        // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
     const int bz = list_bin_of(0.f, m.edges, m.nbins);
     if (bz < m.nbins)
       for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&hrep[0][q * kMaxBins + bz], n_oov);
@@ -382,26 +336,46 @@ constexpr int kWaveCopies = 8, kWaveBins = 32, kWaveStride = kQT * kWaveBins + 1
 
 __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
   __shared__ int hrep[4][kWaveCopies * kWaveStride];
+  __shared__ __attribute__((aligned(16))) uint32_t hot[kPoolHotBins > 0 ? kPoolHotBins : 4];       // the 4-byte entries of the frequent terms (see the KNRM pooling)
   int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int doc = dq * 4 + wave;
-  if (doc >= g.len[l]) return;
-  const int b = g.start[l] + doc, NB = m.nbins + 1;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
+  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
+  if (kPoolHotBins > 0) {
+    const int nh = a.Vp < kPoolHotBins ? (int)a.Vp : kPoolHotBins;
+    for (int i = tid * 4; i < nh; i += 1024) *reinterpret_cast<uint4*>(&hot[i]) = *reinterpret_cast<const uint4*>(&tab[i]);   // (Vp is a multiple of 1024)
+    __syncthreads();
+  }
+  const int NB = m.nbins + 1;
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
+  for (int di = 0; di < kPoolDocs; ++di) {
+  const int doc = (dq * kPoolDocs + di) * 4 + wave;
+  if (doc >= g.len[l]) break;
+  const int b = g.start[l] + doc;
+  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
+  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
+  const int n = dm[0], n_oov = dm[1];
   int* H = hrep[wave];
   for (int i = lane; i < kWaveCopies * kWaveStride; i += 64) H[i] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
   int* myh = H + (lane & (kWaveCopies - 1)) * kWaveStride;
-  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
-  int n_oov = 0;
-  for (int j0 = 0; j0 < a.L; j0 += 64 * kDrmmTrips) {
+  for (int j0 = 0; j0 < n; j0 += 64 * kDrmmTrips) {
     int id[kDrmmTrips];
-    if (!load_pass_ids<kDrmmTrips, 64, false>(ids, j0, lane, a.L, a.V, id)) continue;
+    load_pass_cids<kDrmmTrips, 64>(row, j0, lane, n, id);
     uint32_t e[kDrmmTrips];
+    if (kPoolHotBins > 0) {
+      uint32_t eg[kDrmmTrips], el[kDrmmTrips];
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u] > 0 ? id[u] : 0];        // (entry 0 is never written and never used)
+      for (int u = 0; u < kDrmmTrips; ++u) eg[u] = tab[id[u] >= kPoolHotBins ? id[u] : 0];
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) el[u] = hot[id[u] < kPoolHotBins ? id[u] : 0];
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) e[u] = id[u] >= kPoolHotBins ? eg[u] : el[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u]];        // (entry 0 is never written and never used)
+    }
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
@@ -415,14 +389,10 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
             if (by & kBinExact) atomicAdd(&myh[q * kWaveBins + m.nbins], 1);
           }
         }
-      } else if (id[u] < 0) {
-        ++n_oov;       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n_oov += __shfl_xor(n_oov, o, 64);
-  if (lane == 0 && n_oov > 0) {
+  if (lane == 0 && n_oov > 0) {       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
     const int bz = list_bin_of(0.f, m.edges, m.nbins);
     if (bz < m.nbins)
       for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&H[q * kWaveBins + bz], n_oov);
@@ -491,6 +461,8 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
     }
     if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's histograms are cleared for its next document)
+  }   // documents of this wave
 }
 
 // ---- 3c: DRMM-TKS pooling -------------------------------------------------------------------------------------------------------
@@ -523,47 +495,64 @@ __device__ __forceinline__ float group_allreduce_max(float v) {
 template <int KT>
 __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGeom g, TksPoolArgs m) {
   __shared__ float heads[4][KT][64];        // [wave][list entry][lane]
+  __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];       // the frequent terms' entries (see the KNRM pooling)
   int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of four documents here)
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
-  const int doc = dq * 4 + wave;
-  if (doc >= g.len[l]) return;
-  const int b = g.start[l] + doc, K = m.topk;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
+  if (kPoolHot > 0) {
+    const float4* src = a.table + (int64_t)l * a.Vp;
+    const int nh = a.Vp < kPoolHot ? (int)a.Vp : kPoolHot;
+    for (int i = tid; i < nh; i += 256) hot[i] = src[i];
+    __syncthreads();
+  }
+  const float* hotf = reinterpret_cast<const float*>(hot) + t;
+  const int K = m.topk;
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
   int64_t qid = t < a.Q ? qids.q(t) : 0;
   if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
   const float ffw_l = lane < K ? m.ffw_w[lane] : 0.f;
   const float gl0 = t < a.Q ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + t] : 0.f;
+  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
+  for (int di = 0; di < kPoolDocs; ++di) {
+  const int doc = (dq * kPoolDocs + di) * 4 + wave;
+  if (doc >= g.len[l]) break;
+  const int b = g.start[l] + doc;
+  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
+  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
+  const int n = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
   float top[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
-  int n_one = 0, n_real = 0;
-  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
-  for (int j0 = 0; j0 < a.L; j0 += 16 * kWaveTrips) {
+  for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
-    if (!load_pass_ids<kWaveTrips, 16, true>(ids, j0, ps, a.L, a.V, id)) continue;
+    load_pass_cids<kWaveTrips, 16>(row, j0, ps, n, id);
     float s[kWaveTrips];
+    if (kPoolHot > 0) {
+      float sg[kWaveTrips], sl[kWaveTrips];
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] > 0 ? id[u] : 0) * 4];     // (entry 0 is never written and never used)
+      for (int u = 0; u < kWaveTrips; ++u) sg[u] = tab[(int64_t)(id[u] >= kPoolHot ? id[u] : 0) * 4];
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) sl[u] = hotf[(id[u] < kPoolHot ? id[u] : 0) * 4];
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+    }
     // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) {
-      if (!__any(id[u] != 0)) continue;
-      if (id[u] > 0) {
-        ++n_real;
-        sorted_insert<KT>(top, s[u]);
-      } else if (id[u] < 0 && id[u] != (int)0x80000000 && qid < 0 && (int)qid == id[u]) {
-        ++n_one;         // an OOV term equal to this lane's OOV query term: similarity 1 (common.py:155-158)
-      }
+      if (j0 + u * 16 >= n) continue;          // (wave-uniform)
+      if (id[u] > 0) sorted_insert<KT>(top, s[u]);
     }
   }
 #pragma unroll
   for (int i = 0; i < KT; ++i) heads[wave][i][lane] = top[i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
-  const int no = (int)group_allreduce((float)n_one), nreal = (int)group_allreduce((float)n_real);
+  const int no = n_one_t, nreal = n;
   const int nz = a.L - nreal - no;          // pads and OOV terms without a match: similarity 0
   int head = 0, used1 = 0, used0 = 0;
   float acc = m.ffw_b[0];
@@ -597,6 +586,8 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
     }
   }
   if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's list heads are rewritten by its next document)
+  }   // documents of this wave
 }
 
 }  // namespace
@@ -625,10 +616,10 @@ extern "C" int capamd_debug_lists_timing_read(double* ms) {
 }
 #endif
 
-extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V) {
-  if (n_lists < 1 || V < 1) return 0;
+extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L) {
+  if (n_lists < 1 || V < 1 || n_pairs < 0 || L < 1) return 0;
   const int n = n_lists < kListChunk ? n_lists : kListChunk;
-  return (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes) + kListConstBytes;
+  return lists_pair_bytes(n_pairs, L) + (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes) + kListConstBytes;
 }
 
 extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
@@ -643,10 +634,10 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const KnrmPoolArgs m{mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K, true,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
-                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                     aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
                      if (K == 11) hipLaunchKernelGGL(lists_knrm_pool_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                      else hipLaunchKernelGGL(lists_knrm_pool_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                    });
@@ -667,11 +658,11 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const DrmmPoolArgs m{idf, edges, nbins, hist_type, gate_type, D, gate_w, emb_raw, ld, w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0, true,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      if (nbins + 1 <= kWaveBins && nodes <= 16) {
                        ListsArgs aq = a;
-                       aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                       aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
                        hipLaunchKernelGGL(lists_drmm_pool_wave_kernel, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                      } else {
                        hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
@@ -691,10 +682,10 @@ extern "C" int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t*
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const TksPoolArgs m{idf, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, true,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
-                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                     aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
                      const dim3 grid = list_doc_grid(nl, aq.longest);
                      if (topk <= 4) hipLaunchKernelGGL(lists_tks_pool_kernel<4>, grid, dim3(256), 0, s, aq, g, m);
                      else if (topk <= 8) hipLaunchKernelGGL(lists_tks_pool_kernel<8>, grid, dim3(256), 0, s, aq, g, m);

@@ -477,15 +477,28 @@ def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V,
 
 # ---- whole candidate lists (capamd_*_forward_lists) ------------------------------------------------------------------------------
 _list_workspaces = {}
+# Bytes the per-list part of a whole-list call's workspace may take (17 B x V per list in flight: 6.8 MB at V = 400,001, but 68 MB at
+# V = 4 M - 64 lists would be 4.3 GB): fewer lists are kept in flight when it would be exceeded (the library then works through the
+# lists in more, smaller groups).  The per-pair part (4 L + 32 bytes per pair of the call) comes on top.
+LISTS_WORKSPACE_BUDGET = 2 << 30
 
 
-def _lists_workspace(device, n_lists, V):
-    nbytes = int(_lib.load().capamd_lists_workspace_bytes(int(n_lists), int(V)))
+def _lists_workspace(device, n_lists, V, n_pairs, L):
+    lib = _lib.load()
+    one = int(lib.capamd_lists_workspace_bytes(1, int(V), 0, int(L)))
+    per_list = int(lib.capamd_lists_workspace_bytes(2, int(V), 0, int(L))) - one
+    in_flight = max(1, min(int(n_lists), LISTS_WORKSPACE_BUDGET // max(per_list, 1)))
+    nbytes = int(lib.capamd_lists_workspace_bytes(in_flight, int(V), int(n_pairs), int(L)))
     key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _list_workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _list_workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws
+    return ws[:nbytes]
+
+
+def release_workspaces():
+    """Drops the cached whole-list workspaces (one per device and stream; a later call allocates again)."""
+    _list_workspaces.clear()
 
 
 def _list_offsets(offsets):
@@ -519,7 +532,7 @@ def knrm_forward_lists(offsets, packed, V, D, mu, sigma, w1, b1, w2=None, b2=Non
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
     hidden = 0 if w2 is None else w1.shape[0]
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
     rc = _lib.load().capamd_knrm_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D, _ptr(mu),
         _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
@@ -541,7 +554,7 @@ def drmm_forward_lists(offsets, idf, packed, V, D, edges, hist_type, gate_type, 
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
     ld = emb_raw.stride(0) if emb_raw is not None else 0
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
     rc = _lib.load().capamd_drmm_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         _ptr(edges), edges.numel(), HIST_TYPES[hist_type], GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0],
@@ -550,6 +563,81 @@ def drmm_forward_lists(offsets, idf, packed, V, D, edges, hist_type, gate_type, 
     if check:
         st.raise_if_set()
     return out
+
+
+class AdamStep:
+    """What a fused training step needs of a torch.optim.Adam: the parameters' device pointers with their moments (created the way
+    Adam's own first step creates them), the host-side step count, and the step's scalars computed in double as the optimizer's
+    non-capturable path does (torch/optim/adam.py: bias_correction = 1 - beta ** step; step_size = lr / bias_correction1;
+    denom = sqrt(v) / sqrt(bias_correction2) + eps).  The state stays a plain Adam state_dict: checkpoints written during fused training
+    load into the reference's trainer and vice versa."""
+
+    def __init__(self, optimizer, params):
+        if not isinstance(optimizer, torch.optim.Adam) or len(optimizer.param_groups) != 1:
+            raise NotImplementedError("fused training steps follow torch.optim.Adam with one parameter group")
+        g = optimizer.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or torch.is_tensor(g["lr"]):
+            raise NotImplementedError("fused training steps follow the plain Adam of the reference (no weight decay / amsgrad / capturable)")
+        self.optimizer, self.group, self.params = optimizer, g, list(params)
+        in_opt = {id(p) for p in g["params"]}
+        ptrs = [[], [], []]
+        for p in self.params:
+            if p is None or id(p) not in in_opt:        # not trained (requires_grad False): no moments
+                for col, v in zip(ptrs, (p.data_ptr() if p is not None else 0, 0, 0)):
+                    col.append(v)
+                continue
+            st = optimizer.state[p]
+            if len(st) == 0:       # (Adam._init_group)
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if st["step"].is_cuda:
+                raise NotImplementedError("fused training steps keep Adam's step count on the host")
+            for col, v in zip(ptrs, (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())):
+                col.append(v)
+        dev = next(p for p in self.params if p is not None).device
+        self.table = torch.tensor(ptrs[0] + ptrs[1] + ptrs[2], dtype=torch.int64).to(dev)
+        self.key = tuple(ptrs[0] + ptrs[1] + ptrs[2])
+        self.trained = [p for p in self.params if p is not None and id(p) in in_opt]
+
+    def still_valid(self):
+        st = self.optimizer.state
+        return all(len(st[p]) and st[p]["exp_avg"].data_ptr() in self.key for p in self.trained)
+
+    def advance(self):
+        """(step_size, 1 - beta1, beta2, eps, sqrt(bias_correction2)) of the NEXT step; the step counters move on"""
+        b1, b2 = self.group["betas"]
+        for p in self.trained:
+            self.optimizer.state[p]["step"] += 1
+        t = float(self.optimizer.state[self.trained[0]]["step"])
+        return float(self.group["lr"]) / (1 - b1 ** t), 1 - b1, b2, float(self.group["eps"]), (1 - b2 ** t) ** 0.5
+
+
+_step_workspaces = {}
+
+
+def knrm_train_step(query, posdoc, negdoc, packed, V, D, K, adam, train_kernels, scoretanh, softmax, check=True):
+    """capamd_knrm_train_step: score(pos), score(neg), the trainer's pairwise loss, backward, Adam - on the device; returns the loss [1]."""
+    _need_gpu(query, posdoc, negdoc, packed)
+    q, dp, dn = _i64(query), _i64(posdoc), _i64(negdoc)
+    B, Q = q.shape
+    L = dp.shape[1]
+    lib = _lib.load()
+    n = int(lib.capamd_knrm_train_step_workspace_floats(B, K))
+    key = (q.device.index, int(torch.cuda.current_stream(q.device).cuda_stream))
+    ws = _step_workspaces.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _step_workspaces[key] = torch.empty(n, dtype=torch.float32, device=q.device)
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    step_size, omb1, b2, eps, bc2s = adam.advance()
+    st = status_word(q.device)
+    rc = lib.capamd_knrm_train_step(_ptr(q), _ptr(dp), _ptr(dn), B, Q, L, _ptr(packed), V, D, K, _ptr(adam.table), int(bool(train_kernels)),
+                                    int(bool(scoretanh)), int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(),
+                                    _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_knrm_train_step")
+    if check:
+        st.raise_if_set()
+    return loss
 
 
 def knrm_features(query, doc, packed, V, D, mu, sigma, need_grad=True, check=True):
@@ -715,7 +803,7 @@ def drmmtks_forward_lists(offsets, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b
     idf = _f32(idf)
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
     rc = _lib.load().capamd_drmmtks_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         int(topk), _ptr(gate_w), _ptr(ffw_w), _ptr(ffw_b), _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
@@ -780,7 +868,7 @@ def pacrr_forward_lists(offsets, idf, packed, V, D, mingram, maxgram, nfilters, 
     idf = _f32(idf)
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
     rc = _lib.load().capamd_pacrr_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         int(mingram), int(maxgram), int(nfilters), int(kmax), _ptr(conv_w), _ptr(conv_b), int(bool(use_idf)), w1.shape[0], NONLINEARITIES[nonlinearity],

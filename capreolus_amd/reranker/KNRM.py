@@ -90,6 +90,25 @@ class KNRM_class(nn.Module):
         feats = engine.KnrmFeatures.apply(mu, sigma, querytoks, doctoks, packed, w.shape[0], w.shape[1])
         return self.combine(feats)
 
+    def fused_train_step(self, d, optimizer, softmax=False):
+        """One whole training step on the device (capamd_knrm_train_step: score(pos), score(neg), pairwise loss, backward, Adam) - or
+        None when this configuration keeps the autograd route (a two-layer `combine`, `finetune`).  Parameters and Adam moments are
+        updated in place; their version counters are bumped so that weight-derived caches notice."""
+        if not self.p["singlefc"] or self.embedding.weight.requires_grad:
+            return None
+        ks = list(self.kernels.kernels)
+        lin = self.combine[0]
+        params = [k.mu for k in ks] + [k.sigma for k in ks] + [lin.weight, lin.bias]
+        hit = self.__dict__.get("_adam_step")
+        if hit is None or hit.optimizer is not optimizer or hit.key[: len(params)] != tuple(p.data_ptr() for p in params) or not hit.still_valid():
+            hit = self.__dict__["_adam_step"] = engine.AdamStep(optimizer, params)
+        w = self.embedding.weight
+        loss = engine.knrm_train_step(d["query"], d["posdoc"], d["negdoc"], self._packed.get(w), w.shape[0], w.shape[1], len(ks), hit,
+                                      bool(self.p["gradkernels"]), bool(self.p["scoretanh"]), softmax)
+        with torch.no_grad():
+            torch._foreach_mul_(hit.trained, 1.0)          # (exact no-op: the kernel wrote the parameters behind autograd's back)
+        return loss[0]
+
     def forward_indexed(self, store, pair_q, pair_d):
         """Scores (query row, document row) pairs of a device-resident `CandidateStore` -> [B]."""
         w = self.embedding.weight
@@ -134,6 +153,9 @@ class KNRM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def fused_train_step(self, d, optimizer, softmax=False):
+        return self.model.fused_train_step(d, optimizer, softmax)
 
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)

@@ -110,6 +110,11 @@ class PytorchTrainer:
         # graph and replayed per batch (at batch 32 a step is ~40 launches of microsecond kernels, i.e. host time).
         # Needs a GPU, gradacc = 1 and no loss scaling (amp = train / both); anything else, and batches of another shape, run eagerly.
         "graph": True,
+        # `fused` (default on): rerankers that bring a whole training step as device kernels (`fused_train_step`: KNRM with a single-Linear
+        # `combine` - score(pos), score(neg), the pairwise loss, backward and Adam's update in four launches, capamd_knrm_train_step) train
+        # through it with the PLAIN torch.optim.Adam of the reference as the optimizer object (its state_dict / checkpoints unchanged,
+        # bias corrections in double on the host).  Same conditions as `graph`; a reranker or configuration without one falls back to it.
+        "fused": True,
     }
     # amp = "pred" / "both" at prediction time (reference :323-326, 343: autocast around `reranker.test`) selects nothing here: the
     # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
@@ -243,6 +248,20 @@ class PytorchTrainer:
             loss = step()
         return {"sig": sig, "reranker": reranker, "static": static, "graph": graph, "loss": loss}
 
+    def _fused_allowed(self, reranker):
+        return bool(self.config["fused"]) and self.device.type == "cuda" and self.config["gradacc"] == 1 and self.scaler is None and \
+            callable(getattr(reranker, "fused_train_step", None)) and not getattr(self, "_fused_failed", False)
+
+    def _fused_step(self, reranker, batch):
+        """The batch's step as the reranker's own device kernels; None when its configuration has none (then: graph / eager)."""
+        try:
+            loss = reranker.fused_train_step(batch, self.optimizer, softmax=bool(self.config["softmaxloss"]))
+        except NotImplementedError:
+            loss = None
+        if loss is None:
+            self._fused_failed = True
+        return loss
+
     def _graphed_step(self, reranker, batch):
         """Replays the captured step on `batch`; None when this batch cannot take the graph (another shape: the short last batch)."""
         from .. import engine
@@ -275,7 +294,7 @@ class PytorchTrainer:
         compute in fp32 whatever `amp` says."""
         n_batch_per_iter = self.n_batch_per_iter
         cur_step = cur_iter * n_batch_per_iter
-        graphed = self._graph_allowed()
+        graphed = self._graph_allowed() or getattr(self, "_use_fused", False)
         if graphed:      # no device -> host read inside the iteration: data-dependent errors of the kernels are raised once, after it
             from .. import engine
 
@@ -285,14 +304,19 @@ class PytorchTrainer:
 
     def _train_batches(self, reranker, train_dataloader, n_batch_per_iter, cur_step, graphed):
         losses, since_update, replayed = [], 0, False
+        fused = getattr(self, "_use_fused", False)
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
-            done = self._graphed_step(reranker, batch) if graphed else None
+            done = None
+            if fused and not getattr(self, "_fused_failed", False):
+                done = self._fused_step(reranker, batch)
+            elif graphed and not fused:
+                done = self._graphed_step(reranker, batch)
+                replayed = replayed or done is not None
             if done is not None:
                 losses.append(done)
-                replayed = True
             else:
-                if graphed and since_update == 0:
+                if graphed and not fused and since_update == 0:
                     # a batch the graph cannot take (another shape): after a replay every p.grad IS the graph's static gradient tensor,
                     # still holding the previous step's values - backward() would add to them
                     self.optimizer.zero_grad(set_to_none=True)
@@ -384,8 +408,11 @@ class PytorchTrainer:
             self.scaler = torch.amp.GradScaler("cuda")
         else:
             self._train_autocast, self.scaler = contextlib.nullcontext, None
-        self._train_graph, self._graph_failed = None, False
-        if self._graph_allowed():      # the captured step needs Adam's device-side step count and a device scalar as the learning rate
+        self._train_graph, self._graph_failed, self._fused_failed = None, False, False
+        self._use_fused = self._fused_allowed(reranker)
+        if self._use_fused:            # the reranker's own step kernels update parameters and moments of the reference's plain Adam
+            self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=self.config["lr"])
+        elif self._graph_allowed():    # the captured step needs Adam's device-side step count and a device scalar as the learning rate
             self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()),
                                               lr=torch.tensor(float(self.config["lr"]), device=self.device), capturable=True)
         else:

@@ -98,6 +98,23 @@ int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int 
                          int D, const float* mu, const float* sigma, int K, float* feat_out, float* dfdmu_out,
                          float* dfdsigma_out, int* status, void* stream);
 
+/* One KNRM training step on the device, no host round trip (reference capreolus/trainer/pytorch.py:93-108):
+ * `reranker.score()` on B (query, positive document, negative document) triples -> the trainer's pairwise loss (loss_type 0: hinge,
+ * reranker/common.py:101-103; 1: softmax, :96-98) -> backward through `combine` (a single Linear, KNRM.py:27-34: `singlefc`; under tanh when
+ * `scoretanh`) and the RBF kernels' mu / sigma (when train_kernels: `gradkernels`) -> torch.optim.Adam's in-place update (betas / eps as
+ * given, no weight decay, no amsgrad).  The caller owns the step count and hands in what depends on it, computed in double as the plain
+ * Adam of the reference does: step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).
+ * ptrs: DEVICE array of 3 P device pointers, P = 2 K + 2 - the parameters (mu_0 .. mu_{K-1}, sigma_0 .. sigma_{K-1}: one scalar each, as the
+ * reference's state_dict names them, common.py:229-230; the Linear's weight [K]; its bias [1]), then their exp_avg, then their exp_avg_sq
+ * (the mu / sigma moments may be NULL when !train_kernels).  loss_out: [1] the batch's mean loss.  workspace:
+ * capamd_knrm_train_step_workspace_floats(B, K) floats.  B <= 1024.  Four launches on `stream`: a gather of the scalar parameters, the two
+ * feature launches of capamd_knrm_features, one workgroup for everything that is per batch. */
+size_t capamd_knrm_train_step_workspace_floats(int B, int K);
+int capamd_knrm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, int B, int Q, int L, const float* packed,
+                           int64_t V, int D, int K, float* const* ptrs, int train_kernels, int scoretanh, int loss_type, float step_size,
+                           float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace,
+                           size_t workspace_floats, int* status, void* stream);
+
 /* Same scoring from a device-resident candidate store (replaces the per-sample
  * PredSampler -> DataLoader collate -> .to(device) of capreolus/sampler/__init__.py:207-264 and
  * trainer/pytorch.py:334-342): the run's query / document id rows are uploaded ONCE as int32 tables
@@ -146,9 +163,15 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * Pairs are laid out list after list: list l owns pairs list_offsets_host[l] .. list_offsets_host[l+1] (a HOST array of n_lists + 1
  * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row).  Ids either as [B,Q] / [B,L] int64
  * (q_ids, d_ids; the table arguments NULL) or through a candidate store (q_table, d_table, pair_q, pair_d; q_ids / d_ids NULL).
- * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V) bytes (16-byte aligned; any
- * contents; 17 B x V + 5 KB per list in flight, at most 64 lists at a time - fewer if the buffer is smaller, CAPAMD_ERR_WORKSPACE below one). */
-size_t capamd_lists_workspace_bytes(int n_lists, int64_t V);
+ * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V, n_pairs, L) bytes (16-byte aligned;
+ * any contents), in two parts:
+ *   per PAIR of the call   4 x L + 32 bytes: the document's real term ids, compacted to int32 by the first pass (what the pooling pass reads
+ *                          instead of the [L] id row), and its pad / OOV counts - 3.2 KB per pair at L = 800 (capamd_pacrr_forward_lists does not
+ *                          use this part: pass n_pairs = 0 for it)
+ *   per LIST in flight     17 B x V + 5 KB (a 16-byte table entry and a flag byte per vocabulary id): 6.8 MB at V = 400,001, 68 MB at V = 4 M;
+ *                          at most 64 lists are in flight at a time - FEWER when the buffer is smaller (a caller bounds the workspace by
+ *                          handing in less: the lists are then processed in more, smaller groups; CAPAMD_ERR_WORKSPACE below one list). */
+size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L);
 int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
                               const int32_t* pair_d, const int64_t* list_offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V,
                               int D, const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden, const float* w2,

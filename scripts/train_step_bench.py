@@ -81,4 +81,21 @@ for name, r in (("KNRM", KNRM({}, ext)), ("DRMM", DRMM({}, ext)), ("DRMMTKS", DR
             tr._graphed_step(r, d)
         g_ms, g_wall, gl = timed(lambda: tr._graphed_step(r, d))
         rec.update(ms_per_step=round(g_ms, 3), wall_ms_per_step=round(g_wall, 3), train_steps_per_s=round(1e3 / g_ms, 1), loss_last_graph=round(float(gl), 5))
+    # ... and as the reranker's own fused step where it has one (capamd_knrm_train_step: four launches, plain Adam state updated in place)
+    if callable(getattr(r, "fused_train_step", None)):
+        del m
+        r = type(r)({}, ext)
+        torch.manual_seed(0)
+        m = r.build_model().to(dev).train()
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        from capreolus_amd import engine
+
+        with engine.deferred_status(dev):
+            first = r.fused_train_step(d, opt)
+            if first is not None:
+                for _ in range(2):
+                    r.fused_train_step(d, opt)
+                f_ms, f_wall, fl = timed(lambda: r.fused_train_step(d, opt))
+                rec.update(fused_ms_per_step=round(f_ms, 3), fused_wall_ms_per_step=round(f_wall, 3), fused_train_steps_per_s=round(1e3 / max(f_ms, f_wall), 1),
+                           loss_last_fused=round(float(fl), 5))
     print(json.dumps(rec))

@@ -1510,6 +1510,74 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
     assert moved > 1e-3          # the five steps did train something
 
 
+@pytest.mark.parametrize("name,softmax", [("default", False), ("ranklist", True), ("glove50_short", False)])
+def test_knrm_fused_training_steps_equal_eager_steps(name, softmax):
+    """Row N3 as one device step (capamd_knrm_train_step: score(pos), score(neg), the pairwise loss, backward through `combine` and the RBF
+    kernels, Adam - four launches, no autograd): five steps leave every parameter AND the optimizer's state where five eager steps of the
+    reference's own sequence leave them - reranker.score() under autograd, the trainer's loss, loss.backward(), torch.optim.Adam.step()
+    (plain Adam on both sides, with the per-step learning-rate schedule)."""
+    import contextlib
+
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("knrm", name)
+    B = min(32, c["query"].shape[0])
+    rs = np.random.RandomState(5)
+    batches = []
+    for _ in range(5):
+        perm = rs.permutation(c["query"].shape[0])
+        batches.append({"qid": [str(i) for i in range(B)], "query": torch.as_tensor(c["query"][:B]), "query_idf": torch.as_tensor(c["query_idf"][:B]),
+                        "posdoc": torch.as_tensor(c["posdoc"][:B]), "negdoc": torch.as_tensor(c["posdoc"][perm[:B]])})
+
+    def run(fused):
+        r = _knrm_model(c)
+        if not r.model.p["singlefc"]:
+            pytest.skip("two-layer combine keeps the autograd route")
+        m = r.model
+        m.train()
+        t = PytorchTrainer({"batch": B, "itersize": 5 * B, "lr": 0.01, "warmupiters": 1, "decay": 0.5, "decaytype": "linear", "graph": False, "fused": fused,
+                            "softmaxloss": softmax})
+        t.device, t.scaler, t._train_autocast = torch.device(DEV), None, contextlib.nullcontext
+        t.loss = t.pair_softmax_loss if softmax else t.pair_hinge_loss
+        t._train_graph, t._graph_failed, t._fused_failed = None, False, False
+        t._use_fused = t._fused_allowed(r)
+        assert t._use_fused == fused
+        t.optimizer = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.01)
+        t._set_lr(0)
+        loss = t.single_train_iteration(r, batches, cur_iter=1)
+        assert not t._fused_failed
+        sd = t.optimizer.state_dict()
+        return float(loss), {k: v.detach().cpu().clone() for k, v in m.named_parameters() if v.requires_grad}, sd
+
+    loss_e, eager, sd_e = run(False)
+    loss_f, fused, sd_f = run(True)
+    assert abs(loss_e - loss_f) <= 2e-6 * max(1.0, abs(loss_e)), (loss_e, loss_f)
+    moved = 0.0
+    # The Linear's bias is added to the positive AND the negative score: without the final tanh its gradient under a pairwise loss is
+    # exactly zero.  The fused step computes that zero; autograd sums +1/B and -1/B over the batch's rows, and Adam turns the rounding
+    # residue of that sum (1e-9) into a step of +-lr whichever way it falls - the reference's bias "trains" on noise.  Not compared.
+    noise = {"combine.0.bias"} if not bool(c["scoretanh"]) else set()
+    for k, v in eager.items():
+        init = torch.as_tensor(np.asarray(c["sd." + k])).reshape(v.shape)
+        if k in noise:
+            assert float((fused[k] - init).abs().max()) == 0.0 and float((v - init).abs().max()) <= 5 * 0.01 * 1.001
+            continue
+        scale = float(v.abs().max()) + 1e-6
+        assert float((fused[k] - v).abs().max()) <= 2e-4 * scale, (k, float((fused[k] - v).abs().max()), scale)
+        moved = max(moved, float((v - init).abs().max()))
+    assert moved > 1e-3          # the five steps did train something
+    # the optimizer's state is a plain Adam state on both routes: same step counts, same moments
+    assert sd_e["param_groups"][0]["lr"] == pytest.approx(sd_f["param_groups"][0]["lr"])
+    names = [k for k, v in _knrm_model(c).model.named_parameters() if v.requires_grad]
+    for i, st in sd_e["state"].items():
+        assert float(st["step"]) == float(sd_f["state"][i]["step"]) == 5.0
+        if names[i] in noise:
+            continue
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = st[key].cpu(), sd_f["state"][i][key].cpu()
+            assert float((a - b).abs().max()) <= 2e-4 * (float(a.abs().max()) + 1e-12) + 1e-12, (i, key)
+
+
 def _graph_trainer(r, B, n_batches, graph):
     import contextlib
 
