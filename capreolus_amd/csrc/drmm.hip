@@ -53,6 +53,8 @@ struct DrmmArgs {
   int32_t* counts_out;
   int* status;
   float* feat_out;  // optional [B, Q, nbins+1]: the histogram features after CH/NH/LCH (input of the feed-forward net)
+  const int64_t* d64_b;  // training step: a second block of documents - pairs split .. B - 1 take query row (b - split) and row (b - split) of d64_b
+  int split;
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce_sum(v); }   // (interaction.cuh: DPP + readlane, no LDS-pipe permutes)
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   const int lane = tid & 63;
   const int b = blockIdx.x;
   const int NB = a.nbins + 1;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  PairIds ids = pair_ids(a.ids, a.d64_b && b >= a.split ? b - a.split : b, a.Q, a.L);
+  if (a.d64_b && b >= a.split) ids.d64 = a.d64_b + (int64_t)(b - a.split) * a.L;
 
   if (tid < a.nbins) edges[tid] = a.edges[tid];
   // the first feed-forward layer's weights go where the hash of the distinct-term pass was (dead after it), when they fit
@@ -411,15 +414,8 @@ extern "C" int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, c
                      b2, out_w, out_b, out, counts_out, status, workspace, workspace_bytes, flags, stream);
 }
 
-extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
-                                    int D, const float* edges, int nbins, int hist_type, float* feat_out, int* status, void* stream) {
-  if (B == 0) return CAPAMD_OK;
-  if (!q_ids || !d_ids || !packed || !edges || !feat_out || !status) return CAPAMD_ERR_ARG;
-  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
-  if (nbins < 1 || nbins + 1 > kMaxBins || hist_type < 0 || hist_type > 2 || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
-  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
-  DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
-             nullptr, nullptr, nullptr, nullptr, status, feat_out};
+static int drmm_features_launch(DrmmArgs a, void* stream) {
+  const int B = a.B, L = a.L;
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
@@ -429,7 +425,7 @@ extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, 
     if (const int bad = lds_budget(kern, smem)) return bad;                          \
     hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
   } while (0)
-  switch (nv_for_dim(D)) {
+  switch (nv_for_dim(a.D)) {
     case 1: LAUNCH(1, 2, false, 3); break;
     case 2: LAUNCH(2, 2, false, 3); break;
     case 3: LAUNCH(3, 2, false, 3); break;
@@ -437,6 +433,188 @@ extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, 
     default: LAUNCH(5, 1, true, 6); break;
   }
 #undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+extern "C" int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                    int D, const float* edges, int nbins, int hist_type, float* feat_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !edges || !feat_out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (nbins < 1 || nbins + 1 > kMaxBins || hist_type < 0 || hist_type > 2 || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  DrmmArgs a{ids, nullptr, B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
+             nullptr, nullptr, nullptr, nullptr, status, feat_out};
+  return drmm_features_launch(a, stream);
+}
+
+// ---- one DRMM training step without a host round trip (reference trainer/pytorch.py:93-108) -----------------------
+// score() on the positive and the negative documents - matching histograms (the kernel above over the 2 B documents), the 30 -> nodes -> 1
+// tanh net per query term (DRMM.py:25), the softmax idf gate (:83-99, gateType = IDF), the output layer (:114) - the trainer's pairwise loss,
+// backward through all of it and torch.optim.Adam's update of the seven parameter tensors in place, in two launches.  ptrs: DEVICE array of
+// 3 x 7 device pointers - ffw.0.weight [nodes, NB], ffw.0.bias [nodes], ffw.2.weight [nodes], ffw.2.bias [1], gates.weight [1],
+// output_layer.weight [1], output_layer.bias [1] (NB = nbins + 1), then their exp_avg, then their exp_avg_sq.  The caller owns the step
+// count: step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), computed in double.
+constexpr int kMaxStepBatch = 1024, kMaxStepNodes = 16;
+
+struct DrmmStepArgs {
+  const float* feat;      // [2 B, Q, NB]: the positive documents, then the negative ones
+  const int64_t* q_ids;   // [B, Q]
+  const float* idf;       // [B, Q]
+  int B, Q, NB, nodes;
+  float* const* ptrs;
+  int loss_type;
+  float step_size, one_minus_beta1, beta2, eps, bc2_sqrt;
+  float* loss_out;
+  float* inter;           // workspace [B][Q]: d loss / d gate logit
+};
+
+// Phases of the one workgroup (every sum in a fixed order):  A1 a thread per (document, query term): the net's hidden activations and z;
+// A2 a thread per pair: gate, scores, loss, the gradients at the net's output and at the gate logits;  B a thread per parameter element:
+// its gradient over the batch from the LDS copies, then Adam's update.
+constexpr int kMaxStepDQ = 1024;       // 2 B Q (batches beyond it keep the graph route)
+
+__global__ __launch_bounds__(256) void drmm_step_kernel(DrmmStepArgs a) {
+  __shared__ float W1[kMaxStepNodes * kMaxBins], B1[kMaxStepNodes], W2[kMaxStepNodes], sc_par[4];
+  __shared__ float T1[kMaxStepDQ][kMaxStepNodes + 1], Z[kMaxStepDQ], DO[kMaxStepDQ];       // hidden activations | z | d loss / d o
+  __shared__ float lsum[kMaxStepBatch], dso[kMaxStepBatch], dbo[kMaxStepBatch];
+  const int tid = threadIdx.x, Q = a.Q, NB = a.NB, N = a.nodes, DQ = 2 * a.B * Q;
+  for (int i = tid; i < N * NB; i += 256) W1[i] = a.ptrs[0][i];
+  if (tid < N) { B1[tid] = a.ptrs[1][tid]; W2[tid] = a.ptrs[2][tid]; }
+  if (tid == 0) { sc_par[0] = a.ptrs[3][0]; sc_par[1] = a.ptrs[4][0]; sc_par[2] = a.ptrs[5][0]; sc_par[3] = a.ptrs[6][0]; }
+  __syncthreads();
+  const float b2 = sc_par[0], wg = sc_par[1], wo = sc_par[2], bo = sc_par[3], inv_b = 1.f / (float)a.B;
+  float* dgl = a.inter;                  // [B][Q] d loss / d gate logit (workspace)
+  for (int dq = tid; dq < DQ; dq += 256) {          // A1
+    const float* H = a.feat + (int64_t)dq * NB;
+    float o = b2;
+    for (int n = 0; n < N; ++n) {
+      float v = B1[n];
+      for (int j = 0; j < NB; ++j) v = __builtin_fmaf(W1[n * NB + j], H[j], v);
+      const float t1 = tanhf(v);
+      T1[dq][n] = t1;
+      o = __builtin_fmaf(W2[n], t1, o);
+    }
+    Z[dq] = tanhf(o);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.B; i += 256) {            // A2
+    float g[kMaxQ], sagg[2], score[2];
+    float mx = -INFINITY;
+    for (int q = 0; q < Q; ++q) {
+      g[q] = wg * a.idf[(int64_t)i * Q + q] + (a.q_ids[(int64_t)i * Q + q] == 0 ? -1e7f : 0.f);
+      mx = fmaxf(mx, g[q]);
+    }
+    float den = 0.f;
+    for (int q = 0; q < Q; ++q) { g[q] = expf(g[q] - mx); den += g[q]; }
+    for (int q = 0; q < Q; ++q) g[q] /= den;
+    for (int h = 0; h < 2; ++h) {
+      float acc = 0.f;
+      for (int q = 0; q < Q; ++q) acc = __builtin_fmaf(g[q], Z[(h * a.B + i) * Q + q], acc);
+      sagg[h] = acc;
+      score[h] = __builtin_fmaf(wo, acc, bo);
+    }
+    float li, ds[2];
+    if (a.loss_type == 0) {
+      const float mrg = 1.f - (score[0] - score[1]);
+      li = fmaxf(mrg, 0.f);
+      const float on = mrg >= 0.f ? inv_b : 0.f;
+      ds[0] = -on; ds[1] = on;
+    } else {
+      const float m2 = fmaxf(score[0], score[1]), e0 = expf(score[0] - m2), e1 = expf(score[1] - m2), p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+      li = 1.f - p0;
+      ds[0] = -p0 * p1 * inv_b; ds[1] = p0 * p1 * inv_b;
+    }
+    lsum[i] = li;
+    dso[i] = ds[0] * sagg[0] + ds[1] * sagg[1];       // d loss / d output_layer.weight of this pair
+    dbo[i] = ds[0] + ds[1];
+    float dg[kMaxQ];
+    for (int q = 0; q < Q; ++q) dg[q] = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const float dagg = ds[h] * wo;
+      float dot = 0.f;
+      for (int q = 0; q < Q; ++q) dot = __builtin_fmaf(g[q], dagg * Z[(h * a.B + i) * Q + q], dot);
+      for (int q = 0; q < Q; ++q) {
+        const float z = Z[(h * a.B + i) * Q + q];
+        dg[q] += g[q] * (dagg * z - dot);                               // softmax backward
+        DO[(h * a.B + i) * Q + q] = dagg * g[q] * (1.f - z * z);       // d loss / d o_q (the second layer's pre-activation)
+      }
+    }
+    for (int q = 0; q < Q; ++q) dgl[(int64_t)i * Q + q] = dg[q];
+  }
+  __syncthreads();
+  __threadfence_block();
+  const int n_el = N * NB + N + N + 4;
+  for (int j = tid; j <= n_el; j += 256) {          // B
+    if (j == n_el) {
+      float l = 0.f;
+      for (int i = 0; i < a.B; ++i) l += lsum[i];
+      a.loss_out[0] = l * inv_b;
+      continue;
+    }
+    float gsum = 0.f;
+    int slot, el;
+    if (j < N * NB) {                       // ffw.0.weight[n][jb] = sum d_o W2[n] (1 - t1^2) H[jb]
+      slot = 0; el = j;
+      const int n = j / NB, jb = j % NB;
+      const float w2n = W2[n];
+#pragma unroll 8
+      for (int dq = 0; dq < DQ; ++dq) gsum = __builtin_fmaf(DO[dq] * w2n * (1.f - T1[dq][n] * T1[dq][n]), a.feat[(int64_t)dq * NB + jb], gsum);
+    } else if (j < N * NB + N) {            // ffw.0.bias[n]
+      slot = 1; el = j - N * NB;
+      for (int dq = 0; dq < DQ; ++dq) gsum += DO[dq] * W2[el] * (1.f - T1[dq][el] * T1[dq][el]);
+    } else if (j < N * NB + 2 * N) {        // ffw.2.weight[n] = sum d_o t1[n]
+      slot = 2; el = j - N * NB - N;
+      for (int dq = 0; dq < DQ; ++dq) gsum = __builtin_fmaf(DO[dq], T1[dq][el], gsum);
+    } else {
+      const int w = j - N * NB - 2 * N;     // 0: ffw.2.bias, 1: gates.weight, 2: output_layer.weight, 3: output_layer.bias
+      slot = 3 + w; el = 0;
+      if (w == 0) {
+        for (int dq = 0; dq < DQ; ++dq) gsum += DO[dq];
+      } else if (w == 1) {
+        for (int i = 0; i < a.B * Q; ++i) gsum = __builtin_fmaf(dgl[i], a.idf[i], gsum);
+      } else if (w == 2) {
+        for (int i = 0; i < a.B; ++i) gsum += dso[i];
+      } else {
+        for (int i = 0; i < a.B; ++i) gsum += dbo[i];
+      }
+    }
+    float* pp = a.ptrs[slot] + el;
+    float* pm = a.ptrs[7 + slot] + el;
+    float* pv = a.ptrs[14 + slot] + el;
+    float m = *pm, v = *pv;
+    m = m + (gsum - m) * a.one_minus_beta1;                    // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (1.f - a.beta2) * (gsum * gsum);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    *pm = m;
+    *pv = v;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    *pp = *pp - a.step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+  }
+}
+
+extern "C" size_t capamd_drmm_train_step_workspace_floats(int B, int Q, int nbins, int nodes) {
+  return B > 0 && Q > 0 && nbins > 0 && nodes > 0 ? (size_t)2 * B * Q * (nbins + 1) + (size_t)B * Q : 0;
+}
+
+extern "C" int capamd_drmm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, const float* idf, int B, int Q, int L,
+                                      const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type, int nodes, float* const* ptrs,
+                                      int loss_type, float step_size, float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out,
+                                      float* workspace, size_t workspace_floats, int* status, void* stream) {
+  if (!q_ids || !pos_ids || !neg_ids || !idf || !packed || !edges || !ptrs || !loss_out || !workspace || !status) return CAPAMD_ERR_ARG;
+  if (B < 1 || B > kMaxStepBatch || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (nbins < 1 || nbins + 1 > kMaxBins || hist_type < 0 || hist_type > 2 || nodes < 1 || nodes > kMaxStepNodes || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  if (loss_type < 0 || loss_type > 1 || !(bc2_sqrt > 0.f) || 2 * B * Q > kMaxStepDQ) return CAPAMD_ERR_ARG;
+  if (workspace_floats < capamd_drmm_train_step_workspace_floats(B, Q, nbins, nodes)) return CAPAMD_ERR_WORKSPACE;
+  const int NB = nbins + 1;
+  float* feat = workspace;
+  float* inter = workspace + (size_t)2 * B * Q * NB;
+  const IdSource ids{q_ids, pos_ids, nullptr, nullptr, nullptr, nullptr};
+  DrmmArgs fa{ids, nullptr, 2 * B, Q, L, packed, V, D, edges, nbins, hist_type, 0, nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr,
+              nullptr, nullptr, nullptr, nullptr, status, feat, neg_ids, B};
+  const int rc = drmm_features_launch(fa, stream);
+  if (rc != CAPAMD_OK) return rc;
+  DrmmStepArgs a{feat, q_ids, idf, B, Q, NB, nodes, ptrs, loss_type, step_size, one_minus_beta1, beta2, eps, bc2_sqrt, loss_out, inter};
+  hipLaunchKernelGGL(drmm_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 

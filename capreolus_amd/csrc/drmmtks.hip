@@ -34,6 +34,8 @@ struct TksArgs {
   float* out;
   int* status;
   float* feat;           // training-step mode (capamd_drmmtks_features): [B][Q][topk] sorted top-k similarities instead of scores
+  const int64_t* d64_b;  // training step: a second block of documents - pairs split .. B - 1 take query row (b - split) and row (b - split) of d64_b
+  int split;
 };
 
 #ifndef CAPAMD_TKS_U
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
 
   const int tid = threadIdx.x, lane16 = tid & 15, g = tid >> 4, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x, K = a.topk;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  PairIds ids = pair_ids(a.ids, a.d64_b && b >= a.split ? b - a.split : b, a.Q, a.L);
+  if (a.d64_b && b >= a.split) ids.d64 = a.d64_b + (int64_t)(b - a.split) * a.L;
 
   // the document's distinct real terms with their multiplicities (interaction.cuh: distinct_terms): a repeated term is gathered once
   // and its similarity enters the top-k lists as many times as the document repeats it (at most k copies can matter)
@@ -202,14 +205,8 @@ extern "C" int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
-extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
-                                       int D, int topk, float* features, int* status, void* stream) {
-  if (B == 0) return CAPAMD_OK;
-  if (!q_ids || !d_ids || !packed || !features || !status) return CAPAMD_ERR_ARG;
-  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
-  if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
-  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
-  TksArgs a{ids, nullptr, B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, features};
+static int drmmtks_features_launch(TksArgs a, int D, void* stream) {
+  const int B = a.B, L = a.L, topk = a.topk;
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kGroupsPerWG * kQT * kMaxTopK + 2 * kMaxQ + 56 + 2 * kHashSlots) * 4 + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
@@ -228,5 +225,148 @@ extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_id
     default: LAUNCH(5); break;
   }
 #undef LAUNCH
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+extern "C" int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                       int D, int topk, float* features, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !features || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  TksArgs a{ids, nullptr, B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, features};
+  return drmmtks_features_launch(a, D, stream);
+}
+
+// ---- one DRMM-TKS training step without a host round trip (reference trainer/pytorch.py:93-108) -------------------
+// score() on the positive and the negative documents - top-k features (the kernel above over the 2 B documents), Linear(topk, 1) / tanh per
+// query term, softmax idf gate, output layer (DRMMTKS.py:57-62) - the trainer's pairwise loss, backward through all of it, and
+// torch.optim.Adam's update of the five parameter tensors in place, in two launches.  ptrs: DEVICE array of 3 x 5 device pointers - the
+// parameters ffw.0.weight [topk], ffw.0.bias [1], gates.weight [1], output_layer.weight [1], output_layer.bias [1], then their exp_avg, then
+// their exp_avg_sq.  The caller owns the step count: step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), computed in double.
+constexpr int kMaxStepBatch = 1024;
+
+struct TksStepArgs {
+  const float* feat;      // [2 B, Q, topk]: the positive documents, then the negative ones
+  const int64_t* q_ids;   // [B, Q]
+  const float* idf;       // [B, Q]
+  int B, Q, topk;
+  float* const* ptrs;
+  int loss_type;
+  float step_size, one_minus_beta1, beta2, eps, bc2_sqrt;
+  float* loss_out;
+  float* grads;           // [B][topk + 4] per-pair gradient contributions (workspace)
+};
+
+__global__ __launch_bounds__(256) void drmmtks_step_kernel(TksStepArgs a) {
+  __shared__ float wf[kMaxTopK], sc_par[4], lsum[kMaxStepBatch];
+  const int tid = threadIdx.x, K = a.topk, Q = a.Q, NP = K + 4;
+  if (tid < K) wf[tid] = a.ptrs[0][tid];
+  if (tid == 0) { sc_par[0] = a.ptrs[1][0]; sc_par[1] = a.ptrs[2][0]; sc_par[2] = a.ptrs[3][0]; sc_par[3] = a.ptrs[4][0]; }
+  __syncthreads();
+  const float bf = sc_par[0], wg = sc_par[1], wo = sc_par[2], bo = sc_par[3], inv_b = 1.f / (float)a.B;
+  for (int i = tid; i < a.B; i += 256) {
+    float z[2][kMaxQ], g[kMaxQ], sagg[2], score[2];
+    // the gate: one per PAIR (the query is the same for both documents)
+    float gl[kMaxQ], mx = -INFINITY;
+    for (int q = 0; q < Q; ++q) {
+      gl[q] = wg * a.idf[(int64_t)i * Q + q] + (a.q_ids[(int64_t)i * Q + q] == 0 ? -1e7f : 0.f);     // DRMMTKS.py:38
+      mx = fmaxf(mx, gl[q]);
+    }
+    float den = 0.f;
+    for (int q = 0; q < Q; ++q) { g[q] = expf(gl[q] - mx); den += g[q]; }
+    for (int q = 0; q < Q; ++q) g[q] /= den;
+    for (int h = 0; h < 2; ++h) {
+      const float* T = a.feat + ((int64_t)(h * a.B + i) * Q) * K;
+      float acc = 0.f;
+      for (int q = 0; q < Q; ++q) {
+        float v = bf;
+        for (int j = 0; j < K; ++j) v = __builtin_fmaf(wf[j], T[q * K + j], v);
+        z[h][q] = tanhf(v);
+        acc = __builtin_fmaf(g[q], z[h][q], acc);
+      }
+      sagg[h] = acc;
+      score[h] = __builtin_fmaf(wo, acc, bo);
+    }
+    float li, ds[2];
+    if (a.loss_type == 0) {
+      const float mrg = 1.f - (score[0] - score[1]);
+      li = fmaxf(mrg, 0.f);
+      const float on = mrg >= 0.f ? inv_b : 0.f;
+      ds[0] = -on; ds[1] = on;
+    } else {
+      const float m2 = fmaxf(score[0], score[1]), e0 = expf(score[0] - m2), e1 = expf(score[1] - m2), p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+      li = 1.f - p0;
+      ds[0] = -p0 * p1 * inv_b; ds[1] = p0 * p1 * inv_b;
+    }
+    lsum[i] = li;
+    // backward: this pair's contribution to every parameter element
+    float* G = a.grads + (int64_t)i * NP;
+    float dwf[kMaxTopK], dbf = 0.f, dwg = 0.f, dwo = 0.f, dbo = 0.f;
+    for (int j = 0; j < K; ++j) dwf[j] = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const float* T = a.feat + ((int64_t)(h * a.B + i) * Q) * K;
+      dbo += ds[h];
+      dwo = __builtin_fmaf(ds[h], sagg[h], dwo);
+      const float dagg = ds[h] * wo;
+      float dot = 0.f;                       // sum_r g_r dg_r with dg_r = dagg z_r
+      for (int q = 0; q < Q; ++q) dot = __builtin_fmaf(g[q], dagg * z[h][q], dot);
+      for (int q = 0; q < Q; ++q) {
+        const float dgl = g[q] * (dagg * z[h][q] - dot);      // softmax backward
+        dwg = __builtin_fmaf(dgl, a.idf[(int64_t)i * Q + q], dwg);
+        const float da = dagg * g[q] * (1.f - z[h][q] * z[h][q]);
+        dbf += da;
+        for (int j = 0; j < K; ++j) dwf[j] = __builtin_fmaf(da, T[q * K + j], dwf[j]);
+      }
+    }
+    for (int j = 0; j < K; ++j) G[j] = dwf[j];
+    G[K] = dbf; G[K + 1] = dwg; G[K + 2] = dwo; G[K + 3] = dbo;
+  }
+  __syncthreads();      // (one workgroup: the barrier also orders its global writes for its own reads below)
+  __threadfence_block();
+  const int j = tid;
+  if (j > NP) return;
+  if (j == NP) {
+    float l = 0.f;
+    for (int i = 0; i < a.B; ++i) l += lsum[i];
+    a.loss_out[0] = l * inv_b;
+    return;
+  }
+  float gsum = 0.f;
+  for (int i = 0; i < a.B; ++i) gsum += a.grads[(int64_t)i * NP + j];
+  const int slot = j < K ? 0 : j - K + 1, el = j < K ? j : 0;
+  float* pp = a.ptrs[slot] + el;
+  float* pm = a.ptrs[5 + slot] + el;
+  float* pv = a.ptrs[10 + slot] + el;
+  float m = *pm, v = *pv;
+  m = m + (gsum - m) * a.one_minus_beta1;                    // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.beta2 + (1.f - a.beta2) * (gsum * gsum);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+  *pm = m;
+  *pv = v;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  *pp = *pp - a.step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+}
+
+extern "C" size_t capamd_drmmtks_train_step_workspace_floats(int B, int Q, int topk) {
+  return B > 0 && Q > 0 && topk > 0 ? (size_t)2 * B * Q * topk + (size_t)B * (topk + 4) : 0;
+}
+
+extern "C" int capamd_drmmtks_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, const float* idf, int B, int Q, int L,
+                                         const float* packed, int64_t V, int D, int topk, float* const* ptrs, int loss_type, float step_size,
+                                         float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace,
+                                         size_t workspace_floats, int* status, void* stream) {
+  if (!q_ids || !pos_ids || !neg_ids || !idf || !packed || !ptrs || !loss_out || !workspace || !status) return CAPAMD_ERR_ARG;
+  if (B < 1 || B > kMaxStepBatch || Q < 1 || Q > kMaxQ || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL) return CAPAMD_ERR_ARG;
+  if (topk < 1 || topk > kMaxTopK || topk > L || capamd_packed_row_stride(D) < 0 || loss_type < 0 || loss_type > 1 || !(bc2_sqrt > 0.f)) return CAPAMD_ERR_ARG;
+  if (workspace_floats < capamd_drmmtks_train_step_workspace_floats(B, Q, topk)) return CAPAMD_ERR_WORKSPACE;
+  float* feat = workspace;
+  float* grads = workspace + (size_t)2 * B * Q * topk;
+  const IdSource ids{q_ids, pos_ids, nullptr, nullptr, nullptr, nullptr};
+  TksArgs fa{ids, nullptr, 2 * B, Q, L, packed, V, topk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, status, feat, neg_ids, B};
+  const int rc = drmmtks_features_launch(fa, D, stream);
+  if (rc != CAPAMD_OK) return rc;
+  TksStepArgs a{feat, q_ids, idf, B, Q, topk, ptrs, loss_type, step_size, one_minus_beta1, beta2, eps, bc2_sqrt, loss_out, grads};
+  hipLaunchKernelGGL(drmmtks_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }

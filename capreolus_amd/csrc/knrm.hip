@@ -58,6 +58,11 @@ struct KnrmArgs {
   float* feat;      // GRAD: [B, K] kernel-pooling features f_k (the input of `combine`)
   float* dfdmu;     // GRAD: [B, K] d f_k / d mu_k      (may be NULL)
   float* dfdsigma;  // GRAD: [B, K] d f_k / d sigma_k   (may be NULL)
+  // GRAD, training step: the kernel parameters as the reference keeps them - one scalar tensor each (ptrs[k] = mu_k, ptrs[K + k] = sigma_k)
+  // - and a second block of documents: pairs split .. B - 1 take query row (b - split) and document row (b - split) of d64_b
+  float* const* kptrs;
+  const int64_t* d64_b;
+  int split;
 };
 
 // GRAD additionally accumulates sum_j K (s - mu) and sum_j K (s - mu)^2, which give d f_k / d mu_k and d f_k / d sigma_k
@@ -88,7 +93,8 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const int b = blockIdx.x;
-  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  PairIds ids = pair_ids(a.ids, GRAD && a.d64_b && b >= a.split ? b - a.split : b, a.Q, a.L);
+  if (GRAD && a.d64_b && b >= a.split) ids.d64 = a.d64_b + (int64_t)(b - a.split) * a.L;
 
   // ---- phase 1: the document's distinct real terms with their multiplicities (interaction.cuh) ---------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
@@ -103,15 +109,16 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int k = krow + 4 * s, kc = k < a.K ? k : a.K - 1;
-      sg_l[s] = a.sigma[kc];
-      mu_l[s] = a.mu[kc];
+      sg_l[s] = (GRAD && a.kptrs) ? *a.kptrs[a.K + kc] : a.sigma[kc];
+      mu_l[s] = (GRAD && a.kptrs) ? *a.kptrs[kc] : a.mu[kc];
     }
     // ... and with them what the per-pair tail needs (kernel k's mu / sigma, the single Linear's weights): from LDS there instead of
     // from global memory - thread 0's 11-term combine was four to five dependent memory round trips at the very end of every pair
     if (tid < 16) {
       const int kc = tid < a.K ? tid : a.K - 1;
       // (the feature / gradient call has no combine layer: w1 and b1 are NULL there)
-      const float m = a.mu[kc], sg = a.sigma[kc], w = (a.out && a.hidden == 0) ? a.w1[kc] : 0.f, bb = a.out ? a.b1[0] : 0.f;
+      const float m = (GRAD && a.kptrs) ? *a.kptrs[kc] : a.mu[kc], sg = (GRAD && a.kptrs) ? *a.kptrs[a.K + kc] : a.sigma[kc],
+                  w = (a.out && a.hidden == 0) ? a.w1[kc] : 0.f, bb = a.out ? a.b1[0] : 0.f;
       Clds[tid] = m;
       Clds[16 + tid] = sg;
       Clds[32 + tid] = w;
@@ -486,24 +493,15 @@ extern "C" int capamd_knrm_forward(const int64_t* q_ids, const int64_t* d_ids, i
                      stream);
 }
 
-extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
-                                    int D, const float* mu, const float* sigma, int K, float* feat_out, float* dfdmu_out,
-                                    float* dfdsigma_out, int* status, void* stream) {
-  if (B == 0) return CAPAMD_OK;
-  if (!q_ids || !d_ids || !packed || !mu || !sigma || !feat_out || !status) return CAPAMD_ERR_ARG;
-  if (B < 0 || Q < 1 || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || K < 1 || K > kMaxK) return CAPAMD_ERR_ARG;
-  if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
-  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
-  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
-             dfdsigma_out};
-  const size_t smem = (size_t)((L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 64) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
+static int knrm_features_launch(KnrmArgs a, int D, void* stream) {
+  const size_t smem = (size_t)((a.L + 3) & ~3) * 8 + (3072 + 144 + 48 + kMaxHidden + 48 + 8 + 64) * 4 + dedup_hash_bytes(a.L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
 #define LAUNCH(NV_)                                                                  \
   do {                                                                               \
     auto kern = knrm_forward_kernel<NV_, 1, true, 4, true>;                          \
     if (const int bad = lds_budget(kern, smem)) return bad;                          \
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), smem, s, a);                   \
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kThreads), smem, s, a);                 \
   } while (0)
   switch (nv_for_dim(D)) {
     case 1: LAUNCH(1); break;
@@ -516,12 +514,25 @@ extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, 
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
+extern "C" int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
+                                    int D, const float* mu, const float* sigma, int K, float* feat_out, float* dfdmu_out,
+                                    float* dfdsigma_out, int* status, void* stream) {
+  if (B == 0) return CAPAMD_OK;
+  if (!q_ids || !d_ids || !packed || !mu || !sigma || !feat_out || !status) return CAPAMD_ERR_ARG;
+  if (B < 0 || Q < 1 || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || K < 1 || K > kMaxK) return CAPAMD_ERR_ARG;
+  if (capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
+  const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
+  KnrmArgs a{ids, B, Q, L, packed, V, mu, sigma, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat_out, dfdmu_out,
+             dfdsigma_out};
+  return knrm_features_launch(a, D, stream);
+}
+
 // ---- one KNRM training step without a host round trip (reference trainer/pytorch.py:93-108) -----------------------
 // score() on the positive and the negative documents -> pairwise hinge (reranker/common.py:101-103) or softmax (:96-98) loss -> backward
 // through `combine` (a single Linear, KNRM.py:27-34, optionally under tanh) and the RBF kernels' mu / sigma -> torch.optim.Adam's update
 // (no weight decay, no amsgrad; bias corrections computed by the caller in double, as the plain Adam of the reference does), all on the
-// device: the two feature launches above (values + d f / d mu, d f / d sigma per document), a gather of the 2 K scalar parameters, and ONE
-// workgroup for everything that is per batch.  Parameters and Adam moments are updated IN PLACE through a table of device pointers
+// device, in TWO launches: the feature kernel above over the 2 B documents (values + d f / d mu, d f / d sigma per document; it reads
+// the 2 K scalar kernel parameters through the pointer table) and ONE workgroup for everything that is per batch.  Parameters and Adam moments are updated IN PLACE through a table of device pointers
 // (the reference's state_dict names one scalar nn.Parameter per kernel and quantity, common.py:229-230):
 //   ptrs[0 .. P)  the parameters, [P .. 2 P) their exp_avg, [2 P .. 3 P) their exp_avg_sq;  P = 2 K + 2:  mu_0 .. mu_{K-1}, sigma_0 .. sigma_{K-1},
 //   the Linear's weight [K], its bias [1]
@@ -537,14 +548,6 @@ struct KnrmStepArgs {
   float step_size, one_minus_beta1, beta2, eps, bc2_sqrt;
   float* loss_out;
 };
-
-__global__ void knrm_stack_kernel(float* const* ptrs, int K, float* mu, float* sigma) {
-  const int t = threadIdx.x;
-  if (t < K) {
-    mu[t] = *ptrs[t];
-    sigma[t] = *ptrs[K + t];
-  }
-}
 
 __global__ __launch_bounds__(256) void knrm_step_kernel(KnrmStepArgs a) {
   __shared__ float W[kMaxK + 4], gsc[2][kMaxStepBatch], lsum[kMaxStepBatch];
@@ -619,25 +622,24 @@ __global__ __launch_bounds__(256) void knrm_step_kernel(KnrmStepArgs a) {
   *pp = *pp - a.step_size * (m / denom);                     // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
 }
 
-extern "C" size_t capamd_knrm_train_step_workspace_floats(int B, int K) { return B > 0 && K > 0 ? (size_t)32 + (size_t)6 * B * K : 0; }
+extern "C" size_t capamd_knrm_train_step_workspace_floats(int B, int K) { return B > 0 && K > 0 ? (size_t)6 * B * K : 0; }
 
 extern "C" int capamd_knrm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, int B, int Q, int L, const float* packed,
                                       int64_t V, int D, int K, float* const* ptrs, int train_kernels, int scoretanh, int loss_type, float step_size,
                                       float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace,
                                       size_t workspace_floats, int* status, void* stream) {
   if (!q_ids || !pos_ids || !neg_ids || !packed || !ptrs || !loss_out || !workspace || !status) return CAPAMD_ERR_ARG;
-  if (B < 1 || B > kMaxStepBatch || K < 1 || K > kMaxK || loss_type < 0 || loss_type > 1 || !(bc2_sqrt > 0.f)) return CAPAMD_ERR_ARG;
+  if (B < 1 || B > kMaxStepBatch || Q < 1 || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || K < 1 || K > kMaxK) return CAPAMD_ERR_ARG;
+  if (loss_type < 0 || loss_type > 1 || !(bc2_sqrt > 0.f) || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if (workspace_floats < capamd_knrm_train_step_workspace_floats(B, K)) return CAPAMD_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  float *mu = workspace, *sigma = workspace + 16, *w = workspace + 32;
   const size_t n = (size_t)B * K;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(knrm_stack_kernel, dim3(1), dim3(64), 0, s, ptrs, K, mu, sigma);
-  int rc = capamd_knrm_features(q_ids, pos_ids, B, Q, L, packed, V, D, mu, sigma, K, w, w + n, w + 2 * n, status, stream);
+  float *feat = workspace, *dmu = workspace + 2 * n, *dsg = workspace + 4 * n;       // [2 B, K] each: the positive documents, then the negative ones
+  const IdSource ids{q_ids, pos_ids, nullptr, nullptr, nullptr, nullptr};
+  KnrmArgs fa{ids, 2 * B, Q, L, packed, V, nullptr, nullptr, K, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, status, feat, dmu, dsg, ptrs, neg_ids, B};
+  const int rc = knrm_features_launch(fa, D, stream);
   if (rc != CAPAMD_OK) return rc;
-  rc = capamd_knrm_features(q_ids, neg_ids, B, Q, L, packed, V, D, mu, sigma, K, w + 3 * n, w + 4 * n, w + 5 * n, status, stream);
-  if (rc != CAPAMD_OK) return rc;
-  KnrmStepArgs a{{w, w + 3 * n}, {w + n, w + 4 * n}, {w + 2 * n, w + 5 * n}, B, K, ptrs, train_kernels, scoretanh, loss_type, step_size,
+  KnrmStepArgs a{{feat, feat + n}, {dmu, dmu + n}, {dsg, dsg + n}, B, K, ptrs, train_kernels, scoretanh, loss_type, step_size,
                  one_minus_beta1, beta2, eps, bc2_sqrt, loss_out};
   hipLaunchKernelGGL(knrm_step_kernel, dim3(1), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;

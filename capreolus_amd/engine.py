@@ -623,11 +623,7 @@ def knrm_train_step(query, posdoc, negdoc, packed, V, D, K, adam, train_kernels,
     B, Q = q.shape
     L = dp.shape[1]
     lib = _lib.load()
-    n = int(lib.capamd_knrm_train_step_workspace_floats(B, K))
-    key = (q.device.index, int(torch.cuda.current_stream(q.device).cuda_stream))
-    ws = _step_workspaces.get(key)
-    if ws is None or ws.numel() < n:
-        ws = _step_workspaces[key] = torch.empty(n, dtype=torch.float32, device=q.device)
+    ws = _step_workspace(q.device, int(lib.capamd_knrm_train_step_workspace_floats(B, K)))
     loss = torch.empty(1, dtype=torch.float32, device=q.device)
     step_size, omb1, b2, eps, bc2s = adam.advance()
     st = status_word(q.device)
@@ -635,6 +631,53 @@ def knrm_train_step(query, posdoc, negdoc, packed, V, D, K, adam, train_kernels,
                                     int(bool(scoretanh)), int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(),
                                     _ptr(st.t), _stream())
     _lib.check(rc, "capamd_knrm_train_step")
+    if check:
+        st.raise_if_set()
+    return loss
+
+
+def _step_workspace(device, n):
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _step_workspaces.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _step_workspaces[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return ws
+
+
+def drmm_train_step(query, posdoc, negdoc, idf, packed, V, D, edges, hist_type, nodes, adam, softmax, check=True):
+    """capamd_drmm_train_step: score(pos), score(neg), the trainer's pairwise loss, backward, Adam - on the device; returns the loss [1]."""
+    _need_gpu(query, posdoc, negdoc, idf, packed, edges)
+    q, dp, dn, idf = _i64(query), _i64(posdoc), _i64(negdoc), _f32(idf)
+    B, Q = q.shape
+    L = dp.shape[1]
+    lib = _lib.load()
+    ws = _step_workspace(q.device, int(lib.capamd_drmm_train_step_workspace_floats(B, Q, edges.numel(), int(nodes))))
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    step_size, omb1, b2, eps, bc2s = adam.advance()
+    st = status_word(q.device)
+    rc = lib.capamd_drmm_train_step(_ptr(q), _ptr(dp), _ptr(dn), _ptr(idf), B, Q, L, _ptr(packed), V, D, _ptr(edges), edges.numel(), HIST_TYPES[hist_type],
+                                    int(nodes), _ptr(adam.table), int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(),
+                                    _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmm_train_step")
+    if check:
+        st.raise_if_set()
+    return loss
+
+
+def drmmtks_train_step(query, posdoc, negdoc, idf, packed, V, D, topk, adam, softmax, check=True):
+    """capamd_drmmtks_train_step: score(pos), score(neg), the trainer's pairwise loss, backward, Adam - on the device; returns the loss [1]."""
+    _need_gpu(query, posdoc, negdoc, idf, packed)
+    q, dp, dn, idf = _i64(query), _i64(posdoc), _i64(negdoc), _f32(idf)
+    B, Q = q.shape
+    L = dp.shape[1]
+    lib = _lib.load()
+    ws = _step_workspace(q.device, int(lib.capamd_drmmtks_train_step_workspace_floats(B, Q, int(topk))))
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    step_size, omb1, b2, eps, bc2s = adam.advance()
+    st = status_word(q.device)
+    rc = lib.capamd_drmmtks_train_step(_ptr(q), _ptr(dp), _ptr(dn), _ptr(idf), B, Q, L, _ptr(packed), V, D, int(topk), _ptr(adam.table), int(bool(softmax)),
+                                       step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_drmmtks_train_step")
     if check:
         st.raise_if_set()
     return loss

@@ -58,6 +58,23 @@ class DRMM_class(nn.Module):
             self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), counts_out=counts_out)
         return out.view(-1, 1)
 
+    def fused_train_step(self, d, optimizer, softmax=False):
+        """One whole training step on the device (capamd_drmm_train_step) - or None when this configuration keeps the autograd route (the
+        term-vector gate, more than 16 hidden nodes).  Parameters and Adam moments are updated in place."""
+        if self.gate_type != "IDF" or self.nodes > 16 or 2 * d["query"].numel() > 1024:       # (the step kernel's limits: 2 B Q <= 1024)
+            return None
+        params = [self.ffw[0].weight, self.ffw[0].bias, self.ffw[2].weight, self.ffw[2].bias, self.gates.weight, self.output_layer.weight,
+                  self.output_layer.bias]
+        hit = self.__dict__.get("_adam_step")
+        if hit is None or hit.optimizer is not optimizer or hit.key[: len(params)] != tuple(p.data_ptr() for p in params) or not hit.still_valid():
+            hit = self.__dict__["_adam_step"] = engine.AdamStep(optimizer, params)
+        w = self.embedding.weight
+        loss = engine.drmm_train_step(d["query"], d["posdoc"], d["negdoc"], d["query_idf"], self._packed.get(w), w.shape[0], w.shape[1],
+                                      self._bin_edges(w.device), self.hist_type, self.nodes, hit, softmax)
+        with torch.no_grad():
+            torch._foreach_mul_(hit.trained, 1.0)          # (exact no-op: the kernel wrote the parameters behind autograd's back)
+        return loss[0]
+
     def _forward_train(self, sentence, query_sentence, query_idf):
         """Training step: the matching histogram (everything that touches [B, Q, L]) is the HIP kernel and has no
         trainable inputs (DRMM.py:22 freezes the embedding); the 30 -> 5 -> 1 net, the gate and the output layer --
@@ -117,6 +134,9 @@ class DRMM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def fused_train_step(self, d, optimizer, softmax=False):
+        return self.model.fused_train_step(d, optimizer, softmax)
 
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)

@@ -49,6 +49,21 @@ class DRMMTKS_class(nn.Module):
             self.gates.weight.detach().view(-1), self.ffw[0].weight.detach().contiguous().view(-1), self.ffw[0].bias.detach(),
             self.output_layer.weight.detach().view(-1), self.output_layer.bias.detach(), query=query, doc=doc, store=store, pair_q=pair_q, pair_d=pair_d)
 
+    def fused_train_step(self, d, optimizer, softmax=False):
+        """One whole training step on the device (capamd_drmmtks_train_step); parameters and Adam moments are updated in place."""
+        if d["query"].shape[0] > 1024:
+            return None
+        params = [self.ffw[0].weight, self.ffw[0].bias, self.gates.weight, self.output_layer.weight, self.output_layer.bias]
+        hit = self.__dict__.get("_adam_step")
+        if hit is None or hit.optimizer is not optimizer or hit.key[: len(params)] != tuple(p.data_ptr() for p in params) or not hit.still_valid():
+            hit = self.__dict__["_adam_step"] = engine.AdamStep(optimizer, params)
+        w = self.embedding.weight
+        loss = engine.drmmtks_train_step(d["query"], d["posdoc"], d["negdoc"], d["query_idf"], self._packed.get(w), w.shape[0], w.shape[1], self.topk, hit,
+                                         softmax)
+        with torch.no_grad():
+            torch._foreach_mul_(hit.trained, 1.0)          # (exact no-op: the kernel wrote the parameters behind autograd's back)
+        return loss[0]
+
     def _forward_train(self, doc, query, query_idf):
         """Training step (reference trainer/pytorch.py:96-99 -> DRMMTKS.score): the gather / similarity / top-k - everything that
         touches the [B, Q, L] tensors - is the HIP kernel (capamd_drmmtks_features); the embedding table is frozen, so no
@@ -81,6 +96,9 @@ class DRMMTKS(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def fused_train_step(self, d, optimizer, softmax=False):
+        return self.model.fused_train_step(d, optimizer, softmax)
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmmtks_forward_lists)
     lists_bit_identical = True # (top-k selections of bit-identical similarities, fed to the Linear in the same order)

@@ -94,7 +94,7 @@ class KNRM_class(nn.Module):
         """One whole training step on the device (capamd_knrm_train_step: score(pos), score(neg), pairwise loss, backward, Adam) - or
         None when this configuration keeps the autograd route (a two-layer `combine`, `finetune`).  Parameters and Adam moments are
         updated in place; their version counters are bumped so that weight-derived caches notice."""
-        if not self.p["singlefc"] or self.embedding.weight.requires_grad:
+        if not self.p["singlefc"] or self.embedding.weight.requires_grad or d["query"].shape[0] > 1024:
             return None
         ks = list(self.kernels.kernels)
         lin = self.combine[0]

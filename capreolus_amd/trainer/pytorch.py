@@ -111,7 +111,7 @@ class PytorchTrainer:
         # Needs a GPU, gradacc = 1 and no loss scaling (amp = train / both); anything else, and batches of another shape, run eagerly.
         "graph": True,
         # `fused` (default on): rerankers that bring a whole training step as device kernels (`fused_train_step`: KNRM with a single-Linear
-        # `combine` - score(pos), score(neg), the pairwise loss, backward and Adam's update in four launches, capamd_knrm_train_step) train
+        # `combine` - score(pos), score(neg), the pairwise loss, backward and Adam's update in two launches, capamd_knrm_train_step) train
         # through it with the PLAIN torch.optim.Adam of the reference as the optimizer object (its state_dict / checkpoints unchanged,
         # bias corrections in double on the host).  Same conditions as `graph`; a reranker or configuration without one falls back to it.
         "fused": True,

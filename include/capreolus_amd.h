@@ -107,8 +107,8 @@ int capamd_knrm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int 
  * ptrs: DEVICE array of 3 P device pointers, P = 2 K + 2 - the parameters (mu_0 .. mu_{K-1}, sigma_0 .. sigma_{K-1}: one scalar each, as the
  * reference's state_dict names them, common.py:229-230; the Linear's weight [K]; its bias [1]), then their exp_avg, then their exp_avg_sq
  * (the mu / sigma moments may be NULL when !train_kernels).  loss_out: [1] the batch's mean loss.  workspace:
- * capamd_knrm_train_step_workspace_floats(B, K) floats.  B <= 1024.  Four launches on `stream`: a gather of the scalar parameters, the two
- * feature launches of capamd_knrm_features, one workgroup for everything that is per batch. */
+ * capamd_knrm_train_step_workspace_floats(B, K) floats.  B <= 1024.  Two launches on `stream`: capamd_knrm_features' kernel over the 2 B
+ * documents (it reads the scalar kernel parameters through `ptrs`), then one workgroup for everything that is per batch. */
 size_t capamd_knrm_train_step_workspace_floats(int B, int K);
 int capamd_knrm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, int B, int Q, int L, const float* packed,
                            int64_t V, int D, int K, float* const* ptrs, int train_kernels, int scoretanh, int loss_type, float step_size,
@@ -144,6 +144,18 @@ int capamd_drmm_forward(const int64_t* q_ids, const int64_t* d_ids, const float*
  * feed-forward net, gate and output layer run under autograd on it. */
 int capamd_drmm_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V,
                          int D, const float* edges, int nbins, int hist_type, float* feat_out, int* status, void* stream);
+
+/* One DRMM training step on the device (see capamd_knrm_train_step; reference DRMM.py:101-116 under trainer/pytorch.py:93-108; gateType = IDF):
+ * matching histograms of the 2 B documents, the 30 -> nodes -> 1 tanh net per query term, softmax idf gate, output layer, the pairwise loss
+ * (0 hinge / 1 softmax), backward and torch.optim.Adam's in-place update, in two launches.  ptrs: DEVICE array of 3 x 7 device pointers -
+ * ffw.0.weight [nodes, nbins + 1], ffw.0.bias [nodes], ffw.2.weight [nodes], ffw.2.bias [1], gates.weight [1], output_layer.weight [1],
+ * output_layer.bias [1], then their exp_avg, then their exp_avg_sq.  idf: [B, Q].  workspace:
+ * capamd_drmm_train_step_workspace_floats(B, Q, nbins, nodes) floats.  B <= 1024, nodes <= 16. */
+size_t capamd_drmm_train_step_workspace_floats(int B, int Q, int nbins, int nodes);
+int capamd_drmm_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, const float* idf, int B, int Q, int L,
+                           const float* packed, int64_t V, int D, const float* edges, int nbins, int hist_type, int nodes, float* const* ptrs,
+                           int loss_type, float step_size, float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out,
+                           float* workspace, size_t workspace_floats, int* status, void* stream);
 
 /* indexed variant (see capamd_knrm_forward_indexed); idf_table fp32 [NQ, Q] is indexed by the pair's query row */
 int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, const float* idf_table,
@@ -211,6 +223,17 @@ int capamd_drmmtks_forward(const int64_t* q_ids, const int64_t* d_ids, const flo
  * through them; the Linear(topk,1)/tanh, the idf gate and the output layer (a few dozen flops per pair) run under autograd. */
 int capamd_drmmtks_features(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* packed, int64_t V, int D,
                             int topk, float* features, int* status, void* stream);
+
+/* One DRMM-TKS training step on the device (see capamd_knrm_train_step; reference DRMMTKS.py:50-64 under trainer/pytorch.py:93-108): top-k
+ * features of the 2 B documents, Linear(topk, 1) / tanh, softmax idf gate, output layer, the pairwise loss (0 hinge / 1 softmax), backward and
+ * torch.optim.Adam's in-place update, in two launches.  ptrs: DEVICE array of 3 x 5 device pointers - ffw.0.weight [topk], ffw.0.bias [1],
+ * gates.weight [1], output_layer.weight [1], output_layer.bias [1], then their exp_avg, then their exp_avg_sq.  idf: [B, Q] of the queries.
+ * workspace: capamd_drmmtks_train_step_workspace_floats(B, Q, topk) floats.  B <= 1024. */
+size_t capamd_drmmtks_train_step_workspace_floats(int B, int Q, int topk);
+int capamd_drmmtks_train_step(const int64_t* q_ids, const int64_t* pos_ids, const int64_t* neg_ids, const float* idf, int B, int Q, int L,
+                              const float* packed, int64_t V, int D, int topk, float* const* ptrs, int loss_type, float step_size,
+                              float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace,
+                              size_t workspace_floats, int* status, void* stream);
 
 /* ---- PTBERTMaxP_Class.predict_step (capreolus/reranker/ptBERTMaxP.py:67-96) behind PTBERTMaxP.test
  * (ptBERTMaxP.py:134-135), including the transformers.BertForSequenceClassification forward it calls

@@ -81,7 +81,7 @@ for name, r in (("KNRM", KNRM({}, ext)), ("DRMM", DRMM({}, ext)), ("DRMMTKS", DR
             tr._graphed_step(r, d)
         g_ms, g_wall, gl = timed(lambda: tr._graphed_step(r, d))
         rec.update(ms_per_step=round(g_ms, 3), wall_ms_per_step=round(g_wall, 3), train_steps_per_s=round(1e3 / g_ms, 1), loss_last_graph=round(float(gl), 5))
-    # ... and as the reranker's own fused step where it has one (capamd_knrm_train_step: four launches, plain Adam state updated in place)
+    # ... and as the reranker's own fused step where it has one (capamd_{knrm,drmm,drmmtks}_train_step: two launches, plain Adam state updated in place)
     if callable(getattr(r, "fused_train_step", None)):
         del m
         r = type(r)({}, ext)
