@@ -1,10 +1,10 @@
 #!/bin/bash
-# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r03
+# Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r04
 set -eu
-D=profiles/${1:-r03}
+D=profiles/${1:-r04}
 G=gpurun_out
 mkdir -p $D
-for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_pingpong drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; done
+for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_pingpong drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; [ -f $G/bench_full_$f.json ] && cp $G/bench_full_$f.json $D/; done
 for m in knrm knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm cedrknrm; do
   f=$(ls $G/prof/$m/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${m}_bench_kernel_stats.csv
 done
@@ -28,6 +28,7 @@ cp $G/knrm_hbm_traffic.json $G/drmm_hbm_traffic.json $D/
 cp $G/pmc_summary.txt $D/pmc_summary.txt
 cp $G/mfma_power.txt $D/mfma_power.txt
 [ -f $G/hbm_read.txt ] && cp $G/hbm_read.txt $D/hbm_read.txt
+[ -f $G/valu_rates.txt ] && cp $G/valu_rates.txt $D/valu_rates.txt
 cp $G/pytest_gpu.log $D/pytest_gpu.log
 [ -f $G/train_steps.jsonl ] && cp $G/train_steps.jsonl $D/train_steps.jsonl
 [ -f $G/predict_e2e.json ] && cp $G/predict_e2e.json $D/predict_e2e.json

@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU-box session (round 3): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
-# (scripts/collect_profiles.sh r03 copies what is kept into profiles/r03/).
+# One GPU-box session (round 4): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
+# (scripts/collect_profiles.sh r04 copies what is kept into profiles/r04/).  bench.py prints ONE compact line and writes the whole record
+# to bench_full.json: both are kept per run (bench_<name>.json = the line, bench_full_<name>.json = the record).
 set -u
 rm -rf gpurun_out/prof gpurun_out/ab_*.json; mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
@@ -9,20 +10,21 @@ B="python $R/bench.py"
 ( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
 # ---- bench lines -------------------------------------------------------------------------------------------------------
-timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json
-timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-pmc-traffic --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json
-timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json
-timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json
-timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json
-timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json
-CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json
-for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; done
-PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cat gpurun_out/bench_cedrknrm.json
+timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json; cp bench_full.json gpurun_out/bench_full_default.json 2>/dev/null
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json; cp bench_full.json gpurun_out/bench_full_knrm_b1000.json 2>/dev/null
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json; cp bench_full.json gpurun_out/bench_full_knrm_b1000_serial.json 2>/dev/null
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-pmc-traffic --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json; cp bench_full.json gpurun_out/bench_full_drmm_b1000.json 2>/dev/null
+timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_out/bench_bert.json; cp bench_full.json gpurun_out/bench_full_bert.json 2>/dev/null
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json; cp bench_full.json gpurun_out/bench_full_bert_skip_padding.json 2>/dev/null
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json; cp bench_full.json gpurun_out/bench_full_bert_fp16.json 2>/dev/null
+timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json; cp bench_full.json gpurun_out/bench_full_bert_one_stream.json 2>/dev/null
+CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json; cp bench_full.json gpurun_out/bench_full_bert_pingpong.json 2>/dev/null
+for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; cp bench_full.json gpurun_out/bench_full_$mdl.json 2>/dev/null; done
+PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cp bench_full.json gpurun_out/bench_full_cedrknrm.json 2>/dev/null; cat gpurun_out/bench_cedrknrm.json
 PYTHONPATH=$R timeout 300 python $R/scripts/predict_e2e_bench.py 2>/dev/null | tail -1 > gpurun_out/predict_e2e.json; cat gpurun_out/predict_e2e.json
+timeout 120 ./scripts/ubench/valu_rates > gpurun_out/valu_rates.txt 2>&1
 PYTHONPATH=$R timeout 300 python $R/scripts/train_step_bench.py 2>/dev/null | grep "^{" > gpurun_out/train_steps.jsonl; cat gpurun_out/train_steps.jsonl
-CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
+CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cp bench_full.json gpurun_out/bench_full_cedrknrm_separate_layernorm.json 2>/dev/null; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
 python - <<'PY'
 import json
 for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):

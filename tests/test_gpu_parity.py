@@ -120,6 +120,23 @@ def test_knrm_multiquery_run_matches_the_reference_by_either_route(route):
             assert np.array_equal(rank_order(g16[a:b]), rank_order(r16[a:b]))
 
 
+def test_lists_workspace_budget_only_changes_the_grouping(monkeypatch):
+    """`engine.LISTS_WORKSPACE_BUDGET` bounds the per-list part of the whole-list workspace (17 B x V per list in flight): with room for a
+    single list the library works through the lists one by one - same scores, bit for bit, as with all of them in flight."""
+    c = load_case("knrm", "multiquery")
+    r = _knrm_model(c)
+    off = c["list_offsets"]
+    with torch.no_grad():
+        want = r.test_lists(_batch(c), off).clone()
+        engine.release_workspaces()
+        monkeypatch.setattr(engine, "LISTS_WORKSPACE_BUDGET", 17 * 20480 + 8192)       # one list's table + flags + query image
+        got = r.test_lists(_batch(c), off)
+        ws = next(iter(engine._list_workspaces.values()))
+    assert torch.equal(got, want)
+    assert ws.numel() < 1200 * (800 * 4 + 32) + 2 * (17 * 20480 + 8192)
+    engine.release_workspaces()
+
+
 def test_knrm_score_pair_interface():
     c = load_case("knrm", "default")
     r = _knrm_model(c)
@@ -876,6 +893,8 @@ def test_train_loop_reduces_loss_and_checkpoints(tmp_path):
     qrels = {qid: {f"d{i}": int(i < 3) for i in range(10)} for qid in queries}
     t = PytorchTrainer({"batch": 16, "itersize": 64, "niters": 6, "lr": 0.02, "evalbatch": 40})
     losses = t.train(r, Train(), tmp_path / "train", Dev(), tmp_path / "dev", qrels, "ndcg_cut_20")
+    assert t._use_fused and not t._fused_failed      # KNRM with a single-Linear combine trains through capamd_knrm_train_step (the plain Adam's state)
+    assert not t.optimizer.param_groups[0].get("capturable") and not torch.is_tensor(t.optimizer.param_groups[0]["lr"])
     assert losses[0] > 0.1 and min(losses[1:]) < 0.2 * losses[0], losses  # starts at 1.0 per pair, separates within a few steps
     assert (tmp_path / "train" / "dev.best").exists() and (tmp_path / "dev" / "6.run").exists()
     before = r.model.combine[0].weight.detach().clone()
