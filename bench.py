@@ -1352,15 +1352,22 @@ def config0_gpu(leg):
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3)
 
+    from capreolus_amd import engine
+
     def train16():
+        # what PytorchTrainer.single_train_iteration does by default: the reranker's fused step (capamd_knrm_train_step: score(pos),
+        # score(neg), hinge loss, backward and Adam in two launches, the kernels' status read once at the end)
         m.train()
-        for s in range(16):
-            lo = (s * 64) % max(1, n - 64)
-            pos, neg = rr.score({"query": q[lo:lo + 32], "posdoc": d[lo:lo + 32], "negdoc": d[lo + 32:lo + 64], "query_idf": idf[lo:lo + 32]})
-            loss = torch.clamp(1.0 - (pos - neg), min=0).mean()
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
+        with engine.deferred_status(leg.ctx.dev):
+            for s in range(16):
+                lo = (s * 64) % max(1, n - 64)
+                batch = {"query": q[lo:lo + 32], "posdoc": d[lo:lo + 32], "negdoc": d[lo + 32:lo + 64], "query_idf": idf[lo:lo + 32]}
+                if rr.fused_train_step(batch, opt) is None:
+                    pos, neg = rr.score(batch)
+                    loss = torch.clamp(1.0 - (pos - neg), min=0).mean()
+                    loss.backward()
+                    opt.step()
+                    opt.zero_grad()
         m.eval()
         torch.cuda.synchronize()
 
@@ -1386,8 +1393,8 @@ def config0_gpu(leg):
         pred1_s = time.perf_counter() - t0
     m.load_state_dict(saved, strict=False)
     return {"config0_gpu_s": train_s + pred1_s, "config0_gpu_train_s": train_s, "config0_gpu_predict_s": pred1_s, "config0_gpu_predict_evalbatch32_s": pred32_s,
-            "config0_gpu_note": "the same stand-in through this engine on the GPU (batches already in HBM): 16 training steps of batch 32 via reranker.score() "
-                                "(HIP feature kernel with in-kernel mu / sigma derivatives + autograd combine layer, hinge loss, Adam) + the 325 x 100 predict as "
+            "config0_gpu_note": "the same stand-in through this engine on the GPU (batches already in HBM): 16 training steps of batch 32 via reranker.fused_train_step() "
+                                "(the trainer's default: features of positives and negatives, hinge loss, backward, Adam in two launches per step) + the 325 x 100 predict as "
                                 "ONE scoring call (what this engine's trainer makes of the evalbatch-32 loader; config0_gpu_predict_evalbatch32_s = the same "
                                 "pairs as 1,016 separate test() calls of 32, each checking the status word)"}
 

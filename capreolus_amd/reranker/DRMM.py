@@ -138,6 +138,10 @@ class DRMM(Reranker):
     def fused_train_step(self, d, optimizer, softmax=False):
         return self.model.fused_train_step(d, optimizer, softmax)
 
+    def fused_step_available(self, batch_size):
+        """whether `fused_train_step` takes this configuration (idf gate, <= 16 hidden nodes, 2 B Q <= 1024: B <= 128 at the extractor's four query terms)"""
+        return self.config["gateType"] == "IDF" and self.config["nodes"] <= 16 and batch_size <= 128
+
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)
 

@@ -100,6 +100,9 @@ class DRMMTKS(Reranker):
     def fused_train_step(self, d, optimizer, softmax=False):
         return self.model.fused_train_step(d, optimizer, softmax)
 
+    def fused_step_available(self, batch_size):
+        return batch_size <= 1024
+
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmmtks_forward_lists)
     lists_bit_identical = True # (top-k selections of bit-identical similarities, fed to the Linear in the same order)
 

@@ -157,6 +157,10 @@ class KNRM(Reranker):
     def fused_train_step(self, d, optimizer, softmax=False):
         return self.model.fused_train_step(d, optimizer, softmax)
 
+    def fused_step_available(self, batch_size):
+        """whether `fused_train_step` takes this configuration (a single-Linear `combine`, frozen table, batches of <= 1024 pairs)"""
+        return bool(self.config["singlefc"]) and not self.config["finetune"] and batch_size <= 1024
+
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)
 

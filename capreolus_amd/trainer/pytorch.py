@@ -249,8 +249,12 @@ class PytorchTrainer:
         return {"sig": sig, "reranker": reranker, "static": static, "graph": graph, "loss": loss}
 
     def _fused_allowed(self, reranker):
+        """The reranker brings its training step as device kernels AND takes this configuration with them (otherwise the captured-graph
+        route, with its own kind of Adam, is the better second choice than a plain Adam stepping eagerly)."""
+        available = getattr(reranker, "fused_step_available", None)
         return bool(self.config["fused"]) and self.device.type == "cuda" and self.config["gradacc"] == 1 and self.scaler is None and \
-            callable(getattr(reranker, "fused_train_step", None)) and not getattr(self, "_fused_failed", False)
+            callable(getattr(reranker, "fused_train_step", None)) and callable(available) and bool(available(self.config["batch"])) and \
+            not getattr(self, "_fused_failed", False)
 
     def _fused_step(self, reranker, batch):
         """The batch's step as the reranker's own device kernels; None when its configuration has none (then: graph / eager)."""

@@ -1608,6 +1608,25 @@ def test_knrm_fused_training_steps_equal_eager_steps(name, softmax):
             assert float((a - b).abs().max()) <= 2e-3 * (float(a.abs().max()) + 1e-12) + 1e-12, (i, key)
 
 
+def test_fused_step_is_chosen_only_where_the_reranker_takes_the_configuration():
+    """`PytorchTrainer._fused_allowed`: KNRM's two-layer `combine` and DRMM's term-vector gate have no fused step - they keep the
+    captured-graph route (and its capturable Adam) instead of falling back to a plain Adam stepping eagerly."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    t = PytorchTrainer({"batch": 32})
+    t.device, t.scaler = torch.device(DEV), None
+    assert t._fused_allowed(_knrm_model(load_case("knrm", "default")))
+    assert not t._fused_allowed(_knrm_model(load_case("knrm", "twolayer_tanh")))
+    assert t._fused_allowed(_drmm_model(load_case("drmm", "default")))
+    assert not t._fused_allowed(_drmm_model(load_case("drmm", "tv_nh")))
+    big = PytorchTrainer({"batch": 256, "itersize": 512})
+    big.device, big.scaler = torch.device(DEV), None
+    assert big._fused_allowed(_knrm_model(load_case("knrm", "default"))) and not big._fused_allowed(_drmm_model(load_case("drmm", "default")))
+    off = PytorchTrainer({"batch": 32, "fused": False})
+    off.device, off.scaler = torch.device(DEV), None
+    assert not off._fused_allowed(_knrm_model(load_case("knrm", "default")))
+
+
 @pytest.mark.parametrize("name,softmax", [("default", False), ("ranklist", True), ("top3_short", False)])
 def test_drmmtks_fused_training_steps_equal_eager_steps(name, softmax):
     """DRMM-TKS's training step as two launches (capamd_drmmtks_train_step: top-k features, Linear / tanh, idf gate, output layer, the
