@@ -40,6 +40,8 @@ def med(fn, n=20, warm=5):
 
 shapes = [("QKV   N=2304 K=768  bias", 2304, 768, 0), ("Oproj N=768  K=768  bias", 768, 768, 0), ("FFN1  N=3072 K=768  bias+GELU", 3072, 768, 1),
           ("FFN2  N=768  K=3072 bias", 768, 3072, 0)]
+if os.environ.get("GEMM_FFN1_BIAS_ONLY"):      # what the GELU epilogue costs: the FFN1 shape once more with the bias-only epilogue
+    shapes.append(("FFN1* N=3072 K=768  bias only", 3072, 768, 0))
 print(f"M = {M}, {dt_name} operands, fp32 accumulate; us per launch (TFLOP/s)")
 print(f"{'shape':30s} {'ring 128x256 (2 wg/CU)':>24s} {'ring 256x256 (1 wg/CU)':>24s} {'ping-pong 256x256':>22s} {'hipBLASLt (bias only)':>24s}   best in-tree / vendor")
 tot = {"ring128": 0.0, "ring256": 0.0, "pp": 0.0, "vendor": 0.0, "best": 0.0}
