@@ -59,6 +59,15 @@ struct ListsArgs {
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
 constexpr int kDocMeta = 8;                          // ints of per-document metadata the mark pass leaves for the pooling pass
+// What the pooling pass reads of a document: CAPAMD_LISTS_COMPACT = 1 (default) its compact row (the mark pass appends every real term
+// id, int32, to a per-pair workspace row: 4 L bytes per pair); 0 the document's own id row up to its LAST real position, which the mark
+// pass leaves in the metadata - no compaction in the mark pass, no per-pair rows in the workspace.  Measured (profiles/r04/
+// lists_compact_ab.txt): 0 takes 16 us off the mark pass and puts 15-30 us on every pooling kernel (8-byte ids, pads inside the row) -
+// a wash for DRMM, a loss for KNRM and DRMM-TKS - so the compact rows stay.
+#ifndef CAPAMD_LISTS_COMPACT
+#define CAPAMD_LISTS_COMPACT 1
+#endif
+constexpr bool kCompactRows = CAPAMD_LISTS_COMPACT != 0;
 struct ListQuery {
   int id[kQT];             // query term ids (0: pad or beyond Q)
   float den[kQT];          // their rows' norms
@@ -109,8 +118,8 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
     qo[t] = (q < 0 && q > -2147483648LL) ? (int)q : 0;
   }
   uint8_t* f = a.flags + (int64_t)l * a.Vp;
-  int32_t* out = EMIT ? a.cid + (int64_t)b * a.cid_stride : nullptr;
-  int n_real = 0, c_oov = 0, c_one[kQT] = {0, 0, 0, 0};
+  int32_t* out = (EMIT && kCompactRows) ? a.cid + (int64_t)b * a.cid_stride : nullptr;
+  int n_real = 0, c_oov = 0, c_one[kQT] = {0, 0, 0, 0}, used = 0;      // used: positions up to the last one that is not a pad
   bool bad = false;
   for (int j0 = 0; j0 < a.L; j0 += 64 * kMarkTrips) {
     int64_t id[kMarkTrips];
@@ -152,7 +161,11 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
       if (real) f[v] = 1;                    // (unconditional: a check of the flag first puts a load in front of every store and measures the same)
       if (EMIT) {
         const uint64_t set = __ballot(real);
-        if (real) out[n_real + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = (int)v;
+        if (kCompactRows) {
+          if (real) out[n_real + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = (int)v;
+        } else if (set) {
+          used = j0 + u * 64 + 64 - __builtin_clzll(set);
+        }
         n_real += __builtin_popcountll(set);
         const uint64_t neg = __ballot(v < 0);       // (counts as wave-uniform scalars: no cross-lane reduction at the end of the document)
         if (neg) {
@@ -171,9 +184,52 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
       int32_t* m = a.meta + (int64_t)b * kDocMeta;
       m[0] = n_real;
       m[1] = c_oov;
+      m[6] = kCompactRows ? n_real : used;     // entries the pooling pass walks
 #pragma unroll
       for (int t = 0; t < kQT; ++t) m[2 + t] = c_one[t];
     }
+  }
+}
+
+// The ids of one pass of a pooling kernel over a document's OWN id row (kCompactRows = false) - TRIPS trips of STRIDE consecutive
+// positions below `used`, this lane's slot `ps` - as int: > 0 a real term of the table, 0 anything else (pads, OOV terms and ids beyond the
+// table: the mark pass counted them).
+template <int TRIPS, int STRIDE>
+__device__ __forceinline__ void load_pass_rows(const PairIds& ids, int j0, int ps, int used, int64_t V, int (&id)[TRIPS]) {
+  const bool full = j0 + TRIPS * STRIDE <= used;
+  if (ids.d32) {
+    if (full) {
+      const int* p = ids.d32 + j0 + ps;
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) id[u] = p[u * STRIDE];
+    } else {
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int j = j0 + u * STRIDE + ps;
+        id[u] = ids.d32[j < used ? j : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) id[u] = (j0 + u * STRIDE + ps < used) ? id[u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) id[u] = (id[u] > 0 && id[u] < V) ? id[u] : 0;
+  } else {
+    int64_t w[TRIPS];
+    if (full) {
+      const int64_t* p = ids.d64 + j0 + ps;
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) w[u] = __builtin_nontemporal_load(p + u * STRIDE);
+    } else {
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) {
+        const int j = j0 + u * STRIDE + ps;
+        w[u] = __builtin_nontemporal_load(ids.d64 + (j < used ? j : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < TRIPS; ++u) w[u] = (j0 + u * STRIDE + ps < used) ? w[u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) id[u] = (w[u] > 0 && w[u] < V) ? (int)w[u] : 0;
   }
 }
 
@@ -193,6 +249,27 @@ __device__ __forceinline__ void load_pass_cids(const int32_t* row, int j0, int p
 #pragma unroll
     for (int u = 0; u < TRIPS; ++u) id[u] = (j0 + u * STRIDE + ps < n) ? id[u] : 0;
   }
+}
+
+// what a pooling kernel walks of document b: (entries, loader of a pass)
+struct DocWalk {
+  PairIds ids;
+  const int32_t* row;
+  int n;          // entries to walk: the compact row's length, or the positions up to the document's last real one
+  int64_t V;
+};
+__device__ __forceinline__ DocWalk doc_walk(const ListsArgs& a, int b, const int32_t* dm) {
+  DocWalk w;
+  w.ids = pair_ids(a.ids, b, a.Q, a.L);
+  w.row = kCompactRows ? a.cid + (int64_t)b * a.cid_stride : nullptr;
+  w.n = dm[6];
+  w.V = a.V;
+  return w;
+}
+template <int TRIPS, int STRIDE>
+__device__ __forceinline__ void load_pass(const DocWalk& w, int j0, int ps, int (&id)[TRIPS]) {
+  if (kCompactRows) load_pass_cids<TRIPS, STRIDE>(w.row, j0, ps, w.n, id);
+  else load_pass_rows<TRIPS, STRIDE>(w.ids, j0, ps, w.n, w.V, id);
 }
 
 // ---- 2: sims -------------------------------------------------------------------------------------------------------------------
@@ -511,7 +588,7 @@ __global__ __launch_bounds__(256, CAPAMD_SIMS_MFMA_BLOCKS) void lists_sims_mfma_
 constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 6 * kMaxK * sizeof(float);
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 int lists_cid_stride(int L) { return (L + 3) & ~3; }
-size_t lists_pair_bytes(int64_t n_pairs, int L) { return (size_t)n_pairs * ((size_t)lists_cid_stride(L) * 4 + kDocMeta * 4); }
+size_t lists_pair_bytes(int64_t n_pairs, int L) { return (size_t)n_pairs * ((kCompactRows ? (size_t)lists_cid_stride(L) * 4 : 0) + kDocMeta * 4); }
 
 // runs `pool(geometry, lists in the chunk, longest list)` for chunks of lists that fit the workspace, after marking and the sims pass
 template <class Pool>
@@ -548,7 +625,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     // per-list part: table [cap][Vp] x 16 B | byte maps [cap][Vp] | query images [cap] | query ids and norms [cap] | KNRM kernel constants
     char* ws = static_cast<char*>(workspace) + pair_bytes;
     int32_t* cid = emit ? reinterpret_cast<int32_t*>(workspace) : nullptr;
-    int32_t* meta = emit ? cid + (size_t)n_pairs * lists_cid_stride(L) : nullptr;
+    int32_t* meta = emit ? cid + (kCompactRows ? (size_t)n_pairs * lists_cid_stride(L) : 0) : nullptr;
     float4* table = reinterpret_cast<float4*>(ws);
     uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
     float4* qimg = reinterpret_cast<float4*>(ws + (size_t)cap * Vp * 17);

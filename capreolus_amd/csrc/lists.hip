@@ -124,15 +124,15 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   if (doc >= g.len[l]) break;
   const int b = g.start[l] + doc;
   // what the mark pass left: the document's real terms, dense (int32), and its counts
-  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
-  const int n = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
+  const DocWalk dw = doc_walk(a, b, dm);
+  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
   float acc[KK], rs = 0.f;
 #pragma unroll
   for (int k = 0; k < KK; ++k) acc[k] = 0.f;
   for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
-    load_pass_cids<kWaveTrips, 16>(row, j0, ps, n, id);
+    load_pass<kWaveTrips, 16>(dw, j0, ps, id);
     float s[kWaveTrips];
     if (kPoolHot > 0) {
       float sg[kWaveTrips], sl[kWaveTrips];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     S = k == kk ? v : S;
   }
   const float R0 = group_allreduce(rs);
-  const int no = n_one_t, nreal = n;
+  const int no = n_one_t, nreal = n_real_doc;
   float f = 0.f;
   if (k < m.K && t < a.Q) {
     const float k0 = k0c, k1 = k1c;
@@ -238,16 +238,16 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = g.start[l] + doc, NB = m.nbins + 1;
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
-  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
-  const int n = dm[0], n_oov = dm[1];
+  const DocWalk dw = doc_walk(a, b, dm);
+  const int n = dw.n, n_oov = dm[1];
   for (int i = tid; i < kHistCopies * (kQT * kMaxBins + 1); i += 256) (&hrep[0][0])[i] = 0;
   __syncthreads();
   int* myh = hrep[lane & (kHistCopies - 1)];
   const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
   for (int j0 = 0; j0 < n; j0 += 256 * kDrmmTrips) {
     int id[kDrmmTrips];
-    load_pass_cids<kDrmmTrips, 256>(row, j0, tid, n, id);
+    load_pass<kDrmmTrips, 256>(dw, j0, tid, id);
     uint32_t e[kDrmmTrips];
 #pragma unroll
     for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u]];        // (entry 0 is never written and never used)
@@ -353,16 +353,16 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, 
   const int doc = (dq * kPoolDocs + di) * 4 + wave;
   if (doc >= g.len[l]) break;
   const int b = g.start[l] + doc;
-  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
-  const int n = dm[0], n_oov = dm[1];
+  const DocWalk dw = doc_walk(a, b, dm);
+  const int n = dw.n, n_oov = dm[1];
   int* H = hrep[wave];
   for (int i = lane; i < kWaveCopies * kWaveStride; i += 64) H[i] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
   int* myh = H + (lane & (kWaveCopies - 1)) * kWaveStride;
   for (int j0 = 0; j0 < n; j0 += 64 * kDrmmTrips) {
     int id[kDrmmTrips];
-    load_pass_cids<kDrmmTrips, 64>(row, j0, lane, n, id);
+    load_pass<kDrmmTrips, 64>(dw, j0, lane, id);
     uint32_t e[kDrmmTrips];
     if (kPoolHotBins > 0) {
       uint32_t eg[kDrmmTrips], el[kDrmmTrips];
@@ -518,15 +518,15 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
   const int doc = (dq * kPoolDocs + di) * 4 + wave;
   if (doc >= g.len[l]) break;
   const int b = g.start[l] + doc;
-  const int32_t* row = a.cid + (int64_t)b * a.cid_stride;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
-  const int n = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
+  const DocWalk dw = doc_walk(a, b, dm);
+  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
   float top[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
   for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
-    load_pass_cids<kWaveTrips, 16>(row, j0, ps, n, id);
+    load_pass<kWaveTrips, 16>(dw, j0, ps, id);
     float s[kWaveTrips];
     if (kPoolHot > 0) {
       float sg[kWaveTrips], sl[kWaveTrips];
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
 #pragma unroll
   for (int i = 0; i < KT; ++i) heads[wave][i][lane] = top[i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
-  const int no = n_one_t, nreal = n;
+  const int no = n_one_t, nreal = n_real_doc;
   const int nz = a.L - nreal - no;          // pads and OOV terms without a match: similarity 0
   int head = 0, used1 = 0, used0 = 0;
   float acc = m.ffw_b[0];
