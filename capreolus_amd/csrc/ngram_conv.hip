@@ -1,0 +1,401 @@
+// ConvKNRM's trainable n-gram convolutions, forward and backward, as fp32 matrix-pipe GEMMs for gfx950.
+//
+// Reference: ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-51 - for every n-gram size g = 1..G
+//     rep_g = Conv1d(D -> F, kernel g)(ConstantPad1d((0, g - 1), 0)(embeddings(ids).permute(0, 2, 1))).permute(0, 2, 1)
+// on the query and on the document, under the reference trainer's loss.backward() (trainer/pytorch.py:96-107).  The embedding table is
+// frozen (ConvKNRM.py:17), so the step needs the convolutions' outputs and the gradients of their weights and biases, nothing else.
+//
+// A Conv1d over gathered embedding rows is a sum of g matrix products, one per tap c, whose left operand is the SAME gathered matrix
+// shifted by c positions:
+//     rep_g[m][f] = b_g[f] + sum_{c < g} sum_d E[ids[m + c]][d] W_g[f][d][c]           (zero rows beyond the sequence end: the ConstantPad1d)
+//     dW_g[f][d][c] = sum_m E[ids[m + c]][d] dRep_g[m][f]        db_g[f] = sum_m dRep_g[m][f]
+// so nothing is materialised: no [B, D, L] embedding tensor, no permutes, no padded copies, no im2col - the kernels gather the table's rows.
+// Both directions run on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, 157 TFLOP/s peak = the fp32
+// vector peak, but one operand register per lane and the VALU left free).  The bias rides along as column D of the left operand (a constant
+// 1 in tap 0) and row D of the weights, forward and backward.
+//
+//   forward:  one workgroup per (128 positions, n-gram size): the weights of its taps as [d][f] panels (ngram_pack_kernel turns the Conv1d
+//             layout [F][D][g] once per call), K loop over (tap, 32 embedding dimensions), both operands staged in LDS - gathered rows by
+//             float4, read back column-wise (pitch 33: conflict-free).  Tiles without a single real token (the padding behind a training
+//             document) are written as zeros and skipped: the kernel pooling behind the convolutions masks pad positions.
+//   backward: C[d][f] = sum_m X[m + c][d] dRep[m][f] - both operands are position-major, which is what the 32x32x2 MFMA wants of a "TN"
+//             product (lane = column, the two k of an instruction = two consecutive positions): no transposes.  One workgroup per
+//             (tap panel, slice of the positions), wave w owns filters 32 w .. 32 w + 31 and all of D; the slices' partial panels are
+//             summed in a FIXED order by ngram_reduce_kernel, which also writes the Conv1d layout: deterministic, no atomics.
+//             Blocks of 32 positions without a real token are skipped (their dRep rows are zero: masked positions).
+#include "capreolus_amd.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kNcMaxG = 4;             // n-gram sizes 1..G
+constexpr int kNcMaxParts = kNcMaxG * (kNcMaxG + 1) / 2;
+constexpr int kNcMaxDp = 320;          // padded embedding width (D + 1 rounded up to 32): D <= 319
+constexpr int kFwdRows = 128;          // positions per forward tile
+constexpr int kPA = 33;                // LDS pitch of the gathered-row tile (floats): column reads conflict-free
+constexpr int kPB = 160;               // LDS pitch of a 128-wide panel: the two k rows of an MFMA land 32 banks apart
+constexpr int kBwdBlock = 32;          // positions per backward K step
+
+struct ConvArgs {
+  const int64_t* ids[2];     // segment 0: queries [N, len[0]], segment 1: documents [N, len[1]]   (pad = 0)
+  int N, len[2];
+  const float* emb;          // [V, D] fp32 row-major (nn.Embedding.weight)
+  int64_t V;
+  int D, Dp, G, F;
+  const float* w[kNcMaxG];   // Conv1d weights [F][D][g]
+  const float* b[kNcMaxG];   // [F]
+  float* wt;                 // [parts][Dp][F]: tap panels, part(g, c) = g (g - 1) / 2 + c for n-gram size g (1-based), bias in row D of tap 0
+  float* out[2];             // forward: [N, G, len, F]
+  const float* dout[2];      // backward: gradients of out
+  float* partial;            // backward: [S][parts][Dp][F]
+  int S;
+  float* dw[kNcMaxG];        // [F][D][g]
+  float* db[kNcMaxG];        // [F]
+  int* status;
+};
+
+__device__ __forceinline__ int part_of(int g1, int c) { return g1 * (g1 - 1) / 2 + c; }   // g1 = n-gram size, 1-based
+
+// ---- weights: Conv1d layout -> tap panels ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ngram_pack_kernel(ConvArgs a) {
+  const int part = blockIdx.y;
+  int g1 = 1;
+  while (part_of(g1 + 1, 0) <= part) ++g1;
+  const int c = part - part_of(g1, 0);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.Dp * a.F) return;
+  const int d = i / a.F, f = i - d * a.F;
+  float v = 0.f;
+  if (d < a.D) v = a.w[g1 - 1][((int64_t)f * a.D + d) * g1 + c];
+  else if (d == a.D && c == 0) v = a.b[g1 - 1][f];
+  a.wt[((int64_t)part * a.Dp + d) * a.F + f] = v;
+}
+
+// the table row behind position (segment, row m) shifted by tap c: -1 = a zero row (beyond the sequence end, or an id outside the table)
+__device__ __forceinline__ int64_t tap_row(const ConvArgs& a, int seg, int64_t m, int c, bool& bad) {
+  const int len = a.len[seg];
+  const int64_t n = m / len;
+  const int j = (int)(m - n * len) + c;
+  if (n >= a.N || j >= len) return -1;
+  const int64_t id = a.ids[seg][n * len + j];
+  if (id < 0 || id >= a.V) {
+    bad = true;
+    return -1;
+  }
+  return id;
+}
+
+// ---- forward --------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void ngram_forward_kernel(ConvArgs a, int tiles0) {
+  __shared__ float As[kFwdRows * kPA];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * kPB];
+  __shared__ int64_t rid[kNcMaxG][kFwdRows];
+  __shared__ int any_real;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = (int)blockIdx.x < tiles0 ? 0 : 1;
+  const int64_t m0 = (int64_t)(seg ? blockIdx.x - tiles0 : blockIdx.x) * kFwdRows;
+  const int g1 = a.G - (int)blockIdx.y;          // heavy n-gram sizes first
+  const int f0 = blockIdx.z * 128;
+  const int len = a.len[seg];
+  const int64_t M = (int64_t)a.N * len;
+  if (tid == 0) any_real = 0;
+  __syncthreads();
+  {
+    bool bad = false, real = false;
+    for (int i = tid; i < g1 * kFwdRows; i += 256) {
+      const int c = i / kFwdRows, r = i - c * kFwdRows;
+      const int64_t id = tap_row(a, seg, m0 + r, c, bad);
+      rid[c][r] = id;
+      if (c == 0 && id > 0) real = true;
+    }
+    if (bad) atomicOr(a.status, CAPAMD_STATUS_DOC_ID_RANGE);
+    if (real) any_real = 1;
+  }
+  __syncthreads();
+  float* out = a.out[seg];
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if (any_real) {
+    const int ksteps = a.Dp / 32, steps = g1 * ksteps;
+    const float* wt = a.wt + (int64_t)part_of(g1, 0) * a.Dp * a.F;
+    float4 ra[4], rb[4];
+    auto fetch = [&](int s) {
+      const int c = s / ksteps, k0 = (s - c * ksteps) * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + 32 * i, d = k0 + 4 * (tid & 7);
+        const int64_t id = rid[c][r];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && d < a.D) v = *reinterpret_cast<const float4*>(a.emb + id * a.D + d);        // (D % 4 == 0)
+        if (c == 0 && d == a.D) v.x = 1.f;                                                            // the bias column
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = (tid >> 5) + 8 * i, f = f0 + 4 * (tid & 31);
+        rb[i] = f < a.F ? *reinterpret_cast<const float4*>(wt + ((int64_t)c * a.Dp + k0 + kk) * a.F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto stage = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* p = As + ((tid >> 3) + 32 * i) * kPA + 4 * (tid & 7);
+        p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Bs + ((tid >> 5) + 8 * i) * kPB + 4 * (tid & 31)) = rb[i];
+    };
+    fetch(0);
+    for (int s = 0; s < steps; ++s) {
+      __syncthreads();          // the previous step's reads are done
+      stage();
+      __syncthreads();
+      if (s + 1 < steps) fetch(s + 1);
+      const float* ap = As + (wr * 64 + (lane & 31)) * kPA + (lane >> 5);
+      const float* bp = Bs + (lane >> 5) * kPB + wc * 64 + (lane & 31);
+#pragma unroll
+      for (int kp = 0; kp < 16; ++kp) {
+        const float a0 = ap[2 * kp], a1 = ap[32 * kPA + 2 * kp];
+        const float b0 = bp[2 * kp * kPB], b1 = bp[2 * kp * kPB + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+  // C/D map of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
+      const int64_t n = m / len;
+      const int j = (int)(m - n * len);
+      float* dst = out + (((n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int f = f0 + wc * 64 + jj * 32 + (lane & 31);
+        if (f < a.F) dst[f] = acc[i][jj][e];
+      }
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------------------------
+constexpr int kBwdList = 2048;         // 32-position blocks a slice can hold (the batch limit: S * 2048 * 32 positions)
+
+// DT = 32-row tiles of the padded embedding width a wave keeps accumulators for (Dp = 32 DT): 16 DT accumulator registers
+template <int DT>
+__global__ __launch_bounds__(256, 1) void ngram_backward_kernel(ConvArgs a, int blocks0, int blocks) {
+  extern __shared__ __attribute__((aligned(16))) float bw_lds[];
+  __shared__ int list[kBwdList];
+  __shared__ int wave_cnt[4];
+  constexpr int PX = 32 * DT + 32;               // pitch of a position's row: the two k rows of an MFMA land 32 banks apart
+  constexpr int XV = DT;                         // float4 loads per thread and block: 8 DT per position, 8 threads per position
+  float* Xs = bw_lds;                            // [32][PX]
+  float* Rs = bw_lds + kBwdBlock * PX;           // [32][kPB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int part = blockIdx.y, split = blockIdx.x, f0 = blockIdx.z * 128;
+  int g1 = 1;
+  while (part_of(g1 + 1, 0) <= part) ++g1;
+  const int c = part - part_of(g1, 0);
+  // this slice's blocks (split, split + S, ...) that hold a real token, in order: a position's gradient row is zero unless the position
+  // itself is a real token (the kernel pooling masks pads)
+  int total = 0;
+  {
+    const int mine = (blocks - split + a.S - 1) / a.S;           // (<= kBwdList: checked by the host)
+    for (int base = 0; base < mine; base += 256) {
+      const int k = base + tid, blk = split + k * a.S;
+      bool real = false;
+      if (k < mine) {
+        const int seg = blk < blocks0 ? 0 : 1;
+        const int64_t m0 = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock, M = (int64_t)a.N * a.len[seg];
+        const int64_t* p = a.ids[seg] + m0;
+        const int n = M - m0 < kBwdBlock ? (int)(M - m0) : kBwdBlock;
+        for (int r = 0; r < n; ++r) real |= p[r] != 0;
+      }
+      const uint64_t set = __ballot(real);
+      if (lane == 0) wave_cnt[wave] = __builtin_popcountll(set);
+      __syncthreads();
+      int before = total;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+      if (real) list[before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = blk;
+      total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+  }
+  f32x16 acc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  // a thread stages ONE position of a block (8 threads per position): its tap-c table row, its gradient row
+  const int r = tid >> 3, sub = tid & 7;
+  float4 rx[XV], rr[4];
+  bool bad = false;
+  auto fetch = [&](int blk) {
+    const int seg = blk < blocks0 ? 0 : 1;
+    const int64_t m = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock + r;
+    const int len = a.len[seg];
+    const int64_t M = (int64_t)a.N * len;
+    const int64_t id = tap_row(a, seg, m, c, bad);
+    const float* row = a.emb + (id >= 0 ? id : 0) * a.D;
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int d = 4 * (sub + 8 * k);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id >= 0 && d < a.D) v = *reinterpret_cast<const float4*>(row + d);           // (D % 4 == 0)
+      if (c == 0 && d == a.D && m < M) v.x = 1.f;                                       // the bias column
+      rx[k] = v;
+    }
+    const int n = (int)(m / len), j = (int)(m - (int64_t)n * len);
+    const float* src = a.dout[seg] + ((((int64_t)n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = f0 + 4 * (sub + 8 * i);
+      rr[i] = (m < M && f < a.F) ? *reinterpret_cast<const float4*>(src + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (total > 0) fetch(list[0]);
+  for (int i = 0; i < total; ++i) {
+    __syncthreads();            // the previous block's reads are done
+#pragma unroll
+    for (int k = 0; k < XV; ++k) *reinterpret_cast<float4*>(Xs + r * PX + 4 * (sub + 8 * k)) = rx[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(Rs + r * kPB + 4 * (sub + 8 * k)) = rr[k];
+    __syncthreads();
+    if (i + 1 < total) fetch(list[i + 1]);
+    const float* xp = Xs + (lane >> 5) * PX + (lane & 31);
+    const float* rp = Rs + (lane >> 5) * kPB + wave * 32 + (lane & 31);
+#pragma unroll 2
+    for (int kp = 0; kp < kBwdBlock / 2; ++kp) {
+      const float bv = rp[2 * kp * kPB];
+      float av[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) av[t] = xp[2 * kp * PX + 32 * t];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+    }
+  }
+  if (bad) atomicOr(a.status, CAPAMD_STATUS_DOC_ID_RANGE);
+  float* dst = a.partial + ((int64_t)split * gridDim.y + part) * a.Dp * a.F;
+  const int f = f0 + wave * 32 + (lane & 31);
+  if (f < a.F) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int d = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        dst[(int64_t)d * a.F + f] = acc[t][e];
+      }
+  }
+}
+
+// partial panels -> the Conv1d layout, slices summed in their order
+__global__ __launch_bounds__(256) void ngram_reduce_kernel(ConvArgs a, int parts) {
+  const int part = blockIdx.y;
+  int g1 = 1;
+  while (part_of(g1 + 1, 0) <= part) ++g1;
+  const int c = part - part_of(g1, 0);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (a.D + 1) * a.F) return;
+  const int d = i / a.F, f = i - d * a.F;
+  if (d == a.D && c != 0) return;
+  float v = 0.f;
+  for (int s = 0; s < a.S; ++s) v += a.partial[(((int64_t)s * parts + part) * a.Dp + d) * a.F + f];
+  if (d < a.D) a.dw[g1 - 1][((int64_t)f * a.D + d) * g1 + c] = v;
+  else a.db[g1 - 1][f] = v;
+}
+
+int conv_check(const ConvArgs& a) {
+  if (!a.ids[0] || !a.ids[1] || !a.emb || !a.wt || !a.status) return CAPAMD_ERR_ARG;
+  if (a.N < 0 || a.len[0] < 1 || a.len[1] < 1 || a.V < 1 || a.D < 4 || (a.D & 3) || a.D + 1 > kNcMaxDp || a.G < 1 || a.G > kNcMaxG || a.F < 4 || (a.F & 3) ||
+      a.F > 256)
+    return CAPAMD_ERR_ARG;
+  for (int g = 0; g < a.G; ++g)
+    if (!a.w[g] || !a.b[g]) return CAPAMD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(a.emb) | reinterpret_cast<uintptr_t>(a.wt)) & 15) return CAPAMD_ERR_ALIGN;
+  return CAPAMD_OK;
+}
+
+int padded_width(int D) { return (D + 1 + 31) / 32 * 32; }
+int n_parts(int G) { return G * (G + 1) / 2; }
+int n_splits(int G, int F) { return 256 / (n_parts(G) * ((F + 127) / 128)) > 0 ? 256 / (n_parts(G) * ((F + 127) / 128)) : 1; }
+
+}  // namespace
+
+extern "C" size_t capamd_ngram_conv_workspace_floats(int D, int G, int F, int backward) {
+  if (D < 1 || G < 1 || G > kNcMaxG || F < 1) return 0;
+  const size_t panel = (size_t)n_parts(G) * padded_width(D) * F;
+  return backward ? panel * n_splits(G, F) : panel;
+}
+
+extern "C" int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D,
+                                         const float* const* conv_w, const float* const* conv_b, int G, int F, float* qrep, float* drep,
+                                         float* workspace, size_t workspace_floats, int* status, void* stream) {
+  if (!conv_w || !conv_b || !qrep || !drep) return CAPAMD_ERR_ARG;
+  ConvArgs a{};
+  a.ids[0] = q_ids; a.ids[1] = d_ids; a.N = N; a.len[0] = Q; a.len[1] = L; a.emb = emb; a.V = V; a.D = D; a.Dp = padded_width(D); a.G = G; a.F = F;
+  for (int g = 0; g < G && g < kNcMaxG; ++g) { a.w[g] = conv_w[g]; a.b[g] = conv_b[g]; }
+  a.wt = workspace; a.out[0] = qrep; a.out[1] = drep; a.status = status;
+  const int rc = conv_check(a);
+  if (rc != CAPAMD_OK) return rc;
+  if (workspace_floats < capamd_ngram_conv_workspace_floats(D, G, F, 0)) return CAPAMD_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(qrep) | reinterpret_cast<uintptr_t>(drep)) & 3) return CAPAMD_ERR_ALIGN;
+  if (N == 0) return CAPAMD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ngram_pack_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a);
+  const int tiles0 = (int)(((int64_t)N * Q + kFwdRows - 1) / kFwdRows), tiles1 = (int)(((int64_t)N * L + kFwdRows - 1) / kFwdRows);
+  hipLaunchKernelGGL(ngram_forward_kernel, dim3(tiles0 + tiles1, G, (F + 127) / 128), dim3(256), 0, s, a, tiles0);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}
+
+extern "C" int capamd_ngram_conv_backward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D,
+                                          int G, int F, const float* dqrep, const float* ddrep, float* const* dconv_w, float* const* dconv_b,
+                                          float* workspace, size_t workspace_floats, int* status, void* stream) {
+  if (!dconv_w || !dconv_b || !dqrep || !ddrep) return CAPAMD_ERR_ARG;
+  ConvArgs a{};
+  a.ids[0] = q_ids; a.ids[1] = d_ids; a.N = N; a.len[0] = Q; a.len[1] = L; a.emb = emb; a.V = V; a.D = D; a.Dp = padded_width(D); a.G = G; a.F = F;
+  for (int g = 0; g < G && g < kNcMaxG; ++g) {
+    a.dw[g] = dconv_w[g]; a.db[g] = dconv_b[g];
+    a.w[g] = dconv_w[g]; a.b[g] = dconv_b[g];          // (only checked for null)
+  }
+  a.wt = workspace; a.partial = workspace; a.dout[0] = dqrep; a.dout[1] = ddrep; a.status = status;
+  const int rc = conv_check(a);
+  if (rc != CAPAMD_OK) return rc;
+  if (workspace_floats < capamd_ngram_conv_workspace_floats(D, G, F, 1)) return CAPAMD_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(dqrep) | reinterpret_cast<uintptr_t>(ddrep)) & 15) return CAPAMD_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipGetLastError();
+  a.S = n_splits(G, F);
+  const int parts = n_parts(G);
+  const int blocks0 = (int)(((int64_t)N * Q + kBwdBlock - 1) / kBwdBlock), blocks1 = (int)(((int64_t)N * L + kBwdBlock - 1) / kBwdBlock);
+  const dim3 grid(a.S, parts, (F + 127) / 128);
+  if ((blocks0 + blocks1 + a.S - 1) / a.S > kBwdList) return CAPAMD_ERR_ARG;          // (S * 65,536 positions: far beyond a training batch)
+  const size_t lds = (size_t)kBwdBlock * (a.Dp + 32 + kPB) * 4;
+  switch (a.Dp / 32) {
+#define CASE(DT_)                                                                                                                          \
+  case DT_: {                                                                                                                              \
+    auto k = ngram_backward_kernel<DT_>;                                                                                                   \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
+      return CAPAMD_ERR_LAUNCH;                                                                                                            \
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, blocks0, blocks0 + blocks1);                                                         \
+  } break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+    default: return CAPAMD_ERR_ARG;
+  }
+  hipLaunchKernelGGL(ngram_reduce_kernel, dim3(((D + 1) * F + 255) / 256, parts), dim3(256), 0, s, a, parts);
+  return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
+}

@@ -723,6 +723,53 @@ class KnrmFeatures(torch.autograd.Function):
         return (g * dmu).sum(0), (g * dsg).sum(0), None, None, None, None, None
 
 
+class NgramConv(torch.autograd.Function):
+    """ConvKNRM's n-gram convolutions over the frozen embedding table, differentiable in their weights and biases
+    (capamd_ngram_conv_forward / _backward; ConvKNRM.py:42-51 under the trainer's loss.backward()).
+    apply(q_ids [N, Q], d_ids [N, L], emb [V, D], w_1, b_1, ..., w_G, b_G) -> qrep [N, G, Q, F], drep [N, G, L, F]."""
+
+    @staticmethod
+    def forward(ctx, q_ids, d_ids, emb, *wb):
+        _need_gpu(q_ids, d_ids, emb, *wb)
+        qi, di, e = _i64(q_ids), _i64(d_ids), _f32(emb.detach())
+        ws, bs = [_f32(w.detach()) for w in wb[0::2]], [_f32(b.detach()) for b in wb[1::2]]
+        G, F, D = len(ws), ws[0].shape[0], e.shape[1]
+        N, Q, L = qi.shape[0], qi.shape[1], di.shape[1]
+        lib = _lib.load()
+        qrep = torch.empty((N, G, Q, F), dtype=torch.float32, device=e.device)
+        drep = torch.empty((N, G, L, F), dtype=torch.float32, device=e.device)
+        work = _step_workspace(e.device, int(lib.capamd_ngram_conv_workspace_floats(D, G, F, 0)))
+        wp, bp = (ctypes.c_void_p * G)(*[w.data_ptr() for w in ws]), (ctypes.c_void_p * G)(*[b.data_ptr() for b in bs])
+        st = status_word(e.device)
+        rc = lib.capamd_ngram_conv_forward(_ptr(qi), _ptr(di), N, Q, L, _ptr(e), e.shape[0], D, wp, bp, G, F, _ptr(qrep), _ptr(drep), _ptr(work),
+                                           work.numel(), _ptr(st.t), _stream())
+        _lib.check(rc, "capamd_ngram_conv_forward")
+        st.raise_if_set()
+        ctx.save_for_backward(qi, di, e)
+        ctx.geom = (G, F, [tuple(w.shape) for w in ws])
+        return qrep, drep
+
+    @staticmethod
+    def backward(ctx, dq, dd):
+        qi, di, e = ctx.saved_tensors
+        G, F, shapes = ctx.geom
+        N, Q, L, D = qi.shape[0], qi.shape[1], di.shape[1], e.shape[1]
+        lib = _lib.load()
+        dws = [torch.empty(sh, dtype=torch.float32, device=e.device) for sh in shapes]
+        dbs = [torch.empty(F, dtype=torch.float32, device=e.device) for _ in shapes]
+        work = _step_workspace(e.device, int(lib.capamd_ngram_conv_workspace_floats(D, G, F, 1)))
+        wp, bp = (ctypes.c_void_p * G)(*[w.data_ptr() for w in dws]), (ctypes.c_void_p * G)(*[b.data_ptr() for b in dbs])
+        dq, dd = _f32(dq), _f32(dd)
+        st = status_word(e.device)
+        rc = lib.capamd_ngram_conv_backward(_ptr(qi), _ptr(di), N, Q, L, _ptr(e), e.shape[0], D, G, F, _ptr(dq), _ptr(dd), wp, bp, _ptr(work),
+                                            work.numel(), _ptr(st.t), _stream())
+        _lib.check(rc, "capamd_ngram_conv_backward")
+        out = [None, None, None]
+        for w, b in zip(dws, dbs):
+            out += [w, b]
+        return tuple(out)
+
+
 class KernelPool(torch.autograd.Function):
     """Cosine similarity + RBF kernel pooling over dense n-gram views, differentiable in both operands and in (mu, sigma)
     (capamd_kernel_pool_forward / _backward): ConvKNRM's training step between its convolutions and `combine`.

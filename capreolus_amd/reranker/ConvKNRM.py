@@ -52,27 +52,26 @@ class ConvKNRM_class(nn.Module):
     def _forward_train(self, sentence, query_sentence):
         """Training step (reference trainer/pytorch.py:96-99 -> ConvKNRM.score).  The trainable convolutions sit IN FRONT of the
         similarity matrices, so the projection tables of the scoring kernel (rebuilt from the weights, not differentiable) cannot be
-        used: the n-gram convolutions run as Conv1d on the GPU (MIOpen, a library convolution), and everything behind them - cosine
-        similarity of every (query view, document view) pair, pad masks, RBF kernel pooling, log / mask / sum - is ONE HIP kernel
-        forward and one backward (capreolus_amd/csrc/kernel_pool.hip through `engine.KernelPool`), which hands the gradient back to
-        both convolution outputs and to the kernels' mu / sigma.  Geometries outside that kernel's limits (filters > 256, more than
-        24 query vectors per document view) keep the reference's op sequence under autograd (`_forward_train_aten`)."""
-        import torch.nn.functional as F
-
+        used.  Two HIP stages, each one kernel forward and one backward: the n-gram convolutions over the frozen table as fp32
+        matrix-pipe products that gather the table's rows themselves (capreolus_amd/csrc/ngram_conv.hip through `engine.NgramConv`:
+        no embedding tensor, no permutes, no padded copies, no library convolution), and everything behind them - cosine similarity of
+        every (query view, document view) pair, pad masks, RBF kernel pooling, log / mask / sum - in capreolus_amd/csrc/kernel_pool.hip
+        (`engine.KernelPool`), which hands the gradient back to both convolution outputs and to the kernels' mu / sigma.  Geometries
+        outside those kernels' limits (filters > 256 or not a multiple of 4, more than 24 query vectors per document view, an embedding
+        width that is not a multiple of 4 or beyond 316, n-grams beyond 4) keep the reference's op sequence under autograd
+        (`_forward_train_aten`)."""
         engine._need_gpu(sentence, query_sentence, self.embeddings.weight)
         G, Q = len(self.convs), query_sentence.shape[1]
-        nf = self.p["filters"]
-        if nf % 4 or nf > 256 or (G if self.p["crossmatch"] else 1) * Q > 24 or self.kernels.count() > 16:
+        nf, D = self.p["filters"], self.embeddings.weight.shape[1]
+        if nf % 4 or nf > 256 or (G if self.p["crossmatch"] else 1) * Q > 24 or self.kernels.count() > 16 or D % 4 or D > 316 or G > 4:
             return self._forward_train_aten(sentence, query_sentence)
-        a_emb, b_emb = self.embeddings(query_sentence).permute(0, 2, 1), self.embeddings(sentence).permute(0, 2, 1)
-        a_reps, b_reps = [], []
-        for g, conv in enumerate(self.convs, start=1):
-            a_reps.append(conv[0](F.pad(a_emb, (0, g - 1))).permute(0, 2, 1))   # ConstantPad1d((0, g - 1), 0), ConvKNRM.py:27-28
-            b_reps.append(conv[0](F.pad(b_emb, (0, g - 1))).permute(0, 2, 1))
+        wb = []
+        for conv in self.convs:
+            wb += [conv[0].weight, conv[0].bias]
+        a_reps, b_reps = engine.NgramConv.apply(query_sentence, sentence, self.embeddings.weight, *wb)      # [B, G, Q, F], [B, G, L, F]
         mu = torch.stack([k.mu for k in self.kernels.kernels]).float()          # live parameters: gradkernels trains them (ConvKNRM.py:22)
         sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
-        feats = engine.KernelPool.apply(torch.stack(a_reps, dim=1), torch.stack(b_reps, dim=1), query_sentence, sentence, mu, sigma,
-                                        bool(self.p["crossmatch"]))
+        feats = engine.KernelPool.apply(a_reps, b_reps, query_sentence, sentence, mu, sigma, bool(self.p["crossmatch"]))
         return self.combine(feats)
 
     def _forward_train_aten(self, sentence, query_sentence):

@@ -387,6 +387,29 @@ int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, const float
                          const float* w2, const float* b2, const float* w3, const float* b3, float* out, int* status,
                          void* stream);
 
+/* ---- ConvKNRM's trainable n-gram convolutions, forward and backward (ConvKNRM's training step) --------------
+ * Replaces, for training, the convolution stack of ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-51 - embeddings(ids) ->
+ * permute -> ConstantPad1d((0, g - 1), 0) -> Conv1d(D -> F, kernel g) -> permute, for g = 1..G, on the query and on the document -
+ * and its gradient under the reference trainer's loss.backward() (trainer/pytorch.py:96-107): no [B, D, L] embedding tensor, no padded
+ * copies, no library convolution - the kernels gather the table's rows and run the g taps as fp32 matrix products on
+ * v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate).  The table is frozen (ConvKNRM.py:17): gradients go to the weights and biases only.
+ * q_ids int64 [N, Q], d_ids int64 [N, L] (pad = 0; ids outside [0, V) set CAPAMD_STATUS_DOC_ID_RANGE and count as zero rows);
+ * emb fp32 [V, D] row-major (nn.Embedding.weight), 16-byte aligned, D % 4 == 0, D <= 316; conv_w / conv_b: HOST arrays of G device
+ * pointers, Conv1d weight [F][D][g] and bias [F] of n-gram size g = index + 1; G <= 4; F % 4 == 0, F <= 256.
+ * forward:  qrep fp32 [N, G, Q, F], drep fp32 [N, G, L, F].  A 128-position tile without a single real token is written as ZEROS (the
+ *           reference's value there is the bias plus the pad row's projection): capamd_kernel_pool_* masks those positions.
+ * backward: dqrep / ddrep (16-byte aligned) -> dconv_w / dconv_b (HOST arrays of device pointers, the weights' layouts), overwritten.
+ *           Rows of ddrep at pad positions are taken to be zero (what capamd_kernel_pool_backward writes there).  Deterministic: the
+ *           position slices are summed in a fixed order.
+ * workspace: capamd_ngram_conv_workspace_floats(D, G, F, backward) fp32 values, 16-byte aligned (CAPAMD_ERR_WORKSPACE below that). */
+size_t capamd_ngram_conv_workspace_floats(int D, int G, int F, int backward);
+int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D,
+                              const float* const* conv_w, const float* const* conv_b, int G, int F, float* qrep, float* drep,
+                              float* workspace, size_t workspace_floats, int* status, void* stream);
+int capamd_ngram_conv_backward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D, int G,
+                               int F, const float* dqrep, const float* ddrep, float* const* dconv_w, float* const* dconv_b,
+                               float* workspace, size_t workspace_floats, int* status, void* stream);
+
 /* ---- differentiable kernel pooling over dense n-gram representations (ConvKNRM's training step) ---------
  * The part of ConvKNRM_class.forward between its trainable n-gram convolutions and `combine`, capreolus/reranker/ConvKNRM.py:53-76
  * (StackedSimilarityMatrix common.py:195-221 + RbfKernelBank common.py:224-250), forward and backward - so that the reference

@@ -1825,6 +1825,60 @@ def test_optimizer_checkpoint_is_the_plain_kind_and_resumes_a_graphed_run(tmp_pa
         assert torch.equal(cap2.state[p]["exp_avg"], cap.state[p]["exp_avg"])
 
 
+@pytest.mark.parametrize("N,Q,L,D,G,F", [(5, 4, 300, 300, 3, 128), (3, 3, 70, 64, 2, 32), (2, 5, 130, 48, 4, 96), (64, 4, 800, 300, 3, 128), (1, 1, 1, 8, 1, 4),
+                                         (2, 4, 40, 316, 3, 160)])
+def test_ngram_conv_matches_conv1d(N, Q, L, D, G, F):
+    """ConvKNRM's convolution stack as the matrix-pipe kernels of ngram_conv.hip (`engine.NgramConv`) against the reference's op sequence
+    (ConvKNRM.py:42-51: embeddings -> permute -> ConstantPad1d -> Conv1d -> permute) in FLOAT64 on the same tensors: the outputs at
+    every real position, and the gradients of every weight and bias under an upstream gradient that is zero at pad positions (what the
+    kernel pooling hands back).  Documents end in padding of different lengths, one is all padding, one has a pad inside."""
+    import torch.nn.functional as Fn
+
+    rng = np.random.default_rng(N * 1000 + L)
+    V = 500
+    emb = _t(rng.normal(0, 0.5, (V, D)).astype(np.float32))
+    q = rng.integers(1, V, (N, Q))
+    d = rng.integers(1, V, (N, L))
+    for n in range(N):
+        d[n, int(rng.integers(1, L + 1)):] = 0
+    if N > 1:
+        d[1] = 0
+        q[N - 1, Q - 1] = 0
+    if L > 10:
+        d[0, 3] = 0
+        d[0, :3] = [7, 8, 9]
+    q, d = _t(q), _t(d)
+    ws = [_t(rng.normal(0, 0.1, (F, D, g)).astype(np.float32)).requires_grad_() for g in range(1, G + 1)]
+    bs = [_t(rng.normal(0, 0.1, (F,)).astype(np.float32)).requires_grad_() for g in range(1, G + 1)]
+    wb = [t for pair in zip(ws, bs) for t in pair]
+    qrep, drep = engine.NgramConv.apply(q, d, emb, *wb)
+    gq = _t(rng.normal(0, 1, qrep.shape).astype(np.float32)) * (q != 0)[:, None, :, None]
+    gd = _t(rng.normal(0, 1, drep.shape).astype(np.float32)) * (d != 0)[:, None, :, None]
+    ((qrep * gq).sum() + (drep * gd).sum()).backward()
+    got = [t.grad.clone() for t in wb]
+    w64 = [w.detach().double().requires_grad_() for w in ws]
+    b64 = [b.detach().double().requires_grad_() for b in bs]
+    want_q, want_d = [], []
+    for g in range(1, G + 1):
+        for ids, out in ((q, want_q), (d, want_d)):
+            x = Fn.pad(emb.double()[ids].permute(0, 2, 1), (0, g - 1))
+            out.append(Fn.conv1d(x, w64[g - 1], b64[g - 1]).permute(0, 2, 1))
+    want_q, want_d = torch.stack(want_q, 1), torch.stack(want_d, 1)
+    ((want_q * gq.double()).sum() + (want_d * gd.double()).sum()).backward()
+    for have, want, ids in ((qrep, want_q, q), (drep, want_d, d)):
+        real = (ids != 0)[:, None, :, None].expand_as(have)
+        assert torch.isfinite(have).all()
+        err = ((have.double() - want).abs() * real).max()
+        assert float(err.detach()) <= 1e-5 * float(want.detach().abs().max()), float(err.detach())
+    for have, want in zip(got, [t.grad for pair in zip(w64, b64) for t in pair]):
+        assert have.shape == want.shape
+        assert float((have.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, (tuple(have.shape), float((have.double() - want).abs().max()))
+    bad = d.clone()
+    bad[0, 0] = V
+    with pytest.raises(IndexError):
+        engine.NgramConv.apply(q, bad, emb, *wb)
+
+
 @pytest.mark.parametrize("name", ["default", "nocross_2fc_short"])
 def test_convknrm_hip_kernel_pooling_matches_autograd_through_aten(name):
     """ConvKNRM's training step behind its convolutions - cosine of every n-gram view pair, pad masks, RBF kernel pooling, log / mask /
