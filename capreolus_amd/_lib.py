@@ -85,7 +85,8 @@ SIGNATURES = {
     "capamd_ngram_conv_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "capamd_ngram_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "capamd_ngram_conv_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _sz, _vp, _vp]),
-    "capamd_kernel_pool_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "capamd_kernel_pool_chunks": (_i, [_i]),
+    "capamd_kernel_pool_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_kernel_pool_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_pacrr_convmax_forward": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "capamd_pacrr_convmax_backward": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

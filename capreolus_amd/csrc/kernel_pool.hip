@@ -41,11 +41,20 @@ struct PoolArgs {
   float* ksum;            // [B, GD, T, K]   forward -> backward
   float* rowsum;          // [B, GD, T]
   const float* gfeat;     // [B, K V]
-  float* dq_part;         // [B, GD, T, F]   per document view: summed over it by the caller where a query view meets several
+  float* dq_part;         // [B, GD, C, T, F]   per document view and chunk: summed over them by the caller
   float* dd;              // [B, GD, L, F]
-  float* dmu_part;        // [B GD, K]
-  float* dsigma_part;     // [B GD, K]
+  float* dmu_part;        // [B GD C, K]
+  float* dsigma_part;     // [B GD C, K]
+  int C;                  // chunks a document's real positions are split into: one workgroup per (pair, document view, chunk)
+  float* part;            // forward: [B, GD, C, T, K + 1] kernel sums and row sum of every chunk -> pool_finish_kernel
 };
+
+// chunks per document: ~160 positions each - a (pair, view) per workgroup leaves a batch of 64 documents on 192 of 256 CUs for as long as
+// its LONGEST document takes
+__host__ __device__ inline int pool_chunks(int L) {
+  const int c = (L + 159) / 160;
+  return c < 1 ? 1 : (c > 8 ? 8 : c);
+}
 
 // the a view of query vector t of block (b, gb), and the view index v of its pair
 __device__ __forceinline__ int pool_ga(const PoolArgs& a, int t, int gb) { return a.cross ? t / a.Q : gb; }
@@ -62,11 +71,30 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
   int* qpad = reinterpret_cast<int*>(araw + kPoolMaxT);     // [T]
   float* coef = reinterpret_cast<float*>(qpad + kPoolMaxT); // [T][16]   (BWD)
   float* red = coef + kPoolMaxT * 16;                       // [16 groups][T][16] forward sums / [16][F] backward slices
+  int* jl = reinterpret_cast<int*>(red + 16 * kPoolMaxT * 16 + 16 * kPoolMaxT + 16 * a.F + 64);   // [L] the real positions, then the pads (descending from the end)
+  __shared__ int n_real_s;
   const int tid = threadIdx.x, lane16 = tid & 15, g = tid >> 4;
-  const int b = blockIdx.x / a.GD, gb = blockIdx.x % a.GD;
+  const int b = blockIdx.x / a.GD, gb = blockIdx.x % a.GD, chunk = blockIdx.y;
   const int V = a.cross ? a.GQ * a.GD : a.GD;
   const int F4 = a.F >> 2;
 
+  // the document's real positions in order (front of jl) and its pads (back of jl): pads never reach the similarity loop - a masked entry
+  // is the constant 0, so what a pad adds to a kernel sum (and to d mu / d sigma) is a closed form times the number of pads
+  if (tid < 64) {          // wave 0
+    const int64_t* di = a.d_ids + (int64_t)b * a.L;
+    int nr = 0, np = 0;
+    for (int j0 = 0; j0 < a.L; j0 += 64) {
+      const int j = j0 + tid;
+      const bool in = j < a.L, real = in && di[j] != 0;
+      const uint64_t mr = __ballot(real), mp = __ballot(in && !real);
+      const uint64_t below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
+      if (real) jl[nr + __builtin_popcountll(mr & below)] = j;
+      else if (in) jl[a.L - 1 - (np + __builtin_popcountll(mp & below))] = j;
+      nr += __builtin_popcountll(mr);
+      np += __builtin_popcountll(mp);
+    }
+    if (tid == 0) n_real_s = nr;
+  }
   // the query vectors of this block's pairs, their norms, the pad flags
   for (int i = tid; i < T * F4; i += 256) {
     const int t = i / F4, c = i - t * F4;
@@ -112,7 +140,30 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     }
   }
   const float* drow = a.drep + ((int64_t)b * a.GD + gb) * a.L * a.F;
-  for (int j = g; j < a.L; j += 16) {
+  const int n_real = n_real_s, n_pad = a.L - n_real;
+  if (g == 0 && n_pad > 0 && chunk == 0) {          // the pads' share: similarity 0 at every one of them
+    const float adj = 0.f - mu_k, k0 = __builtin_amdgcn_exp2f(adj * adj * c_k);
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+      if (t < T) {
+        if (!BWD) acc[t] += (float)n_pad * k0;
+        else {
+          const float w = lane16 < a.K ? coef[t * 16 + lane16] * k0 * adj / (sg_k * sg_k) : 0.f;
+          dmu += (float)n_pad * w;
+          dsg += (float)n_pad * (w * adj / sg_k);
+        }
+      }
+  }
+  if (BWD) {                          // no gradient into a pad position's vector
+    float* dz = a.dd + ((int64_t)b * a.GD + gb) * a.L * a.F;
+    for (int i = tid + 256 * chunk; i < n_pad * F4; i += 256 * a.C) {
+      const int p = i / F4, c = i - p * F4;
+      reinterpret_cast<float4*>(dz + (int64_t)jl[a.L - 1 - p] * a.F)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const int ji_lo = (int)((int64_t)n_real * chunk / a.C), ji_hi = (int)((int64_t)n_real * (chunk + 1) / a.C);
+  for (int ji = ji_lo + g; ji < ji_hi; ji += 16) {
+    const int j = jl[ji];
     float4 x[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -124,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     for (int i = 0; i < NC; ++i) nb2 += x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w;
     nb2 = group_allreduce(nb2);
     const float braw = sqrtf(nb2), nb = braw + 1e-9f;
-    const bool dpad = a.d_ids[(int64_t)b * a.L + j] == 0;
+    constexpr bool dpad = false;        // (real positions only)
     float s[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
@@ -197,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     }
   }
 
-  const int64_t blk = (int64_t)b * a.GD + gb;
+  const int64_t blk = ((int64_t)b * a.GD + gb) * a.C + chunk;
   if (!BWD) {
-    // 16 groups -> one, fixed order; lane (group 0) k then has S[t][k]
+    // 16 groups -> one, fixed order: this chunk's kernel sums S[t][k] and row sums (pool_finish_kernel adds the chunks up)
 #pragma unroll
     for (int t = 0; t < TT; ++t)
       if (t < T) {
@@ -207,31 +258,16 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
         if (lane16 == 0) red[16 * kPoolMaxT * 16 + g * kPoolMaxT + t] = rs[t];
       }
     __syncthreads();
-    float* S = coef;         // reuse: [T][16]
     for (int i = tid; i < T * 16; i += 256) {
       const int t = i >> 4, k = i & 15;
       float v = 0.f;
       for (int gg = 0; gg < 16; ++gg) v += red[(gg * kPoolMaxT + t) * 16 + k];
-      S[i] = v;
-      if (k < a.K) a.ksum[(blk * T + t) * a.K + k] = v;
+      if (k < a.K) a.part[(blk * T + t) * (a.K + 1) + k] = v;
     }
     if (tid < T) {
       float v = 0.f;
       for (int gg = 0; gg < 16; ++gg) v += red[16 * kPoolMaxT * 16 + gg * kPoolMaxT + tid];
-      a.rowsum[blk * T + tid] = v;
-      an[tid] = v;           // (norms are dead: keep the row sum next to S)
-    }
-    __syncthreads();
-    // feat[k V + v] = sum over the Q query positions of the pair
-    const int npair = a.cross ? a.GQ : 1;
-    for (int i = tid; i < npair * a.K; i += 256) {
-      const int pr = i / a.K, k = i - pr * a.K;
-      float f = 0.f;
-      for (int q = 0; q < a.Q; ++q) {
-        const int t = pr * a.Q + q;
-        f += an[t] != 0.f ? logf(S[t * 16 + k] + 1e-6f) : 0.f;
-      }
-      a.feat[(int64_t)b * a.K * V + k * V + pool_v(a, pr * a.Q, gb)] = f;
+      a.part[(blk * T + tid) * (a.K + 1) + a.K] = v;
     }
   } else {
     // d mu / d sigma partials of this block: kernel lanes over the 16 groups
@@ -274,6 +310,39 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
   }
 }
 
+// forward, second half: the chunks of a (pair, document view) summed in their order -> ksum, rowsum, and the view's features
+//   feat[k V + v] = sum over the Q query positions of the pair of (row sum != 0 ? log(S + 1e-6) : 0)
+__global__ __launch_bounds__(256) void pool_finish_kernel(PoolArgs a) {
+  __shared__ float S[kPoolMaxT * 16];
+  __shared__ float R[kPoolMaxT];
+  const int T = (a.cross ? a.GQ : 1) * a.Q, V = a.cross ? a.GQ * a.GD : a.GD;
+  const int tid = threadIdx.x, b = blockIdx.x / a.GD, gb = blockIdx.x % a.GD;
+  const int64_t blk = (int64_t)b * a.GD + gb;
+  for (int i = tid; i < T * (a.K + 1); i += 256) {
+    const int t = i / (a.K + 1), k = i - t * (a.K + 1);
+    float v = 0.f;
+    for (int c = 0; c < a.C; ++c) v += a.part[((blk * a.C + c) * T + t) * (a.K + 1) + k];
+    if (k < a.K) {
+      S[t * 16 + k] = v;
+      a.ksum[(blk * T + t) * a.K + k] = v;
+    } else {
+      R[t] = v;
+      a.rowsum[blk * T + t] = v;
+    }
+  }
+  __syncthreads();
+  const int npair = a.cross ? a.GQ : 1;
+  for (int i = tid; i < npair * a.K; i += 256) {
+    const int pr = i / a.K, k = i - pr * a.K;
+    float f = 0.f;
+    for (int q = 0; q < a.Q; ++q) {
+      const int t = pr * a.Q + q;
+      f += R[t] != 0.f ? logf(S[t * 16 + k] + 1e-6f) : 0.f;
+    }
+    a.feat[(int64_t)b * a.K * V + k * V + pool_v(a, pr * a.Q, gb)] = f;
+  }
+}
+
 int pool_check(const PoolArgs& a) {
   if (!a.qrep || !a.drep || !a.q_ids || !a.d_ids || !a.mu || !a.sigma || !a.ksum || !a.rowsum) return CAPAMD_ERR_ARG;
   if (a.B < 0 || a.GQ < 1 || a.GD < 1 || a.Q < 1 || a.L < 1 || a.F < 4 || (a.F & 3) || a.F > 64 * kPoolMaxNC || a.K < 1 || a.K > kPoolMaxK)
@@ -286,7 +355,8 @@ int pool_check(const PoolArgs& a) {
 template <bool BWD>
 int pool_launch(const PoolArgs& a, void* stream) {
   if (a.B == 0) return CAPAMD_OK;
-  const size_t lds = ((size_t)kPoolMaxT * a.F + 3 * kPoolMaxT + kPoolMaxT * 16 + 16 * kPoolMaxT * 16 + 16 * kPoolMaxT + 16 * (size_t)a.F + 64) * 4;
+  const size_t lds = ((size_t)kPoolMaxT * a.F + 3 * kPoolMaxT + kPoolMaxT * 16 + 16 * kPoolMaxT * 16 + 16 * kPoolMaxT + 16 * (size_t)a.F + 64 + (size_t)a.L) * 4;
+  if (lds > 160 * 1024) return CAPAMD_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   const int nc = (a.F + 63) / 64;
@@ -295,7 +365,7 @@ int pool_launch(const PoolArgs& a, void* stream) {
     auto k = kernel_pool_kernel<NC_, TT_, BWD>;                                                                              \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return CAPAMD_ERR_LAUNCH;                                                                                              \
-    hipLaunchKernelGGL(k, dim3(a.B * a.GD), dim3(256), lds, s, a);                                                           \
+    hipLaunchKernelGGL(k, dim3(a.B * a.GD, a.C), dim3(256), lds, s, a);                                                      \
   } while (0)
 #define GO(NC_)                                 \
   do {                                          \
@@ -311,16 +381,20 @@ int pool_launch(const PoolArgs& a, void* stream) {
   }
 #undef GO
 #undef GO2
+  if (!BWD) hipLaunchKernelGGL(pool_finish_kernel, dim3(a.B * a.GD), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
 }  // namespace
 
+extern "C" int capamd_kernel_pool_chunks(int L) { return pool_chunks(L); }
+
 extern "C" int capamd_kernel_pool_forward(const float* qrep, const float* drep, const int64_t* q_ids, const int64_t* d_ids, int B, int GQ, int GD,
                                           int Q, int L, int F, int crossmatch, const float* mu, const float* sigma, int K, float* feat,
-                                          float* ksum, float* rowsum, void* stream) {
-  PoolArgs a{qrep, drep, q_ids, d_ids, B, GQ, GD, Q, L, F, crossmatch ? 1 : 0, mu, sigma, K, feat, ksum, rowsum, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (!feat) return CAPAMD_ERR_ARG;
+                                          float* ksum, float* rowsum, float* chunk_sums, void* stream) {
+  PoolArgs a{qrep, drep, q_ids, d_ids, B, GQ, GD, Q, L, F, crossmatch ? 1 : 0, mu, sigma, K, feat, ksum, rowsum, nullptr, nullptr, nullptr, nullptr, nullptr,
+             pool_chunks(L), chunk_sums};
+  if (!feat || !chunk_sums) return CAPAMD_ERR_ARG;
   const int rc = pool_check(a);
   return rc != CAPAMD_OK ? rc : pool_launch<false>(a, stream);
 }
@@ -330,7 +404,7 @@ extern "C" int capamd_kernel_pool_backward(const float* qrep, const float* drep,
                                            const float* ksum, const float* rowsum, float* dq_part, float* dd, float* dmu_part,
                                            float* dsigma_part, void* stream) {
   PoolArgs a{qrep, drep, q_ids, d_ids, B, GQ, GD, Q, L, F, crossmatch ? 1 : 0, mu, sigma, K, nullptr, const_cast<float*>(ksum), const_cast<float*>(rowsum),
-             gfeat, dq_part, dd, dmu_part, dsigma_part};
+             gfeat, dq_part, dd, dmu_part, dsigma_part, pool_chunks(L), nullptr};
   if (!gfeat || !dq_part || !dd || !dmu_part || !dsigma_part) return CAPAMD_ERR_ARG;
   const int rc = pool_check(a);
   return rc != CAPAMD_OK ? rc : pool_launch<true>(a, stream);

@@ -128,38 +128,49 @@ __global__ __launch_bounds__(256, 2) void ngram_forward_kernel(ConvArgs a, int t
     const int ksteps = a.Dp / 32, steps = g1 * ksteps;
     const float* wt = a.wt + (int64_t)part_of(g1, 0) * a.Dp * a.F;
     float4 ra[4], rb[4];
+    // (every load unconditional - a clamped address, the value masked afterwards: a load under a condition becomes a branch with a
+    //  wait for everything in flight behind it, and the eight loads of a step then go out one round trip at a time)
     auto fetch = [&](int s) {
       const int c = s / ksteps, k0 = (s - c * ksteps) * 32;
+      const int d = k0 + 4 * (tid & 7);
+      const int dcl = d < a.D ? d : 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 3) + 32 * i, d = k0 + 4 * (tid & 7);
-        const int64_t id = rid[c][r];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0 && d < a.D) v = *reinterpret_cast<const float4*>(a.emb + id * a.D + d);        // (D % 4 == 0)
-        if (c == 0 && d == a.D) v.x = 1.f;                                                            // the bias column
-        ra[i] = v;
+        const int64_t id = rid[c][(tid >> 3) + 32 * i];
+        ra[i] = *reinterpret_cast<const float4*>(a.emb + (id >= 0 ? id : 0) * a.D + dcl);        // (D % 4 == 0)
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kk = (tid >> 5) + 8 * i, f = f0 + 4 * (tid & 31);
-        rb[i] = f < a.F ? *reinterpret_cast<const float4*>(wt + ((int64_t)c * a.Dp + k0 + kk) * a.F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = *reinterpret_cast<const float4*>(wt + ((int64_t)c * a.Dp + k0 + kk) * a.F + (f < a.F ? f : 0));
       }
     };
-    auto stage = [&]() {
+    // (masked HERE, a whole MFMA loop after the loads were issued: touching a loaded value earlier makes the wave wait for it there)
+    auto stage = [&](int s) {
+      const int c = s / ksteps, d = (s - c * ksteps) * 32 + 4 * (tid & 7);
+      const float one = (c == 0 && d == a.D) ? 1.f : 0.f;                                         // (d == D: the bias column)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const bool live = rid[c][(tid >> 3) + 32 * i] >= 0 && d < a.D;
         float* p = As + ((tid >> 3) + 32 * i) * kPA + 4 * (tid & 7);
-        p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+        p[0] = live ? ra[i].x : one; p[1] = live ? ra[i].y : 0.f; p[2] = live ? ra[i].z : 0.f; p[3] = live ? ra[i].w : 0.f;
       }
+      const bool cols = f0 + 4 * (tid & 31) < a.F;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Bs + ((tid >> 5) + 8 * i) * kPB + 4 * (tid & 31)) = rb[i];
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(Bs + ((tid >> 5) + 8 * i) * kPB + 4 * (tid & 31)) = cols ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
+#ifndef CAPAMD_NC_ABL
+#define CAPAMD_NC_ABL 0        // profiling builds: 1 = the K loop fetches nothing after its first step, 2 = nor stages anything (MFMAs on stale tiles)
+#endif
     fetch(0);
     for (int s = 0; s < steps; ++s) {
-      __syncthreads();          // the previous step's reads are done
-      stage();
-      __syncthreads();
-      if (s + 1 < steps) fetch(s + 1);
+      if (!(CAPAMD_NC_ABL & 2) || s == 0) {
+        __syncthreads();          // the previous step's reads are done
+        stage(s);
+        __syncthreads();
+      }
+      if (s + 1 < steps && !(CAPAMD_NC_ABL & 1)) fetch(s + 1);
       const float* ap = As + (wr * 64 + (lane & 31)) * kPA + (lane >> 5);
       const float* bp = Bs + (lane >> 5) * kPB + wc * 64 + (lane & 31);
 #pragma unroll
@@ -242,39 +253,75 @@ __global__ __launch_bounds__(256, 1) void ngram_backward_kernel(ConvArgs a, int 
   // a thread stages ONE position of a block (8 threads per position): its tap-c table row, its gradient row
   const int r = tid >> 3, sub = tid & 7;
   float4 rx[XV], rr[4];
-  bool bad = false;
-  auto fetch = [&](int blk) {
+  bool bad = false, live_row = false, in_range = false;
+  // the table row of this thread's position of block blk: one unconditional load (the id, clamped address) whose value is looked at one
+  // block LATER - the id -> row address -> row loads chain costs a round trip per link, so the id travels a block ahead of its rows
+  auto tap_id = [&](int blk) -> int64_t {
+    const int seg = blk < blocks0 ? 0 : 1;
+    const int64_t m = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock + r;
+    const int len = a.len[seg];
+    const int64_t n = m / len;
+    const int j = (int)(m - n * len) + c;
+    return a.ids[seg][(n < a.N && j < len) ? n * len + j : 0];           // (the raw value: fetch() decides whether it counts)
+  };
+  auto fetch = [&](int blk, int64_t id) {
     const int seg = blk < blocks0 ? 0 : 1;
     const int64_t m = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock + r;
     const int len = a.len[seg];
     const int64_t M = (int64_t)a.N * len;
-    const int64_t id = tap_row(a, seg, m, c, bad);
+    {
+      const int64_t n = m / len;
+      if (!(n < a.N && (int)(m - n * len) + c < len)) id = -1;           // beyond the sequence end: the ConstantPad1d's zero row
+      else if (id < 0 || id >= a.V) {
+        bad = true;
+        id = -1;
+      }
+    }
     const float* row = a.emb + (id >= 0 ? id : 0) * a.D;
+    const int n = (int)(m < M ? m / len : 0), j = (int)(m < M ? m - (int64_t)n * len : 0);
+    const float* src = a.dout[seg] + ((((int64_t)n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
+    // (unconditional loads from clamped addresses, masked afterwards: see the forward kernel)
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
       const int d = 4 * (sub + 8 * k);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (id >= 0 && d < a.D) v = *reinterpret_cast<const float4*>(row + d);           // (D % 4 == 0)
-      if (c == 0 && d == a.D && m < M) v.x = 1.f;                                       // the bias column
-      rx[k] = v;
+      rx[k] = *reinterpret_cast<const float4*>(row + (d < a.D ? d : 0));           // (D % 4 == 0)
     }
-    const int n = (int)(m / len), j = (int)(m - (int64_t)n * len);
-    const float* src = a.dout[seg] + ((((int64_t)n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = f0 + 4 * (sub + 8 * i);
-      rr[i] = (m < M && f < a.F) ? *reinterpret_cast<const float4*>(src + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rr[i] = *reinterpret_cast<const float4*>(src + (f < a.F ? f : 0));
+    }
+    live_row = id >= 0;
+    in_range = m < M;
+  };
+  // (masked a whole MFMA loop after the loads were issued)
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int d = 4 * (sub + 8 * k);
+      const bool live = live_row && d < a.D;
+      float4 v;
+      v.x = live ? rx[k].x : (c == 0 && d == a.D && in_range ? 1.f : 0.f);        // (d == D: the bias column)
+      v.y = live ? rx[k].y : 0.f;
+      v.z = live ? rx[k].z : 0.f;
+      v.w = live ? rx[k].w : 0.f;
+      *reinterpret_cast<float4*>(Xs + r * PX + d) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int fo = 4 * (sub + 8 * i);
+      *reinterpret_cast<float4*>(Rs + r * kPB + fo) = (in_range && f0 + fo < a.F) ? rr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  if (total > 0) fetch(list[0]);
+  int64_t id_next = -1;
+  if (total > 0) fetch(list[0], tap_id(list[0]));
+  if (total > 1) id_next = tap_id(list[1]);
   for (int i = 0; i < total; ++i) {
     __syncthreads();            // the previous block's reads are done
-#pragma unroll
-    for (int k = 0; k < XV; ++k) *reinterpret_cast<float4*>(Xs + r * PX + 4 * (sub + 8 * k)) = rx[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(Rs + r * kPB + 4 * (sub + 8 * k)) = rr[k];
+    stage();
     __syncthreads();
-    if (i + 1 < total) fetch(list[i + 1]);
+    if (i + 1 < total) fetch(list[i + 1], id_next);
+    if (i + 2 < total) id_next = tap_id(list[i + 2]);
     const float* xp = Xs + (lane >> 5) * PX + (lane & 31);
     const float* rp = Rs + (lane >> 5) * kPB + wave * 32 + (lane & 31);
 #pragma unroll 2

@@ -788,8 +788,10 @@ class KernelPool(torch.autograd.Function):
         feat = torch.empty((B, K * V), dtype=torch.float32, device=qr.device)
         ksum = torch.empty((B, GD, T, K), dtype=torch.float32, device=qr.device)
         rowsum = torch.empty((B, GD, T), dtype=torch.float32, device=qr.device)
+        C = int(_lib.load().capamd_kernel_pool_chunks(L))
+        sums = torch.empty((B, GD, C, T, K + 1), dtype=torch.float32, device=qr.device)
         rc = _lib.load().capamd_kernel_pool_forward(_ptr(qr), _ptr(dr), _ptr(qi), _ptr(di), B, GQ, GD, Q, L, F, int(bool(crossmatch)), _ptr(m), _ptr(sg), K,
-                                                    _ptr(feat), _ptr(ksum), _ptr(rowsum), _stream())
+                                                    _ptr(feat), _ptr(ksum), _ptr(rowsum), _ptr(sums), _stream())
         _lib.check(rc, "capamd_kernel_pool_forward")
         ctx.save_for_backward(qr, dr, qi, di, m, sg, ksum, rowsum)
         ctx.crossmatch = bool(crossmatch)
@@ -801,14 +803,16 @@ class KernelPool(torch.autograd.Function):
         B, GQ, Q, F = qr.shape
         GD, L = dr.shape[1], dr.shape[2]
         K, T = m.numel(), ksum.shape[2]
-        dq_part = torch.empty((B, GD, T, F), dtype=torch.float32, device=qr.device)
+        C = int(_lib.load().capamd_kernel_pool_chunks(L))
+        dq_part = torch.empty((B, GD, C, T, F), dtype=torch.float32, device=qr.device)
         dd = torch.empty_like(dr)
-        dmu = torch.empty((B * GD, K), dtype=torch.float32, device=qr.device)
+        dmu = torch.empty((B * GD * C, K), dtype=torch.float32, device=qr.device)
         dsg = torch.empty_like(dmu)
         rc = _lib.load().capamd_kernel_pool_backward(_ptr(qr), _ptr(dr), _ptr(qi), _ptr(di), B, GQ, GD, Q, L, F, int(ctx.crossmatch), _ptr(m), _ptr(sg), K,
                                                      _ptr(_f32(g)), _ptr(ksum), _ptr(rowsum), _ptr(dq_part), _ptr(dd), _ptr(dmu), _ptr(dsg), _stream())
         _lib.check(rc, "capamd_kernel_pool_backward")
-        dq = dq_part.view(B, GD, GQ, Q, F).sum(1) if ctx.crossmatch else dq_part     # (without crossmatch block gd holds query view gd: T = Q)
+        # (without crossmatch block gd holds query view gd: T = Q)
+        dq = dq_part.view(B, GD * C, GQ, Q, F).sum(1) if ctx.crossmatch else dq_part.sum(2)
         return dq, dd, None, None, dmu.sum(0), dsg.sum(0), None
 
 

@@ -417,14 +417,18 @@ int capamd_ngram_conv_backward(const int64_t* q_ids, const int64_t* d_ids, int N
  * qrep fp32 [B, GQ, Q, F] / drep fp32 [B, GD, L, F]: the GQ / GD n-gram views of query and document (F % 4 == 0, F <= 256);
  * q_ids / d_ids: the token ids (pad = 0: masked positions); crossmatch != 0: every (query view, document view) pair, V = GQ GD
  * views (v = gq GD + gd), else the matching ones (GQ == GD, V = GD).  (crossmatch ? GQ : 1) * Q <= 24, K <= 16.
+ * A document's real positions are split into C = capamd_kernel_pool_chunks(L) chunks (1..8, ~160 positions each), one workgroup per
+ * (pair, document view, chunk); pad positions never reach the similarity loop (a masked entry is the constant 0: a closed form).
  * forward:  feat fp32 [B, K V] (feature k V + v, the reference's kernels.reshape(B, K V, Q, L) order); ksum fp32 [B, GD, T, K] and
- *           rowsum fp32 [B, GD, T] (T = (crossmatch ? GQ : 1) Q) are what the backward needs of it.
- * backward: gfeat fp32 [B, K V] -> dq_part fp32 [B, GD, T, F] (the caller sums over GD the blocks that share a query view: with
- *           crossmatch view gq = t / Q of every gd; without, block gd holds query view gd), dd fp32 [B, GD, L, F],
- *           dmu_part / dsigma_part fp32 [B GD, K] (summed over their first axis by the caller). */
+ *           rowsum fp32 [B, GD, T] (T = (crossmatch ? GQ : 1) Q) are what the backward needs of it; chunk_sums: B GD C T (K + 1) fp32
+ *           values of scratch (the chunks' partial sums, added up in their order by a second launch).
+ * backward: gfeat fp32 [B, K V] -> dq_part fp32 [B, GD, C, T, F] (the caller sums over C, and over GD the blocks that share a query
+ *           view: with crossmatch view gq = t / Q of every gd; without, block gd holds query view gd), dd fp32 [B, GD, L, F] (zero
+ *           rows at pad positions), dmu_part / dsigma_part fp32 [B GD C, K] (summed over their first axis by the caller). */
+int capamd_kernel_pool_chunks(int L);
 int capamd_kernel_pool_forward(const float* qrep, const float* drep, const int64_t* q_ids, const int64_t* d_ids, int B, int GQ, int GD, int Q,
                                int L, int F, int crossmatch, const float* mu, const float* sigma, int K, float* feat, float* ksum,
-                               float* rowsum, void* stream);
+                               float* rowsum, float* chunk_sums, void* stream);
 int capamd_kernel_pool_backward(const float* qrep, const float* drep, const int64_t* q_ids, const int64_t* d_ids, int B, int GQ, int GD, int Q,
                                 int L, int F, int crossmatch, const float* mu, const float* sigma, int K, const float* gfeat,
                                 const float* ksum, const float* rowsum, float* dq_part, float* dd, float* dmu_part, float* dsigma_part,
