@@ -34,7 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kNcMaxG = 4;             // n-gram sizes 1..G
 constexpr int kNcMaxParts = kNcMaxG * (kNcMaxG + 1) / 2;
 constexpr int kNcMaxDp = 320;          // padded embedding width (D + 1 rounded up to 32): D <= 319
-constexpr int kFwdRows = 128;          // positions per forward tile
+constexpr int kFwdRows = 64;           // positions per forward tile
 constexpr int kPA = 33;                // LDS pitch of the gathered-row tile (floats): column reads conflict-free
 constexpr int kPB = 160;               // LDS pitch of a 128-wide panel: the two k rows of an MFMA land 32 banks apart
 constexpr int kBwdBlock = 32;          // positions per backward K step
@@ -60,12 +60,13 @@ struct ConvArgs {
 __device__ __forceinline__ int part_of(int g1, int c) { return g1 * (g1 - 1) / 2 + c; }   // g1 = n-gram size, 1-based
 
 // ---- weights: Conv1d layout -> tap panels ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ngram_pack_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void ngram_pack_kernel(ConvArgs a, unsigned* queue) {
   const int part = blockIdx.y;
   int g1 = 1;
   while (part_of(g1 + 1, 0) <= part) ++g1;
   const int c = part - part_of(g1, 0);
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && part == 0) *queue = 0u;          // the forward kernel's work queue
   if (i >= a.Dp * a.F) return;
   const int d = i / a.F, f = i - d * a.F;
   float v = 0.f;
@@ -89,117 +90,136 @@ __device__ __forceinline__ int64_t tap_row(const ConvArgs& a, int seg, int64_t m
 }
 
 // ---- forward --------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void ngram_forward_kernel(ConvArgs a, int tiles0) {
+// Persistent workgroups over a queue of (64-position tile, n-gram size, 128-filter panel) units, heaviest n-gram size first: a training
+// batch's documents end in padding of very different lengths, so which tiles hold work is known only on the device, and a g = 3 unit
+// costs three times a g = 1 unit - a fixed grid left CUs idle for 40 % of the launch (profiles/r04/ngram_conv.txt).
+__global__ __launch_bounds__(256, 3) void ngram_forward_kernel(ConvArgs a, int tiles0, int tiles, int panels, unsigned* queue) {
   __shared__ float As[kFwdRows * kPA];
   __shared__ __attribute__((aligned(16))) float Bs[32 * kPB];
   __shared__ int64_t rid[kNcMaxG][kFwdRows];
+  __shared__ int64_t orow[kFwdRows];
   __shared__ int any_real;
+  __shared__ unsigned unit_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seg = (int)blockIdx.x < tiles0 ? 0 : 1;
-  const int64_t m0 = (int64_t)(seg ? blockIdx.x - tiles0 : blockIdx.x) * kFwdRows;
-  const int g1 = a.G - (int)blockIdx.y;          // heavy n-gram sizes first
-  const int f0 = blockIdx.z * 128;
-  const int len = a.len[seg];
-  const int64_t M = (int64_t)a.N * len;
-  if (tid == 0) any_real = 0;
-  __syncthreads();
-  {
-    bool bad = false, real = false;
-    for (int i = tid; i < g1 * kFwdRows; i += 256) {
-      const int c = i / kFwdRows, r = i - c * kFwdRows;
-      const int64_t id = tap_row(a, seg, m0 + r, c, bad);
-      rid[c][r] = id;
-      if (c == 0 && id > 0) real = true;
+  const unsigned units = (unsigned)tiles * a.G * panels;
+  const int ksteps = a.Dp / 32;
+  const int wr = wave >> 1, wc = wave & 1;               // a wave: 32 positions x 64 filters
+  for (;;) {
+    __syncthreads();                                     // (the previous unit's readers of unit_s, rid, any_real are done)
+    if (tid == 0) {
+      unit_s = atomicAdd(queue, 1u);
+      any_real = 0;
     }
-    if (bad) atomicOr(a.status, CAPAMD_STATUS_DOC_ID_RANGE);
-    if (real) any_real = 1;
-  }
-  __syncthreads();
-  float* out = a.out[seg];
-  const int wr = wave >> 1, wc = wave & 1;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+    __syncthreads();
+    const unsigned unit = unit_s;
+    if (unit >= units) return;
+    const int tile = unit % tiles, rest = unit / tiles;
+    const int f0 = (rest % panels) * 128, g1 = a.G - rest / panels;          // heavy n-gram sizes first
+    const int seg = tile < tiles0 ? 0 : 1;
+    const int64_t m0 = (int64_t)(seg ? tile - tiles0 : tile) * kFwdRows;
+    const int len = a.len[seg];
+    const int64_t M = (int64_t)a.N * len;
+    // one thread per position of the tile: its (sequence, offset) once - the only division of the unit -, the table rows of its taps,
+    // where its output row starts
+    if (tid < kFwdRows) {
+      bool bad = false, real = false;
+      const int64_t m = m0 + tid;
+      const unsigned n = m < M ? (unsigned)m / (unsigned)len : 0u;             // (N * len < 2^31: checked by the host)
+      const int j = m < M ? (int)((unsigned)m - n * (unsigned)len) : 0;
+      orow[tid] = m < M ? ((int64_t)n * a.G + (g1 - 1)) * len + j : -1;
+      for (int c = 0; c < g1; ++c) {
+        int64_t id = -1;
+        if (m < M && j + c < len) {
+          id = a.ids[seg][(int64_t)n * len + j + c];
+          if (id < 0 || id >= a.V) {
+            bad = true;
+            id = -1;
+          }
+        }
+        rid[c][tid] = id;
+        if (c == 0 && id > 0) real = true;
+      }
+      if (bad) atomicOr(a.status, CAPAMD_STATUS_DOC_ID_RANGE);
+      if (real) any_real = 1;
+    }
+    __syncthreads();
+    f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  if (any_real) {
-    const int ksteps = a.Dp / 32, steps = g1 * ksteps;
-    const float* wt = a.wt + (int64_t)part_of(g1, 0) * a.Dp * a.F;
-    float4 ra[4], rb[4];
-    // (every load unconditional - a clamped address, the value masked afterwards: a load under a condition becomes a branch with a
-    //  wait for everything in flight behind it, and the eight loads of a step then go out one round trip at a time)
-    auto fetch = [&](int s) {
-      const int c = s / ksteps, k0 = (s - c * ksteps) * 32;
-      const int d = k0 + 4 * (tid & 7);
-      const int dcl = d < a.D ? d : 0;
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    if (any_real) {
+      const int steps = g1 * ksteps;
+      const float* wt = a.wt + (int64_t)part_of(g1, 0) * a.Dp * a.F;
+      float4 ra[2], rb[4];
+      // (every load unconditional - a clamped address, the value masked afterwards: a load under a condition becomes a branch with a
+      //  wait for everything in flight behind it, and the loads of a step then go out one round trip at a time)
+      auto fetch = [&](int s) {
+        const int c = s / ksteps, k0 = (s - c * ksteps) * 32;
+        const int d = k0 + 4 * (tid & 7);
+        const int dcl = d < a.D ? d : 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t id = rid[c][(tid >> 3) + 32 * i];
-        ra[i] = *reinterpret_cast<const float4*>(a.emb + (id >= 0 ? id : 0) * a.D + dcl);        // (D % 4 == 0)
-      }
+        for (int i = 0; i < 2; ++i) {
+          const int64_t id = rid[c][(tid >> 3) + 32 * i];
+          ra[i] = *reinterpret_cast<const float4*>(a.emb + (id >= 0 ? id : 0) * a.D + dcl);        // (D % 4 == 0)
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = (tid >> 5) + 8 * i, f = f0 + 4 * (tid & 31);
-        rb[i] = *reinterpret_cast<const float4*>(wt + ((int64_t)c * a.Dp + k0 + kk) * a.F + (f < a.F ? f : 0));
-      }
-    };
-    // (masked HERE, a whole MFMA loop after the loads were issued: touching a loaded value earlier makes the wave wait for it there)
-    auto stage = [&](int s) {
-      const int c = s / ksteps, d = (s - c * ksteps) * 32 + 4 * (tid & 7);
-      const float one = (c == 0 && d == a.D) ? 1.f : 0.f;                                         // (d == D: the bias column)
+        for (int i = 0; i < 4; ++i) {
+          const int kk = (tid >> 5) + 8 * i, f = f0 + 4 * (tid & 31);
+          rb[i] = *reinterpret_cast<const float4*>(wt + ((int64_t)c * a.Dp + k0 + kk) * a.F + (f < a.F ? f : 0));
+        }
+      };
+      // (masked HERE, a whole MFMA loop after the loads were issued: touching a loaded value earlier makes the wave wait for it there)
+      auto stage = [&](int s) {
+        const int c = s / ksteps, d = (s - c * ksteps) * 32 + 4 * (tid & 7);
+        const float one = (c == 0 && d == a.D) ? 1.f : 0.f;                                         // (d == D: the bias column)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool live = rid[c][(tid >> 3) + 32 * i] >= 0 && d < a.D;
-        float* p = As + ((tid >> 3) + 32 * i) * kPA + 4 * (tid & 7);
-        p[0] = live ? ra[i].x : one; p[1] = live ? ra[i].y : 0.f; p[2] = live ? ra[i].z : 0.f; p[3] = live ? ra[i].w : 0.f;
-      }
-      const bool cols = f0 + 4 * (tid & 31) < a.F;
+        for (int i = 0; i < 2; ++i) {
+          const bool live = rid[c][(tid >> 3) + 32 * i] >= 0 && d < a.D;
+          float* p = As + ((tid >> 3) + 32 * i) * kPA + 4 * (tid & 7);
+          p[0] = live ? ra[i].x : one; p[1] = live ? ra[i].y : 0.f; p[2] = live ? ra[i].z : 0.f; p[3] = live ? ra[i].w : 0.f;
+        }
+        const bool cols = f0 + 4 * (tid & 31) < a.F;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(Bs + ((tid >> 5) + 8 * i) * kPB + 4 * (tid & 31)) = cols ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(Bs + ((tid >> 5) + 8 * i) * kPB + 4 * (tid & 31)) = cols ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      };
 #ifndef CAPAMD_NC_ABL
 #define CAPAMD_NC_ABL 0        // profiling builds: 1 = the K loop fetches nothing after its first step, 2 = nor stages anything (MFMAs on stale tiles)
 #endif
-    fetch(0);
-    for (int s = 0; s < steps; ++s) {
-      if (!(CAPAMD_NC_ABL & 2) || s == 0) {
-        __syncthreads();          // the previous step's reads are done
-        stage(s);
-        __syncthreads();
-      }
-      if (s + 1 < steps && !(CAPAMD_NC_ABL & 1)) fetch(s + 1);
-      const float* ap = As + (wr * 64 + (lane & 31)) * kPA + (lane >> 5);
-      const float* bp = Bs + (lane >> 5) * kPB + wc * 64 + (lane & 31);
+      fetch(0);
+      for (int s = 0; s < steps; ++s) {
+        if (!(CAPAMD_NC_ABL & 2) || s == 0) {
+          __syncthreads();          // the previous step's reads are done
+          stage(s);
+          __syncthreads();
+        }
+        if (s + 1 < steps && !(CAPAMD_NC_ABL & 1)) fetch(s + 1);
+        const float* ap = As + (wr * 32 + (lane & 31)) * kPA + (lane >> 5);
+        const float* bp = Bs + (lane >> 5) * kPB + wc * 64 + (lane & 31);
 #pragma unroll
-      for (int kp = 0; kp < 16; ++kp) {
-        const float a0 = ap[2 * kp], a1 = ap[32 * kPA + 2 * kp];
-        const float b0 = bp[2 * kp * kPB], b1 = bp[2 * kp * kPB + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kp = 0; kp < 16; ++kp) {
+          const float a0 = ap[2 * kp];
+          const float b0 = bp[2 * kp * kPB], b1 = bp[2 * kp * kPB + 32];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+        }
       }
     }
-  }
-  // C/D map of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+    // C/D map of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  (A tile without work: zeros.)
+    float* out = a.out[seg];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-      if (m >= M) continue;
-      const int64_t n = m / len;
-      const int j = (int)(m - n * len);
-      float* dst = out + (((n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
+      const int64_t o = orow[wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+      if (o < 0) continue;
+      float* dst = out + o * (int64_t)a.F;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int f = f0 + wc * 64 + jj * 32 + (lane & 31);
-        if (f < a.F) dst[f] = acc[i][jj][e];
+        if (f < a.F) dst[f] = acc[jj][e];
       }
     }
+  }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------------------
@@ -256,29 +276,24 @@ __global__ __launch_bounds__(256, 1) void ngram_backward_kernel(ConvArgs a, int 
   bool bad = false, live_row = false, in_range = false;
   // the table row of this thread's position of block blk: one unconditional load (the id, clamped address) whose value is looked at one
   // block LATER - the id -> row address -> row loads chain costs a round trip per link, so the id travels a block ahead of its rows
+  // (positions as 32-bit numbers - N * len < 2^31, checked by the host: one 32-bit division per thread and block)
   auto tap_id = [&](int blk) -> int64_t {
     const int seg = blk < blocks0 ? 0 : 1;
-    const int64_t m = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock + r;
-    const int len = a.len[seg];
-    const int64_t n = m / len;
-    const int j = (int)(m - n * len) + c;
-    return a.ids[seg][(n < a.N && j < len) ? n * len + j : 0];           // (the raw value: fetch() decides whether it counts)
+    const unsigned m = (unsigned)(seg ? blk - blocks0 : blk) * kBwdBlock + r, len = (unsigned)a.len[seg];
+    const unsigned n = m / len, j = m - n * len + c;
+    return a.ids[seg][(n < (unsigned)a.N && j < len) ? (int64_t)n * len + j : 0];           // (the raw value: fetch() decides whether it counts)
   };
   auto fetch = [&](int blk, int64_t id) {
     const int seg = blk < blocks0 ? 0 : 1;
-    const int64_t m = (int64_t)(seg ? blk - blocks0 : blk) * kBwdBlock + r;
-    const int len = a.len[seg];
-    const int64_t M = (int64_t)a.N * len;
-    {
-      const int64_t n = m / len;
-      if (!(n < a.N && (int)(m - n * len) + c < len)) id = -1;           // beyond the sequence end: the ConstantPad1d's zero row
-      else if (id < 0 || id >= a.V) {
-        bad = true;
-        id = -1;
-      }
+    const unsigned m = (unsigned)(seg ? blk - blocks0 : blk) * kBwdBlock + r, len = (unsigned)a.len[seg];
+    const unsigned M = (unsigned)a.N * len;
+    const unsigned n = m < M ? m / len : 0u, j = m < M ? m - n * len : 0u;
+    if (!(m < M && j + c < len)) id = -1;                                  // beyond the sequence end: the ConstantPad1d's zero row
+    else if (id < 0 || id >= a.V) {
+      bad = true;
+      id = -1;
     }
     const float* row = a.emb + (id >= 0 ? id : 0) * a.D;
-    const int n = (int)(m < M ? m / len : 0), j = (int)(m < M ? m - (int64_t)n * len : 0);
     const float* src = a.dout[seg] + ((((int64_t)n * a.G + (g1 - 1)) * len + j) * (int64_t)a.F);
     // (unconditional loads from clamped addresses, masked afterwards: see the forward kernel)
 #pragma unroll
@@ -384,7 +399,7 @@ int n_splits(int G, int F) { return 256 / (n_parts(G) * ((F + 127) / 128)) > 0 ?
 extern "C" size_t capamd_ngram_conv_workspace_floats(int D, int G, int F, int backward) {
   if (D < 1 || G < 1 || G > kNcMaxG || F < 1) return 0;
   const size_t panel = (size_t)n_parts(G) * padded_width(D) * F;
-  return backward ? panel * n_splits(G, F) : panel;
+  return backward ? panel * n_splits(G, F) : panel + 4;          // (forward: the tap panels and the work queue's counter)
 }
 
 extern "C" int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D,
@@ -400,11 +415,16 @@ extern "C" int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_
   if (workspace_floats < capamd_ngram_conv_workspace_floats(D, G, F, 0)) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(qrep) | reinterpret_cast<uintptr_t>(drep)) & 3) return CAPAMD_ERR_ALIGN;
   if (N == 0) return CAPAMD_OK;
+  if ((int64_t)N * L >= (1ll << 31) || (int64_t)N * Q >= (1ll << 31)) return CAPAMD_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ngram_pack_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a);
-  const int tiles0 = (int)(((int64_t)N * Q + kFwdRows - 1) / kFwdRows), tiles1 = (int)(((int64_t)N * L + kFwdRows - 1) / kFwdRows);
-  hipLaunchKernelGGL(ngram_forward_kernel, dim3(tiles0 + tiles1, G, (F + 127) / 128), dim3(256), 0, s, a, tiles0);
+  unsigned* queue = reinterpret_cast<unsigned*>(workspace + (size_t)n_parts(G) * a.Dp * F);
+  hipLaunchKernelGGL(ngram_pack_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a, queue);
+  const int64_t tiles0 = ((int64_t)N * Q + kFwdRows - 1) / kFwdRows, tiles1 = ((int64_t)N * L + kFwdRows - 1) / kFwdRows;
+  const int panels = (F + 127) / 128;
+  if ((tiles0 + tiles1) * G * panels >= (1ll << 31)) return CAPAMD_ERR_ARG;
+  const int64_t units = (tiles0 + tiles1) * G * panels;
+  hipLaunchKernelGGL(ngram_forward_kernel, dim3((unsigned)(units < 768 ? units : 768)), dim3(256), 0, s, a, (int)tiles0, (int)(tiles0 + tiles1), panels, queue);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
@@ -423,6 +443,7 @@ extern "C" int capamd_ngram_conv_backward(const int64_t* q_ids, const int64_t* d
   if (rc != CAPAMD_OK) return rc;
   if (workspace_floats < capamd_ngram_conv_workspace_floats(D, G, F, 1)) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(dqrep) | reinterpret_cast<uintptr_t>(ddrep)) & 15) return CAPAMD_ERR_ALIGN;
+  if ((int64_t)N * L >= (1ll << 31) || (int64_t)N * Q >= (1ll << 31)) return CAPAMD_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   a.S = n_splits(G, F);
