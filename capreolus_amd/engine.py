@@ -636,6 +636,27 @@ def knrm_train_step(query, posdoc, negdoc, packed, V, D, K, adam, train_kernels,
     return loss
 
 
+def convknrm_train_step(query, posdoc, negdoc, emb, G, F, K, crossmatch, adam, scoretanh, softmax, check=True):
+    """capamd_convknrm_train_step: score(pos), score(neg), the trainer's pairwise loss, backward, Adam - on the device; returns the loss [1]."""
+    _need_gpu(query, posdoc, negdoc, emb)
+    q, dp, dn, e = _i64(query), _i64(posdoc), _i64(negdoc), _f32(emb.detach())
+    B, Q = q.shape
+    L = dp.shape[1]
+    q2, d2 = torch.cat([q, q]), torch.cat([dp, dn])
+    lib = _lib.load()
+    ws = _step_workspace(q.device, int(lib.capamd_convknrm_train_step_workspace_floats(B, Q, L, e.shape[1], G, F, K, int(bool(crossmatch)))))
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    step_size, omb1, b2, eps, bc2s = adam.advance()
+    ptrs = (ctypes.c_void_p * len(adam.key))(*[p or None for p in adam.key])
+    st = status_word(q.device)
+    rc = lib.capamd_convknrm_train_step(_ptr(q2), _ptr(d2), B, Q, L, _ptr(e), e.shape[0], e.shape[1], G, F, K, int(bool(crossmatch)), ptrs, int(bool(scoretanh)),
+                                        int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_convknrm_train_step")
+    if check:
+        st.raise_if_set()
+    return loss
+
+
 def _step_workspace(device, n):
     key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _step_workspaces.get(key)

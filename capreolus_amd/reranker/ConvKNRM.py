@@ -74,6 +74,32 @@ class ConvKNRM_class(nn.Module):
         feats = engine.KernelPool.apply(a_reps, b_reps, query_sentence, sentence, mu, sigma, bool(self.p["crossmatch"]))
         return self.combine(feats)
 
+    def fused_train_step(self, d, optimizer, softmax=False):
+        """One whole training step on the device (capamd_convknrm_train_step: convolutions, kernel pooling, combine, pairwise loss,
+        backward, Adam - eleven launches, no autograd) - or None when this configuration keeps the autograd route (a two-layer `combine`,
+        geometries beyond the kernels' limits).  Parameters and Adam moments are updated in place; their version counters are bumped so
+        that weight-derived caches (the scoring kernel's projection tables) notice."""
+        G, Q = len(self.convs), d["query"].shape[1]
+        nf, D = self.p["filters"], self.embeddings.weight.shape[1]
+        if not self.p["singlefc"] or d["query"].shape[0] > 512:
+            return None
+        if nf % 4 or nf > 256 or (G if self.p["crossmatch"] else 1) * Q > 24 or self.kernels.count() > 16 or D % 4 or D > 316 or G > 4:
+            return None
+        ks = list(self.kernels.kernels)
+        lin = self.combine[0]
+        params = [k.mu for k in ks] + [k.sigma for k in ks]
+        for conv in self.convs:
+            params += [conv[0].weight, conv[0].bias]
+        params += [lin.weight, lin.bias]
+        hit = self.__dict__.get("_adam_step")
+        if hit is None or hit.optimizer is not optimizer or hit.key[: len(params)] != tuple(p.data_ptr() for p in params) or not hit.still_valid():
+            hit = self.__dict__["_adam_step"] = engine.AdamStep(optimizer, params)
+        loss = engine.convknrm_train_step(d["query"], d["posdoc"], d["negdoc"], self.embeddings.weight, G, nf, len(ks), bool(self.p["crossmatch"]), hit,
+                                          bool(self.p["scoretanh"]), softmax)
+        with torch.no_grad():
+            torch._foreach_mul_(hit.trained, 1.0)          # (exact no-op: the kernels wrote the parameters behind autograd's back)
+        return loss[0]
+
     def _forward_train_aten(self, sentence, query_sentence):
         """The reference's arithmetic (ConvKNRM.py:42-77, common.py:195-221) as ATen ops under autograd: the checker of the HIP
         training path in the tests, and the route of geometries the kernel-pooling kernel does not take."""
@@ -122,6 +148,14 @@ class ConvKNRM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def fused_train_step(self, d, optimizer, softmax=False):
+        return self.model.fused_train_step(d, optimizer, softmax)
+
+    def fused_step_available(self, batch_size):
+        """whether `fused_train_step` takes this configuration (a single-Linear `combine`, batches of <= 512 pairs, the HIP training kernels' geometry limits)"""
+        c = self.config
+        return bool(c["singlefc"]) and batch_size <= 512 and c["filters"] % 4 == 0 and c["filters"] <= 256 and c["maxngram"] <= 4
 
     def zero_grad(self, *args, **kwargs):
         self.model.zero_grad(*args, **kwargs)

@@ -410,6 +410,22 @@ int capamd_ngram_conv_backward(const int64_t* q_ids, const int64_t* d_ids, int N
                                int F, const float* dqrep, const float* ddrep, float* const* dconv_w, float* const* dconv_b,
                                float* workspace, size_t workspace_floats, int* status, void* stream);
 
+/* One ConvKNRM training step on the device (reference ConvKNRM.py:42-77 under trainer/pytorch.py:93-108, the loss
+ * reranker/common.py:96-103, torch.optim.Adam): convolutions (capamd_ngram_conv_forward) -> kernel pooling (capamd_kernel_pool_forward) ->
+ * single-Linear combine (+ tanh), pairwise loss (0 hinge / 1 softmax), its backward and Adam on the Linear in ONE workgroup -> pooling
+ * backward -> the partial results' reductions + Adam on the kernels' mu / sigma -> convolution weight gradients
+ * (capamd_ngram_conv_backward) -> Adam on the convolutions.  Eleven launches, no autograd, no ATen node.
+ * q_ids int64 [2 B, Q] (the batch's queries twice), d_ids int64 [2 B, L] (the positive documents, then the negative ones);
+ * ptrs: HOST array of 3 P device pointers, P = 2 K + 2 G + 2 - kernels.kernels.{k}.mu (K), .sigma (K), convs.{g}.0.weight / .bias (G pairs),
+ * combine.0.weight [K V], combine.0.bias [1], then their exp_avg, then their exp_avg_sq (null moments: a parameter that is not trained).
+ * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) from the host (double).  loss_out: fp32 [1].  B <= 512; other limits as
+ * the two kernel families'.  workspace: capamd_convknrm_train_step_workspace_floats(...) floats, 16-byte aligned. */
+size_t capamd_convknrm_train_step_workspace_floats(int B, int Q, int L, int D, int G, int F, int K, int crossmatch);
+int capamd_convknrm_train_step(const int64_t* q_ids, const int64_t* d_ids, int B, int Q, int L, const float* emb, int64_t V, int D, int G, int F,
+                               int K, int crossmatch, float* const* ptrs, int scoretanh, int loss_type, float step_size, float one_minus_beta1,
+                               float beta2, float eps, float bc2_sqrt, float* loss_out, float* workspace, size_t workspace_floats, int* status,
+                               void* stream);
+
 /* ---- differentiable kernel pooling over dense n-gram representations (ConvKNRM's training step) ---------
  * The part of ConvKNRM_class.forward between its trainable n-gram convolutions and `combine`, capreolus/reranker/ConvKNRM.py:53-76
  * (StackedSimilarityMatrix common.py:195-221 + RbfKernelBank common.py:224-250), forward and backward - so that the reference

@@ -1619,6 +1619,8 @@ def test_fused_step_is_chosen_only_where_the_reranker_takes_the_configuration():
     assert not t._fused_allowed(_knrm_model(load_case("knrm", "twolayer_tanh")))
     assert t._fused_allowed(_drmm_model(load_case("drmm", "default")))
     assert not t._fused_allowed(_drmm_model(load_case("drmm", "tv_nh")))
+    assert t._fused_allowed(_convknrm_reranker(load_case("convknrm", "default")))
+    assert not t._fused_allowed(_convknrm_reranker(load_case("convknrm", "nocross_2fc_short")))
     big = PytorchTrainer({"batch": 256, "itersize": 512})
     big.device, big.scaler = torch.device(DEV), None
     assert big._fused_allowed(_knrm_model(load_case("knrm", "default"))) and not big._fused_allowed(_drmm_model(load_case("drmm", "default")))
@@ -1675,6 +1677,105 @@ def test_drmmtks_fused_training_steps_equal_eager_steps(name, softmax):
         assert float((fused[k] - v).abs().max()) <= 5e-4 * scale, (k, float((fused[k] - v).abs().max()), scale)
         moved = max(moved, float((v - init).abs().max()))
     assert moved > 1e-3
+
+
+@pytest.mark.parametrize("name,softmax", [("default", False), ("ranklist", True)])
+def test_convknrm_fused_training_steps_equal_eager_steps(name, softmax):
+    """ConvKNRM's training step as device kernels only (capamd_convknrm_train_step: n-gram convolutions over the frozen table, kernel
+    pooling, the single-Linear combine, the pairwise loss, backward, Adam on 2 K + 2 G + 2 parameter tensors - eleven launches, no autograd)
+    against five eager steps of reranker.score() under autograd with the same plain Adam: the loss of the iteration, every parameter, the
+    optimizer's moments."""
+    import contextlib
+
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case("convknrm", name)
+    B = min(32, c["query"].shape[0])
+    rs = np.random.RandomState(5)
+    batches = []
+    for _ in range(5):
+        perm = rs.permutation(c["query"].shape[0])
+        batches.append({"qid": [str(i) for i in range(B)], "query": torch.as_tensor(c["query"][:B]), "query_idf": torch.as_tensor(c["query_idf"][:B]),
+                        "posdoc": torch.as_tensor(c["posdoc"][:B]), "negdoc": torch.as_tensor(c["posdoc"][perm[:B]])})
+
+    def run(fused, steps=5):
+        r = _convknrm_reranker(c)
+        if not r.model.p["singlefc"]:
+            pytest.skip("two-layer combine keeps the autograd route")
+        m = r.model
+        m.train()
+        t = PytorchTrainer({"batch": B, "itersize": steps * B, "lr": 0.01, "graph": False, "fused": fused, "softmaxloss": softmax})
+        t.device, t.scaler, t._train_autocast = torch.device(DEV), None, contextlib.nullcontext
+        t.loss = t.pair_softmax_loss if softmax else t.pair_hinge_loss
+        t._train_graph, t._graph_failed, t._fused_failed = None, False, False
+        t._use_fused = t._fused_allowed(r)
+        assert t._use_fused == fused
+        t.optimizer = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.01)
+        t._set_lr(0)
+        loss = t.single_train_iteration(r, batches[:steps], cur_iter=1)
+        assert not t._fused_failed
+        with torch.no_grad():      # the scoring kernel's projection tables follow the weights the step kernels wrote: a fresh model with these weights scores alike
+            b0 = {k: v.to(DEV) if torch.is_tensor(v) else v for k, v in batches[0].items()}
+            after = r.test(b0).cpu()
+            fresh = _convknrm_reranker(c)
+            fresh.model.load_state_dict(m.state_dict())
+            assert torch.equal(fresh.test(b0).cpu(), after)
+        return float(loss), {k: v.detach().cpu().clone() for k, v in m.named_parameters() if v.requires_grad}, t.optimizer.state_dict(), after
+
+    # ONE step: Adam's first moments are (1 - beta1) x the gradients - the two routes' gradients of every parameter, element by element
+    names = [k for k, v in _convknrm_reranker(c).model.named_parameters() if v.requires_grad]
+    loss_e, _, sd_e, _ = run(False, 1)
+    loss_f, _, sd_f, _ = run(True, 1)
+    assert abs(loss_e - loss_f) <= 1e-5 * max(1.0, abs(loss_e)), (loss_e, loss_f)
+    residue = {}       # per parameter: the elements whose gradient is rounding residue (a difference of equal features): Adam moves them +-lr a step whichever way the residue falls
+    for i, st in sd_e["state"].items():
+        a, b = st["exp_avg"].cpu(), sd_f["state"][i]["exp_avg"].cpu()
+        residue[names[i]] = a.abs() <= 1e-4 * float(a.abs().max())
+        if names[i] == "combine.0.bias" and not bool(int(c["cfg.scoretanh"])):
+            assert float(b.abs().max()) == 0.0 and float(a.abs().max()) <= 1e-7      # exactly zero under a pairwise loss; autograd's rounding residue
+            continue
+        sig = names[i].rsplit(".", 1)[0] + ".sigma"
+        exact = names[i].startswith("kernels.kernels.") and float(dict(_convknrm_reranker(c).model.named_parameters())[sig].detach()) < 0.01
+        assert float((a - b).abs().max()) <= (2e-2 if exact else 1e-3) * float(a.abs().max()) + 1e-12, (names[i], float((a - b).abs().max()), float(a.abs().max()))
+    # FIVE steps: where the trajectories end
+    loss_e, eager, sd_e, after_e = run(False)
+    loss_f, fused, sd_f, after_f = run(True)
+    assert abs(loss_e - loss_f) <= 1e-4 * max(1.0, abs(loss_e)), (loss_e, loss_f)      # (the mean of five steps' losses)
+    moved, noise = 0.0, set()
+    start = {k: v.detach().cpu().clone() for k, v in _convknrm_reranker(c).model.named_parameters()}
+    for k, v in eager.items():
+        init = start[k]
+        if k == "combine.0.bias" and not bool(int(c["cfg.scoretanh"])):      # gradient exactly zero under a pairwise loss: see the KNRM test
+            assert float((fused[k] - init).abs().max()) == 0.0
+            noise.add(k)
+            continue
+        scale = float(v.abs().max()) + 1e-6
+        exact = k.startswith("kernels.kernels.") and float(start[k.rsplit(".", 1)[0] + ".sigma"]) < 0.01
+        # (Adam normalises a gradient's magnitude away: an element whose gradient is rounding residue moves by +-lr per step on either
+        # route - the convolutions' 115,200-element weights hold some - so the bulk is compared tightly and the outliers counted)
+        diff = (fused[k] - v).abs()
+        assert float(diff.max()) <= 5 * 0.01 * 2.001
+        diff = diff * (~residue[k])
+        if k.startswith("convs."):
+            assert float((diff > 2e-3 * scale).float().mean()) <= 2e-3, (k, float((diff > 2e-3 * scale).float().mean()))
+        else:
+            assert float(diff.max()) <= (5e-3 if exact else 2e-3) * scale, (k, float(diff.max()), scale)
+        if exact:
+            noise.add(k)
+        moved = max(moved, float((v - init).abs().max()))
+    assert moved > 1e-3          # the five steps did train something
+    for i, st in sd_e["state"].items():
+        assert float(st["step"]) == float(sd_f["state"][i]["step"]) == 5.0
+        if names[i] in noise:
+            continue
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = st[key].cpu(), sd_f["state"][i][key].cpu()
+            # (after five steps the routes' convolution weights differ in the elements Adam moved on rounding residue: the moments follow to ~1 %)
+            assert float((a - b).abs().max()) <= 5e-2 * (float(a.abs().max()) + 1e-12) + 1e-12, (names[i], key, float((a - b).abs().max()), float(a.abs().max()))
+    # the trained models score alike (five steps of lr = 0.01 on weights of scale 0.05: the trajectories' difference, on the scores' scale)
+    # (centred: the residue elements of the Linear weigh features that are the same for every document - a common offset of all scores)
+    ce, cf = after_e - after_e.mean(), after_f - after_f.mean()
+    assert float((cf - ce).abs().max()) <= 5e-2 * float(ce.abs().max()), (float((cf - ce).abs().max()), float(ce.abs().max()))
 
 
 @pytest.mark.parametrize("name,softmax", [("default", False), ("zero_idf", True), ("ch", False)])
