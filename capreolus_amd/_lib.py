@@ -87,6 +87,9 @@ SIGNATURES = {
     "capamd_ngram_conv_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _sz, _vp, _vp]),
     "capamd_convknrm_train_step_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "capamd_convknrm_train_step": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, ctypes.POINTER(_vp), _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _sz, _vp, _vp]),
+    "capamd_pacrr_train_step_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "capamd_pacrr_train_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_vp), _i, _f, _f, _f, _f, _f, _vp, _vp, _sz,
+                                     _vp, _vp]),
     "capamd_kernel_pool_chunks": (_i, [_i]),
     "capamd_kernel_pool_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_kernel_pool_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

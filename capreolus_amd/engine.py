@@ -657,6 +657,34 @@ def convknrm_train_step(query, posdoc, negdoc, emb, G, F, K, crossmatch, adam, s
     return loss
 
 
+def pacrr_train_step_fits(B, Q, n_ngrams, kmax, use_idf, combine):
+    """whether a batch's activations fit the one-workgroup stage of capamd_pacrr_train_step (include/capreolus_amd.h)"""
+    H, X = int(combine), int(Q) * (int(n_ngrams) * int(kmax) + int(bool(use_idf)))
+    return H <= 128 and H * X + H * H + H + 2 * B * X + 8 * B * H + 5 * B <= 36 * 1024
+
+
+def pacrr_train_step(query, posdoc, negdoc, idf, packed, V, D, mingram, maxgram, nfilters, kmax, use_idf, combine, nonlinearity, adam, softmax, check=True):
+    """capamd_pacrr_train_step: score(pos), score(neg), the trainer's pairwise loss, backward, Adam - on the device; returns the loss [1]."""
+    _need_gpu(query, posdoc, negdoc, idf, packed)
+    q, dp, dn, idf = _i64(query), _i64(posdoc), _i64(negdoc), _f32(idf)
+    B, Q = q.shape
+    L = dp.shape[1]
+    q2, d2, idf2 = torch.cat([q, q]), torch.cat([dp, dn]), torch.cat([idf, idf])
+    lib = _lib.load()
+    ws = _step_workspace(q.device, int(lib.capamd_pacrr_train_step_workspace_floats(B, Q, L, int(mingram), int(maxgram), int(nfilters), int(kmax))))
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    step_size, omb1, b2, eps, bc2s = adam.advance()
+    ptrs = (ctypes.c_void_p * len(adam.key))(*[p or None for p in adam.key])
+    st = status_word(q.device)
+    rc = lib.capamd_pacrr_train_step(_ptr(q2), _ptr(d2), _ptr(idf2), B, Q, L, _ptr(packed), V, D, int(mingram), int(maxgram), int(nfilters), int(kmax),
+                                     int(bool(use_idf)), int(combine), NONLINEARITIES[nonlinearity], ptrs, int(bool(softmax)), step_size, omb1, b2, eps, bc2s,
+                                     _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
+    _lib.check(rc, "capamd_pacrr_train_step")
+    if check:
+        st.raise_if_set()
+    return loss
+
+
 def _step_workspace(device, n):
     key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _step_workspaces.get(key)

@@ -88,6 +88,30 @@ class PACRR_class(nn.Module):
         scores = torch.cat(feats, dim=2).reshape(B, -1)
         return self.combine(scores)
 
+    def fused_train_step(self, d, optimizer, softmax=False):
+        """One whole training step on the device (capamd_pacrr_train_step: similarity matrices, the convolution / k-max stage, the three
+        Linear layers, the pairwise loss, backward, Adam - six launches, no autograd) - or None where the geometry is beyond its kernels
+        (then the autograd route over the same HIP stages).  Parameters and Adam moments are updated in place; their version counters
+        are bumped."""
+        p = self.p
+        B, Q, L = d["query"].shape[0], d["query"].shape[1], d["posdoc"].shape[1]
+        if Q > 8 or L > 1024 or p["maxgram"] > 3 or p["kmax"] > 4 or p["nfilters"] > 256 or L < p["kmax"] or \
+                not engine.pacrr_train_step_fits(B, Q, len(self.ngrams), p["kmax"], p["idf"], p["combine"]):
+            return None
+        params = []
+        for m in self.ngrams:
+            params += [m.conv.weight, m.conv.bias]
+        params += [self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.linear3.weight, self.linear3.bias]
+        hit = self.__dict__.get("_adam_step")
+        if hit is None or hit.optimizer is not optimizer or hit.key[: len(params)] != tuple(t.data_ptr() for t in params) or not hit.still_valid():
+            hit = self.__dict__["_adam_step"] = engine.AdamStep(optimizer, params)
+        w = self.embedding.weight
+        loss = engine.pacrr_train_step(d["query"], d["posdoc"], d["negdoc"], d["query_idf"], self._packed.get(w), w.shape[0], w.shape[1], p["mingram"],
+                                       p["maxgram"], p["nfilters"], p["kmax"], p["idf"], p["combine"], p["nonlinearity"], hit, softmax)
+        with torch.no_grad():
+            torch._foreach_mul_(hit.trained, 1.0)          # (exact no-op: the kernels wrote the parameters behind autograd's back)
+        return loss[0]
+
     def _forward_train_aten(self, doc, query, query_idf):
         """The trainable stage as the reference's ATen op sequence under autograd on the HIP similarity matrix: the checker of the
         HIP training path in the tests, and the route of geometries `engine.PacrrConvMax` does not take."""
@@ -126,6 +150,15 @@ class PACRR(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    def fused_train_step(self, d, optimizer, softmax=False):
+        return self.model.fused_train_step(d, optimizer, softmax)
+
+    def fused_step_available(self, batch_size):
+        """whether `fused_train_step` takes this configuration (the training kernels' geometry, a batch whose activations fit one workgroup)"""
+        c = self.config
+        return c["maxgram"] <= 3 and c["kmax"] <= 4 and c["nfilters"] <= 256 and \
+            engine.pacrr_train_step_fits(batch_size, self.extractor.config["maxqlen"], c["maxgram"] - c["mingram"] + 1, c["kmax"], c["idf"], c["combine"])
 
     lists_bit_identical = True # (the similarity matrix is the same: lookups of bit-identical similarities)
 

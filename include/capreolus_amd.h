@@ -387,6 +387,23 @@ int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, const float
                          const float* w2, const float* b2, const float* w3, const float* b3, float* out, int* status,
                          void* stream);
 
+/* One PACRR training step on the device (reference PACRR.py:42-78 under trainer/pytorch.py:93-108, the loss
+ * reranker/common.py:96-103, torch.optim.Adam): similarity matrices -> n-gram Conv2d / ReLU / max over filters / k-max with the winners'
+ * coordinates (capamd_pacrr_convmax_forward) -> ONE workgroup: features + idf softmax, linear1 / linear2 / linear3 with `nonlinearity`
+ * (0 none, 1 relu, 2 tanh), the pairwise loss (0 hinge / 1 softmax), the backward through the layers, their gradients summed in document
+ * order, Adam on them -> convolution gradients (capamd_pacrr_convmax_backward) -> Adam on the convolutions.  Six launches, no autograd.
+ * q_ids int64 [2 B, Q] (the batch's queries twice), d_ids int64 [2 B, L] (positive documents, then negative), idf fp32 [2 B, Q] (use_idf);
+ * ptrs: HOST array of 3 P device pointers, P = 2 n_ngrams + 6 - ngrams.{i}.conv.weight / .bias (mingram..maxgram), linear1.weight / .bias,
+ * linear2.weight / .bias, linear3.weight / .bias, then their exp_avg, then their exp_avg_sq (null moments: not trained).
+ * Limits: those of capamd_pacrr_convmax_*, combine <= 128, and the batch's activations must fit one workgroup's LDS:
+ * H X + H^2 + H + 2 B X + 8 B H + 5 B <= 36,864 floats (H = combine, X = Q (n_ngrams kmax + use_idf)); CAPAMD_ERR_ARG beyond.
+ * workspace: capamd_pacrr_train_step_workspace_floats(...) floats, 16-byte aligned. */
+size_t capamd_pacrr_train_step_workspace_floats(int B, int Q, int L, int mingram, int maxgram, int nfilters, int kmax);
+int capamd_pacrr_train_step(const int64_t* q_ids, const int64_t* d_ids, const float* idf, int B, int Q, int L, const float* packed, int64_t V, int D,
+                            int mingram, int maxgram, int nfilters, int kmax, int use_idf, int combine, int nonlinearity, float* const* ptrs,
+                            int loss_type, float step_size, float one_minus_beta1, float beta2, float eps, float bc2_sqrt, float* loss_out,
+                            float* workspace, size_t workspace_floats, int* status, void* stream);
+
 /* ---- ConvKNRM's trainable n-gram convolutions, forward and backward (ConvKNRM's training step) --------------
  * Replaces, for training, the convolution stack of ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-51 - embeddings(ids) ->
  * permute -> ConstantPad1d((0, g - 1), 0) -> Conv1d(D -> F, kernel g) -> permute, for g = 1..G, on the query and on the document -
