@@ -82,13 +82,38 @@ class KNRM_class(nn.Module):
         everything that touches the [B, Q, L] tensors -- is the HIP kernel (capamd_knrm_features, which also returns
         d f/d mu and d f/d sigma); the 11 -> 1 `combine` and the loss stay under autograd on the [B, 11] features."""
         if self.embedding.weight.requires_grad:
-            raise NotImplementedError("finetune=True (gradients into the embedding table) is not supported by the MI355X engine")
+            return self._forward_train_finetune(doctoks, querytoks)
         w = self.embedding.weight
         packed = self._packed.get(w)
         mu = torch.stack([k.mu for k in self.kernels.kernels]).float()
         sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float()
         feats = engine.KnrmFeatures.apply(mu, sigma, querytoks, doctoks, packed, w.shape[0], w.shape[1])
         return self.combine(feats)
+
+    def _forward_train_finetune(self, doctoks, querytoks):
+        """`finetune=True` (KNRM.py:23: the embedding table trains too): the gradient has to reach the [V, D] table through both operands
+        of every cosine, which the feature kernel does not provide - the reference's op sequence (SimilarityMatrix common.py:155-182,
+        RbfKernelBank :224-250, KNRM.py:39-55) as ATen ops under autograd ON THE GPU, dense table gradient like the reference's
+        nn.Embedding.  A rarely used option (the reference's own comment: "TODO check save when True"); scoring in eval mode stays on
+        the fused kernels, whose packed copy of the table follows its version counter."""
+        engine._need_gpu(doctoks, querytoks, self.embedding.weight)
+        q, d = querytoks.long(), doctoks.long()
+        # exact matches of OOV terms (negative ids), cosine of in-vocabulary terms (id 0 = the pad row for everything else), pads zeroed
+        qo, do = q.clamp(max=0), d.clamp(max=0)
+        exact = (qo[:, :, None] == do[:, None, :]).float().masked_fill((qo == 0)[:, :, None], 0.0).masked_fill((do == 0)[:, None, :], 0.0)
+        qi, di = q.clamp(min=0), d.clamp(min=0)
+        a, b = self.embedding(qi), self.embedding(di)
+        den = (a.norm(p=2, dim=2)[:, :, None] + 1e-9) * (b.norm(p=2, dim=2)[:, None, :] + 1e-9)
+        cos = (a.bmm(b.permute(0, 2, 1)) / den).masked_fill((qi == 0)[:, :, None], 0.0).masked_fill((di == 0)[:, None, :], 0.0)
+        simmat = exact + cos                                                  # [B, Q, L]
+        mu = torch.stack([k.mu for k in self.kernels.kernels]).float().view(1, -1, 1, 1)
+        sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float().view(1, -1, 1, 1)
+        adj = simmat[:, None] - mu
+        kernels = torch.exp(-0.5 * adj * adj / sigma / sigma)                 # [B, K, Q, L]
+        result = kernels.sum(dim=3)
+        mask = (simmat.sum(dim=2) != 0.0)[:, None, :].expand_as(result)
+        result = torch.where(mask, (result + 1e-6).log(), mask.float()).sum(dim=2)
+        return self.combine(result)
 
     def fused_train_step(self, d, optimizer, softmax=False):
         """One whole training step on the device (capamd_knrm_train_step: score(pos), score(neg), pairwise loss, backward, Adam) - or

@@ -34,7 +34,7 @@ def _set_weights(model, fx):
     model.load_state_dict(sd)
 
 
-def _grads(common, model, fx, name, idf_wrap=None):
+def _grads(common, model, fx, name, idf_wrap=None, with_table=False):
     q = torch.from_numpy(fx["query"].astype(np.int64))
     d = torch.from_numpy(fx["posdoc"].astype(np.int64))
     neg = d.roll(1, 0)
@@ -52,7 +52,7 @@ def _grads(common, model, fx, name, idf_wrap=None):
     out = {"ref_loss": np.float64(loss.item()), "ref_pos_scores": pos_s.detach().numpy().astype(np.float32),
            "ref_neg_scores": neg_s.detach().numpy().astype(np.float32)}
     for k, p in model.named_parameters():
-        if p.requires_grad and "embedding" not in k:
+        if p.requires_grad and (with_table or "embedding" not in k):
             assert p.grad is not None, k
             out["ref_grad." + k] = p.grad.detach().numpy().astype(np.float32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -70,6 +70,12 @@ def gen_grads(common, KNRM, DRMM, TKS, PACRR, CONVKNRM):
         m = KNRM.KNRM_class(SimpleNamespace(embeddings=emb), cfg)
         _set_weights(m, fx)
         _grads(common, m, fx, "knrm_grad_" + case)
+    # finetune=True (KNRM.py:23): the table trains too - its dense gradient, on the small table of the glove50 case
+    fx = _load("knrm_glove50_short")
+    emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+    m = KNRM.KNRM_class(SimpleNamespace(embeddings=emb), dict(gradkernels=True, finetune=True, singlefc=bool(fx["singlefc"]), scoretanh=bool(fx["scoretanh"])))
+    _set_weights(m, fx)
+    _grads(common, m, fx, "knrm_grad_finetune_glove50_short", with_table=True)
     for case in ("zero_idf",):           # (a case on which the reference's bin counts and this build's agree: no coin flip inside the gradient)
         fx = _load("drmm_" + case)
         emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
