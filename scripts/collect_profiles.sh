@@ -5,7 +5,7 @@ D=profiles/${1:-r04}
 G=gpurun_out
 mkdir -p $D
 for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_pingpong drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; [ -f $G/bench_full_$f.json ] && cp $G/bench_full_$f.json $D/; done
-for m in knrm knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm cedrknrm; do
+for m in knrm knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm cedrknrm train_ConvKNRM train_PACRR; do
   f=$(ls $G/prof/$m/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${m}_bench_kernel_stats.csv
 done
 for m in knrm knrm_roofline_leg drmm drmm_roofline_leg; do for c in fetch write tcc; do

@@ -47,6 +47,7 @@ timeout 300 $KS -d $P/bert -o bert -- $B --steps 3 --warmup 1 --no-cpu-baseline 
 timeout 300 $KS -d $P/default -o default -- $B --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 for mdl in drmmtks pacrr convknrm; do timeout 300 $KS -d $P/$mdl -o $mdl -- $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl > /dev/null 2>&1; done
 PYTHONPATH=$R timeout 300 $KS -d $P/cedrknrm -o cedrknrm -- python $R/scripts/sibling_bench.py --only CEDRKNRM > /dev/null 2>&1
+for mdl in ConvKNRM PACRR; do PYTHONPATH=$R timeout 300 $KS -d $P/train_$mdl -o t -- python $R/scripts/train_step_bench.py --only $mdl --steps 40 > /dev/null 2>&1; done
 # ---- PMC passes (own runs, counters only): HBM traffic of the KNRM / DRMM headline and roofline legs, MFMA busy of the BERT GEMMs ------
 PM="rocprofv3 --output-format csv --pmc"
 for leg in "knrm:" "knrm_roofline_leg:--uniform-ids --vocab 4000001 --batches 2" "drmm:--model drmm" "drmm_roofline_leg:--model drmm --uniform-ids --vocab 4000001 --batches 2"; do
