@@ -772,6 +772,22 @@ class KnrmFeatures(torch.autograd.Function):
         return (g * dmu).sum(0), (g * dsg).sum(0), None, None, None, None, None
 
 
+def similarity_matrix_autograd(embedding, query, doc):
+    """SimilarityMatrix.forward (capreolus/reranker/common.py:155-182) as ATen ops under autograd ON THE GPU, for the configurations in
+    which the embedding table trains (KNRM finetune=True, DRMM-TKS freezeemb=False): the gradient has to reach the [V, D] table through
+    both operands of every cosine, which the HIP front end (frozen tables only) does not provide.  Exact matches of OOV terms (negative
+    ids) + cosine of in-vocabulary terms (everything else looks up row 0), pads zeroed.  -> [B, Q, L]."""
+    _need_gpu(query, doc, embedding.weight)
+    q, d = query.long(), doc.long()
+    qo, do = q.clamp(max=0), d.clamp(max=0)
+    exact = (qo[:, :, None] == do[:, None, :]).float().masked_fill((qo == 0)[:, :, None], 0.0).masked_fill((do == 0)[:, None, :], 0.0)
+    qi, di = q.clamp(min=0), d.clamp(min=0)
+    a, b = embedding(qi), embedding(di)
+    den = (a.norm(p=2, dim=2)[:, :, None] + 1e-9) * (b.norm(p=2, dim=2)[:, None, :] + 1e-9)
+    cos = (a.bmm(b.permute(0, 2, 1)) / den).masked_fill((qi == 0)[:, :, None], 0.0).masked_fill((di == 0)[:, None, :], 0.0)
+    return exact + cos
+
+
 class NgramConv(torch.autograd.Function):
     """ConvKNRM's n-gram convolutions over the frozen embedding table, differentiable in their weights and biases
     (capamd_ngram_conv_forward / _backward; ConvKNRM.py:42-51 under the trainer's loss.backward()).

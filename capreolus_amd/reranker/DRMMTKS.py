@@ -17,12 +17,10 @@ class DRMMTKS_class(nn.Module):
         self.gate_type = config["gateType"]
         if self.gate_type != "IDF":
             raise NotImplementedError("DRMMTKS gateType=TV: the reference feeds integer ids to nn.Linear (DRMMTKS.py:42); only IDF is scored")
-        if not config["freezeemb"]:
-            raise NotImplementedError("freezeemb=False (gradients into the embedding table) is not supported by the MI355X engine")
         weights = torch.as_tensor(np.asarray(extractor.embeddings, dtype=np.float32))
         self.embedding = nn.Embedding(*weights.shape)
         self.embedding.weight.data.copy_(weights)
-        self.embedding.weight.requires_grad = False
+        self.embedding.weight.requires_grad = not config["freezeemb"]          # create_emb_layer(non_trainable=freezeemb), DRMMTKS.py:25
         self.ffw = nn.Sequential(nn.Linear(self.topk, 1), nn.Tanh())
         self.gates = nn.Linear(1, 1, bias=False)
         self.output_layer = nn.Linear(1, 1)
@@ -51,7 +49,7 @@ class DRMMTKS_class(nn.Module):
 
     def fused_train_step(self, d, optimizer, softmax=False):
         """One whole training step on the device (capamd_drmmtks_train_step); parameters and Adam moments are updated in place."""
-        if d["query"].shape[0] > 1024:
+        if d["query"].shape[0] > 1024 or self.embedding.weight.requires_grad:
             return None
         params = [self.ffw[0].weight, self.ffw[0].bias, self.gates.weight, self.output_layer.weight, self.output_layer.bias]
         hit = self.__dict__.get("_adam_step")
@@ -69,10 +67,15 @@ class DRMMTKS_class(nn.Module):
         touches the [B, Q, L] tensors - is the HIP kernel (capamd_drmmtks_features); the embedding table is frozen, so no
         gradient flows through the similarities, and the Linear(topk, 1)/tanh, the idf gate and the output layer
         (DRMMTKS.py:57-62) run under autograd on the [B, Q, topk] features."""
-        if self.embedding.weight.requires_grad:
-            raise NotImplementedError("freezeemb=False (gradients into the embedding table) is not supported by the MI355X engine")
         w = self.embedding.weight
-        topk = engine.drmmtks_features(query, doc, self._packed.get(w), w.shape[0], w.shape[1], self.topk)
+        if w.requires_grad:
+            # freezeemb=False: the table trains too - the similarity matrix and the top-k as ATen ops under autograd on the GPU (dense table
+            # gradient, like the reference's nn.Embedding); the one DRMM-TKS training configuration that is not on the HIP feature kernel
+            if self.topk > doc.shape[1]:
+                raise RuntimeError("selected index k out of range")
+            topk = torch.topk(engine.similarity_matrix_autograd(self.embedding, query, doc), k=self.topk, dim=-1)[0]
+        else:
+            topk = engine.drmmtks_features(query, doc, self._packed.get(w), w.shape[0], w.shape[1], self.topk)
         ffw_vec = self.ffw(topk).squeeze(-1)                                            # (B, Q)
         gate = self.gates(query_idf.float()[:, :, None]).squeeze(-1) + (1 - (query != 0).float()) * -1e7
         wgt = torch.softmax(gate, dim=1)
@@ -101,7 +104,7 @@ class DRMMTKS(Reranker):
         return self.model.fused_train_step(d, optimizer, softmax)
 
     def fused_step_available(self, batch_size):
-        return batch_size <= 1024
+        return batch_size <= 1024 and bool(self.config["freezeemb"])
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmmtks_forward_lists)
     lists_bit_identical = True # (top-k selections of bit-identical similarities, fed to the Linear in the same order)

@@ -96,16 +96,7 @@ class KNRM_class(nn.Module):
         RbfKernelBank :224-250, KNRM.py:39-55) as ATen ops under autograd ON THE GPU, dense table gradient like the reference's
         nn.Embedding.  A rarely used option (the reference's own comment: "TODO check save when True"); scoring in eval mode stays on
         the fused kernels, whose packed copy of the table follows its version counter."""
-        engine._need_gpu(doctoks, querytoks, self.embedding.weight)
-        q, d = querytoks.long(), doctoks.long()
-        # exact matches of OOV terms (negative ids), cosine of in-vocabulary terms (id 0 = the pad row for everything else), pads zeroed
-        qo, do = q.clamp(max=0), d.clamp(max=0)
-        exact = (qo[:, :, None] == do[:, None, :]).float().masked_fill((qo == 0)[:, :, None], 0.0).masked_fill((do == 0)[:, None, :], 0.0)
-        qi, di = q.clamp(min=0), d.clamp(min=0)
-        a, b = self.embedding(qi), self.embedding(di)
-        den = (a.norm(p=2, dim=2)[:, :, None] + 1e-9) * (b.norm(p=2, dim=2)[:, None, :] + 1e-9)
-        cos = (a.bmm(b.permute(0, 2, 1)) / den).masked_fill((qi == 0)[:, :, None], 0.0).masked_fill((di == 0)[:, None, :], 0.0)
-        simmat = exact + cos                                                  # [B, Q, L]
+        simmat = engine.similarity_matrix_autograd(self.embedding, querytoks, doctoks)                # [B, Q, L]
         mu = torch.stack([k.mu for k in self.kernels.kernels]).float().view(1, -1, 1, 1)
         sigma = torch.stack([k.sigma for k in self.kernels.kernels]).float().view(1, -1, 1, 1)
         adj = simmat[:, None] - mu

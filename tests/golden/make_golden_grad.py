@@ -89,6 +89,12 @@ def gen_grads(common, KNRM, DRMM, TKS, PACRR, CONVKNRM):
         m = TKS.DRMMTKS_class(SimpleNamespace(embeddings=emb), dict(topk=int(fx["topk"]), gateType="IDF", freezeemb=True))
         _set_weights(m, fx)
         _grads(common, m, fx, "drmmtks_grad_" + case)
+    # freezeemb=False (DRMMTKS.py:25): the table trains too
+    fx = _load("drmmtks_top3_short")
+    emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))
+    m = TKS.DRMMTKS_class(SimpleNamespace(embeddings=emb), dict(topk=int(fx["topk"]), gateType="IDF", freezeemb=False))
+    _set_weights(m, fx)
+    _grads(common, m, fx, "drmmtks_grad_unfrozen_top3_short", with_table=True)
     for case in ("default", "tanh_noidf_short"):
         fx = _load("pacrr_" + case)
         emb = synthetic.make_embeddings(int(fx["V"]), int(fx["D"]), seed=int(fx["emb_seed"]))

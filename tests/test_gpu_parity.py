@@ -1367,6 +1367,17 @@ def _tks_reranker(c):
     return r
 
 
+def _tks_unfrozen_reranker(c):
+    from capreolus_amd.reranker import DRMMTKS
+
+    r = DRMMTKS({"topk": int(c["topk"]), "freezeemb": False}, SimpleNamespace(embeddings=c["emb"]))      # DRMMTKS.py:25: the table trains too
+    m = r.build_model()
+    m.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in c.items() if k.startswith("sd.")}, strict=False)
+    m.to(DEV).eval()
+    assert m.embedding.weight.requires_grad and not r.fused_step_available(32)
+    return r
+
+
 def _knrm_finetune_model(c):
     r = _knrm_model(c)
     r.model.embedding.weight.requires_grad = True      # finetune=True (KNRM.py:23)
@@ -1374,7 +1385,7 @@ def _knrm_finetune_model(c):
 
 
 REF_GRAD_CASES = [("knrm", "default", _knrm_model), ("knrm", "twolayer_tanh", _knrm_model), ("knrm", "finetune_glove50_short", _knrm_finetune_model),
-                  ("drmm", "zero_idf", _drmm_model),
+                  ("drmmtks", "unfrozen_top3_short", _tks_unfrozen_reranker), ("drmm", "zero_idf", _drmm_model),
                   ("drmmtks", "default", _tks_reranker), ("pacrr", "default", _pacrr_reranker), ("pacrr", "tanh_noidf_short", _pacrr_reranker),
                   ("convknrm", "default", _convknrm_reranker), ("convknrm", "nocross_2fc_short", _convknrm_reranker)]
 
@@ -1389,7 +1400,8 @@ def test_training_gradients_match_the_reference(kind, name, build):
 
     from tests.helpers import GOLDEN
 
-    c = load_case(kind, name[len("finetune_"):] if name.startswith("finetune_") else name)      # (finetune: the same inputs and weights, the table trainable)
+    trains_table = name.startswith(("finetune_", "unfrozen_"))             # (the same inputs and weights as the plain case, the table trainable)
+    c = load_case(kind, name.split("_", 1)[1] if trains_table else name)
     g = np.load(os.path.join(GOLDEN, f"{kind}_grad_{name}.npz"))
     r = build(c)
     m = r.model
@@ -1422,7 +1434,7 @@ def test_training_gradients_match_the_reference(kind, name, build):
         else:
             # (the finetune route is the reference's own op sequence on the GPU: what differs is the order of fp32 reductions, and a kernel
             # gradient that is a difference of nearly equal document sums shows it at 2.2e-3)
-            tol = 5e-3 if name.startswith("finetune_") else 2e-3
+            tol = 5e-3 if trains_table else 2e-3
             assert float(np.abs(got - want).max()) <= tol * scale, (key, float(np.abs(got - want).max()), scale)
         checked += 1
     assert checked >= 5
