@@ -55,6 +55,9 @@ struct ListsArgs {
   int cid_stride;
   float* kn_consts;        // ... and what the pooling pass needs of them, computed once per call: [6][kMaxK] mu, c = -log2(e) / (2 sigma^2),
                            //     K(0) = 2^(c mu^2), K(1) = 2^(c (1 - mu)^2), A = sqrt(-c), B = -A mu   (slots beyond K repeat the last kernel)
+  float4* qplain;          // [lists][64 NV] the list's query rows once more, as [column][term]: what the dense head pass stages in LDS
+  float* head;             // [H / 16][64 NV][16] the first H table rows, sixteen by sixteen, column-major inside a block (lists_head_pack_kernel)
+  int H;                   // rows 0 .. H - 1 get their similarities from the dense matrix-pipe pass (lists_head_sims_kernel), for EVERY list
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
@@ -309,6 +312,16 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
   __syncthreads();
   float4* img = a.qimg + (int64_t)l * kQueryImage;
   for (int i = tid; i < kQT * NV * 16; i += 128) img[i] = qlds[i];
+  if (a.H > 0 && !kSimsOnMfma) {
+    // [column][term] for the dense head pass.  In the paired image float (term 2 P + s, column 64 i + 4 p + e) is component 2 (e & 1) + s
+    // of float4 ((P NV + i) 2 + (e >> 1)) 16 + p (rows_dot2_pk)
+    const float* qf = reinterpret_cast<const float*>(qlds);
+    float* out = reinterpret_cast<float*>(a.qplain + (int64_t)l * (64 * kMaxNV));
+    for (int idx = tid; idx < 64 * NV * 4; idx += 128) {
+      const int col = idx >> 2, t = idx & 3, i = col >> 6, p = (col >> 2) & 15, e = col & 3, P = t >> 1;
+      out[idx] = qf[((((P * NV + i) * 2 + (e >> 1)) * 16 + p) << 2) + 2 * (e & 1) + (t & 1)];
+    }
+  }
   if (tid < kQT) {           // lane16 = tid: the term this lane "owns" in QueryPass
     a.qmeta[l].id[tid] = qp.id_my;
     a.qmeta[l].den[tid] = qp.den_my;
@@ -346,8 +359,13 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
   constexpr int kPer = kSimsIds / 256;      // ids per thread: their flag bytes in one load
   static_assert(kPer == 2 || kPer == 4 || kPer == 8, "kSimsIds is 512, 1024 or 2048");
   const uint8_t* fp = a.flags + (int64_t)l * a.Vp + id0 + tid * kPer;
-  const uint64_t fw = kPer == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(fp) : kPer == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(fp)
-                                                                                               : *reinterpret_cast<const uint64_t*>(fp);
+  if (id0 + kSimsIds <= a.H) return;          // the dense head pass has these rows
+  uint64_t fw = kPer == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(fp) : kPer == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(fp)
+                                                                                         : *reinterpret_cast<const uint64_t*>(fp);
+  {
+    const int below = a.H - (id0 + tid * kPer);        // this thread's first `below` ids belong to the head pass
+    if (below > 0) fw = below >= kPer ? 0ull : fw & (~0ull << (8 * below));
+  }
   // the list's query rows: the LDS image lists_query_kernel left (built here, from the ids, it is five dependent loads per workgroup)
   {
     const float4* img = a.qimg + (int64_t)l * kQueryImage;
@@ -411,6 +429,130 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
 }
 
 #endif
+
+// ---- 2h: the dense head of the vocabulary on the matrix pipe ---------------------------------------------------------------------
+// Vocabularies are frequency-ordered (GloVe's is; the benchmark's ids are Zipf ranks): on 1000-candidate lists the first ~16,000 ids are
+// flagged in almost every list - 30 % of all (list, term) rows.  For those a gather buys nothing, and a dense product has the shape the
+// matrix pipe wants: rows 0 .. H - 1 against the 4 x 4 query terms of FOUR lists = a [16 rows] x [16 columns] tile per
+// v_mfma_f32_16x16x4_f32, for every list, flagged or not (an entry nobody looks up costs nothing).  BIT-IDENTICAL to lists_sims_kernel -
+// the pooling kernels and the per-pair kernels must not see which pass produced a similarity: the VALU form sums, per (row, term), 16
+// lane-partial fma chains (lane p: floats 64 c + 4 p + e, c ascending, e = x, y, z, w) and then a balanced tree over the partials
+// (group_allreduce: p ^ 1, p ^ 2, the other quad, the other half).  An fp32 MFMA accumulates as a k-ordered fmaf chain, so partial p IS a
+// chain of NV MFMAs over k = (c, e) into its own accumulator: 16 accumulators of 4 registers, 16 NV MFMAs per tile (the flops of one long
+// chain, arranged as sixteen short ones), the tree as 15 register adds per result.  The operands arrive in MFMA layout without any turn:
+// the A side from a copy of the head rows laid out [block of 16 rows][column][row] (lists_head_pack_kernel, 21 MB per call for H = 16,384:
+// lane (row i, e) reads float (column 64 c + 4 p + e, row i) = 64 consecutive floats per instruction), the B side from an LDS image of the
+// four lists' query rows laid out [column][16 query columns] (conflict-free: 64 consecutive floats per read).
+// MEASURED AND NOT THE DEFAULT (profiles/r04/lists_head_mfma.txt; -DCAPAMD_LISTS_HEAD_ROWS=16384 builds it, every list-route parity test
+// passes with it - bit-identical tables): the gather pass loses the 58 us of its head rows (285 -> 227 us), this pass costs 48 us
+// (21 of MFMAs - an fp32 MFMA is the vector rate, not sixteen times it -, 13 of row loads that four blocks per wave cannot hide, 11 of
+// launch / query staging / tree, 3 of stores) and the per-call copy of the head rows 9: no gain, for 21 MB more workspace.
+#ifndef CAPAMD_LISTS_HEAD_ROWS
+#define CAPAMD_LISTS_HEAD_ROWS 0          // 0: no dense head pass (every row through lists_sims_kernel)
+#endif
+constexpr int kHeadMax = CAPAMD_LISTS_HEAD_ROWS;
+#ifndef CAPAMD_HEAD_ABL
+#define CAPAMD_HEAD_ABL 0      // profiling builds of lists_head_sims_kernel: 1 = no stores, 2 = no MFMAs, 4 = no row loads
+#endif
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+// rows of the dense head for a call: a term of rank r is in a list when the list holds about r positions, so H follows the list length
+// (positions per list / 32, pads included: ~1/12 of the real positions), capped by the table and by kHeadMax
+inline int lists_head_rows(int64_t V, int64_t n_pairs, int L, int n_lists) {
+  if (kHeadMax <= 0 || n_lists < 1) return 0;
+  int64_t h = n_pairs * L / n_lists / 32;
+  if (h > kHeadMax) h = kHeadMax;
+  if (h > V) h = V;
+  return (int)(h / 16 * 16);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void lists_head_pack_kernel(ListsArgs a) {
+  __shared__ float t[64 * NV * 17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* src = a.packed + (int64_t)b * 16 * (64 * NV);
+  for (int i = tid; i < 16 * 64 * NV; i += 256) {
+    const int r = i / (64 * NV), c = i - r * (64 * NV);
+    t[c * 17 + r] = src[i];
+  }
+  __syncthreads();
+  float* dst = a.head + (int64_t)b * 16 * (64 * NV);
+  for (int i = tid; i < 16 * 64 * NV; i += 256) dst[i] = t[(i >> 4) * 17 + (i & 15)];
+}
+
+template <int NV, bool BINS>
+__global__ __launch_bounds__(256, 4) void lists_head_sims_kernel(ListsArgs a, ListGeom g) {
+  __shared__ __attribute__((aligned(16))) float QT[64 * NV * 16];        // [column][query column j = 4 (list of the group) + term]
+  __shared__ float qden[16];
+  __shared__ int qid[16];
+  __shared__ float edges[kMaxBins];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l0 = blockIdx.y * 4;            // the group's lists l0 .. l0 + 3
+  // the four lists' [column][term] images side by side: one float4 per (column, list) - unconditional loads, a clamped list index
+  for (int idx = tid; idx < 64 * NV * 4; idx += 256) {
+    const int col = idx >> 2, lg = idx & 3, ll = l0 + lg;
+    const float4 v = a.qplain[(int64_t)(ll < a.nl ? ll : a.nl - 1) * (64 * kMaxNV) + col];
+    *reinterpret_cast<float4*>(QT + col * 16 + 4 * lg) = ll < a.nl ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid < 16) {
+    const int ll = l0 + (tid >> 2);
+    qden[tid] = ll < a.nl ? a.qmeta[ll].den[tid & 3] : 1.f;
+    qid[tid] = ll < a.nl ? a.qmeta[ll].id[tid & 3] : 0;
+  }
+  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
+  __syncthreads();
+  const int j = lane & 15, ll = l0 + (j >> 2), t = j & 3, r0 = 4 * (lane >> 4);
+  const float qd = qden[j];
+  const bool live = qid[j] > 0;
+  float* tab = reinterpret_cast<float*>(a.table + (int64_t)(ll < a.nl ? ll : 0) * a.Vp);
+  uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)(ll < a.nl ? ll : 0) * a.Vp);
+  // a wave walks row blocks (the query image above is built once per workgroup: sixteen-row blocks are 2.5 k MFMA cycles each)
+  for (int blk = blockIdx.x * 4 + wave; blk * 16 < a.H; blk += gridDim.x * 4) {          // (no barrier below)
+  const float* hp = a.head + (int64_t)blk * 16 * (64 * NV) + lane;
+  // (the query operands are re-read from LDS for every block: hoisted out of this loop - they do not depend on the block - they occupy
+  //  16 NV registers per lane, and what hides a block's 16 NV row loads is the number of resident waves, four per SIMD at <= 128 registers)
+  int qoff = lane;
+  asm volatile("" : "+v"(qoff));
+  f32x4m acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    float av[16], bv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) av[p] = (CAPAMD_HEAD_ABL & 4) ? (float)(p + c) : hp[(64 * c + 4 * p) * 16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) bv[p] = QT[(64 * c + 4 * p) * 16 + qoff];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      if (CAPAMD_HEAD_ABL & 2) acc[p][0] += av[p] * bv[p];
+      else acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p], acc[p], 0, 0, 0);
+    }
+  }
+  // C/D map: column j = lane & 15, rows 4 (lane >> 4) + r.  The tree of group_allreduce over the partials, in registers.
+  f32x4m lv[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) lv[p] = acc[2 * p] + acc[2 * p + 1];
+  const f32x4m s = ((lv[0] + lv[1]) + (lv[2] + lv[3])) + ((lv[4] + lv[5]) + (lv[6] + lv[7]));
+  if (ll >= a.nl) continue;
+  const float4 dd = *reinterpret_cast<const float4*>(a.head + (int64_t)blk * 16 * (64 * NV) + (64 * NV - 1) * 16 + r0);   // the rows' norms: their last float
+  const float dden[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int id = blk * 16 + r0 + r;
+    if (id == 0) continue;                  // (the pad row: never looked up)
+    if ((CAPAMD_HEAD_ABL & 1) && s[r] != 12345.f) continue;
+    const float q = s[r] / (qd * dden[r]);
+    const float sm = live ? q : 0.f;
+    if (BINS) {
+      const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
+      tabb[(int64_t)id * 4 + t] = (uint8_t)bin;
+    } else {
+      tab[(int64_t)id * 4 + t] = sm;
+    }
+  }
+  }
+}
 
 // ---- 2': sims on the matrix pipe (round-4 experiment, not the default: -DCAPAMD_LISTS_SIMS_MFMA) --------------------------------------
 #ifdef CAPAMD_LISTS_SIMS_MFMA
@@ -585,7 +727,10 @@ __global__ __launch_bounds__(256, CAPAMD_SIMS_MFMA_BLOCKS) void lists_sims_mfma_
 #endif   // CAPAMD_LISTS_SIMS_MFMA
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
-constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery), kListConstBytes = 6 * kMaxK * sizeof(float);
+constexpr size_t kListQueryBytes = kQueryImage * sizeof(float4) + sizeof(ListQuery) + 64 * kMaxNV * sizeof(float4);   // both query images + ids / norms
+// per call: the KNRM kernel constants, then the dense head's copy of the first rows (sized for the widest rows)
+constexpr size_t kListHeadBytes = (size_t)(kHeadMax > 0 ? kHeadMax : 0) * 64 * kMaxNV * sizeof(float), kListKnBytes = 6 * kMaxK * sizeof(float);
+constexpr size_t kListConstBytes = kListKnBytes + kListHeadBytes;
 int64_t lists_vp(int64_t V) { return (V + kSimsIds - 1) / kSimsIds * kSimsIds; }
 int lists_cid_stride(int L) { return (L + 3) & ~3; }
 size_t lists_pair_bytes(int64_t n_pairs, int L) { return (size_t)n_pairs * ((kCompactRows ? (size_t)lists_cid_stride(L) * 4 : 0) + kDocMeta * 4); }
@@ -630,9 +775,13 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     uint8_t* flags = reinterpret_cast<uint8_t*>(ws + (size_t)cap * Vp * 16);
     float4* qimg = reinterpret_cast<float4*>(ws + (size_t)cap * Vp * 17);
     ListQuery* qmeta = reinterpret_cast<ListQuery*>(qimg + (size_t)cap * kQueryImage);
-    float* kn_consts = kn_mu ? reinterpret_cast<float*>(qmeta + cap) : nullptr;
+    float4* qplain = reinterpret_cast<float4*>(qmeta + cap);
+    float* kn_consts = reinterpret_cast<float*>(qplain + (size_t)cap * 64 * kMaxNV);
+    float* head = reinterpret_cast<float*>(reinterpret_cast<char*>(kn_consts) + kListKnBytes);        // (16-byte aligned: every part before it is)
+    if (!kn_mu) kn_consts = nullptr;
+    const int H = lists_head_rows(V, n_pairs, L, n_lists);
     ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, cid, meta, lists_cid_stride(L),
-                kn_consts};
+                kn_consts, qplain, head, H};
     lists_stamp(s);
     if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
     lists_stamp(s);
@@ -647,6 +796,13 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl), dim3(128), 0, s, a, g);                                  \
   lists_stamp(s);                                                                                               \
+  if (H > 0) {                                                                                                  \
+    const unsigned hgroups = (unsigned)(nl + 3) / 4, hwg = (unsigned)(H / 16 + 3) / 4;                          \
+    const dim3 hg(hwg * hgroups <= 1024 ? hwg : (1024 / hgroups > 0 ? 1024 / hgroups : 1), hgroups);            \
+    if (l0 == 0) hipLaunchKernelGGL(lists_head_pack_kernel<NV>, dim3(H / 16), dim3(256), 0, s, a);              \
+    if (edges) hipLaunchKernelGGL((lists_head_sims_kernel<NV, true>), hg, dim3(256), 0, s, a, g);               \
+    else hipLaunchKernelGGL((lists_head_sims_kernel<NV, false>), hg, dim3(256), 0, s, a, g);                    \
+  }                                                                                                             \
   if (edges) hipLaunchKernelGGL((CAPAMD_SIMS_KERNEL<NV, true>), sg, dim3(256), 0, s, a, g);                     \
   else hipLaunchKernelGGL((CAPAMD_SIMS_KERNEL<NV, false>), sg, dim3(256), 0, s, a, g)
     switch (nv_for_dim(D)) {
