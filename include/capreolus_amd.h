@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CAPAMD_VERSION 300
+#define CAPAMD_VERSION 400
 
 #define CAPAMD_OK 0
 #define CAPAMD_ERR_ARG 1       /* null pointer / bad size / unsupported configuration */
