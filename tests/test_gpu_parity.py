@@ -1872,6 +1872,47 @@ def test_pacrr_fused_training_steps_equal_eager_steps(name, softmax):
         assert float(st["step"]) == float(sd_f["state"][i]["step"]) == 5.0
 
 
+@pytest.mark.parametrize("kind", ["convknrm", "pacrr"])
+@pytest.mark.parametrize("B", [1, 5])
+def test_fused_steps_take_small_and_odd_batches(kind, B):
+    """The device-kernel training steps of ConvKNRM and PACRR at batch sizes that fill no tile, chunk or wave evenly (1 pair, 5 pairs): the
+    step's loss and, through Adam's first moments, every gradient against the autograd route."""
+    import contextlib
+
+    from capreolus_amd.trainer import PytorchTrainer
+
+    c = load_case(kind, "default")
+    build = _convknrm_reranker if kind == "convknrm" else _pacrr_reranker
+    batch = {"qid": [str(i) for i in range(B)], "query": torch.as_tensor(c["query"][:B]), "query_idf": torch.as_tensor(c["query_idf"][:B]),
+             "posdoc": torch.as_tensor(c["posdoc"][:B]), "negdoc": torch.as_tensor(c["posdoc"][B:2 * B])}
+
+    def run(fused):
+        r = build(c)
+        r.model.train()
+        t = PytorchTrainer({"batch": B, "itersize": B, "lr": 0.01, "graph": False, "fused": fused})
+        t.device, t.scaler, t._train_autocast = torch.device(DEV), None, contextlib.nullcontext
+        t.loss = t.pair_hinge_loss
+        t._train_graph, t._graph_failed, t._fused_failed = None, False, False
+        t._use_fused = t._fused_allowed(r)
+        assert t._use_fused == fused
+        t.optimizer = torch.optim.Adam([p for p in r.model.parameters() if p.requires_grad], lr=0.01)
+        t._set_lr(0)
+        loss = t.single_train_iteration(r, [batch], cur_iter=1)
+        assert not t._fused_failed
+        return float(loss), t.optimizer.state_dict(), [k for k, v in r.model.named_parameters() if v.requires_grad]
+
+    loss_e, sd_e, names = run(False)
+    loss_f, sd_f, _ = run(True)
+    assert abs(loss_e - loss_f) <= 1e-5 * max(1.0, abs(loss_e)), (loss_e, loss_f)
+    for i, st in sd_e["state"].items():
+        a, b = st["exp_avg"].cpu(), sd_f["state"][i]["exp_avg"].cpu()
+        if names[i] in ("combine.0.bias", "linear3.bias"):        # exactly zero under a pairwise loss (see the five-step tests)
+            continue
+        if names[i].startswith("kernels.kernels.10."):            # the exact-match kernel: rounding noise x 1e6 on either route
+            continue
+        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-10, (names[i], float((a - b).abs().max()), float(a.abs().max()))
+
+
 @pytest.mark.parametrize("name,softmax", [("default", False), ("zero_idf", True), ("ch", False)])
 def test_drmm_fused_training_steps_equal_eager_steps(name, softmax):
     """DRMM's training step as two launches (capamd_drmm_train_step: matching histograms, the 30 -> 5 -> 1 tanh net, idf gate, output layer,
