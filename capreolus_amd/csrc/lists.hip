@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
       for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
     } else {
 #pragma unroll
+#ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * 4];
+#else
       for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+#endif
     }
     // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
@@ -538,7 +542,11 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
       for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
     } else {
 #pragma unroll
+#ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * 4];
+#else
       for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+#endif
     }
     // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
