@@ -479,7 +479,7 @@ class InteractionLeg:
         """The passes of the whole-list route one by one: HIP events on the stream the kernels run on, recorded by the library between the
         passes of `steps` more steps after the timed loop (csrc/capamd_profiling.h: capamd_debug_lists_timing; the events sit between
         launches, so a pass's figure includes its launch gap - the five add up to the step).  Returns ms per step of
-        (memset, mark, query, sims, pool)."""
+        (clear, mark, query, sims, pool)."""
         from capreolus_amd import _lib
 
         with _lib.profiling_build() as lib:      # the -DCAPAMD_PROFILING build of the same kernels: the product library has no hooks
@@ -567,7 +567,7 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
     bytes = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: gfx950 tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B.
       route "per_pair_hbm": per launch of the per-pair kernel on the HBM-bound leg (uniform ids over the --roofline-vocab table)
       route "lists":        per CALL of the whole-list route on the headline configuration: every kernel of the call summed (the byte-map
-                            memset, lists_mark, lists_query, lists_sims, the pooling kernel)
+                            lists_clear, lists_mark, lists_query, lists_sims, the pooling kernel)
     Returns (bytes or None, how / why not)."""
     import csv
     import glob
@@ -712,7 +712,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
             tokens = nonpad * n_pairs
             K = 11
             idb = 4 if (args.resident and model == "knrm") else 8       # bytes per id: the candidate store's tables are int32
-            names = ["hipMemsetAsync (byte maps)", "lists_mark_kernel", "lists_query_kernel<5>", f"lists_sims_kernel<5, {'false' if model == 'knrm' else 'true'}>",
+            names = ["lists_clear_kernel (byte maps)", "lists_mark_kernel", "lists_query_kernel<5>", f"lists_sims_kernel<5, {'false' if model == 'knrm' else 'true'}>",
                      "lists_knrm_pool_kernel" if model == "knrm" else "lists_drmm_pool_wave_kernel"]
             work = [
                 {"bytes_cleared": (n_pairs / args.docs) * ((args.vocab + 1023) // 1024 * 1024)},
@@ -1008,7 +1008,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
         rstride = row // 4
         tokens = nonpad * n_pairs
         pool_name = {"drmmtks": "lists_tks_pool_kernel<12>", "pacrr": "pacrr_mfma_lists_kernel<5, 2>"}[model]
-        ptab = [{"pass": "hipMemsetAsync (byte maps)", "ms": passes[0], "bytes_cleared": (n_pairs / docs) * ((V + 1023) // 1024 * 1024)},
+        ptab = [{"pass": "lists_clear_kernel (byte maps)", "ms": passes[0], "bytes_cleared": (n_pairs / docs) * ((V + 1023) // 1024 * 1024)},
                 {"pass": "lists_mark_kernel", "ms": passes[1], "id_row_bytes": n_pairs * L * 8, "byte_stores": tokens},
                 {"pass": "lists_query_kernel<5>", "ms": passes[2]},
                 {"pass": "lists_sims_kernel<5, false>", "ms": passes[3], "rows_gathered": rows, "fp32_fma": rows * Q * rstride, "pipe": SIMS_PIPE},

@@ -8,7 +8,7 @@
 #include <stdlib.h>
 
 namespace capamd {
-constexpr int kListStamps = 6;        // stamps per launch group: before the memset and after each of memset, mark, query, sims, pool
+constexpr int kListStamps = 6;        // stamps per launch group: before the clear and after each of clear, mark, query, sims, pool
 #ifdef CAPAMD_PROFILING
 void lists_stamp(hipStream_t s);      // lists.hip: records an event between passes while capamd_debug_lists_timing is on
 #else
@@ -58,6 +58,7 @@ struct ListsArgs {
   float4* qplain;          // [lists][64 NV] the list's query rows once more, as [column][term]: what the dense head pass stages in LDS
   float* head;             // [H / 16][64 NV][16] the first H table rows, sixteen by sixteen, column-major inside a block (lists_head_pack_kernel)
   int H;                   // rows 0 .. H - 1 get their similarities from the dense matrix-pipe pass (lists_head_sims_kernel), for EVERY list
+  int preflag;             // ids below this count as flagged in every list (lists_clear_kernel): the mark pass does not store their bytes
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
@@ -92,6 +93,38 @@ __device__ __forceinline__ bool list_doc_of(const ListsArgs& a, int& l, int& doc
 dim3 list_doc_grid(int nl, int longest) { return nl >= 8 ? dim3((unsigned)longest * 8, (unsigned)(nl + 7) / 8) : dim3((unsigned)longest, (unsigned)nl); }
 
 __device__ __forceinline__ int64_t doc_id_at(const PairIds& ids, int j) { return ids.d32 ? (int64_t)ids.d32[j] : ids.d64[j]; }
+
+// ---- 0: clear ------------------------------------------------------------------------------------------------------------------
+// The byte maps of the launch group's lists: zero, except the first `preflag` ids, which count as flagged in EVERY list - vocabularies
+// are frequency-ordered (GloVe's is; the benchmark's ids are Zipf ranks), the first thousand ids are two thirds of all document
+// positions and in (almost) every 1000-candidate list anyway, so the mark pass skips their byte stores (134 -> 1xx us) and the sims pass
+// computes at most `preflag` rows per list that nobody looks up (+2-5 % of its rows on the benchmark's lists).  A flag is only ever a
+// licence to compute an entry: a superset of the list's terms changes no result.  (Replaces the hipMemsetAsync of rounds 3-4.)
+// How many: a term of rank r is in a list that holds a few times r positions; the call's positions per list (pads included) / 256, at
+// most kPreflagMax - 3,120 on the benchmark's 1000 x 800 lists (mark 135 -> 104 us, sims +5), 300 on 100-candidate lists.
+// (profiles/r04/lists_preflag_ab.txt)
+#ifndef CAPAMD_LISTS_PREFLAG
+#define CAPAMD_LISTS_PREFLAG 4096
+#endif
+constexpr int kPreflagMax = CAPAMD_LISTS_PREFLAG;
+inline int lists_preflag(int64_t n_pairs, int L, int n_lists) {
+  if (kPreflagMax <= 0 || n_lists < 1) return 0;
+  const int64_t p = n_pairs * L / n_lists / 256;
+  return (int)((p < kPreflagMax ? p : kPreflagMax) / 16 * 16);
+}
+__global__ __launch_bounds__(256) void lists_clear_kernel(ListsArgs a) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;          // (Vp is a multiple of kSimsIds, itself a multiple of 16)
+  if (i >= a.Vp) return;
+  const int64_t lim = a.V < a.preflag ? a.V : a.preflag;                      // (only rows of the table)
+  unsigned w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w[k] = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) w[k] |= (i + 4 * k + b < lim) ? (1u << (8 * b)) : 0u;
+  }
+  *reinterpret_cast<uint4*>(a.flags + (int64_t)blockIdx.y * a.Vp + i) = make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 // ---- 1: mark -------------------------------------------------------------------------------------------------------------------
 // A wave per document (four per workgroup): every real term id (0 < id < V) flags its byte of the list's map AND is appended to the
@@ -161,7 +194,9 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
       if (!__any(v != 0)) continue;          // padding only (wave-uniform): the tail of most documents
       const bool real = v > 0 && v < a.V;
       if (v >= a.V) bad = true;
-      if (real) f[v] = 1;                    // (unconditional: a check of the flag first puts a load in front of every store and measures the same)
+      // (unconditional: a check of the flag first puts a load in front of every store and measures the same.  Ids below a.preflag are
+      //  flagged by lists_clear_kernel for every list - on frequency-ordered vocabularies two thirds of all positions' stores)
+      if (real && v >= a.preflag) f[v] = 1;
       if (EMIT) {
         const uint64_t set = __ballot(real);
         if (kCompactRows) {
@@ -781,9 +816,9 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     if (!kn_mu) kn_consts = nullptr;
     const int H = lists_head_rows(V, n_pairs, L, n_lists);
     ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, cid, meta, lists_cid_stride(L),
-                kn_consts, qplain, head, H};
+                kn_consts, qplain, head, H, lists_preflag(n_pairs, L, n_lists)};
     lists_stamp(s);
-    if (hipMemsetAsync(flags, 0, (size_t)nl * Vp, s) != hipSuccess) return CAPAMD_ERR_LAUNCH;
+    hipLaunchKernelGGL(lists_clear_kernel, dim3((unsigned)((Vp + 256 * 16 - 1) / (256 * 16)), (unsigned)nl), dim3(256), 0, s, a);
     lists_stamp(s);
     {
       ListsArgs am = a;
