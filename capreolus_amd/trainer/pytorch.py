@@ -539,14 +539,18 @@ class PytorchTrainer:
                 # samples (then the predictions are one dict(zip(...)) per query)
                 {"counts": counts, "offsets": np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))]).astype(np.int64),
                  "one_run_per_qid": len({q for q, _, _ in groups}) == len(groups)})
-        # runs of at least 16 lists and 16,000 pairs are scored as two halves of about equal size (predict overlaps the second half's
-        # kernels with the first half's dict building); the pinned buffer the fp16 scores come back in is kept with the plan
+        # runs of at least 16 lists and 16,000 pairs are scored in two (from 32 lists and 32,000 pairs: four) parts of about equal size
+        # (predict overlaps a part's kernels with the dict building of the parts before it); the pinned buffer the fp16 scores come back
+        # in is kept with the plan
         off = plan[4]["offsets"]
         if self.device.type == "cuda" and len(counts) >= 16 and int(off[-1]) >= 16000:
-            mid = int(np.searchsorted(off, off[-1] // 2))
-            mid = min(max(mid, 2), len(counts) - 2)
-            plan[4]["parts"] = [(0, mid), (mid, len(counts))]
-            plan[4]["pinned"] = torch.empty(int(off[-1]), dtype=torch.float16).pin_memory()
+            n_parts = 4 if len(counts) >= 32 and int(off[-1]) >= 32000 else 2
+            cuts = sorted({min(max(int(np.searchsorted(off, off[-1] * k // n_parts)), 2), len(counts) - 2) for k in range(1, n_parts)})
+            edges = [0] + cuts + [len(counts)]
+            parts = [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b - a >= 2]
+            if len(parts) >= 2 and parts[0][0] == 0 and parts[-1][1] == len(counts) and all(x[1] == y[0] for x, y in zip(parts[:-1], parts[1:])):
+                plan[4]["parts"] = parts
+                plan[4]["pinned"] = torch.empty(int(off[-1]), dtype=torch.float16).pin_memory()
         try:
             ref = weakref.ref(pred_data)
         except TypeError:
@@ -672,8 +676,8 @@ class PytorchTrainer:
             # copy is 2 bytes per pair and `tolist` is all the host still does per score.
             parts = extra.get("parts") if not distributed and extra["one_run_per_qid"] else None
             if parts:
-                # Two halves of the lists (round 4): the second half's kernels run while the host turns the first half's scores into
-                # dicts - 64,000 dict inserts and float objects cost CPython twice what the kernels take.  Same kernels, same scores.
+                # The lists in two or four parts (round 4): a part's kernels run while the host turns the parts before it into dicts -
+                # 64,000 dict inserts and float objects cost CPython twice what the kernels take.  Same kernels, same scores.
                 with engine.deferred_status(self.device):
                     host = extra["pinned"]
                     done = []
