@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
     put(idb, sim_from_dots<NV>(pb, row_den<NV>(db), qp, lane16));    // (an odd last row is done twice: a branch here makes hipcc sink row b's
                                                                      //  fma chain into it and keep the whole query copy in registers for that)
   }
-  // (one row per trip with the NEXT row requested before the current one is used - a software pipeline - is 4-5 % slower end to end)
+  // (one row per trip with the NEXT row requested before the current one is used - a software pipeline - is 4-5 % slower end to end;
+  //  FOUR rows per trip - half the LDS query reads per row, twice the loads in flight, 126 registers - 10 % slower: 317-327 against 291-293 us)
 }
 
 #endif
