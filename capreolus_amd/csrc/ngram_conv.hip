@@ -10,8 +10,11 @@
 //     rep_g[m][f] = b_g[f] + sum_{c < g} sum_d E[ids[m + c]][d] W_g[f][d][c]           (zero rows beyond the sequence end: the ConstantPad1d)
 //     dW_g[f][d][c] = sum_m E[ids[m + c]][d] dRep_g[m][f]        db_g[f] = sum_m dRep_g[m][f]
 // so nothing is materialised: no [B, D, L] embedding tensor, no permutes, no padded copies, no im2col - the kernels gather the table's rows.
-// Both directions run on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, 157 TFLOP/s peak = the fp32
-// vector peak, but one operand register per lane and the VALU left free).  The bias rides along as column D of the left operand (a constant
+// The backward runs on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, 157 TFLOP/s peak = the fp32
+// vector peak, but one operand register per lane and the VALU left free); the forward on v_mfma_f32_32x32x16_bf16 with both operands
+// split EXACTLY into three bf16 values each (six products per fp32 product, at sixteen times the fp32 MFMA rate: ngram_forward3_kernel;
+// the fp32 form, ngram_forward_kernel, is kept behind -DCAPAMD_NGRAM_FP32=1).  The same split in the backward measured no faster - its
+// tiles have to be transposed at the LDS stage, and that costs what the MFMAs save (profiles/r04/ngram_conv.txt).  The bias rides along as column D of the left operand (a constant
 // 1 in tap 0) and row D of the weights, forward and backward.
 //
 //   forward:  one workgroup per (128 positions, n-gram size): the weights of its taps as [d][f] panels (ngram_pack_kernel turns the Conv1d
@@ -26,6 +29,10 @@
 #include "capreolus_amd.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifndef CAPAMD_NGRAM_FP32
+#define CAPAMD_NGRAM_FP32 0        // 1: the forward K loop on v_mfma_f32_32x32x2_f32 too (the first round-4 version) instead of bf16 x 3
+#endif
 
 namespace {
 
@@ -58,6 +65,7 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ int part_of(int g1, int c) { return g1 * (g1 - 1) / 2 + c; }   // g1 = n-gram size, 1-based
+__device__ __forceinline__ int n_parts_dev(int G) { return G * (G + 1) / 2; }
 
 // ---- weights: Conv1d layout -> tap panels ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ngram_pack_kernel(ConvArgs a, unsigned* queue) {
@@ -73,6 +81,42 @@ __global__ __launch_bounds__(256) void ngram_pack_kernel(ConvArgs a, unsigned* q
   if (d < a.D) v = a.w[g1 - 1][((int64_t)f * a.D + d) * g1 + c];
   else if (d == a.D && c == 0) v = a.b[g1 - 1][f];
   a.wt[((int64_t)part * a.Dp + d) * a.F + f] = v;
+}
+
+// ---- three-way bf16 split -------------------------------------------------------------------------------------------------------------
+// An fp32 value is EXACTLY hi + mid + lo with three bf16 values (8 significant bits each, truncation; bf16 has fp32's exponent range, so no
+// scaling and no range to watch): x = hi + r, hi = x & 0xffff0000; r = mid + lo likewise.  A product of two fp32 values is then
+// hi hi + (hi mid + mid hi) + (mid mid + hi lo + lo hi) + terms below 2^-24 of it: six bf16 MFMAs at sixteen times the fp32 MFMA rate.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+struct Split3 {
+  unsigned hi, mid, lo;      // the values' upper 16 bits (the bf16 patterns), in the low half-words
+};
+__device__ __forceinline__ Split3 split3(float x) {
+  const unsigned xb = __float_as_uint(x), hb = xb & 0xffff0000u;
+  const float r = x - __uint_as_float(hb);
+  const unsigned rb = __float_as_uint(r), mb = rb & 0xffff0000u;
+  const float r2 = r - __uint_as_float(mb);
+  return Split3{hb >> 16, mb >> 16, __float_as_uint(r2) >> 16};
+}
+
+// weights: Conv1d layout -> [plane][part][f][Dp] bf16 (d contiguous: the MFMA's B fragment is eight consecutive d of one filter)
+__global__ __launch_bounds__(256) void ngram_pack3_kernel(ConvArgs a, unsigned short* wt3, unsigned* queue) {
+  const int part = blockIdx.y;
+  int g1 = 1;
+  while (part_of(g1 + 1, 0) <= part) ++g1;
+  const int c = part - part_of(g1, 0);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && part == 0) *queue = 0u;          // the forward kernel's work queue
+  if (i >= a.Dp * a.F) return;
+  const int f = i / a.Dp, d = i - f * a.Dp;
+  float v = 0.f;
+  if (d < a.D) v = a.w[g1 - 1][((int64_t)f * a.D + d) * g1 + c];
+  else if (d == a.D && c == 0) v = a.b[g1 - 1][f];
+  const Split3 sp = split3(v);
+  const int64_t plane = (int64_t)gridDim.y * a.F * a.Dp, at = ((int64_t)part * a.F + f) * a.Dp + d;
+  wt3[at] = (unsigned short)sp.hi;
+  wt3[plane + at] = (unsigned short)sp.mid;
+  wt3[2 * plane + at] = (unsigned short)sp.lo;
 }
 
 // the table row behind position (segment, row m) shifted by tap c: -1 = a zero row (beyond the sequence end, or an id outside the table)
@@ -219,6 +263,157 @@ __global__ __launch_bounds__(256, 3) void ngram_forward_kernel(ConvArgs a, int t
         if (f < a.F) dst[f] = acc[jj][e];
       }
     }
+  }
+}
+
+// ---- forward on bf16 x 3 ----------------------------------------------------------------------------------------------------------------
+// The same units, queue and epilogue as ngram_forward_kernel, the K loop on v_mfma_f32_32x32x16_bf16 with both operands split three ways:
+// the weights once per call (ngram_pack3_kernel), the gathered rows at the LDS stage (4 VALU instructions per value + packing).  Per
+// 32-dimension step a wave issues 24 MFMAs of 32 cycles where the fp32 form issues 32 of 64.
+constexpr int kRows3 = 128;            // positions per tile of the bf16 x 3 forward (the weight planes are re-staged per tile and step: 64-position tiles made the LDS, not the MFMAs, the bound)
+constexpr int kP3 = 80;                // LDS pitch (bytes) of a 32-k row of one plane: 64 B of bf16 + 16: ds_read_b128 of 32 rows conflict-free
+__global__ __launch_bounds__(256, 2) void ngram_forward3_kernel(ConvArgs a, const unsigned short* wt3, int tiles0, int tiles, int panels, unsigned* queue) {
+  __shared__ __attribute__((aligned(16))) unsigned char A3[3 * kRows3 * kP3];
+  __shared__ __attribute__((aligned(16))) unsigned char B3[3 * 128 * kP3];
+  __shared__ int64_t rid[kNcMaxG][kRows3];
+  __shared__ int64_t orow[kRows3];
+  __shared__ int any_real;
+  __shared__ unsigned unit_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned units = (unsigned)tiles * a.G * panels;
+  const int ksteps = a.Dp / 32;
+  const int wr = wave >> 1, wc = wave & 1;               // a wave: 64 positions x 64 filters
+  const int64_t plane = (int64_t)n_parts_dev(a.G) * a.F * a.Dp;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      unit_s = atomicAdd(queue, 1u);
+      any_real = 0;
+    }
+    __syncthreads();
+    const unsigned unit = unit_s;
+    if (unit >= units) return;
+    const int tile = unit % tiles, rest = unit / tiles;
+    const int f0 = (rest % panels) * 128, g1 = a.G - rest / panels;          // heavy n-gram sizes first
+    const int seg = tile < tiles0 ? 0 : 1;
+    const int64_t m0 = (int64_t)(seg ? tile - tiles0 : tile) * kRows3;
+    const int len = a.len[seg];
+    const int64_t M = (int64_t)a.N * len;
+    if (tid < kRows3) {
+      bool bad = false, real = false;
+      const int64_t m = m0 + tid;
+      const unsigned n = m < M ? (unsigned)m / (unsigned)len : 0u;
+      const int j = m < M ? (int)((unsigned)m - n * (unsigned)len) : 0;
+      orow[tid] = m < M ? ((int64_t)n * a.G + (g1 - 1)) * len + j : -1;
+      for (int c = 0; c < g1; ++c) {
+        int64_t id = -1;
+        if (m < M && j + c < len) {
+          id = a.ids[seg][(int64_t)n * len + j + c];
+          if (id < 0 || id >= a.V) {
+            bad = true;
+            id = -1;
+          }
+        }
+        rid[c][tid] = id;
+        if (c == 0 && id > 0) real = true;
+      }
+      if (bad) atomicOr(a.status, CAPAMD_STATUS_DOC_ID_RANGE);
+      if (real) any_real = 1;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (any_real) {
+      const int steps = g1 * ksteps;
+      const unsigned short* wt = wt3 + (int64_t)part_of(g1, 0) * a.F * a.Dp;
+      float4 ra[4];
+      uint4 rb[6];
+      auto fetch = [&](int s) {
+        const int c = s / ksteps, k0 = (s - c * ksteps) * 32;
+        const int d = k0 + 4 * (tid & 7);
+        const int dcl = d < a.D ? d : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t id = rid[c][(tid >> 3) + 32 * i];
+          ra[i] = *reinterpret_cast<const float4*>(a.emb + (id >= 0 ? id : 0) * a.D + dcl);        // (D % 4 == 0)
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int idx = tid + 256 * j, p = idx >> 9, f = (idx >> 2) & 127, ch = idx & 3;
+          const int fg = f0 + f < a.F ? f0 + f : 0;
+          rb[j] = *reinterpret_cast<const uint4*>(wt + p * plane + ((int64_t)c * a.F + fg) * a.Dp + k0 + 8 * ch);
+        }
+      };
+      auto stage = [&](int s) {
+        const int c = s / ksteps, d = (s - c * ksteps) * 32 + 4 * (tid & 7);
+        const float one = (c == 0 && d == a.D) ? 1.f : 0.f;                                         // (d == D: the bias column)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = (tid >> 3) + 32 * i;
+          const bool live = rid[c][r] >= 0 && d < a.D;
+          const Split3 s0 = split3(live ? ra[i].x : one), s1 = split3(live ? ra[i].y : 0.f), s2 = split3(live ? ra[i].z : 0.f), s3 = split3(live ? ra[i].w : 0.f);
+          unsigned char* at = A3 + r * kP3 + 8 * (tid & 7);
+          *reinterpret_cast<uint2*>(at) = make_uint2(s0.hi | (s1.hi << 16), s2.hi | (s3.hi << 16));
+          *reinterpret_cast<uint2*>(at + kRows3 * kP3) = make_uint2(s0.mid | (s1.mid << 16), s2.mid | (s3.mid << 16));
+          *reinterpret_cast<uint2*>(at + 2 * kRows3 * kP3) = make_uint2(s0.lo | (s1.lo << 16), s2.lo | (s3.lo << 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int idx = tid + 256 * j, p = idx >> 9, f = (idx >> 2) & 127, ch = idx & 3;
+          *reinterpret_cast<uint4*>(B3 + (p * 128 + f) * kP3 + 16 * ch) = f0 + f < a.F ? rb[j] : make_uint4(0u, 0u, 0u, 0u);
+        }
+      };
+      fetch(0);
+      for (int s = 0; s < steps; ++s) {
+        __syncthreads();          // the previous step's reads are done
+        stage(s);
+        __syncthreads();
+        if (s + 1 < steps) fetch(s + 1);
+        const unsigned char* ap = A3 + (wr * 64 + (lane & 31)) * kP3 + 16 * (lane >> 5);
+        const unsigned char* bp = B3 + (wc * 64 + (lane & 31)) * kP3 + 16 * (lane >> 5);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          bf16x8v av[2][3], bv[2][3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            av[0][p] = *reinterpret_cast<const bf16x8v*>(ap + p * kRows3 * kP3 + 32 * kb);
+            av[1][p] = *reinterpret_cast<const bf16x8v*>(ap + (p * kRows3 + 32) * kP3 + 32 * kb);
+            bv[0][p] = *reinterpret_cast<const bf16x8v*>(bp + p * 128 * kP3 + 32 * kb);
+            bv[1][p] = *reinterpret_cast<const bf16x8v*>(bp + (p * 128 + 32) * kP3 + 32 * kb);
+          }
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {      // the small products first
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][2], bv[jj][0], acc[ii][jj], 0, 0, 0);
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][0], bv[jj][2], acc[ii][jj], 0, 0, 0);
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][1], bv[jj][1], acc[ii][jj], 0, 0, 0);
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][1], bv[jj][0], acc[ii][jj], 0, 0, 0);
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][0], bv[jj][1], acc[ii][jj], 0, 0, 0);
+              acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][0], bv[jj][0], acc[ii][jj], 0, 0, 0);
+            }
+        }
+      }
+    }
+    float* out = a.out[seg];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t o = orow[wr * 64 + ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+        if (o < 0) continue;
+        float* dst = out + o * (int64_t)a.F;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int f = f0 + wc * 64 + jj * 32 + (lane & 31);
+          if (f < a.F) dst[f] = acc[ii][jj][e];
+        }
+      }
   }
 }
 
@@ -399,7 +594,8 @@ int n_splits(int G, int F) { return 256 / (n_parts(G) * ((F + 127) / 128)) > 0 ?
 extern "C" size_t capamd_ngram_conv_workspace_floats(int D, int G, int F, int backward) {
   if (D < 1 || G < 1 || G > kNcMaxG || F < 1) return 0;
   const size_t panel = (size_t)n_parts(G) * padded_width(D) * F;
-  return backward ? panel * n_splits(G, F) : panel + 4;          // (forward: the tap panels and the work queue's counter)
+  // (forward: the tap panels - fp32 [d][f], or three bf16 planes [f][d] = 1.5 x the bytes - and the work queue's counter)
+  return backward ? panel * n_splits(G, F) : panel + panel / 2 + 8;
 }
 
 extern "C" int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_ids, int N, int Q, int L, const float* emb, int64_t V, int D,
@@ -418,13 +614,21 @@ extern "C" int capamd_ngram_conv_forward(const int64_t* q_ids, const int64_t* d_
   if ((int64_t)N * L >= (1ll << 31) || (int64_t)N * Q >= (1ll << 31)) return CAPAMD_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  unsigned* queue = reinterpret_cast<unsigned*>(workspace + (size_t)n_parts(G) * a.Dp * F);
-  hipLaunchKernelGGL(ngram_pack_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a, queue);
-  const int64_t tiles0 = ((int64_t)N * Q + kFwdRows - 1) / kFwdRows, tiles1 = ((int64_t)N * L + kFwdRows - 1) / kFwdRows;
+  const size_t panel = (size_t)n_parts(G) * a.Dp * F;
+  unsigned* queue = reinterpret_cast<unsigned*>(workspace + panel + panel / 2 + 4);
+  unsigned short* wt3 = reinterpret_cast<unsigned short*>(workspace);
+  if (CAPAMD_NGRAM_FP32) hipLaunchKernelGGL(ngram_pack_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a, queue);
+  else hipLaunchKernelGGL(ngram_pack3_kernel, dim3((a.Dp * F + 255) / 256, n_parts(G)), dim3(256), 0, s, a, wt3, queue);
+  const int rows = CAPAMD_NGRAM_FP32 ? kFwdRows : kRows3;
+  const int64_t tiles0 = ((int64_t)N * Q + rows - 1) / rows, tiles1 = ((int64_t)N * L + rows - 1) / rows;
   const int panels = (F + 127) / 128;
   if ((tiles0 + tiles1) * G * panels >= (1ll << 31)) return CAPAMD_ERR_ARG;
   const int64_t units = (tiles0 + tiles1) * G * panels;
-  hipLaunchKernelGGL(ngram_forward_kernel, dim3((unsigned)(units < 768 ? units : 768)), dim3(256), 0, s, a, (int)tiles0, (int)(tiles0 + tiles1), panels, queue);
+  if (CAPAMD_NGRAM_FP32)
+    hipLaunchKernelGGL(ngram_forward_kernel, dim3((unsigned)(units < 768 ? units : 768)), dim3(256), 0, s, a, (int)tiles0, (int)(tiles0 + tiles1), panels, queue);
+  else
+    hipLaunchKernelGGL(ngram_forward3_kernel, dim3((unsigned)(units < 512 ? units : 512)), dim3(256), 0, s, a, wt3, (int)tiles0, (int)(tiles0 + tiles1), panels,
+                       queue);
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
