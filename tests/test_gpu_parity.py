@@ -902,6 +902,67 @@ def test_train_loop_reduces_loss_and_checkpoints(tmp_path):
     assert torch.isfinite(r.model.combine[0].weight).all() and not torch.equal(r.model.combine[0].weight, torch.zeros_like(before))
 
 
+@pytest.mark.parametrize("kind", ["KNRM", "DRMM", "DRMMTKS", "PACRR", "ConvKNRM"])
+def test_train_loop_runs_every_interaction_model_on_its_device_step(kind, tmp_path):
+    """`PytorchTrainer.train` end to end for each trainable interaction model with its defaults: the trainer picks the reranker's
+    device-kernel step (`capamd_*_train_step`, the plain Adam's state), the loss of a learnable synthetic task goes down, the dev set is
+    predicted and ranked each iteration, `dev.best` is written and loads back."""
+    import capreolus_amd.reranker as rr
+    from capreolus_amd.trainer import PytorchTrainer
+
+    rs = np.random.RandomState(11)
+    V, L, Q = 600, 96, 4
+    emb = synthetic.make_embeddings(V, 52, seed=9)
+    r = getattr(rr, kind)({}, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
+    r.build_model()
+    queries = {str(q): rs.randint(1, V, size=Q) for q in range(12)}
+    idf = {qid: rs.uniform(0.5, 3.0, size=Q).astype(np.float32) for qid in queries}
+
+    def doc(qid, relevant):
+        d = rs.randint(1, V, size=L)
+        d[rs.randint(L // 2, L):] = 0                       # padded tails of different lengths
+        if relevant:
+            d[rs.choice(L // 2, 8, replace=False)] = rs.choice(queries[qid], 8)
+        return d
+
+    class Train(torch.utils.data.IterableDataset):
+        def __iter__(self):
+            while True:
+                qid = str(rs.randint(0, 12))
+                yield {"query": torch.as_tensor(queries[qid]), "posdoc": torch.as_tensor(doc(qid, True)),
+                       "negdoc": torch.as_tensor(doc(qid, False)), "query_idf": torch.as_tensor(idf[qid])}
+
+    docs = {(qid, f"d{i}"): doc(qid, i < 3) for qid in queries for i in range(10)}
+
+    class Dev(torch.utils.data.IterableDataset):
+        qid_to_docids = {qid: [f"d{i}" for i in range(10)] for qid in queries}
+
+        def __iter__(self):
+            for qid, ds in self.qid_to_docids.items():
+                for d in ds:
+                    yield {"qid": qid, "posdocid": d, "query": torch.as_tensor(queries[qid]), "posdoc": torch.as_tensor(docs[(qid, d)]),
+                           "query_idf": torch.as_tensor(idf[qid])}
+
+        def __len__(self):
+            return 120
+
+        def get_qid_docid_pairs(self):
+            for qid, ds in self.qid_to_docids.items():
+                for d in ds:
+                    yield qid, d
+
+    qrels = {qid: {f"d{i}": int(i < 3) for i in range(10)} for qid in queries}
+    t = PytorchTrainer({"batch": 16, "itersize": 64, "niters": 8, "lr": 0.01, "evalbatch": 40})
+    losses = t.train(r, Train(), tmp_path / "train", Dev(), tmp_path / "dev", qrels, "ndcg_cut_20")
+    assert t._use_fused and not t._fused_failed, kind
+    assert not t.optimizer.param_groups[0].get("capturable")
+    assert all(np.isfinite(losses)) and min(losses[2:]) < losses[0], (kind, losses)
+    assert (tmp_path / "train" / "dev.best").exists() and (tmp_path / "dev" / "8.run").exists()
+    t.load_best_model(r, tmp_path / "train")
+    preds = t.predict(r, Dev())
+    assert len(preds) == 12 and all(len(v) == 10 and all(np.isfinite(list(v.values()))) for v in preds.values())
+
+
 @pytest.mark.parametrize("name", ["default", "top3_short", "ranklist"])
 def test_drmmtks_scores(name):
     from capreolus_amd.reranker import DRMMTKS
