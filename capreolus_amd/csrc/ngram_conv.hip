@@ -1,4 +1,4 @@
-// ConvKNRM's trainable n-gram convolutions, forward and backward, as fp32 matrix-pipe GEMMs for gfx950.
+// ConvKNRM's trainable n-gram convolutions, forward and backward, as fp32-exact matrix-pipe GEMMs for gfx950.
 //
 // Reference: ConvKNRM_class.forward, capreolus/reranker/ConvKNRM.py:42-51 - for every n-gram size g = 1..G
 //     rep_g = Conv1d(D -> F, kernel g)(ConstantPad1d((0, g - 1), 0)(embeddings(ids).permute(0, 2, 1))).permute(0, 2, 1)
@@ -14,13 +14,14 @@
 // vector peak, but one operand register per lane and the VALU left free); the forward on v_mfma_f32_32x32x16_bf16 with both operands
 // split EXACTLY into three bf16 values each (six products per fp32 product, at sixteen times the fp32 MFMA rate: ngram_forward3_kernel;
 // the fp32 form, ngram_forward_kernel, is kept behind -DCAPAMD_NGRAM_FP32=1).  The same split in the backward measured no faster - its
-// tiles have to be transposed at the LDS stage, and that costs what the MFMAs save (profiles/r04/ngram_conv.txt).  The bias rides along as column D of the left operand (a constant
-// 1 in tap 0) and row D of the weights, forward and backward.
+// tiles have to be transposed at the LDS stage, and that costs what the MFMAs save (profiles/r04/ngram_conv.txt).  The bias rides along as
+// column D of the left operand (a constant 1 in tap 0) and row D of the weights, forward and backward.
 //
-//   forward:  one workgroup per (128 positions, n-gram size): the weights of its taps as [d][f] panels (ngram_pack_kernel turns the Conv1d
-//             layout [F][D][g] once per call), K loop over (tap, 32 embedding dimensions), both operands staged in LDS - gathered rows by
-//             float4, read back column-wise (pitch 33: conflict-free).  Tiles without a single real token (the padding behind a training
-//             document) are written as zeros and skipped: the kernel pooling behind the convolutions masks pad positions.
+//   forward:  persistent workgroups over a device queue of (128-position tile, n-gram size, 128-filter panel) units, heaviest n-gram size
+//             first; the weights of a unit's taps as three bf16 planes [f][d] (ngram_pack3_kernel splits the Conv1d layout [F][D][g] once
+//             per call), K loop over (tap, 32 embedding dimensions), both operands staged in LDS - gathered rows by float4, split at the
+//             stage, fragments by 16-byte reads (pitch 80 B: conflict-free).  Tiles without a single real token (the padding behind a
+//             training document) are written as zeros and skipped: the kernel pooling behind the convolutions masks pad positions.
 //   backward: C[d][f] = sum_m X[m + c][d] dRep[m][f] - both operands are position-major, which is what the 32x32x2 MFMA wants of a "TN"
 //             product (lane = column, the two k of an instruction = two consecutive positions): no transposes.  One workgroup per
 //             (tap panel, slice of the positions), wave w owns filters 32 w .. 32 w + 31 and all of D; the slices' partial panels are
