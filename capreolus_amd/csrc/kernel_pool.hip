@@ -49,13 +49,13 @@ struct PoolArgs {
   float* part;            // forward: [B, GD, C, T, K + 1] kernel sums and row sum of every chunk -> pool_finish_kernel
 };
 
-// chunks per document: ~160 positions each - a (pair, view) per workgroup leaves a batch of 64 documents on 192 of 256 CUs for as long as
-// its LONGEST document takes
+// chunk slots per document: one per 160 positions of L, at most 8 - a (pair, view) per workgroup leaves a batch of 64 documents on 192 of
+// 256 CUs for as long as its LONGEST document takes.  How many of the slots a document uses depends on its real positions (below).
+// (One slot per 64 positions, up to 16, so that long documents split finer in the backward: 141 -> 155 us, the partial results' sums grow.)
 __host__ __device__ inline int pool_chunks(int L) {
   const int c = (L + 159) / 160;
   return c < 1 ? 1 : (c > 8 ? 8 : c);
 }
-
 // the a view of query vector t of block (b, gb), and the view index v of its pair
 __device__ __forceinline__ int pool_ga(const PoolArgs& a, int t, int gb) { return a.cross ? t / a.Q : gb; }
 __device__ __forceinline__ int pool_v(const PoolArgs& a, int t, int gb) { return a.cross ? (t / a.Q) * a.GD + gb : gb; }
@@ -102,6 +102,27 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     reinterpret_cast<float4*>(A)[t * F4 + c] = reinterpret_cast<const float4*>(src)[c];
   }
   __syncthreads();
+  // The document's real positions go to its first `act` chunks; a chunk beyond them (most documents end in padding: 303 real
+  // positions of 800 on the benchmark's lists = 2 chunks of 5) writes zeros for its partial results and is done - a workgroup costs its
+  // prologue and epilogue whatever it holds, so five chunks of 60 positions were slower than two of 150.
+  // (The backward's loop is a long dependent chain per position and wants SHORT chunks - 64 positions: 153 us at 160, 141 at 64; the
+  //  forward 160: 45 us against 57.)
+  constexpr int kPerChunk = BWD ? 64 : 160;
+  const int want = (n_real_s + kPerChunk - 1) / kPerChunk;
+  const int act = want < 1 ? 1 : (want < a.C ? want : a.C);
+  if (chunk >= act) {
+    const int64_t blk0 = ((int64_t)b * a.GD + gb) * a.C + chunk;
+    if (!BWD) {
+      for (int i = tid; i < T * (a.K + 1); i += 256) a.part[blk0 * T * (a.K + 1) + i] = 0.f;
+    } else {
+      for (int i = tid; i < T * a.F; i += 256) a.dq_part[blk0 * T * a.F + i] = 0.f;
+      if (tid < a.K) {
+        a.dmu_part[blk0 * a.K + tid] = 0.f;
+        a.dsigma_part[blk0 * a.K + tid] = 0.f;
+      }
+    }
+    return;
+  }
   if (tid < T) {
     float s = 0.f;
     for (int c = 0; c < a.F; ++c) s = __builtin_fmaf(A[tid * a.F + c], A[tid * a.F + c], s);
@@ -156,12 +177,12 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
   }
   if (BWD) {                          // no gradient into a pad position's vector
     float* dz = a.dd + ((int64_t)b * a.GD + gb) * a.L * a.F;
-    for (int i = tid + 256 * chunk; i < n_pad * F4; i += 256 * a.C) {
+    for (int i = tid + 256 * chunk; i < n_pad * F4; i += 256 * act) {
       const int p = i / F4, c = i - p * F4;
       reinterpret_cast<float4*>(dz + (int64_t)jl[a.L - 1 - p] * a.F)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const int ji_lo = (int)((int64_t)n_real * chunk / a.C), ji_hi = (int)((int64_t)n_real * (chunk + 1) / a.C);
+  const int ji_lo = (int)((int64_t)n_real * chunk / act), ji_hi = (int)((int64_t)n_real * (chunk + 1) / act);
   for (int ji = ji_lo + g; ji < ji_hi; ji += 16) {
     const int j = jl[ji];
     float4 x[NC];

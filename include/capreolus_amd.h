@@ -450,7 +450,7 @@ int capamd_convknrm_train_step(const int64_t* q_ids, const int64_t* d_ids, int B
  * qrep fp32 [B, GQ, Q, F] / drep fp32 [B, GD, L, F]: the GQ / GD n-gram views of query and document (F % 4 == 0, F <= 256);
  * q_ids / d_ids: the token ids (pad = 0: masked positions); crossmatch != 0: every (query view, document view) pair, V = GQ GD
  * views (v = gq GD + gd), else the matching ones (GQ == GD, V = GD).  (crossmatch ? GQ : 1) * Q <= 24, K <= 16.
- * A document's real positions are split into C = capamd_kernel_pool_chunks(L) chunks (1..8, ~160 positions each), one workgroup per
+ * A document's real positions are split into at most C = capamd_kernel_pool_chunks(L) chunks (1..8 slots; 160 real positions per chunk forward, 64 backward; unused slots hold zeros), one workgroup per
  * (pair, document view, chunk); pad positions never reach the similarity loop (a masked entry is the constant 0: a closed form).
  * forward:  feat fp32 [B, K V] (feature k V + v, the reference's kernels.reshape(B, K V, Q, L) order); ksum fp32 [B, GD, T, K] and
  *           rowsum fp32 [B, GD, T] (T = (crossmatch ? GQ : 1) Q) are what the backward needs of it; chunk_sums: B GD C T (K + 1) fp32
