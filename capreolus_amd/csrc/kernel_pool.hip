@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     }
   }
   const int ji_lo = (int)((int64_t)n_real * chunk / act), ji_hi = (int)((int64_t)n_real * (chunk + 1) / act);
-  for (int ji = ji_lo + g; ji < ji_hi; ji += 16) {
+#ifndef CAPAMD_KPOOL_ABL
+#define CAPAMD_KPOOL_ABL 0       // profiling builds: 1 = no position loop, 2 = no d a_t epilogue, 4 = one query vector in the loop's update half, 8 = no exp / reduction in its first half
+#endif
+  for (int ji = ji_lo + g; ji < ((CAPAMD_KPOOL_ABL & 1) ? 0 : ji_hi); ji += 16) {
     const int j = jl[ji];
     float4 x[NC];
 #pragma unroll
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
         dsim[t] = 0.f;
         if (t < T) {
           const float adj = s[t] - mu_k;
-          const float w = lane16 < a.K ? coef[t * 16 + lane16] * __builtin_amdgcn_exp2f(adj * adj * c_k) * adj / (sg_k * sg_k) : 0.f;
+          const float w = (CAPAMD_KPOOL_ABL & 8) ? adj : lane16 < a.K ? coef[t * 16 + lane16] * __builtin_amdgcn_exp2f(adj * adj * c_k) * adj / (sg_k * sg_k) : 0.f;
           dmu += w;
           dsg += w * adj / sg_k;
-          const float ds = group_allreduce(-w);
+          const float ds = (CAPAMD_KPOOL_ABL & 8) ? w : group_allreduce(-w);
           dsim[t] = (dpad || qpad[t]) ? 0.f : ds;
           cb += dsim[t] * s[t];
           ca[t] += dsim[t] * s[t];
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
 #pragma unroll
       for (int i = 0; i < NC; ++i) o[i] = make_float4(-binv * x[i].x, -binv * x[i].y, -binv * x[i].z, -binv * x[i].w);
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
+      for (int t = 0; t < ((CAPAMD_KPOOL_ABL & 4) ? 1 : TT); ++t)
         if (t < T) {
           const float w = dsim[t] / (an[t] * nb);
 #pragma unroll
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
     // (unrolled over the compile-time bound, barriers outside the guards: a run-time index into the register arrays would move
     // them to scratch)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < ((CAPAMD_KPOOL_ABL & 2) ? 0 : TT); ++t) {
       if (t < T) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
