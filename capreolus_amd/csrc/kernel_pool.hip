@@ -80,20 +80,59 @@ __global__ __launch_bounds__(256, 1) void kernel_pool_kernel(PoolArgs a) {
 
   // the document's real positions in order (front of jl) and its pads (back of jl): pads never reach the similarity loop - a masked entry
   // is the constant 0, so what a pad adds to a kernel sum (and to d mu / d sigma) is a closed form times the number of pads
-  if (tid < 64) {          // wave 0
+  // (all four waves, 1024 positions a round, every lane's four ids requested together: one wave walking the row 64 positions at a time
+  //  was thirteen dependent round trips at L = 800 - most of the fixed cost of a workgroup, and every chunk's workgroup pays it)
+  {
+    __shared__ int trip_real[16], trip_pad[16], tot_real, tot_pad;
     const int64_t* di = a.d_ids + (int64_t)b * a.L;
-    int nr = 0, np = 0;
-    for (int j0 = 0; j0 < a.L; j0 += 64) {
-      const int j = j0 + tid;
-      const bool in = j < a.L, real = in && di[j] != 0;
-      const uint64_t mr = __ballot(real), mp = __ballot(in && !real);
-      const uint64_t below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
-      if (real) jl[nr + __builtin_popcountll(mr & below)] = j;
-      else if (in) jl[a.L - 1 - (np + __builtin_popcountll(mp & below))] = j;
-      nr += __builtin_popcountll(mr);
-      np += __builtin_popcountll(mp);
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (tid == 0) tot_real = tot_pad = 0;
+    for (int base = 0; base < a.L; base += 1024) {
+      int64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = base + (wave * 4 + u) * 64 + lane;
+        v[u] = di[j < a.L ? j : a.L - 1];
+      }
+      uint64_t mr[4], mp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = base + (wave * 4 + u) * 64 + lane;
+        const bool in = j < a.L;
+        mr[u] = __ballot(in && v[u] != 0);
+        mp[u] = __ballot(in && v[u] == 0);
+        if (lane == 0) {
+          trip_real[wave * 4 + u] = __builtin_popcountll(mr[u]);
+          trip_pad[wave * 4 + u] = __builtin_popcountll(mp[u]);
+        }
+      }
+      __syncthreads();
+      int nr = tot_real, np = tot_pad, all_r = 0, all_p = 0;
+      for (int k = 0; k < 16; ++k) {
+        if (k < wave * 4) {
+          nr += trip_real[k];
+          np += trip_pad[k];
+        }
+        all_r += trip_real[k];
+        all_p += trip_pad[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = base + (wave * 4 + u) * 64 + lane;
+        if ((mr[u] >> lane) & 1) jl[nr + __builtin_popcountll(mr[u] & below)] = j;
+        else if ((mp[u] >> lane) & 1) jl[a.L - 1 - (np + __builtin_popcountll(mp[u] & below))] = j;
+        nr += __builtin_popcountll(mr[u]);
+        np += __builtin_popcountll(mp[u]);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        tot_real += all_r;
+        tot_pad += all_p;
+      }
     }
-    if (tid == 0) n_real_s = nr;
+    __syncthreads();
+    if (tid == 0) n_real_s = tot_real;
   }
   // the query vectors of this block's pairs, their norms, the pad flags
   for (int i = tid; i < T * F4; i += 256) {

@@ -913,8 +913,11 @@ def test_train_loop_runs_every_interaction_model_on_its_device_step(kind, tmp_pa
     rs = np.random.RandomState(11)
     V, L, Q = 600, 96, 4
     emb = synthetic.make_embeddings(V, 52, seed=9)
+    torch.manual_seed(3)
     r = getattr(rr, kind)({}, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
     r.build_model()
+    last = {"KNRM": "combine.0", "ConvKNRM": "combine.0", "DRMM": "output_layer", "DRMMTKS": "output_layer", "PACRR": "linear3"}[kind]
+    r.model.get_submodule(last).weight.data.zero_()      # every pair scores the same at the start -> hinge loss exactly 1
     queries = {str(q): rs.randint(1, V, size=Q) for q in range(12)}
     idf = {qid: rs.uniform(0.5, 3.0, size=Q).astype(np.float32) for qid in queries}
 
@@ -956,7 +959,8 @@ def test_train_loop_runs_every_interaction_model_on_its_device_step(kind, tmp_pa
     losses = t.train(r, Train(), tmp_path / "train", Dev(), tmp_path / "dev", qrels, "ndcg_cut_20")
     assert t._use_fused and not t._fused_failed, kind
     assert not t.optimizer.param_groups[0].get("capturable")
-    assert all(np.isfinite(losses)) and min(losses[2:]) < losses[0], (kind, losses)
+    # (a loss per ITERATION of four batches: it starts at 1.0 per pair and the first iteration's mean is already below that)
+    assert all(np.isfinite(losses)) and losses[0] > 0.05 and min(losses[1:]) < 0.9 * losses[0], (kind, losses)
     assert (tmp_path / "train" / "dev.best").exists() and (tmp_path / "dev" / "8.run").exists()
     t.load_best_model(r, tmp_path / "train")
     preds = t.predict(r, Dev())
