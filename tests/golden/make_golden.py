@@ -61,6 +61,20 @@ def _edge_cases(rs, batch, vocab):
     return batch
 
 
+def _multi_list_batch(rs, c):
+    """several queries' candidate lists in one run (what `predict` scores): one list with an OOV query term some of its candidates contain,
+    one with a single-term query"""
+    n_lists, per = c["lists"], c["B"] // c["lists"]
+    parts = [synthetic.make_candidate_list(rs, per, c["V"], c["Q"], c["L"], same_query=True, oov_range=40, query_oov_frac=0.0) for _ in range(n_lists)]
+    for p in parts:                                     # idf is a property of the query: one row per list (the synthetic generator draws one per pair)
+        p["query_idf"][:] = p["query_idf"][0]
+    parts[2]["query"][:, 1] = -11                       # an OOV query term ...
+    parts[2]["posdoc"][::7, 13] = -11                   # ... that every seventh candidate of that list contains (exact match, common.py:155-158)
+    parts[5]["query"][:, 1:] = 0                        # a one-term query
+    parts[5]["query_idf"][:, 1:] = 0
+    return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
 def gen_knrm(KNRM, only=None):
     cases = {
         # name: (V, D, B, Q, L, config, seeds, perturb kernels?)
@@ -181,18 +195,22 @@ def gen_drmm(DRMM):
         print("drmm", name, scores[:6], "n_ambiguous", n_amb.tolist())
 
 
-def gen_drmmtks(TKS):
+def gen_drmmtks(TKS, only=None):
     cases = {
         "default": dict(V=5000, D=300, B=24, Q=4, L=800, cfg=dict(topk=10, gateType="IDF", freezeemb=True)),
         "top3_short": dict(V=800, D=50, B=16, Q=3, L=100, cfg=dict(topk=3, gateType="IDF", freezeemb=True)),
         "ranklist": dict(V=20000, D=300, B=200, Q=4, L=800, cfg=dict(topk=10, gateType="IDF", freezeemb=True), same_query=True),
+        # several queries' candidate lists in one run (8 x 100): what the whole-list route of `predict` is pinned on
+        "multiquery": dict(V=20000, D=300, B=800, Q=4, L=800, cfg=dict(topk=10, gateType="IDF", freezeemb=True), same_query=True, lists=8),
     }
     for name, c in cases.items():
+        if only and name not in only:
+            continue
         seed = 300 + len(name)
         rs = np.random.RandomState(seed)
         emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
         same = c.get("same_query", False)
-        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
+        batch = _multi_list_batch(rs, c) if c.get("lists") else synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
                                               query_oov_frac=0.0 if same else 0.1)
         if not same:
             batch = _edge_cases(rs, batch, c["V"])
@@ -208,6 +226,8 @@ def gen_drmmtks(TKS):
         out = dict(emb_seed=np.int64(seed), V=np.int64(c["V"]), D=np.int64(c["D"]), topk=np.int64(c["cfg"]["topk"]),
                    query=batch["query"].astype(np.int32), posdoc=batch["posdoc"].astype(np.int32), query_idf=batch["query_idf"],
                    ref_scores=scores.astype(np.float32), ref_scores_f16=scores.astype(np.float16))
+        if c.get("lists"):
+            out["list_offsets"] = np.arange(0, c["B"] + 1, c["B"] // c["lists"], dtype=np.int64)
         for k, v in sd.items():
             out["sd." + k] = v
         np.savez_compressed(os.path.join(HERE, f"drmmtks_{name}.npz"), **out)
@@ -228,7 +248,7 @@ class _IdfTensor(torch.Tensor):
         return torch.Tensor.reshape(torch.Tensor._make_subclass(torch.Tensor, self), *flat)
 
 
-def gen_pacrr(PACRR):
+def gen_pacrr(PACRR, only=None):
     cases = {
         "default": dict(V=5000, D=300, B=24, Q=4, L=800,
                         cfg=dict(mingram=1, maxgram=3, nfilters=32, idf=True, kmax=2, combine=32, nonlinearity="relu")),
@@ -236,13 +256,17 @@ def gen_pacrr(PACRR):
                                  cfg=dict(mingram=2, maxgram=3, nfilters=8, idf=False, kmax=3, combine=16, nonlinearity="tanh")),
         "ranklist": dict(V=20000, D=300, B=200, Q=4, L=800,
                          cfg=dict(mingram=1, maxgram=3, nfilters=32, idf=True, kmax=2, combine=32, nonlinearity="relu"), same_query=True),
+        "multiquery": dict(V=20000, D=300, B=800, Q=4, L=800,
+                           cfg=dict(mingram=1, maxgram=3, nfilters=32, idf=True, kmax=2, combine=32, nonlinearity="relu"), same_query=True, lists=8),
     }
     for name, c in cases.items():
+        if only and name not in only:
+            continue
         seed = 400 + len(name)
         rs = np.random.RandomState(seed)
         emb = synthetic.make_embeddings(c["V"], c["D"], seed=seed)
         same = c.get("same_query", False)
-        batch = synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
+        batch = _multi_list_batch(rs, c) if c.get("lists") else synthetic.make_candidate_list(rs, c["B"], c["V"], c["Q"], c["L"], same_query=same, oov_range=40,
                                               query_oov_frac=0.0 if same else 0.1)
         if not same:
             batch = _edge_cases(rs, batch, c["V"])
@@ -265,6 +289,8 @@ def gen_pacrr(PACRR):
                    posdoc=batch["posdoc"].astype(np.int32), query_idf=batch["query_idf"], ref_scores=scores.astype(np.float32),
                    ref_scores_f16=scores.astype(np.float16), nonlinearity=np.array(c["cfg"]["nonlinearity"]),
                    **{"cfg." + k: np.int64(v) for k, v in c["cfg"].items() if k != "nonlinearity"})
+        if c.get("lists"):
+            out["list_offsets"] = np.arange(0, c["B"] + 1, c["B"] // c["lists"], dtype=np.int64)
         for k, v in sd.items():
             out["sd." + k] = v
         np.savez_compressed(os.path.join(HERE, f"pacrr_{name}.npz"), **out)
@@ -328,14 +354,14 @@ if __name__ == "__main__":
         gen_cedr(CEDR)
     if "convknrm" in which:
         gen_convknrm(CONVKNRM)
-    if "pacrr" in which:
-        gen_pacrr(PACRR)
+    if "pacrr" in which or any(w.startswith("pacrr:") for w in which):
+        gen_pacrr(PACRR, only={w[6:] for w in which if w.startswith("pacrr:")} or None)
     if "knrm" in which or any(w.startswith("knrm:") for w in which):     # "knrm:multiquery" = only that case
         gen_knrm(KNRM, only={w[5:] for w in which if w.startswith("knrm:")} or None)
     if "drmm" in which:
         gen_drmm(DRMM)
-    if "drmmtks" in which:
-        gen_drmmtks(TKS)
+    if "drmmtks" in which or any(w.startswith("drmmtks:") for w in which):
+        gen_drmmtks(TKS, only={w[8:] for w in which if w.startswith("drmmtks:")} or None)
     if "roberta" in which or (which >= {"knrm", "bert", "cedr"}):
         from make_golden_bert import gen_roberta
 

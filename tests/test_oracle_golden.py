@@ -296,17 +296,17 @@ def _tks_oracle(c):
                           c["sd.ffw.0.weight"], c["sd.ffw.0.bias"], c["sd.output_layer.weight"], c["sd.output_layer.bias"])
 
 
-@pytest.mark.parametrize("name", ["default", "top3_short", "ranklist"])
+@pytest.mark.parametrize("name", ["default", "top3_short", "ranklist", "multiquery"])
 def test_drmmtks_oracle_matches_reference(name):
     c = load_case("drmmtks", name)
     got, err = _tks_oracle(c)
     assert err == 0
     assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
-    if name == "ranklist":
+    if name in ("ranklist", "multiquery"):
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
 
 
-@pytest.mark.parametrize("name", ["default", "tanh_noidf_short", "ranklist"])
+@pytest.mark.parametrize("name", ["default", "tanh_noidf_short", "ranklist", "multiquery"])
 def test_pacrr_oracle_matches_reference(name):
     from tests.helpers import pacrr_args
 
@@ -314,7 +314,7 @@ def test_pacrr_oracle_matches_reference(name):
     got, err = oracle.pacrr(c["query"], c["posdoc"], c["query_idf"], oracle.pack(c["emb"]), int(c["D"]), *pacrr_args(c))
     assert err == 0
     assert rel_err(got, c["ref_scores"]).max() <= REL_TOL, (name, rel_err(got, c["ref_scores"]).max())
-    if name == "ranklist":
+    if name in ("ranklist", "multiquery"):
         assert (got.astype(np.float16) == c["ref_scores_f16"]).mean() > 0.98
 
 
