@@ -147,6 +147,27 @@ def test_multiquery_run_matches_the_reference_by_either_route(kind):
             assert np.array_equal(rank_order(g16[a:b]), rank_order(r16[a:b]))
 
 
+def test_drmm_lists_equal_the_per_pair_kernel_on_a_multi_query_run():
+    """DRMM over eight queries' candidate lists with DIFFERENT queries and idf rows (the inputs of the DRMM-TKS multi-query fixture, its OOV
+    query term replaced: DRMM.py:109 cannot take one): the whole-list route - a list scored against its first pair's query and idf row -
+    gives the per-pair kernel's scores and matching histograms bit for bit."""
+    from capreolus_amd.reranker import DRMM
+
+    c = load_case("drmmtks", "multiquery")
+    torch.manual_seed(21)
+    r = DRMM({}, SimpleNamespace(embeddings=c["emb"]))
+    r.build_model().to(DEV).eval()
+    b = _batch(c)
+    b["query"] = b["query"].clone()
+    b["query"][b["query"] < 0] = 17
+    off = c["list_offsets"]
+    with torch.no_grad():
+        pair = r.test(b)
+        got = r.test_lists(b, off)
+    assert torch.equal(pair, got) and torch.isfinite(got).all()
+    assert float(got.std()) > 0       # (the lists' queries do differ: the scores are not one constant)
+
+
 def test_lists_workspace_budget_only_changes_the_grouping(monkeypatch):
     """`engine.LISTS_WORKSPACE_BUDGET` bounds the per-list part of the whole-list workspace (17 B x V per list in flight): with room for a
     single list the library works through the lists one by one - same scores, bit for bit, as with all of them in flight."""
