@@ -204,7 +204,11 @@ __device__ __forceinline__ void pacrr_insert(float (&top)[KM], float v) {
 }
 
 // idf channel + the three linear layers (PACRR.py:48-55); feat = [Q][qts] in LDS
-__device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& ids, float* feat, float* h1, float* h2, int qts, int tid, int b) {
+// `hw` != nullptr: the three layers' weights and biases staged in LDS by the caller (w1 [C][nin] | w2 [C][C] | w3 [C] | b1 [C] | b2 [C] |
+// b3) - one parallel round trip for all of them; from global memory a thread walks its row's weights a few loads at a time, about a dozen
+// dependent round trips per pair during which the workgroup does nothing else.
+__device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& ids, float* feat, float* h1, float* h2, int qts, int tid, int b,
+                                           const float* hw = nullptr) {
   if (a.use_idf && tid == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50)
     const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
     float idf[kPacrrMaxQ];   // (Q <= 8; requested together - clamped index - instead of one dependent load per use: three loops over Q by one thread)
@@ -224,23 +228,46 @@ __device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& id
   }
   __syncthreads();
   const int nin = a.Q * qts;
+  const float *w1 = a.w1, *w2 = a.w2, *w3 = a.w3, *b1 = a.b1, *b2 = a.b2, *b3 = a.b3;
+  if (hw) {
+    w1 = hw;
+    w2 = w1 + a.C * nin;
+    w3 = w2 + a.C * a.C;
+    b1 = w3 + a.C;
+    b2 = b1 + a.C;
+    b3 = b2 + a.C;
+  }
   if (tid < a.C) {
-    float s = a.b1[tid];
-    for (int i = 0; i < nin; ++i) s = __builtin_fmaf(a.w1[tid * nin + i], feat[i], s);
+    float s = b1[tid];
+    for (int i = 0; i < nin; ++i) s = __builtin_fmaf(w1[tid * nin + i], feat[i], s);
     h1[tid] = pacrr_act(s, a.nonlin);
   }
   __syncthreads();
   if (tid < a.C) {
-    float s = a.b2[tid];
-    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w2[tid * a.C + i], h1[i], s);
+    float s = b2[tid];
+    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(w2[tid * a.C + i], h1[i], s);
     h2[tid] = pacrr_act(s, a.nonlin);
   }
   __syncthreads();
   if (tid == 0) {
-    float s = a.b3[0];
-    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(a.w3[i], h2[i], s);
+    float s = b3[0];
+    for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(w3[i], h2[i], s);
     a.out[b] = s;
   }
+}
+
+// floats of the head's weights and biases as pacrr_head wants them staged
+__device__ __forceinline__ int pacrr_head_floats(const PacrrArgs& a, int nin) { return a.C * nin + a.C * a.C + 3 * a.C + 1; }
+__device__ __forceinline__ void pacrr_stage_head(const PacrrArgs& a, int nin, float* hw, int tid) {
+  const int n1 = a.C * nin, n2 = a.C * a.C;
+  for (int i = tid; i < n1; i += kThreads) hw[i] = a.w1[i];
+  for (int i = tid; i < n2; i += kThreads) hw[n1 + i] = a.w2[i];
+  if (tid < a.C) {
+    hw[n1 + n2 + tid] = a.w3[tid];
+    hw[n1 + n2 + a.C + tid] = a.b1[tid];
+    hw[n1 + n2 + 2 * a.C + tid] = a.b2[tid];
+  }
+  if (tid == 0) hw[n1 + n2 + 3 * a.C] = a.b3[0];
 }
 
 // ---- general kernel: fp32 VALU convolutions.  PPL = document positions per lane in the back end (64 * PPL >= L) ----
@@ -548,7 +575,17 @@ __device__ __forceinline__ void pacrr_mfma_body(const PacrrArgs& a, const int b,
     if (tid == 0) a.out[b] = feat[0];
     return;
   }
-  pacrr_head(a, ids, feat, h1, h2, qts, tid, b);
+  // the matrix planes are dead once every wave has its rows' k-max values: the head's weights take their place (when they fit)
+  const float* hw = nullptr;
+  {
+    const int nin = a.Q * qts;
+    if ((size_t)pacrr_head_floats(a, nin) * 4 <= (size_t)LP * 32) {
+      __syncthreads();
+      pacrr_stage_head(a, nin, reinterpret_cast<float*>(s_hi), tid);
+      hw = reinterpret_cast<const float*>(s_hi);
+    }
+  }
+  pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw);
 }
 
 template <int NV, int KM>
