@@ -763,6 +763,33 @@ Workspace carve(char* p, int H, int F, int S, int64_t n_psg_mb, int64_t n_psg_to
   return w;
 }
 
+// Passages per micro-batch of a call over NP passages under the caller's cap (both in passages of S tokens; the loop in encode_passages
+// runs full micro-batches and one remainder).  Two candidates: EQUAL parts (4000 passages under a cap of 256 -> 16 x 250) and FULL parts
+// plus a tail (15 x 256 + 160).  The persistent GEMM kernels hand out whole tiles to num_cus() workgroups (2 num_cus() for the 128-row
+// tile), so a launch takes ceil(tiles / slots) rounds whatever the last round holds: 250 row tiles x 3 column tiles = 750 tiles on 256
+// CUs is 3 rounds for 2.93 rounds of work, in every GEMM of every layer, while 256 row tiles fill every round exactly and only the
+// tail pays.  The cheaper plan by that count wins (rounds weighted by the K of the GEMM); the workspace is sized for the cap either way.
+int64_t plan_microbatch(int64_t NP, int64_t cap, int S, int H, int F) {
+  const int64_t q = tile_passages(S);
+  auto up = [&](int64_t x) { return (x + q - 1) / q * q; };
+  const int64_t n_mb = (NP + cap - 1) / cap;
+  const int64_t equal = up((NP + n_mb - 1) / n_mb), full = up(cap);
+  if (NP <= cap || equal == full) return equal;
+  static const int forced = [] { const char* e = getenv("CAPAMD_BERT_MB_PLAN"); return e ? (e[0] == 'e' ? 1 : e[0] == 'f' ? 2 : 0) : 0; }();   // A/B runs: equal / full
+  if (forced) return forced == 1 ? equal : full;
+  const int64_t cus = num_cus();
+  auto rounds = [&](int64_t rows, int64_t cols, int64_t slots) { return ((rows / 256) * (cols / 256) + slots - 1) / slots; };
+  auto cost_mb = [&](int64_t np) {     // one layer of one micro-batch, in (rounds x K) units
+    const int64_t rows = (up(np) * S + 255) / 256 * 256;
+    return rounds(rows, 3 * H, cus) * H + rounds(rows, H, cus) * (H + F) + rounds(rows, F, cus) * H;
+  };
+  auto cost = [&](int64_t mbp) {
+    const int64_t whole = NP / mbp, rest = NP - whole * mbp;
+    return whole * cost_mb(mbp) + (rest ? cost_mb(rest) : 0);
+  };
+  return cost(full) < cost(equal) ? full : equal;
+}
+
 template <typename T>
 hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_t* seg, int64_t NP, int64_t mb, int S,
                            const capamd_bert_model* m, const Workspace& w, int* status, hipStream_t s, const CedrTap* tap = nullptr) {
@@ -1080,15 +1107,7 @@ int capamd_bert_maxp_forward(const int64_t* ids, const int64_t* mask, const int6
   const int H = m->hidden, F = m->ffn;
   const int64_t NP = (int64_t)B * P;
   if (passages_per_microbatch < 1) return CAPAMD_ERR_ARG;
-  // equal-sized micro-batches (4000 passages at a cap of 256 -> 16 x 250, not 15 x 256 + 160: no ragged last pass)
-  const int64_t n_mb = (NP + passages_per_microbatch - 1) / passages_per_microbatch;
-  int64_t mb = (NP + n_mb - 1) / n_mb;
-  // rows of a micro-batch in multiples of 256 where the passage length allows it: the 256x256-tile GEMM kernels (and the
-  // folded-LayerNorm path) need M % 256 == 0; only the last micro-batch of a call may then fall back to the small tiles
-  {
-    const int64_t q = tile_passages(S);
-    mb = (mb + q - 1) / q * q;
-  }
+  const int64_t mb = plan_microbatch(NP, passages_per_microbatch, S, H, F);
   if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
@@ -1119,12 +1138,7 @@ int capamd_cedr_passage_features(const int64_t* ids, const int64_t* mask, const 
     if (simmat_layers[i] < 0 || simmat_layers[i] > m->layers) return CAPAMD_ERR_ARG;
   const int H = m->hidden, F = m->ffn;
   const int64_t NP = (int64_t)B * P;
-  const int64_t n_mb = (NP + passages_per_microbatch - 1) / passages_per_microbatch;
-  int64_t mb = (NP + n_mb - 1) / n_mb;
-  {
-    const int64_t q = tile_passages(S);
-    mb = (mb + q - 1) / q * q;
-  }
+  const int64_t mb = plan_microbatch(NP, passages_per_microbatch, S, H, F);
   if ((int64_t)ws_bytes_for(H, F, S, mb, NP) > workspace_bytes) return CAPAMD_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return CAPAMD_ERR_ALIGN;
   if (cedr_pool_smem(S, maxqlen + 1) > 160 * 1024) return CAPAMD_ERR_ARG;

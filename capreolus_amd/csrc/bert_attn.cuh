@@ -154,7 +154,11 @@ __device__ __forceinline__ float softmax_pack(const f32x16 (&sc)[NT], typename H
     for (int s2 = 0; s2 < 2; ++s2) {
       float x[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][8 * s2 + e], kLog2e, nb));
+      for (int e = 0; e < 8; e += 2) {   // (s log2e - m log2e) for two scores per v_pk_fma_f32: the same fma per element, half the issue slots
+        const f32x2 y = f32x2{sc[t][8 * s2 + e], sc[t][8 * s2 + e + 1]} * f32x2{kLog2e, kLog2e} + f32x2{nb, nb};
+        x[e] = __builtin_amdgcn_exp2f(y.x);
+        x[e + 1] = __builtin_amdgcn_exp2f(y.y);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         part[e & 3] += x[e];

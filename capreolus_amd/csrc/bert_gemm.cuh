@@ -50,12 +50,21 @@ struct Half<__bf16> {
   typedef __attribute__((ext_vector_type(8))) __bf16 x8;
   typedef __attribute__((ext_vector_type(4))) __bf16 x4;
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  // the two values of one packed register as fp32 (a shift and a mask: bf16 is the upper half of an fp32)
+  static __device__ __forceinline__ __attribute__((ext_vector_type(2))) float unpack2(unsigned u) {
+    return {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+  }
 };
 template <>
 struct Half<_Float16> {
   typedef __attribute__((ext_vector_type(8))) _Float16 x8;
   typedef __attribute__((ext_vector_type(4))) _Float16 x4;
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ __attribute__((ext_vector_type(2))) float unpack2(unsigned u) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 h = __builtin_bit_cast(h2, u);
+    return {(float)h.x, (float)h.y};
+  }
 };
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -122,18 +131,25 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 //   gelu(x) = max(x, 0) - 0.5 |x| 2^P(|x|)         (erf odd; the polynomial below is in |x| = z sqrt2 directly)
 // fp32 evaluation error of the whole expression < 1.2e-6 absolute for any x: three orders below the 16-bit rounding
 // applied to the result (2^-11 relative for fp16, 2^-8 for bf16).  tests/test_gpu_bert.py::test_gemm_gelu pins it.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  const f32x2 ax = {__builtin_fminf(__builtin_fabsf(x.x), 12.f), __builtin_fminf(__builtin_fabsf(x.y), 12.f)};
-  f32x2 p = ax * -5.1971009666e-04f + 7.3937495955e-03f;
-  p = p * ax + -5.2555056596e-02f;
-  p = p * ax + -4.5925845106e-01f;
-  p = p * ax + -1.1510906938e+00f;
-  p = p * ax;
+//
+// The argument is h = x / 2 (the epilogues fold the 1/2 into the affine form that produces x: a power of two, exact):
+//   max(x, 0) = h + |h| exactly, 0.5 |x| = |h|, and P(|x|) evaluated by Horner in |h| with the coefficients scaled by 2, 4, ... 32
+//   has every intermediate an exact power-of-two multiple of the Horner chain in |x| - the same bits as the form in x, with
+//   per PAIR of values 2 v_and (|h|), 4 v_pk_fma + 1 v_pk_mul, 2 v_exp, 1 v_pk_add, 1 v_pk_fma: 11 issue slots where the form in x needed
+//   15 (its two v_max, its 0.5 |x| product, and a clamp of |x| the polynomial does not need: its leading coefficient is
+//   negative, P(|x|) < -147 beyond |x| = 12 and falls monotonically from there, so 2^P underflows to 0 by itself).
+__device__ __forceinline__ f32x2 gelu_erf_half2(f32x2 h) {
+  const f32x2 ah = {__builtin_fabsf(h.x), __builtin_fabsf(h.y)};
+  f32x2 p = ah * (32.f * -5.1971009666e-04f) + (16.f * 7.3937495955e-03f);
+  p = p * ah + (8.f * -5.2555056596e-02f);
+  p = p * ah + (4.f * -4.5925845106e-01f);
+  p = p * ah + (2.f * -1.1510906938e+00f);
+  p = p * ah;
   const f32x2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
-  const f32x2 r = {__builtin_fmaxf(x.x, 0.f), __builtin_fmaxf(x.y, 0.f)};
-  const f32x2 hax = {__builtin_fabsf(x.x) * 0.5f, __builtin_fabsf(x.y) * 0.5f};
-  return r - hax * e;
+  const f32x2 r = h + ah;
+  return r - ah * e;
 }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) { return gelu_erf_half2(x * 0.5f); }
 
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }   // 128-byte rows (attention K tile)
 __device__ __forceinline__ int swz_chunk4(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }  // 64-byte rows (GEMM half regions)
@@ -351,40 +367,33 @@ struct GemmKernel {
       bias_t[i] = TRANS ? a.bias[n0 + L.wn * WNT + i * 32 + L.l31] : 0.f;
       cs_t[i] = (TRANS && a.ln_mu) ? a.ln_cs[n0 + L.wn * WNT + i * 32 + L.l31] : 0.f;
     }
+    // (one straight-line form: without folded LayerNorm mu = 0, rstd = 1 and the cs vector is never dereferenced - the row statistics
+    // are then the neutral pair, and rstd (acc - 0 cs) + b is acc + b exactly; a run-time branch per 4 values cost more than it saved)
+    const bool ln = a.ln_mu != nullptr;
+    const bool q_tile = (EPI == kEpiQkv) && !TRANS && n0 < a.H;   // 1/sqrt(head_dim = 64) folded into Q (exact in 16 bits)
+    const float es = q_tile ? 0.125f : 1.f;
     auto finish = [&](int i, int j, int g4, float (&v)[4]) {
-      float4 b4;
-      if (TRANS) {
-        const float b = bias_t[i];
-        b4 = make_float4(b, b, b, b);
-      } else {
-        b4 = *reinterpret_cast<const float4*>(a.bias + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
-      }
-      if (a.ln_mu) {  // A was an un-normalised pre-LayerNorm sum: rstd_m (acc - mu_m cs_n) + c_n
-        if (TRANS) {    // registers <-> 4 consecutive rows m, lane <-> n
+      if (TRANS) {    // registers <-> 4 consecutive rows m, lane <-> n
+        const float b = bias_t[i], cs = cs_t[i];
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ln) {
           const int mrow = m0 + L.wm * WMT + j * 32 + 8 * g4 + 4 * L.half;
-          const float4 mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow), rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
-          const float cs = cs_t[i];
-          v[0] = rs.x * (acc[i][j][g4 * 4 + 0] - mu.x * cs) + b4.x;
-          v[1] = rs.y * (acc[i][j][g4 * 4 + 1] - mu.y * cs) + b4.y;
-          v[2] = rs.z * (acc[i][j][g4 * 4 + 2] - mu.z * cs) + b4.z;
-          v[3] = rs.w * (acc[i][j][g4 * 4 + 3] - mu.w * cs) + b4.w;
-        } else {        // lane <-> row m, registers <-> 4 consecutive n
-          const float mu = mr_row[j].x, rs = mr_row[j].y;
-          const float4 cs = *reinterpret_cast<const float4*>(a.ln_cs + n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half);
-          v[0] = rs * (acc[i][j][g4 * 4 + 0] - mu * cs.x) + b4.x;
-          v[1] = rs * (acc[i][j][g4 * 4 + 1] - mu * cs.y) + b4.y;
-          v[2] = rs * (acc[i][j][g4 * 4 + 2] - mu * cs.z) + b4.z;
-          v[3] = rs * (acc[i][j][g4 * 4 + 3] - mu * cs.w) + b4.w;
+          mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow);
+          rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
         }
-      } else {
-        v[0] = acc[i][j][g4 * 4 + 0] + b4.x;
-        v[1] = acc[i][j][g4 * 4 + 1] + b4.y;
-        v[2] = acc[i][j][g4 * 4 + 2] + b4.z;
-        v[3] = acc[i][j][g4 * 4 + 3] + b4.w;
-      }
-      if (EPI == kEpiQkv && n0 < a.H) {  // 1/sqrt(head_dim = 64) folded into Q (exact in bf16)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= 0.125f;
+        v[0] = rs.x * (acc[i][j][g4 * 4 + 0] - mu.x * cs) + b;
+        v[1] = rs.y * (acc[i][j][g4 * 4 + 1] - mu.y * cs) + b;
+        v[2] = rs.z * (acc[i][j][g4 * 4 + 2] - mu.z * cs) + b;
+        v[3] = rs.w * (acc[i][j][g4 * 4 + 3] - mu.w * cs) + b;
+      } else {        // lane <-> row m, registers <-> 4 consecutive n
+        const int n = n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half;
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+        const float4 cs = *reinterpret_cast<const float4*>((ln ? a.ln_cs : a.bias) + n);
+        const float mu = mr_row[j].x, rs = mr_row[j].y * es;
+        v[0] = rs * (acc[i][j][g4 * 4 + 0] - mu * cs.x) + b4.x * es;
+        v[1] = rs * (acc[i][j][g4 * 4 + 1] - mu * cs.y) + b4.y * es;
+        v[2] = rs * (acc[i][j][g4 * 4 + 2] - mu * cs.z) + b4.z * es;
+        v[3] = rs * (acc[i][j][g4 * 4 + 3] - mu * cs.w) + b4.w * es;
       }
       if (EPI == kEpiBiasGeluBf16) {
         const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
@@ -594,10 +603,16 @@ struct CmEpilogue {
       if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
       else scale = 0.125f;  // 1/sqrt(head_dim = 64) folded into Q (exact in 16-bit)
     }
+    // a power of two applied to the result - Q / 8, and the 1/2 of the GELU's half-argument form (gelu_erf_half2) - is folded into the
+    // affine form's row scale and column constant: es (rstd (acc - mu cs) + c) = (es rstd)(acc - mu cs) + es c, bit for bit
+    const float es = EPI == kEpiBiasGeluBf16 ? 0.5f : scale;
     const bool ln = a.ln_mu != nullptr;
     float2 mr[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) mr[j] = ln ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
+    for (int j = 0; j < TM; ++j) {
+      mr[j] = ln ? a.ln_mr[m0 + L.wm * WMT + j * 32 + L.l31] : make_float2(0.f, 1.f);
+      mr[j].y *= es;
+    }
     // The column vectors of 32-column group i+1 are fetched BEFORE the stores of group i are issued: VMEM operations retire in order,
     // so a load issued behind 32 stores would wait for all of them (with one wave per SIMD - the ring kernel - nothing hides that).
     float4 b4s[2][4], cs4s[2][4];
@@ -624,7 +639,12 @@ struct CmEpilogue {
         pin_acc(acc[i]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const float4 (&b4)[4] = b4s[i & 1];
+      float4 b4[4];   // (scaled at the point of use, once per column group: the prefetched vectors are not touched before they are needed)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        b4[g4] = b4s[i & 1][g4];
+        if (EPI == kEpiBiasGeluBf16 || EPI == kEpiQkv) { b4[g4].x *= es; b4[g4].y *= es; b4[g4].z *= es; b4[g4].w *= es; }
+      }
       const float4 (&cs4)[4] = cs4s[i & 1];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
@@ -633,15 +653,11 @@ struct CmEpilogue {
         unsigned pk[4][2];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          // rstd_m (acc - mu_m cs_n) + c_n ; with mu = 0, rstd = 1 this is acc + bias exactly
+          // es (rstd_m (acc - mu_m cs_n) + c_n) ; with mu = 0, rstd = 1, es = 1 this is acc + bias exactly
           float v[4] = {rs * (acc[i][j][g4 * 4 + 0] - mu * cs4[g4].x) + b4[g4].x, rs * (acc[i][j][g4 * 4 + 1] - mu * cs4[g4].y) + b4[g4].y,
                         rs * (acc[i][j][g4 * 4 + 2] - mu * cs4[g4].z) + b4[g4].z, rs * (acc[i][j][g4 * 4 + 3] - mu * cs4[g4].w) + b4[g4].w};
-          if (EPI == kEpiQkv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= scale;
-          }
-          if (EPI == kEpiBiasGeluBf16) {
-            const f32x2 g0 = gelu_erf2(f32x2{v[0], v[1]}), g1 = gelu_erf2(f32x2{v[2], v[3]});
+          if (EPI == kEpiBiasGeluBf16) {   // v = x / 2
+            const f32x2 g0 = gelu_erf_half2(f32x2{v[0], v[1]}), g1 = gelu_erf_half2(f32x2{v[2], v[3]});
             v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
           }
           const bf16x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
@@ -663,43 +679,50 @@ struct CmEpilogue {
 
   // kEpiResidStats: the pre-LayerNorm sum of a residual block, chunk-major, with the LayerNorm of the block's input
   // re-computed on the fly and the row statistics of the result collected for the next LayerNorm:
-  //     P[m][n] = acc + bias'[n] + (R[m][n] - rmu_m) rrstd_m rgamma_n           (bias' = b + rbeta, folded when packed)
+  //     P[m][n] = acc + bias'[n] + (R[m][n] rrstd_m - rmu_m rrstd_m) rgamma_n       (bias' = b + rbeta, folded when packed)
   //     stat_part[m][n0/64 + wn] = (sum_n P, sum_n P^2) over this wave's 64 columns, of the ROUNDED values the consumers
-  //     will read.  fp32 sum, one rounding; the residual is read with coalesced 8-byte loads at the positions the lane's
-  //     own values will occupy (chunk-major), so no LDS and no transposition is involved.
+  //     will read.  fp32 sum, one rounding.
+  // Everything up to the rounding happens where the accumulator layout put the value: a lane owns, of each 8-column chunk of its
+  // row, the 4 columns 4 half .. 4 half + 3, so it reads the residual as 8-byte pieces at those positions (the lane pair of a row
+  // reads 16 adjacent bytes) and the column vectors as float4 at the same columns.  Only the ROUNDED result changes lanes - two
+  // v_permlane32_swap per 8-column chunk pair on packed registers, as in epilogue_cm (round 4 exchanged the fp32 accumulators
+  // first: one swap, with its two hazard no-ops, per value pair).  The arithmetic per PAIR of values is packed throughout:
+  // 1 v_pk_fma (r rrstd - mu rrstd), 1 v_pk_add (acc + bias'), 1 v_pk_fma (. gamma +), 1 v_cvt_pk, 1 v_pk_add + 1 v_pk_fma (statistics)
+  // beside the two 16-bit -> fp32 expansions of the residual and of the rounded result.
   static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x16 (&acc)[TN][TM]) {
     T* base = static_cast<T*>(a.out_bf16);
     const T* rsrc = static_cast<const T*>(a.res_src);
     const int nchunks = a.N >> 3, nloc = n0 + L.wn * WNT, nslot = a.N >> 6;
-    float2 mr[TM];
-    float s1[TN / 2][TM], s2[TN / 2][TM];     // per 64-column slot of the wave's WNT columns
+    float rrs[TM], rc[TM];                      // per row: rrstd and -rmu rrstd
+    f32x2 s1[TN / 2][TM], s2[TN / 2][TM];       // per 64-column slot of the wave's WNT columns: (even, odd) element partial sums
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      mr[j] = a.res_mr[m0 + L.wm * WMT + j * 32 + L.l31];
+      const float2 mr = a.res_mr[m0 + L.wm * WMT + j * 32 + L.l31];
+      rrs[j] = mr.y;
+      rc[j] = -mr.x * mr.y;
 #pragma unroll
-      for (int sl = 0; sl < TN / 2; ++sl) s1[sl][j] = s2[sl][j] = 0.f;
+      for (int sl = 0; sl < TN / 2; ++sl) s1[sl][j] = s2[sl][j] = f32x2{0.f, 0.f};
     }
     // Operands are fetched one step AHEAD of their use and before the stores of the step in between are issued (in-order retirement of
-    // VMEM operations, see epilogue_cm): the column vectors (bias', gamma) of 32-column group i+1 during group i, the residual chunks
-    // of row block (i, j+1) during (i, j).  kPipe = false (8-wave kernel): everything inside its own step, as before.
-    float4 bbs[2][2][2], ggs[2][2][2];
-    bf16x8 r8s[2][2];
+    // VMEM operations, see epilogue_cm): the column vectors (bias', gamma) of 32-column group i+1 during group i, the residual pieces
+    // of row block (i, j+1) during (i, j).  kPipe = false (two waves per SIMD): everything inside its own step.
+    float4 bbs[2][4], ggs[2][4];
+    bf16x4 r4s[2][4];
     auto load_cols = [&](int i, int buf) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int n = n0 + L.wn * WNT + i * 32 + (2 * p + L.half) * 8;
-        bbs[buf][p][0] = *reinterpret_cast<const float4*>(a.bias + n); bbs[buf][p][1] = *reinterpret_cast<const float4*>(a.bias + n + 4);
-        ggs[buf][p][0] = *reinterpret_cast<const float4*>(a.res_gamma + n); ggs[buf][p][1] = *reinterpret_cast<const float4*>(a.res_gamma + n + 4);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + L.wn * WNT + i * 32 + 8 * g4 + 4 * L.half;
+        bbs[buf][g4] = *reinterpret_cast<const float4*>(a.bias + n);
+        ggs[buf][g4] = *reinterpret_cast<const float4*>(a.res_gamma + n);
       }
     };
     auto load_res = [&](int t, int buf) {   // t = i * TM + j
       const int i = t / TM, j = t % TM;
       const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
+      // (one address per step: the four chunks of a 32-column group are 512 bytes apart - immediate offsets)
+      const T* rp = rsrc + ((mblk * nchunks + ((nloc + i * 32) >> 3)) * 32 + L.l31) * 8 + 4 * L.half;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
-        r8s[buf][p] = *reinterpret_cast<const bf16x8*>(rsrc + ((mblk * nchunks + chunk) * 32 + L.l31) * 8);
-      }
+      for (int g4 = 0; g4 < 4; ++g4) r4s[buf][g4] = *reinterpret_cast<const bf16x4*>(rp + g4 * 256);
     };
     if (kPipe) { load_cols(0, 0); load_res(0, 0); }
 #pragma unroll
@@ -711,9 +734,8 @@ struct CmEpilogue {
         pin_acc(acc[i]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // after the exchange below this lane owns chunks 2p + half (p = 0, 1) of the 32 columns of tile i: 8 consecutive n each
-      const float4 (&bb)[2][2] = bbs[i & 1];
-      const float4 (&gg)[2][2] = ggs[i & 1];
+      const float4 (&bb)[4] = bbs[i & 1];
+      const float4 (&gg)[4] = ggs[i & 1];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int t = i * TM + j;
@@ -724,35 +746,34 @@ struct CmEpilogue {
           __builtin_amdgcn_sched_barrier(0);
         }
         const int64_t mblk = (m0 + L.wm * WMT + j * 32) >> 5;
-        const float rmu = mr[j].x, rrs = mr[j].y;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const uint2 ru = __builtin_bit_cast(uint2, r4s[t & 1][g4]);
+          const f32x2 rr = {rrs[j], rrs[j]}, cc = {rc[j], rc[j]};
+          const f32x2 b01 = {bb[g4].x, bb[g4].y}, b23 = {bb[g4].z, bb[g4].w}, g01 = {gg[g4].x, gg[g4].y}, g23 = {gg[g4].z, gg[g4].w};
+          const f32x2 v01 = f32x2{acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1]} + b01, v23 = f32x2{acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]} + b23;
+          const f32x2 t01 = Half<T>::unpack2(ru.x) * rr + cc, t23 = Half<T>::unpack2(ru.y) * rr + cc;
+          const f32x2 o01 = t01 * g01 + v01, o23 = t23 * g23 + v23;             // fp32 sum, ONE rounding
+          const bf16x4 o = {(T)o01.x, (T)o01.y, (T)o23.x, (T)o23.y};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          pk[g4][0] = u.x; pk[g4][1] = u.y;
+        }
+        T* op = base + ((mblk * nchunks + ((nloc + i * 32) >> 3) + L.half) * 32 + L.l31) * 8;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          // fp32 exchange: lanes 32..63 of the first operand <-> lanes 0..31 of the second.  Afterwards the lower lane holds
-          // chunk 2p (n 0..3 its own, 4..7 from the upper lane), the upper lane chunk 2p+1, both as v[0..7] in order
-          float v[8];
+          // the lower lane collects chunk 2p (its own 4 values + the upper lane's), the upper lane chunk 2p+1
+          swap32(pk[2 * p][0], pk[2 * p + 1][0]);
+          swap32(pk[2 * p][1], pk[2 * p + 1][1]);
+          *reinterpret_cast<uint4*>(op + p * 512) = make_uint4(pk[2 * p][0], pk[2 * p][1], pk[2 * p + 1][0], pk[2 * p + 1][1]);
+          // statistics of what the consumers will read, from the registers as stored (the exchange only moved values between the two
+          // lanes of a row, whose sums are added below: reading them before it would need a copy of every register it overwrites)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // (element -> named float -> bits: __builtin_bit_cast applied directly to a vector element picked element 0 every time)
-            const float fx = acc[i][j][(2 * p) * 4 + e], fy = acc[i][j][(2 * p + 1) * 4 + e];
-            unsigned x = __float_as_uint(fx), y = __float_as_uint(fy);
-            swap32(x, y);
-            v[e] = __uint_as_float(x);
-            v[4 + e] = __uint_as_float(y);
-          }
-          const int chunk = ((nloc + i * 32) >> 3) + 2 * p + L.half;
-          const int64_t off = ((mblk * nchunks + chunk) * 32 + L.l31) * 8;
-          const bf16x8 r8 = r8s[t & 1][p];
-          const float bv[8] = {bb[p][0].x, bb[p][0].y, bb[p][0].z, bb[p][0].w, bb[p][1].x, bb[p][1].y, bb[p][1].z, bb[p][1].w};
-          const float gv[8] = {gg[p][0].x, gg[p][0].y, gg[p][0].z, gg[p][0].w, gg[p][1].x, gg[p][1].y, gg[p][1].z, gg[p][1].w};
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] = (T)(v[e] + bv[e] + ((float)r8[e] - rmu) * rrs * gv[e]);   // fp32 sum, ONE rounding
-            const float q = (float)o[e];                                    // statistics of what the consumers will read
+          for (int k = 0; k < 4; ++k) {
+            const f32x2 q = Half<T>::unpack2(pk[2 * p + (k >> 1)][k & 1]);
             s1[i >> 1][j] += q;
-            s2[i >> 1][j] = __builtin_fmaf(q, q, s2[i >> 1][j]);
+            s2[i >> 1][j] = q * q + s2[i >> 1][j];
           }
-          *reinterpret_cast<bf16x8*>(base + off) = o;
         }
       }
     }
@@ -761,7 +782,8 @@ struct CmEpilogue {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         // the two lanes of a row hold its 2 x 32 columns: add them and let the lower lane write the wave's partial
-        const float t1 = s1[sl][j] + __shfl_xor(s1[sl][j], 32, 64), t2 = s2[sl][j] + __shfl_xor(s2[sl][j], 32, 64);
+        const float p1 = s1[sl][j].x + s1[sl][j].y, p2 = s2[sl][j].x + s2[sl][j].y;
+        const float t1 = p1 + __shfl_xor(p1, 32, 64), t2 = p2 + __shfl_xor(p2, 32, 64);
         const int mrow = m0 + L.wm * WMT + j * 32 + L.l31;
         if (L.half == 0)
           *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + ((n0 + L.wn * WNT) >> 6) + sl) * 2) = make_float2(t1, t2);

@@ -130,18 +130,15 @@ struct GemmRing {
       const bool more = G::tile_of(g, it + 1, m1, n1);
       if (!more) { m1 = 0; n1 = 0; }                  // nothing follows: the run-ahead LDS-DMAs re-read the first tile's slices (never consumed)
       const Bases nxt = bases_of(g, m1, n1, L.wave);
+      // (no zero fill: the first k-slice of a tile issues its MFMAs with the inline constant 0 as the C operand - every accumulator is
+      // written exactly once per slice - instead of 128 / 256 register writes per tile ahead of the K loop; same bits: 0 + a b)
       f32x16 acc[4][TM];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       const bool trans = (EPI == kEpiQkv) && n0 >= 2 * g.H;
-      // one k-slice; U = which fragment set holds the slice, VM = outstanding VMEM operations allowed at its top; s = its index in the tile
-      auto kslice = [&](auto u_c, auto vm_c, auto tr_c, int s) {
+      // one k-slice; U = which fragment set holds the slice, VM = outstanding VMEM operations allowed at its top; s = its index in the
+      // tile; FIRST: slice 0 of the tile (the accumulators start here)
+      auto kslice = [&](auto u_c, auto vm_c, auto tr_c, int s, auto first_c) {
         constexpr int cu = decltype(u_c)::value, nx = cu ^ 1, VM = decltype(vm_c)::value;
-        constexpr bool TR = decltype(tr_c)::value;
+        constexpr bool TR = decltype(tr_c)::value, FIRST = decltype(first_c)::value;
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(VM, 0));   // (the builtin, not inline asm: the compiler's own waitcnt pass then knows the
         __builtin_amdgcn_s_barrier();                      // fragment registers are ready and adds no waits of its own in the slice)
         const int nslot = slot_off + kSlot == kRing ? 0 : slot_off + kSlot;
@@ -155,7 +152,12 @@ struct GemmRing {
         for (int p = 0; p < P; ++p) soff[p] = (own ? cur.off[p] : nxt.off[p]) + so;
         auto M = [&](int idx) {
           const int i = idx / TM, j = idx % TM;
-          acc[i][j] = TR ? Half<T>::mfma(fa[cu][j], fb[cu][i], acc[i][j]) : Half<T>::mfma(fb[cu][i], fa[cu][j], acc[i][j]);
+          f32x16 c;
+          if constexpr (FIRST) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+          } else c = acc[i][j];
+          acc[i][j] = TR ? Half<T>::mfma(fa[cu][j], fb[cu][i], c) : Half<T>::mfma(fb[cu][i], fa[cu][j], c);
         };
         auto R = [&](int q) {
           if (CAPAMD_RING_ABLATE & 2) return;
@@ -194,16 +196,21 @@ struct GemmRing {
       using U1 = std::integral_constant<int, 1>;
       using VS = std::integral_constant<int, kVm>;
       using VE = std::integral_constant<int, kVm + kEpiVmem>;
+      using F0 = std::false_type;
+      using F1 = std::true_type;
+      static_assert(kHead >= 2, "the first slice pair of a tile is peeled off the head loop");
       auto tile_loop = [&](auto tr_c) {
         if (after_epilogue) {
+          kslice(U0{}, VE{}, tr_c, 0, F1{}); kslice(U1{}, VE{}, tr_c, 1, F0{});
 #pragma unroll 1
-          for (int s = 0; s < kHead; s += 2) { kslice(U0{}, VE{}, tr_c, s); kslice(U1{}, VE{}, tr_c, s + 1); }
+          for (int s = 2; s < kHead; s += 2) { kslice(U0{}, VE{}, tr_c, s, F0{}); kslice(U1{}, VE{}, tr_c, s + 1, F0{}); }
         } else {
+          kslice(U0{}, VS{}, tr_c, 0, F1{}); kslice(U1{}, VS{}, tr_c, 1, F0{});
 #pragma unroll 1
-          for (int s = 0; s < kHead; s += 2) { kslice(U0{}, VS{}, tr_c, s); kslice(U1{}, VS{}, tr_c, s + 1); }
+          for (int s = 2; s < kHead; s += 2) { kslice(U0{}, VS{}, tr_c, s, F0{}); kslice(U1{}, VS{}, tr_c, s + 1, F0{}); }
         }
 #pragma unroll 1
-        for (int s = kHead; s < S; s += 2) { kslice(U0{}, VS{}, tr_c, s); kslice(U1{}, VS{}, tr_c, s + 1); }
+        for (int s = kHead; s < S; s += 2) { kslice(U0{}, VS{}, tr_c, s, F0{}); kslice(U1{}, VS{}, tr_c, s + 1, F0{}); }
       };
       if (trans) tile_loop(std::true_type{});
       else tile_loop(std::false_type{});

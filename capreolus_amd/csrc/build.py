@@ -4,6 +4,9 @@
     libcapreolus_amd_prof.so   the same objects, with the sources that carry profiling hooks (csrc/capamd_profiling.h) compiled
                                once more with -DCAPAMD_PROFILING - bound by bench.py's per-pass timing legs and scripts/ only
                                (capreolus_amd._lib.profiling_build())
+    libcapamd_pyhost.so        pyhost.c: the CPython helper that turns a run's fp16 score vector into the {qid: {docid: score}}
+                               dictionaries `predict` returns (gcc against the interpreter's headers; no device code, not part of the
+                               C-ABI; capreolus_amd/pyhost.py)
 
 Incremental: an object is rebuilt when its source or anything in its depfile (-MMD) is newer than it.
 """
@@ -16,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libcapreolus_amd.so")
 OUT_PROF = os.path.join(HERE, "libcapreolus_amd_prof.so")
+OUT_PYHOST = os.path.join(HERE, "libcapamd_pyhost.so")
+PYHOST_SRC = os.path.join(HERE, "pyhost.c")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + HERE]
 PROF_SOURCES = ("bert.hip", "lists.hip", "pacrr.hip")     # sources whose code differs under -DCAPAMD_PROFILING
 
@@ -57,7 +62,20 @@ def stale():
         os.path.getmtime(o) > min(os.path.getmtime(OUT), os.path.getmtime(OUT_PROF)) for _, o, _ in _jobs() if os.path.exists(o))
 
 
+def build_pyhost(force=False, verbose=False):
+    import sysconfig
+
+    if not force and os.path.exists(OUT_PYHOST) and os.path.getmtime(OUT_PYHOST) >= os.path.getmtime(PYHOST_SRC):
+        return OUT_PYHOST
+    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], PYHOST_SRC, "-o", OUT_PYHOST]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT_PYHOST
+
+
 def build(force=False, verbose=False):
+    build_pyhost(force, verbose)
     if not force and not stale():
         return OUT
     procs = []

@@ -360,6 +360,10 @@ class BertEngine:
             q = 256 // math.gcd(S, 256)                      # passages per whole 256-row GEMM tile
             ns = max(1, min(self.n_streams, NP // self.microbatch))
             per = (NP // ns + q - 1) // q * q if ns > 1 else NP   # passages per stream, in whole tiles
+            if ns > 1 and NP // ns >= 4 * self.microbatch and S == 256:
+                # long runs: cut at whole micro-batches, so that every stream but the last runs FULL micro-batches only (whole rounds of
+                # GEMM tiles on every CU, bert.hip: plan_microbatch) and one tail exists per call, not one per stream
+                per = (NP // ns + self.microbatch - 1) // self.microbatch * self.microbatch
             cuts = [min(NP, k * per) for k in range(ns)] + [NP]
             if ns < 2 or cuts[-2] >= NP:
                 plog = torch.empty(NP, dtype=torch.float32, device=ids.device) if return_passage_logits else None

@@ -98,7 +98,11 @@ class PytorchTrainer:
         # distinct query / document id rows as int32 tables (capreolus_amd.feeder.CandidateStore); that call and every later one on the
         # same sampler (the dev set after every training iteration, RerankTask's repeated predict) score it by index pairs without
         # touching the host per sample (SURVEY.md row N1 through the reference's own call site, trainer/pytorch.py:310-353).
-        "resident": True, "resident_verify": "sampled",
+        # `resident_verify`: how a later call recognises that the sampler still holds what the store was built from.  "auto" (default):
+        # up to 100,000 pairs every docid of every list is compared with the plan's own copy (0.2 ms per 64,000 - an in-place edit of a
+        # candidate list cannot go unnoticed), above that "sampled" (the list objects' identities, sizes and eight docids each); "full"
+        # hashes every docid at any size.
+        "resident": True, "resident_verify": "auto",
         # `lists`: which rerankers the resident route scores as whole candidate lists (csrc/lists.hip: every distinct term of a LIST
         # gathered once).  "always" (default): every reranker that takes lists - KNRM, DRMM, DRMM-TKS, PACRR; this is the route
         # `bench.py` times.  DRMM / DRMM-TKS / PACRR list scores equal their per-pair scores bit for bit; KNRM's pooling sums run in
@@ -150,8 +154,8 @@ class PytorchTrainer:
             raise ValueError("amp must be one of: None, train, pred, both")
         if c["decaytype"] not in (None, "exponential", "linear"):
             raise ValueError("decaytype must be one of: None, exponential, linear")
-        if c["resident_verify"] not in ("sampled", "full"):
-            raise ValueError("resident_verify must be one of: sampled, full")
+        if c["resident_verify"] not in ("auto", "sampled", "full"):
+            raise ValueError("resident_verify must be one of: auto, sampled, full")
         if c["lists"] not in ("exact", "always", "never"):
             raise ValueError("lists must be one of: exact, always, never")
         torch.manual_seed(c["seed"])
@@ -482,11 +486,24 @@ class PytorchTrainer:
         if not isinstance(q2d, dict) or not q2d:
             return None
         try:
-            if self.config["resident_verify"] == "full":
+            if self.config["resident_verify"] == "full":      # ("auto" adds its element-wise comparison in _plan_still_mirrors)
                 return (len(q2d), hash(tuple((q, tuple(d)) for q, d in q2d.items())))
             return (len(q2d), hash(tuple((q, len(d), id(d)) + tuple(d[:: max(1, (len(d) - 1) // 7)]) + (d[-1],) if len(d) else (q, 0) for q, d in q2d.items())))
         except TypeError:
             return None
+
+    def _plan_still_mirrors(self, pred_data, plan):
+        """resident_verify = "auto": the element-wise check of a plan whose lists were, when it was built, exactly the sampler's
+        `qid_to_docids` lists (the PredSampler contract) and hold at most 100,000 pairs - tuple(list) == the plan's tuple, an identity
+        comparison per docid.  Other plans rest on the sampled fingerprint alone."""
+        extra = plan[4]
+        if self.config["resident_verify"] != "auto" or not extra.get("mirrors_q2d") or int(extra["offsets"][-1]) > 100000:
+            return True
+        q2d = pred_data.qid_to_docids
+        try:
+            return all(tuple(q2d[q]) == ds for q, ds, _ in plan[3])
+        except (KeyError, TypeError):
+            return False
 
     def forget_candidate_stores(self):
         """Drops the device-resident candidate stores `predict` built (the next call on a sampler tokenises and uploads it again)."""
@@ -504,7 +521,7 @@ class PytorchTrainer:
         plans = self.__dict__.setdefault("_resident_plans", {})
         key = (id(pred_data), rank, world, str(self.device))
         hit = plans.get(key)
-        if hit is not None and hit[0] == fp and hit[1]() is pred_data:
+        if hit is not None and hit[0] == fp and hit[1]() is pred_data and self._plan_still_mirrors(pred_data, hit[2]):
             return hit[2]
         store, pq, pd, groups = CandidateStore(self.device), [], [], []
         for sample in part:           # the same walk the DataLoader would do - once
@@ -539,6 +556,9 @@ class PytorchTrainer:
                 # samples (then the predictions are one dict(zip(...)) per query)
                 {"counts": counts, "offsets": np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))]).astype(np.int64),
                  "one_run_per_qid": len({q for q, _, _ in groups}) == len(groups)})
+        q2d = pred_data.qid_to_docids
+        # (the lists this rank scores ARE the sampler's lists, docid for docid: what lets later calls compare them element-wise)
+        plan[4]["mirrors_q2d"] = plan[4]["one_run_per_qid"] and all(q in q2d and tuple(q2d[q]) == ds for q, ds, _ in plan[3])
         # runs of at least 16 lists and 16,000 pairs are scored in two (from 32 lists and 32,000 pairs: four) parts of about equal size
         # (predict overlaps a part's kernels with the dict building of the parts before it); the pinned buffer the fp16 scores come back
         # in is kept with the plan
@@ -666,7 +686,7 @@ class PytorchTrainer:
         if count > 0 and self.config["resident"] and self.device.type == "cuda" and getattr(reranker, "supports_resident", False):
             plan = self._resident_plan(pred_data, part, rank, world)
         if plan is not None:
-            from .. import engine
+            from .. import engine, pyhost
 
             store, pq, pd, groups, extra = plan
             step = max(evalbatch, self.config["coalesce"])
@@ -691,10 +711,7 @@ class PytorchTrainer:
                     preds, arr = {}, host.numpy()
                     for (g0, g1), ev in zip(parts, done):
                         ev.synchronize()
-                        lo, hi = int(extra["offsets"][g0]), int(extra["offsets"][g1])
-                        vals = arr[lo:hi].tolist()
-                        for qid, docids, at in groups[g0:g1]:
-                            preds[qid] = dict(zip(docids, vals[at - lo:at - lo + len(docids)]))
+                        pyhost.preds_from_fp16(groups, arr, preds, g0, g1)      # preds[qid] = dict(zip(docids, that list's fp16 scores))
                 if pred_fn is not None:
                     os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
                     write_trec_run(preds, pred_fn)
@@ -702,16 +719,11 @@ class PytorchTrainer:
             with engine.deferred_status(self.device):
                 chunks = [self._score_store(reranker, store, pq, pd, extra["counts"], step, extra["offsets"])]
                 if not distributed:      # the {qid: {docid: score}} dict straight from the per-query slices
-                    vals = chunks[0].to(torch.float16).cpu().numpy().tolist()
+                    vals = np.ascontiguousarray(chunks[0].to(torch.float16).cpu().numpy())
             if not distributed:
                 if len(vals) != count:
                     raise RuntimeError(f"rank {rank} scored {len(vals)} pairs, expected {count}")
-                if extra["one_run_per_qid"]:
-                    preds = {qid: dict(zip(docids, vals[lo:lo + len(docids)])) for qid, docids, lo in groups}
-                else:
-                    preds = {}
-                    for qid, docids, lo in groups:
-                        preds.setdefault(qid, {}).update(zip(docids, vals[lo:lo + len(docids)]))
+                preds = pyhost.preds_from_fp16(groups, vals, {}, merge=not extra["one_run_per_qid"])
                 if pred_fn is not None:
                     os.makedirs(os.path.dirname(os.fspath(pred_fn)) or ".", exist_ok=True)
                     write_trec_run(preds, pred_fn)

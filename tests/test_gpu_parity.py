@@ -1600,6 +1600,17 @@ def test_predict_builds_its_candidate_store_on_first_use():
     third = t.predict(r, s)
     assert walked[0] == 2 * n - 5 and third == PytorchTrainer({"batch": 32, "resident": False}).predict(r, s)
     q2d["12"] = [f"d{i}" for i in range(150, B)]
+    # ... also when the edit keeps the list object, its length and every docid the sampled fingerprint looks at (the default
+    # `resident_verify` = "auto" compares every docid of a run of this size with the plan's own copy)
+    fourth = t.predict(r, s)
+    lst = q2d["12"]
+    step = max(1, (len(lst) - 1) // 7)
+    assert 2 % step and 3 % step and len(lst) > 5     # positions the 8-docid sample skips
+    lst[2], lst[3] = "d10", lst[2]                    # one candidate replaced by another document, one moved
+    fifth = t.predict(r, s)
+    assert fifth == PytorchTrainer({"batch": 32, "resident": False}).predict(r, s)
+    assert "d10" in fifth["12"] and "d10" not in fourth["12"] and list(fifth["12"])[:4] == lst[:4]
+    q2d["12"] = [f"d{i}" for i in range(150, B)]
 
     # a sampler whose document rows depend on the query they come with is not a candidate-store sampler: DataLoader route, same answers
     class Coupled(Sampler):

@@ -392,3 +392,60 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     assert calls == [("pairs", 20)]
     with pytest.raises(ValueError):
         PytorchTrainer({"lists": "sometimes"}).build()
+
+
+def test_pyhost_builds_the_dictionaries_of_the_python_expression():
+    """csrc/pyhost.c (the CPython helper `predict` builds its {qid: {docid: score}} result with) against the expression it replaces:
+    same keys in the same insertion order, values float(np.float16(x)) - incl. inf / nan / -0.0 / subnormals -, later duplicates win,
+    merge = dict.update semantics for a qid that comes in several runs, errors as Python exceptions."""
+    from capreolus_amd import pyhost
+    from capreolus_amd.csrc import build as hipbuild
+
+    hipbuild.build_pyhost()
+    assert pyhost.available()
+    rs = np.random.RandomState(5)
+    bits = rs.randint(0, 65536, size=5000).astype(np.uint16)      # every kind of fp16 value
+    scores = bits.view(np.float16)
+    groups, lo = [], 0
+    for q in range(40):
+        n = int(rs.randint(0, 200))
+        docids = tuple(f"d{rs.randint(0, 150)}" for _ in range(n))      # duplicates inside a list
+        groups.append((f"q{q % 25}" if q >= 30 else q, docids, lo))      # int and str qids; q30.. repeat qids (merge)
+        lo += n
+    groups = [g for g in groups if g[2] + len(g[1]) <= scores.size]
+
+    def python_form(gs, merge):
+        out = {}
+        for qid, docids, at in gs:
+            vals = scores[at:at + len(docids)].tolist()
+            if merge and qid in out:
+                out[qid].update(zip(docids, vals))
+            else:
+                out[qid] = dict(zip(docids, vals))
+        return out
+
+    def same(a, b):
+        assert list(a) == list(b)
+        for k in a:
+            assert list(a[k]) == list(b[k])
+            for d in a[k]:
+                x, y = a[k][d], b[k][d]
+                assert type(x) is float and type(y) is float
+                assert (x != x and y != y) or (x == y and math.copysign(1, x) == math.copysign(1, y)), (k, d, x, y)
+
+    import math
+
+    for merge in (False, True):
+        same(pyhost.preds_from_fp16(groups, scores, {}, merge=merge), python_form(groups, merge))
+    # a slice of the groups against a slice of the score vector (how `predict` converts part after part)
+    g0, g1 = 5, 17
+    base = groups[g0][2]
+    end = groups[g1 - 1][2] + len(groups[g1 - 1][1])
+    part = np.ascontiguousarray(scores[base:end])
+    same(pyhost.preds_from_fp16(groups, part, {}, g0, g1, base=base), python_form(groups[g0:g1], False))
+    with pytest.raises(IndexError):
+        pyhost.preds_from_fp16(groups, part, {}, g0, g1 + 1, base=base)
+    with pytest.raises(TypeError):
+        pyhost.preds_from_fp16(groups, scores.astype(np.float32), {})
+    with pytest.raises(TypeError):
+        pyhost.preds_from_fp16([("q", ["not", "a", "tuple"], 0)], scores, {})
