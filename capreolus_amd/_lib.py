@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CAPAMD_LIB_PATH") or os.path.join(_HERE, "csrc", "lib
 
 OK, ERR_ARG, ERR_ALIGN, ERR_LAUNCH, ERR_WORKSPACE = 0, 1, 2, 3, 4
 LAUNCH_CONCURRENT = 1
-STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV, STATUS_SCORE_NAN, STATUS_TIE_RANGE = 1, 2, 4, 8, 16
+STATUS_DOC_ID_RANGE, STATUS_QUERY_ID_RANGE, STATUS_QUERY_OOV, STATUS_SCORE_NAN, STATUS_TIE_RANGE, STATUS_LIST_QUERY = 1, 2, 4, 8, 16, 32
 
 _vp, _i, _i64, _sz, _u, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint, ctypes.c_float
 

@@ -10,11 +10,12 @@
 // was measured to give the same logit error: the error is set by the 16-bit GEMM operands.)
 #include "bert_attn.cuh"
 #include "bert_gemm.cuh"
-#include "bert_gemm_ring.cuh"
+#include "bert_gemm_ring16.cuh"
 #include "capreolus_amd.h"
 #include "capamd_profiling.h"
 #include "cedr_tap.cuh"
 #include <stdlib.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 
@@ -487,13 +488,35 @@ int ring_rows() {   // CAPAMD_RING_BM=256: one workgroup per CU with 128 x 128 w
   static const int bm = [] { const char* e = getenv("CAPAMD_RING_BM"); return (e && atoi(e) == 256) ? 256 : 128; }();
   return bm;
 }
-int producer_ring_rows() {   // tile rows of the residual + statistics GEMMs (O-proj, FFN2); CAPAMD_RING_BM overrides every GEMM alike
-  static const int v = [] { const char* e = getenv("CAPAMD_RING_BM"); return e ? 0 : 256; }();
-  return v;
+// Which ring kernel each of the encoder's four GEMMs runs on: tile rows (256: one workgroup per CU, 128: two) and, for 256, the MFMA
+// shape (16x16x32, bert_gemm_ring16.cuh, or 32x32x16).  Defaults = what measured fastest inside the encoder at M = 64,000
+// (profiles/r05/bert_gemm_pick_ab.txt); CAPAMD_GEMM_PICK="qkv=256x16,ffn1=128,oproj=256x32,ffn2=256x32" overrides any of them (A/B runs),
+// CAPAMD_RING_BM every one alike.
+struct GemmPick { int rows, mfma32; };
+GemmPick gemm_pick(int kind /* 0 QKV, 1 FFN1, 2 O-proj, 3 FFN2 */) {
+  static const struct Picks { GemmPick p[4]; } picks = [] {
+    Picks k{{{256, 0}, {128, 0}, {256, 0}, {256, 0}}};
+    const char* names[4] = {"qkv=", "ffn1=", "oproj=", "ffn2="};
+    if (const char* e = getenv("CAPAMD_GEMM_PICK"))
+      for (int i = 0; i < 4; ++i)
+        if (const char* f = strstr(e, names[i])) {
+          const char* v = f + strlen(names[i]);
+          k.p[i].rows = atoi(v) == 256 ? 256 : 128;
+          k.p[i].mfma32 = strncmp(v, "256x32", 6) == 0 ? 1 : 0;
+        }
+    if (const char* e = getenv("CAPAMD_RING_BM"))
+      for (int i = 0; i < 4; ++i) k.p[i].rows = atoi(e) == 256 ? 256 : 128;
+    return k;
+  }();
+  return picks.p[kind];
 }
 int ring_stagger_override() {
   static const int v = [] { const char* e = getenv("CAPAMD_RING_STAGGER"); return e ? atoi(e) : -1; }();
   return v;
+}
+bool ring16_enabled() {   // CAPAMD_RING16=0: the 256-row ring kernel on 32x32x16 MFMAs (round 4's; A/B runs)
+  static const bool on = [] { const char* e = getenv("CAPAMD_RING16"); return !(e && e[0] == '0'); }();
+  return on;
 }
 bool ring_enabled() {
   static const bool on = [] { const char* e = getenv("CAPAMD_GEMM_RING"); return !(e && e[0] == '0'); }();
@@ -532,7 +555,19 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       if (!g.a_cm || !ring_shape(g.M, g.N, g.K) || (EPI == kEpiResidStats && !g.out_cm)) return hipErrorInvalidValue;
       GemmArgs gg = g;
       gg.ngroup = column_group(g.N / 256, g.K);
-      if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256) {
+      if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256 && ring16_enabled() && !g.ring_mfma32 && g.out_cm && g.K % 64 == 0) {
+        // one workgroup per CU on 16x16x32 MFMAs (bert_gemm_ring16.cuh)
+        using R = GemmRing16<EPI, T>;
+        auto k = gemm_ring16_kernel<EPI, T>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
+          if (e != hipSuccess) return e;
+          attr_set = true;
+        }
+        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();
+        hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      } else if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256) {
         using R = GemmRing<EPI, T, 256>;
         auto k = gemm_ring_kernel<EPI, T, 256>;
         static bool attr_set = false;
@@ -856,6 +891,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         if (l == 0) { g.W = wqkv + cmo; g.bias = bqkv; }
         else { g.W = wqkv_s + cmo; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
         g.w_cm = ring;
+        g.ring_rows = gemm_pick(0).rows; g.ring_mfma32 = gemm_pick(0).mfma32;
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
         AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1, ring ? 1 : 0};
@@ -896,7 +932,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         // (ring kernel, measured per GEMM inside the encoder at M = 64,000: the residual + statistics producers run faster on its 256-row
         // tile - 181 us against 200 on the 128-row tile and 193 on the ping-pong kernel - QKV and FFN1, with their heavier epilogues,
         // on the 128-row tile whose two workgroups per CU overlap epilogue and K loop: 248 / 341 us against 253 / 356)
-        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.ring_rows = producer_ring_rows();
+        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(2).rows; g.ring_mfma32 = gemm_pick(2).mfma32;
         g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
         g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
@@ -906,13 +942,14 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         g = GemmArgs{};
         g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s + cmo; g.w_cm = ring; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
         g.out_bf16 = w.mid; g.out_cm = 1;
+        g.ring_rows = gemm_pick(1).rows; g.ring_mfma32 = gemm_pick(1).mfma32;
         Ffn1Timing::begin(s);
         e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
         Ffn1Timing::end(s, M);
         if (e != hipSuccess) break;
         // xb = mid W2^T + b2 + LN1(pre)   (+ row statistics of xb)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.ring_rows = producer_ring_rows();
+        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(3).rows; g.ring_mfma32 = gemm_pick(3).mfma32;
         g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
         g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
@@ -1186,6 +1223,7 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
+  g.ring_mfma32 = (epilogue & CAPAMD_GEMM_RING_MFMA32) ? 1 : 0;
   epilogue &= 0xff;
   if ((g.a_cm || g.out_cm) && (!pingpong_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
@@ -1201,10 +1239,12 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
   (void)hipGetLastError();
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out_bf16 = out;
+  g.dbg = g_gemm_dbg;
   g.a_cm = (epilogue & CAPAMD_GEMM_A_CHUNK_MAJOR) ? 1 : 0;
   g.out_cm = (epilogue & CAPAMD_GEMM_OUT_CHUNK_MAJOR) ? 1 : 0;
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
+  g.ring_mfma32 = (epilogue & CAPAMD_GEMM_RING_MFMA32) ? 1 : 0;
   epilogue &= 0xff;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K))) return CAPAMD_ERR_ARG;
   if (ln_mu) {

@@ -1,0 +1,437 @@
+// 256 x 256 tile, four waves, the k-slice ring of bert_gemm_ring.cuh consumed by v_mfma_f32_16x16x32 (round 5).
+//
+// Why another K loop.  Every 32x32x16 kernel of this library lands at the same 0.95-1.1 PFLOP/s on the encoder's shapes whatever its
+// schedule, at clocks between 1.06 and 1.5 GHz (profiles/r05/ring_timeline.txt): the part is power-limited and cycles saved come back as
+// clock.  The vendor's kernel is 6-12 % faster on the same shapes with 16x16x32 MFMAs; scripts/ubench/gemm4w5.hip - this file's K loop
+// on its own, next to gemm4w2.hip, the 32x32x16 ring - measured why that is not the epilogue: the SAME ring, the same LDS bytes per
+// flop, one barrier per 1024 MFMA cycles in both, and the K step (64 k of a 256 x 256 tile) takes 1.78 us instead of 1.97 (QKV), 1.30
+// instead of 1.42 (output projection), 1.73 instead of 1.91 (FFN1), 2.03 instead of 2.06 (FFN2) at the same clock
+// (profiles/r05/gemm4w5_vs_4w2.txt).  Per flop a 16x16x32 MFMA moves half the accumulator registers of a 32x32x16 one (4 in, 4 out per
+// 16 k-flops against 16 and 16 per 32 k) for twice the operand registers: 0.25 against 0.31 register bytes per flop.
+//
+// Layout.  Operands chunk-major as in bert_gemm_ring.cuh; a ring SLOT is a k-slice of 16 (8 A pieces + 8 B pieces of 1 KiB), a STEP is
+// 32 k = two adjacent slots (the ring's 8 slots = 4 steps).  An operand fragment of a 16-row tile is 16 rows x 32 k: lane (l15 = lane
+// % 16, q = lane / 16) reads row l15 of k-chunk q - chunks 0, 1 in the step's first slot, 2, 3 in its second - one ds_read_b128, the 16
+// lanes of a q 256 contiguous bytes: conflict-free.  A wave owns 128 x 128 = 8 x 8 tiles of 16 x 16, 64 accumulators of 4 registers
+// (AGPRs; the MFMAs are inline assembly accumulating in place - left to the register allocator the 64 four-register tuples get copied
+// around); with the weight fragment as the A operand lane (l15, q) holds, of tile (i, j), row m = 16 j + l15, columns n = 16 i + 4 q
+// + 0..3.  Accumulation order per output element: k ascending in steps of 32, the 32 products of a step summed by the MFMA - NOT the
+// bits of the 32x32x16 kernels (k in steps of 16); every launch of a given GEMM of the encoder takes the same kernel whatever its M.
+//
+// Schedule.  Per step and wave: 64 MFMAs, the 16 fragment reads of the next step, the wave's 8 pieces of the step four ahead (into the
+// two slots every wave has just finished reading), ONE barrier; issue order pinned: M M R M M, a DMA after every second group.  vmcnt
+// arithmetic as in the 32x32x16 ring with a step as the unit: 16 pieces (two steps) may stay in flight at the top of a step, 32 more
+// in the two steps after an epilogue.  The first step of a tile writes the accumulators (C = 0): no zero fill.
+//
+// Epilogues.  The chunk-major ones of bert_gemm.cuh re-derived for the 16 x 16 layout: a lane owns 4 consecutive columns of a row; the
+// two lanes that hold the halves of an 8-column chunk are 16 apart, and the two 16-row tiles of a 32-row block sit in the same lanes -
+// v_permlane16_swap on the PACKED registers of tile (i, 2 jp) and (i, 2 jp + 1) leaves lane q even with the whole chunk of row l15 and
+// lane q odd with the whole chunk of row 16 + l15: one 16-byte store per lane, 1 KiB contiguous per instruction.  V^T tiles (QKV): the
+// operand roles swapped (lane <-> n, registers <-> 4 consecutive keys), regrouped through the wave's 4 KiB of LDS into 128-byte row
+// segments as before.
+#pragma once
+#include "bert_gemm_ring.cuh"
+
+namespace capamd {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<__bf16> {
+  using x8 = typename Half<__bf16>::x8;
+  static __device__ __forceinline__ void first(f32x4& c, x8 a, x8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc(f32x4& c, x8 a, x8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+};
+template <>
+struct Mfma16<_Float16> {
+  using x8 = typename Half<_Float16>::x8;
+  static __device__ __forceinline__ void first(f32x4& c, x8 a, x8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc(f32x4& c, x8 a, x8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+};
+
+template <int EPI, typename T>
+struct GemmRing16 {
+  using G = GemmKernel<256, 256, 2, 2, EPI, T>;   // tile schedule (tile_of), V^T addressing (out_offset), staging bytes
+  using x8 = typename Half<T>::x8;
+  using x4 = typename Half<T>::x4;
+  static constexpr int NI = 8, NJ = 8;                       // 16 x 16 tiles of a wave: i along n, j along m
+  static constexpr int P = 4;                                // 1-KiB pieces of a k-slice per wave (8 A + 8 B over four waves)
+  static constexpr int kSlotA = 8 * 1024, kSlot = 16 * 1024, kSlots = 8, kRing = kSlot * kSlots;
+  static constexpr int kThreads = 256;
+  static constexpr int kLdsBytes = kRing + 4 * G::kEpiLds;
+  static constexpr int kEpiVmem = 32;                        // VMEM instructions every epilogue issues per wave, at least
+  static constexpr int kVm = 2 * 2 * P;                      // pieces of the two youngest steps may stay in flight at the top of a step
+  static_assert(kVm + kEpiVmem <= 63 && kLdsBytes <= 160 * 1024, "vmcnt immediate / LDS budget");
+  static_assert(EPI == kEpiBiasBf16 || EPI == kEpiBiasGeluBf16 || EPI == kEpiQkv || EPI == kEpiResidStats, "epilogues of the fused encoder");
+
+  static constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+  struct Lane {
+    int tid, lane, wave, wm, wn, l15, q;
+  };
+  struct Bases { unsigned off[P]; };
+  static __device__ __forceinline__ Bases bases_of(const GemmArgs& g, int m0, int n0, int wave) {
+    Bases b;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int pc = wave + 4 * p;     // piece: 0..7 A row blocks, 8..15 B row blocks
+      b.off[p] = p < 2 ? (unsigned)(((m0 >> 5) + pc) * (g.K >> 3)) * 512u : (unsigned)(((n0 >> 5) + pc - 8) * (g.K >> 3)) * 512u;
+    }
+    return b;
+  }
+
+  // lanes of row 1 / 3 (lanes 16..31, 48..63) of x <-> lanes of row 0 / 2 of y   (wait states by hand, as swap32 in bert_gemm.cuh)
+  static __device__ __forceinline__ void swap16(unsigned& x, unsigned& y) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  }
+  static __device__ __forceinline__ void pin_group(f32x4 (&row)[NJ]) {   // keeps a column group's tiles in AGPRs up to this point
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(row[j]));
+  }
+
+  // ---- epilogue: bias / folded LayerNorm (+ Q / 8, + GELU) into a chunk-major output ------------------------------------------------
+  static __device__ __forceinline__ void epilogue_cm(const GemmArgs& a, int m0, int n0, const Lane& L, f32x4 (&acc)[NI][NJ]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    int ncols = a.N, nloc = n0 + L.wn * 128;
+    float scale = 1.f;
+    if (EPI == kEpiQkv) {
+      ncols = a.H;
+      if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
+      else scale = 0.125f;
+    }
+    const float es = EPI == kEpiBiasGeluBf16 ? 0.5f : scale;     // folded into the affine form (bert_gemm.cuh: epilogue_cm)
+    const bool ln = a.ln_mu != nullptr;
+    float2 mr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      mr[j] = ln ? a.ln_mr[m0 + L.wm * 128 + j * 16 + L.l15] : make_float2(0.f, 1.f);
+      mr[j].y *= es;
+    }
+    const float* csp = ln ? a.ln_cs : a.bias;      // (mu = 0 without folded LayerNorm: any finite vector serves as cs)
+    float4 b4s[2], cs4s[2];
+    auto load_cols = [&](int i, int buf) {
+      const int n = n0 + L.wn * 128 + i * 16 + 4 * L.q;
+      b4s[buf] = *reinterpret_cast<const float4*>(a.bias + n);
+      cs4s[buf] = *reinterpret_cast<const float4*>(csp + n);
+    };
+    load_cols(0, 0);
+    const int nch = ncols >> 3;
+    // byte offset of this lane's 16-byte piece of (column group 0, row block 0) from `base`; a column group further + 1024, a 32-row
+    // block further + jstride: 32-bit arithmetic on a wave-uniform base (a tensor stays below 4 GiB: ring_shape)
+    const unsigned lane_off = (unsigned)((((m0 + L.wm * 128) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 32 + (L.q & 1) * 16 + L.l15) * 16u;
+    const unsigned jstride = (unsigned)nch * 512u;
+    char* const baseb = reinterpret_cast<char*>(base);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < NI) load_cols(i + 1, (i + 1) & 1);      // one group ahead, before this group's stores (in-order VMEM retirement)
+      pin_group(acc[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      float4 b4 = b4s[i & 1];
+      b4.x *= es; b4.y *= es; b4.z *= es; b4.w *= es;
+      const float4 cs4 = cs4s[i & 1];
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * jp + h;
+          const float mu = mr[j].x, rs = mr[j].y;
+          f32x2 v01 = {rs * (acc[i][j][0] - mu * cs4.x) + b4.x, rs * (acc[i][j][1] - mu * cs4.y) + b4.y};
+          f32x2 v23 = {rs * (acc[i][j][2] - mu * cs4.z) + b4.z, rs * (acc[i][j][3] - mu * cs4.w) + b4.w};
+          if (EPI == kEpiBiasGeluBf16) { v01 = gelu_erf_half2(v01); v23 = gelu_erf_half2(v23); }
+          const x4 o = {(T)v01.x, (T)v01.y, (T)v23.x, (T)v23.y};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          pk[h][0] = u.x; pk[h][1] = u.y;
+        }
+        // even q: row l15 of the 32-row block, columns 8 (q / 2) .. + 7 (its own 4 + the odd lane's); odd q: row 16 + l15, same chunk
+        swap16(pk[0][0], pk[1][0]);
+        swap16(pk[0][1], pk[1][1]);
+        *reinterpret_cast<uint4*>(baseb + (size_t)(lane_off + (unsigned)i * 1024u + (unsigned)jp * jstride)) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+      }
+    }
+  }
+
+  // ---- epilogue: pre-LayerNorm sum with the residual re-normalised on the fly + row statistics (bert_gemm.cuh: epilogue_cm_resid) ---
+  static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x4 (&acc)[NI][NJ]) {
+    T* base = static_cast<T*>(a.out_bf16);
+    const T* rsrc = static_cast<const T*>(a.res_src);
+    const int nch = a.N >> 3, nloc = n0 + L.wn * 128, nslot = a.N >> 6;
+    float rrs[NJ], rc[NJ];
+    f32x2 s1[2][NJ / 2], s2[2][NJ / 2];       // per 64-column slot and 32-row block: (even, odd) element partial sums of this lane's row
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float2 mr = a.res_mr[m0 + L.wm * 128 + j * 16 + L.l15];
+      rrs[j] = mr.y;
+      rc[j] = -mr.x * mr.y;
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) s1[sl][jp] = s2[sl][jp] = f32x2{0.f, 0.f};
+    // The residual comes from HBM / the Infinity Cache (a 98 MB tensor another kernel wrote) and nothing else runs on this SIMD: a piece
+    // requested one step (16 values of arithmetic) ahead arrives 20-30 steps' worth of cycles later, and the epilogue - 31 k cycles
+    // against the K loop's 30 k at K = 768 (profiles/r05/ring16_timeline.txt) - was a chain of 32 memory latencies.  kResAhead steps
+    // are in flight: the first kResAhead requested together at the top, piece t + kResAhead when step t's registers are free.
+    constexpr int kResAhead = 16;
+    float4 bbs[2], ggs[2];
+    x4 r4s[kResAhead][2];
+    auto load_cols = [&](int i, int buf) {
+      const int n = n0 + L.wn * 128 + i * 16 + 4 * L.q;
+      bbs[buf] = *reinterpret_cast<const float4*>(a.bias + n);
+      ggs[buf] = *reinterpret_cast<const float4*>(a.res_gamma + n);
+    };
+    // byte offsets from the wave-uniform tensor bases (32-bit: a tensor stays below 4 GiB); a column group further + 1024, a 32-row
+    // block further + jstride
+    const unsigned blk_off = (unsigned)(((m0 + L.wm * 128) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 512u;
+    const unsigned res_off = blk_off + (unsigned)L.l15 * 16u + 8u * (unsigned)(L.q & 1);             // the lane's own 8 bytes of row l15
+    const unsigned out_off = blk_off + (unsigned)((L.q & 1) * 16 + L.l15) * 16u;                     // its 16-byte piece after the exchange
+    const unsigned jstride = (unsigned)nch * 512u;
+    const char* const rsrcb = reinterpret_cast<const char*>(rsrc);
+    char* const baseb = reinterpret_cast<char*>(base);
+    auto load_res = [&](int t, int buf) {   // t = i * 4 + jp: the residual where the accumulators put the value - row l15 (tile 2 jp) and 16 + l15
+      const int i = t >> 2, jp = t & 3;
+      const char* rp = rsrcb + (size_t)(res_off + (unsigned)i * 1024u + (unsigned)jp * jstride);
+      r4s[buf][0] = *reinterpret_cast<const x4*>(rp);
+      r4s[buf][1] = *reinterpret_cast<const x4*>(rp + 256);
+    };
+    load_cols(0, 0);
+#pragma unroll
+    for (int t = 0; t < kResAhead; ++t) load_res(t, t);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < NI) load_cols(i + 1, (i + 1) & 1);
+      pin_group(acc[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 bb = bbs[i & 1], gg = ggs[i & 1];
+      const f32x2 b01 = {bb.x, bb.y}, b23 = {bb.z, bb.w}, g01 = {gg.x, gg.y}, g23 = {gg.z, gg.w};
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        const int t = i * 4 + jp;
+        unsigned pk[2][2];
+        uint2 rus[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rus[h] = __builtin_bit_cast(uint2, r4s[t % kResAhead][h]);
+        if (t + kResAhead < NI * 4) load_res(t + kResAhead, t % kResAhead);     // (its registers were just read)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * jp + h;
+          const uint2 ru = rus[h];
+          const f32x2 rr = {rrs[j], rrs[j]}, cc = {rc[j], rc[j]};
+          const f32x2 v01 = f32x2{acc[i][j][0], acc[i][j][1]} + b01, v23 = f32x2{acc[i][j][2], acc[i][j][3]} + b23;
+          const f32x2 t01 = Half<T>::unpack2(ru.x) * rr + cc, t23 = Half<T>::unpack2(ru.y) * rr + cc;
+          const f32x2 o01 = t01 * g01 + v01, o23 = t23 * g23 + v23;             // fp32 sum, ONE rounding
+          const x4 o = {(T)o01.x, (T)o01.y, (T)o23.x, (T)o23.y};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          pk[h][0] = u.x; pk[h][1] = u.y;
+        }
+        swap16(pk[0][0], pk[1][0]);
+        swap16(pk[0][1], pk[1][1]);
+        *reinterpret_cast<uint4*>(baseb + (size_t)(out_off + (unsigned)i * 1024u + (unsigned)jp * jstride)) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+        // statistics of what the consumers will read, from the registers as stored: 8 values of ONE row (l15, or 16 + l15 for odd q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x2 qv = Half<T>::unpack2(pk[k >> 1][k & 1]);
+          s1[i >> 2][jp] += qv;
+          s2[i >> 2][jp] = qv * qv + s2[i >> 2][jp];
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        // lanes q and q + 2 hold the two chunks of the same row: add them; lanes 0..31 are the 32 rows of the block
+        const float p1 = s1[sl][jp].x + s1[sl][jp].y, p2 = s2[sl][jp].x + s2[sl][jp].y;
+        const float t1 = p1 + __shfl_xor(p1, 32, 64), t2 = p2 + __shfl_xor(p2, 32, 64);
+        const int mrow = m0 + L.wm * 128 + jp * 32 + (L.lane & 31);
+        if (L.lane < 32) *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + ((n0 + L.wn * 128) >> 6) + sl) * 2) = make_float2(t1, t2);
+      }
+  }
+
+  // ---- epilogue: V^T tiles of the QKV projection (operand roles swapped: lane <-> n = l15, registers <-> keys m = 4 q + 0..3) --------
+  static __device__ __forceinline__ void epilogue_vt(const GemmArgs& a, char* wl, int m0, int n0, const Lane& L, f32x4 (&acc)[NI][NJ]) {
+    const bool ln = a.ln_mu != nullptr;
+    float bias_t[NI], cs_t[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bias_t[i] = a.bias[n0 + L.wn * 128 + i * 16 + L.l15];
+      cs_t[i] = ln ? a.ln_cs[n0 + L.wn * 128 + i * 16 + L.l15] : 0.f;
+    }
+    T* base = static_cast<T*>(a.out_vt);
+    typename G::Lane GL;
+    GL.wm = L.wm; GL.wn = L.wn;
+    // a round: 32 rows of n (tiles 2 ip, 2 ip + 1) x 64 keys (tiles 4 jq .. 4 jq + 3) = 32 x 128 bytes in the wave's LDS
+#pragma unroll
+    for (int ip = 0; ip < NI / 2; ++ip) {
+      __builtin_amdgcn_sched_barrier(0);
+      pin_group(acc[2 * ip]);
+      pin_group(acc[2 * ip + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jq = 0; jq < NJ / 4; ++jq) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = 4 * jq + jj;
+          float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (ln) {
+            const int mrow = m0 + L.wm * 128 + j * 16 + 4 * L.q;
+            mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow);
+            rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
+          }
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * ip + ii;
+            const float b = bias_t[i], cs = cs_t[i];
+            const x4 o = {(T)(rs.x * (acc[i][j][0] - mu.x * cs) + b), (T)(rs.y * (acc[i][j][1] - mu.y * cs) + b),
+                          (T)(rs.z * (acc[i][j][2] - mu.z * cs) + b), (T)(rs.w * (acc[i][j][3] - mu.w * cs) + b)};
+            const int row = ii * 16 + L.l15, c16 = jj * 2 + (L.q >> 1);
+            *reinterpret_cast<x4*>(wl + row * 128 + ((c16 ^ (row & 7)) << 4) + (L.q & 1) * 8) = o;
+          }
+        }
+        // (no wait between a wave's own LDS writes and reads: its DS operations execute in issue order)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = L.lane + 64 * k, row = c >> 3, ch = c & 7;
+          const uint4 x = *reinterpret_cast<const uint4*>(wl + row * 128 + ((ch ^ (row & 7)) << 4));
+          *reinterpret_cast<uint4*>(base + G::template out_offset<true>(a, m0, n0, GL, ip, row, jq * 64 + ch * 8)) = x;
+        }
+        asm volatile("" ::: "memory");  // the next round's writes stay behind these reads
+      }
+    }
+  }
+
+  static __device__ __forceinline__ void run(const GemmArgs& g, char* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Lane L;
+    L.tid = threadIdx.x; L.lane = L.tid & 63; L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+    L.wm = L.wave >> 1; L.wn = L.wave & 1; L.l15 = L.lane & 15; L.q = L.lane >> 4;
+    unsigned long long* dbg = g.dbg ? g.dbg + (size_t)blockIdx.x * 32 : nullptr;
+    int dbg_i = 0;
+#define CAPAMD_STAMP() do { if (dbg && L.tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+    int m0, n0;
+    if (!G::tile_of(g, 0, m0, n0)) return;
+    const int S2 = g.K >> 5;                         // steps per tile (ring16_shape: even, >= 8)
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)((size_t)g.M * g.K * 2), 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, (int)((size_t)g.N * g.K * 2), 0x00020000);
+    const int voff = L.lane * 16;
+    auto dma = [&](int p, char* slot, unsigned soff) {
+      const int pc = L.wave + 4 * p;
+      if (p < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(slot + pc * 1024), 16, voff, (int)soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(slot + pc * 1024), 16, voff, (int)soff, 0, 0);
+    };
+    // fragment of 16-row tile t of the A (m) / B (n) panel inside a step: + (t >> 1) * 1024 + (t & 1) * 256
+    const int a_base = L.wm * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
+    const int b_base = kSlotA + L.wn * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
+
+    Bases cur = bases_of(g, m0, n0, L.wave);
+    CAPAMD_STAMP();
+#pragma unroll 1
+    for (int i = 0; i < kSlots; ++i)
+#pragma unroll
+      for (int p = 0; p < P; ++p) dma(p, lds + i * kSlot, cur.off[p] + (unsigned)i * 1024u);
+    x8 fa[2][NJ], fb[2][NI];
+    auto read_first = [&](int slot) {
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) fa[0][t] = *reinterpret_cast<const x8*>(lds + slot + a_base + (t >> 1) * 1024 + (t & 1) * 256);
+#pragma unroll
+      for (int t = 0; t < NI; ++t) fb[0][t] = *reinterpret_cast<const x8*>(lds + slot + b_base + (t >> 1) * 1024 + (t & 1) * 256);
+    };
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm((kSlots - 2) * P, 15));     // the first step's two slices have landed
+    __builtin_amdgcn_s_barrier();
+    read_first(0);
+    int slot_off = 0;          // byte offset of the first slot of the step being consumed
+    bool after_epilogue = false;
+    for (int it = 0;; ++it) {
+      int m1 = 0, n1 = 0;
+      const bool more = G::tile_of(g, it + 1, m1, n1);
+      if (!more) { m1 = 0; n1 = 0; }                  // nothing follows: the run-ahead LDS-DMAs re-read the first tile's slices (never consumed)
+      const Bases nxt = bases_of(g, m1, n1, L.wave);
+      f32x4 acc[NI][NJ];
+      const bool trans = (EPI == kEpiQkv) && n0 >= 2 * g.H;
+      // one step (32 k); U: which fragment set holds it, VM: outstanding VMEM operations allowed at its top, s: its index in the tile
+      auto kstep = [&](auto u_c, auto vm_c, auto tr_c, int s, auto first_c) {
+        constexpr int cu = decltype(u_c)::value, nx = cu ^ 1, VM = decltype(vm_c)::value;
+        constexpr bool TR = decltype(tr_c)::value, FIRST = decltype(first_c)::value;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(VM, 0));
+        __builtin_amdgcn_s_barrier();
+        const int nslot = slot_off + 2 * kSlot == kRing ? 0 : slot_off + 2 * kSlot;
+        const char* stn = lds + nslot;
+        char* dst = lds + slot_off;
+        // the step four ahead: of this tile, or (the tile's last four steps) of the block's next tile
+        const bool own = s + 4 < S2;
+        const unsigned so = (unsigned)(own ? s + 4 : s + 4 - S2) * 2048u;
+        unsigned soff[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) soff[p] = (own ? cur.off[p] : nxt.off[p]) + so;
+#define CAPAMD_M16(idx)                                                                  \
+  do {                                                                                   \
+    constexpr int i_ = (idx) >> 3, j_ = (idx) & 7;                                       \
+    if (FIRST) { if (TR) Mfma16<T>::first(acc[i_][j_], fa[cu][j_], fb[cu][i_]); else Mfma16<T>::first(acc[i_][j_], fb[cu][i_], fa[cu][j_]); } \
+    else { if (TR) Mfma16<T>::acc(acc[i_][j_], fa[cu][j_], fb[cu][i_]); else Mfma16<T>::acc(acc[i_][j_], fb[cu][i_], fa[cu][j_]); }            \
+  } while (0)
+#define CAPAMD_SB __builtin_amdgcn_sched_barrier(0)
+        auto R = [&](int r) {
+          if (r < NJ) fa[nx][r] = *reinterpret_cast<const x8*>(stn + a_base + (r >> 1) * 1024 + (r & 1) * 256);
+          else fb[nx][r - NJ] = *reinterpret_cast<const x8*>(stn + b_base + ((r - NJ) >> 1) * 1024 + ((r - NJ) & 1) * 256);
+        };
+        auto D = [&](int d) {       // piece d of the step's eight: slice d >> 2, the wave's piece d & 3
+          dma(d & 3, dst + (d >> 2) * kSlot, soff[d & 3] + (unsigned)(d >> 2) * 1024u);
+        };
+        CAPAMD_SB;
+#define CAPAMD_G16(g_)                                                                                                    \
+  CAPAMD_M16(4 * (g_)); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 1); CAPAMD_SB; R(g_); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 2); CAPAMD_SB; \
+  CAPAMD_M16(4 * (g_) + 3); CAPAMD_SB;                                                                                   \
+  if ((g_) & 1) { D((g_) >> 1); CAPAMD_SB; }
+        CAPAMD_G16(0) CAPAMD_G16(1) CAPAMD_G16(2) CAPAMD_G16(3) CAPAMD_G16(4) CAPAMD_G16(5) CAPAMD_G16(6) CAPAMD_G16(7)
+        CAPAMD_G16(8) CAPAMD_G16(9) CAPAMD_G16(10) CAPAMD_G16(11) CAPAMD_G16(12) CAPAMD_G16(13) CAPAMD_G16(14) CAPAMD_G16(15)
+#undef CAPAMD_G16
+#undef CAPAMD_SB
+#undef CAPAMD_M16
+        slot_off = nslot;
+      };
+      using U0 = std::integral_constant<int, 0>;
+      using U1 = std::integral_constant<int, 1>;
+      using VS = std::integral_constant<int, kVm>;
+      using VE = std::integral_constant<int, kVm + kEpiVmem>;
+      using F0 = std::false_type;
+      using F1 = std::true_type;
+      auto tile_loop = [&](auto tr_c) {
+        // (after an epilogue the first two steps wait for pieces older than the epilogue's >= kEpiVmem VMEM operations: steps 1 and 2
+        // of the tile were issued before it)
+        if (after_epilogue) { kstep(U0{}, VE{}, tr_c, 0, F1{}); kstep(U1{}, VE{}, tr_c, 1, F0{}); }
+        else { kstep(U0{}, VS{}, tr_c, 0, F1{}); kstep(U1{}, VS{}, tr_c, 1, F0{}); }
+#pragma unroll 1
+        for (int s = 2; s < S2; s += 2) { kstep(U0{}, VS{}, tr_c, s, F0{}); kstep(U1{}, VS{}, tr_c, s + 1, F0{}); }
+      };
+      if (EPI == kEpiQkv && trans) tile_loop(std::true_type{});
+      else tile_loop(std::false_type{});
+      // the last MFMAs' results are read by the epilogue's v_accvgpr_read: the wait states the assembler would insert behind a
+      // matrix instruction it can see (inline assembly hides them from its hazard recogniser)
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      CAPAMD_STAMP();
+      if constexpr (EPI == kEpiResidStats) epilogue_cm_resid(g, m0, n0, L, acc);
+      else if (EPI == kEpiQkv && trans) epilogue_vt(g, lds + kRing + L.wave * G::kEpiLds, m0, n0, L, acc);
+      else epilogue_cm(g, m0, n0, L, acc);
+      CAPAMD_STAMP();
+      if (!more) break;
+      after_epilogue = true;
+      cur = nxt;
+      m0 = m1; n0 = n1;
+      read_first(slot_off);
+    }
+#undef CAPAMD_STAMP
+#endif
+  }
+};
+
+template <int EPI, typename T>
+__global__ __launch_bounds__(256, 1) void gemm_ring16_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char gemm_ring16_lds[];
+  GemmRing16<EPI, T>::run(a, gemm_ring16_lds);
+}
+
+}  // namespace capamd

@@ -37,6 +37,7 @@ constexpr int kMaxNV = 5;         // D <= 319
 constexpr int kErrDocIdRange = 1;    // doc id >= V
 constexpr int kErrQueryIdRange = 2;  // query id >= V
 constexpr int kErrQueryOOV = 4;      // negative query id where the reference model cannot take one (DRMM.py:109)
+constexpr int kErrListQuery = 32;    // whole-list entries: a pair's query (idf) row differs from its list's first pair's
 
 __host__ __device__ inline int nv_for_dim(int D) { return (D + 1 + 63) / 64; }
 __host__ __device__ inline int row_stride_for_dim(int D) { return 64 * nv_for_dim(D); }

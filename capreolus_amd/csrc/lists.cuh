@@ -59,6 +59,7 @@ struct ListsArgs {
   float* head;             // [H / 16][64 NV][16] the first H table rows, sixteen by sixteen, column-major inside a block (lists_head_pack_kernel)
   int H;                   // rows 0 .. H - 1 get their similarities from the dense matrix-pipe pass (lists_head_sims_kernel), for EVERY list
   int preflag;             // ids below this count as flagged in every list (lists_clear_kernel): the mark pass does not store their bytes
+  const float* list_idf;   // [B, Q] / [NQ, Q]: the idf rows of models that read the LIST's (its first pair's) row - DRMM, DRMM-TKS; else null
 };
 
 constexpr int kQueryImage = kQT * kMaxNV * 16;      // float4s
@@ -152,6 +153,20 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
   for (int t = 0; t < kQT; ++t) {
     const int64_t q = t < a.Q ? qids.q(t) : 0;
     qo[t] = (q < 0 && q > -2147483648LL) ? (int)q : 0;
+  }
+  // A list is ONE query against its documents: the passes below use the first pair's query row (and, where the model gates by idf, its
+  // idf row) for all of them.  A pair that brings another row is a caller error - said through the status word instead of scoring the
+  // pair against a query it does not have.  (Wave-uniform loads of 2 Q ids per document next to its L.)
+  if (doc > 0 && ids.qrow != qids.qrow) {
+    bool differs = false;
+#pragma unroll
+    for (int t = 0; t < kQT; ++t)
+      if (t < a.Q) {
+        differs |= ids.q(t) != qids.q(t);
+        if (a.list_idf)
+          differs |= __float_as_uint(a.list_idf[(int64_t)ids.qrow * a.Q + t]) != __float_as_uint(a.list_idf[(int64_t)qids.qrow * a.Q + t]);
+      }
+    if (differs && lane == 0) atomicOr(a.status, kErrListQuery);
   }
   uint8_t* f = a.flags + (int64_t)l * a.Vp;
   int32_t* out = (EMIT && kCompactRows) ? a.cid + (int64_t)b * a.cid_stride : nullptr;
@@ -775,7 +790,7 @@ size_t lists_pair_bytes(int64_t n_pairs, int L) { return (size_t)n_pairs * ((kCo
 template <class Pool>
 int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V, int D, int* status,
               void* workspace, size_t workspace_bytes, hipStream_t s, const float* edges, int nbins, const float* kn_mu, const float* kn_sigma, int kn_K,
-              bool emit, Pool pool) {
+              bool emit, const float* list_idf, Pool pool) {
   if (!offsets_host || !packed || !status || !workspace) return CAPAMD_ERR_ARG;
   if (n_lists < 0 || Q < 1 || Q > kQT || L < 1 || L > 32768 || V < 1 || V > 0x7fffffffLL || capamd_packed_row_stride(D) < 0) return CAPAMD_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return CAPAMD_ERR_ALIGN;
@@ -817,7 +832,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     if (!kn_mu) kn_consts = nullptr;
     const int H = lists_head_rows(V, n_pairs, L, n_lists);
     ListsArgs a{ids, Q, L, packed, V, Vp, flags, table, status, nl, longest, edges, nbins, qimg, qmeta, kn_mu, kn_sigma, kn_K, cid, meta, lists_cid_stride(L),
-                kn_consts, qplain, head, H, lists_preflag(n_pairs, L, n_lists)};
+                kn_consts, qplain, head, H, lists_preflag(n_pairs, L, n_lists), list_idf};
     lists_stamp(s);
     hipLaunchKernelGGL(lists_clear_kernel, dim3((unsigned)((Vp + 256 * 16 - 1) / (256 * 16)), (unsigned)nl), dim3(256), 0, s, a);
     lists_stamp(s);

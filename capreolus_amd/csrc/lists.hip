@@ -642,7 +642,7 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const KnrmPoolArgs m{mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K, true,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K, true, nullptr,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
                      aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
@@ -667,6 +667,7 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const DrmmPoolArgs m{idf, edges, nbins, hist_type, gate_type, D, gate_w, emb_raw, ld, w1, b1, nodes, w2, b2, out_w, out_b, out, counts_out};
   hipStream_t s = (hipStream_t)stream;
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0, true,
+                   gate_type == 0 ? idf : nullptr,      // (the term-vector gate never reads an idf row)
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      if (nbins + 1 <= kWaveBins && nodes <= 16) {
                        ListsArgs aq = a;
@@ -690,7 +691,7 @@ extern "C" int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t*
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const TksPoolArgs m{idf, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, true,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, true, idf,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
                      aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup

@@ -701,7 +701,7 @@ extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 192 +
                       (size_t)kQT * kMaxNV * 16 * 16;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, false,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, false, nullptr,
                    [&](const ListsArgs& la, const ListGeom& g, int nl, int longest) {
 #define LAUNCH_L(NV_)                                                                                                           \
   do {                                                                                                                          \

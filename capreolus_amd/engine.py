@@ -87,6 +87,9 @@ class StatusWord:
                 msgs.append("a query term id is >= the embedding table size")
             if bits & _lib.STATUS_QUERY_OOV:
                 msgs.append("a negative (OOV) query term id where the reference model cannot take one (DRMM.py:109, nn.Embedding in ConvKNRM.py:43)")
+            if bits & _lib.STATUS_LIST_QUERY:
+                raise ValueError("a candidate list holds pairs of more than one query (or idf row): a list is the pairs of ONE query, "
+                                 "laid out as its offsets say (capamd_*_forward_lists)")
             if bits & (_lib.STATUS_SCORE_NAN | _lib.STATUS_TIE_RANGE):
                 raise ValueError("ranking: " + ("a score is NaN; " if bits & _lib.STATUS_SCORE_NAN else "") +
                                  ("a tie-break rank is outside 0..n-1" if bits & _lib.STATUS_TIE_RANGE else ""))

@@ -43,6 +43,8 @@ extern "C" {
 #define CAPAMD_STATUS_QUERY_OOV 4      /* negative query id in DRMM      (reference DRMM.py:109 raises IndexError) */
 #define CAPAMD_STATUS_SCORE_NAN 8      /* a NaN score reached the ranking kernels (ranked last) */
 #define CAPAMD_STATUS_TIE_RANGE 16     /* capamd_ndcg_cut: a tie-break rank outside 0..n-1 */
+#define CAPAMD_STATUS_LIST_QUERY 32    /* *_forward_lists: a pair of a list brings another query row (DRMM, DRMM-TKS: or another idf row) than
+                                          the list's first pair - a list is ONE query against its documents */
 
 /* library identity */
 int capamd_version(void);
@@ -173,7 +175,8 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * into a float4 table over the vocabulary, and every document is pooled from 16-byte lookups.  DRMM's scores are bit-identical to
  * capamd_drmm_forward's, KNRM's equal to fp32 rounding of the pooling sums (another summation order).
  * Pairs are laid out list after list: list l owns pairs list_offsets_host[l] .. list_offsets_host[l+1] (a HOST array of n_lists + 1
- * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row).  Ids either as [B,Q] / [B,L] int64
+ * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row); a pair whose own query (idf) row differs
+ * sets CAPAMD_STATUS_LIST_QUERY - the scores of such a call are those of the first pair's query, not the reference's.  Ids either as [B,Q] / [B,L] int64
  * (q_ids, d_ids; the table arguments NULL) or through a candidate store (q_table, d_table, pair_q, pair_d; q_ids / d_ids NULL).
  * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V, n_pairs, L) bytes (16-byte aligned;
  * any contents), in two parts:
@@ -309,7 +312,10 @@ int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int
  * Its producers store straight from MFMA registers (no LDS regrouping), its consumers still fetch full 128-byte lines. */
 #define CAPAMD_GEMM_A_CHUNK_MAJOR 0x200   /* A is chunk-major */
 #define CAPAMD_GEMM_OUT_CHUNK_MAJOR 0x100 /* out is chunk-major */
-#define CAPAMD_GEMM_RING_256 0x800         /* with W chunk-major: the ring kernel's 256-row tile (one workgroup per CU) instead of its default 128-row tile (two per CU) */
+#define CAPAMD_GEMM_RING_256 0x800         /* with W chunk-major: the ring kernel's 256-row tile (one workgroup per CU) instead of its default 128-row tile (two per CU);
+                                            with a chunk-major output and K % 64 == 0 that tile runs on 16x16x32 MFMAs (k accumulated in steps of 32: not the
+                                            bits of the other kernels, which accumulate in steps of 16) */
+#define CAPAMD_GEMM_RING_MFMA32 0x1000     /* with CAPAMD_GEMM_RING_256: keep the 256-row tile on 32x32x16 MFMAs (the bits of the 128-row tile and the 8-wave kernel) */
 #define CAPAMD_GEMM_W_CHUNK_MAJOR 0x400   /* W is chunk-major too (with A chunk-major, M, N % 256 == 0, K % 32 == 0, K >= 256: the 4-wave ring kernel) */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,
                      const void* resid, void* out, int dtype /* 0 bf16, 1 fp16 */, void* stream);

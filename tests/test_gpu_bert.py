@@ -497,6 +497,23 @@ def _big_operands(M, N, K, seed, tdt):
     return g, A, W
 
 
+def _assert_one_ulp_apart(got, ref, tdt, what, frac=2e-2):
+    """Two kernels that accumulate the same products in another order (k in steps of 32 on 16x16x32 MFMAs against steps of 16): fp32 sums
+    that differ in their last bits, i.e. 16-bit results that are equal or - where a sum sat next to a rounding boundary - ONE unit in the
+    last place apart, and that only for a small fraction of the elements."""
+    a, b = got.view(torch.int16).int(), ref.view(torch.int16).int()
+    # (adjacent finite values of one sign differ by 1 as integers; across zero both are tiny: compare the values there)
+    d = (a - b).abs()
+    same_sign = (a ^ b) >= 0
+    bad = same_sign & (d > 1)
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements more than one ulp apart"
+    cross = ~same_sign
+    if bool(cross.any()):
+        assert float((got.float() - ref.float())[cross].abs().max()) < 1e-3, f"{what}: values of opposite sign that are not both tiny"
+    assert float((d != 0).float().mean()) < frac, f"{what}: {float((d != 0).float().mean()):.4f} of the elements differ"
+
+
+
 def _assert_close_big(got, ref, rtol, atol, what):
     """row-blocked comparison: 65,536 x 3,072 fp32 temporaries stay below a few GB"""
     M = ref.shape[0]
@@ -523,10 +540,16 @@ def test_gemm_at_benchmark_scale(N, K, epi, dt):
     assert torch.equal(_from_cm(out_cm, M, N), out)
     # weights chunk-major too -> the 4-wave ring kernel (bert_gemm_ring.cuh): same accumulation order, identical bits
     out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(W)
-    for rows256 in (0, 0x800):          # the 128-row tile (two workgroups per CU) and the 256-row tile (one)
+    for rows256 in (0, 0x1800):         # the 128-row tile (two workgroups per CU) and the 256-row tile (one) on 32x32x16 MFMAs
         out_ring.zero_()
         assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700 | rows256, None, _p(out_ring), code, _stream()) == 0
         assert torch.equal(out_ring, out_cm)
+    # the 256-row tile on 16x16x32 MFMAs (bert_gemm_ring16.cuh, round 5): k accumulated in steps of 32 - the reference's numbers to the
+    # same tolerance, the other kernels' to one unit in the last place
+    out_ring.zero_()
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0xF00, None, _p(out_ring), code, _stream()) == 0
+    _assert_close_big(_from_cm(out_ring, M, N), ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"gemm {N}x{K} epi {epi} on 16x16x32")
+    _assert_one_ulp_apart(out_ring, out_cm, tdt, f"gemm {N}x{K} epi {epi}: 16x16x32 vs 32x32x16")
     out_ring_rm = torch.empty((M, N), dtype=tdt, device=DEV)      # ... and its row-major (LDS-staged) epilogue
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x600, None, _p(out_ring_rm), code, _stream()) == 0
     assert torch.equal(out_ring_rm, out)
@@ -560,11 +583,17 @@ def test_gemm_folded_layernorm_consumer_at_benchmark_scale(N, K, epi, dt):
         ref = torch.nn.functional.gelu(ref)
     _assert_close_big(_from_cm(out, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K}")
     out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(Ws)      # the ring kernel: identical bits
-    for rows256 in (0, 0x800):
+    for rows256 in (0, 0x1800):
         out_ring.zero_()
         rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0x700 | rows256, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None,
                                              None, _p(out_ring), code, _stream())
         assert rc == 0 and torch.equal(out_ring, out)
+    out_ring.zero_()          # the 256-row tile on 16x16x32 MFMAs
+    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0xF00, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+                                         _p(out_ring), code, _stream())
+    assert rc == 0
+    _assert_close_big(_from_cm(out_ring, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K} on 16x16x32")
+    _assert_one_ulp_apart(out_ring, out, tdt, f"folded-LN consumer {N}x{K}: 16x16x32 vs 32x32x16")
 
 
 @pytest.mark.parametrize("N,K", [(768, 768), (768, 3072)])
@@ -592,11 +621,20 @@ def test_gemm_residual_stats_producer_at_benchmark_scale(N, K, dt):
     want = torch.stack([got.reshape(M, N // 64, 64).sum(2), (got * got).reshape(M, N // 64, 64).sum(2)], 2)
     torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-3)
     out_ring, part_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), torch.zeros((M, N // 64, 2), device=DEV), _to_cm(W)
-    for rows256 in (0, 0x800):
+    for rows256 in (0, 0x1800):
         out_ring.zero_(), part_ring.zero_()
         rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0x700 | rows256, None, None, None, None, _p(R_cm), _p(mr), _p(gamma),
                                              _p(part_ring), _p(out_ring), code, _stream())
         assert rc == 0 and torch.equal(out_ring, out) and torch.equal(part_ring, part)      # the ring kernel: identical bits
+    out_ring.zero_(), part_ring.zero_()          # the 256-row tile on 16x16x32 MFMAs: its own sums, statistics of what IT stored
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0xF00, None, None, None, None, _p(R_cm), _p(mr), _p(gamma),
+                                         _p(part_ring), _p(out_ring), code, _stream())
+    assert rc == 0
+    got16 = _from_cm(out_ring, M, N).float()
+    _assert_close_big(got16, ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"residual+stats producer {N}x{K} on 16x16x32")
+    _assert_one_ulp_apart(out_ring, out, tdt, f"residual+stats producer {N}x{K}: 16x16x32 vs 32x32x16")
+    want16 = torch.stack([got16.reshape(M, N // 64, 64).sum(2), (got16 * got16).reshape(M, N // 64, 64).sum(2)], 2)
+    torch.testing.assert_close(part_ring, want16, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (512, 768, 512, 1), (768, 256, 1024, 0), (256, 256, 0x800 | 256, 0), (768, 512, 0x800 | 320, 1), (768, 512, 320, 1)])

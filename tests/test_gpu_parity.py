@@ -2356,6 +2356,71 @@ def test_knrm_lists_match_the_per_pair_kernels():
         r.test_lists({**d, "query": torch.cat([d["query"], d["query"]], dim=1)}, off)
 
 
+@pytest.mark.parametrize("kind", ["knrm", "drmm", "drmmtks", "pacrr"])
+def test_lists_of_more_than_one_query_are_refused(kind):
+    """a list is scored against its FIRST pair's query (DRMM / DRMM-TKS: and that pair's idf row).  Offsets that put
+    the pairs of two queries in one list - or a pair whose own query / idf row was edited - used to return the first query's scores
+    silently; the mark pass now compares every pair's rows with its list's and the call raises (CAPAMD_STATUS_LIST_QUERY), by the int64
+    route and through a candidate store alike.  Rows that differ only in an idf the model never reads are not an error."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.reranker import DRMM
+
+    c = load_case("knrm" if kind == "knrm" else "drmmtks" if kind in ("drmm", "drmmtks") else "pacrr", "multiquery")
+    if kind == "knrm":
+        r = _knrm_model(c)
+    elif kind == "drmm":
+        torch.manual_seed(21)
+        r = DRMM({}, SimpleNamespace(embeddings=c["emb"]))
+        r.build_model().to(DEV).eval()
+    else:
+        r = _tks_reranker(c) if kind == "drmmtks" else _pacrr_reranker(c)
+    b = _batch(c)
+    if kind == "drmm":
+        b["query"] = b["query"].clone()
+        b["query"][b["query"] < 0] = 17
+    off = np.asarray(c["list_offsets"], dtype=np.int64)
+    with torch.no_grad():
+        good = r.test_lists(b, off)                       # the fixture's own lists: fine
+        merged = np.concatenate([off[:1], off[2:]])       # lists 0 and 1 as ONE list: two queries
+        assert not torch.equal(b["query"][off[0]], b["query"][off[1]])
+        with pytest.raises(ValueError, match="more than one query"):
+            r.test_lists(b, merged)
+        assert torch.equal(r.test_lists(b, off), good)    # (the status word is clean again)
+        # one pair in the middle of a list with another query term
+        edited = {k: v.clone() for k, v in b.items()}
+        mid = int(off[2] + 3)
+        edited["query"][mid, 0] = 2 if int(edited["query"][mid, 0]) != 2 else 3
+        with pytest.raises(ValueError, match="more than one query"):
+            r.test_lists(edited, off)
+        # ... or another idf value: an error only for the models that read the list's idf row
+        edited = {k: v.clone() for k, v in b.items()}
+        edited["query_idf"][mid, 0] += 0.5
+        if kind in ("drmm", "drmmtks"):
+            with pytest.raises(ValueError, match="more than one query"):
+                r.test_lists(edited, off)
+        else:
+            r.test_lists(edited, off)
+        # through a candidate store: the pair's query ROW index decides (equal rows under two indices are one query)
+        store = CandidateStore(DEV)
+        bq, bi, bd = b["query"].cpu().numpy(), b["query_idf"].cpu().numpy(), b["posdoc"].cpu().numpy()
+        for i in range(len(off) - 1):
+            store.add_query(f"q{i}", bq[off[i]], bi[off[i]])
+        store.add_query("twin", bq[off[0]], bi[off[0]])      # the same content as q0 under another row
+        for j in range(bd.shape[0]):
+            store.add_doc(f"d{j}", bd[j])
+        store.finalize()
+        pq = np.repeat(np.arange(len(off) - 1), np.diff(off)).astype(np.int32)
+        pd = _t(np.arange(bd.shape[0], dtype=np.int32))
+        assert torch.equal(r.test_resident_lists(store, _t(pq), pd, off), good)
+        twin = pq.copy()
+        twin[int(off[0]) + 1] = len(off) - 1                  # a pair of list 0 pointing at the twin row: same query, no error
+        assert torch.equal(r.test_resident_lists(store, _t(twin), pd, off), good)
+        wrong = pq.copy()
+        wrong[int(off[0]) + 1] = 3                            # ... at another query's row
+        with pytest.raises(ValueError, match="more than one query"):
+            r.test_resident_lists(store, _t(wrong), pd, off)
+
+
 def test_drmm_lists_are_bit_identical_to_the_per_pair_kernels():
     """DRMM over whole lists: the similarities are computed by the same arithmetic and the bin counts are integers - scores, counts and
     fp16 rank order equal capamd_drmm_forward's bit for bit."""
