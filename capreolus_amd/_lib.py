@@ -102,7 +102,7 @@ SIGNATURES = {
 
 # builder-side profiling hooks (capreolus_amd/csrc/capamd_profiling.h): exported ONLY by the -DCAPAMD_PROFILING build of the library
 # (csrc/libcapreolus_amd_prof.so), never by the product library - see profiling_build()
-PROF_LIB_PATH = os.path.join(_HERE, "csrc", "libcapreolus_amd_prof.so")
+PROF_LIB_PATH = os.environ.get("CAPAMD_PROF_LIB_PATH") or os.path.join(_HERE, "csrc", "libcapreolus_amd_prof.so")  # override: ablation builds only
 PROFILING_SIGNATURES = {
     "capamd_debug_set_gemm_stamps": (None, [_vp]),
     "capamd_debug_ffn1_timing": (None, [_i]),

@@ -389,6 +389,13 @@ int64_t layer_blob_elems(int H, int F) { return layer_rowmajor_elems(H, F) * (fu
 //                | cs_qkv 3H | c_qkv 3H | cs_1 F | c_1 F | g_in H | bo + beta_in H | b2 + ln1b H      (folded-LayerNorm vectors)
 int64_t layer_f32_floats(int H, int F) { return (int64_t)9 * H + F + (int64_t)9 * H + 2 * F; }
 
+int num_cus();
+// Workgroup slots a persistent ring GEMM asks for: all CUs, or - CAPAMD_GEMM_CU_SHARE=n - 1/n of them, so that the kernels of n streams run
+// side by side on disjoint CUs with their phases (K loop / HBM-bound epilogue) out of step instead of one after the other.
+int gemm_cus() {
+  static const int share = [] { const char* e = getenv("CAPAMD_GEMM_CU_SHARE"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+  return num_cus() / share;
+}
 int num_cus() {
   static int n = [] {
     int dev = 0, cus = 256;
@@ -565,7 +572,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
           if (e != hipSuccess) return e;
           attr_set = true;
         }
-        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();
+        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < gemm_cus() ? tiles : gemm_cus();
+        static const int touch = [] { const char* e = getenv("CAPAMD_R16_TOUCH"); return (e && e[0] == '1') ? 1 : 0; }();
+        gg.res_touch = touch;
         hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
       } else if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256) {
         using R = GemmRing<EPI, T, 256>;
@@ -576,7 +585,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
           if (e != hipSuccess) return e;
           attr_set = true;
         }
-        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < num_cus() ? tiles : num_cus();  // one persistent workgroup per CU
+        const int tiles = (g.N / 256) * (g.M / 256), grid = tiles < gemm_cus() ? tiles : gemm_cus();  // one persistent workgroup per CU
         hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
       } else {
         using R = GemmRing<EPI, T, 128>;
@@ -587,7 +596,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
           if (e != hipSuccess) return e;
           attr_set = true;
         }
-        const int tiles = (g.N / 256) * (g.M / 128), cap = 2 * num_cus(), grid = tiles < cap ? tiles : cap;  // two persistent workgroups per CU
+        const int tiles = (g.N / 256) * (g.M / 128), cap = 2 * gemm_cus(), grid = tiles < cap ? tiles : cap;  // two persistent workgroups per CU
         // (a deliberate half-tile start offset of the grid's second half - CAPAMD_RING_STAGGER, in units of 64 cycles - measured 0.7 %
         // SLOWER end to end than letting the two workgroups of a CU drift apart by themselves: default 0)
         gg.ring_stagger = ring_stagger_override() >= 0 ? ring_stagger_override() : 0;

@@ -105,6 +105,7 @@ struct GemmArgs {
   float* stat_part;     // [M][N / 64][2]: (sum, sum of squares) of the 64 output columns each wave column writes
   int ring_rows;        // ring kernel: 256 = one workgroup per CU (128 x 128 wave tiles), 128 = two per CU; 0 = the library default
   int ring_mfma32;      // 256-row ring tile: stay on 32x32x16 MFMAs (bert_gemm_ring.cuh) instead of 16x16x32 (bert_gemm_ring16.cuh)
+  int res_touch;        // 16x16x32 ring, kEpiResidStats: touch the tile's residual lines in the first steps of its K loop (A/B switch; default off)
   int ring_stagger;     // ring kernel, two workgroups per CU: blocks of the grid's second half start this many x 64 cycles late
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)
 };

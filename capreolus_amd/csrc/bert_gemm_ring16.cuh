@@ -36,6 +36,10 @@ namespace capamd {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifndef CAPAMD_R16_ABL
+#define CAPAMD_R16_ABL 0   // profiling builds of the residual epilogue only: 1 no residual loads, 2 no statistics, 4 no stores, 8 no exchange
+#endif
+
 template <typename T>
 struct Mfma16;
 template <>
@@ -194,6 +198,7 @@ struct GemmRing16 {
     auto load_res = [&](int t, int buf) {   // t = i * 4 + jp: the residual where the accumulators put the value - row l15 (tile 2 jp) and 16 + l15
       const int i = t >> 2, jp = t & 3;
       const char* rp = rsrcb + (size_t)(res_off + (unsigned)i * 1024u + (unsigned)jp * jstride);
+      if (CAPAMD_R16_ABL & 1) { r4s[buf][0] = r4s[buf][1] = x4{(T)1.f, (T)1.f, (T)1.f, (T)1.f}; return; }
       r4s[buf][0] = *reinterpret_cast<const x4*>(rp);
       r4s[buf][1] = *reinterpret_cast<const x4*>(rp + 256);
     };
@@ -228,12 +233,16 @@ struct GemmRing16 {
           const uint2 u = __builtin_bit_cast(uint2, o);
           pk[h][0] = u.x; pk[h][1] = u.y;
         }
-        swap16(pk[0][0], pk[1][0]);
-        swap16(pk[0][1], pk[1][1]);
+        if (!(CAPAMD_R16_ABL & 8)) {
+          swap16(pk[0][0], pk[1][0]);
+          swap16(pk[0][1], pk[1][1]);
+        }
+        if (!(CAPAMD_R16_ABL & 4) || L.lane == 99)
         *reinterpret_cast<uint4*>(baseb + (size_t)(out_off + (unsigned)i * 1024u + (unsigned)jp * jstride)) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
         // statistics of what the consumers will read, from the registers as stored: 8 values of ONE row (l15, or 16 + l15 for odd q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (CAPAMD_R16_ABL & 2) { s1[i >> 2][jp][0] += __uint_as_float(pk[k >> 1][k & 1]); continue; }
           const f32x2 qv = Half<T>::unpack2(pk[k >> 1][k & 1]);
           s1[i >> 2][jp] += qv;
           s2[i >> 2][jp] = qv * qv + s2[i >> 2][jp];
@@ -327,6 +336,19 @@ struct GemmRing16 {
     const int a_base = L.wm * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
     const int b_base = kSlotA + L.wn * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
 
+    // kEpiResidStats: the epilogue reads the tile's 128 KiB of residual, and every CU reaches its epilogue at about the same time - 32 MB
+    // requested at once from a tensor another kernel wrote ~1 GB of traffic ago: HBM-bound, 11 k of the epilogue's 20 k cycles
+    // (profiles/r05/resid16_ablation.txt).  GemmArgs::res_touch (CAPAMD_R16_TOUCH=1; NOT the default) lets the first four steps of a tile
+    // TOUCH the wave's part of it - 4 x 8 KiB contiguous, one 128-byte line per lane, as a 4-byte LDS-DMA into the (otherwise unused)
+    // staging bytes: no destination register to keep alive - so that the lines come in under the K loop.  Measured: the epilogue 20 k ->
+    // 15 k cycles, the K loop 31.5 k -> 38.5 k (VMEM operations retire in order: a miss to HBM in the queue holds up the counted waits
+    // for the L2-hit pieces behind it) - a loss (profiles/r05/ring16_timeline_touch.txt).
+    const auto rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == kEpiResidStats ? g.res_src : g.A), 0,
+                                                        (int)((size_t)g.M * (EPI == kEpiResidStats ? g.N : g.K) * 2), 0x00020000);
+    auto touch_residual = [&](int blk, int tm0, int tn0) {
+      const unsigned soff = (unsigned)((((tm0 + L.wm * 128 + blk * 32) >> 5) * (g.N >> 3) + ((tn0 + L.wn * 128) >> 3)) * 32) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, (lds_void_t*)(lds + kRing + L.wave * G::kEpiLds + blk * 256), 4, L.lane * 128, (int)soff, 0, 0);
+    };
     Bases cur = bases_of(g, m0, n0, L.wave);
     CAPAMD_STAMP();
 #pragma unroll 1
@@ -388,6 +410,9 @@ struct GemmRing16 {
   if ((g_) & 1) { D((g_) >> 1); CAPAMD_SB; }
         CAPAMD_G16(0) CAPAMD_G16(1) CAPAMD_G16(2) CAPAMD_G16(3) CAPAMD_G16(4) CAPAMD_G16(5) CAPAMD_G16(6) CAPAMD_G16(7)
         CAPAMD_G16(8) CAPAMD_G16(9) CAPAMD_G16(10) CAPAMD_G16(11) CAPAMD_G16(12) CAPAMD_G16(13) CAPAMD_G16(14) CAPAMD_G16(15)
+        // (one more VMEM operation in flight in steps 0..3: the counted waits above only get stricter by it - everything older than the
+        // youngest kVm operations has landed, and those are a subset of what is younger than the awaited step)
+        if (EPI == kEpiResidStats && g.res_touch && s < 4) { touch_residual(s, m0, n0); CAPAMD_SB; }
 #undef CAPAMD_G16
 #undef CAPAMD_SB
 #undef CAPAMD_M16

@@ -11,7 +11,13 @@ M = 64000
 def to_cm(x):
     M_, C = x.shape
     return x.reshape(M_ // 32, 32, C // 8, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
-for name, N, K, epi in [("qkv-like bias", 2304, 768, 0), ("ffn1 gelu", 3072, 768, 1), ("oproj resid", 768, 768, 5), ("ffn2 resid", 768, 3072, 5)]:
+SHAPES = [("qkv-like bias", 2304, 768, 0), ("ffn1 gelu", 3072, 768, 1), ("oproj resid", 768, 768, 5), ("ffn2 resid", 768, 3072, 5)]
+if os.environ.get("ONLY"):
+    SHAPES = [x for x in SHAPES if x[0].startswith(os.environ["ONLY"])]
+KERNELS = ((0x700, "ring128/32"), (0x1F00, "ring256/32"), (0xF00, "ring256/16"))
+if os.environ.get("ONLY16"):
+    KERNELS = KERNELS[2:]
+for name, N, K, epi in SHAPES:
     A = to_cm((torch.randn((M, K), device=dev) * 0.5).bfloat16()); Wc = to_cm((torch.randn((N, K), device=dev) * 0.05).bfloat16())
     bias = torch.randn(N, device=dev)
     out = torch.empty(M * N, dtype=torch.bfloat16, device=dev)
@@ -22,7 +28,7 @@ for name, N, K, epi in [("qkv-like bias", 2304, 768, 0), ("ffn1 gelu", 3072, 768
         if epi == 5:
             return lib.capamd_bert_gemm_ln(vp(A), vp(Wc), vp(bias), M, N, K, 5 | flags, None, None, None, None, vp(R), vp(mr), vp(gamma), vp(part), vp(out), 0, st)
         return lib.capamd_bert_gemm(vp(A), vp(Wc), vp(bias), M, N, K, epi | flags, None, vp(out), 0, st)
-    for flags, tag in ((0x700, "ring128/32"), (0x1F00, "ring256/32"), (0xF00, "ring256/16")):
+    for flags, tag in KERNELS:
         stamps = torch.zeros((512, 32), dtype=torch.int64, device=dev)
         ts = []
         for i in range(8):
