@@ -60,6 +60,12 @@ def algorithmic_bytes_per_pair(model, Q, L, D):
     return b + (4 * Q if model == "drmm" else 0)
 
 
+def default_queries(model):
+    """Queries per step when --queries is not given: 64 (configs[1] as SURVEY 8(d) concretises it); DRMM: 250 - configs[2] stands in for
+    Robust04's 250 topics x BM25 top-1000."""
+    return 250 if model == "drmm" else 64
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,7 +73,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="knrm", choices=["knrm", "drmm", "bert", "drmmtks", "pacrr", "convknrm"],
                     help="knrm (default, BASELINE.json's metric) | drmm | bert | the row-N4 siblings drmmtks, pacrr, convknrm")
-    ap.add_argument("--queries", type=int, default=0, help="queries per step per GPU (0 = 64 for the interaction models, 1 for bert)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step per GPU (0 = 64 for the interaction models - 250 for drmm, configs[2] - and 1 for bert)")
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
     ap.add_argument("--launch-streams", type=int, default=4,
@@ -168,6 +174,8 @@ def compact(rec, full_path):
         out["parity"] = _pick(rec["parity"], ("dtype", "documents", "max_score_error_of_scale_vs_fp32_port"))
     if isinstance(rec.get("other_operand_type"), dict):
         out["other_operand_type"] = _pick(rec["other_operand_type"], ("dtype", "value", "ms_per_step", "whole_step_frac", "whole_step_frac_nominal"))
+    if isinstance(rec.get("zero_idf_run"), dict):
+        out["zero_idf_run"] = _pick(rec["zero_idf_run"], ("value", "unit", "ms_per_step", "steps"))
     also = []
     for a in rec.get("also", []) or []:
         if not isinstance(a, dict) or "error" in a:
@@ -184,6 +192,8 @@ def compact(rec, full_path):
             e["oracle_err"] = a["oracle_check"].get("max_err_of_scale")
         if isinstance(a.get("other_operand_type"), dict):
             e["other_operand_type"] = _pick(a["other_operand_type"], ("dtype", "value", "whole_step_frac", "whole_step_frac_nominal"))
+        if isinstance(a.get("zero_idf_run"), dict):
+            e["zero_idf_run"] = _pick(a["zero_idf_run"], ("value", "ms_per_step"))
         also.append(e)
     if also:
         out["also"] = also
@@ -326,7 +336,7 @@ def table(dev, V, D):
 class InteractionLeg:
     """KNRM / DRMM over `nb` distinct batches of `n_queries` x `docs` candidate lists on one GPU."""
 
-    def __init__(self, args, ctx, model, V, uniform, n_queries, nb, seed0):
+    def __init__(self, args, ctx, model, V, uniform, n_queries, nb, seed0, zero_idf=False):
         from types import SimpleNamespace
 
         from capreolus_amd import engine, synthetic
@@ -343,6 +353,8 @@ class InteractionLeg:
                                                         uniform_ids=uniform)
             if model == "drmm":
                 batch["query"] = batch["query"].clamp(min=0)
+            if zero_idf:        # EmbedText's default behaviour (no idf computed: all zeros) - SURVEY 8(d), configs[2]'s second run
+                batch["query_idf"] = torch.zeros_like(batch["query_idf"])
             self.batches.append(batch)
         torch.manual_seed(0)
         stub = SimpleNamespace(embeddings=np.zeros((2, self.D), dtype=np.float32))
@@ -591,7 +603,7 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
         def unit(name):
             return mine(name)
     else:
-        child += ["--vocab", str(args.vocab), "--queries", str(args.queries or 64), "--docs", str(args.docs), "--no-pass-times"]
+        child += ["--vocab", str(args.vocab), "--queries", str(args.queries or default_queries(model)), "--docs", str(args.docs), "--no-pass-times"]
 
         def mine(name):
             return "lists_" in name or "fillBuffer" in name
@@ -685,8 +697,20 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     per_rank_q = n_queries // world if strong else n_queries
     if strong and n_queries % world:
         raise SystemExit("--scaling strong needs --queries divisible by the number of GPUs")
-    leg = InteractionLeg(args, ctx, model, args.vocab, args.uniform_ids, per_rank_q, max(1, args.batches), 1 + ctx.rank)
+    nb = max(1, args.batches if model == "knrm" else min(args.batches, 2))      # (a DRMM batch is 250,000 pairs = 1.6 GB of id rows)
+    leg = InteractionLeg(args, ctx, model, args.vocab, args.uniform_ids, per_rank_q, nb, 1 + ctx.rank)
     elapsed, dev_s = leg.run(warmup, steps)
+    zero_idf = None
+    if model == "drmm" and world == 1 and not args.uniform_ids:
+        # configs[2]'s second run: the same lists with the all-zero idf rows EmbedText produces by default
+        z = InteractionLeg(args, ctx, model, args.vocab, args.uniform_ids, per_rank_q, 1, 1 + ctx.rank, zero_idf=True)
+        z_elapsed, _ = z.run(2, max(3, steps // 2))
+        z_err = z.check_against_oracle(min(64, z.n_pairs))[2]       # (the timed scores of its last step against the C oracle)
+        zero_idf = {"value": z.n_pairs * max(3, steps // 2) / z_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * z_elapsed / max(3, steps // 2),
+                    "steps": max(3, steps // 2), "query_idf": "all zeros (EmbedText without an idf table, extractor/embedtext.py:86-96)",
+                    "oracle_check": z_err}
+        del z
+        torch.cuda.empty_cache()
     n_pairs = leg.n_pairs
     req_b, nonpad, distinct = leg.bytes_requested_per_pair()
     abytes = algorithmic_bytes_per_pair(model, Q, L, D)
@@ -796,13 +820,16 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                         f"{'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, lognormal doc lengths, "
                         + ("scored as whole candidate lists, " if leg.lists else "") +
                         f"{launches} launch(es) per step" + (f" round-robin over {len(leg.side)} HIP streams" if leg.side else "") + (", replayed as one captured HIP graph" if leg.graphs else "") +
-                        f", {len(leg.batches)} distinct batches in rotation",
+                        f", {len(leg.batches)} distinct batches in rotation"
+                        + (", query_idf ~ U(0.5, 8) per query (a second run with all-zero idf rows: zero_idf_run)" if model == "drmm" else ""),
             "pairs_per_step_per_gpu": n_pairs,
             "parallelism": f"query-sharded x{world}, one all_gather of scores per step (asynchronous, under the next step's scoring)" if world > 1 else "single GPU",
         },
         "roofline": roof if roof is not None else {"bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": None, "peak": HBM_PEAK_GBS,
                                                    "unit": "GB/s", "frac": None, "traffic": None, "headline_leg": headline},
     }
+    if zero_idf is not None:
+        rec["zero_idf_run"] = zero_idf
     if ctx.use_dist:
         rec["collective"] = collective_info(ctx, n_pairs)
     if with_cpu and world == 1:
@@ -833,7 +860,7 @@ def main():
     elif args.model in ("drmmtks", "pacrr", "convknrm"):
         rec = bench_sibling(args, ctx)
     else:
-        rec = interaction_record(args, ctx, args.model, args.steps, args.warmup, args.queries or 64, with_cpu=not args.no_cpu_baseline)
+        rec = interaction_record(args, ctx, args.model, args.steps, args.warmup, args.queries or default_queries(args.model), with_cpu=not args.no_cpu_baseline)
         default_line = args.model == "knrm" and ctx.world == 1 and not args.no_also and not args.uniform_ids and not args.launch_docs and not args.resident
         if default_line and ctx.rank == 0:
             # the other two north-star models, timed by the same driver run (short legs; their own roofline / cpu_baseline)
@@ -841,7 +868,7 @@ def main():
             torch.cuda.empty_cache()
             rec["also"] = []
             # ... and the row-N4 siblings (short legs: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)
-            for leg in (lambda: interaction_record(args, ctx, "drmm", args.steps, 3, 64, with_cpu=not args.no_cpu_baseline),     # (a 1.3 ms step: as many as the headline)
+            for leg in (lambda: interaction_record(args, ctx, "drmm", max(5, args.steps // 2), 3, default_queries("drmm"), with_cpu=not args.no_cpu_baseline),
                         lambda: bench_bert(args, ctx, 5, 2, with_cpu=not args.no_cpu_baseline),
                         lambda: bench_sibling(args, ctx, "drmmtks", 5, 2, with_cpu=False),
                         lambda: bench_sibling(args, ctx, "pacrr", 5, 2, with_cpu=False),
