@@ -176,6 +176,8 @@ def compact(rec, full_path):
         out["other_operand_type"] = _pick(rec["other_operand_type"], ("dtype", "value", "ms_per_step", "whole_step_frac", "whole_step_frac_nominal"))
     if isinstance(rec.get("zero_idf_run"), dict):
         out["zero_idf_run"] = _pick(rec["zero_idf_run"], ("value", "unit", "ms_per_step", "steps"))
+    if isinstance(rec.get("resident_int32_route"), dict):
+        out["resident_int32_route"] = _pick(rec["resident_int32_route"], ("value", "unit", "ms_per_step", "error"))
     also = []
     for a in rec.get("also", []) or []:
         if not isinstance(a, dict) or "error" in a:
@@ -645,6 +647,15 @@ F32_PEAK_TFLOPS = 157.3        # fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.
 # kernel's evaluation (v_fma, v_mul, v_exp_f32, v_add per value), every SIMD busy; profiles/r04/valu_rates.txt
 KERNEL_EVAL_PEAK_G = 7150.0
 SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("mfma" once they are v_mfma_f32_4x4x1_16b_f32)
+# What binds the sims pass, from the builder-run counter passes (scripts/dbg/pmc_lists.sh -> profiles/r05/pmc_lists_{knrm,drmm}.txt; PMC runs
+# cannot share a process with the timed loop): VALU issue utilisation = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (SIMDs x kernel cycles),
+# L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS), waves waiting = SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY, fma share = packed fmas / SQ_INSTS_VALU.
+# No single pipe is saturated: the VALU issues half of the cycles (37 % of what it issues are the dot products' packed fmas, 30 % the
+# per-workgroup prologue - flag scan, query copy - of ~123 rows each), a sixth of the row requests miss L2, and with every row load
+# redirected to 16 hot rows the pass still takes 214 of its 289 us.  The register-resident query (lists_sims_qreg_kernel, round 5) - no
+# LDS reads at all, occupancy 3 instead of 6 - is 30-70 % SLOWER (profiles/r05/lists_sims_qreg_ab.txt): latency, not the LDS pipe.
+SIMS_LIMITER = {"bound": "latency (VALU issue 0.52 of the cycles, L2 hit rate 0.84; no pipe saturated)", "valu_issue_utilisation": 0.52, "l2_hit_rate": 0.84,
+                "waves_waiting_over_issuing": 2.9, "packed_fma_share_of_valu_instructions": 0.37, "source": "profiles/r05/pmc_lists_knrm.txt (builder-run counter passes)"}
 
 
 def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic, traffic_src):
@@ -659,6 +670,8 @@ def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic
             e.update(bound="hbm", achieved=q["bytes_cleared"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         elif "fp32_fma" in q:
             e.update(bound=q.get("pipe", "valu"), achieved=2 * q["fp32_fma"] / (ms * 1e-3) / 1e12, peak=F32_PEAK_TFLOPS, unit="TFLOP/s")
+            if q.get("pipe", "valu") == "valu":      # (priced against the fp32 vector peak - the pipe its arithmetic runs on - but bound by its waits)
+                e.update(bound="latency", limiter=SIMS_LIMITER)
         elif "exponentials" in q:
             e.update(bound="valu", achieved=q["exponentials"] / (ms * 1e-3) / 1e9, peak=KERNEL_EVAL_PEAK_G, unit="G kernel evaluations/s")
         elif "id_row_bytes" in q:
@@ -865,6 +878,22 @@ def main():
         if default_line and ctx.rank == 0:
             # the other two north-star models, timed by the same driver run (short legs; their own roofline / cpu_baseline)
             short = max(5, min(args.steps, 10))
+            torch.cuda.empty_cache()
+            try:
+                # the same lists through a device-resident candidate store (int32 id tables + index pairs: what `PytorchTrainer.predict` scores
+                # from its second call on) - half the id-row bytes of the int64 headline
+                import copy
+
+                a2 = copy.copy(args)
+                a2.resident = True
+                rl = InteractionLeg(a2, ctx, "knrm", args.vocab, False, args.queries or 64, 2, 1 + ctx.rank)
+                r_elapsed, _ = rl.run(3, args.steps)
+                rl.check_against_oracle(min(64, rl.n_pairs))
+                rec["resident_int32_route"] = {"value": rl.n_pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps,
+                                               "what": "bench.py --resident: the headline's lists as int32 tables + index pairs (capamd_knrm_forward_lists, indexed form)"}
+                del rl
+            except Exception as e:  # noqa: BLE001
+                rec["resident_int32_route"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
             rec["also"] = []
             # ... and the row-N4 siblings (short legs: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)

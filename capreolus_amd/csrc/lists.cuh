@@ -349,8 +349,19 @@ constexpr bool kSimsOnMfma = true;
 #define CAPAMD_SIMS_KERNEL lists_sims_mfma_kernel
 #else
 constexpr bool kSimsOnMfma = false;
+#ifndef CAPAMD_LISTS_SIMS_QREG
+#define CAPAMD_LISTS_SIMS_QREG 0       // 1: lists_sims_qreg_kernel - the list's query rows in REGISTERS instead of LDS (see there)
+#endif
+#if CAPAMD_LISTS_SIMS_QREG
+#define CAPAMD_SIMS_KERNEL lists_sims_qreg_kernel
+#else
 #define CAPAMD_SIMS_KERNEL lists_sims_kernel
 #endif
+#endif
+#ifndef CAPAMD_SIMS_QREG_BLOCKS
+#define CAPAMD_SIMS_QREG_BLOCKS 4      // id blocks (of kSimsIds ids) one workgroup of lists_sims_qreg_kernel walks with one copy of the query
+#endif
+constexpr int kSimsBlocksPerWG = (CAPAMD_LISTS_SIMS_QREG && !kSimsOnMfma) ? CAPAMD_SIMS_QREG_BLOCKS : 1;
 template <int NV>
 __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom g) {
   __shared__ __attribute__((aligned(16))) float4 qlds[kQueryImage];
@@ -477,6 +488,112 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
   }
   // (one row per trip with the NEXT row requested before the current one is used - a software pipeline - is 4-5 % slower end to end;
   //  FOUR rows per trip - half the LDS query reads per row, twice the loads in flight, 126 registers - 10 % slower: 317-327 against 291-293 us)
+}
+
+// The same pass with the list's query rows in REGISTERS (round 5; -DCAPAMD_LISTS_SIMS_QREG=1).  lists_sims_kernel reads the query copy
+// from LDS again for every pair of rows: 20 ds_read_b128 per lane and trip = 20 KiB per wave and trip, 8 GB per call through a 128 B/clk
+// LDS pipe - 117 us of LDS time beside 108 us of VALU time in a 289 us pass, and a dependent wait per read.  A lane only ever needs ITS 20
+// float4 of the image (2 term pairs x NV chunks x 2 halves at its lane16): 80 registers, loaded once per workgroup, which then walks
+// kSimsBlocksPerWG id blocks with them.  Same fma order per (row, term) as rows_dot2_pk: the same bits.
+template <int NV>
+__device__ __forceinline__ void rows_dot2_pk_reg(const RowRegs<NV>& d0, const RowRegs<NV>& d1, const float4 (&qr)[2 * NV * 2], float (&p0)[kQT],
+                                                 float (&p1)[kQT]) {
+  f32x2 acc0[2] = {{0.f, 0.f}, {0.f, 0.f}}, acc1[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const float4 qa = qr[(P * NV + i) * 2 + 0], qb = qr[(P * NV + i) * 2 + 1];
+      f32x2 a = acc0[P], b = acc1[P];
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].x, d0.v[i].x}, (f32x2){qa.x, qa.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].x, d1.v[i].x}, (f32x2){qa.x, qa.y}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].y, d0.v[i].y}, (f32x2){qa.z, qa.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].y, d1.v[i].y}, (f32x2){qa.z, qa.w}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].z, d0.v[i].z}, (f32x2){qb.x, qb.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].z, d1.v[i].z}, (f32x2){qb.x, qb.y}, b);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].w, d0.v[i].w}, (f32x2){qb.z, qb.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].w, d1.v[i].w}, (f32x2){qb.z, qb.w}, b);
+      acc0[P] = a;
+      acc1[P] = b;
+    }
+  }
+  p0[0] = acc0[0].x; p0[1] = acc0[0].y; p0[2] = acc0[1].x; p0[3] = acc0[1].y;
+  p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
+}
+
+template <int NV, bool BINS>
+__global__ __launch_bounds__(256, 2) void lists_sims_qreg_kernel(ListsArgs a, ListGeom g) {
+  __shared__ int lst[kSimsIds];
+  __shared__ int wave_cnt[4];
+  __shared__ float edges[kMaxBins];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane16 = tid & 15, grp = tid >> 4;
+  const int l = blockIdx.x >> 3, blk0 = (blockIdx.y * 8 + (blockIdx.x & 7)) * kSimsBlocksPerWG;
+  if ((int64_t)blk0 * kSimsIds >= a.Vp) return;
+  constexpr int kPer = kSimsIds / 256;
+  float4 qr[2 * NV * 2];
+  {
+    const float4* img = a.qimg + (int64_t)l * kQueryImage;
+#pragma unroll
+    for (int k = 0; k < 2 * NV * 2; ++k) qr[k] = img[k * 16 + lane16];
+  }
+  QueryPass<NV> qp;
+  qp.den_my = a.qmeta[l].den[lane16 & 3];
+  qp.id_my = a.qmeta[l].id[lane16 & 3];
+  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
+  float* tab = reinterpret_cast<float*>(a.table + (int64_t)l * a.Vp);
+  uint8_t* tabb = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l * a.Vp);
+  auto put = [&](int id, float sm) {
+    if (lane16 < kQT) {
+      if (BINS) {
+        const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
+        tabb[(int64_t)id * 4 + lane16] = (uint8_t)bin;
+      } else {
+        tab[(int64_t)id * 4 + lane16] = sm;
+      }
+    }
+  };
+#pragma unroll 1
+  for (int bi = 0; bi < kSimsBlocksPerWG; ++bi) {
+    const int id0 = (blk0 + bi) * kSimsIds;
+    if (id0 >= a.Vp) break;
+    if (id0 + kSimsIds <= a.H) continue;
+    const uint8_t* fp = a.flags + (int64_t)l * a.Vp + id0 + tid * kPer;
+    uint64_t fw = kPer == 2 ? (uint64_t)*reinterpret_cast<const uint16_t*>(fp) : kPer == 4 ? (uint64_t)*reinterpret_cast<const uint32_t*>(fp)
+                                                                                           : *reinterpret_cast<const uint64_t*>(fp);
+    {
+      const int below = a.H - (id0 + tid * kPer);
+      if (below > 0) fw = below >= kPer ? 0ull : fw & (~0ull << (8 * below));
+    }
+    int slot[kPer], mine = 0;
+#pragma unroll
+    for (int c = 0; c < kPer; ++c) {
+      const uint64_t set = __ballot(((fw >> (8 * c)) & 0xffu) != 0);
+      slot[c] = mine + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u));
+      mine += __builtin_popcountll(set);
+    }
+    __syncthreads();             // (the previous block's list and counts have been read by everyone)
+    if (lane == 0) wave_cnt[wave] = mine;
+    __syncthreads();
+    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+    const int total = c0 + c1 + c2 + c3;
+    if (total == 0) continue;
+    const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+#pragma unroll
+    for (int c = 0; c < kPer; ++c)
+      if ((fw >> (8 * c)) & 0xffu) lst[base + slot[c]] = tid * kPer + c;
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int e = grp; e < total; e += 2 * kGroupsPerWG) {
+      const int ida = id0 + lst[e], idb = id0 + lst[e + kGroupsPerWG < total ? e + kGroupsPerWG : e];
+      RowRegs<NV> da, db;
+      load_row<NV>(a.packed, ida, lane16, da);
+      load_row<NV>(a.packed, idb, lane16, db);
+      float pa[kQT], pb[kQT];
+      rows_dot2_pk_reg<NV>(da, db, qr, pa, pb);
+      put(ida, sim_from_dots<NV>(pa, row_den<NV>(da), qp, lane16));
+      put(idb, sim_from_dots<NV>(pb, row_den<NV>(db), qp, lane16));
+    }
+  }
 }
 
 #endif
@@ -843,7 +960,7 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       else hipLaunchKernelGGL(lists_mark_kernel<false>, list_doc_grid(nl, am.longest), dim3(256), 0, s, am, g);
     }
     lists_stamp(s);
-    const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
+    const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 8 * kSimsBlocksPerWG - 1) / (8 * kSimsBlocksPerWG)));
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl), dim3(128), 0, s, a, g);                                  \
   lists_stamp(s);                                                                                               \
