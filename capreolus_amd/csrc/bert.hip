@@ -499,10 +499,10 @@ int ring_rows() {   // CAPAMD_RING_BM=256: one workgroup per CU with 128 x 128 w
 // shape (16x16x32, bert_gemm_ring16.cuh, or 32x32x16).  Defaults = what measured fastest inside the encoder at M = 64,000
 // (profiles/r05/bert_gemm_pick_ab.txt); CAPAMD_GEMM_PICK="qkv=256x16,ffn1=128,oproj=256x32,ffn2=256x32" overrides any of them (A/B runs),
 // CAPAMD_RING_BM every one alike.
-struct GemmPick { int rows, mfma32; };
+struct GemmPick { int rows, mfma32, mfma16; };   // mfma32: 256 rows on 32x32x16; mfma16: 128 rows on 16x16x32
 GemmPick gemm_pick(int kind /* 0 QKV, 1 FFN1, 2 O-proj, 3 FFN2 */) {
   static const struct Picks { GemmPick p[4]; } picks = [] {
-    Picks k{{{256, 0}, {128, 0}, {256, 0}, {256, 0}}};
+    Picks k{{{256, 0, 0}, {128, 0, 0}, {256, 0, 0}, {256, 0, 0}}};
     const char* names[4] = {"qkv=", "ffn1=", "oproj=", "ffn2="};
     if (const char* e = getenv("CAPAMD_GEMM_PICK"))
       for (int i = 0; i < 4; ++i)
@@ -510,6 +510,7 @@ GemmPick gemm_pick(int kind /* 0 QKV, 1 FFN1, 2 O-proj, 3 FFN2 */) {
           const char* v = f + strlen(names[i]);
           k.p[i].rows = atoi(v) == 256 ? 256 : 128;
           k.p[i].mfma32 = strncmp(v, "256x32", 6) == 0 ? 1 : 0;
+          k.p[i].mfma16 = strncmp(v, "128x16", 6) == 0 ? 1 : 0;
         }
     if (const char* e = getenv("CAPAMD_RING_BM"))
       for (int i = 0; i < 4; ++i) k.p[i].rows = atoi(e) == 256 ? 256 : 128;
@@ -562,10 +563,12 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       if (!g.a_cm || !ring_shape(g.M, g.N, g.K) || (EPI == kEpiResidStats && !g.out_cm)) return hipErrorInvalidValue;
       GemmArgs gg = g;
       gg.ngroup = column_group(g.N / 256, g.K);
-      if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256 && ring16_enabled() && !g.ring_mfma32 && g.out_cm && g.K % 64 == 0) {
+      const int rows = g.ring_rows ? g.ring_rows : ring_rows();
+      const bool r16 = ring16_enabled() && !g.ring_mfma32 && g.out_cm && g.K % 64 == 0;
+      if (rows == 256 && r16) {
         // one workgroup per CU on 16x16x32 MFMAs (bert_gemm_ring16.cuh)
-        using R = GemmRing16<EPI, T>;
-        auto k = gemm_ring16_kernel<EPI, T>;
+        using R = GemmRing16<EPI, T, 256>;
+        auto k = gemm_ring16_kernel<EPI, T, 256>;
         static bool attr_set = false;
         if (!attr_set) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
@@ -576,6 +579,20 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         static const int touch = [] { const char* e = getenv("CAPAMD_R16_TOUCH"); return (e && e[0] == '1') ? 1 : 0; }();
         gg.res_touch = touch;
         hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+      } else if (rows == 128 && r16 && g.ring_mfma16 && EPI != kEpiQkv) {
+        // two workgroups per CU on 16x16x32 MFMAs (the 128-row form of bert_gemm_ring16.cuh; no V^T tiles)
+        if constexpr (EPI != kEpiQkv) {
+          using R = GemmRing16<EPI, T, 128>;
+          auto k = gemm_ring16_kernel<EPI, T, 128>;
+          static bool attr_set = false;
+          if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R::kLdsBytes);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+          }
+          const int tiles = (g.N / 256) * (g.M / 128), cap = 2 * gemm_cus(), grid = tiles < cap ? tiles : cap;
+          hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
+        }
       } else if ((g.ring_rows ? g.ring_rows : ring_rows()) == 256) {
         using R = GemmRing<EPI, T, 256>;
         auto k = gemm_ring_kernel<EPI, T, 256>;
@@ -900,7 +917,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         if (l == 0) { g.W = wqkv + cmo; g.bias = bqkv; }
         else { g.W = wqkv_s + cmo; g.bias = c_qkv; g.ln_cs = cs_qkv; g.ln_mu = w.mu_x; g.ln_rstd = w.rstd_x; g.ln_mr = w.mr_x; }
         g.w_cm = ring;
-        g.ring_rows = gemm_pick(0).rows; g.ring_mfma32 = gemm_pick(0).mfma32;
+        g.ring_rows = gemm_pick(0).rows; g.ring_mfma32 = gemm_pick(0).mfma32; g.ring_mfma16 = gemm_pick(0).mfma16;
         e = launch_gemm<kEpiQkv, T>(g, s);
         if (e != hipSuccess) break;
         AttnArgs at{w.q, w.k, w.vt, mask_mb, w.ctx, H, m->heads, 1, ring ? 1 : 0};
@@ -941,7 +958,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         // (ring kernel, measured per GEMM inside the encoder at M = 64,000: the residual + statistics producers run faster on its 256-row
         // tile - 181 us against 200 on the 128-row tile and 193 on the ping-pong kernel - QKV and FFN1, with their heavier epilogues,
         // on the 128-row tile whose two workgroups per CU overlap epilogue and K loop: 248 / 341 us against 253 / 356)
-        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(2).rows; g.ring_mfma32 = gemm_pick(2).mfma32;
+        g.M = (int)M; g.N = H; g.K = H; g.A = w.ctx; g.a_cm = ring; g.W = wo + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(2).rows; g.ring_mfma32 = gemm_pick(2).mfma32; g.ring_mfma16 = gemm_pick(2).mfma16;
         g.bias = bo_f; g.out_bf16 = w.pre; g.out_cm = 1;
         g.res_src = w.xb; g.res_mr = w.mr_x; g.res_gamma = g_in; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
@@ -951,14 +968,14 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         g = GemmArgs{};
         g.M = (int)M; g.N = F; g.K = H; g.A = w.pre; g.a_cm = 1; g.W = w1_s + cmo; g.w_cm = ring; g.bias = c_1; g.ln_cs = cs_1; g.ln_mu = w.mu_p; g.ln_rstd = w.rstd_p; g.ln_mr = w.mr_p;
         g.out_bf16 = w.mid; g.out_cm = 1;
-        g.ring_rows = gemm_pick(1).rows; g.ring_mfma32 = gemm_pick(1).mfma32;
+        g.ring_rows = gemm_pick(1).rows; g.ring_mfma32 = gemm_pick(1).mfma32; g.ring_mfma16 = gemm_pick(1).mfma16;
         Ffn1Timing::begin(s);
         e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);
         Ffn1Timing::end(s, M);
         if (e != hipSuccess) break;
         // xb = mid W2^T + b2 + LN1(pre)   (+ row statistics of xb)
         g = GemmArgs{};
-        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(3).rows; g.ring_mfma32 = gemm_pick(3).mfma32;
+        g.M = (int)M; g.N = H; g.K = F; g.A = w.mid; g.a_cm = 1; g.W = w2 + cmo; g.w_cm = ring; g.ring_rows = gemm_pick(3).rows; g.ring_mfma32 = gemm_pick(3).mfma32; g.ring_mfma16 = gemm_pick(3).mfma16;
         g.bias = b2_f; g.out_bf16 = w.xb; g.out_cm = 1;
         g.res_src = w.pre; g.res_mr = w.mr_p; g.res_gamma = ln1g; g.stat_part = w.part;
         e = launch_gemm<kEpiResidStats, T>(g, s);
@@ -1233,6 +1250,7 @@ int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
   g.ring_mfma32 = (epilogue & CAPAMD_GEMM_RING_MFMA32) ? 1 : 0;
+  g.ring_mfma16 = (epilogue & CAPAMD_GEMM_RING_MFMA16) ? 1 : 0;
   epilogue &= 0xff;
   if ((g.a_cm || g.out_cm) && (!pingpong_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K) || epilogue == kEpiBiasResidBf16)) return CAPAMD_ERR_ARG;
@@ -1254,6 +1272,7 @@ int capamd_bert_gemm_ln(const void* A, const void* W, const float* bias, int M, 
   g.w_cm = (epilogue & CAPAMD_GEMM_W_CHUNK_MAJOR) ? 1 : 0;
   g.ring_rows = (epilogue & CAPAMD_GEMM_RING_256) ? 256 : 0;
   g.ring_mfma32 = (epilogue & CAPAMD_GEMM_RING_MFMA32) ? 1 : 0;
+  g.ring_mfma16 = (epilogue & CAPAMD_GEMM_RING_MFMA16) ? 1 : 0;
   epilogue &= 0xff;
   if (g.w_cm && (!g.a_cm || !ring_shape(M, N, K))) return CAPAMD_ERR_ARG;
   if (ln_mu) {

@@ -104,6 +104,7 @@ struct GemmArgs {
   const float* res_gamma;                      // [N]
   float* stat_part;     // [M][N / 64][2]: (sum, sum of squares) of the 64 output columns each wave column writes
   int ring_rows;        // ring kernel: 256 = one workgroup per CU (128 x 128 wave tiles), 128 = two per CU; 0 = the library default
+  int ring_mfma16;      // 128-row ring tile: on 16x16x32 MFMAs (bert_gemm_ring16.cuh, two workgroups per CU) instead of 32x32x16
   int ring_mfma32;      // 256-row ring tile: stay on 32x32x16 MFMAs (bert_gemm_ring.cuh) instead of 16x16x32 (bert_gemm_ring16.cuh)
   int res_touch;        // 16x16x32 ring, kEpiResidStats: touch the tile's residual lines in the first steps of its K loop (A/B switch; default off)
   int ring_stagger;     // ring kernel, two workgroups per CU: blocks of the grid's second half start this many x 64 cycles late

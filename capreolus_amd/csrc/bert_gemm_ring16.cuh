@@ -55,19 +55,28 @@ struct Mfma16<_Float16> {
   static __device__ __forceinline__ void acc(f32x4& c, x8 a, x8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
 };
 
-template <int EPI, typename T>
+// BM = 256: one workgroup per CU (wave tile 128 x 128, ring of 4 steps).  BM = 128: TWO workgroups per CU (wave tile 64 x 128: 32
+// accumulators of 4 AGPRs + 96 fragment registers of a wave's 256; ring of 3 steps x 24 KiB) that run unsynchronised, so one workgroup's
+// epilogue - FFN1's erf-GELU is 15.8 k cycles on one wave per SIMD beside a 30.5 k K loop - overlaps the other's K loop; no LDS staging
+// bytes, so no V^T tiles (QKV stays on 256 rows).
+template <int EPI, typename T, int BM = 256>
 struct GemmRing16 {
-  using G = GemmKernel<256, 256, 2, 2, EPI, T>;   // tile schedule (tile_of), V^T addressing (out_offset), staging bytes
+  static_assert(BM == 256 || BM == 128, "tile rows");
+  using G = GemmKernel<BM, 256, 2, 2, EPI, T>;    // tile schedule (tile_of), V^T addressing (out_offset), staging bytes
   using x8 = typename Half<T>::x8;
   using x4 = typename Half<T>::x4;
-  static constexpr int NI = 8, NJ = 8;                       // 16 x 16 tiles of a wave: i along n, j along m
-  static constexpr int P = 4;                                // 1-KiB pieces of a k-slice per wave (8 A + 8 B over four waves)
-  static constexpr int kSlotA = 8 * 1024, kSlot = 16 * 1024, kSlots = 8, kRing = kSlot * kSlots;
+  static constexpr int WM = BM / 2;                          // rows of a wave's tile
+  static constexpr int NI = 8, NJ = WM / 16;                 // 16 x 16 tiles of a wave: i along n, j along m
+  static constexpr int kPiecesA = BM / 32, kPieces = kPiecesA + 8, P = kPieces / 4;   // 1-KiB pieces of a k-slice; per wave
+  static constexpr int kSlotA = kPiecesA * 1024, kSlot = kPieces * 1024, kSteps = BM == 256 ? 4 : 3, kSlots = 2 * kSteps, kRing = kSlot * kSlots;
   static constexpr int kThreads = 256;
-  static constexpr int kLdsBytes = kRing + 4 * G::kEpiLds;
+  static constexpr int kWgPerCu = BM == 256 ? 1 : 2;
+  static constexpr int kLdsBytes = kRing + (BM == 256 ? 4 * G::kEpiLds : 0);
   static constexpr int kEpiVmem = 32;                        // VMEM instructions every epilogue issues per wave, at least
-  static constexpr int kVm = 2 * 2 * P;                      // pieces of the two youngest steps may stay in flight at the top of a step
-  static_assert(kVm + kEpiVmem <= 63 && kLdsBytes <= 160 * 1024, "vmcnt immediate / LDS budget");
+  static constexpr int kVm = (kSteps - 2) * 2 * P;           // pieces of the youngest kSteps - 2 steps may stay in flight at the top of a step
+  static_assert(kPiecesA % 4 == 0, "a wave's p-th piece is an A piece or a B piece for all four waves alike");
+  static_assert(BM == 256 || EPI != kEpiQkv, "V^T tiles are regrouped through LDS staging bytes only the 256-row tile has");
+  static_assert(kVm + kEpiVmem <= 63 && kLdsBytes * kWgPerCu <= 160 * 1024, "vmcnt immediate / LDS budget");
   static_assert(EPI == kEpiBiasBf16 || EPI == kEpiBiasGeluBf16 || EPI == kEpiQkv || EPI == kEpiResidStats, "epilogues of the fused encoder");
 
   static constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
@@ -80,8 +89,8 @@ struct GemmRing16 {
     Bases b;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int pc = wave + 4 * p;     // piece: 0..7 A row blocks, 8..15 B row blocks
-      b.off[p] = p < 2 ? (unsigned)(((m0 >> 5) + pc) * (g.K >> 3)) * 512u : (unsigned)(((n0 >> 5) + pc - 8) * (g.K >> 3)) * 512u;
+      const int pc = wave + 4 * p;     // piece: the first kPiecesA are A row blocks, the other 8 B row blocks
+      b.off[p] = 4 * p < kPiecesA ? (unsigned)(((m0 >> 5) + pc) * (g.K >> 3)) * 512u : (unsigned)(((n0 >> 5) + pc - kPiecesA) * (g.K >> 3)) * 512u;
     }
     return b;
   }
@@ -110,7 +119,7 @@ struct GemmRing16 {
     float2 mr[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      mr[j] = ln ? a.ln_mr[m0 + L.wm * 128 + j * 16 + L.l15] : make_float2(0.f, 1.f);
+      mr[j] = ln ? a.ln_mr[m0 + L.wm * WM + j * 16 + L.l15] : make_float2(0.f, 1.f);
       mr[j].y *= es;
     }
     const float* csp = ln ? a.ln_cs : a.bias;      // (mu = 0 without folded LayerNorm: any finite vector serves as cs)
@@ -124,7 +133,7 @@ struct GemmRing16 {
     const int nch = ncols >> 3;
     // byte offset of this lane's 16-byte piece of (column group 0, row block 0) from `base`; a column group further + 1024, a 32-row
     // block further + jstride: 32-bit arithmetic on a wave-uniform base (a tensor stays below 4 GiB: ring_shape)
-    const unsigned lane_off = (unsigned)((((m0 + L.wm * 128) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 32 + (L.q & 1) * 16 + L.l15) * 16u;
+    const unsigned lane_off = (unsigned)((((m0 + L.wm * WM) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 32 + (L.q & 1) * 16 + L.l15) * 16u;
     const unsigned jstride = (unsigned)nch * 512u;
     char* const baseb = reinterpret_cast<char*>(base);
 #pragma unroll
@@ -167,7 +176,7 @@ struct GemmRing16 {
     f32x2 s1[2][NJ / 2], s2[2][NJ / 2];       // per 64-column slot and 32-row block: (even, odd) element partial sums of this lane's row
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const float2 mr = a.res_mr[m0 + L.wm * 128 + j * 16 + L.l15];
+      const float2 mr = a.res_mr[m0 + L.wm * WM + j * 16 + L.l15];
       rrs[j] = mr.y;
       rc[j] = -mr.x * mr.y;
     }
@@ -179,7 +188,7 @@ struct GemmRing16 {
     // requested one step (16 values of arithmetic) ahead arrives 20-30 steps' worth of cycles later, and the epilogue - 31 k cycles
     // against the K loop's 30 k at K = 768 (profiles/r05/ring16_timeline.txt) - was a chain of 32 memory latencies.  kResAhead steps
     // are in flight: the first kResAhead requested together at the top, piece t + kResAhead when step t's registers are free.
-    constexpr int kResAhead = 16;
+    constexpr int kResSteps = NI * NJ / 2, kResAhead = kResSteps < 16 ? kResSteps : 16;
     float4 bbs[2], ggs[2];
     x4 r4s[kResAhead][2];
     auto load_cols = [&](int i, int buf) {
@@ -189,14 +198,14 @@ struct GemmRing16 {
     };
     // byte offsets from the wave-uniform tensor bases (32-bit: a tensor stays below 4 GiB); a column group further + 1024, a 32-row
     // block further + jstride
-    const unsigned blk_off = (unsigned)(((m0 + L.wm * 128) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 512u;
+    const unsigned blk_off = (unsigned)(((m0 + L.wm * WM) >> 5) * nch + (nloc >> 3) + (L.q >> 1)) * 512u;
     const unsigned res_off = blk_off + (unsigned)L.l15 * 16u + 8u * (unsigned)(L.q & 1);             // the lane's own 8 bytes of row l15
     const unsigned out_off = blk_off + (unsigned)((L.q & 1) * 16 + L.l15) * 16u;                     // its 16-byte piece after the exchange
     const unsigned jstride = (unsigned)nch * 512u;
     const char* const rsrcb = reinterpret_cast<const char*>(rsrc);
     char* const baseb = reinterpret_cast<char*>(base);
-    auto load_res = [&](int t, int buf) {   // t = i * 4 + jp: the residual where the accumulators put the value - row l15 (tile 2 jp) and 16 + l15
-      const int i = t >> 2, jp = t & 3;
+    auto load_res = [&](int t, int buf) {   // t = i * (NJ / 2) + jp: the residual where the accumulators put the value - row l15 (tile 2 jp) and 16 + l15
+      const int i = t / (NJ / 2), jp = t % (NJ / 2);
       const char* rp = rsrcb + (size_t)(res_off + (unsigned)i * 1024u + (unsigned)jp * jstride);
       if (CAPAMD_R16_ABL & 1) { r4s[buf][0] = r4s[buf][1] = x4{(T)1.f, (T)1.f, (T)1.f, (T)1.f}; return; }
       r4s[buf][0] = *reinterpret_cast<const x4*>(rp);
@@ -215,12 +224,12 @@ struct GemmRing16 {
       const f32x2 b01 = {bb.x, bb.y}, b23 = {bb.z, bb.w}, g01 = {gg.x, gg.y}, g23 = {gg.z, gg.w};
 #pragma unroll
       for (int jp = 0; jp < NJ / 2; ++jp) {
-        const int t = i * 4 + jp;
+        const int t = i * (NJ / 2) + jp;
         unsigned pk[2][2];
         uint2 rus[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) rus[h] = __builtin_bit_cast(uint2, r4s[t % kResAhead][h]);
-        if (t + kResAhead < NI * 4) load_res(t + kResAhead, t % kResAhead);     // (its registers were just read)
+        if (t + kResAhead < kResSteps) load_res(t + kResAhead, t % kResAhead);     // (its registers were just read)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int j = 2 * jp + h;
@@ -256,7 +265,7 @@ struct GemmRing16 {
         // lanes q and q + 2 hold the two chunks of the same row: add them; lanes 0..31 are the 32 rows of the block
         const float p1 = s1[sl][jp].x + s1[sl][jp].y, p2 = s2[sl][jp].x + s2[sl][jp].y;
         const float t1 = p1 + __shfl_xor(p1, 32, 64), t2 = p2 + __shfl_xor(p2, 32, 64);
-        const int mrow = m0 + L.wm * 128 + jp * 32 + (L.lane & 31);
+        const int mrow = m0 + L.wm * WM + jp * 32 + (L.lane & 31);
         if (L.lane < 32) *reinterpret_cast<float2*>(a.stat_part + ((int64_t)mrow * nslot + ((n0 + L.wn * 128) >> 6) + sl) * 2) = make_float2(t1, t2);
       }
   }
@@ -287,7 +296,7 @@ struct GemmRing16 {
           const int j = 4 * jq + jj;
           float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
           if (ln) {
-            const int mrow = m0 + L.wm * 128 + j * 16 + 4 * L.q;
+            const int mrow = m0 + L.wm * WM + j * 16 + 4 * L.q;
             mu = *reinterpret_cast<const float4*>(a.ln_mu + mrow);
             rs = *reinterpret_cast<const float4*>(a.ln_rstd + mrow);
           }
@@ -318,22 +327,26 @@ struct GemmRing16 {
     Lane L;
     L.tid = threadIdx.x; L.lane = L.tid & 63; L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
     L.wm = L.wave >> 1; L.wn = L.wave & 1; L.l15 = L.lane & 15; L.q = L.lane >> 4;
+#ifdef CAPAMD_PROFILING      // (cycle stamps per tile: the profiling build only - the pointer and its index cost the 128-row form two spills)
     unsigned long long* dbg = g.dbg ? g.dbg + (size_t)blockIdx.x * 32 : nullptr;
     int dbg_i = 0;
 #define CAPAMD_STAMP() do { if (dbg && L.tid == 0 && dbg_i < 32) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CAPAMD_STAMP() do { } while (0)
+#endif
     int m0, n0;
     if (!G::tile_of(g, 0, m0, n0)) return;
-    const int S2 = g.K >> 5;                         // steps per tile (ring16_shape: even, >= 8)
+    const int S2 = g.K >> 5;                         // steps per tile (launch_gemm: even, >= 8)
     const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)((size_t)g.M * g.K * 2), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.W), 0, (int)((size_t)g.N * g.K * 2), 0x00020000);
     const int voff = L.lane * 16;
     auto dma = [&](int p, char* slot, unsigned soff) {
       const int pc = L.wave + 4 * p;
-      if (p < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(slot + pc * 1024), 16, voff, (int)soff, 0, 0);
+      if (4 * p < kPiecesA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(slot + pc * 1024), 16, voff, (int)soff, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(slot + pc * 1024), 16, voff, (int)soff, 0, 0);
     };
     // fragment of 16-row tile t of the A (m) / B (n) panel inside a step: + (t >> 1) * 1024 + (t & 1) * 256
-    const int a_base = L.wm * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
+    const int a_base = L.wm * (WM / 32) * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
     const int b_base = kSlotA + L.wn * 4 * 1024 + (L.q & 1) * 512 + L.l15 * 16 + (L.q >> 1) * kSlot;
 
     // kEpiResidStats: the epilogue reads the tile's 128 KiB of residual, and every CU reaches its epilogue at about the same time - 32 MB
@@ -346,7 +359,7 @@ struct GemmRing16 {
     const auto rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == kEpiResidStats ? g.res_src : g.A), 0,
                                                         (int)((size_t)g.M * (EPI == kEpiResidStats ? g.N : g.K) * 2), 0x00020000);
     auto touch_residual = [&](int blk, int tm0, int tn0) {
-      const unsigned soff = (unsigned)((((tm0 + L.wm * 128 + blk * 32) >> 5) * (g.N >> 3) + ((tn0 + L.wn * 128) >> 3)) * 32) * 16u;
+      const unsigned soff = (unsigned)((((tm0 + L.wm * WM + blk * 32) >> 5) * (g.N >> 3) + ((tn0 + L.wn * 128) >> 3)) * 32) * 16u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, (lds_void_t*)(lds + kRing + L.wave * G::kEpiLds + blk * 256), 4, L.lane * 128, (int)soff, 0, 0);
     };
     Bases cur = bases_of(g, m0, n0, L.wave);
@@ -384,14 +397,14 @@ struct GemmRing16 {
         const char* stn = lds + nslot;
         char* dst = lds + slot_off;
         // the step four ahead: of this tile, or (the tile's last four steps) of the block's next tile
-        const bool own = s + 4 < S2;
-        const unsigned so = (unsigned)(own ? s + 4 : s + 4 - S2) * 2048u;
+        const bool own = s + kSteps < S2;
+        const unsigned so = (unsigned)(own ? s + kSteps : s + kSteps - S2) * 2048u;
         unsigned soff[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) soff[p] = (own ? cur.off[p] : nxt.off[p]) + so;
 #define CAPAMD_M16(idx)                                                                  \
   do {                                                                                   \
-    constexpr int i_ = (idx) >> 3, j_ = (idx) & 7;                                       \
+    constexpr int i_ = (idx) / NJ, j_ = (idx) % NJ;                                      \
     if (FIRST) { if (TR) Mfma16<T>::first(acc[i_][j_], fa[cu][j_], fb[cu][i_]); else Mfma16<T>::first(acc[i_][j_], fb[cu][i_], fa[cu][j_]); } \
     else { if (TR) Mfma16<T>::acc(acc[i_][j_], fa[cu][j_], fb[cu][i_]); else Mfma16<T>::acc(acc[i_][j_], fb[cu][i_], fa[cu][j_]); }            \
   } while (0)
@@ -400,19 +413,30 @@ struct GemmRing16 {
           if (r < NJ) fa[nx][r] = *reinterpret_cast<const x8*>(stn + a_base + (r >> 1) * 1024 + (r & 1) * 256);
           else fb[nx][r - NJ] = *reinterpret_cast<const x8*>(stn + b_base + ((r - NJ) >> 1) * 1024 + ((r - NJ) & 1) * 256);
         };
-        auto D = [&](int d) {       // piece d of the step's eight: slice d >> 2, the wave's piece d & 3
-          dma(d & 3, dst + (d >> 2) * kSlot, soff[d & 3] + (unsigned)(d >> 2) * 1024u);
+        auto D = [&](int d) {       // piece d of the step's 2 P: slice d / P, the wave's piece d % P
+          dma(d % P, dst + (d / P) * kSlot, soff[d % P] + (unsigned)(d / P) * 1024u);
         };
         CAPAMD_SB;
 #define CAPAMD_G16(g_)                                                                                                    \
   CAPAMD_M16(4 * (g_)); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 1); CAPAMD_SB; R(g_); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 2); CAPAMD_SB; \
   CAPAMD_M16(4 * (g_) + 3); CAPAMD_SB;                                                                                   \
   if ((g_) & 1) { D((g_) >> 1); CAPAMD_SB; }
-        CAPAMD_G16(0) CAPAMD_G16(1) CAPAMD_G16(2) CAPAMD_G16(3) CAPAMD_G16(4) CAPAMD_G16(5) CAPAMD_G16(6) CAPAMD_G16(7)
-        CAPAMD_G16(8) CAPAMD_G16(9) CAPAMD_G16(10) CAPAMD_G16(11) CAPAMD_G16(12) CAPAMD_G16(13) CAPAMD_G16(14) CAPAMD_G16(15)
+        // 128 rows: 32 MFMAs, 12 reads, 6 DMAs in eight groups - M M R M M, a second read in the first four groups, a DMA from the third on
+#define CAPAMD_G16H(g_)                                                                                                   \
+  CAPAMD_M16(4 * (g_)); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 1); CAPAMD_SB; R((g_) < 4 ? 2 * (g_) : 4 + (g_)); CAPAMD_SB;    \
+  CAPAMD_M16(4 * (g_) + 2); CAPAMD_SB; CAPAMD_M16(4 * (g_) + 3); CAPAMD_SB;                                              \
+  if ((g_) < 4) { R(2 * (g_) + 1); CAPAMD_SB; }                                                                           \
+  if ((g_) >= 2) { D((g_) - 2); CAPAMD_SB; }
+        if constexpr (BM == 256) {
+          CAPAMD_G16(0) CAPAMD_G16(1) CAPAMD_G16(2) CAPAMD_G16(3) CAPAMD_G16(4) CAPAMD_G16(5) CAPAMD_G16(6) CAPAMD_G16(7)
+          CAPAMD_G16(8) CAPAMD_G16(9) CAPAMD_G16(10) CAPAMD_G16(11) CAPAMD_G16(12) CAPAMD_G16(13) CAPAMD_G16(14) CAPAMD_G16(15)
+        } else {
+          CAPAMD_G16H(0) CAPAMD_G16H(1) CAPAMD_G16H(2) CAPAMD_G16H(3) CAPAMD_G16H(4) CAPAMD_G16H(5) CAPAMD_G16H(6) CAPAMD_G16H(7)
+        }
         // (one more VMEM operation in flight in steps 0..3: the counted waits above only get stricter by it - everything older than the
         // youngest kVm operations has landed, and those are a subset of what is younger than the awaited step)
-        if (EPI == kEpiResidStats && g.res_touch && s < 4) { touch_residual(s, m0, n0); CAPAMD_SB; }
+        if (BM == 256 && EPI == kEpiResidStats && g.res_touch && s < 4) { touch_residual(s, m0, n0); CAPAMD_SB; }
+#undef CAPAMD_G16H
 #undef CAPAMD_G16
 #undef CAPAMD_SB
 #undef CAPAMD_M16
@@ -453,10 +477,10 @@ struct GemmRing16 {
   }
 };
 
-template <int EPI, typename T>
-__global__ __launch_bounds__(256, 1) void gemm_ring16_kernel(GemmArgs a) {
+template <int EPI, typename T, int BM>
+__global__ __launch_bounds__(256, (BM == 256 ? 1 : 2)) void gemm_ring16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char gemm_ring16_lds[];
-  GemmRing16<EPI, T>::run(a, gemm_ring16_lds);
+  GemmRing16<EPI, T, BM>::run(a, gemm_ring16_lds);
 }
 
 }  // namespace capamd

@@ -315,6 +315,8 @@ int capamd_maxp_pool(const float* passage_logits, const int64_t* mask, const int
 #define CAPAMD_GEMM_RING_256 0x800         /* with W chunk-major: the ring kernel's 256-row tile (one workgroup per CU) instead of its default 128-row tile (two per CU);
                                             with a chunk-major output and K % 64 == 0 that tile runs on 16x16x32 MFMAs (k accumulated in steps of 32: not the
                                             bits of the other kernels, which accumulate in steps of 16) */
+#define CAPAMD_GEMM_RING_MFMA16 0x2000     /* without CAPAMD_GEMM_RING_256: the 128-row tile (two workgroups per CU) on 16x16x32 MFMAs too (chunk-major output, K % 64 == 0;
+                                            not for the QKV epilogue) - the bits of the 256-row 16x16x32 tile */
 #define CAPAMD_GEMM_RING_MFMA32 0x1000     /* with CAPAMD_GEMM_RING_256: keep the 256-row tile on 32x32x16 MFMAs (the bits of the 128-row tile and the 8-wave kernel) */
 #define CAPAMD_GEMM_W_CHUNK_MAJOR 0x400   /* W is chunk-major too (with A chunk-major, M, N % 256 == 0, K % 32 == 0, K >= 256: the 4-wave ring kernel) */
 int capamd_bert_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epilogue,

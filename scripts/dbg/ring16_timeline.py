@@ -14,7 +14,7 @@ def to_cm(x):
 SHAPES = [("qkv-like bias", 2304, 768, 0), ("ffn1 gelu", 3072, 768, 1), ("oproj resid", 768, 768, 5), ("ffn2 resid", 768, 3072, 5)]
 if os.environ.get("ONLY"):
     SHAPES = [x for x in SHAPES if x[0].startswith(os.environ["ONLY"])]
-KERNELS = ((0x700, "ring128/32"), (0x1F00, "ring256/32"), (0xF00, "ring256/16"))
+KERNELS = ((0x700, "ring128/32"), (0x1F00, "ring256/32"), (0xF00, "ring256/16"), (0x2700, "ring128/16"))
 if os.environ.get("ONLY16"):
     KERNELS = KERNELS[2:]
 for name, N, K, epi in SHAPES:

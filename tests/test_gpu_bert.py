@@ -550,6 +550,10 @@ def test_gemm_at_benchmark_scale(N, K, epi, dt):
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0xF00, None, _p(out_ring), code, _stream()) == 0
     _assert_close_big(_from_cm(out_ring, M, N), ref, rtol, 2e-2 if dt == "bf16" else 3e-3, f"gemm {N}x{K} epi {epi} on 16x16x32")
     _assert_one_ulp_apart(out_ring, out_cm, tdt, f"gemm {N}x{K} epi {epi}: 16x16x32 vs 32x32x16")
+    # ... and its 128-row form (two workgroups per CU): the same accumulation order, the same bits
+    out_ring128 = torch.zeros_like(out_ring)
+    assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x2700, None, _p(out_ring128), code, _stream()) == 0
+    assert torch.equal(out_ring128, out_ring)
     out_ring_rm = torch.empty((M, N), dtype=tdt, device=DEV)      # ... and its row-major (LDS-staged) epilogue
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x600, None, _p(out_ring_rm), code, _stream()) == 0
     assert torch.equal(out_ring_rm, out)
@@ -594,6 +598,10 @@ def test_gemm_folded_layernorm_consumer_at_benchmark_scale(N, K, epi, dt):
     assert rc == 0
     _assert_close_big(_from_cm(out_ring, M, N), ref, 4 * rtol, 5e-2 if dt == "bf16" else 8e-3, f"folded-LN consumer {N}x{K} on 16x16x32")
     _assert_one_ulp_apart(out_ring, out, tdt, f"folded-LN consumer {N}x{K}: 16x16x32 vs 32x32x16")
+    out_ring128 = torch.zeros_like(out_ring)          # the 128-row form of the 16x16x32 kernel: identical bits
+    rc = _lib.load().capamd_bert_gemm_ln(_p(P_cm), _p(W_cm), _p(c), M, N, K, epi | 0x2700, _p(mu), _p(rstd), _p(mr), _p(cs), None, None, None, None,
+                                         _p(out_ring128), code, _stream())
+    assert rc == 0 and torch.equal(out_ring128, out_ring)
 
 
 @pytest.mark.parametrize("N,K", [(768, 768), (768, 3072)])
@@ -635,6 +643,10 @@ def test_gemm_residual_stats_producer_at_benchmark_scale(N, K, dt):
     _assert_one_ulp_apart(out_ring, out, tdt, f"residual+stats producer {N}x{K}: 16x16x32 vs 32x32x16")
     want16 = torch.stack([got16.reshape(M, N // 64, 64).sum(2), (got16 * got16).reshape(M, N // 64, 64).sum(2)], 2)
     torch.testing.assert_close(part_ring, want16, rtol=1e-4, atol=1e-3)
+    out_ring128, part_ring128 = torch.zeros_like(out_ring), torch.zeros_like(part_ring)      # the 128-row form: identical bits
+    rc = _lib.load().capamd_bert_gemm_ln(_p(A_cm), _p(W_cm), _p(bp), M, N, K, 5 | 0x2700, None, None, None, None, _p(R_cm), _p(mr), _p(gamma),
+                                         _p(part_ring128), _p(out_ring128), code, _stream())
+    assert rc == 0 and torch.equal(out_ring128, out_ring) and torch.equal(part_ring128, part_ring)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, 0), (512, 768, 512, 1), (768, 256, 1024, 0), (256, 256, 0x800 | 256, 0), (768, 512, 0x800 | 320, 1), (768, 512, 320, 1)])
