@@ -158,10 +158,20 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
       if (j0 + u * 16 >= n) continue;          // (wave-uniform)
       if (id[u] > 0) {
         rs += s[u];
+        // two kernels per packed instruction (v_pk_fma / v_pk_mul / v_pk_add: the same fma, product and sum per element, half the
+        // issue slots - 2.5 instead of 4 VALU instructions per evaluation beside its v_exp_f32); an odd last kernel on its own
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-          const float tk = __builtin_fmaf(s[u], ka[k], kb[k]);
-          acc[k] += __builtin_amdgcn_exp2f(-tk * tk);
+        for (int k = 0; k + 1 < KK; k += 2) {
+          const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + f32x2{kb[k], kb[k + 1]};
+          const f32x2 nq = -tk * tk;
+          const f32x2 e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+          f32x2 ac = {acc[k], acc[k + 1]};
+          ac += e;
+          acc[k] = ac.x; acc[k + 1] = ac.y;
+        }
+        if (KK & 1) {
+          const float tk = __builtin_fmaf(s[u], ka[KK - 1], kb[KK - 1]);
+          acc[KK - 1] += __builtin_amdgcn_exp2f(-tk * tk);
         }
       }
     }
