@@ -521,8 +521,12 @@ __device__ __forceinline__ void rows_dot2_pk_reg(const RowRegs<NV>& d0, const Ro
   p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
 }
 
+// CAPAMD_LISTS_SIMS_QREG = 2: the multi-block walk with the query copy in LDS (lists_sims_kernel's arithmetic, its per-workgroup
+// prologue - query copy, norms, edges - once per kSimsBlocksPerWG id blocks)
+constexpr bool kSimsQueryInLds = CAPAMD_LISTS_SIMS_QREG == 2;
 template <int NV, bool BINS>
 __global__ __launch_bounds__(256, 2) void lists_sims_qreg_kernel(ListsArgs a, ListGeom g) {
+  __shared__ __attribute__((aligned(16))) float4 qlds[kSimsQueryInLds ? kQT * kMaxNV * 16 : 1];
   __shared__ int lst[kSimsIds];
   __shared__ int wave_cnt[4];
   __shared__ float edges[kMaxBins];
@@ -530,11 +534,15 @@ __global__ __launch_bounds__(256, 2) void lists_sims_qreg_kernel(ListsArgs a, Li
   const int l = blockIdx.x >> 3, blk0 = (blockIdx.y * 8 + (blockIdx.x & 7)) * kSimsBlocksPerWG;
   if ((int64_t)blk0 * kSimsIds >= a.Vp) return;
   constexpr int kPer = kSimsIds / 256;
-  float4 qr[2 * NV * 2];
+  float4 qr[kSimsQueryInLds ? 1 : 2 * NV * 2];
   {
     const float4* img = a.qimg + (int64_t)l * kQueryImage;
+    if (kSimsQueryInLds) {
+      for (int i = tid; i < kQT * NV * 16; i += 256) qlds[i] = img[i];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 2 * NV * 2; ++k) qr[k] = img[k * 16 + lane16];
+      for (int k = 0; k < (kSimsQueryInLds ? 1 : 2 * NV * 2); ++k) qr[k] = img[k * 16 + lane16];
+    }
   }
   QueryPass<NV> qp;
   qp.den_my = a.qmeta[l].den[lane16 & 3];
@@ -589,7 +597,13 @@ __global__ __launch_bounds__(256, 2) void lists_sims_qreg_kernel(ListsArgs a, Li
       load_row<NV>(a.packed, ida, lane16, da);
       load_row<NV>(a.packed, idb, lane16, db);
       float pa[kQT], pb[kQT];
-      rows_dot2_pk_reg<NV>(da, db, qr, pa, pb);
+      if constexpr (kSimsQueryInLds) {
+        int qoff = 0;
+        asm volatile("" : "+v"(qoff));
+        rows_dot2_pk<NV>(da, db, qlds + qoff, lane16, pa, pb);
+      } else {
+        rows_dot2_pk_reg<NV>(da, db, qr, pa, pb);
+      }
       put(ida, sim_from_dots<NV>(pa, row_den<NV>(da), qp, lane16));
       put(idb, sim_from_dots<NV>(pb, row_den<NV>(db), qp, lane16));
     }

@@ -1,13 +1,13 @@
 #!/bin/bash
-# One GPU-box session (round 4): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
-# (scripts/collect_profiles.sh r04 copies what is kept into profiles/r04/).  bench.py prints ONE compact line and writes the whole record
+# One GPU-box session (round 5): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
+# (scripts/collect_profiles.sh r05 copies what is kept into profiles/r05/).  bench.py prints ONE compact line and writes the whole record
 # to bench_full.json: both are kept per run (bench_<name>.json = the line, bench_full_<name>.json = the record).
 set -u
 rm -rf gpurun_out/prof gpurun_out/ab_*.json; mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python $R/bench.py"
-( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
+( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 ) > gpurun_out/pytest_gpu.log 2>&1; cat gpurun_out/pytest_gpu.log
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
 # ---- bench lines -------------------------------------------------------------------------------------------------------
 timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json; cp bench_full.json gpurun_out/bench_full_default.json 2>/dev/null
@@ -18,7 +18,7 @@ timeout 600 $B --steps 5 --warmup 2 --model bert 2>/dev/null | tail -1 > gpurun_
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-skip-padding 2>/dev/null | tail -1 > gpurun_out/bench_bert_skip_padding.json; cp bench_full.json gpurun_out/bench_full_bert_skip_padding.json 2>/dev/null
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-dtype fp16 2>/dev/null | tail -1 > gpurun_out/bench_bert_fp16.json; cp bench_full.json gpurun_out/bench_full_bert_fp16.json 2>/dev/null
 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_bert_one_stream.json; cp bench_full.json gpurun_out/bench_full_bert_one_stream.json 2>/dev/null
-CAPAMD_GEMM_RING=0 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_pingpong.json; cp bench_full.json gpurun_out/bench_full_bert_pingpong.json 2>/dev/null
+CAPAMD_GEMM_PICK=qkv=128,ffn1=128,oproj=256x32,ffn2=256x32 timeout 600 $B --steps 5 --warmup 2 --model bert --no-cpu-baseline --no-bert-other-dtype 2>/dev/null | tail -1 > gpurun_out/bench_bert_r4mix.json; cp bench_full.json gpurun_out/bench_full_bert_r4mix.json 2>/dev/null
 for mdl in drmmtks pacrr convknrm; do timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --model $mdl 2>/dev/null | tail -1 > gpurun_out/bench_$mdl.json; cp bench_full.json gpurun_out/bench_full_$mdl.json 2>/dev/null; done
 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm.json; cp bench_full.json gpurun_out/bench_full_cedrknrm.json 2>/dev/null; cat gpurun_out/bench_cedrknrm.json
 PYTHONPATH=$R timeout 300 python $R/scripts/predict_e2e_bench.py 2>/dev/null | tail -1 > gpurun_out/predict_e2e.json; cat gpurun_out/predict_e2e.json
@@ -27,7 +27,7 @@ PYTHONPATH=$R timeout 300 python $R/scripts/train_step_bench.py 2>/dev/null | gr
 CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cp bench_full.json gpurun_out/bench_full_cedrknrm_separate_layernorm.json 2>/dev/null; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
 python - <<'PY'
 import json
-for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_pingpong", "drmmtks", "pacrr", "convknrm"):
+for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_r4mix", "drmmtks", "pacrr", "convknrm"):
     try:
         r = json.load(open(f"gpurun_out/bench_{f}.json")); ro = r["roofline"]
         print(f"{f:20s} {r['value']:14.1f} {r['unit']}  ms/step {r['ms_per_step']:.3f}  roofline frac {ro.get('frac')}  {ro.get('whole_step_frac_nominal', '')}")
@@ -57,7 +57,7 @@ for leg in "knrm:" "knrm_roofline_leg:--uniform-ids --vocab 4000001 --batches 2"
   timeout 300 $PM TCC_HIT_sum TCC_MISS_sum -d $P/${name}_tcc -o c -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg $extra > /dev/null 2>&1
 done
 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
-CAPAMD_GEMM_RING=0 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_pingpong -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
+CAPAMD_GEMM_PICK=qkv=128,ffn1=128,oproj=256x32,ffn2=256x32 timeout 300 $PM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $P/bert_mfma_r4mix -o c -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-bert-other-dtype --bert-streams 1 --model bert --docs 256 > /dev/null 2>&1
 cd $R
 # what travels back (gpurun_out/ is capped at 64 MiB): the kernel statistics and agent info as they are; of the counter files only the rows of this
 # library's kernels; no kernel traces
