@@ -587,6 +587,11 @@ class AdamStep:
             raise NotImplementedError("fused training steps follow the plain Adam of the reference (no weight decay / amsgrad / capturable)")
         self.optimizer, self.group, self.params = optimizer, g, list(params)
         in_opt = {id(p) for p in g["params"]}
+        # every tensor the optimizer trains must be one the device step updates: a parameter added to a model later would otherwise
+        # silently never move under the fused step - the trainer falls back to the captured-graph route on this error
+        missing = in_opt - {id(p) for p in self.params if p is not None}
+        if missing:
+            raise NotImplementedError(f"{len(missing)} optimizer parameter(s) are not covered by this reranker's device training step")
         ptrs = [[], [], []]
         for p in self.params:
             if p is None or id(p) not in in_opt:        # not trained (requires_grad False): no moments
@@ -612,12 +617,15 @@ class AdamStep:
         return all(len(st[p]) and st[p]["exp_avg"].data_ptr() in self.key for p in self.trained)
 
     def advance(self):
-        """(step_size, 1 - beta1, beta2, eps, sqrt(bias_correction2)) of the NEXT step; the step counters move on"""
+        """(step_size, 1 - beta1, beta2, eps, sqrt(bias_correction2)) of the NEXT step.  The step counters move on in `commit()`, after
+        the C call has validated its arguments and launched: an EngineError must not leave the count ahead of the moments."""
         b1, b2 = self.group["betas"]
+        t = float(self.optimizer.state[self.trained[0]]["step"]) + 1.0
+        return float(self.group["lr"]) / (1 - b1 ** t), 1 - b1, b2, float(self.group["eps"]), (1 - b2 ** t) ** 0.5
+
+    def commit(self):
         for p in self.trained:
             self.optimizer.state[p]["step"] += 1
-        t = float(self.optimizer.state[self.trained[0]]["step"])
-        return float(self.group["lr"]) / (1 - b1 ** t), 1 - b1, b2, float(self.group["eps"]), (1 - b2 ** t) ** 0.5
 
 
 _step_workspaces = {}
@@ -638,6 +646,7 @@ def knrm_train_step(query, posdoc, negdoc, packed, V, D, K, adam, train_kernels,
                                     int(bool(scoretanh)), int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(),
                                     _ptr(st.t), _stream())
     _lib.check(rc, "capamd_knrm_train_step")
+    adam.commit()
     if check:
         st.raise_if_set()
     return loss
@@ -659,6 +668,7 @@ def convknrm_train_step(query, posdoc, negdoc, emb, G, F, K, crossmatch, adam, s
     rc = lib.capamd_convknrm_train_step(_ptr(q2), _ptr(d2), B, Q, L, _ptr(e), e.shape[0], e.shape[1], G, F, K, int(bool(crossmatch)), ptrs, int(bool(scoretanh)),
                                         int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
     _lib.check(rc, "capamd_convknrm_train_step")
+    adam.commit()
     if check:
         st.raise_if_set()
     return loss
@@ -687,6 +697,7 @@ def pacrr_train_step(query, posdoc, negdoc, idf, packed, V, D, mingram, maxgram,
                                      int(bool(use_idf)), int(combine), NONLINEARITIES[nonlinearity], ptrs, int(bool(softmax)), step_size, omb1, b2, eps, bc2s,
                                      _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
     _lib.check(rc, "capamd_pacrr_train_step")
+    adam.commit()
     if check:
         st.raise_if_set()
     return loss
@@ -715,6 +726,7 @@ def drmm_train_step(query, posdoc, negdoc, idf, packed, V, D, edges, hist_type, 
                                     int(nodes), _ptr(adam.table), int(bool(softmax)), step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(),
                                     _ptr(st.t), _stream())
     _lib.check(rc, "capamd_drmm_train_step")
+    adam.commit()
     if check:
         st.raise_if_set()
     return loss
@@ -734,6 +746,7 @@ def drmmtks_train_step(query, posdoc, negdoc, idf, packed, V, D, topk, adam, sof
     rc = lib.capamd_drmmtks_train_step(_ptr(q), _ptr(dp), _ptr(dn), _ptr(idf), B, Q, L, _ptr(packed), V, D, int(topk), _ptr(adam.table), int(bool(softmax)),
                                        step_size, omb1, b2, eps, bc2s, _ptr(loss), _ptr(ws), ws.numel(), _ptr(st.t), _stream())
     _lib.check(rc, "capamd_drmmtks_train_step")
+    adam.commit()
     if check:
         st.raise_if_set()
     return loss
