@@ -124,6 +124,8 @@ class PytorchTrainer:
     # interaction kernels (KNRM, DRMM, ...) compute in fp32 and the BERT encoder already runs on 16-bit operands - the scores are
     # those of the non-autocast reference within the parity bar either way.
 
+    LISTS_PAIR_BYTES = 1 << 30      # per-pair workspace bytes one whole-list scoring call may ask for (see _score_store)
+
     def __init__(self, config=None):
         cfg = dict(self.config_spec)
         unknown = set(config or {}) - set(cfg)
@@ -591,7 +593,22 @@ class PytorchTrainer:
             if as_lists and len(counts) >= 2 and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4 and n >= 8 * len(counts):
                 if offsets is None:
                     offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
-                return reranker.test_resident_lists(store, pq, pd, offsets).float()
+                offsets = np.asarray(offsets, dtype=np.int64)
+                # the per-pair part of the lists workspace (compact id rows + metadata: 4 L + 32 bytes per pair of the CALL) is bounded by
+                # splitting a long run into calls of whole lists (a 1.75 M-pair part at L = 800 asked for 5.6 GB); lists are
+                # scored independently, so the scores do not depend on the split
+                per_pair = 4 * int(store.d_table.shape[1]) + 32
+                if n * per_pair <= self.LISTS_PAIR_BYTES:
+                    return reranker.test_resident_lists(store, pq, pd, offsets).float()
+                out, a = [], 0
+                while a < len(counts):
+                    b = a + 1
+                    while b < len(counts) and (offsets[b + 1] - offsets[a]) * per_pair <= self.LISTS_PAIR_BYTES:
+                        b += 1
+                    lo, hi = int(offsets[a]), int(offsets[b])
+                    out.append(reranker.test_resident_lists(store, pq[lo:hi], pd[lo:hi], offsets[a:b + 1] - lo).float())
+                    a = b
+                return torch.cat(out)
             chunks = [reranker.test_resident(store, pq[i:i + step], pd[i:i + step]).float() for i in range(0, n, step)]
         return torch.cat(chunks) if chunks else torch.zeros(0, device=store.device)
 

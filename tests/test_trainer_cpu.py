@@ -354,6 +354,7 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     class Store:
         device = torch.device("cpu")
         q_table = torch.zeros(3, 4, dtype=torch.int32)
+        d_table = torch.zeros(40, 800, dtype=torch.int32)
 
     class Fake:
         supports_lists = True
@@ -376,6 +377,12 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     assert out.dtype == torch.float32 and out.numel() == n and torch.equal(out, torch.arange(n, dtype=torch.float32))
     if expect_lists:
         assert calls == [("lists", [0, 20, 29, 40])]
+        # a run whose per-pair workspace (4 L + 32 bytes per pair) would pass the bound goes in calls of whole lists, same scores
+        calls.clear()
+        tr.LISTS_PAIR_BYTES = 30 * (4 * 800 + 32)
+        parts = tr._score_store(Fake(), Store(), pq, pd, counts, 16)
+        assert calls == [("lists", [0, 20, 29]), ("lists", [0, 11])] and parts.numel() == n
+        del tr.LISTS_PAIR_BYTES
     else:
         assert calls == [("pairs", 16), ("pairs", 16), ("pairs", 8)]
     # more than four query terms, or short lists: always pair by pair
