@@ -139,8 +139,12 @@ class DRMM(Reranker):
         return self.model.fused_train_step(d, optimizer, softmax)
 
     def fused_step_available(self, batch_size):
-        """whether `fused_train_step` takes this configuration (idf gate, <= 16 hidden nodes, 2 B Q <= 1024: B <= 128 at the extractor's four query terms)"""
-        return self.config["gateType"] == "IDF" and self.config["nodes"] <= 16 and batch_size <= 128
+        """whether `fused_train_step` takes this configuration (idf gate, <= 16 hidden nodes, 2 B Q <= 1024: B <= 128 at the extractor's
+        default of four query terms - a longer `maxqlen` lowers the batch the device step takes, and the trainer must know BEFORE it builds
+        its optimizer: ADVICE r4)"""
+        cfg = getattr(getattr(self, "extractor", None), "config", None)
+        maxqlen = int(cfg["maxqlen"]) if isinstance(cfg, dict) and "maxqlen" in cfg else 4
+        return self.config["gateType"] == "IDF" and self.config["nodes"] <= 16 and 2 * batch_size * maxqlen <= 1024
 
     def test_resident(self, store, pair_q, pair_d):
         return self.model.forward_indexed(store, pair_q, pair_d)
