@@ -516,16 +516,36 @@ __global__ __launch_bounds__(256, 2) void attention_s256_kernel(AttnArgs a, int 
   auto qk_block = [&](const bf16x8 (&q)[4], f32x16 (&sc)[NT], auto&& hook) {
     int kbase = lperm * 128 + half * 16, ksw = ((lperm >> 1) & 7) << 4;   // K image: row * 128 + ((2 ks + half) ^ ((row >> 1) & 7)) * 16
     asm volatile("" : "+v"(kbase), "+v"(ksw));                          // (re-derived per block: not hoisted out of the item loop)
+    // The K fragments are requested a whole tile pair AHEAD of their MFMA: asked for right before it - what hipcc makes of the plain
+    // loop: two fragment registers, an `s_waitcnt lgkmcnt` in front of every MFMA - a pair of MFMAs (64 cycles of the matrix pipe) waits
+    // for an LDS round trip of twice that.  ONE set of eight fragment registers: fragment i of the next pair is requested right behind the
+    // MFMA that consumed fragment i of this one (eight MFMAs = 256 cycles before its use), and the mask rows that initialise the next
+    // pair's accumulators travel with them, into the accumulators themselves; the issue order (M R R ..) is pinned with sched_group_barrier.
+    bf16x8 kf[8];
+    auto load_frag = [&](int t, int i) {   // fragment i = 2 ks + u of the tile pair (t, t + 1)
+      kf[i] = *reinterpret_cast<const bf16x8*>(Ks + (t + (i & 1)) * 4096 + ((kbase + (i >> 1) * 32) ^ ksw));
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) load_frag(0, i);
+    sc[0] = scores_init_permuted<NT>(madd + 8 * half);
+    sc[1] = scores_init_permuted<NT>(madd + 32 + 8 * half);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
 #pragma unroll
     for (int t = 0; t < NT; t += 2) {
-      sc[t] = scores_init_permuted<NT>(madd + t * 32 + 8 * half);
-      sc[t + 1] = scores_init_permuted<NT>(madd + (t + 1) * 32 + 8 * half);
+      if (t + 2 < NT) {
+        sc[t + 2] = scores_init_permuted<NT>(madd + (t + 2) * 32 + 8 * half);
+        sc[t + 3] = scores_init_permuted<NT>(madd + (t + 3) * 32 + 8 * half);
+      }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int i = 0; i < 8; ++i) {
+        sc[t + (i & 1)] = Half<T>::mfma(kf[i], q[i >> 1], sc[t + (i & 1)]);
+        if (t + 2 < NT) load_frag(t + 2, i);
+      }
+      if (t + 2 < NT) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (t + u) * 4096 + ((kbase + ks * 32) ^ ksw));
-          sc[t + u] = Half<T>::mfma(kf, q[ks], sc[t + u]);
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA i
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the next pair's fragment i + one of its eight mask-row reads
         }
       }
       hook(t >> 1);
