@@ -68,7 +68,10 @@ struct KnrmPoolArgs {
 // No LDS and no barrier: the row reduction is DPP, the per-kernel logs run in lanes (query term, kernel), the read-out takes the
 // kernels' features by readlane.  (A workgroup per document - four waves sharing its positions, LDS reduction, one lane per kernel for
 // the logs - measured 465 us per 64,000 documents against this form's 352.)
-constexpr int kWaveTrips = 8;      // 128 positions per pass
+#ifndef CAPAMD_POOL_TRIPS
+#define CAPAMD_POOL_TRIPS 8
+#endif
+constexpr int kWaveTrips = CAPAMD_POOL_TRIPS;      // 128 positions per pass (A/B builds: 4 / 12 / 16 - profiles/r05/lists_pool_trips_ab.txt)
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
