@@ -16,7 +16,7 @@ dev = "cuda:0"
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 64000
 dt_name = sys.argv[2] if len(sys.argv) > 2 else "bf16"
-tdt, code = (torch.bfloat16, 1) if dt_name == "bf16" else (torch.float16, 0)
+tdt, code = (torch.bfloat16, 0) if dt_name == "bf16" else (torch.float16, 1)      # (capamd_bert_gemm: dtype 0 = bf16, 1 = fp16; rounds 3-4 had them swapped here)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -43,8 +43,8 @@ shapes = [("QKV   N=2304 K=768  bias", 2304, 768, 0), ("Oproj N=768  K=768  bias
 if os.environ.get("GEMM_FFN1_BIAS_ONLY"):      # what the GELU epilogue costs: the FFN1 shape once more with the bias-only epilogue
     shapes.append(("FFN1* N=3072 K=768  bias only", 3072, 768, 0))
 print(f"M = {M}, {dt_name} operands, fp32 accumulate; us per launch (TFLOP/s)")
-print(f"{'shape':30s} {'ring 128x256 (2 wg/CU)':>24s} {'ring 256x256 (1 wg/CU)':>24s} {'ping-pong 256x256':>22s} {'hipBLASLt (bias only)':>24s}   best in-tree / vendor")
-tot = {"ring128": 0.0, "ring256": 0.0, "pp": 0.0, "vendor": 0.0, "best": 0.0}
+print(f"{'shape':30s} {'ring 128 rows 32x32x16':>24s} {'ring 256 rows 32x32x16':>24s} {'ring 256 rows 16x16x32':>24s} {'ring 128 rows 16x16x32':>24s} {'ping-pong 256x256':>22s} {'hipBLASLt (bias only)':>24s}   best in-tree / vendor")
+tot = {"ring128": 0.0, "ring256": 0.0, "ring256_16": 0.0, "ring128_16": 0.0, "pp": 0.0, "vendor": 0.0, "best": 0.0}
 only = os.environ.get("GEMM_ONLY")            # e.g. GEMM_ONLY=FFN1: one shape (sweeps of CAPAMD_GEMM_NGROUP / CAPAMD_RING_* builds)
 for name, N, K, epi in shapes:
     if only and not name.startswith(only):
@@ -61,14 +61,16 @@ for name, N, K, epi in shapes:
         assert lib.capamd_bert_gemm(vp(a), vp(w), vp(bias), M, N, K, epi | flags, None, vp(out), code, st) == 0
 
     t128 = med(lambda: run(0x700, A_cm, W_cm))
-    t256 = med(lambda: run(0xF00, A_cm, W_cm))
+    t256 = med(lambda: run(0x1F00, A_cm, W_cm))
+    t256_16 = med(lambda: run(0xF00, A_cm, W_cm))
+    t128_16 = med(lambda: run(0x2700, A_cm, W_cm))
     tpp = med(lambda: run(0x300, A_cm, W))
     bb = bias.to(tdt)
     tv = med(lambda: torch.nn.functional.linear(A, W, bb))
     fl = 2.0 * M * N * K
-    best = min(t128, t256, tpp)
-    for k, v in (("ring128", t128), ("ring256", t256), ("pp", tpp), ("vendor", tv), ("best", best)):
+    best = min(t128, t256, t256_16, t128_16, tpp)
+    for k, v in (("ring128", t128), ("ring256", t256), ("ring256_16", t256_16), ("ring128_16", t128_16), ("pp", tpp), ("vendor", tv), ("best", best)):
         tot[k] += v
     f = lambda t: f"{t * 1e6:8.1f} ({fl / t / 1e12:6.1f})"  # noqa: E731
-    print(f"{name:30s} {f(t128):>24s} {f(t256):>24s} {f(tpp):>22s} {f(tv):>24s}   {best / tv:.3f}")
-print(f"{'sum of the four':30s} {tot['ring128'] * 1e6:24.1f} {tot['ring256'] * 1e6:24.1f} {tot['pp'] * 1e6:22.1f} {tot['vendor'] * 1e6:24.1f}   {tot['best'] / tot['vendor']:.3f}")
+    print(f"{name:30s} {f(t128):>24s} {f(t256):>24s} {f(t256_16):>24s} {f(t128_16):>24s} {f(tpp):>22s} {f(tv):>24s}   {best / tv:.3f}")
+print(f"{'sum':30s} {tot['ring128'] * 1e6:24.1f} {tot['ring256'] * 1e6:24.1f} {tot['ring256_16'] * 1e6:24.1f} {tot['ring128_16'] * 1e6:24.1f} {tot['pp'] * 1e6:22.1f} {tot['vendor'] * 1e6:24.1f}   {tot['best'] / tot['vendor']:.3f}")
