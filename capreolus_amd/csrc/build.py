@@ -16,6 +16,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)          # hazard_lint, when build.py is imported as capreolus_amd.csrc.build
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libcapreolus_amd.so")
 OUT_PROF = os.path.join(HERE, "libcapreolus_amd_prof.so")
@@ -78,7 +79,7 @@ def build(force=False, verbose=False):
     build_pyhost(force, verbose)
     if not force and not stale():
         return OUT
-    procs = []
+    procs, rebuilt = [], []
     for src, obj, extra in _jobs():
         if not force and not _obj_stale(obj, src):
             continue
@@ -86,9 +87,21 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
+        rebuilt.append(obj)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    # the inline-assembly MFMAs' results must not be touched too early by code the compiler put behind them (hazard_lint.py): checked
+    # on every object (re)compiled in this run - a finding is a wrong-answer bug in that build, so the library is not linked
+    import hazard_lint
+
+    for obj in rebuilt:
+        found = hazard_lint.lint_object(obj)
+        if found:
+            func, mfma, ins, seen, need = found[0]
+            os.remove(obj)
+            raise RuntimeError(f"{os.path.basename(obj)}: {len(found)} MFMA result(s) read too early, e.g. in {func}: '{ins}' "
+                               f"{seen} wait states behind '{mfma}' ({need} needed) - see csrc/hazard_lint.py")
     objs = [o for _, o, extra in _jobs() if not extra]
     prof = {s: o for s, o, extra in _jobs() if extra}
     prof_objs = [prof.get(s, o) for s, o, extra in _jobs() if not extra]

@@ -199,6 +199,33 @@ def test_abi_header_and_library_agree():
     assert lib.capamd_packed_table_bytes(400001, 300) == 400001 * 320 * 4
 
 
+def test_no_compiler_generated_read_sits_too_close_behind_an_inline_mfma():
+    """csrc/hazard_lint.py: the hazard LLVM cannot see (an accumulator spilled or copied right behind an inline-assembly MFMA) is
+    reported on a listing that has it, not on one that waits, and is absent from every object the libraries are linked from."""
+    import glob
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "capreolus_amd", "csrc"))
+    import hazard_lint
+
+    mfma = "\tv_mfma_f32_16x16x32_bf16 a[208:211], v[80:83], v[96:99], a[208:211]"
+    early = ["k:", mfma, "\ts_nop 0", "\tv_accvgpr_read_b32 v100, a208"]
+    found = hazard_lint.lint_listing(early)
+    assert len(found) == 1 and found[0][3] == 1 and found[0][4] == 6
+    assert hazard_lint.lint_listing(["k:", mfma, "\ts_nop 5", "\tv_accvgpr_read_b32 v100, a208"]) == []
+    assert hazard_lint.lint_listing(["k:", mfma, "\tv_accvgpr_read_b32 v100, a212"]) == []          # another tile's register
+    assert hazard_lint.lint_listing(["k:", mfma, mfma.replace("v[80:83]", "v[84:87]")]) == []          # MFMA on MFMA: interlocked
+    assert hazard_lint.lint_listing(["k:", mfma, "\ts_branch 12", "\tv_accvgpr_read_b32 v100, a208"]) == []
+    wide = "\tv_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]"
+    assert len(hazard_lint.lint_listing(["k:", wide] + ["\ts_nop 0"] * 9 + ["\tv_mul_f32_e32 v40, v41, v7"])) == 1
+    assert hazard_lint.lint_listing(["k:", wide] + ["\ts_nop 0"] * 10 + ["\tv_mul_f32_e32 v40, v41, v7"]) == []
+    objs = glob.glob(os.path.join(root, "capreolus_amd", "csrc", "*.o"))
+    assert len(objs) >= 17
+    for obj in objs:
+        assert hazard_lint.lint_object(obj) == [], obj
+
+
 def test_abi_entries_reject_null_pointers():
     """Error behaviour at the boundary: every status-returning entry answers CAPAMD_ERR_ARG to null pointers before it touches the
     device (argument checks come first, so this runs without a GPU) - a caller's mistake is an error code, never a crash."""
