@@ -26,6 +26,9 @@
 //                filters = max over the lane's 16 accumulator registers and 0, then one v_permlane32_swap joins the two
 //                halves of two adjacent tiles so that all 64 lanes carry one position each into the top-k insertion.
 //                (Most K slots multiply zeros - 3 of 16 carry weights - and the matrix pipe is still ~9x the VALU form.)
+//   Q <= 4 (pacrr_mfma4_kernel, and every whole-list call): the two-term split of a document offset in ONE product - 6 instead of 12
+//                matrix instructions per 32 positions - and no convolutions further than one 64-position step behind the document's
+//                last term (see pacrr_mfma4_body).  The form above remains for Q = 5.
 #include "capreolus_amd.h"
 #include "interaction.cuh"
 #include "lists.cuh"
@@ -352,7 +355,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifndef CAPAMD_PACRR_ABLATE
-#define CAPAMD_PACRR_ABLATE 0       // profiling builds only: 1 = no convolutions, 2 = no gather, 3 = no combine layers
+#define CAPAMD_PACRR_ABLATE 0       // measurement builds only: 1 = no convolutions, 2 = no gather, 3 = no combine layers, 4 = no table lookups (list route)
 #endif
 #ifndef CAPAMD_PACRR_U
 #define CAPAMD_PACRR_U 1            // embedding rows in flight per 16-lane group in the gather loop
@@ -588,9 +591,206 @@ __device__ __forceinline__ void pacrr_mfma_body(const PacrrArgs& a, const int b,
   pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw);
 }
 
+// ---- the Q <= 4 form of the MFMA back end: half the matrix instructions of the form above ----
+// A 32x32x16 product has 16 K slots; the form above fills 3 of them per half-wave and spends one product on each of hi*hi, lo*hi, hi*lo.
+// With at most four query rows the WHOLE two-term split of one document offset fits one product:
+//     image (LDS, 32 bytes per position):  chunk A = [hi row 0..3 | lo row 0..3]      chunk B = [hi row 0..3 | 1 | 1 | 0 | 0]
+//     lanes 0-31  (K 0-7)  read chunk A of position p + dl:  weights' hi part at slots q + dq (x hi) and 4 + q + dq (x lo)
+//     lanes 32-63 (K 8-15) read chunk B of the same position: weights' lo part at slots q + dq (x hi), the bias' hi and lo parts at the
+//                                                             two constant slots (first product of an n-gram size)
+// i.e. w_hi * (s_hi + s_lo) + w_lo * s_hi + b in ONE instruction per (n-gram size, column dl) - 1 + 2 + 3 = 6 per 32 positions instead
+// of 12 - and the same three terms as before (lo * lo dropped, 2^-22 relative).  Rows q + dq >= 4 are the bottom padding: their slots
+// fall off the 64-bit shift.  The front end writes a position's image as two 16-byte stores (the lookup route) instead of eight
+// halfword stores.
+__device__ __forceinline__ h8 pacrr_a4_fragment(const float* w_ng, const float* b_ng, int ng, int dl, int nfilters, int q, bool with_bias, int lane) {
+  const int f = lane & 31;
+  const bool upper = lane >= 32, live = f < nfilters && dl < ng;
+  unsigned long long x = 0;
+#pragma unroll
+  for (int dq = 0; dq < kPacrrMaxGram; ++dq)
+    if (dq < ng) {
+      const float w = live ? w_ng[(f * ng + dq) * ng + dl] : 0.f;
+      const float h = f16_round(w);
+      x |= (unsigned long long)f16_bits(upper ? w - h : h) << (16 * dq);
+    }
+  const unsigned long long rows = x << (16 * q);
+  u32x4 r = {(unsigned)rows, (unsigned)(rows >> 32), upper ? 0u : (unsigned)rows, upper ? 0u : (unsigned)(rows >> 32)};
+  if (with_bias && upper && f < nfilters) {
+    const float bv = b_ng[f], h = f16_round(bv);
+    r[2] = f16_bits(h) | (f16_bits(bv - h) << 16);
+  }
+  return __builtin_bit_cast(h8, r);
+}
+
+template <int NV, int KM>
+__device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b, const float4* table) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tok_cap = (a.L + 7) & ~7;
+  const int LP = ((a.L + 63) & ~63) + 4;                         // positions in the LDS image (zero tail = right padding)
+  const int r0 = pacrr_mfma_region0(a.L, a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters);
+  int* tok = reinterpret_cast<int*>(smem_raw);
+  unsigned short* start = reinterpret_cast<unsigned short*>(tok + tok_cap);
+  unsigned short* plist = start + tok_cap + 8;
+  float* wts = reinterpret_cast<float*>(smem_raw);               // conv_w | conv_b   (after the front end; the lookup route: from the start)
+  float* feat = wts + a.n_conv_w + (a.maxgram - a.mingram + 1) * a.nfilters;
+  float* h1 = feat + kPacrrMaxFeat;
+  float* h2 = h1 + kPacrrMaxC;
+  _Float16* img = reinterpret_cast<_Float16*>(smem_raw + r0);    // [LP][16]: chunk A | chunk B of the comment above
+  int* wave_cnt = reinterpret_cast<int*>(img + LP * 16);
+  float4* qlds = reinterpret_cast<float4*>(wave_cnt + 48);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u}, ones4 = {0u, 0u, 0x3C003C00u, 0u};   // chunk B of an empty position: slots 4, 5 = 1.0
+  int last = -1;         // this thread's last position that is not padding (id != 0)
+
+  if (table) {
+    // one pass: every position of the image is written once (pads and the tail as zeros), the weights go to region 0 under it
+    int64_t qid[kQT];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) qid[t] = t < a.Q ? ids.q(t) : 0;
+    for (int j = tid; j < LP; j += kThreads) {
+      float x[kQT] = {0.f, 0.f, 0.f, 0.f};
+      const int64_t did = j < a.L ? ids.d(j) : 0;
+      if (did != 0) last = j;
+      if (did > 0 && did < a.V) {        // (an id beyond the table was flagged by the mark pass)
+        const float4 v = CAPAMD_PACRR_ABLATE == 4 ? make_float4(0.25f, 0.5f, 0.125f, 0.75f) : table[did];
+        x[0] = v.x;
+        if (a.Q > 1) x[1] = v.y;
+        if (a.Q > 2) x[2] = v.z;
+        if (a.Q > 3) x[3] = v.w;
+      } else if (did < 0 && did > -2147483648LL) {   // OOV exact matches (equal negative ids): 1.0 (common.py:155-158)
+#pragma unroll
+        for (int t = 0; t < kQT; ++t)
+          if (qid[t] < 0 && (int)qid[t] == (int)did) x[t] = 1.f;
+      }
+      unsigned hb[kQT], lb[kQT];
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) {
+        const float h = f16_round(x[t]);
+        hb[t] = f16_bits(h);
+        lb[t] = f16_bits(x[t] - h);
+      }
+      const u32x4 ca = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+      const u32x4 cb = {ca[0], ca[1], 0x3C003C00u, 0u};
+      reinterpret_cast<u32x4*>(img)[2 * j] = ca;
+      reinterpret_cast<u32x4*>(img)[2 * j + 1] = cb;
+    }
+  } else {
+    // distinct terms and their positions first: the hash of that pass borrows the (not yet initialised) image
+    const TermList tl = distinct_terms_positions(ids, a.L, a.V, a.status, tok, start, plist, reinterpret_cast<int*>(img), LP * 8, wave_cnt);
+    int n_real = tl.n_unique;
+    for (int i = tid; i < LP; i += kThreads) {
+      reinterpret_cast<u32x4*>(img)[2 * i] = zero4;
+      reinterpret_cast<u32x4*>(img)[2 * i + 1] = ones4;
+    }
+    if (CAPAMD_PACRR_ABLATE == 2) n_real = 0;
+    auto put = [&](int row, int j, float x) {
+      const float h = f16_round(x);
+      img[j * 16 + row] = (_Float16)h;
+      img[j * 16 + 4 + row] = (_Float16)(x - h);
+      img[j * 16 + 8 + row] = (_Float16)h;
+    };
+    pacrr_similarities_distinct<NV, CAPAMD_PACRR_U>(a, ids, tok, start, plist, n_real, qlds, tid, put);
+    // (the front end ended on a barrier: tok / pos are dead, region 0 now takes the weights)
+    for (int j = tid; j < a.L; j += kThreads)
+      if (ids.d(j) != 0) last = j;
+  }
+  for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
+  for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+  if (lane == 0) wave_cnt[wave] = last;
+  __syncthreads();
+  // Behind the document's last term every window is all padding: the same value (ReLU of the bias, max over the filters) at every such
+  // position.  The reference takes its k largest over ALL positions, so those values count - but kmax <= 4 copies of them are all the
+  // k-max can use.  The loop below covers the positions up to the last term in 64-position steps plus ONE more step: either that step
+  // holds the rest of the document, or it holds 64 all-padding positions, more copies than the k-max can take.  Same k largest, bit for bit.
+  const int l_end = min(a.L, ((max(max(wave_cnt[0], wave_cnt[1]), max(wave_cnt[2], wave_cnt[3])) + 64) & ~63) + 64);
+
+  // ---- convolutions on the matrix pipe; wave w owns query row w ----
+  for (int q = wave; q < (CAPAMD_PACRR_ABLATE == 1 ? 0 : a.Q); q += 4) {
+    // products: [0] ng=1 dl 0; [1], [2] ng=2 dl 0, 1; [3], [4], [5] ng=3 dl 0, 1, 2
+    h8 af[6];
+    {
+      const float* w = wts;
+      const float* bb = wts + a.n_conv_w;
+#pragma unroll
+      for (int ng = 1; ng <= kPacrrMaxGram; ++ng) {
+        const bool on = ng >= a.mingram && ng <= a.maxgram;
+        const int first = ng * (ng - 1) / 2;
+        // an n-gram size that is switched off keeps all-zero fragments (nfilters = 0)
+#pragma unroll
+        for (int dl = 0; dl < ng; ++dl) af[first + dl] = pacrr_a4_fragment(w, bb, ng, dl, on ? a.nfilters : 0, q, dl == 0, lane);
+        if (on) {
+          w += a.nfilters * ng * ng;
+          bb += a.nfilters;
+        }
+      }
+    }
+    float top[kPacrrMaxGram][KM];
+#pragma unroll
+    for (int g = 0; g < kPacrrMaxGram; ++g)
+#pragma unroll
+      for (int i = 0; i < KM; ++i) top[g][i] = -INFINITY;
+
+    const _Float16* mine = img + (lane & 31) * 16 + (lane >> 5) * 8;       // lanes 32-63: chunk B
+    for (int l0 = 0; l0 < l_end; l0 += 64) {
+      float m[kPacrrMaxGram][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const _Float16* at = mine + (l0 + 32 * t) * 16;
+        const h8 b0 = *reinterpret_cast<const h8*>(at), b1 = *reinterpret_cast<const h8*>(at + 16), b2 = *reinterpret_cast<const h8*>(at + 32);
+        f32x16 c1 = {0}, c2 = {0}, c3 = {0};
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], b0, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], b0, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], b0, c3, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], b1, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[4], b1, c3, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[5], b2, c3, 0, 0, 0);
+        m[0][t] = pacrr_relu_max(c1);   // ReLU + max over this lane's 16 filters
+        m[1][t] = pacrr_relu_max(c2);
+        m[2][t] = pacrr_relu_max(c3);
+      }
+#pragma unroll
+      for (int g = 0; g < kPacrrMaxGram; ++g) {
+        // lanes 0-31 end with tile 0's position (lane), lanes 32-63 with tile 1's (lane - 32): the value of position l0 + lane
+        pacrr_swap32(m[g][0], m[g][1]);
+        const float v = fmaxf(m[g][0], m[g][1]);
+        pacrr_insert(top[g], (l0 + lane < a.L) ? v : -INFINITY);
+      }
+    }
+#pragma unroll
+    for (int ng = 1; ng <= kPacrrMaxGram; ++ng)
+      if (ng >= a.mingram && ng <= a.maxgram) pacrr_wave_topk(top[ng - 1], a.kmax, lane, feat + q * qts + (ng - a.mingram) * a.kmax);
+  }
+  if (CAPAMD_PACRR_ABLATE == 3) {
+    __syncthreads();
+    if (tid == 0) a.out[b] = feat[0];
+    return;
+  }
+  // the image is dead once every wave has its rows' k-max values: the head's weights take its place (when they fit)
+  const float* hw = nullptr;
+  {
+    const int nin = a.Q * qts;
+    if ((size_t)pacrr_head_floats(a, nin) * 4 <= (size_t)LP * 32) {
+      __syncthreads();
+      pacrr_stage_head(a, nin, reinterpret_cast<float*>(img), tid);
+      hw = reinterpret_cast<const float*>(img);
+    }
+  }
+  pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw);
+}
+
 template <int NV, int KM>
 __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_kernel(PacrrArgs a) {
   pacrr_mfma_body<NV, KM>(a, blockIdx.x, nullptr);
+}
+
+template <int NV, int KM>
+__global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma4_kernel(PacrrArgs a) {
+  pacrr_mfma4_body<NV, KM>(a, blockIdx.x, nullptr);
 }
 
 // whole candidate lists: a workgroup per (list, document) in the XCD-aware numbering of lists.cuh
@@ -598,7 +798,7 @@ template <int NV, int KM>
 __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_lists_kernel(PacrrArgs a, ListsArgs la, ListGeom g) {
   int l, doc;
   if (!list_doc_of(la, l, doc) || doc >= g.len[l]) return;
-  pacrr_mfma_body<NV, KM>(a, g.start[l] + doc, la.table + (int64_t)l * la.Vp);
+  pacrr_mfma4_body<NV, KM>(a, g.start[l] + doc, la.table + (int64_t)l * la.Vp);     // (Q <= kQT = 4 on this route)
 }
 
 }  // namespace
@@ -634,7 +834,8 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
                         (size_t)kQT * kMaxNV * 16 * 16;
 #define LAUNCH_M(NV_)                                                                                                           \
   do {                                                                                                                          \
-    auto k = kmax <= 2 ? pacrr_mfma_kernel<NV_, 2> : pacrr_mfma_kernel<NV_, kPacrrMaxK>;                                       \
+    auto k = Q <= 4 ? (kmax <= 2 ? pacrr_mfma4_kernel<NV_, 2> : pacrr_mfma4_kernel<NV_, kPacrrMaxK>)                           \
+                    : (kmax <= 2 ? pacrr_mfma_kernel<NV_, 2> : pacrr_mfma_kernel<NV_, kPacrrMaxK>);                            \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(k, dim3(B), dim3(kThreads), smem, s, a);                                                                 \
   } while (0)

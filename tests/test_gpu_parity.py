@@ -1130,6 +1130,48 @@ def test_pacrr_geometries_match_oracle(Q, L, lo, hi, nf, kmax, idf, nonlin, comb
     assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
 
 
+@pytest.mark.parametrize("last", [-1, 0, 62, 63, 64, 126, 127, 128, 191, 199])
+def test_pacrr_positions_behind_the_last_term_count_as_the_reference_counts_them(last, monkeypatch):
+    """The matrix-pipe kernel (Q <= 4) stops its convolutions one 64-position step behind the document's last term: every window further
+    on is all padding and has the same value, and the k-max can use at most kmax copies of it (PACRR.py:64-75 takes the k largest over ALL
+    positions).  Documents whose last term sits on and around the step boundaries, with padding INSIDE the document and a bias vector that
+    makes the padding value the largest (positive biases) or irrelevant (negative ones): the oracle's scores, the general kernel's, and the
+    whole-list route's bit for bit."""
+    Q, L, lo, hi, nf, kmax, comb, V, D = 4, 200, 1, 3, 32, 4, 16, 150, 60
+    rng = np.random.default_rng(1000 + last)
+    emb = synthetic.make_embeddings(V, D, seed=5)
+    B = 12
+    q = rng.integers(1, V, (B, Q)); d = rng.integers(1, V, (B, L))
+    d[:, last + 1:] = 0
+    if last > 3:
+        d[:, 2:last:3] *= rng.integers(0, 2, (B, len(range(2, last, 3))))       # padding inside the document
+        d[:, last] = rng.integers(1, V, B)
+    idfv = rng.random((B, Q), dtype=np.float32) * 6
+    n = hi - lo + 1
+    cws = [rng.standard_normal((nf, 1, g, g)).astype(np.float32) * 0.5 for g in range(lo, hi + 1)]
+    sign = 1.0 if last % 2 == 0 else -1.0
+    cbs = [(sign * np.abs(rng.standard_normal(nf)) * 0.6).astype(np.float32) for _ in range(n)]
+    F = Q * (n * kmax + 1)
+    w1 = rng.standard_normal((comb, F)).astype(np.float32) * 0.3; b1 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w2 = rng.standard_normal((comb, comb)).astype(np.float32) * 0.3; b2 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w3 = rng.standard_normal((1, comb)).astype(np.float32) * 0.3; b3 = rng.standard_normal(1).astype(np.float32)
+    want, err = oracle.pacrr(q, d, idfv, oracle.pack(emb), D, lo, hi, nf, kmax, cws, cbs, True, w1, b1, w2, b2, w3, b3, "relu")
+    assert err == 0
+    pe = engine.PackedEmbedding()
+    args = (pe.get(_t(emb)), V, D, lo, hi, nf, kmax, _t(np.concatenate([w.ravel() for w in cws])), _t(np.concatenate(cbs)), True, "relu",
+            _t(w1), _t(b1), _t(w2), _t(b2), _t(w3.ravel()), _t(b3))
+    got = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args).cpu().numpy()
+    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    monkeypatch.setenv("CAPAMD_PACRR_VALU", "1")
+    valu = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args).cpu().numpy()
+    assert rel_err(valu, got).max() <= ORACLE_TOL
+    monkeypatch.delenv("CAPAMD_PACRR_VALU")
+    ql = np.repeat(q[:3], 4, axis=0); il = np.repeat(idfv[:3], 4, axis=0)            # three lists of four documents
+    pair = engine.pacrr_forward(_t(ql), _t(d), _t(il), *args)
+    lists = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d))
+    assert torch.equal(pair, lists)
+
+
 def test_pacrr_errors():
     c = load_case("pacrr", "tanh_noidf_short")
     r = _pacrr_reranker(c)
