@@ -1,0 +1,16 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { python bench.py --no-cpu-baseline --no-also --no-roofline-leg --no-pmc-traffic --no-pass-times "$@" 2>gpurun_out/err.txt | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$*', round(d['value']/1e6,2), 'M pairs/s', round(d['ms_per_step'],4), 'ms')" || tail -3 gpurun_out/err.txt; }
+for round in 1 2; do
+run --model knrm
+run --model knrm --launch-docs 32000 --launch-streams 2
+run --model knrm --launch-docs 16000 --launch-streams 4
+run --model knrm --launch-docs 16000 --launch-streams 2
+run --model knrm --launch-docs 8000 --launch-streams 4
+run --model drmm
+run --model drmm --launch-docs 125000 --launch-streams 2
+run --model drmm --launch-docs 50000 --launch-streams 5
+run --model drmm --launch-docs 50000 --launch-streams 2
+done
