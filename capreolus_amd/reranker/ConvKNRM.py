@@ -153,9 +153,23 @@ class ConvKNRM(Reranker):
         return self.model.fused_train_step(d, optimizer, softmax)
 
     def fused_step_available(self, batch_size):
-        """whether `fused_train_step` takes this configuration (a single-Linear `combine`, batches of <= 512 pairs, the HIP training kernels' geometry limits)"""
+        """whether `fused_train_step` takes this configuration: every limit that method checks per batch (a single-Linear `combine`,
+        <= 512 pairs, the HIP training kernels' geometry - filters, n-gram sizes x query terms, kernel bank, embedding width), from the
+        configuration, the extractor's `maxqlen` and the built model, so that the trainer chooses between the device step and the graph
+        route BEFORE it builds its optimizer"""
         c = self.config
-        return bool(c["singlefc"]) and batch_size <= 512 and c["filters"] % 4 == 0 and c["filters"] <= 256 and c["maxngram"] <= 4
+        if not (bool(c["singlefc"]) and batch_size <= 512 and c["filters"] % 4 == 0 and c["filters"] <= 256 and c["maxngram"] <= 4):
+            return False
+        cfg = getattr(getattr(self, "extractor", None), "config", None)
+        maxqlen = int(cfg["maxqlen"]) if isinstance(cfg, dict) and "maxqlen" in cfg else 4
+        if (c["maxngram"] if c["crossmatch"] else 1) * maxqlen > 24:
+            return False
+        m = getattr(self, "model", None)
+        if m is not None:
+            D = m.embeddings.weight.shape[1]
+            if m.kernels.count() > 16 or D % 4 or D > 316:
+                return False
+        return True
 
     def zero_grad(self, *args, **kwargs):
         self.model.zero_grad(*args, **kwargs)

@@ -80,3 +80,16 @@ def test_cedrknrm_mirror_names():
     assert not any("pooler" in k for k in e.state_dict()) and "bert.encoder.layer.1.output.dense.bias" in e.state_dict()
     with pytest.raises(AssertionError):
         rr.CEDRKNRM(dict(cfg, simmat_layers=[-1], cls=None), r.extractor).build_model()
+
+
+def test_fused_step_available_knows_the_per_batch_limits_before_the_optimizer_is_built():
+    """`fused_step_available` answers from the configuration and the extractor's maxqlen what `fused_train_step` would only find out on
+    the first batch (a `None` from the first batch leaves the trainer on eager steps instead of the captured-graph route)."""
+    emb = np.zeros((10, 60), dtype=np.float32)
+    ck = lambda maxqlen, **kw: rr.ConvKNRM(dict(rr.ConvKNRM.config_spec, **kw), SimpleNamespace(embeddings=emb, config={"maxqlen": maxqlen}))
+    assert ck(4).fused_step_available(32) and ck(8).fused_step_available(512)
+    assert not ck(9).fused_step_available(32)                  # 3 n-gram sizes x 9 query terms > 24 rows
+    assert ck(24, crossmatch=False).fused_step_available(32)   # without crossmatch a view meets its own size only
+    assert not ck(4).fused_step_available(513) and not ck(4, singlefc=False).fused_step_available(32) and not ck(4, filters=130).fused_step_available(32)
+    dr = lambda maxqlen: rr.DRMM(dict(rr.DRMM.config_spec), SimpleNamespace(embeddings=emb, config={"maxqlen": maxqlen}))
+    assert dr(4).fused_step_available(128) and not dr(4).fused_step_available(129) and not dr(8).fused_step_available(128) and dr(8).fused_step_available(64)
