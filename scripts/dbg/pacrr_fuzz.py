@@ -1,0 +1,56 @@
+"""PACRR matrix-pipe kernels against the C oracle on random geometries (per-pair route and whole-list route): python scripts/dbg/pacrr_fuzz.py [n]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from capreolus_amd import engine, synthetic
+from oracle import cpu as oracle
+from tests.helpers import rel_err
+
+DEV = "cuda:0"
+_t = lambda a: torch.as_tensor(a).to(DEV)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(7)
+worst = 0.0
+for it in range(n):
+    Q = int(rng.integers(1, 6)); L = int(rng.integers(4, 420)) if it % 5 else int(rng.integers(700, 1001))
+    lo = int(rng.integers(1, 4)); hi = int(rng.integers(lo, 4)); nf = int(rng.integers(1, 33)); kmax = int(rng.integers(1, min(4, L) + 1))
+    idf = bool(rng.integers(0, 2)); nonlin = ["relu", "tanh"][int(rng.integers(0, 2))]; comb = int(rng.integers(1, 33))
+    V, D, B = 150, 60, 12
+    emb = synthetic.make_embeddings(V, D, seed=5)
+    q = rng.integers(0, V, (B, Q)); d = rng.integers(0, V, (B, L))
+    cut = rng.integers(0, L + 1, B)
+    for b in range(B):
+        d[b, cut[b]:] = 0
+    d *= (rng.random((B, L)) > 0.1)                    # padding inside the document
+    q[0, :] = -5 if it % 7 == 0 else q[0, :]           # an OOV query (equal negative ids match OOV document terms)
+    if it % 7 == 0:
+        d[0, : min(3, L)] = -5
+    q[:, 0] = np.maximum(q[:, 0], 1) if it % 7 else q[:, 0]
+    idfv = rng.random((B, Q), dtype=np.float32) * 6
+    ng = hi - lo + 1
+    cws = [rng.standard_normal((nf, 1, g, g)).astype(np.float32) * 0.5 for g in range(lo, hi + 1)]
+    cbs = [rng.standard_normal(nf).astype(np.float32) * 0.3 for _ in range(ng)]
+    F = Q * (ng * kmax + int(idf))
+    w1 = rng.standard_normal((comb, F)).astype(np.float32) * 0.3; b1 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w2 = rng.standard_normal((comb, comb)).astype(np.float32) * 0.3; b2 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w3 = rng.standard_normal((1, comb)).astype(np.float32) * 0.3; b3 = rng.standard_normal(1).astype(np.float32)
+    want, err = oracle.pacrr(q, d, idfv, oracle.pack(emb), D, lo, hi, nf, kmax, cws, cbs, idf, w1, b1, w2, b2, w3, b3, nonlin)
+    assert err == 0
+    pe = engine.PackedEmbedding()
+    args = (pe.get(_t(emb)), V, D, lo, hi, nf, kmax, _t(np.concatenate([w.ravel() for w in cws])), _t(np.concatenate(cbs)), idf, nonlin,
+            _t(w1), _t(b1), _t(w2), _t(b2), _t(w3.ravel()), _t(b3))
+    got = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args)
+    e = float(rel_err(got.cpu().numpy(), want).max())
+    worst = max(worst, e)
+    if e > 2e-5:      # (conditioning: the general fp32 kernel lands at the same level on these)
+        os.environ["CAPAMD_PACRR_VALU"] = "1"
+        valu = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args)
+        del os.environ["CAPAMD_PACRR_VALU"]
+        ev = float(rel_err(valu.cpu().numpy(), want).max())
+        print("ABOVE 2e-5:", (it, Q, L, lo, hi, nf, kmax, idf, nonlin, comb), "mfma", e, "valu", ev, "scale", float(np.abs(want).max()))
+    if Q <= 4:
+        ql = np.repeat(q[:3], 4, axis=0); il = np.repeat(idfv[:3], 4, axis=0)
+        pair = engine.pacrr_forward(_t(ql), _t(d), _t(il), *args)
+        lists = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d))
+        assert torch.equal(pair, lists), (it, Q, L, lo, hi, nf, kmax)
+print(f"pacrr_fuzz: {n} geometries, worst error of scale {worst:.2e}")
