@@ -40,6 +40,9 @@ constexpr int kCkMaxRows = kCkMaxG * kCkMaxG * kCkMaxQ;   // (view, query term) 
 constexpr int kCkMaxTpr = 16;                             // threads per row in the pooling phase
 constexpr int kCkPoolCols = 2 * kCkTile;                  // the pooling phase runs once per two tiles
 constexpr float kLog2e = 1.4426950408889634f;
+#ifndef CAPAMD_CK_WAVES
+#define CAPAMD_CK_WAVES 3    // waves per SIMD the register budget allows (164 registers at 128 filters); 4 measured: see DESIGN.md §6 N4
+#endif
 #ifndef CAPAMD_CK_ABLATE
 #define CAPAMD_CK_ABLATE 0   // profiling builds only, bit mask: 1 = no gather (phase A), 2 = no MFMA (phase B), 4 = no pooling (phase C)
 #endif
@@ -232,7 +235,7 @@ __device__ __forceinline__ void ck_store_unit(const float4 (&v)[NF4], int F4, in
 }
 
 template <int NF4>
-__global__ __launch_bounds__(kThreads, 3) void convknrm_forward_kernel(ConvKnrmArgs a) {
+__global__ __launch_bounds__(kThreads, CAPAMD_CK_WAVES) void convknrm_forward_kernel(ConvKnrmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lane16 = tid & 15, grp = tid >> 4;
   const int b = blockIdx.x;
