@@ -896,12 +896,12 @@ def main():
                 rec["resident_int32_route"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
             rec["also"] = []
-            # ... and the row-N4 siblings (short legs: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)
+            # ... and the row-N4 siblings (short legs - 12 steps after 4, one warm-up step per rotating batch: timed scores checked against the oracle, an HBM-bound leg each, no CPU timing)
             for leg in (lambda: interaction_record(args, ctx, "drmm", max(5, args.steps // 2), 3, default_queries("drmm"), with_cpu=not args.no_cpu_baseline),
                         lambda: bench_bert(args, ctx, 5, 2, with_cpu=not args.no_cpu_baseline),
-                        lambda: bench_sibling(args, ctx, "drmmtks", 5, 2, with_cpu=False),
-                        lambda: bench_sibling(args, ctx, "pacrr", 5, 2, with_cpu=False),
-                        lambda: bench_sibling(args, ctx, "convknrm", 5, 2, with_cpu=False)):
+                        lambda: bench_sibling(args, ctx, "drmmtks", 12, 4, with_cpu=False),
+                        lambda: bench_sibling(args, ctx, "pacrr", 12, 4, with_cpu=False),
+                        lambda: bench_sibling(args, ctx, "convknrm", 12, 4, with_cpu=False)):
                 try:
                     rec["also"].append(leg())
                 except Exception as e:  # noqa: BLE001  a failing secondary leg must not take the headline line with it
