@@ -508,7 +508,15 @@ __device__ __forceinline__ void pacrr_mfma_body(const PacrrArgs& a, const int b,
   // (the front end ended on a barrier: tok / pos are dead, region 0 now takes the weights)
   for (int i = tid; i < a.n_conv_w; i += kThreads) wts[i] = a.conv_w[i];
   for (int i = tid; i < n_ng * a.nfilters; i += kThreads) wts[a.n_conv_w + i] = a.conv_b[i];
+  // no convolutions further than one 64-position step behind the document's last term (see pacrr_mfma4_body: the same k largest)
+  int last = -1;
+  for (int j = tid; j < a.L; j += kThreads)
+    if (ids.d(j) != 0) last = j;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+  if (lane == 0) wave_cnt[wave] = last;
   __syncthreads();
+  const int l_end = min(a.L, ((max(max(wave_cnt[0], wave_cnt[1]), max(wave_cnt[2], wave_cnt[3])) + 64) & ~63) + 64);
 
   // ---- convolutions on the matrix pipe; wave w owns query rows w, w + 4 ----
   for (int q = wave; q < (CAPAMD_PACRR_ABLATE == 1 ? 0 : a.Q); q += 4) {
@@ -537,7 +545,7 @@ __device__ __forceinline__ void pacrr_mfma_body(const PacrrArgs& a, const int b,
 #pragma unroll
       for (int i = 0; i < KM; ++i) top[g][i] = -INFINITY;
 
-    for (int l0 = 0; l0 < a.L; l0 += 64) {
+    for (int l0 = 0; l0 < l_end; l0 += 64) {
       float m[kPacrrMaxGram][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {

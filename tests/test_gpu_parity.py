@@ -1130,15 +1130,16 @@ def test_pacrr_geometries_match_oracle(Q, L, lo, hi, nf, kmax, idf, nonlin, comb
     assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
 
 
+@pytest.mark.parametrize("Q", [4, 5])
 @pytest.mark.parametrize("last", [-1, 0, 62, 63, 64, 126, 127, 128, 191, 199])
-def test_pacrr_positions_behind_the_last_term_count_as_the_reference_counts_them(last, monkeypatch):
-    """The matrix-pipe kernel (Q <= 4) stops its convolutions one 64-position step behind the document's last term: every window further
+def test_pacrr_positions_behind_the_last_term_count_as_the_reference_counts_them(last, Q, monkeypatch):
+    """The matrix-pipe kernels (the Q <= 4 form and the Q = 5 form) stop their convolutions one 64-position step behind the document's last term: every window further
     on is all padding and has the same value, and the k-max can use at most kmax copies of it (PACRR.py:64-75 takes the k largest over ALL
     positions).  Documents whose last term sits on and around the step boundaries, with padding INSIDE the document and a bias vector that
     makes the padding value the largest (positive biases) or irrelevant (negative ones): the oracle's scores, the general kernel's, and the
     whole-list route's bit for bit."""
-    Q, L, lo, hi, nf, kmax, comb, V, D = 4, 200, 1, 3, 32, 4, 16, 150, 60
-    rng = np.random.default_rng(1000 + last)
+    L, lo, hi, nf, kmax, comb, V, D = 200, 1, 3, 32, 4, 16, 150, 60
+    rng = np.random.default_rng(1000 + last + 17 * Q)
     emb = synthetic.make_embeddings(V, D, seed=5)
     B = 12
     q = rng.integers(1, V, (B, Q)); d = rng.integers(1, V, (B, L))
@@ -1161,11 +1162,15 @@ def test_pacrr_positions_behind_the_last_term_count_as_the_reference_counts_them
     args = (pe.get(_t(emb)), V, D, lo, hi, nf, kmax, _t(np.concatenate([w.ravel() for w in cws])), _t(np.concatenate(cbs)), True, "relu",
             _t(w1), _t(b1), _t(w2), _t(b2), _t(w3.ravel()), _t(b3))
     got = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args).cpu().numpy()
-    assert rel_err(got, want).max() <= ORACLE_TOL, rel_err(got, want).max()
+    # (against the batch's largest score: with random combine weights a score can be a cancellation to ~0, where 2e-7 is not 2e-5 of it)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= ORACLE_TOL * scale, np.abs(got - want).max() / scale
     monkeypatch.setenv("CAPAMD_PACRR_VALU", "1")
     valu = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args).cpu().numpy()
-    assert rel_err(valu, got).max() <= ORACLE_TOL
+    assert np.abs(valu - got).max() <= ORACLE_TOL * scale
     monkeypatch.delenv("CAPAMD_PACRR_VALU")
+    if Q > 4:
+        return                 # (the whole-list route takes up to four query terms)
     ql = np.repeat(q[:3], 4, axis=0); il = np.repeat(idfv[:3], 4, axis=0)            # three lists of four documents
     pair = engine.pacrr_forward(_t(ql), _t(d), _t(il), *args)
     lists = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d))
