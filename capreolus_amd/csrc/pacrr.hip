@@ -210,13 +210,14 @@ __device__ __forceinline__ void pacrr_insert(float (&top)[KM], float v) {
 // `hw` != nullptr: the three layers' weights and biases staged in LDS by the caller (w1 [C][nin] | w2 [C][C] | w3 [C] | b1 [C] | b2 [C] |
 // b3) - one parallel round trip for all of them; from global memory a thread walks its row's weights a few loads at a time, about a dozen
 // dependent round trips per pair during which the workgroup does nothing else.
+// `idf_pre` != nullptr: the query's raw idf values (clamped index beyond Q) the caller requested earlier, under its convolutions
 __device__ __forceinline__ void pacrr_head(const PacrrArgs& a, const PairIds& ids, float* feat, float* h1, float* h2, int qts, int tid, int b,
-                                           const float* hw = nullptr) {
+                                           const float* hw = nullptr, const float* idf_pre = nullptr) {
   if (a.use_idf && tid == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50)
     const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
     float idf[kPacrrMaxQ];   // (Q <= 8; requested together - clamped index - instead of one dependent load per use: three loops over Q by one thread)
 #pragma unroll
-    for (int q = 0; q < kPacrrMaxQ; ++q) idf[q] = idf_g[q < a.Q ? q : a.Q - 1];
+    for (int q = 0; q < kPacrrMaxQ; ++q) idf[q] = idf_pre ? idf_pre[q < kQT ? q : kQT - 1] : idf_g[q < a.Q ? q : a.Q - 1];
     float m = idf[0];
 #pragma unroll
     for (int q = 1; q < 8; ++q)
@@ -717,6 +718,29 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
   // holds the rest of the document, or it holds 64 all-padding positions, more copies than the k-max can take.  Same k largest, bit for bit.
   const int l_end = min(a.L, ((max(max(wave_cnt[0], wave_cnt[1]), max(wave_cnt[2], wave_cnt[3])) + 64) & ~63) + 64);
 
+  // The head's weights and the query's idf row are REQUESTED here, into registers, and reach LDS behind the convolutions: asked for
+  // after them, the two round trips (idf row; ~8 KB of weights) sit in a pair's serial tail with nothing of this workgroup beside them
+  // (the combine layers were 0.19 ms of the 1.37 ms call).  8 weights per thread cover the reference's default head (2,017 floats).
+  constexpr int kHeadRegs = 8;
+  const int nin_h = a.Q * qts, n1_h = a.C * nin_h, n2_h = a.C * a.C, nh = pacrr_head_floats(a, nin_h);
+  // (kmax <= 2 builds only: with four candidates per lane and n-gram size the eight registers are two spills at 128)
+  const bool head_in_regs = KM <= 2 && (size_t)nh * 4 <= (size_t)LP * 32 && nh <= kHeadRegs * kThreads;
+  float hreg[kHeadRegs], idf_pre[kQT];
+  if (head_in_regs) {
+#pragma unroll
+    for (int k = 0; k < kHeadRegs; ++k) {
+      const int i = tid + k * kThreads;
+      const float* src = i < n1_h ? a.w1 + i : i < n1_h + n2_h ? a.w2 + (i - n1_h) : i < n1_h + n2_h + a.C ? a.w3 + (i - n1_h - n2_h)
+                         : i < n1_h + n2_h + 2 * a.C ? a.b1 + (i - n1_h - n2_h - a.C) : i < n1_h + n2_h + 3 * a.C ? a.b2 + (i - n1_h - n2_h - 2 * a.C) : a.b3;
+      hreg[k] = i < nh ? *src : 0.f;
+    }
+  }
+  if (a.use_idf) {
+    const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) idf_pre[t] = idf_g[t < a.Q ? t : a.Q - 1];
+  }
+
   // ---- convolutions on the matrix pipe; wave w owns query row w ----
   for (int q = wave; q < (CAPAMD_PACRR_ABLATE == 1 ? 0 : a.Q); q += 4) {
     // products: [0] ng=1 dl 0; [1], [2] ng=2 dl 0, 1; [3], [4], [5] ng=3 dl 0, 1, 2
@@ -782,13 +806,22 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
   const float* hw = nullptr;
   {
     const int nin = a.Q * qts;
-    if ((size_t)pacrr_head_floats(a, nin) * 4 <= (size_t)LP * 32) {
+    if (head_in_regs) {
+      __syncthreads();
+      float* dst = reinterpret_cast<float*>(img);
+#pragma unroll
+      for (int k = 0; k < kHeadRegs; ++k) {
+        const int i = tid + k * kThreads;
+        if (i < nh) dst[i] = hreg[k];
+      }
+      hw = dst;
+    } else if ((size_t)pacrr_head_floats(a, nin) * 4 <= (size_t)LP * 32) {
       __syncthreads();
       pacrr_stage_head(a, nin, reinterpret_cast<float*>(img), tid);
       hw = reinterpret_cast<const float*>(img);
     }
   }
-  pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw);
+  pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw, a.use_idf ? idf_pre : nullptr);
 }
 
 template <int NV, int KM>
