@@ -57,6 +57,8 @@ struct PacrrArgs {
   const float *w1, *b1, *w2, *b2, *w3, *b3;
   float* out;
   int* status;
+  float* feats;          // whole-list route: != nullptr -> the pair's [Q][qts] k-max features go here (row stride kPacrrMaxFeat) and the combine
+                         // layers run in pacrr_head_lists_kernel afterwards; nullptr -> the kernel ends with the pair's own head
 };
 
 __device__ __forceinline__ float pacrr_act(float x, int nonlin) { return nonlin == 1 ? fmaxf(x, 0.f) : (nonlin == 2 ? tanhf(x) : x); }
@@ -724,7 +726,7 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
   constexpr int kHeadRegs = 8;
   const int nin_h = a.Q * qts, n1_h = a.C * nin_h, n2_h = a.C * a.C, nh = pacrr_head_floats(a, nin_h);
   // (kmax <= 2 builds only: with four candidates per lane and n-gram size the eight registers are two spills at 128)
-  const bool head_in_regs = KM <= 2 && (size_t)nh * 4 <= (size_t)LP * 32 && nh <= kHeadRegs * kThreads;
+  const bool head_in_regs = KM <= 2 && !a.feats && (size_t)nh * 4 <= (size_t)LP * 32 && nh <= kHeadRegs * kThreads;
   float hreg[kHeadRegs], idf_pre[kQT];
   if (head_in_regs) {
 #pragma unroll
@@ -735,7 +737,7 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
       hreg[k] = i < nh ? *src : 0.f;
     }
   }
-  if (a.use_idf) {
+  if (a.use_idf && !a.feats) {
     const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
 #pragma unroll
     for (int t = 0; t < kQT; ++t) idf_pre[t] = idf_g[t < a.Q ? t : a.Q - 1];
@@ -802,6 +804,11 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
     if (tid == 0) a.out[b] = feat[0];
     return;
   }
+  if (a.feats) {          // the combine layers of all the call's pairs run in one pass afterwards (pacrr_head_lists_kernel)
+    __syncthreads();
+    if (tid < a.Q * qts) a.feats[(int64_t)b * kPacrrMaxFeat + tid] = feat[tid];
+    return;
+  }
   // the image is dead once every wave has its rows' k-max values: the head's weights take its place (when they fit)
   const float* hw = nullptr;
   {
@@ -822,6 +829,165 @@ __device__ __forceinline__ void pacrr_mfma4_body(const PacrrArgs& a, const int b
     }
   }
   pacrr_head(a, ids, feat, h1, h2, qts, tid, b, hw, a.use_idf ? idf_pre : nullptr);
+}
+
+// The combine layers of the whole-list route, for all pairs [p0, p0 + n) of a launch group in one pass: inside pacrr_mfma_lists_kernel they
+// are a serial tail per pair - idf row, 8 KB of weights staged, three dependent layers on 32 of 256 threads - 0.19 ms of a 1.33 ms call.
+// Here the weights are staged once per workgroup, TPP threads take a pair (TPP >= C), 256 / TPP pairs per trip.  The arithmetic per pair is
+// pacrr_head's, operation for operation (sequential idf softmax by the pair's first thread, fma chains in input order): the same bits.
+// The reference's default head (Q x (3 kmax + 1) <= 32 inputs, combine <= 32) with every thread's weight rows in REGISTERS across its
+// workgroup's trips: thread (slot, o) keeps row o of w1 and w2 (zeros beyond nin / C: fma(0, x, s) = s exactly, so the unrolled 32-step
+// chains round like pacrr_head's nin- and C-step chains), the trip's inputs are one LDS broadcast read per four values, and the next
+// trip's features and idf row are requested before the current trip's layers.  (The general kernel below walks its chains one LDS
+// round trip per input: 144 us per 64,000 pairs where this form needs ~15.)
+__global__ __launch_bounds__(kThreads) void pacrr_head32_lists_kernel(PacrrArgs a, int p0, int n) {
+  constexpr int TPP = 32, kSlots = kThreads / TPP;
+  __shared__ __attribute__((aligned(16))) float feat_s[kSlots][32], h1_s[kSlots][32], h2_s[kSlots][32];
+  const int tid = threadIdx.x, slot = tid / TPP, o = tid % TPP;
+  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0), nin = a.Q * qts;
+  const int oc = o < a.C ? o : a.C - 1;
+  float w1r[32], w2r[32], w3r[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    w1r[i] = i < nin ? a.w1[oc * nin + i] : 0.f;
+    w2r[i] = i < a.C ? a.w2[oc * a.C + i] : 0.f;
+    w3r[i] = i < a.C ? a.w3[i] : 0.f;
+  }
+  const float b1v = a.b1[oc], b2v = a.b2[oc], b3v = a.b3[0];
+  auto request = [&](int pr, float& f, float (&idf)[kQT]) {      // thread o: feature o of the pair; its first thread: the query's idf row
+    const int b = p0 + (pr < n ? pr : n - 1);
+    f = o < nin ? a.feats[(int64_t)b * kPacrrMaxFeat + o] : 0.f;
+    if (a.use_idf && o == 0) {
+      const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+      const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) idf[t] = idf_g[t < a.Q ? t : a.Q - 1];
+    }
+  };
+  float f_next, idf_next[kQT] = {0.f, 0.f, 0.f, 0.f};
+  request(blockIdx.x * kSlots + slot, f_next, idf_next);
+  for (int base = blockIdx.x * kSlots; base < n; base += gridDim.x * kSlots) {
+    const int pr = base + slot;
+    const bool live = pr < n;
+    const float f = f_next;
+    float idf[kQT];
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) idf[t] = idf_next[t];
+    if (base + gridDim.x * kSlots < n) request(pr + gridDim.x * kSlots, f_next, idf_next);
+    __syncthreads();      // (the previous trip's h2 has been read)
+    if (!(a.use_idf && o < nin && o % qts == qts - 1)) feat_s[slot][o] = f;     // (the idf channel's slots are its first thread's, below)
+    if (a.use_idf && o == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50), as pacrr_head computes it
+      float m = idf[0];
+#pragma unroll
+      for (int q = 1; q < kQT; ++q)
+        if (q < a.Q) m = fmaxf(m, idf[q]);
+      float den = 0.f;
+#pragma unroll
+      for (int q = 0; q < kQT; ++q)
+        if (q < a.Q) den += expf(idf[q] - m);
+#pragma unroll
+      for (int q = 0; q < kQT; ++q)
+        if (q < a.Q) feat_s[slot][q * qts + qts - 1] = expf(idf[q] - m) / den;
+    }
+    __syncthreads();
+    {
+      float s = b1v;
+#pragma unroll
+      for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 x = *reinterpret_cast<const float4*>(&feat_s[slot][4 * i4]);
+        s = __builtin_fmaf(w1r[4 * i4], x.x, s);
+        s = __builtin_fmaf(w1r[4 * i4 + 1], x.y, s);
+        s = __builtin_fmaf(w1r[4 * i4 + 2], x.z, s);
+        s = __builtin_fmaf(w1r[4 * i4 + 3], x.w, s);
+      }
+      h1_s[slot][o] = o < a.C ? pacrr_act(s, a.nonlin) : 0.f;
+    }
+    __syncthreads();
+    {
+      float s = b2v;
+#pragma unroll
+      for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 x = *reinterpret_cast<const float4*>(&h1_s[slot][4 * i4]);
+        s = __builtin_fmaf(w2r[4 * i4], x.x, s);
+        s = __builtin_fmaf(w2r[4 * i4 + 1], x.y, s);
+        s = __builtin_fmaf(w2r[4 * i4 + 2], x.z, s);
+        s = __builtin_fmaf(w2r[4 * i4 + 3], x.w, s);
+      }
+      h2_s[slot][o] = o < a.C ? pacrr_act(s, a.nonlin) : 0.f;
+    }
+    __syncthreads();
+    if (live && o == 0) {
+      float s = b3v;
+#pragma unroll
+      for (int i4 = 0; i4 < 8; ++i4) {
+        const float4 x = *reinterpret_cast<const float4*>(&h2_s[slot][4 * i4]);
+        s = __builtin_fmaf(w3r[4 * i4], x.x, s);
+        s = __builtin_fmaf(w3r[4 * i4 + 1], x.y, s);
+        s = __builtin_fmaf(w3r[4 * i4 + 2], x.z, s);
+        s = __builtin_fmaf(w3r[4 * i4 + 3], x.w, s);
+      }
+      a.out[p0 + pr] = s;
+    }
+  }
+}
+
+template <int TPP>
+__global__ __launch_bounds__(kThreads) void pacrr_head_lists_kernel(PacrrArgs a, int p0, int n) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int kSlots = kThreads / TPP;
+  const int tid = threadIdx.x, slot = tid / TPP, o = tid % TPP;
+  const int n_ng = a.maxgram - a.mingram + 1, qts = n_ng * a.kmax + (a.use_idf ? 1 : 0), nin = a.Q * qts;
+  float* hw = reinterpret_cast<float*>(smem_raw);
+  float* feat = hw + ((pacrr_head_floats(a, nin) + 3) & ~3) + slot * (kPacrrMaxFeat + 2 * kPacrrMaxC);
+  float* h1 = feat + kPacrrMaxFeat;
+  float* h2 = h1 + kPacrrMaxC;
+  pacrr_stage_head(a, nin, hw, tid);
+  const float *w1 = hw, *w2 = w1 + a.C * nin, *w3 = w2 + a.C * a.C, *b1 = w3 + a.C, *b2 = b1 + a.C, *b3 = b2 + a.C;
+  for (int base = blockIdx.x * kSlots; base < n; base += gridDim.x * kSlots) {
+    const int pr = base + slot, b = p0 + pr;
+    const bool live = pr < n;
+    __syncthreads();      // (the staged weights; the previous trip's h2 has been read)
+    if (live) {
+      for (int i = o; i < nin; i += TPP)
+        if (!(a.use_idf && i % qts == qts - 1)) feat[i] = a.feats[(int64_t)b * kPacrrMaxFeat + i];     // (the idf channel's slots: below)
+      if (a.use_idf && o == 0) {   // softmax over the raw idf values of the query (PACRR.py:48-50), as pacrr_head computes it
+        const PairIds ids = pair_ids(a.ids, b, a.Q, a.L);
+        const float* idf_g = a.idf + (int64_t)ids.qrow * a.Q;
+        float idf[kPacrrMaxQ];
+#pragma unroll
+        for (int q = 0; q < kPacrrMaxQ; ++q) idf[q] = idf_g[q < a.Q ? q : a.Q - 1];
+        float m = idf[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+          if (q < a.Q) m = fmaxf(m, idf[q]);
+        float den = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < a.Q) den += expf(idf[q] - m);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < a.Q) feat[q * qts + qts - 1] = expf(idf[q] - m) / den;
+      }
+    }
+    __syncthreads();
+    if (live && o < a.C) {
+      float s = b1[o];
+      for (int i = 0; i < nin; ++i) s = __builtin_fmaf(w1[o * nin + i], feat[i], s);
+      h1[o] = pacrr_act(s, a.nonlin);
+    }
+    __syncthreads();
+    if (live && o < a.C) {
+      float s = b2[o];
+      for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(w2[o * a.C + i], h1[i], s);
+      h2[o] = pacrr_act(s, a.nonlin);
+    }
+    __syncthreads();
+    if (live && o == 0) {
+      float s = b3[0];
+      for (int i = 0; i < a.C; ++i) s = __builtin_fmaf(w3[i], h2[i], s);
+      a.out[b] = s;
+    }
+  }
 }
 
 template <int NV, int KM>
@@ -865,7 +1031,7 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
   for (int ng = mingram; ng <= maxgram; ++ng) ncw += nfilters * ng * ng;
   const IdSource ids{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   PacrrArgs a{ids, idf, B, Q, L, packed, V, mingram, maxgram, nfilters, kmax, conv_w, conv_b, ncw, use_idf ? 1 : 0, combine, nonlinearity,
-              w1, b1, w2, b2, w3, b3, out, status};
+              w1, b1, w2, b2, w3, b3, out, status, nullptr};
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
   const size_t tail = (size_t)(ncw + (maxgram - mingram + 1) * nfilters) * 4 + (size_t)(kPacrrMaxFeat + 2 * kPacrrMaxC + 8) * 4 + 16 +
@@ -939,10 +1105,28 @@ extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d
   for (int ng = mingram; ng <= maxgram; ++ng) ncw += nfilters * ng * ng;
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   PacrrArgs a{ids, idf, 0, Q, L, packed, V, mingram, maxgram, nfilters, kmax, conv_w, conv_b, ncw, use_idf ? 1 : 0, combine, nonlinearity,
-              w1, b1, w2, b2, w3, b3, out, status};
+              w1, b1, w2, b2, w3, b3, out, status, nullptr};
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = (size_t)pacrr_mfma_region0(L, ncw + (maxgram - mingram + 1) * nfilters) + (size_t)(((L + 63) & ~63) + 4) * 32 + 192 +
                       (size_t)kQT * kMaxNV * 16 * 16;
+  // The combine layers in one pass behind the convolutions (pacrr_head_lists_kernel) when the workspace has room for the pairs' features
+  // BEHIND what the lists in flight need (416 B per pair; a workspace sized by capamd_lists_workspace_bytes with the call's n_pairs has
+  // 4 L + 32 per pair that this entry does not otherwise use) and the head's weights fit a workgroup's LDS; else every pair's own head at
+  // the end of the convolution kernel.  Same scores bit for bit either way: a matter of speed only.
+  const int qts = (maxgram - mingram + 1) * kmax + (use_idf ? 1 : 0), nin = Q * qts;
+  const size_t head_floats = (size_t)combine * nin + (size_t)combine * combine + 3 * (size_t)combine + 1;
+  const int tpp = combine <= 32 ? 32 : combine <= 64 ? 64 : 128;
+  const size_t head_smem = (((head_floats + 3) & ~(size_t)3) + (size_t)(kThreads / tpp) * (kPacrrMaxFeat + 2 * kPacrrMaxC)) * 4;
+  if (list_offsets_host && workspace && head_smem <= 48 * 1024) {
+    const int64_t n_pairs = list_offsets_host[n_lists];
+    const size_t feat_bytes = ((size_t)(n_pairs > 0 ? n_pairs : 0) * kPacrrMaxFeat * 4 + 15) & ~(size_t)15;
+    const size_t lists_need = capamd_lists_workspace_bytes(n_lists, V, 0, L);
+    if (n_pairs > 0 && lists_need > 0 && workspace_bytes >= lists_need + feat_bytes + 16) {
+      const size_t at = (workspace_bytes - feat_bytes) & ~(size_t)15;
+      a.feats = reinterpret_cast<float*>(static_cast<char*>(workspace) + at);
+      workspace_bytes = at;
+    }
+  }
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, false, nullptr,
                    [&](const ListsArgs& la, const ListGeom& g, int nl, int longest) {
 #define LAUNCH_L(NV_)                                                                                                           \
@@ -959,5 +1143,14 @@ extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d
                        default: LAUNCH_L(5); break;
                      }
 #undef LAUNCH_L
+                     if (a.feats) {       // the group's pairs are contiguous: lists laid out one after the other
+                       const int p0 = g.start[0], n = g.start[nl - 1] + g.len[nl - 1] - p0;
+                       const int slots = kThreads / tpp, trips = (n + slots - 1) / slots;
+                       const dim3 hg((unsigned)(trips < 2048 ? trips : 2048));
+                       if (nin <= 32 && combine <= 32) hipLaunchKernelGGL(pacrr_head32_lists_kernel, dim3((unsigned)(trips < 1024 ? trips : 1024)), dim3(kThreads), 0, s, a, p0, n);
+                       else if (tpp == 32) hipLaunchKernelGGL(pacrr_head_lists_kernel<32>, hg, dim3(kThreads), head_smem, s, a, p0, n);
+                       else if (tpp == 64) hipLaunchKernelGGL(pacrr_head_lists_kernel<64>, hg, dim3(kThreads), head_smem, s, a, p0, n);
+                       else hipLaunchKernelGGL(pacrr_head_lists_kernel<128>, hg, dim3(kThreads), head_smem, s, a, p0, n);
+                     }
                    });
 }

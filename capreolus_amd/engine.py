@@ -1035,8 +1035,10 @@ def pacrr_forward(query, doc, idf, packed, V, D, mingram, maxgram, nfilters, kma
 
 
 def pacrr_forward_lists(offsets, idf, packed, V, D, mingram, maxgram, nfilters, kmax, conv_w, conv_b, use_idf, nonlinearity, w1, b1, w2, b2, w3, b3,
-                        query=None, doc=None, store=None, pair_q=None, pair_d=None, out=None, check=True):
-    """PACRR over whole candidate lists (capamd_pacrr_forward_lists); `idf`: [B, Q] per pair, or the store's [NQ, Q] table."""
+                        query=None, doc=None, store=None, pair_q=None, pair_d=None, out=None, check=True, pair_part=True):
+    """PACRR over whole candidate lists (capamd_pacrr_forward_lists); `idf`: [B, Q] per pair, or the store's [NQ, Q] table.
+    `pair_part=False` hands the library a workspace without the per-pair part (capamd_lists_workspace_bytes with n_pairs = 0): the combine
+    layers then run at the end of every pair's convolution workgroup instead of in one pass behind them - the same scores, bit for bit."""
     q, d, qt, dt, pq, pd, B, Q, L, dev = _lists_ids(query, doc, store, pair_q, pair_d)
     _need_gpu(packed, conv_w, conv_b, w1, b1, w2, b2, w3, b3)
     off = _list_offsets(offsets)
@@ -1047,7 +1049,7 @@ def pacrr_forward_lists(offsets, idf, packed, V, D, mingram, maxgram, nfilters, 
     idf = _f32(idf)
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B if pair_part else 0, L)
     rc = _lib.load().capamd_pacrr_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         int(mingram), int(maxgram), int(nfilters), int(kmax), _ptr(conv_w), _ptr(conv_b), int(bool(use_idf)), w1.shape[0], NONLINEARITIES[nonlinearity],

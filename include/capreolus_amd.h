@@ -181,8 +181,9 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V, n_pairs, L) bytes (16-byte aligned;
  * any contents), in two parts:
  *   per PAIR of the call   4 x L + 32 bytes: the document's real term ids, compacted to int32 by the first pass (what the pooling pass reads
- *                          instead of the [L] id row), and its pad / OOV counts - 3.2 KB per pair at L = 800 (capamd_pacrr_forward_lists does not
- *                          use this part: pass n_pairs = 0 for it)
+ *                          instead of the [L] id row), and its pad / OOV counts - 3.2 KB per pair at L = 800 (capamd_pacrr_forward_lists keeps
+ *                          416 B of features per pair there and runs its combine layers in one pass behind the convolutions; with n_pairs = 0
+ *                          - no such room - every pair's combine layers run inside its convolution workgroup: same scores, slower)
  *   per LIST in flight     17 B x V + 5 KB (a 16-byte table entry and a flag byte per vocabulary id): 6.8 MB at V = 400,001, 68 MB at V = 4 M;
  *                          at most 64 lists are in flight at a time - FEWER when the buffer is smaller (a caller bounds the workspace by
  *                          handing in less: the lists are then processed in more, smaller groups; CAPAMD_ERR_WORKSPACE below one list). */

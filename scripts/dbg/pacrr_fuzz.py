@@ -14,7 +14,7 @@ worst = 0.0
 for it in range(n):
     Q = int(rng.integers(1, 6)); L = int(rng.integers(4, 420)) if it % 5 else int(rng.integers(700, 1001))
     lo = int(rng.integers(1, 4)); hi = int(rng.integers(lo, 4)); nf = int(rng.integers(1, 33)); kmax = int(rng.integers(1, min(4, L) + 1))
-    idf = bool(rng.integers(0, 2)); nonlin = ["relu", "tanh"][int(rng.integers(0, 2))]; comb = int(rng.integers(1, 33))
+    idf = bool(rng.integers(0, 2)); nonlin = ["relu", "tanh"][int(rng.integers(0, 2))]; comb = int(rng.integers(1, 33)) if it % 6 else int(rng.integers(33, 129))
     V, D, B = 150, 60, 12
     emb = synthetic.make_embeddings(V, D, seed=5)
     q = rng.integers(0, V, (B, Q)); d = rng.integers(0, V, (B, L))
@@ -54,4 +54,6 @@ for it in range(n):
         pair = engine.pacrr_forward(_t(ql), _t(d), _t(il), *args)
         lists = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d))
         assert torch.equal(pair, lists), (it, Q, L, lo, hi, nf, kmax)
+        lists2 = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d), pair_part=False)
+        assert torch.equal(pair, lists2), ("no pair part", it, Q, L, lo, hi, nf, kmax)
 print(f"pacrr_fuzz: {n} geometries, worst error of scale {worst:.2e}")

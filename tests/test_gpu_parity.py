@@ -1175,6 +1175,38 @@ def test_pacrr_positions_behind_the_last_term_count_as_the_reference_counts_them
     pair = engine.pacrr_forward(_t(ql), _t(d), _t(il), *args)
     lists = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d))
     assert torch.equal(pair, lists)
+    # ... and with a workspace that has no room for the pairs' features: the combine layers inside the convolution kernel, the same bits
+    lists2 = engine.pacrr_forward_lists(np.array([0, 4, 8, 12]), _t(il), *args, query=_t(ql), doc=_t(d), pair_part=False)
+    assert torch.equal(pair, lists2)
+
+
+@pytest.mark.parametrize("comb,kmax,idf", [(8, 2, True), (32, 2, True), (32, 4, True), (48, 2, False), (100, 3, True), (128, 4, True)])
+def test_pacrr_list_route_combine_layers_in_one_pass_give_the_per_pair_bits(comb, kmax, idf):
+    """The whole-list route runs the combine layers of all pairs behind the convolutions (pacrr_head32_lists_kernel for the default head
+    size - inputs and width <= 32 -, pacrr_head_lists_kernel<32 / 64 / 128> otherwise, every pair's own head inside the convolution kernel
+    when the weights do not fit a workgroup's LDS or the workspace has no per-pair part): each form against the per-pair kernel, bit for bit."""
+    Q, L, lo, hi, nf, V, D, B = 4, 120, 1, 3, 32, 150, 60, 40
+    rng = np.random.default_rng(comb * 10 + kmax)
+    emb = synthetic.make_embeddings(V, D, seed=5)
+    q = np.repeat(rng.integers(1, V, (4, Q)), 10, axis=0); d = rng.integers(0, V, (B, L))
+    d[:, 70:] *= rng.integers(0, 2, (B, 1))
+    idfv = np.repeat(rng.random((4, Q), dtype=np.float32) * 6, 10, axis=0)
+    n = hi - lo + 1
+    cws = [rng.standard_normal((nf, 1, g, g)).astype(np.float32) * 0.5 for g in range(lo, hi + 1)]
+    cbs = [rng.standard_normal(nf).astype(np.float32) * 0.1 for _ in range(n)]
+    F = Q * (n * kmax + int(idf))
+    w1 = rng.standard_normal((comb, F)).astype(np.float32) * 0.3; b1 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w2 = rng.standard_normal((comb, comb)).astype(np.float32) * 0.2; b2 = rng.standard_normal(comb).astype(np.float32) * 0.1
+    w3 = rng.standard_normal((1, comb)).astype(np.float32) * 0.3; b3 = rng.standard_normal(1).astype(np.float32)
+    pe = engine.PackedEmbedding()
+    args = (pe.get(_t(emb)), V, D, lo, hi, nf, kmax, _t(np.concatenate([w.ravel() for w in cws])), _t(np.concatenate(cbs)), idf, "tanh",
+            _t(w1), _t(b1), _t(w2), _t(b2), _t(w3.ravel()), _t(b3))
+    pair = engine.pacrr_forward(_t(q), _t(d), _t(idfv), *args)
+    want, err = oracle.pacrr(q, d, idfv, oracle.pack(emb), D, lo, hi, nf, kmax, cws, cbs, idf, w1, b1, w2, b2, w3, b3, "tanh")
+    assert err == 0 and np.abs(pair.cpu().numpy() - want).max() <= ORACLE_TOL * np.abs(want).max()
+    off = np.array([0, 10, 20, 30, 40])
+    assert torch.equal(pair, engine.pacrr_forward_lists(off, _t(idfv), *args, query=_t(q), doc=_t(d)))
+    assert torch.equal(pair, engine.pacrr_forward_lists(off, _t(idfv), *args, query=_t(q), doc=_t(d), pair_part=False))
 
 
 def test_pacrr_errors():
