@@ -20,7 +20,10 @@ using namespace capamd;
 
 namespace {
 
-constexpr int kListChunk = 64;            // lists per launch group (their start / length travel as kernel arguments)
+#ifndef CAPAMD_LIST_CHUNK
+#define CAPAMD_LIST_CHUNK 256     // 64 until round 5: DRMM at configs[2] (250 lists per call) 129.8 -> 140.4 (128) -> 142.3 M pairs/s (256): fewer, longer passes, fewer tails
+#endif
+constexpr int kListChunk = CAPAMD_LIST_CHUNK;            // lists per launch group (their start / length travel as kernel arguments)
 #ifndef CAPAMD_LISTS_SIMS_IDS
 #define CAPAMD_LISTS_SIMS_IDS 1024
 #endif

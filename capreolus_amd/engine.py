@@ -485,7 +485,7 @@ def drmm_forward_indexed(q_table, d_table, idf_table, pair_q, pair_d, packed, V,
 # ---- whole candidate lists (capamd_*_forward_lists) ------------------------------------------------------------------------------
 _list_workspaces = {}
 # Bytes the per-list part of a whole-list call's workspace may take (17 B x V per list in flight: 6.8 MB at V = 400,001, but 68 MB at
-# V = 4 M - 64 lists would be 4.3 GB): fewer lists are kept in flight when it would be exceeded (the library then works through the
+# V = 4 M - 64 lists would be 4.3 GB, the 256 a launch group takes 17 GB): fewer lists are kept in flight when it would be exceeded (the library then works through the
 # lists in more, smaller groups).  The per-pair part (4 L + 32 bytes per pair of the call) comes on top.
 LISTS_WORKSPACE_BUDGET = 2 << 30
 

@@ -185,7 +185,7 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  *                          416 B of features per pair there and runs its combine layers in one pass behind the convolutions; with n_pairs = 0
  *                          - no such room - every pair's combine layers run inside its convolution workgroup: same scores, slower)
  *   per LIST in flight     17 B x V + 5 KB (a 16-byte table entry and a flag byte per vocabulary id): 6.8 MB at V = 400,001, 68 MB at V = 4 M;
- *                          at most 64 lists are in flight at a time - FEWER when the buffer is smaller (a caller bounds the workspace by
+ *                          at most 256 lists are in flight at a time - FEWER when the buffer is smaller (a caller bounds the workspace by
  *                          handing in less: the lists are then processed in more, smaller groups; CAPAMD_ERR_WORKSPACE below one list). */
 size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L);
 int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
