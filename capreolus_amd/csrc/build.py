@@ -95,6 +95,9 @@ def build(force=False, verbose=False):
     # on every object (re)compiled in this run - a finding is a wrong-answer bug in that build, so the library is not linked
     import hazard_lint
 
+    if not os.path.exists(hazard_lint.OBJDUMP):      # (a toolchain without llvm-objdump: the check cannot run - say so, do not fail the build)
+        print(f"build.py: {hazard_lint.OBJDUMP} not found - the MFMA hazard lint is skipped", file=sys.stderr)
+        rebuilt = []
     for obj in rebuilt:
         found = hazard_lint.lint_object(obj)
         if found:
