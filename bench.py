@@ -644,8 +644,12 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
 # What bounds each pass of the whole-list route and the peak it is priced against:
 F32_PEAK_TFLOPS = 157.3        # fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md "Peak FP32 (vector)" / "(matrix)")
 # RBF kernel evaluations per second the VALUs sustain when they do nothing else: scripts/ubench/valu_rates.hip's loop of the pooling
-# kernel's evaluation (v_fma, v_mul, v_exp_f32, v_add per value), every SIMD busy; profiles/r04/valu_rates.txt
-KERNEL_EVAL_PEAK_G = 7150.0
+# kernel's evaluation in the form the kernel uses (K(s) = 2^-(A s + B)^2: fma, mul, exp, add per value), every SIMD busy.  The row taken:
+# "4-instruction form", 16 waves per CU = 8,529 G/s (profiles/r05/valu_rates.txt; 8,160 at 8 waves per CU, 8,735 at 32; the pooling kernel
+# runs 24 waves per CU at 76 registers).  Until round 5 this constant was 7,150 - the 5-instruction form's row, which the kernel no longer uses.
+KERNEL_EVAL_PEAK_G = 8529.0
+KERNEL_EVAL_PEAK_SOURCE = ("scripts/ubench/valu_rates.hip, 4-instruction form (fma mul exp add), 16 waves per CU: 8,529 G evaluations/s "
+                           "(8,160 at 8 waves per CU, 8,735 at 32; the kernel runs 24): profiles/r05/valu_rates.txt")
 SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("mfma" once they are v_mfma_f32_4x4x1_16b_f32)
 # What binds the sims pass, from the builder-run counter passes (scripts/dbg/pmc_lists.sh -> profiles/r05/pmc_lists_{knrm,drmm}.txt; PMC runs
 # cannot share a process with the timed loop): VALU issue utilisation = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (SIMDs x kernel cycles),
@@ -673,7 +677,8 @@ def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic
             if q.get("pipe", "valu") == "valu":      # (priced against the fp32 vector peak - the pipe its arithmetic runs on - but bound by its waits)
                 e.update(bound="latency", limiter=SIMS_LIMITER)
         elif "exponentials" in q:
-            e.update(bound="valu", achieved=q["exponentials"] / (ms * 1e-3) / 1e9, peak=KERNEL_EVAL_PEAK_G, unit="G kernel evaluations/s")
+            e.update(bound="valu", achieved=q["exponentials"] / (ms * 1e-3) / 1e9, peak=KERNEL_EVAL_PEAK_G, unit="G kernel evaluations/s",
+                     peak_source=KERNEL_EVAL_PEAK_SOURCE)
         elif "id_row_bytes" in q:
             e.update(bound="hbm", achieved=(q["id_row_bytes"] + q.get("bytes_written", 0)) / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         if "achieved" in e:
