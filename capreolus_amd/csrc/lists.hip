@@ -68,6 +68,15 @@ struct KnrmPoolArgs {
 // No LDS and no barrier: the row reduction is DPP, the per-kernel logs run in lanes (query term, kernel), the read-out takes the
 // kernels' features by readlane.  (A workgroup per document - four waves sharing its positions, LDS reduction, one lane per kernel for
 // the logs - measured 465 us per 64,000 documents against this form's 352.)
+#ifndef CAPAMD_POOL_WAVES
+#define CAPAMD_POOL_WAVES 1     // register budget as waves per SIMD (the kernel takes 76 registers: 6 waves; 8 = at most 64 registers)
+#endif
+#ifndef CAPAMD_POOL_KB_VGPR
+#define CAPAMD_POOL_KB_VGPR 1        // (0: the round-4 form - A/B builds; profiles/r05/lists_pool_kbv_ab.txt)
+#endif
+#ifndef CAPAMD_POOL_LATE_WEIGHTS
+#define CAPAMD_POOL_LATE_WEIGHTS 1   // the read-out's weights requested behind the position loop: 14 registers fewer across it (what pays for the B pairs)
+#endif
 #ifndef CAPAMD_POOL_TRIPS
 #define CAPAMD_POOL_TRIPS 8
 #endif
@@ -95,7 +104,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin
 constexpr int kPoolHot = CAPAMD_POOL_HOT, kPoolDocs = CAPAMD_POOL_DOCS, kPoolHotBins = CAPAMD_POOL_HOT_BINS;
 
 template <int KK>
-__global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+__global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
   __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];
   int l, dq;
   if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
@@ -114,7 +123,18 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     ka[k] = a.kn_consts[4 * kMaxK + k];
     kb[k] = a.kn_consts[5 * kMaxK + k];
   }
+#if CAPAMD_POOL_KB_VGPR
+  // the kernels' B constants as register PAIRS in VGPRs: uniform values live in SGPRs, and a VALU instruction reads one SGPR operand -
+  // with A and B both there every packed fma is preceded by a v_mov_b64 of its B pair (6 of ~37 VALU instructions per trip)
+  f32x2 kbv[KK / 2 + 1];
+#pragma unroll
+  for (int k = 0; k + 1 < KK; k += 2) {
+    kbv[k / 2] = f32x2{kb[k], kb[k + 1]};
+    asm volatile("" : "+v"(kbv[k / 2]));
+  }
+#endif
   const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
+#if CAPAMD_POOL_LATE_WEIGHTS == 0
   // the read-out's weights: the same for every document
   const int hn = lane < m.hidden ? lane : 0;
   float w1v[kMaxK];
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
   for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
   const int kq = lane & 15;
   const float k0c = (kq < m.K) ? a.kn_consts[2 * kMaxK + kq] : 0.f, k1c = (kq < m.K) ? a.kn_consts[3 * kMaxK + kq] : 0.f;
+#endif
   for (int di = 0; di < kPoolDocs; ++di) {
   const int doc = (dq * kPoolDocs + di) * 4 + wave;
   if (doc >= g.len[l]) break;
@@ -165,7 +186,11 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
         // issue slots - 2.5 instead of 4 VALU instructions per evaluation beside its v_exp_f32); an odd last kernel on its own
 #pragma unroll
         for (int k = 0; k + 1 < KK; k += 2) {
+#if CAPAMD_POOL_KB_VGPR
+          const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + kbv[k / 2];
+#else
           const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + f32x2{kb[k], kb[k + 1]};
+#endif
           const f32x2 nq = -tk * tk;
           const f32x2 e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
           f32x2 ac = {acc[k], acc[k + 1]};
@@ -179,6 +204,15 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
       }
     }
   }
+#if CAPAMD_POOL_LATE_WEIGHTS
+  // the read-out's weights requested only now: 14 registers fewer across the position loop
+  const int hn = lane < m.hidden ? lane : 0;
+  float w1v[kMaxK];
+#pragma unroll
+  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
+  const int kq = lane & 15;
+  const float k0c = (kq < m.K) ? a.kn_consts[2 * kMaxK + kq] : 0.f, k1c = (kq < m.K) ? a.kn_consts[3 * kMaxK + kq] : 0.f;
+#endif
   // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
   const int k = lane & 15;
   float S = 0.f;

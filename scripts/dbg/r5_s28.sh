@@ -1,0 +1,11 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT
+for round in 1 2 3; do
+for v in base kbv kbv0; do
+  libenv="X=1"; [ $v != base ] && libenv="CAPAMD_LIB_PATH=$R/capreolus_amd/csrc/ablate/libcapreolus_amd_$v.so"
+  env $libenv python bench.py --model knrm --no-cpu-baseline --no-also --no-roofline-leg --no-pmc-traffic --no-pass-times 2>gpurun_out/err_$v.txt | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$v knrm', round(d['value']/1e6,2), 'M pairs/s', round(d['ms_per_step'],4), 'ms')"
+done
+done
