@@ -71,6 +71,9 @@ struct KnrmPoolArgs {
 #ifndef CAPAMD_POOL_WAVES
 #define CAPAMD_POOL_WAVES 1     // register budget as waves per SIMD (the kernel takes 76 registers: 6 waves; 8 = at most 64 registers)
 #endif
+#ifndef CAPAMD_POOL_PREFETCH
+#define CAPAMD_POOL_PREFETCH 0
+#endif
 #ifndef CAPAMD_POOL_KB_VGPR
 #define CAPAMD_POOL_KB_VGPR 1        // (0: the round-4 form - A/B builds; profiles/r05/lists_pool_kbv_ab.txt)
 #endif
@@ -154,8 +157,29 @@ __global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_kernel
   float acc[KK], rs = 0.f;
 #pragma unroll
   for (int k = 0; k < KK; ++k) acc[k] = 0.f;
+#if CAPAMD_POOL_PREFETCH
+  // The compact row's entries of the NEXT pass are requested before the current pass's lookups and arithmetic, and the first pass's
+  // before the document's length is known (the row has cid_stride entries whatever it holds: indices clamped, entries masked by n once
+  // it is here) - per document the chain  metadata -> ids -> table entries -> arithmetic  loses its second link.
+  int idn[kWaveTrips];
+  auto request = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) {
+      const int j = j0 + u * 16 + ps;
+      idn[u] = __builtin_nontemporal_load(dw.row + (j < a.cid_stride ? j : a.cid_stride - 1));
+    }
+  };
+  if (kCompactRows) request(0);
+#endif
   for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
     int id[kWaveTrips];
+#if CAPAMD_POOL_PREFETCH
+    if (kCompactRows) {
+#pragma unroll
+      for (int u = 0; u < kWaveTrips; ++u) id[u] = (j0 + u * 16 + ps < n) ? idn[u] : 0;
+      if (j0 + 16 * kWaveTrips < n) request(j0 + 16 * kWaveTrips);
+    } else
+#endif
     load_pass<kWaveTrips, 16>(dw, j0, ps, id);
     float s[kWaveTrips];
     if (kPoolHot > 0) {
