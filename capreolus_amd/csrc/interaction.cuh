@@ -586,6 +586,40 @@ __device__ __forceinline__ void rows_dot2_pk(const RowRegs<NV>& d0, const RowReg
   p0[0] = acc0[0].x; p0[1] = acc0[0].y; p0[2] = acc0[1].x; p0[3] = acc0[1].y;
   p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
 }
+// three rows per trip: the LDS query copy read once for three rows (A/B builds: -DCAPAMD_LISTS_SIMS_ROWS=3)
+template <int NV>
+__device__ __forceinline__ void rows_dot3_pk(const RowRegs<NV>& d0, const RowRegs<NV>& d1, const RowRegs<NV>& d2, const float4* qlds, int lane16,
+                                             float (&p0)[kQT], float (&p1)[kQT], float (&p2)[kQT]) {
+  f32x2 acc0[2] = {{0.f, 0.f}, {0.f, 0.f}}, acc1[2] = {{0.f, 0.f}, {0.f, 0.f}}, acc2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const float4 qa = qlds[((P * NV + i) * 2 + 0) * 16 + lane16], qb = qlds[((P * NV + i) * 2 + 1) * 16 + lane16];
+      f32x2 a = acc0[P], b = acc1[P], c = acc2[P];
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].x, d0.v[i].x}, (f32x2){qa.x, qa.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].x, d1.v[i].x}, (f32x2){qa.x, qa.y}, b);
+      c = __builtin_elementwise_fma((f32x2){d2.v[i].x, d2.v[i].x}, (f32x2){qa.x, qa.y}, c);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].y, d0.v[i].y}, (f32x2){qa.z, qa.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].y, d1.v[i].y}, (f32x2){qa.z, qa.w}, b);
+      c = __builtin_elementwise_fma((f32x2){d2.v[i].y, d2.v[i].y}, (f32x2){qa.z, qa.w}, c);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].z, d0.v[i].z}, (f32x2){qb.x, qb.y}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].z, d1.v[i].z}, (f32x2){qb.x, qb.y}, b);
+      c = __builtin_elementwise_fma((f32x2){d2.v[i].z, d2.v[i].z}, (f32x2){qb.x, qb.y}, c);
+      a = __builtin_elementwise_fma((f32x2){d0.v[i].w, d0.v[i].w}, (f32x2){qb.z, qb.w}, a);
+      b = __builtin_elementwise_fma((f32x2){d1.v[i].w, d1.v[i].w}, (f32x2){qb.z, qb.w}, b);
+      c = __builtin_elementwise_fma((f32x2){d2.v[i].w, d2.v[i].w}, (f32x2){qb.z, qb.w}, c);
+      acc0[P] = a;
+      acc1[P] = b;
+      acc2[P] = c;
+    }
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc2[0]), "+v"(acc2[1]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  p0[0] = acc0[0].x; p0[1] = acc0[0].y; p0[2] = acc0[1].x; p0[3] = acc0[1].y;
+  p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
+  p2[0] = acc2[0].x; p2[1] = acc2[0].y; p2[2] = acc2[1].x; p2[3] = acc2[1].y;
+}
 template <int NV>
 __device__ __forceinline__ float sim_from_dots(const float (&p)[kQT], float dden, const QueryPass<NV>& qp, int lane16) {
   float r[kQT];

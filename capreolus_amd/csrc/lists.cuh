@@ -406,6 +406,9 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
 }
 
 #ifndef CAPAMD_LISTS_SIMS_MFMA
+#ifndef CAPAMD_LISTS_SIMS_ROWS
+#define CAPAMD_LISTS_SIMS_ROWS 2      // rows per 16-lane group and trip (3: A/B builds)
+#endif
 #ifndef CAPAMD_LISTS_SIMS_WAVES
 #define CAPAMD_LISTS_SIMS_WAVES 1
 #endif
@@ -470,6 +473,25 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
     }
   };
   // two rows per group and trip: the LDS query copy is read once for both; packed fmas (rows_dot2_pk: per row and term the fma order of rows_dot)
+#if CAPAMD_LISTS_SIMS_ROWS == 3
+#pragma clang loop unroll(disable)
+  for (int e = grp; e < total; e += 3 * kGroupsPerWG) {
+    const int ida = id0 + lst[e], idb = id0 + lst[e + kGroupsPerWG < total ? e + kGroupsPerWG : e],
+              idc = id0 + lst[e + 2 * kGroupsPerWG < total ? e + 2 * kGroupsPerWG : e];
+    RowRegs<NV> da, db, dc;
+    load_row<NV>(a.packed, ida, lane16, da);
+    load_row<NV>(a.packed, idb, lane16, db);
+    load_row<NV>(a.packed, idc, lane16, dc);
+    float pa[kQT], pb[kQT], pc[kQT];
+    int qoff = 0;
+    asm volatile("" : "+v"(qoff));
+    rows_dot3_pk<NV>(da, db, dc, qlds + qoff, lane16, pa, pb, pc);
+    put(ida, sim_from_dots<NV>(pa, row_den<NV>(da), qp, lane16));
+    put(idb, sim_from_dots<NV>(pb, row_den<NV>(db), qp, lane16));
+    put(idc, sim_from_dots<NV>(pc, row_den<NV>(dc), qp, lane16));
+  }
+  return;
+#endif
 #pragma clang loop unroll(disable)
   for (int e = grp; e < total; e += 2 * kGroupsPerWG) {
     const int ida = id0 + lst[e], idb = id0 + lst[e + kGroupsPerWG < total ? e + kGroupsPerWG : e];
