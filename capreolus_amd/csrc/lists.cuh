@@ -136,6 +136,9 @@ __global__ __launch_bounds__(256) void lists_clear_kernel(ListsArgs a) {
 // real terms of 800 positions on the benchmark's lists: 78 MB written here, 330 MB not read there); the OOV terms are counted, those
 // equal to one of the list's OOV query terms per term (their similarity is exactly 1, common.py:155-158; everything else without a row
 // is exactly 0: the pooling pass adds both in closed form).  EMIT = false (PACRR: its kernel needs positions) only flags.
+#ifndef CAPAMD_MARK_ABL
+#define CAPAMD_MARK_ABL 0        // measurement builds: 1 = no flag stores, 2 = no compact-row stores
+#endif
 #ifndef CAPAMD_MARK_TRIPS
 #define CAPAMD_MARK_TRIPS 13
 #endif
@@ -214,11 +217,11 @@ __global__ __launch_bounds__(256) void lists_mark_kernel(ListsArgs a, ListGeom g
       if (v >= a.V) bad = true;
       // (unconditional: a check of the flag first puts a load in front of every store and measures the same.  Ids below a.preflag are
       //  flagged by lists_clear_kernel for every list - on frequency-ordered vocabularies two thirds of all positions' stores)
-      if (real && v >= a.preflag) f[v] = 1;
+      if (!(CAPAMD_MARK_ABL & 1) && real && v >= a.preflag) f[v] = 1;
       if (EMIT) {
         const uint64_t set = __ballot(real);
         if (kCompactRows) {
-          if (real) out[n_real + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = (int)v;
+          if (!(CAPAMD_MARK_ABL & 2) && real) out[n_real + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u))] = (int)v;
         } else if (set) {
           used = j0 + u * 64 + 64 - __builtin_clzll(set);
         }
