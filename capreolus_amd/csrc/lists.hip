@@ -107,7 +107,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin
 constexpr int kPoolHot = CAPAMD_POOL_HOT, kPoolDocs = CAPAMD_POOL_DOCS, kPoolHotBins = CAPAMD_POOL_HOT_BINS;
 
 template <int KK>
-__global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+__global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_wide_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
   __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];
   int l, dq;
   if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
@@ -278,6 +278,174 @@ __global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_kernel
     if (lane == 0) m.out[b] = sc;
   }
   }   // documents of this wave
+}
+
+// ---- 3a': the pooling pass that does not evaluate what it knows ----------------------------------------------------------------
+// lists_knrm_pool_wide_kernel above gives every query term 16 lanes whatever the query holds.  A term that is NOT real (a pad of the
+// reference's fixed-length query row, or an OOV term) has similarity exactly 0 with every table entry - the sims pass wrote 0.f - so its
+// row's sums are known without a lookup: sum_j K_k(0) over the document's real positions, with K_k(0) = 2^-(B_k^2) exactly as the
+// evaluation produces it for s = 0 (fma(0, A, B) = B), and its feature is 0 anyway unless it is an OOV term the document matches
+// (KNRM.py:51-53: rows whose similarities sum to 0 are masked).  With one or two real terms (half of the benchmark's queries: 1-4 terms,
+// uniform; Robust04 titles average 2.7) the wave's 64 lanes take 64 or 32 positions per trip instead of 16:
+//     real terms 1:  lane = position slot (64 per trip);  2: lanes 0-31 the first, 32-63 the second real term (32 per trip);  3-4: as above.
+// The sums of an evaluated row add the same values as before in another order (lanes hold other positions): KNRM's list route was never
+// bit-identical to the per-pair kernel's summation order (include/capreolus_amd.h); DRMM / DRMM-TKS / PACRR do not come through here.
+#ifndef CAPAMD_POOL_NARROW
+#define CAPAMD_POOL_NARROW 1      // 0: lists_knrm_pool_wide_kernel for every list (A/B builds)
+#endif
+
+// one document's positions in trips of W (64 / W lanes-groups take the wave's 64 / W ... terms): acc[k] += K_k(s), rs += s for this lane's positions
+template <int KK, int W>
+__device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lane, const float* tabsel, const float (&ka)[KK], const float (&kb)[KK],
+                                               const f32x2 (&kbv)[KK / 2 + 1], float (&acc)[KK], float& rs) {
+  const int ps = lane & (W - 1);
+  for (int j0 = 0; j0 < n; j0 += W * kWaveTrips) {
+    int id[kWaveTrips];
+    load_pass<kWaveTrips, W>(dw, j0, ps, id);
+    float s[kWaveTrips];
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) s[u] = tabsel[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+    // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
+#pragma unroll
+    for (int u = 0; u < kWaveTrips; ++u) {
+      if (j0 + u * W >= n) continue;          // (wave-uniform)
+      if (id[u] > 0) {
+        rs += s[u];
+#pragma unroll
+        for (int k = 0; k + 1 < KK; k += 2) {
+          const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + kbv[k / 2];
+          const f32x2 nq = -tk * tk;
+          const f32x2 e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+          f32x2 ac = {acc[k], acc[k + 1]};
+          ac += e;
+          acc[k] = ac.x; acc[k + 1] = ac.y;
+        }
+        if (KK & 1) {
+          const float tk = __builtin_fmaf(s[u], ka[KK - 1], kb[KK - 1]);
+          acc[KK - 1] += __builtin_amdgcn_exp2f(-tk * tk);
+        }
+      }
+    }
+  }
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+  int l, dq;
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 documents here)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane >> 4, k = lane & 15;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
+  float ka[KK], kb[KK];      // K_k(s) = 2^-(ka s + kb)^2
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    ka[kk] = a.kn_consts[4 * kMaxK + kk];
+    kb[kk] = a.kn_consts[5 * kMaxK + kk];
+  }
+  // (B as register PAIRS in VGPRs: both constants in SGPRs cost a v_mov_b64 in front of every packed fma - lists_knrm_pool_wide_kernel)
+  f32x2 kbv[KK / 2 + 1];
+#pragma unroll
+  for (int kk = 0; kk + 1 < KK; kk += 2) {
+    kbv[kk / 2] = f32x2{kb[kk], kb[kk + 1]};
+    asm volatile("" : "+v"(kbv[kk / 2]));
+  }
+  // the list's real query terms (wave-uniform): how many, and the first two
+  int nq = 0, r0 = 0, r1 = 0;
+#pragma unroll
+  for (int tt = 0; tt < kQT; ++tt) {
+    const bool real = tt < a.Q && a.qmeta[l].id[tt] > 0;
+    r1 = (real && nq == 1) ? tt : r1;
+    r0 = (real && nq == 0) ? tt : r0;
+    nq += real ? 1 : 0;
+  }
+  nq = __builtin_amdgcn_readfirstlane(nq); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+  const int b = g.start[l] + doc;
+  // what the mark pass left: the document's real terms, dense (int32), and its counts
+  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
+  const DocWalk dw = doc_walk(a, b, dm);
+  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
+  const float* tab0 = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp);
+  float acc[KK], rs = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) acc[kk] = 0.f;
+  float S = 0.f, R0 = 0.f;
+  if (nq == 1) {
+    knrm_pool_walk<KK, 64>(dw, n, lane, tab0 + r0, ka, kb, kbv, acc, rs);
+    const bool mine = t == r0;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const float v = group_allreduce(acc[kk]);
+      const float sum = (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+      S = (k == kk && mine) ? sum : S;
+    }
+    const float v = group_allreduce(rs);
+    R0 = mine ? (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48)) : 0.f;
+  } else if (nq == 2) {
+    knrm_pool_walk<KK, 32>(dw, n, lane, tab0 + (lane < 32 ? r0 : r1), ka, kb, kbv, acc, rs);
+    const bool mine0 = t == r0, mine1 = t == r1;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const float v = group_allreduce(acc[kk]);
+      const float s0 = lane_bcast(v, 0) + lane_bcast(v, 16), s1 = lane_bcast(v, 32) + lane_bcast(v, 48);
+      S = (k == kk && mine0) ? s0 : (k == kk && mine1) ? s1 : S;
+    }
+    const float v = group_allreduce(rs);
+    const float s0 = lane_bcast(v, 0) + lane_bcast(v, 16), s1 = lane_bcast(v, 32) + lane_bcast(v, 48);
+    R0 = mine0 ? s0 : mine1 ? s1 : 0.f;
+  } else {
+    knrm_pool_walk<KK, 16>(dw, n, lane, tab0 + t, ka, kb, kbv, acc, rs);
+    // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const float v = group_allreduce(acc[kk]);
+      S = k == kk ? v : S;
+    }
+    R0 = group_allreduce(rs);
+  }
+  // the read-out's weights requested only now: 14 registers fewer across the position loop
+  const int hn = lane < m.hidden ? lane : 0;
+  float w1v[kMaxK];
+#pragma unroll
+  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
+  const float k0c = (k < m.K) ? a.kn_consts[2 * kMaxK + k] : 0.f, k1c = (k < m.K) ? a.kn_consts[3 * kMaxK + k] : 0.f;
+  if ((nq == 1 && t != r0) || (nq == 2 && t != r0 && t != r1)) {
+    // a row that was not evaluated: K_k(0) = 2^-(B_k^2) at every real position (what the evaluation adds for s = 0)
+    const float bq = a.kn_consts[5 * kMaxK + (k < m.K ? k : 0)];
+    S = (float)n_real_doc * __builtin_amdgcn_exp2f(-(bq * bq));
+  }
+  const int no = n_one_t, nreal = n_real_doc;
+  float f = 0.f;
+  if (k < m.K && t < a.Q) {
+    const float k0 = k0c, k1 = k1c;
+    const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
+    S += (float)nz * k0;
+    S += (float)no * k1;
+    const float R = R0 + (float)no;
+    f = R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
+  }
+  // over the query terms, in their order
+  const float F = ((__shfl(f, k, 64) + __shfl(f, 16 + k, 64)) + __shfl(f, 32 + k, 64)) + __shfl(f, 48 + k, 64);
+  if (m.hidden > 0) {
+    float h = 0.f;
+    const int nn = lane < m.hidden ? lane : 0;
+    h = m.b1[nn];
+#pragma unroll
+    for (int kk = 0; kk < kMaxK; ++kk)
+      if (kk < m.K) h = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), h);
+    h = lane < m.hidden ? m.w2[nn] * tanhf(h) : 0.f;
+    float sc = wave_allreduce_sum(h) + m.b2[0];
+    if (m.scoretanh) sc = tanhf(sc);
+    if (lane == 0) m.out[b] = sc;
+  } else {
+    float sc = m.b1[0];
+#pragma unroll
+    for (int kk = 0; kk < kMaxK; ++kk)
+      if (kk < m.K) sc = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), sc);
+    if (m.scoretanh) sc = tanhf(sc);
+    if (lane == 0) m.out[b] = sc;
+  }
 }
 
 // ---- 3b: DRMM pooling ----------------------------------------------------------------------------------------------------------
@@ -717,8 +885,11 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
                      aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
-                     if (K == 11) hipLaunchKernelGGL(lists_knrm_pool_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
-                     else hipLaunchKernelGGL(lists_knrm_pool_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     const bool narrow = CAPAMD_POOL_NARROW && kPoolHot == 0 && kPoolDocs == 1;
+                     if (narrow && K == 11) hipLaunchKernelGGL(lists_knrm_pool_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     else if (narrow) hipLaunchKernelGGL(lists_knrm_pool_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     else if (K == 11) hipLaunchKernelGGL(lists_knrm_pool_wide_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     else hipLaunchKernelGGL(lists_knrm_pool_wide_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
                    });
 }
 

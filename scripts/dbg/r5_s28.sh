@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 for round in 1 2 3; do
-for v in base rows3; do
+for v in base wide; do
   libenv="X=1"; [ $v != base ] && libenv="CAPAMD_LIB_PATH=$R/capreolus_amd/csrc/ablate/libcapreolus_amd_$v.so"
   env $libenv python bench.py --model knrm --no-cpu-baseline --no-also --no-roofline-leg --no-pmc-traffic --no-pass-times 2>gpurun_out/err_$v.txt | tail -1 | python -c "
 import json,sys
