@@ -559,14 +559,16 @@ __device__ __forceinline__ void rows_dot_pk(const RowRegs<NV>& d, const float4* 
   }
   p[0] = acc[0].x; p[1] = acc[0].y; p[2] = acc[1].x; p[3] = acc[1].y;
 }
-template <int NV>
+// NP = 1: only the first pair of query terms (terms 2 and 3 are not real - pads of the fixed-length query row: their similarities are 0 whatever
+// their dot products are, sim_from_dots) - half the fmas and half the LDS reads; the partials of the second pair are returned as 0
+template <int NV, int NP = 2>
 __device__ __forceinline__ void rows_dot2_pk(const RowRegs<NV>& d0, const RowRegs<NV>& d1, const float4* qlds, int lane16, float (&p0)[kQT],
                                              float (&p1)[kQT]) {
   f32x2 acc0[2] = {{0.f, 0.f}, {0.f, 0.f}}, acc1[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
 #pragma unroll
-    for (int P = 0; P < 2; ++P) {
+    for (int P = 0; P < NP; ++P) {
       const float4 qa = qlds[((P * NV + i) * 2 + 0) * 16 + lane16], qb = qlds[((P * NV + i) * 2 + 1) * 16 + lane16];
       f32x2 a = acc0[P], b = acc1[P];
       a = __builtin_elementwise_fma((f32x2){d0.v[i].x, d0.v[i].x}, (f32x2){qa.x, qa.y}, a);
@@ -580,7 +582,8 @@ __device__ __forceinline__ void rows_dot2_pk(const RowRegs<NV>& d0, const RowReg
       acc0[P] = a;
       acc1[P] = b;
     }
-    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc1[0]), "+v"(acc1[1]));
+    if (NP == 2) asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc1[0]), "+v"(acc1[1]));
+    else asm volatile("" : "+v"(acc0[0]), "+v"(acc1[0]));
     __builtin_amdgcn_sched_barrier(0);
   }
   p0[0] = acc0[0].x; p0[1] = acc0[0].y; p0[2] = acc0[1].x; p0[3] = acc0[1].y;
@@ -620,11 +623,12 @@ __device__ __forceinline__ void rows_dot3_pk(const RowRegs<NV>& d0, const RowReg
   p1[0] = acc1[0].x; p1[1] = acc1[0].y; p1[2] = acc1[1].x; p1[3] = acc1[1].y;
   p2[0] = acc2[0].x; p2[1] = acc2[0].y; p2[2] = acc2[1].x; p2[3] = acc2[1].y;
 }
-template <int NV>
+// NT: the terms whose dot products were computed (the others' similarities are 0: their ids are not real)
+template <int NV, int NT = kQT>
 __device__ __forceinline__ float sim_from_dots(const float (&p)[kQT], float dden, const QueryPass<NV>& qp, int lane16) {
   float r[kQT];
 #pragma unroll
-  for (int t = 0; t < kQT; ++t) r[t] = group_allreduce(p[t]);
+  for (int t = 0; t < kQT; ++t) r[t] = t < NT ? group_allreduce(p[t]) : 0.f;
   const int myq = lane16 & 3;
   const float pm = myq == 0 ? r[0] : myq == 1 ? r[1] : myq == 2 ? r[2] : r[3];
   const float s = pm / (qp.den_my * dden);

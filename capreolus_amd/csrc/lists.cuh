@@ -409,6 +409,9 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
 }
 
 #ifndef CAPAMD_LISTS_SIMS_MFMA
+#ifndef CAPAMD_LISTS_SIMS_HALF
+#define CAPAMD_LISTS_SIMS_HALF 1      // 0: every list's four dot products per row (A/B builds)
+#endif
 #ifndef CAPAMD_LISTS_SIMS_ROWS
 #define CAPAMD_LISTS_SIMS_ROWS 2      // rows per 16-lane group and trip (3: A/B builds)
 #endif
@@ -494,6 +497,27 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
     put(idc, sim_from_dots<NV>(pc, row_den<NV>(dc), qp, lane16));
   }
   return;
+#endif
+#if CAPAMD_LISTS_SIMS_HALF
+  // A list whose query terms 2 and 3 are not real (a query of one or two terms in the reference's fixed-length row: half of the
+  // benchmark's queries) needs the first pair's dot products only: the other two similarities are 0 by definition (sim_from_dots) -
+  // half the fmas, LDS query reads and row reductions of a trip; the same table entries, bit for bit.
+  if (a.qmeta[l].id[2] <= 0 && a.qmeta[l].id[3] <= 0) {
+#pragma clang loop unroll(disable)
+    for (int e = grp; e < total; e += 2 * kGroupsPerWG) {
+      const int ida = id0 + lst[e], idb = id0 + lst[e + kGroupsPerWG < total ? e + kGroupsPerWG : e];
+      RowRegs<NV> da, db;
+      load_row<NV>(a.packed, ida, lane16, da);
+      load_row<NV>(a.packed, idb, lane16, db);
+      float pa[kQT], pb[kQT];
+      int qoff = 0;
+      asm volatile("" : "+v"(qoff));
+      rows_dot2_pk<NV, 1>(da, db, qlds + qoff, lane16, pa, pb);
+      put(ida, sim_from_dots<NV, 2>(pa, row_den<NV>(da), qp, lane16));
+      put(idb, sim_from_dots<NV, 2>(pb, row_den<NV>(db), qp, lane16));
+    }
+    return;
+  }
 #endif
 #pragma clang loop unroll(disable)
   for (int e = grp; e < total; e += 2 * kGroupsPerWG) {
