@@ -658,8 +658,8 @@ SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("
 # per-workgroup prologue - flag scan, query copy - of ~123 rows each), a sixth of the row requests miss L2, and with every row load
 # redirected to 16 hot rows the pass still takes 214 of its 289 us.  The register-resident query (lists_sims_qreg_kernel, round 5) - no
 # LDS reads at all, occupancy 3 instead of 6 - is 30-70 % SLOWER (profiles/r05/lists_sims_qreg_ab.txt): latency, not the LDS pipe.
-SIMS_LIMITER = {"bound": "latency (VALU issue 0.52 of the cycles, L2 hit rate 0.84; no pipe saturated): 240 KB of rows in flight per CU - 24 waves x 8 rows in "
-                         "registers - against trips that wait in order for the slowest of their 8 rows, a miss in three trips of four (DESIGN.md section 7)",
+SIMS_LIMITER = {"bound": "latency (VALU issue 0.52 of the cycles, L2 hit rate 0.84, 40 % of the L2's bandwidth; no pipe saturated): ~75 us of compulsory misses seen through "
+                         "in-order trips of 8 rows, ~214 us of a workgroup's dependent phases around ~123 rows (DESIGN.md section 7)",
                 "valu_issue_utilisation": 0.52, "l2_hit_rate": 0.84,
                 "waves_waiting_over_issuing": 2.9, "packed_fma_share_of_valu_instructions": 0.37, "source": "profiles/r05/pmc_lists_knrm.txt (builder-run counter passes)"}
 
