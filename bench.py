@@ -3,6 +3,7 @@
 query-doc pairs scored/sec at 1/2/4/8 GPUs).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W        (no rank environment: starts its own N ranks, benchlib/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -241,8 +242,6 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
@@ -872,6 +871,10 @@ class Ctx1:
 
 def main():
     args = parse()
+    from benchlib import launch
+
+    if launch.needs_self_launch(args.gpus):      # `python bench.py --gpus N`: this process becomes the launcher of N ranks (benchlib/launch.py)
+        raise SystemExit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if os.environ.get("CAPAMD_LIB_PATH"):       # an A/B build of the library (scripts/build_variant*.sh): it has no profiling twin
         args.no_pass_times = True
     ctx = Ctx(args)
