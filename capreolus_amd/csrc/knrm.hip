@@ -65,6 +65,50 @@ struct KnrmArgs {
   int split;
 };
 
+// The per-pair tail both scoring kernels share (knrm_forward_kernel for Q <= kQT, the streaming kernel's list wave): ONE wave, lane =
+// (query term q = lane & 3, kernel kk = lane >> 2); s / rs = the lane's kernel sum and its term's similarity sum over the document's real
+// terms -> closed-form pad / OOV terms, masked log (KNRM.py:50-53), the sum over the query terms, `combine` (KNRM.py:27-34, :54).
+// One piece of code, so that a pair's score does not depend on which of the two kernels a launch's size selected (the trainer's
+// predictions are rounded to fp16: one ulp of fp32 can move a rank).
+// C: LDS [64] mu[16] | sigma[16] | w1[16] (single Linear) | b1;  F: LDS [16] scratch of the hidden-layer variant.
+__device__ __forceinline__ void knrm_pair_tail(const KnrmArgs& a, const float* C, float* F, int lane, float s, float rs, int n_one_q, int n_nonreal, int b) {
+  const int q = lane & 3, kk = lane >> 2;
+  float R = 0.f;
+  if (kk < a.K) {
+    const float mk = C[kk], sg = C[16 + kk];
+    const float ck = (-0.5f * kLog2e) / (sg * sg);
+    const int no = n_one_q;
+    const int nz = n_nonreal - no;
+    const float k0 = __builtin_amdgcn_exp2f(mk * mk * ck), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * ck);
+    s = __builtin_fmaf((float)nz, k0, s);
+    s = __builtin_fmaf((float)no, k1, s);
+    rs += (float)no;
+    R = rs != 0.f ? logf(s + 1e-6f) : 0.f;            // KNRM.py:51-52
+  }
+  // f_k = sum over the query terms: the four lanes of a quad
+  R += dpp_mov<0xB1>(R);
+  R += dpp_mov<0x4E>(R);
+  if (a.hidden > 0) {
+    if (q == 0 && kk < kMaxK) F[kk] = R;
+    wave_fence();
+    float h = 0.f;
+    if (lane < a.hidden) {
+      h = a.b1[lane];
+      for (int k = 0; k < a.K; ++k) h = __builtin_fmaf(a.w1[lane * a.K + k], F[k], h);
+      h = a.w2[lane] * tanhf(h);
+    }
+    float sc = wave_allreduce_sum(h) + a.b2[0];
+    if (a.scoretanh) sc = tanhf(sc);
+    if (lane == 0) a.out[b] = sc;
+    wave_fence();
+  } else {
+    const float v = (q == 0 && kk < a.K) ? C[32 + kk] * R : 0.f;
+    float sc = wave_allreduce_sum(v) + C[48];
+    if (a.scoretanh) sc = tanhf(sc);
+    if (lane == 0) a.out[b] = sc;
+  }
+}
+
 // GRAD additionally accumulates sum_j K (s - mu) and sum_j K (s - mu)^2, which give d f_k / d mu_k and d f_k / d sigma_k
 // (RbfKernel parameters are trainable when `gradkernels`, reference common.py:229-230 / KNRM.py:22): the forward half
 // of the training step; `combine` then runs under autograd on the [B, K] features.
@@ -184,11 +228,14 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 #pragma unroll
           for (int s = 0; s < 3; ++s) {
             const float adj = x[u] - mu_s[s];
-            const float kv = m * __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
-            acc[s] += kv;
+            const float ev = __builtin_amdgcn_exp2f(adj * adj * c_s[s]);
             if (GRAD) {
+              const float kv = m * ev;
+              acc[s] += kv;
               acc1[s] = __builtin_fmaf(kv, adj, acc1[s]);
               acc2[s] = __builtin_fmaf(kv * adj, adj, acc2[s]);
+            } else {
+              acc[s] = __builtin_fmaf(m, ev, acc[s]);      // (spelled out: the streaming kernel's row() must round the same way)
             }
           }
         }
@@ -208,6 +255,23 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
       }
     }
     __syncthreads();
+    if (!GRAD && a.Q <= kQT) {
+      // (the streaming kernel's order: a wave's four groups folded (g0 + g1) + (g2 + g3), the four waves' partials added in turn)
+      if (tid < 64) {
+        const int q = tid & 3, kk = tid >> 2;
+        const int src_lane = (kk & 3) * 4 + q, slot = (kk >> 2) < 3 ? (kk >> 2) : 0;
+        float s = 0.f, rs = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float* p0 = partial + ((4 * w) * kGroup + src_lane) * PS + slot;
+          const float* r0 = partial + ((4 * w) * kGroup + q) * PS + 3;
+          s += (p0[0] + p0[kGroup * PS]) + (p0[2 * kGroup * PS] + p0[3 * kGroup * PS]);
+          rs += (r0[0] + r0[kGroup * PS]) + (r0[2 * kGroup * PS] + r0[3 * kGroup * PS]);
+        }
+        knrm_pair_tail(a, Clds, Flds + 16, tid, s, rs, n_one[q], n_nonreal, b);
+      }
+      return;
+    }
     if (tid < 48) {
       const int q = tid & 3, kk = tid >> 2;
       const int src_lane = (kk & 3) * 4 + q, slot = kk >> 2;
@@ -320,51 +384,15 @@ struct KnrmStream {
 
   __device__ static void finish(const Args& a, const StreamSrc&, char* lds, int buf, const StreamMeta* meta, int lane) {
     const float* P = partial(lds, buf);
-    const float* C = consts(lds);
-    float* F = consts(lds) + 64;
     const int q = lane & 3, kk = lane >> 2;             // lanes 0..47: (query term, kernel)
-    const int src_lane = (kk & 3) * 4 + q, slot = kk >> 2;
-    float R = 0.f;
-    if (kk < a.K) {
-      float s = 0.f, rs = 0.f;
+    const int src_lane = (kk & 3) * 4 + q, slot = (kk >> 2) < 3 ? (kk >> 2) : 0;
+    float s = 0.f, rs = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        s += P[(w * kGroup + src_lane) * 4 + slot];
-        rs += P[(w * kGroup + q) * 4 + 3];
-      }
-      const float mk = C[kk], sg = C[16 + kk];
-      const float ck = (-0.5f * kLog2e) / (sg * sg);
-      const int no = meta->n_one[q];
-      const int nz = meta->n_nonreal - no;
-      const float k0 = __builtin_amdgcn_exp2f(mk * mk * ck), k1 = __builtin_amdgcn_exp2f((1.f - mk) * (1.f - mk) * ck);
-      s += (float)nz * k0;
-      s += (float)no * k1;
-      rs += (float)no;
-      R = rs != 0.f ? logf(s + 1e-6f) : 0.f;            // KNRM.py:51-52
+    for (int w = 0; w < 4; ++w) {
+      s += P[(w * kGroup + src_lane) * 4 + slot];
+      rs += P[(w * kGroup + q) * 4 + 3];
     }
-    // f_k = sum over the query terms: the four lanes of a quad
-    R += dpp_mov<0xB1>(R);
-    R += dpp_mov<0x4E>(R);
-    const int b = meta->pair;
-    if (a.hidden > 0) {
-      if (q == 0 && kk < kMaxK) F[kk] = R;
-      wave_fence();
-      float h = 0.f;
-      if (lane < a.hidden) {
-        h = a.b1[lane];
-        for (int k = 0; k < a.K; ++k) h = __builtin_fmaf(a.w1[lane * a.K + k], F[k], h);
-        h = a.w2[lane] * tanhf(h);
-      }
-      float sc = wave_allreduce_sum(h) + a.b2[0];
-      if (a.scoretanh) sc = tanhf(sc);
-      if (lane == 0) a.out[b] = sc;
-      wave_fence();
-    } else {
-      const float v = (q == 0 && kk < a.K) ? C[32 + kk] * R : 0.f;
-      float sc = wave_allreduce_sum(v) + C[48];
-      if (a.scoretanh) sc = tanhf(sc);
-      if (lane == 0) a.out[b] = sc;
-    }
+    knrm_pair_tail(a, consts(lds), consts(lds) + 64, lane, s, rs, meta->n_one[q], meta->n_nonreal, meta->pair);
   }
 
   __device__ static void gather_init(const Args& a, Gather& gs, int lane16) {
@@ -394,7 +422,7 @@ struct KnrmStream {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const float adj = x - gs.mu_s[s];
-      gs.acc[s] += mlt * __builtin_amdgcn_exp2f(adj * adj * gs.c_s[s]);
+      gs.acc[s] = __builtin_fmaf(mlt, __builtin_amdgcn_exp2f(adj * adj * gs.c_s[s]), gs.acc[s]);      // (as knrm_forward_kernel)
     }
   }
   __device__ static void pair_end(const Args&, Gather& gs, char* lds, int buf, int wave, int lane) {

@@ -70,36 +70,19 @@ def _predict_worker(rank, world, port, out_dir):
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
-    from tests.test_gpu_parity import _knrm_model
+    from tests.test_gpu_parity import _knrm_model, _multiquery_sampler
     from tests.helpers import load_case
     from capreolus_amd.trainer import PytorchTrainer
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
-    c = load_case("knrm", "ranklist")
+    c = load_case("knrm", "multiquery")
     r = _knrm_model(c)
     r.model.to(torch.device("cuda", rank))
-    B = c["query"].shape[0]
-    q2d = {"1": [f"d{i}" for i in range(0, 70)], "2": [f"d{i}" for i in range(70, 120)], "3": [f"d{i}" for i in range(120, B)]}
-
-    class Sampler(torch.utils.data.IterableDataset):
-        qid_to_docids = q2d
-
-        def __iter__(self):
-            for qid, docs in self.qid_to_docids.items():
-                for d in docs:
-                    i = int(d[1:])
-                    yield {"qid": qid, "posdocid": d, "query": c["query"][0], "posdoc": c["posdoc"][i], "query_idf": c["query_idf"][0]}
-
-        def __len__(self):
-            return sum(len(v) for v in self.qid_to_docids.values())
-
-        def get_qid_docid_pairs(self):
-            return ((q, d) for q, docs in self.qid_to_docids.items() for d in docs)
-
-    preds = PytorchTrainer({"batch": 16}).predict(r, Sampler())
-    flat = np.array([preds[q][d] for q, docs in q2d.items() for d in docs], dtype=np.float16)
+    s = _multiquery_sampler(c)
+    preds = PytorchTrainer({"batch": 16}).predict(r, s)
+    flat = np.array([preds[q][d] for q, docs in s.qid_to_docids.items() for d in docs], dtype=np.float16)
     np.save(os.path.join(out_dir, f"preds{rank}.npy"), flat)
     dist.destroy_process_group()
 
@@ -107,13 +90,33 @@ def _predict_worker(rank, world, port, out_dir):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (test_predict_over_rccl_single_rank covers one rank)")
 def test_predict_two_ranks_over_rccl(tmp_path):
     """`PytorchTrainer.predict` sharded by query over two GPUs, scores joined by ONE RCCL all_gather: every rank ends with the
-    predictions of the whole run, equal to the reference fixture's fp16 scores."""
+    predictions of the whole run - the SAME fp16 bits as one process scoring the unsharded run (the reference's 8-query KNRM fixture;
+    tests/test_gpu_parity.py: test_knrm_predictions_do_not_depend_on_the_sharding is the single-GPU form of this assertion)."""
     import numpy as np
     import torch.multiprocessing as mp
 
+    sys.path.insert(0, ROOT)
     from tests.helpers import load_case
+    from tests.test_gpu_parity import _knrm_model, _multiquery_sampler
+    from capreolus_amd.trainer import PytorchTrainer
 
     mp.spawn(_predict_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    want = load_case("knrm", "ranklist")["ref_scores_f16"]
+    c = load_case("knrm", "multiquery")
+    s = _multiquery_sampler(c)
+    unsharded = PytorchTrainer({"batch": 16}).predict(_knrm_model(c), s)
+    want = np.array([unsharded[q][d] for q, docs in s.qid_to_docids.items() for d in docs], dtype=np.float16)
+    assert np.abs(want.astype(np.float64) - c["ref_scores"]).max() <= 2e-3 * np.abs(c["ref_scores"]).max()
     for rank in range(2):
         assert np.array_equal(np.load(tmp_path / f"preds{rank}.npy"), want)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank environment (how the driver's record of round 5 invoked it): bench.py re-executes itself under
+    torch.distributed.run (benchlib/launch.py) and rank 0's JSON line says two RCCL ranks took part."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--queries", "8"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    _check_line(rec, 2, "weak")

@@ -120,6 +120,112 @@ def test_knrm_multiquery_run_matches_the_reference_by_either_route(route):
             assert np.array_equal(rank_order(g16[a:b]), rank_order(r16[a:b]))
 
 
+def _multiquery_sampler(c, qids=None):
+    """the multi-query fixture behind the PredSampler contract (qid_to_docids, per-sample id rows); `qids`: a subset of its queries"""
+    off = c["list_offsets"]
+    q2d = {str(100 + k): [f"d{i}" for i in range(off[k], off[k + 1])] for k in range(len(off) - 1)}
+    if qids is not None:
+        q2d = {q: q2d[q] for q in qids}
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = q2d
+
+        def __iter__(self):
+            for qid, docs in self.qid_to_docids.items():
+                for d in docs:
+                    i = int(d[1:])
+                    yield {"qid": qid, "posdocid": d, "query": c["query"][i].astype(np.int64), "posdoc": c["posdoc"][i].astype(np.int64), "query_idf": c["query_idf"][i]}
+
+        def __len__(self):
+            return sum(len(v) for v in self.qid_to_docids.values())
+
+        def get_qid_docid_pairs(self):
+            return ((q, d) for q, docs in self.qid_to_docids.items() for d in docs)
+
+    return Sampler()
+
+
+def test_knrm_predictions_do_not_depend_on_the_sharding():
+    """`PytorchTrainer.predict` (defaults) on the reference's 8-query KNRM run: the fp16 predictions of every (query, document) are the
+    SAME BITS whether the run is scored in one call, query by query (eight calls of one list), or as the shards `shard_pred_data` gives the
+    ranks of a world of 2, 3 or 8 - the route is a function of the reranker and the configuration, not of how many lists a call holds
+    (a rank holding one query used to take the per-pair kernels, whose pooling sums round differently).  The same with the
+    DataLoader route (`resident` off: the per-pair kernels, whatever the batches' sizes) and with `lists` = "exact"."""
+    from capreolus_amd.trainer import PytorchTrainer
+    from capreolus_amd.trainer.pytorch import shard_pred_data
+
+    c = load_case("knrm", "multiquery")
+    r = _knrm_model(c)
+    whole = _multiquery_sampler(c)
+    qids = list(whole.qid_to_docids)
+    for cfg in ({"batch": 32}, {"batch": 32, "resident": False}, {"batch": 32, "lists": "exact"}, {"batch": 32, "resident": False, "coalesce": 0}):
+        base = PytorchTrainer(dict(cfg)).predict(r, whole)
+        flat = np.array([base[q][d] for q in qids for d in whole.qid_to_docids[q]], dtype=np.float64)
+        assert np.abs(flat - c["ref_scores"]).max() <= 2e-3 * np.abs(c["ref_scores"]).max()
+        # query by query
+        single = {}
+        for q in qids:
+            single.update(PytorchTrainer(dict(cfg)).predict(r, _multiquery_sampler(c, [q])))
+        assert single == base, cfg
+        # the shards of a world of 2 / 3 / 8 ranks, each scored by its own trainer
+        for world in (2, 3, 8):
+            merged = {}
+            for rank in range(world):
+                part, _, count, total = shard_pred_data(whole, rank, world)
+                assert total == 1200
+                if count:
+                    merged.update(PytorchTrainer(dict(cfg)).predict(r, part))
+            assert merged == base, (cfg, world)
+    # ... and the routes agree with each other on this run's fp16 predictions except next to a rounding boundary
+    a = PytorchTrainer({"batch": 32}).predict(r, whole)
+    b = PytorchTrainer({"batch": 32, "resident": False}).predict(r, whole)
+    diff = sum(a[q][d] != b[q][d] for q in qids for d in a[q])
+    assert diff <= 2, diff
+
+
+def test_knrm_predict_in_parts_equals_predict_by_query():
+    """A run big enough for `predict` to score it in two / four overlapped parts (>= 16 lists, >= 16,000 pairs): the same fp16 predictions
+    as scoring every query on its own."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    V, NQ, ND = 5000, 20, 1000
+    rs = np.random.RandomState(3)
+    emb = synthetic.make_embeddings(V, 300, seed=4)
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    r.build_model().to(DEV).eval()
+    lists = [synthetic.make_candidate_list(rs, ND, V, 4, 800, same_query=True, oov_range=30) for _ in range(NQ)]
+
+    def sampler(which):
+        q2d = {str(k): [f"q{k}d{i}" for i in range(ND)] for k in which}
+
+        class Sampler(torch.utils.data.IterableDataset):
+            qid_to_docids = q2d
+
+            def __iter__(self):
+                for qid, docs in self.qid_to_docids.items():
+                    b = lists[int(qid)]
+                    for i, d in enumerate(docs):
+                        yield {"qid": qid, "posdocid": d, "query": b["query"][i], "posdoc": b["posdoc"][i], "query_idf": b["query_idf"][0]}
+
+            def __len__(self):
+                return ND * len(q2d)
+
+            def get_qid_docid_pairs(self):
+                return ((q, d) for q, docs in self.qid_to_docids.items() for d in docs)
+
+        return Sampler()
+
+    t = PytorchTrainer({"batch": 32})
+    s = sampler(range(NQ))
+    whole = t.predict(r, s)
+    assert next(iter(t._resident_plans.values()))[2][4].get("parts"), "the run should have been scored in parts"
+    again = t.predict(r, s)        # (the second call of a sampler: the kept plan)
+    assert again == whole
+    for k in (0, 7, NQ - 1):
+        one = PytorchTrainer({"batch": 32}).predict(r, sampler([k]))
+        assert one[str(k)] == whole[str(k)]
+
+
 @pytest.mark.parametrize("kind", ["drmmtks", "pacrr"])
 def test_multiquery_run_matches_the_reference_by_either_route(kind):
     """DRMM-TKS and PACRR on what `predict` scores - eight queries' candidate lists in one run (one query with an OOV term some candidates
@@ -275,6 +381,28 @@ def full():
     emb[0] = 0
     batch = synthetic.make_candidate_list_torch(2, 1000, V, DEV, seed=1)
     return emb, batch
+
+
+def test_knrm_scores_do_not_depend_on_the_launch_size(full):
+    """A pair's KNRM score is the same bits whichever per-pair kernel its launch's size selects: the streaming kernel (more than 3072
+    pairs per launch), the one-pair-per-workgroup kernel with one row in flight per group (1537 .. 3072) or with four (up to 1536) -
+    one shared tail (csrc/knrm.hip: knrm_pair_tail), the same folding of the sixteen groups' sums.  What `predict` stores is rounded to
+    fp16 (reference trainer/pytorch.py:346-348): a score that moved by one fp32 ulp with the batch size could move a rank between a
+    1-GPU and an 8-GPU run."""
+    emb, _ = full
+    batch = synthetic.make_candidate_list_torch(4, 1000, 400001, DEV, seed=11)
+    torch.manual_seed(0)
+    for cfg in ({}, {"singlefc": False}, {"scoretanh": True}):
+        r = KNRM(cfg, SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32)))
+        m = r.build_model().to(DEV).eval()
+        m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
+        with torch.no_grad():
+            whole = r.test(batch)                                    # 4000 pairs: the streaming kernel
+            assert torch.isfinite(whole).all()
+            for step in (2000, 1000, 1):
+                n = 4000 if step > 1 else 7
+                parts = torch.cat([r.test({k: v[i:i + step] for k, v in batch.items()}) for i in range(0, n, step)])
+                assert torch.equal(parts, whole[:n]), (cfg, step, float((parts - whole[:n]).abs().max()))
 
 
 def test_full_size_knrm_properties(full):

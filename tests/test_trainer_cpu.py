@@ -376,8 +376,8 @@ def pickle_load(fn):
 def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     """`PytorchTrainer._score_store` (predict / predict_resident / evaluate_resident on a candidate store): whole candidate lists for the
     rerankers the `lists` option admits - "exact": only those whose list scores equal their per-pair scores bit for bit - with the
-    lists' offsets handed over as a host array; the per-pair route in `evalbatch` steps otherwise, for more than four query terms, for
-    runs of fewer than eight candidates per query and for a single list."""
+    lists' offsets handed over as a host array; the per-pair route in `evalbatch` steps otherwise, for more than four query terms and -
+    bit-identical rerankers only - for runs of fewer than eight candidates per query and for a single list."""
     calls = []
 
     class Store:
@@ -420,12 +420,19 @@ def test_resident_scoring_picks_lists_by_option(mode, exact, expect_lists):
     wide.q_table = torch.zeros(3, 6, dtype=torch.int32)
     tr._score_store(Fake(), wide, pq, pd, counts, 64)
     assert calls == [("pairs", n)]
+    # short lists and a single list: a reranker whose two routes give the same bits takes the per-pair kernels (they fill the chip
+    # better); one whose list scores round differently (KNRM) keeps the route its configuration names WHATEVER the call holds - a rank's
+    # shard of one query must give the bits the unsharded run gives (test_knrm_predictions_do_not_depend_on_the_sharding on the GPU)
+    sticky = expect_lists and not exact
     calls.clear()
     tr._score_store(Fake(), Store(), pq[:6], pd[:6], [2, 2, 2], 64)
-    assert calls == [("pairs", 6)]
+    assert calls == ([("lists", [0, 2, 4, 6])] if sticky else [("pairs", 6)])
     calls.clear()
-    tr._score_store(Fake(), Store(), pq[:20], pd[:20], [20], 64)       # a single list: the per-pair kernels fill the chip better
-    assert calls == [("pairs", 20)]
+    tr._score_store(Fake(), Store(), pq[:20], pd[:20], [20], 64)
+    assert calls == ([("lists", [0, 20])] if sticky else [("pairs", 20)])
+    calls.clear()
+    tr._score_store(Fake(), Store(), pq[:1], pd[:1], [1], 64)
+    assert calls == ([("lists", [0, 1])] if sticky else [("pairs", 1)])
     with pytest.raises(ValueError):
         PytorchTrainer({"lists": "sometimes"}).build()
 
