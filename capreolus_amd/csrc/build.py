@@ -16,11 +16,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)          # hazard_lint, when build.py is imported as capreolus_amd.csrc.build
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libcapreolus_amd.so")
 OUT_PROF = os.path.join(HERE, "libcapreolus_amd_prof.so")
-OUT_PYHOST = os.path.join(HERE, "libcapamd_pyhost.so")
+OUT_PYHOST = os.path.join(HERE, "libcapamd_pyhost" + (__import__("sysconfig").get_config_var("EXT_SUFFIX") or ".so"))   # (the interpreter's ABI tag: a helper built for another Python is never loaded)
 PYHOST_SRC = os.path.join(HERE, "pyhost.c")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + HERE]
 PROF_SOURCES = ("bert.hip", "lists.hip", "pacrr.hip")     # sources whose code differs under -DCAPAMD_PROFILING
@@ -75,9 +74,34 @@ def build_pyhost(force=False, verbose=False):
     return OUT_PYHOST
 
 
+def _hazard_lint():
+    """csrc/hazard_lint.py as a module, whichever way this file was loaded (package import or `python build.py`) - without putting csrc/ on
+    sys.path (`import build` then resolved to this file for the whole process)"""
+    import importlib.util
+
+    name = "capreolus_amd_csrc_hazard_lint"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, "hazard_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _lint_stamp(obj):
+    return obj + ".lint"
+
+
 def build(force=False, verbose=False):
-    build_pyhost(force, verbose)
-    if not force and not stale():
+    try:
+        build_pyhost(force, verbose)      # optional: capreolus_amd/pyhost.py falls back to the Python expression without it
+    except (OSError, subprocess.CalledProcessError) as e:
+        print(f"build.py: the CPython helper was not built ({type(e).__name__}: {e}); predict() uses its Python fallback", file=sys.stderr)
+    lint = _hazard_lint()
+    objs_all = [o for _, o, _ in _jobs()]
+    unlinted = [o for o in objs_all if os.path.exists(o) and not (os.path.exists(_lint_stamp(o)) and os.path.getmtime(_lint_stamp(o)) >= os.path.getmtime(o))]
+    if not force and not stale() and not unlinted:
         return OUT
     procs, rebuilt = [], []
     for src, obj, extra in _jobs():
@@ -92,19 +116,25 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     # the inline-assembly MFMAs' results must not be touched too early by code the compiler put behind them (hazard_lint.py): checked
-    # on every object (re)compiled in this run - a finding is a wrong-answer bug in that build, so the library is not linked
-    import hazard_lint
-
-    if not os.path.exists(hazard_lint.OBJDUMP):      # (a toolchain without llvm-objdump: the check cannot run - say so, do not fail the build)
-        print(f"build.py: {hazard_lint.OBJDUMP} not found - the MFMA hazard lint is skipped", file=sys.stderr)
-        rebuilt = []
-    for obj in rebuilt:
-        found = hazard_lint.lint_object(obj)
-        if found:
-            func, mfma, ins, seen, need = found[0]
-            os.remove(obj)
-            raise RuntimeError(f"{os.path.basename(obj)}: {len(found)} MFMA result(s) read too early, e.g. in {func}: '{ins}' "
-                               f"{seen} wait states behind '{mfma}' ({need} needed) - see csrc/hazard_lint.py")
+    # on EVERY object that goes into the libraries and has not passed since it was last compiled (a stamp file next to it) - a finding is
+    # a wrong-answer bug in that build, so the library is not linked; a toolchain without llvm-objdump cannot be checked and does not
+    # link either (CAPAMD_SKIP_HAZARD_LINT=1 says "I know")
+    if os.environ.get("CAPAMD_SKIP_HAZARD_LINT") == "1":
+        print("build.py: CAPAMD_SKIP_HAZARD_LINT=1 - the MFMA hazard lint is skipped", file=sys.stderr)
+    else:
+        if lint.objdump() is None:
+            raise RuntimeError("llvm-objdump not found: the inline-assembly MFMA kernels cannot be checked (csrc/hazard_lint.py); "
+                               "set ROCM_PATH, or CAPAMD_SKIP_HAZARD_LINT=1 to link unchecked objects")
+        for obj in objs_all:
+            if os.path.exists(_lint_stamp(obj)) and os.path.getmtime(_lint_stamp(obj)) >= os.path.getmtime(obj):
+                continue
+            found = lint.lint_object(obj)
+            if found:
+                func, mfma, ins, seen, need = found[0]
+                os.remove(obj)
+                raise RuntimeError(f"{os.path.basename(obj)}: {len(found)} MFMA result(s) touched too early, e.g. in {func}: '{ins}' "
+                                   f"{seen} wait states behind '{mfma}' ({need} needed) - see csrc/hazard_lint.py")
+            open(_lint_stamp(obj), "w").close()
     objs = [o for _, o, extra in _jobs() if not extra]
     prof = {s: o for s, o, extra in _jobs() if extra}
     prof_objs = [prof.get(s, o) for s, o, extra in _jobs() if not extra]

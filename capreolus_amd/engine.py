@@ -367,6 +367,8 @@ class BertEngine:
                 # long runs: cut at whole micro-batches, so that every stream but the last runs FULL micro-batches only (whole rounds of
                 # GEMM tiles on every CU, bert.hip: plan_microbatch) and one tail exists per call, not one per stream
                 per = (NP // ns + self.microbatch - 1) // self.microbatch * self.microbatch
+                if (ns - 1) * per >= NP:      # (five or more streams: rounding UP leaves the last stream nothing - round down instead)
+                    per = NP // ns // self.microbatch * self.microbatch
             cuts = [min(NP, k * per) for k in range(ns)] + [NP]
             if ns < 2 or cuts[-2] >= NP:
                 plog = torch.empty(NP, dtype=torch.float32, device=ids.device) if return_passage_logits else None

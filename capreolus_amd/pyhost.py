@@ -14,7 +14,10 @@ import os
 
 import numpy as np
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcapamd_pyhost.so")
+import sysconfig
+
+# (named with the interpreter's ABI tag by csrc/build.py: a helper built for another Python - it uses CPython's object layout - is not found)
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcapamd_pyhost" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 _fn = None
 _lut = None
 
@@ -25,7 +28,11 @@ def _load():
         if not os.path.exists(_PATH):
             _fn = False
             return _fn
-        fn = ctypes.PyDLL(_PATH).capamd_preds_from_fp16
+        try:
+            fn = ctypes.PyDLL(_PATH).capamd_preds_from_fp16
+        except (OSError, AttributeError):      # an unloadable or foreign file: the Python expression below gives the same dictionaries
+            _fn = False
+            return _fn
         fn.argtypes = [ctypes.py_object, ctypes.c_ssize_t, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_ssize_t, ctypes.py_object,
                        ctypes.py_object, ctypes.c_int]
         fn.restype = ctypes.c_int       # -1: a Python exception is set (PyDLL re-raises it)

@@ -318,9 +318,15 @@ class PytorchTrainer:
         for bi, batch in enumerate(train_dataloader):
             batch = {k: v.to(self.device) if torch.is_tensor(v) else v for k, v in batch.items()}
             done = None
-            if fused and not getattr(self, "_fused_failed", False):
+            if fused:
                 done = self._fused_step(reranker, batch)
-            elif graphed and not fused:
+                if done is None:
+                    # the reranker's device step does not cover this configuration (engine.AdamStep: an optimizer parameter it does not
+                    # update, a batch it cannot take): the captured-graph route is the second choice - from this batch on, not eager
+                    # steps for the rest of training
+                    fused = self._use_fused = False
+                    graphed = self._graph_allowed()
+            if done is None and graphed and not fused:
                 done = self._graphed_step(reranker, batch)
                 replayed = replayed or done is not None
             if done is not None:

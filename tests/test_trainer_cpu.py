@@ -206,8 +206,9 @@ def test_no_compiler_generated_read_sits_too_close_behind_an_inline_mfma():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "capreolus_amd", "csrc"))
-    import hazard_lint
+    from capreolus_amd.csrc import build as hipbuild
+
+    hazard_lint = hipbuild._hazard_lint()
 
     mfma = "\tv_mfma_f32_16x16x32_bf16 a[208:211], v[80:83], v[96:99], a[208:211]"
     early = ["k:", mfma, "\ts_nop 0", "\tv_accvgpr_read_b32 v100, a208"]
@@ -220,7 +221,22 @@ def test_no_compiler_generated_read_sits_too_close_behind_an_inline_mfma():
     wide = "\tv_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]"
     assert len(hazard_lint.lint_listing(["k:", wide] + ["\ts_nop 0"] * 9 + ["\tv_mul_f32_e32 v40, v41, v7"])) == 1
     assert hazard_lint.lint_listing(["k:", wide] + ["\ts_nop 0"] * 10 + ["\tv_mul_f32_e32 v40, v41, v7"]) == []
-    if not os.path.exists(hazard_lint.OBJDUMP):
+    # edges, not only text: a read at the TARGET of a branch behind the MFMA (forward: over the waiting path; backward: a loop header
+    # reached from the loop's tail) is seen; the same read far enough down either path is not
+    fwd = ["k:", mfma, "\ts_cbranch_scc1 .LBB0_2", "\ts_nop 7", "\ts_branch .LBB0_3", ".LBB0_2:", "\tv_accvgpr_read_b32 v100, a208", ".LBB0_3:", "\ts_endpgm"]
+    found = hazard_lint.lint_listing(fwd)
+    assert len(found) == 1 and "v_accvgpr_read_b32" in found[0][2]
+    assert hazard_lint.lint_listing([l.replace("v100, a208", "v100, a212") for l in fwd]) == []
+    back = ["k:", ".LBB0_1:", "\tv_accvgpr_read_b32 v100, a208", "\ts_nop 7", mfma, "\ts_cbranch_scc1 .LBB0_1", "\ts_nop 7", "\ts_endpgm"]
+    found = hazard_lint.lint_listing(back)
+    assert len(found) == 1 and found[0][3] == 1 + hazard_lint.kTakenBranchStates
+    assert hazard_lint.lint_listing(["k:", ".LBB0_1:", "\ts_nop 7", "\tv_accvgpr_read_b32 v100, a208", mfma, "\ts_cbranch_scc1 .LBB0_1", "\ts_endpgm"]) == []
+    # llvm-objdump's form: addresses in the trailing comment, the target as <function+0xoffset>
+    dis = ["0000000000001000 <k>:", mfma + "   // 000000001000: D3B50000", "\ts_cbranch_scc1 2   // 000000001008: BF850002 <k+0x14>",
+           "\ts_nop 7   // 00000000100C: BF800007", "\ts_endpgm   // 000000001010: BF810000", "\tv_accvgpr_read_b32 v100, a208   // 000000001014: D3D84064",
+           "\ts_endpgm   // 00000000101C: BF810000"]
+    assert len(hazard_lint.lint_listing(dis)) == 1
+    if hazard_lint.objdump() is None:
         pytest.skip("no llvm-objdump in this toolchain: the listing checks above ran, the objects cannot be disassembled")
     objs = glob.glob(os.path.join(root, "capreolus_amd", "csrc", "*.o"))
     assert len(objs) >= 17
