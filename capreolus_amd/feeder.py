@@ -23,14 +23,14 @@ class CandidateStore:
     def add_query(self, qid, query_ids, query_idf=None):
         if qid not in self.qrow:
             self.qrow[qid] = len(self._q)
-            self._q.append(np.asarray(query_ids, dtype=np.int64))
+            self._q.append(np.asarray(query_ids))
             self._idf.append(np.zeros(len(query_ids), np.float32) if query_idf is None else np.asarray(query_idf, np.float32))
         return self.qrow[qid]
 
     def add_doc(self, docid, doc_ids):
         if docid not in self.drow:
             self.drow[docid] = len(self._d)
-            self._d.append(np.asarray(doc_ids, dtype=np.int64))
+            self._d.append(np.asarray(doc_ids))
         return self.drow[docid]
 
     @classmethod
@@ -46,14 +46,27 @@ class CandidateStore:
                 st.add_doc(docid, v["posdoc"])
         return st.finalize()
 
-    def finalize(self):
-        q, d = np.stack(self._q), np.stack(self._d)
-        for name, a in (("query", q), ("document", d)):
-            if a.min() < -2 ** 31 or a.max() >= 2 ** 31:
+    @staticmethod
+    def _int32_block(rows, name):
+        """[n, L] int32 from a list of equally long id rows (any integer dtype)"""
+        block = np.stack(rows)
+        if block.dtype != np.int32:
+            if block.min() < -2 ** 31 or block.max() >= 2 ** 31:
                 raise ValueError(f"{name} term ids do not fit int32")
-        self.q_table = torch.as_tensor(q.astype(np.int32)).to(self.device)
+            block = block.astype(np.int32)
+        return block
+
+    CHUNK = 512       # rows stacked and narrowed at a time: the int64 rows of a 64,000-document run are 410 MB - stacked whole and then
+                      # narrowed they were read and written three times over (0.3 s of a 0.35 s first `predict`).  (Narrowing in a
+                      # background thread under the caller's loop was tried: np.stack over a list holds the interpreter lock - 4x slower.)
+
+    def finalize(self):
+        self.q_table = torch.as_tensor(self._int32_block(self._q, "query")).to(self.device)
         self.idf_table = torch.as_tensor(np.stack(self._idf)).to(self.device)
-        self.d_table = torch.as_tensor(d.astype(np.int32)).to(self.device)
+        d = np.empty((len(self._d), len(self._d[0])), dtype=np.int32)
+        for lo in range(0, len(self._d), self.CHUNK):
+            d[lo:lo + self.CHUNK] = self._int32_block(self._d[lo:lo + self.CHUNK], "document")
+        self.d_table = torch.as_tensor(d).to(self.device)
         return self
 
     def pairs(self, qid_to_docids):

@@ -532,25 +532,42 @@ class PytorchTrainer:
         if hit is not None and hit[0] == fp and hit[1]() is pred_data and self._plan_still_mirrors(pred_data, hit[2]):
             return hit[2]
         store, pq, pd, groups = CandidateStore(self.device), [], [], []
-        for sample in part:           # the same walk the DataLoader would do - once
-            if not all(k in sample for k in ("qid", "posdocid", "query", "posdoc")):
+        # the same walk the DataLoader would do - once.  Per sample: two dictionary lookups and a comparison of the query row's BYTES with
+        # the ones its qid came with first (np.array_equal on a 4-element row cost more than everything else in this loop); a document's
+        # 800-element row is compared only when its docid comes a second time
+        qrow_of, drow_of, rows_d = store.qrow, store.drow, store._d
+        qbytes, cur_qid, cur_qrow, cur_docs = {}, object(), -1, None
+        ndarray, last_q, last_i, last_sig = np.ndarray, None, None, None
+        for sample in part:
+            try:
+                qid, docid, query, doc = sample["qid"], sample["posdocid"], sample["query"], sample["posdoc"]
+            except KeyError:
                 return None
-            qid, docid = sample["qid"], sample["posdocid"]
-            qrow = store.qrow.get(qid)
-            if qrow is None:
-                qrow = store.add_query(qid, sample["query"], sample.get("query_idf"))
-            elif not (np.array_equal(store._q[qrow], np.asarray(sample["query"])) and
-                      (sample.get("query_idf") is None or np.array_equal(store._idf[qrow], np.asarray(sample["query_idf"], np.float32)))):
+            idf = sample.get("query_idf")
+            if query is last_q and idf is last_i:        # (a sampler that hands out the same row objects per query: nothing to compare)
+                sig = last_sig
+            else:
+                sig = (query.tobytes() if isinstance(query, ndarray) else np.asarray(query).tobytes(),
+                       None if idf is None else idf.tobytes() if isinstance(idf, ndarray) and idf.dtype == np.float32 else np.asarray(idf, np.float32).tobytes())
+                last_q, last_i, last_sig = query, idf, sig
+            if qid != cur_qid:                # a new run of this qid's samples = a new list
+                qrow = qrow_of.get(qid)
+                if qrow is None:
+                    qrow = store.add_query(qid, query, idf)
+                    qbytes[qrow] = sig
+                cur_qid, cur_qrow, cur_docs = qid, qrow, []
+                groups.append([qid, cur_docs, len(pq)])
+            if sig != qbytes[cur_qrow] and not (np.array_equal(store._q[cur_qrow], np.asarray(query)) and
+                                                (idf is None or np.array_equal(store._idf[cur_qrow], np.asarray(idf, np.float32)))):
                 return None       # a qid whose query row changes from sample to sample: not a candidate-store sampler
-            drow = store.drow.get(docid)
+            drow = drow_of.get(docid)
             if drow is None:
-                drow = store.add_doc(docid, sample["posdoc"])
-            elif not np.array_equal(store._d[drow], np.asarray(sample["posdoc"])):
+                drow = drow_of[docid] = len(rows_d)
+                rows_d.append(doc if isinstance(doc, ndarray) else np.asarray(doc))
+            elif not np.array_equal(rows_d[drow], np.asarray(doc)):
                 return None       # this extractor's document row depends on the query: not a candidate-store sampler
-            if not groups or groups[-1][0] != qid:
-                groups.append([qid, [], len(pq)])
-            groups[-1][1].append(docid)
-            pq.append(qrow)
+            cur_docs.append(docid)
+            pq.append(cur_qrow)
             pd.append(drow)
         if not pq:
             return None
