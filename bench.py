@@ -56,6 +56,7 @@ def parse():
                     help="knrm (default, BASELINE.json's metric) | drmm | bert | the row-N4 siblings drmmtks, pacrr, convknrm")
     ap.add_argument("--queries", type=int, default=0, help="queries per step per GPU (0 = 64 for the interaction models - 250 for drmm, configs[2] - and 1 for bert)")
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
+    ap.add_argument("--qlen", type=int, default=4, help="query terms (the extractor's maxqlen): 4 is BASELINE.json's; up to 8 on the list route")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
     ap.add_argument("--launch-streams", type=int, default=4,
                     help="with --launch-docs: the launches of a step go round-robin over this many HIP streams, so the tail of one candidate "
@@ -146,6 +147,20 @@ def main():
                 del ul
             except Exception as e:  # noqa: BLE001
                 rec["lists_on_uniform_ids"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                # ... and queries of eight terms (`maxqlen` is a free option of the reference's extractor, embedtext.py:28-31): two blocks of
+                # four query terms on the list route, the timed scores checked against the C oracle
+                a4 = copy.copy(args)
+                a4.qlen = 8
+                ql = InteractionLeg(a4, ctx, "knrm", args.vocab, False, args.queries or 64, 2, 1 + ctx.rank)
+                q_elapsed, _ = ql.run(2, short)
+                q_err = ql.check_against_oracle(min(64, ql.n_pairs))[2]
+                rec["qlen8_lists"] = {"value": ql.n_pairs * short / q_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * q_elapsed / short, "steps": short,
+                                      "oracle_check_max_err_of_scale": q_err, "lists": bool(ql.lists),
+                                      "what": "bench.py --qlen 8: the headline's lists under eight-term queries (query lengths 1-8), whole-list route"}
+                del ql
+            except Exception as e:  # noqa: BLE001
+                rec["qlen8_lists"] = {"error": f"{type(e).__name__}: {e}"}
             _tables.clear()
             torch.cuda.empty_cache()
             rec["also"] = []

@@ -25,7 +25,7 @@ class InteractionLeg:
 
         self.args, self.ctx, self.model, self.V, self.uniform = args, ctx, model, V, uniform
         dev = ctx.dev
-        self.Q, self.L, self.D = 4, 800, args.dim
+        self.Q, self.L, self.D = getattr(args, "qlen", 4), 800, args.dim
         self.n_pairs = n_queries * args.docs
         self.emb = table(dev, V, self.D)
         self.batches = []
@@ -370,7 +370,7 @@ def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic
 
 def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     """One KNRM / DRMM measurement: headline leg + HBM roofline leg (+ CPU baseline on rank 0 at N = 1)."""
-    Q, L, D = 4, 800, args.dim
+    Q, L, D = getattr(args, "qlen", 4), 800, args.dim
     world = ctx.world
     strong = args.scaling == "strong"
     per_rank_q = n_queries // world if strong else n_queries

@@ -76,6 +76,8 @@ def compact(rec, full_path):
         out["zero_idf_run"] = _pick(rec["zero_idf_run"], ("value", "unit", "ms_per_step", "steps"))
     if isinstance(rec.get("resident_int32_route"), dict):
         out["resident_int32_route"] = _pick(rec["resident_int32_route"], ("value", "unit", "ms_per_step", "error"))
+    if isinstance(rec.get("qlen8_lists"), dict):
+        out["qlen8_lists"] = _pick(rec["qlen8_lists"], ("value", "ms_per_step", "oracle_check_max_err_of_scale", "error"))
     if isinstance(rec.get("lists_on_uniform_ids"), dict):
         out["lists_on_uniform_ids"] = _pick(rec["lists_on_uniform_ids"], ("value", "ms_per_step", "mean_distinct_terms_per_list", "error"))
     also = []

@@ -44,6 +44,7 @@ SIGNATURES = {
     "capamd_similarity_matrix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _vp]),
     "capamd_knrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _u, _vp]),
     "capamd_lists_workspace_bytes": (_sz, [_i, _i64, _i64, _i]),
+    "capamd_lists_workspace_bytes_q": (_sz, [_i, _i64, _i64, _i, _i]),
     "capamd_knrm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "capamd_drmm_forward_lists": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -24,9 +24,10 @@
 // DRMM's bin counts are integers of bit-identical similarities and DRMM-TKS's top-k are selections of them: scores bit-exact with the
 // per-pair kernels.  KNRM sums the same kernel values in another order (per lane over its positions, then over the lanes): equal to
 // fp32 rounding of the sums (1e-6 relative).
-// Workspace (caller-owned): per list in flight a table (16 B per id) and a byte map over the vocabulary, 17 B x V (6.8 MB at V =
-// 400,001) + 5 KB for its query; lists are processed in groups of as many as the workspace holds (<= 64).  Q <= 4 (kQT), other limits
-// as the per-pair entries.
+// Workspace (caller-owned): per list in flight a table (16 B per id and block of four query terms) and a byte map over the vocabulary,
+// 17 B x V (6.8 MB at V = 400,001; 33 B x V for queries of five to eight terms) + 5 KB per block for its query; lists are processed in
+// groups of as many as the workspace holds (<= 256).  Q <= 8 (two blocks of kQT = 4 terms: the reference's `maxqlen` is a free option,
+// extractor/embedtext.py:28-31, and its forwards take any Q: reranker/KNRM.py:39-55, DRMM.py:101-116); other limits as the per-pair entries.
 #include "lists.cuh"
 #include "capamd_profiling.h"
 #include <vector>
@@ -62,240 +63,31 @@ struct KnrmPoolArgs {
   float* out;
 };
 
-// A WAVE per document (four documents per workgroup), a lane per (position slot, query term): row t of the wave (its lanes 16 t ..
-// 16 t + 15) holds query term t of 16 positions ("a trip").  A document is walked in passes of kWaveTrips trips: every id of the pass
-// is requested first, then every table entry, then the arithmetic; a pass without a real or OOV term (padding) stops after the ids.
-// No LDS and no barrier: the row reduction is DPP, the per-kernel logs run in lanes (query term, kernel), the read-out takes the
-// kernels' features by readlane.  (A workgroup per document - four waves sharing its positions, LDS reduction, one lane per kernel for
-// the logs - measured 465 us per 64,000 documents against this form's 352.)
-#ifndef CAPAMD_POOL_WAVES
-#define CAPAMD_POOL_WAVES 1     // register budget as waves per SIMD (the kernel takes 76 registers: 6 waves; 8 = at most 64 registers)
-#endif
-#ifndef CAPAMD_POOL_PREFETCH
-#define CAPAMD_POOL_PREFETCH 0
-#endif
-#ifndef CAPAMD_POOL_KB_VGPR
-#define CAPAMD_POOL_KB_VGPR 1        // (0: the round-4 form - A/B builds; profiles/r05/lists_pool_kbv_ab.txt)
-#endif
-#ifndef CAPAMD_POOL_LATE_WEIGHTS
-#define CAPAMD_POOL_LATE_WEIGHTS 1   // the read-out's weights requested behind the position loop: 14 registers fewer across it (what pays for the B pairs)
-#endif
+// A WAVE per document (four documents per workgroup), no LDS and no barrier: the row reductions are DPP, the per-kernel logs run in
+// lanes (query term, kernel), the read-out takes the kernels' features by readlane.  A document is walked in passes of kWaveTrips trips:
+// every id of the pass is requested first, then every table entry, then the arithmetic; a pass without a real term stops after the ids.
+// (A workgroup per document - four waves sharing its positions, LDS reduction - measured 465 us per 64,000 documents against 352.)
+// The lanes go to the query terms that are REAL: a term that is not (a pad of the reference's fixed-length query row, or an OOV term)
+// has similarity exactly 0 with every table entry, so its row's sums are known without a lookup - sum_j K_k(0) over the document's real
+// positions, K_k(0) = 2^-(B_k^2) exactly as the evaluation produces it for s = 0 - and its feature is 0 anyway unless it is an OOV term
+// the document matches (KNRM.py:51-53: rows whose similarities sum to 0 are masked).  Per block of four query terms:
+//     real terms 1: lane = position slot (64 per trip);  2: lanes 0-31 the first, 32-63 the second real term (32 per trip);
+//     3-4: row t of the wave (lanes 16 t .. 16 t + 15) holds term t of 16 positions;  0 (an empty second block): nothing to walk.
+// Queries of five to eight terms (QP = 2) walk the document once per block; the blocks' feature sums are added in block order, as the
+// per-pair kernel adds its passes (knrm.hip).
+// The sums add the same kernel values as the per-pair kernels in another order: equal to fp32 rounding of the sums (1e-6 relative).
+// Measured and not kept (profiles/r04/lists_pool_variants.txt, r05/lists_pool_*_ab.txt): the frequent terms' entries staged in LDS
+// (bank conflicts of 64 random ds_reads: 227 -> 281 us), eight documents per wave (261), a prefetch of the next pass's ids, 4 / 12 / 16
+// trips per pass.
 #ifndef CAPAMD_POOL_TRIPS
 #define CAPAMD_POOL_TRIPS 8
 #endif
-constexpr int kWaveTrips = CAPAMD_POOL_TRIPS;      // 128 positions per pass (A/B builds: 4 / 12 / 16 - profiles/r05/lists_pool_trips_ab.txt)
+constexpr int kWaveTrips = CAPAMD_POOL_TRIPS;      // 128 positions per pass
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
-// KK: kernels the loops run over (11 - the model's default bank - or kMaxK, slots beyond K repeating the last kernel)
-// Two variants measured in round 4 and NOT kept (profiles/r04/lists_pool_variants.txt), selectable for A/B builds:
-//   -DCAPAMD_POOL_HOT=2048 / -DCAPAMD_POOL_HOT_BINS=8192   the entries of the frequent terms (ids below the bound: ids are frequency ranks in
-//       GloVe-style vocabularies and in the benchmark's Zipf(1.1) ids - 75 % of all document terms have an id below 2048) staged in LDS per
-//       workgroup, so that three of four lookups are an LDS read instead of a 16-byte entry pulled out of L2 by a whole line: the random
-//       ds_read_b32 addresses of 64 lanes conflict on the banks - KNRM pooling 227 -> 281 us per call (388 with 4096 entries)
-//   -DCAPAMD_POOL_DOCS=8   a workgroup walking 8 documents per wave (what the staging needs to pay for itself): 227 -> 261 us without the
-//       table - fewer, longer waves balance the documents' 40x length spread worse
-#ifndef CAPAMD_POOL_HOT
-#define CAPAMD_POOL_HOT 0
-#endif
-#ifndef CAPAMD_POOL_DOCS
-#define CAPAMD_POOL_DOCS 1
-#endif
-#ifndef CAPAMD_POOL_HOT_BINS
-#define CAPAMD_POOL_HOT_BINS 0
-#endif
-constexpr int kPoolHot = CAPAMD_POOL_HOT, kPoolDocs = CAPAMD_POOL_DOCS, kPoolHotBins = CAPAMD_POOL_HOT_BINS;
-
-template <int KK>
-__global__ __launch_bounds__(256, CAPAMD_POOL_WAVES) void lists_knrm_pool_wide_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
-  __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];
-  int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
-  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
-  if (kPoolHot > 0) {
-    const float4* src = a.table + (int64_t)l * a.Vp;
-    const int nh = a.Vp < kPoolHot ? (int)a.Vp : kPoolHot;
-    for (int i = tid; i < nh; i += 256) hot[i] = src[i];
-    __syncthreads();
-  }
-  const float* hotf = reinterpret_cast<const float*>(hot) + t;
-  float ka[KK], kb[KK];      // K_k(s) = 2^-(ka s + kb)^2
-#pragma unroll
-  for (int k = 0; k < KK; ++k) {
-    ka[k] = a.kn_consts[4 * kMaxK + k];
-    kb[k] = a.kn_consts[5 * kMaxK + k];
-  }
-#if CAPAMD_POOL_KB_VGPR
-  // the kernels' B constants as register PAIRS in VGPRs: uniform values live in SGPRs, and a VALU instruction reads one SGPR operand -
-  // with A and B both there every packed fma is preceded by a v_mov_b64 of its B pair (6 of ~37 VALU instructions per trip)
-  f32x2 kbv[KK / 2 + 1];
-#pragma unroll
-  for (int k = 0; k + 1 < KK; k += 2) {
-    kbv[k / 2] = f32x2{kb[k], kb[k + 1]};
-    asm volatile("" : "+v"(kbv[k / 2]));
-  }
-#endif
-  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
-#if CAPAMD_POOL_LATE_WEIGHTS == 0
-  // the read-out's weights: the same for every document
-  const int hn = lane < m.hidden ? lane : 0;
-  float w1v[kMaxK];
-#pragma unroll
-  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
-  const int kq = lane & 15;
-  const float k0c = (kq < m.K) ? a.kn_consts[2 * kMaxK + kq] : 0.f, k1c = (kq < m.K) ? a.kn_consts[3 * kMaxK + kq] : 0.f;
-#endif
-  for (int di = 0; di < kPoolDocs; ++di) {
-  const int doc = (dq * kPoolDocs + di) * 4 + wave;
-  if (doc >= g.len[l]) break;
-  const int b = g.start[l] + doc;
-  // what the mark pass left: the document's real terms, dense (int32), and its counts
-  const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
-  const DocWalk dw = doc_walk(a, b, dm);
-  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
-  float acc[KK], rs = 0.f;
-#pragma unroll
-  for (int k = 0; k < KK; ++k) acc[k] = 0.f;
-#if CAPAMD_POOL_PREFETCH
-  // The compact row's entries of the NEXT pass are requested before the current pass's lookups and arithmetic, and the first pass's
-  // before the document's length is known (the row has cid_stride entries whatever it holds: indices clamped, entries masked by n once
-  // it is here) - per document the chain  metadata -> ids -> table entries -> arithmetic  loses its second link.
-  int idn[kWaveTrips];
-  auto request = [&](int j0) {
-#pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) {
-      const int j = j0 + u * 16 + ps;
-      idn[u] = __builtin_nontemporal_load(dw.row + (j < a.cid_stride ? j : a.cid_stride - 1));
-    }
-  };
-  if (kCompactRows) request(0);
-#endif
-  for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
-    int id[kWaveTrips];
-#if CAPAMD_POOL_PREFETCH
-    if (kCompactRows) {
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) id[u] = (j0 + u * 16 + ps < n) ? idn[u] : 0;
-      if (j0 + 16 * kWaveTrips < n) request(j0 + 16 * kWaveTrips);
-    } else
-#endif
-    load_pass<kWaveTrips, 16>(dw, j0, ps, id);
-    float s[kWaveTrips];
-    if (kPoolHot > 0) {
-      float sg[kWaveTrips], sl[kWaveTrips];
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) sg[u] = tab[(int64_t)(id[u] >= kPoolHot ? id[u] : 0) * 4];   // (entry 0: one shared line for the hot ones)
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) sl[u] = hotf[(id[u] < kPoolHot ? id[u] : 0) * 4];
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
-    } else {
-#pragma unroll
-#ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * 4];
-#else
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
-#endif
-    }
-    // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
-#pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
-#pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) {
-      if (j0 + u * 16 >= n) continue;          // (wave-uniform)
-      if (id[u] > 0) {
-        rs += s[u];
-        // two kernels per packed instruction (v_pk_fma / v_pk_mul / v_pk_add: the same fma, product and sum per element, half the
-        // issue slots - 2.5 instead of 4 VALU instructions per evaluation beside its v_exp_f32); an odd last kernel on its own
-#pragma unroll
-        for (int k = 0; k + 1 < KK; k += 2) {
-#if CAPAMD_POOL_KB_VGPR
-          const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + kbv[k / 2];
-#else
-          const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + f32x2{kb[k], kb[k + 1]};
-#endif
-          const f32x2 nq = -tk * tk;
-          const f32x2 e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
-          f32x2 ac = {acc[k], acc[k + 1]};
-          ac += e;
-          acc[k] = ac.x; acc[k + 1] = ac.y;
-        }
-        if (KK & 1) {
-          const float tk = __builtin_fmaf(s[u], ka[KK - 1], kb[KK - 1]);
-          acc[KK - 1] += __builtin_amdgcn_exp2f(-tk * tk);
-        }
-      }
-    }
-  }
-#if CAPAMD_POOL_LATE_WEIGHTS
-  // the read-out's weights requested only now: 14 registers fewer across the position loop
-  const int hn = lane < m.hidden ? lane : 0;
-  float w1v[kMaxK];
-#pragma unroll
-  for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
-  const int kq = lane & 15;
-  const float k0c = (kq < m.K) ? a.kn_consts[2 * kMaxK + kq] : 0.f, k1c = (kq < m.K) ? a.kn_consts[3 * kMaxK + kq] : 0.f;
-#endif
-  // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
-  const int k = lane & 15;
-  float S = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) {
-    const float v = group_allreduce(acc[kk]);
-    S = k == kk ? v : S;
-  }
-  const float R0 = group_allreduce(rs);
-  const int no = n_one_t, nreal = n_real_doc;
-  float f = 0.f;
-  if (k < m.K && t < a.Q) {
-    const float k0 = k0c, k1 = k1c;
-    const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
-    S += (float)nz * k0;
-    S += (float)no * k1;
-    const float R = R0 + (float)no;
-    f = R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
-  }
-  // over the query terms, in their order
-  const float F = ((__shfl(f, k, 64) + __shfl(f, 16 + k, 64)) + __shfl(f, 32 + k, 64)) + __shfl(f, 48 + k, 64);
-  if (m.hidden > 0) {
-    float h = 0.f;
-    const int n = lane < m.hidden ? lane : 0;
-    h = m.b1[n];
-#pragma unroll
-    for (int kk = 0; kk < kMaxK; ++kk)
-      if (kk < m.K) h = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), h);
-    h = lane < m.hidden ? m.w2[n] * tanhf(h) : 0.f;
-    float sc = wave_allreduce_sum(h) + m.b2[0];
-    if (m.scoretanh) sc = tanhf(sc);
-    if (lane == 0) m.out[b] = sc;
-  } else {
-    float sc = m.b1[0];
-#pragma unroll
-    for (int kk = 0; kk < kMaxK; ++kk)
-      if (kk < m.K) sc = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), sc);
-    if (m.scoretanh) sc = tanhf(sc);
-    if (lane == 0) m.out[b] = sc;
-  }
-  }   // documents of this wave
-}
-
-// ---- 3a': the pooling pass that does not evaluate what it knows ----------------------------------------------------------------
-// lists_knrm_pool_wide_kernel above gives every query term 16 lanes whatever the query holds.  A term that is NOT real (a pad of the
-// reference's fixed-length query row, or an OOV term) has similarity exactly 0 with every table entry - the sims pass wrote 0.f - so its
-// row's sums are known without a lookup: sum_j K_k(0) over the document's real positions, with K_k(0) = 2^-(B_k^2) exactly as the
-// evaluation produces it for s = 0 (fma(0, A, B) = B), and its feature is 0 anyway unless it is an OOV term the document matches
-// (KNRM.py:51-53: rows whose similarities sum to 0 are masked).  With one or two real terms (half of the benchmark's queries: 1-4 terms,
-// uniform; Robust04 titles average 2.7) the wave's 64 lanes take 64 or 32 positions per trip instead of 16:
-//     real terms 1:  lane = position slot (64 per trip);  2: lanes 0-31 the first, 32-63 the second real term (32 per trip);  3-4: as above.
-// The sums of an evaluated row add the same values as before in another order (lanes hold other positions): KNRM's list route was never
-// bit-identical to the per-pair kernel's summation order (include/capreolus_amd.h); DRMM / DRMM-TKS / PACRR do not come through here.
-#ifndef CAPAMD_POOL_NARROW
-#define CAPAMD_POOL_NARROW 1      // 0: lists_knrm_pool_wide_kernel for every list (A/B builds)
-#endif
-
-// one document's positions in trips of W (64 / W lanes-groups take the wave's 64 / W ... terms): acc[k] += K_k(s), rs += s for this lane's positions
-template <int KK, int W>
+// one document's positions in trips of W: acc[k] += K_k(s), rs += s for this lane's positions; table entries ESTRIDE floats apart
+template <int KK, int W, int ESTRIDE>
 __device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lane, const float* tabsel, const float (&ka)[KK], const float (&kb)[KK],
                                                const f32x2 (&kbv)[KK / 2 + 1], float (&acc)[KK], float& rs) {
   const int ps = lane & (W - 1);
@@ -304,7 +96,11 @@ __device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lan
     load_pass<kWaveTrips, W>(dw, j0, ps, id);
     float s[kWaveTrips];
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) s[u] = tabsel[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+#ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
+    for (int u = 0; u < kWaveTrips; ++u) s[u] = tabsel[(int64_t)(id[u] & 1023) * ESTRIDE];
+#else
+    for (int u = 0; u < kWaveTrips; ++u) s[u] = tabsel[(int64_t)id[u] * ESTRIDE];     // (entry 0 is never written and never used)
+#endif
     // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
     for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
@@ -313,6 +109,8 @@ __device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lan
       if (j0 + u * W >= n) continue;          // (wave-uniform)
       if (id[u] > 0) {
         rs += s[u];
+        // two kernels per packed instruction (v_pk_fma / v_pk_mul / v_pk_add: the same fma, product and sum per element, half the
+        // issue slots - 2.5 instead of 4 VALU instructions per evaluation beside its v_exp_f32); an odd last kernel on its own
 #pragma unroll
         for (int k = 0; k + 1 < KK; k += 2) {
           const f32x2 tk = f32x2{s[u], s[u]} * f32x2{ka[k], ka[k + 1]} + kbv[k / 2];
@@ -331,7 +129,8 @@ __device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lan
   }
 }
 
-template <int KK>
+// KK: kernels the loops run over (11 - the model's default bank - or kMaxK, slots beyond K repeating the last kernel)
+template <int KK, int QP>
 __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
   int l, dq;
   if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 documents here)
@@ -344,97 +143,101 @@ __global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListG
     ka[kk] = a.kn_consts[4 * kMaxK + kk];
     kb[kk] = a.kn_consts[5 * kMaxK + kk];
   }
-  // (B as register PAIRS in VGPRs: both constants in SGPRs cost a v_mov_b64 in front of every packed fma - lists_knrm_pool_wide_kernel)
+  // (B as register PAIRS in VGPRs: uniform values live in SGPRs, a VALU instruction reads one SGPR operand - with A and B both there
+  //  every packed fma is preceded by a v_mov_b64 of its B pair)
   f32x2 kbv[KK / 2 + 1];
 #pragma unroll
   for (int kk = 0; kk + 1 < KK; kk += 2) {
     kbv[kk / 2] = f32x2{kb[kk], kb[kk + 1]};
     asm volatile("" : "+v"(kbv[kk / 2]));
   }
-  // the list's real query terms (wave-uniform): how many, and the first two
-  int nq = 0, r0 = 0, r1 = 0;
-#pragma unroll
-  for (int tt = 0; tt < kQT; ++tt) {
-    const bool real = tt < a.Q && a.qmeta[l].id[tt] > 0;
-    r1 = (real && nq == 1) ? tt : r1;
-    r0 = (real && nq == 0) ? tt : r0;
-    nq += real ? 1 : 0;
-  }
-  nq = __builtin_amdgcn_readfirstlane(nq); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
   const int b = g.start[l] + doc;
   // what the mark pass left: the document's real terms, dense (int32), and its counts
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
   const DocWalk dw = doc_walk(a, b, dm);
-  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
-  const float* tab0 = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp);
-  float acc[KK], rs = 0.f;
+  const int n = dw.n, n_real_doc = dm[0];
+  const float* tabl = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp * QP);
+  float F = 0.f;
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) acc[kk] = 0.f;
-  float S = 0.f, R0 = 0.f;
-  if (nq == 1) {
-    knrm_pool_walk<KK, 64>(dw, n, lane, tab0 + r0, ka, kb, kbv, acc, rs);
-    const bool mine = t == r0;
+  for (int h = 0; h < QP; ++h) {
+    // the block's real query terms (wave-uniform): how many, and the first two
+    int nq = 0, r0 = 0, r1 = 0;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const float v = group_allreduce(acc[kk]);
-      const float sum = (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
-      S = (k == kk && mine) ? sum : S;
+    for (int tt = 0; tt < kQT; ++tt) {
+      const bool real = kQT * h + tt < a.Q && a.qmeta[(int64_t)l * QP + h].id[tt] > 0;
+      r1 = (real && nq == 1) ? tt : r1;
+      r0 = (real && nq == 0) ? tt : r0;
+      nq += real ? 1 : 0;
     }
-    const float v = group_allreduce(rs);
-    R0 = mine ? (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48)) : 0.f;
-  } else if (nq == 2) {
-    knrm_pool_walk<KK, 32>(dw, n, lane, tab0 + (lane < 32 ? r0 : r1), ka, kb, kbv, acc, rs);
-    const bool mine0 = t == r0, mine1 = t == r1;
+    nq = __builtin_amdgcn_readfirstlane(nq); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+    const int n_one_t = doc_n_one(dm, kQT * h + t);
+    const float* tab0 = tabl + 4 * h;
+    float acc[KK], rs = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const float v = group_allreduce(acc[kk]);
+    for (int kk = 0; kk < KK; ++kk) acc[kk] = 0.f;
+    float S = 0.f, R0 = 0.f;
+    if (nq == 1) {
+      knrm_pool_walk<KK, 64, 4 * QP>(dw, n, lane, tab0 + r0, ka, kb, kbv, acc, rs);
+      const bool mine = t == r0;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const float v = group_allreduce(acc[kk]);
+        const float sum = (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+        S = (k == kk && mine) ? sum : S;
+      }
+      const float v = group_allreduce(rs);
+      R0 = mine ? (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48)) : 0.f;
+    } else if (nq == 2) {
+      knrm_pool_walk<KK, 32, 4 * QP>(dw, n, lane, tab0 + (lane < 32 ? r0 : r1), ka, kb, kbv, acc, rs);
+      const bool mine0 = t == r0, mine1 = t == r1;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const float v = group_allreduce(acc[kk]);
+        const float s0 = lane_bcast(v, 0) + lane_bcast(v, 16), s1 = lane_bcast(v, 32) + lane_bcast(v, 48);
+        S = (k == kk && mine0) ? s0 : (k == kk && mine1) ? s1 : S;
+      }
+      const float v = group_allreduce(rs);
       const float s0 = lane_bcast(v, 0) + lane_bcast(v, 16), s1 = lane_bcast(v, 32) + lane_bcast(v, 48);
-      S = (k == kk && mine0) ? s0 : (k == kk && mine1) ? s1 : S;
-    }
-    const float v = group_allreduce(rs);
-    const float s0 = lane_bcast(v, 0) + lane_bcast(v, 16), s1 = lane_bcast(v, 32) + lane_bcast(v, 48);
-    R0 = mine0 ? s0 : mine1 ? s1 : 0.f;
-  } else {
-    knrm_pool_walk<KK, 16>(dw, n, lane, tab0 + t, ka, kb, kbv, acc, rs);
-    // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
+      R0 = mine0 ? s0 : mine1 ? s1 : 0.f;
+    } else if (nq > 2) {
+      knrm_pool_walk<KK, 16, 4 * QP>(dw, n, lane, tab0 + t, ka, kb, kbv, acc, rs);
+      // the 16 lanes of a row (one query term): every lane gets the row's sums; lane (t, k) keeps kernel k
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const float v = group_allreduce(acc[kk]);
-      S = k == kk ? v : S;
+      for (int kk = 0; kk < KK; ++kk) {
+        const float v = group_allreduce(acc[kk]);
+        S = k == kk ? v : S;
+      }
+      R0 = group_allreduce(rs);
     }
-    R0 = group_allreduce(rs);
+    const float k0c = (k < m.K) ? a.kn_consts[2 * kMaxK + k] : 0.f, k1c = (k < m.K) ? a.kn_consts[3 * kMaxK + k] : 0.f;
+    if (nq == 0 || (nq == 1 && t != r0) || (nq == 2 && t != r0 && t != r1)) {
+      // a row that was not evaluated: K_k(0) = 2^-(B_k^2) at every real position (what the evaluation adds for s = 0)
+      const float bq = a.kn_consts[5 * kMaxK + (k < m.K ? k : 0)];
+      S = (float)n_real_doc * __builtin_amdgcn_exp2f(-(bq * bq));
+    }
+    float f = 0.f;
+    if (k < m.K && kQT * h + t < a.Q) {
+      const int nz = a.L - n_real_doc - n_one_t;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
+      S += (float)nz * k0c;
+      S += (float)n_one_t * k1c;
+      const float R = R0 + (float)n_one_t;
+      f = R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
+    }
+    // over the block's query terms, in their order; over the blocks in theirs
+    const float Fh = ((__shfl(f, k, 64) + __shfl(f, 16 + k, 64)) + __shfl(f, 32 + k, 64)) + __shfl(f, 48 + k, 64);
+    F = h == 0 ? Fh : F + Fh;
   }
   // the read-out's weights requested only now: 14 registers fewer across the position loop
   const int hn = lane < m.hidden ? lane : 0;
   float w1v[kMaxK];
 #pragma unroll
   for (int kk = 0; kk < kMaxK; ++kk) w1v[kk] = m.w1[hn * m.K + (kk < m.K ? kk : m.K - 1)];
-  const float k0c = (k < m.K) ? a.kn_consts[2 * kMaxK + k] : 0.f, k1c = (k < m.K) ? a.kn_consts[3 * kMaxK + k] : 0.f;
-  if ((nq == 1 && t != r0) || (nq == 2 && t != r0 && t != r1)) {
-    // a row that was not evaluated: K_k(0) = 2^-(B_k^2) at every real position (what the evaluation adds for s = 0)
-    const float bq = a.kn_consts[5 * kMaxK + (k < m.K ? k : 0)];
-    S = (float)n_real_doc * __builtin_amdgcn_exp2f(-(bq * bq));
-  }
-  const int no = n_one_t, nreal = n_real_doc;
-  float f = 0.f;
-  if (k < m.K && t < a.Q) {
-    const float k0 = k0c, k1 = k1c;
-    const int nz = a.L - nreal - no;        // pads and OOV terms without a match: similarity 0 (KNRM.py:50 sums over ALL positions)
-    S += (float)nz * k0;
-    S += (float)no * k1;
-    const float R = R0 + (float)no;
-    f = R != 0.f ? logf(S + 1e-6f) : 0.f;   // KNRM.py:51-53
-  }
-  // over the query terms, in their order
-  const float F = ((__shfl(f, k, 64) + __shfl(f, 16 + k, 64)) + __shfl(f, 32 + k, 64)) + __shfl(f, 48 + k, 64);
   if (m.hidden > 0) {
-    float h = 0.f;
-    const int nn = lane < m.hidden ? lane : 0;
-    h = m.b1[nn];
+    float h = m.b1[hn];
 #pragma unroll
     for (int kk = 0; kk < kMaxK; ++kk)
       if (kk < m.K) h = __builtin_fmaf(w1v[kk], lane_bcast(F, kk), h);
-    h = lane < m.hidden ? m.w2[nn] * tanhf(h) : 0.f;
+    h = lane < m.hidden ? m.w2[hn] * tanhf(h) : 0.f;
     float sc = wave_allreduce_sum(h) + m.b2[0];
     if (m.scoretanh) sc = tanhf(sc);
     if (lane == 0) m.out[b] = sc;
@@ -467,15 +270,35 @@ struct DrmmPoolArgs {
   int32_t* counts_out;
 };
 
+// the softmax gate over the query's terms and the output layer (DRMM.py:97-98, :112-114), in the per-pair kernels' fixed order: term t's
+// gate logit and net output live in lane 16 (t & 3) of register pair [t >> 2]
+template <int QP>
+__device__ __forceinline__ float drmm_gate_sum(const float (&gl)[QP], const float (&z)[QP], int Q) {
+  float mx = lane_bcast(gl[0], 0);
+#pragma unroll
+  for (int t = 1; t < kQT * QP; ++t)
+    if (t < Q) mx = fmaxf(mx, lane_bcast(gl[t >> 2], 16 * (t & 3)));
+  float den = 0.f, num = 0.f;
+#pragma unroll
+  for (int t = 0; t < kQT * QP; ++t)
+    if (t < Q) {
+      const float e = expf(lane_bcast(gl[t >> 2], 16 * (t & 3)) - mx);
+      den += e;
+      num = __builtin_fmaf(e, lane_bcast(z[t >> 2], 16 * (t & 3)), num);
+    }
+  return num / den;
+}
+
 // The general form (more than 32 bins or 16 nodes; otherwise lists_drmm_pool_wave_kernel below): a workgroup per document, a lane per
 // position: 256 consecutive positions per trip, kDrmmTrips trips per pass (ids first, then the 4-byte entries, then the counts).
 // Counts go to one of 16 copies of the histograms (by lane & 15: at most 4 lanes of a wave meet on an address).
 constexpr int kDrmmTrips = 4, kHistCopies = 16;
 
+template <int QP>
 __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
   __shared__ int hist[kQT][kMaxBins];
   __shared__ int hrep[kHistCopies][kQT * kMaxBins + 1];
-  __shared__ float zs[kQT], gs[kQT];
+  __shared__ float zs[kListMaxQ], gs[kListMaxQ];
   int l, doc;
   if (!list_doc_of(a, l, doc) || doc >= g.len[l]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,78 +307,81 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
   const DocWalk dw = doc_walk(a, b, dm);
   const int n = dw.n, n_oov = dm[1];
-  for (int i = tid; i < kHistCopies * (kQT * kMaxBins + 1); i += 256) (&hrep[0][0])[i] = 0;
-  __syncthreads();
   int* myh = hrep[lane & (kHistCopies - 1)];
-  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
-  for (int j0 = 0; j0 < n; j0 += 256 * kDrmmTrips) {
-    int id[kDrmmTrips];
-    load_pass<kDrmmTrips, 256>(dw, j0, tid, id);
-    uint32_t e[kDrmmTrips];
+  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp * QP;
+#pragma unroll 1
+  for (int h = 0; h < QP; ++h) {
+    for (int i = tid; i < kHistCopies * (kQT * kMaxBins + 1); i += 256) (&hrep[0][0])[i] = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256 * kDrmmTrips) {
+      int id[kDrmmTrips];
+      load_pass<kDrmmTrips, 256>(dw, j0, tid, id);
+      uint32_t e[kDrmmTrips];
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u]];        // (entry 0 is never written and never used)
+      for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[(int64_t)id[u] * QP + h];        // (entry 0 is never written and never used)
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
+      for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) {
-      if (id[u] > 0) {
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        if (id[u] > 0) {
 #pragma unroll
-        for (int q = 0; q < kQT; ++q) {
-          if (q < a.Q) {
-            const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
-            if ((int)bin < m.nbins) atomicAdd(&myh[q * kMaxBins + bin], 1);
-            if (by & kBinExact) atomicAdd(&myh[q * kMaxBins + m.nbins], 1);
+          for (int q = 0; q < kQT; ++q) {
+            if (kQT * h + q < a.Q) {
+              const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
+              if ((int)bin < m.nbins) atomicAdd(&myh[q * kMaxBins + bin], 1);
+              if (by & kBinExact) atomicAdd(&myh[q * kMaxBins + m.nbins], 1);
+            }
           }
         }
       }
     }
-  }
-  if (tid == 0 && n_oov > 0) {        // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
-    const int bz = list_bin_of(0.f, m.edges, m.nbins);
-    if (bz < m.nbins)
-      for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&hrep[0][q * kMaxBins + bz], n_oov);
-  }
-  __syncthreads();
-  {
-    int h = 0;
+    if (tid == 0 && n_oov > 0) {        // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
+      const int bz = list_bin_of(0.f, m.edges, m.nbins);
+      if (bz < m.nbins)
+        for (int q = 0; q < kQT && kQT * h + q < a.Q; ++q) atomicAdd(&hrep[0][q * kMaxBins + bz], n_oov);
+    }
+    __syncthreads();
+    {
+      int hs = 0;
 #pragma unroll
-    for (int c = 0; c < kHistCopies; ++c) h += hrep[c][tid];
-    hist[tid >> 6][tid & 63] = h;
-  }
-  // per query term: histogram transform + feed-forward net + gate logit - the tail of drmm.hip
-  // a wave per query term, as the per-pair kernels
-  const int q = wave;
-  if (q < a.Q) {
-    const int64_t qid = qids.q(q);
-    if (lane == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
-    const int* h = hist[q];
-    if (m.counts_out && lane < NB) m.counts_out[((int64_t)b * a.Q + q) * NB + lane] = h[lane];
-    float hv = lane < NB ? (float)(h[lane] + 1) : 0.f;
-    if (m.hist_type == 1) hv = hv / wave_allreduce_sum(hv);
-    else if (m.hist_type == 2) hv = lane < NB ? logf(hv) : 0.f;
-    const float b1v = lane < m.nodes ? m.b1[lane] : 0.f, w2v = lane < m.nodes ? m.w2[lane] : 0.f, b2v = m.b2[0];
-    const float gate0 = m.gate_type == 0 ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
-    float acc = 0.f;
-    for (int n = 0; n < m.nodes; ++n) {
-      const float wv = lane < NB ? m.w1[n * NB + lane] : 0.f;
-      const float sn = wave_allreduce_sum(wv * hv);
-      if (lane == n) acc = sn;
+      for (int c = 0; c < kHistCopies; ++c) hs += hrep[c][tid];
+      hist[tid >> 6][tid & 63] = hs;
     }
-    acc += b1v;
-    const float o = wave_allreduce_sum(lane < m.nodes ? w2v * tanhf(acc) : 0.f) + b2v;
-    float gl;
-    if (m.gate_type == 0) {
-      gl = gate0;
-    } else {
-      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
-      float p = 0.f;
-      for (int c = lane; c < m.D; c += 64) p = __builtin_fmaf(m.gate_w[c], e[c], p);
-      gl = wave_allreduce_sum(p);
+    __syncthreads();
+    // per query term: histogram transform + feed-forward net + gate logit - the tail of drmm.hip; a wave per query term, as the per-pair kernels
+    const int q = kQT * h + wave;
+    if (q < a.Q) {
+      const int64_t qid = qids.q(q);
+      if (lane == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
+      const int* hh = hist[wave];
+      if (m.counts_out && lane < NB) m.counts_out[((int64_t)b * a.Q + q) * NB + lane] = hh[lane];
+      float hv = lane < NB ? (float)(hh[lane] + 1) : 0.f;
+      if (m.hist_type == 1) hv = hv / wave_allreduce_sum(hv);
+      else if (m.hist_type == 2) hv = lane < NB ? logf(hv) : 0.f;
+      const float b1v = lane < m.nodes ? m.b1[lane] : 0.f, w2v = lane < m.nodes ? m.w2[lane] : 0.f, b2v = m.b2[0];
+      const float gate0 = m.gate_type == 0 ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
+      float acc = 0.f;
+      for (int nn = 0; nn < m.nodes; ++nn) {
+        const float wv = lane < NB ? m.w1[nn * NB + lane] : 0.f;
+        const float sn = wave_allreduce_sum(wv * hv);
+        if (lane == nn) acc = sn;
+      }
+      acc += b1v;
+      const float o = wave_allreduce_sum(lane < m.nodes ? w2v * tanhf(acc) : 0.f) + b2v;
+      float gl;
+      if (m.gate_type == 0) {
+        gl = gate0;
+      } else {
+        const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
+        float p = 0.f;
+        for (int c = lane; c < m.D; c += 64) p = __builtin_fmaf(m.gate_w[c], e[c], p);
+        gl = wave_allreduce_sum(p);
+      }
+      if (qid == 0) gl += -1e7f;
+      if (lane == 0) { zs[q] = tanhf(o); gs[q] = gl; }
     }
-    if (qid == 0) gl += -1e7f;
-    if (lane == 0) { zs[q] = tanhf(o); gs[q] = gl; }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
     float mx = gs[0];
     for (int t = 1; t < a.Q; ++t) mx = fmaxf(mx, gs[t]);
@@ -570,151 +396,130 @@ __global__ __launch_bounds__(256) void lists_drmm_pool_kernel(ListsArgs a, ListG
 }
 
 // Up to 32 bins and 16 nodes (the model's defaults: 30 and 5): a WAVE per document, four documents per workgroup, no barrier.  A lane
-// is a position (64 per trip); the counts go to one of 8 copies of the wave's own histograms; then ONE wave does the four terms' tails:
-// row q of the wave (lanes 16 q .. 16 q + 15) stands for the 64 lanes the per-pair tail gives term q - lane j for its lanes j and
-// j + 16 - and reduces as that tail does, (row 0 + row 1) + (row 2 + row 3) with the rows beyond the bins / nodes all zero: the same
+// is a position (64 per trip); the counts go to one of 8 copies of the wave's own histograms; then ONE wave does the block's four
+// terms' tails: row q of the wave (lanes 16 q .. 16 q + 15) stands for the 64 lanes the per-pair tail gives term q - lane j for its lanes
+// j and j + 16 - and reduces as that tail does, (row 0 + row 1) + (row 2 + row 3) with the rows beyond the bins / nodes all zero: the same
 // sums in the same order, bit-identical scores.  (Workgroup per document with a wave per term for the tail: 277 us per 64,000
-// documents, of which the tails 104 and the counting 144; with the single-wave tail 245.)
+// documents, of which the tails 104 and the counting 144; with the single-wave tail 245.)  Queries of five to eight terms: the document
+// is walked once per block of four terms, the gate runs over all of them at the end.
 constexpr int kWaveCopies = 8, kWaveBins = 32, kWaveStride = kQT * kWaveBins + 1;
 
+template <int QP>
 __global__ __launch_bounds__(256) void lists_drmm_pool_wave_kernel(ListsArgs a, ListGeom g, DrmmPoolArgs m) {
   __shared__ int hrep[4][kWaveCopies * kWaveStride];
-  __shared__ __attribute__((aligned(16))) uint32_t hot[kPoolHotBins > 0 ? kPoolHotBins : 4];       // the 4-byte entries of the frequent terms (see the KNRM pooling)
   int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 documents here)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
-  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp;
-  if (kPoolHotBins > 0) {
-    const int nh = a.Vp < kPoolHotBins ? (int)a.Vp : kPoolHotBins;
-    for (int i = tid * 4; i < nh; i += 1024) *reinterpret_cast<uint4*>(&hot[i]) = *reinterpret_cast<const uint4*>(&tab[i]);   // (Vp is a multiple of 1024)
-    __syncthreads();
-  }
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
+  const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.table) + (int64_t)l * a.Vp * QP;
   const int NB = m.nbins + 1;
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);
-  for (int di = 0; di < kPoolDocs; ++di) {
-  const int doc = (dq * kPoolDocs + di) * 4 + wave;
-  if (doc >= g.len[l]) break;
   const int b = g.start[l] + doc;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
   const DocWalk dw = doc_walk(a, b, dm);
   const int n = dw.n, n_oov = dm[1];
   int* H = hrep[wave];
-  for (int i = lane; i < kWaveCopies * kWaveStride; i += 64) H[i] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
   int* myh = H + (lane & (kWaveCopies - 1)) * kWaveStride;
-  for (int j0 = 0; j0 < n; j0 += 64 * kDrmmTrips) {
-    int id[kDrmmTrips];
-    load_pass<kDrmmTrips, 64>(dw, j0, lane, id);
-    uint32_t e[kDrmmTrips];
-    if (kPoolHotBins > 0) {
-      uint32_t eg[kDrmmTrips], el[kDrmmTrips];
+  float zv[QP], glv[QP];
 #pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) eg[u] = tab[id[u] >= kPoolHotBins ? id[u] : 0];
+  for (int h = 0; h < QP; ++h) {
+    for (int i = lane; i < kWaveCopies * kWaveStride; i += 64) H[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
+    for (int j0 = 0; j0 < n; j0 += 64 * kDrmmTrips) {
+      int id[kDrmmTrips];
+      load_pass<kDrmmTrips, 64>(dw, j0, lane, id);
+      uint32_t e[kDrmmTrips];
 #pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) el[u] = hot[id[u] < kPoolHotBins ? id[u] : 0];
+      for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[(int64_t)id[u] * QP + h];        // (entry 0 is never written and never used)
 #pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) e[u] = id[u] >= kPoolHotBins ? eg[u] : el[u];
-    } else {
+      for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
 #pragma unroll
-      for (int u = 0; u < kDrmmTrips; ++u) e[u] = tab[id[u]];        // (entry 0 is never written and never used)
-    }
+      for (int u = 0; u < kDrmmTrips; ++u) {
+        if (id[u] > 0) {
 #pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) asm volatile("" : "+v"(e[u]));      // (pinned: see the KNRM pooling)
-#pragma unroll
-    for (int u = 0; u < kDrmmTrips; ++u) {
-      if (id[u] > 0) {
-#pragma unroll
-        for (int q = 0; q < kQT; ++q) {
-          if (q < a.Q) {
-            const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
-            if ((int)bin < m.nbins) atomicAdd(&myh[q * kWaveBins + bin], 1);
-            if (by & kBinExact) atomicAdd(&myh[q * kWaveBins + m.nbins], 1);
+          for (int q = 0; q < kQT; ++q) {
+            if (kQT * h + q < a.Q) {
+              const unsigned by = (e[u] >> (8 * q)) & 0xffu, bin = by & 0x7fu;
+              if ((int)bin < m.nbins) atomicAdd(&myh[q * kWaveBins + bin], 1);
+              if (by & kBinExact) atomicAdd(&myh[q * kWaveBins + m.nbins], 1);
+            }
           }
         }
       }
     }
-  }
-  if (lane == 0 && n_oov > 0) {       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
-    const int bz = list_bin_of(0.f, m.edges, m.nbins);
-    if (bz < m.nbins)
-      for (int q = 0; q < a.Q && q < kQT; ++q) atomicAdd(&H[q * kWaveBins + bz], n_oov);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  {
-    const int q = lane >> 4, j = lane & 15;
-    const bool on = q < a.Q;
-    const int64_t qid = on ? qids.q(q) : 0;
-    if (on && j == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
-    const bool ina = j < NB, inb = j + 16 < NB;
-    int ha = 0, hb = 0;
+    if (lane == 0 && n_oov > 0) {       // an OOV document term: similarity exactly 0 (DRMM cannot take OOV query terms: no exact match to find)
+      const int bz = list_bin_of(0.f, m.edges, m.nbins);
+      if (bz < m.nbins)
+        for (int q = 0; q < kQT && kQT * h + q < a.Q; ++q) atomicAdd(&H[q * kWaveBins + bz], n_oov);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {
+      const int q = lane >> 4, j = lane & 15, qq = kQT * h + q;
+      const bool on = qq < a.Q;
+      const int64_t qid = on ? qids.q(qq) : 0;
+      if (on && j == 0 && qid < 0) atomicOr(a.status, kErrQueryOOV);
+      const bool ina = j < NB, inb = j + 16 < NB;
+      int ha = 0, hb = 0;
 #pragma unroll
-    for (int c = 0; c < kWaveCopies; ++c) {
-      ha += H[c * kWaveStride + q * kWaveBins + j];
-      hb += H[c * kWaveStride + q * kWaveBins + j + 16];
-    }
-    if (m.counts_out && on) {
-      int32_t* co = m.counts_out + ((int64_t)b * a.Q + q) * NB;
-      if (ina) co[j] = ha;
-      if (inb) co[j + 16] = hb;
-    }
-    float va = ina ? (float)(ha + 1) : 0.f, vb = inb ? (float)(hb + 1) : 0.f;
-    if (m.hist_type == 1) {
-      const float tot = group_allreduce(unfused(va)) + group_allreduce(unfused(vb));
-      va = va / tot;
-      vb = vb / tot;
-    } else if (m.hist_type == 2) {
-      va = ina ? logf(va) : 0.f;
-      vb = inb ? logf(vb) : 0.f;
-    }
-    float acc = 0.f;
-    for (int n = 0; n < m.nodes; ++n) {
-      const float wa = ina ? m.w1[n * NB + j] : 0.f, wb = inb ? m.w1[n * NB + j + 16] : 0.f;
-      const float sn = group_allreduce(unfused(wa * va)) + group_allreduce(unfused(wb * vb));
-      if (j == n) acc = sn;
-    }
-    acc += j < m.nodes ? m.b1[j] : 0.f;
-    const float o = group_allreduce(unfused(j < m.nodes ? m.w2[j] * tanhf(acc) : 0.f)) + m.b2[0];
-    float gl;
-    if (m.gate_type == 0) {
-      gl = on ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + q] : 0.f;
-    } else {
-      const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
-      float p[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] = 0.f;
-        for (int c = j + 16 * r; c < m.D; c += 64) p[r] = __builtin_fmaf(m.gate_w[c], e[c], p[r]);
-        p[r] = group_allreduce(unfused(p[r]));
+      for (int c = 0; c < kWaveCopies; ++c) {
+        ha += H[c * kWaveStride + q * kWaveBins + j];
+        hb += H[c * kWaveStride + q * kWaveBins + j + 16];
       }
-      gl = (p[0] + p[1]) + (p[2] + p[3]);
-    }
-    if (qid == 0) gl += -1e7f;
-    const float z = tanhf(o);
-    float mx = lane_bcast(gl, 0);
-    for (int t = 1; t < a.Q && t < kQT; ++t) mx = fmaxf(mx, lane_bcast(gl, 16 * t));
-    float den = 0.f, num = 0.f;
-#pragma unroll
-    for (int t = 0; t < kQT; ++t) {
-      if (t < a.Q) {
-        const float e = expf(lane_bcast(gl, 16 * t) - mx);
-        den += e;
-        num = __builtin_fmaf(e, lane_bcast(z, 16 * t), num);
+      if (m.counts_out && on) {
+        int32_t* co = m.counts_out + ((int64_t)b * a.Q + qq) * NB;
+        if (ina) co[j] = ha;
+        if (inb) co[j + 16] = hb;
       }
+      float va = ina ? (float)(ha + 1) : 0.f, vb = inb ? (float)(hb + 1) : 0.f;
+      if (m.hist_type == 1) {
+        const float tot = group_allreduce(unfused(va)) + group_allreduce(unfused(vb));
+        va = va / tot;
+        vb = vb / tot;
+      } else if (m.hist_type == 2) {
+        va = ina ? logf(va) : 0.f;
+        vb = inb ? logf(vb) : 0.f;
+      }
+      float acc = 0.f;
+      for (int nn = 0; nn < m.nodes; ++nn) {
+        const float wa = ina ? m.w1[nn * NB + j] : 0.f, wb = inb ? m.w1[nn * NB + j + 16] : 0.f;
+        const float sn = group_allreduce(unfused(wa * va)) + group_allreduce(unfused(wb * vb));
+        if (j == nn) acc = sn;
+      }
+      acc += j < m.nodes ? m.b1[j] : 0.f;
+      const float o = group_allreduce(unfused(j < m.nodes ? m.w2[j] * tanhf(acc) : 0.f)) + m.b2[0];
+      float gl;
+      if (m.gate_type == 0) {
+        gl = on ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + qq] : 0.f;
+      } else {
+        const float* e = m.emb_raw + (qid > 0 && qid < a.V ? qid : 0) * m.ld;
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = 0.f;
+          for (int c = j + 16 * r; c < m.D; c += 64) p[r] = __builtin_fmaf(m.gate_w[c], e[c], p[r]);
+          p[r] = group_allreduce(unfused(p[r]));
+        }
+        gl = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      if (qid == 0) gl += -1e7f;
+      zv[h] = tanhf(o);
+      glv[h] = gl;
     }
-    if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's histograms are cleared for the next block)
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's histograms are cleared for its next document)
-  }   // documents of this wave
+  const float agg = drmm_gate_sum<QP>(glv, zv, a.Q);
+  if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], agg, m.out_b[0]);
 }
 
 // ---- 3c: DRMM-TKS pooling -------------------------------------------------------------------------------------------------------
-//   The KNRM form of the sims pass (four floats per term), then per document the top-k similarities of
-// every query term over ALL positions (reference DRMMTKS.py:55-56; pads and unmatched OOV terms contribute their 0, OOV exact matches
-// their 1) -> Linear(k, 1) + tanh -> idf gate -> output layer, as drmmtks.hip.  A wave per document, a lane per (position slot, query
-// term) as in the KNRM pooling: every lane keeps a sorted top-KT of the similarities it meets (sorted_insert: one v_med3_f32 per element),
-// the 16 lists of a row are merged in k rounds of a row-wide maximum over the list heads (LDS) and the closed-form candidates.  The
-// values are selections of bit-identical similarities and enter the Linear in the same order: the scores equal capamd_drmmtks_forward's.
+//   The KNRM form of the sims pass (four floats per term and block), then per document the top-k
+// similarities of every query term over ALL positions (reference DRMMTKS.py:55-56; pads and unmatched OOV terms contribute their 0, OOV
+// exact matches their 1) -> Linear(k, 1) + tanh -> idf gate -> output layer, as drmmtks.hip.  A wave per document, a lane per (position
+// slot, query term) as in the KNRM pooling's four-term form: every lane keeps a sorted top-KT of the similarities it meets (sorted_insert:
+// one v_med3_f32 per element), the 16 lists of a row are merged in k rounds of a row-wide maximum over the list heads (LDS) and the
+// closed-form candidates.  The values are selections of bit-identical similarities and enter the Linear in the same order: the scores
+// equal capamd_drmmtks_forward's.
 struct TksPoolArgs {
   const float* idf;      // [B, Q] or the query table's [NQ, Q] in indexed mode
   int topk;
@@ -735,106 +540,82 @@ __device__ __forceinline__ float group_allreduce_max(float v) {
   return v;
 }
 
-template <int KT>
+template <int KT, int QP>
 __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGeom g, TksPoolArgs m) {
   __shared__ float heads[4][KT][64];        // [wave][list entry][lane]
-  __shared__ __attribute__((aligned(16))) float4 hot[kPoolHot > 0 ? kPoolHot : 1];       // the frequent terms' entries (see the KNRM pooling)
   int l, dq;
-  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 * kPoolDocs documents here)
+  if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 documents here)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane >> 4, ps = lane & 15;
-  if (dq * 4 * kPoolDocs >= g.len[l]) return;     // (workgroup-uniform)
-  if (kPoolHot > 0) {
-    const float4* src = a.table + (int64_t)l * a.Vp;
-    const int nh = a.Vp < kPoolHot ? (int)a.Vp : kPoolHot;
-    for (int i = tid; i < nh; i += 256) hot[i] = src[i];
-    __syncthreads();
-  }
-  const float* hotf = reinterpret_cast<const float*>(hot) + t;
+  const int doc = dq * 4 + wave;
+  if (doc >= g.len[l]) return;
   const int K = m.topk;
   const PairIds qids = pair_ids(a.ids, g.start[l], a.Q, a.L);   // (the list's query: its first pair's row)
-  int64_t qid = t < a.Q ? qids.q(t) : 0;
-  if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
   const float ffw_l = lane < K ? m.ffw_w[lane] : 0.f;
-  const float gl0 = t < a.Q ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + t] : 0.f;
-  const float* tab = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp) + t;
-  for (int di = 0; di < kPoolDocs; ++di) {
-  const int doc = (dq * kPoolDocs + di) * 4 + wave;
-  if (doc >= g.len[l]) break;
+  const float* tabl = reinterpret_cast<const float*>(a.table + (int64_t)l * a.Vp * QP);
   const int b = g.start[l] + doc;
   const int32_t* dm = a.meta + (int64_t)b * kDocMeta;
   const DocWalk dw = doc_walk(a, b, dm);
-  const int n = dw.n, n_real_doc = dm[0], n_one_t = t < kQT ? dm[2 + t] : 0;
-  float top[KT];
+  const int n = dw.n, n_real_doc = dm[0];
+  float zv[QP], glv[QP];
 #pragma unroll
-  for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
-  for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
-    int id[kWaveTrips];
-    load_pass<kWaveTrips, 16>(dw, j0, ps, id);
-    float s[kWaveTrips];
-    if (kPoolHot > 0) {
-      float sg[kWaveTrips], sl[kWaveTrips];
+  for (int h = 0; h < QP; ++h) {
+    const int tq = kQT * h + t;
+    int64_t qid = tq < a.Q ? qids.q(tq) : 0;
+    if (qid >= a.V) qid = 0;                // (flagged by the sims pass)
+    const float gl0 = tq < a.Q ? m.gate_w[0] * m.idf[(int64_t)qids.qrow * a.Q + tq] : 0.f;
+    const float* tab = tabl + 4 * h + t;
+    const int n_one_t = doc_n_one(dm, tq);
+    float top[KT];
 #pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) sg[u] = tab[(int64_t)(id[u] >= kPoolHot ? id[u] : 0) * 4];
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) sl[u] = hotf[(id[u] < kPoolHot ? id[u] : 0) * 4];
-#pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = id[u] >= kPoolHot ? sg[u] : sl[u];
-    } else {
+    for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
+      int id[kWaveTrips];
+      load_pass<kWaveTrips, 16>(dw, j0, ps, id);
+      float s[kWaveTrips];
 #pragma unroll
 #ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * 4];
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * (4 * QP)];
 #else
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * 4];     // (entry 0 is never written and never used)
+      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * (4 * QP)];     // (entry 0 is never written and never used)
 #endif
-    }
-    // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
+      // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
+      for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
-    for (int u = 0; u < kWaveTrips; ++u) {
-      if (j0 + u * 16 >= n) continue;          // (wave-uniform)
-      if (id[u] > 0) sorted_insert<KT>(top, s[u]);
+      for (int u = 0; u < kWaveTrips; ++u) {
+        if (j0 + u * 16 >= n) continue;          // (wave-uniform)
+        if (id[u] > 0) sorted_insert<KT>(top, s[u]);
+      }
     }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) heads[wave][i][lane] = top[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
+    const int no = n_one_t, nz = a.L - n_real_doc - no;         // nz: pads and OOV terms without a match: similarity 0
+    int head = 0, used1 = 0, used0 = 0;
+    float acc = m.ffw_b[0];
+    for (int r = 0; r < K; ++r) {
+      const float cand = head < KT ? heads[wave][head][lane] : -INFINITY;
+      const float from_lists = group_allreduce_max(cand);
+      const float c1 = used1 < no ? 1.f : -INFINITY, c0 = used0 < nz ? 0.f : -INFINITY;
+      const float best = fmaxf(from_lists, fmaxf(c1, c0));
+      const unsigned row = (unsigned)(__ballot(cand == best && best > -INFINITY) >> (16 * t)) & 0xffffu;
+      if (row) {
+        if (ps == __ffs((int)row) - 1) ++head;          // one list of the row advances
+      } else if (c1 == best) {
+        ++used1;
+      } else {
+        ++used0;
+      }
+      if (best > -INFINITY) acc = __builtin_fmaf(lane_bcast(ffw_l, r), best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
+    }
+    float gl = gl0;
+    if (qid == 0) gl += -1e7f;   // DRMMTKS.py:38
+    zv[h] = tanhf(acc);
+    glv[h] = gl;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's list heads are rewritten by the next block)
   }
-#pragma unroll
-  for (int i = 0; i < KT; ++i) heads[wave][i][lane] = top[i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: LDS program order is the synchronisation)
-  const int no = n_one_t, nreal = n_real_doc;
-  const int nz = a.L - nreal - no;          // pads and OOV terms without a match: similarity 0
-  int head = 0, used1 = 0, used0 = 0;
-  float acc = m.ffw_b[0];
-  for (int r = 0; r < K; ++r) {
-    const float cand = head < KT ? heads[wave][head][lane] : -INFINITY;
-    const float from_lists = group_allreduce_max(cand);
-    const float c1 = used1 < no ? 1.f : -INFINITY, c0 = used0 < nz ? 0.f : -INFINITY;
-    const float best = fmaxf(from_lists, fmaxf(c1, c0));
-    const unsigned row = (unsigned)(__ballot(cand == best && best > -INFINITY) >> (16 * t)) & 0xffffu;
-    if (row) {
-      if (ps == __ffs((int)row) - 1) ++head;          // one list of the row advances
-    } else if (c1 == best) {
-      ++used1;
-    } else {
-      ++used0;
-    }
-    if (best > -INFINITY) acc = __builtin_fmaf(lane_bcast(ffw_l, r), best, acc);   // DRMMTKS.py:22: Linear(topk, 1) on the sorted values
-  }
-  const float z = tanhf(acc);
-  float gl = gl0;
-  if (qid == 0) gl += -1e7f;   // DRMMTKS.py:38
-  float mx = lane_bcast(gl, 0);
-  for (int q = 1; q < a.Q && q < kQT; ++q) mx = fmaxf(mx, lane_bcast(gl, 16 * q));
-  float den = 0.f, num = 0.f;
-#pragma unroll
-  for (int q = 0; q < kQT; ++q) {
-    if (q < a.Q) {
-      const float e = expf(lane_bcast(gl, 16 * q) - mx);
-      den += e;
-      num = __builtin_fmaf(e, lane_bcast(z, 16 * q), num);
-    }
-  }
-  if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], num / den, m.out_b[0]);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the wave's list heads are rewritten by its next document)
-  }   // documents of this wave
+  const float agg = drmm_gate_sum<QP>(glv, zv, a.Q);
+  if (lane == 0) m.out[b] = __builtin_fmaf(m.out_w[0], agg, m.out_b[0]);
 }
 
 }  // namespace
@@ -863,10 +644,14 @@ extern "C" int capamd_debug_lists_timing_read(double* ms) {
 }
 #endif
 
-extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L) {
-  if (n_lists < 1 || V < 1 || n_pairs < 0 || L < 1) return 0;
+extern "C" size_t capamd_lists_workspace_bytes_q(int n_lists, int64_t V, int64_t n_pairs, int L, int Q) {
+  if (n_lists < 1 || V < 1 || n_pairs < 0 || L < 1 || Q < 1 || Q > kListMaxQ) return 0;
   const int n = n_lists < kListChunk ? n_lists : kListChunk;
-  return lists_pair_bytes(n_pairs, L) + (size_t)n * ((size_t)lists_vp(V) * 17 + kListQueryBytes) + kListConstBytes;
+  return lists_pair_bytes(n_pairs, L) + (size_t)n * lists_per_list_bytes(lists_vp(V), (Q + kQT - 1) / kQT) + kListConstBytes;
+}
+
+extern "C" size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L) {
+  return capamd_lists_workspace_bytes_q(n_lists, V, n_pairs, L, kQT);
 }
 
 extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,
@@ -881,15 +666,18 @@ extern "C" int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const KnrmPoolArgs m{mu, sigma, K, w1, b1, hidden, w2, b2, scoretanh, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K, true, nullptr,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, mu, sigma, K, true, nullptr, kListMaxQ,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
-                     aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
-                     const bool narrow = CAPAMD_POOL_NARROW && kPoolHot == 0 && kPoolDocs == 1;
-                     if (narrow && K == 11) hipLaunchKernelGGL(lists_knrm_pool_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
-                     else if (narrow) hipLaunchKernelGGL(lists_knrm_pool_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
-                     else if (K == 11) hipLaunchKernelGGL(lists_knrm_pool_wide_kernel<11>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
-                     else hipLaunchKernelGGL(lists_knrm_pool_wide_kernel<kMaxK>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                     const dim3 grid = list_doc_grid(nl, aq.longest);
+                     if (a.QP == 1) {
+                       if (K == 11) hipLaunchKernelGGL((lists_knrm_pool_kernel<11, 1>), grid, dim3(256), 0, s, aq, g, m);
+                       else hipLaunchKernelGGL((lists_knrm_pool_kernel<kMaxK, 1>), grid, dim3(256), 0, s, aq, g, m);
+                     } else {
+                       if (K == 11) hipLaunchKernelGGL((lists_knrm_pool_kernel<11, 2>), grid, dim3(256), 0, s, aq, g, m);
+                       else hipLaunchKernelGGL((lists_knrm_pool_kernel<kMaxK, 2>), grid, dim3(256), 0, s, aq, g, m);
+                     }
                    });
 }
 
@@ -910,13 +698,17 @@ extern "C" int capamd_drmm_forward_lists(const int64_t* q_ids, const int64_t* d_
   hipStream_t s = (hipStream_t)stream;
   return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, edges, nbins, nullptr, nullptr, 0, true,
                    gate_type == 0 ? idf : nullptr,      // (the term-vector gate never reads an idf row)
+                   kListMaxQ,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      if (nbins + 1 <= kWaveBins && nodes <= 16) {
                        ListsArgs aq = a;
-                       aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
-                       hipLaunchKernelGGL(lists_drmm_pool_wave_kernel, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                       aq.longest = (longest + 3) / 4;       // four documents per workgroup
+                       if (a.QP == 1) hipLaunchKernelGGL(lists_drmm_pool_wave_kernel<1>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                       else hipLaunchKernelGGL(lists_drmm_pool_wave_kernel<2>, list_doc_grid(nl, aq.longest), dim3(256), 0, s, aq, g, m);
+                     } else if (a.QP == 1) {
+                       hipLaunchKernelGGL(lists_drmm_pool_kernel<1>, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
                      } else {
-                       hipLaunchKernelGGL(lists_drmm_pool_kernel, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
+                       hipLaunchKernelGGL(lists_drmm_pool_kernel<2>, list_doc_grid(nl, longest), dim3(256), 0, s, a, g, m);
                      }
                    });
 }
@@ -933,14 +725,17 @@ extern "C" int capamd_drmmtks_forward_lists(const int64_t* q_ids, const int64_t*
   const IdSource ids = indexed ? IdSource{nullptr, nullptr, q_table, d_table, pair_q, pair_d} : IdSource{q_ids, d_ids, nullptr, nullptr, nullptr, nullptr};
   const TksPoolArgs m{idf, topk, gate_w, ffw_w, ffw_b, out_w, out_b, out};
   hipStream_t s = (hipStream_t)stream;
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, true, idf,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, true, idf, kListMaxQ,
                    [&](const ListsArgs& a, const ListGeom& g, int nl, int longest) {
                      ListsArgs aq = a;
-                     aq.longest = (longest + 4 * kPoolDocs - 1) / (4 * kPoolDocs);       // 4 * kPoolDocs documents per workgroup
+                     aq.longest = (longest + 3) / 4;       // four documents per workgroup
                      const dim3 grid = list_doc_grid(nl, aq.longest);
-                     if (topk <= 4) hipLaunchKernelGGL(lists_tks_pool_kernel<4>, grid, dim3(256), 0, s, aq, g, m);
-                     else if (topk <= 8) hipLaunchKernelGGL(lists_tks_pool_kernel<8>, grid, dim3(256), 0, s, aq, g, m);
-                     else if (topk <= 12) hipLaunchKernelGGL(lists_tks_pool_kernel<12>, grid, dim3(256), 0, s, aq, g, m);
-                     else hipLaunchKernelGGL(lists_tks_pool_kernel<16>, grid, dim3(256), 0, s, aq, g, m);
+#define CAPAMD_TKS(QP_)                                                                                         \
+  if (topk <= 4) hipLaunchKernelGGL((lists_tks_pool_kernel<4, QP_>), grid, dim3(256), 0, s, aq, g, m);          \
+  else if (topk <= 8) hipLaunchKernelGGL((lists_tks_pool_kernel<8, QP_>), grid, dim3(256), 0, s, aq, g, m);     \
+  else if (topk <= 12) hipLaunchKernelGGL((lists_tks_pool_kernel<12, QP_>), grid, dim3(256), 0, s, aq, g, m);   \
+  else hipLaunchKernelGGL((lists_tks_pool_kernel<16, QP_>), grid, dim3(256), 0, s, aq, g, m)
+                     if (a.QP == 1) { CAPAMD_TKS(1); } else { CAPAMD_TKS(2); }
+#undef CAPAMD_TKS
                    });
 }

@@ -1127,7 +1127,7 @@ extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d
       workspace_bytes = at;
     }
   }
-  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, false, nullptr,
+  return lists_run(ids, list_offsets_host, n_lists, Q, L, packed, V, D, status, workspace, workspace_bytes, s, nullptr, 0, nullptr, nullptr, 0, false, nullptr, kQT,
                    [&](const ListsArgs& la, const ListGeom& g, int nl, int longest) {
 #define LAUNCH_L(NV_)                                                                                                           \
   do {                                                                                                                          \

@@ -490,14 +490,17 @@ _list_workspaces = {}
 # V = 4 M - 64 lists would be 4.3 GB, the 256 a launch group takes 17 GB): fewer lists are kept in flight when it would be exceeded (the library then works through the
 # lists in more, smaller groups).  The per-pair part (4 L + 32 bytes per pair of the call) comes on top.
 LISTS_WORKSPACE_BUDGET = 2 << 30
+LISTS_MAX_QLEN = 8          # query terms a whole-list call takes (csrc/lists.cuh: kListMaxQ; PACRR: 4)
 
 
-def _lists_workspace(device, n_lists, V, n_pairs, L):
+def _lists_workspace(device, n_lists, V, n_pairs, L, Q=4):
     lib = _lib.load()
-    one = int(lib.capamd_lists_workspace_bytes(1, int(V), 0, int(L)))
-    per_list = int(lib.capamd_lists_workspace_bytes(2, int(V), 0, int(L))) - one
+    one = int(lib.capamd_lists_workspace_bytes_q(1, int(V), 0, int(L), int(Q)))
+    per_list = int(lib.capamd_lists_workspace_bytes_q(2, int(V), 0, int(L), int(Q))) - one
     in_flight = max(1, min(int(n_lists), LISTS_WORKSPACE_BUDGET // max(per_list, 1)))
-    nbytes = int(lib.capamd_lists_workspace_bytes(in_flight, int(V), int(n_pairs), int(L)))
+    nbytes = int(lib.capamd_lists_workspace_bytes_q(in_flight, int(V), int(n_pairs), int(L), int(Q)))
+    if nbytes == 0:
+        raise ValueError(f"whole-list scoring takes queries of up to {LISTS_MAX_QLEN} terms, got {Q}")
     key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
     ws = _list_workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -541,7 +544,7 @@ def knrm_forward_lists(offsets, packed, V, D, mu, sigma, w1, b1, w2=None, b2=Non
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
     hidden = 0 if w2 is None else w1.shape[0]
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L, Q)
     rc = _lib.load().capamd_knrm_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D, _ptr(mu),
         _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), hidden, _ptr(w2), _ptr(b2), int(bool(scoretanh)), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())
@@ -563,7 +566,7 @@ def drmm_forward_lists(offsets, idf, packed, V, D, edges, hist_type, gate_type, 
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
     ld = emb_raw.stride(0) if emb_raw is not None else 0
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L, Q)
     rc = _lib.load().capamd_drmm_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         _ptr(edges), edges.numel(), HIST_TYPES[hist_type], GATE_TYPES[gate_type], _ptr(gate_w), _ptr(emb_raw), ld, _ptr(w1), _ptr(b1), w1.shape[0],
@@ -984,7 +987,7 @@ def drmmtks_forward_lists(offsets, idf, packed, V, D, topk, gate_w, ffw_w, ffw_b
     idf = _f32(idf)
     if out is None:
         out = torch.empty(B, dtype=torch.float32, device=dev)
-    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L)
+    st, ws = status_word(dev), _lists_workspace(dev, off.size - 1, V, B, L, Q)
     rc = _lib.load().capamd_drmmtks_forward_lists(
         _ptr(q), _ptr(d), _ptr(qt), _ptr(dt), _ptr(pq), _ptr(pd), _ptr(idf), ctypes.c_void_p(off.ctypes.data), off.size - 1, Q, L, _ptr(packed), V, D,
         int(topk), _ptr(gate_w), _ptr(ffw_w), _ptr(ffw_b), _ptr(out_w), _ptr(out_b), _ptr(out), _ptr(st.t), _ptr(ws), ws.numel(), _stream())

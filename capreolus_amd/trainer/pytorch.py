@@ -620,7 +620,8 @@ class PytorchTrainer:
         # query are then the same bits whether it was scored alone, in a 64-query run, or on rank 5 of 8.
         worth_it = len(counts) >= 2 and n >= 8 * len(counts)
         with torch.no_grad():
-            if as_lists and len(counts) >= 1 and n >= 1 and (worth_it or not exact) and getattr(reranker, "supports_lists", False) and store.q_table.shape[1] <= 4:
+            if as_lists and len(counts) >= 1 and n >= 1 and (worth_it or not exact) and getattr(reranker, "supports_lists", False) and \
+                    store.q_table.shape[1] <= getattr(reranker, "lists_max_qlen", 4):
                 if offsets is None:
                     offsets = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
                 offsets = np.asarray(offsets, dtype=np.int64)

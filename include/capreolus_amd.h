@@ -178,16 +178,20 @@ int capamd_drmm_forward_indexed(const int32_t* q_table, const int32_t* d_table, 
  * entries) and is scored against the query of its FIRST pair (and, DRMM, that pair's idf row); a pair whose own query (idf) row differs
  * sets CAPAMD_STATUS_LIST_QUERY - the scores of such a call are those of the first pair's query, not the reference's.  Ids either as [B,Q] / [B,L] int64
  * (q_ids, d_ids; the table arguments NULL) or through a candidate store (q_table, d_table, pair_q, pair_d; q_ids / d_ids NULL).
- * Q <= 4; the other limits as the per-pair entries.  workspace: capamd_lists_workspace_bytes(n_lists, V, n_pairs, L) bytes (16-byte aligned;
- * any contents), in two parts:
- *   per PAIR of the call   4 x L + 32 bytes: the document's real term ids, compacted to int32 by the first pass (what the pooling pass reads
+ * Q <= 8 (two blocks of four query terms; the reference's `maxqlen` is a free ConfigOption, extractor/embedtext.py:28-31, its forwards
+ * take any Q: reranker/KNRM.py:39-55, DRMM.py:101-116; capamd_pacrr_forward_lists: Q <= 4); the other limits as the per-pair entries.
+ * workspace: capamd_lists_workspace_bytes_q(n_lists, V, n_pairs, L, Q) bytes (16-byte aligned; any contents;
+ * capamd_lists_workspace_bytes(...) = the same for Q <= 4), in two parts:
+ *   per PAIR of the call   4 x L + 48 bytes: the document's real term ids, compacted to int32 by the first pass (what the pooling pass reads
  *                          instead of the [L] id row), and its pad / OOV counts - 3.2 KB per pair at L = 800 (capamd_pacrr_forward_lists keeps
  *                          416 B of features per pair there and runs its combine layers in one pass behind the convolutions; with n_pairs = 0
  *                          - no such room - every pair's combine layers run inside its convolution workgroup: same scores, slower)
- *   per LIST in flight     17 B x V + 5 KB (a 16-byte table entry and a flag byte per vocabulary id): 6.8 MB at V = 400,001, 68 MB at V = 4 M;
+ *   per LIST in flight     17 B x V + 5 KB (a 16-byte table entry and a flag byte per vocabulary id): 6.8 MB at V = 400,001, 68 MB at V = 4 M
+ *                          (queries of five to eight terms: a second 16-byte entry per id and a second 5 KB: 33 B x V + 10 KB);
  *                          at most 256 lists are in flight at a time - FEWER when the buffer is smaller (a caller bounds the workspace by
  *                          handing in less: the lists are then processed in more, smaller groups; CAPAMD_ERR_WORKSPACE below one list). */
 size_t capamd_lists_workspace_bytes(int n_lists, int64_t V, int64_t n_pairs, int L);
+size_t capamd_lists_workspace_bytes_q(int n_lists, int64_t V, int64_t n_pairs, int L, int Q);
 int capamd_knrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table, const int32_t* pair_q,
                               const int32_t* pair_d, const int64_t* list_offsets_host, int n_lists, int Q, int L, const float* packed, int64_t V,
                               int D, const float* mu, const float* sigma, int K, const float* w1, const float* b1, int hidden, const float* w2,

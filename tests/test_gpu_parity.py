@@ -2554,13 +2554,16 @@ def test_knrm_lists_match_the_per_pair_kernels():
     with torch.no_grad():
         via_store = r.test_resident_lists(store, pq, pd, off).cpu().numpy()
     assert np.array_equal(via_store, lists)
-    # error behaviour: an id beyond the table is flagged, more than four query terms are refused
+    # error behaviour: an id beyond the table is flagged, more than eight query terms are refused (eight are two blocks of four)
     bad = {k: v.clone() for k, v in d.items()}
     bad["posdoc"][2, 1] = V + 5
     with pytest.raises(IndexError):
         r.test_lists(bad, off)
-    with pytest.raises(EngineError):
-        r.test_lists({**d, "query": torch.cat([d["query"], d["query"]], dim=1)}, off)
+    eight = {**d, "query": torch.cat([d["query"], d["query"]], dim=1)}
+    with torch.no_grad():
+        assert np.abs(r.test_lists(eight, off).cpu().numpy() - r.test(eight).cpu().numpy()).max() <= 2e-5 * scale
+    with pytest.raises((EngineError, ValueError)):
+        r.test_lists({**d, "query": torch.cat([d["query"]] * 3, dim=1)}, off)
 
 
 @pytest.mark.parametrize("kind", ["knrm", "drmm", "drmmtks", "pacrr"])
@@ -2684,8 +2687,8 @@ def test_knrm_lists_with_other_kernel_banks(K):
         assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (K, hidden, np.abs(lists - pairwise).max(), scale)
 
 
-@pytest.mark.parametrize("kind", ["knrm", "drmm", "drmmtks", "pacrr"])
-def test_full_size_list_properties(kind):
+@pytest.mark.parametrize("kind,Q", [("knrm", 4), ("drmm", 4), ("drmmtks", 4), ("pacrr", 4), ("knrm", 8), ("drmm", 6), ("drmmtks", 5), ("knrm", 5)])
+def test_full_size_list_properties(kind, Q):
     """The list route at BASELINE.json's geometry (vocabulary 400,001 x 300, 800-term documents, 16 queries x 1000 candidates): a
     document's score does not depend on where it stands in its list or on how the query's documents are cut into lists (both bit for
     bit: the table of a (query, term) pair holds the same four similarities whichever list computes it, and a document is pooled alone),
@@ -2697,11 +2700,11 @@ def test_full_size_list_properties(kind):
     g.manual_seed(0)
     emb = torch.randn((V, D), generator=g, device=DEV) * 0.4
     emb[0] = 0
-    batch = synthetic.make_candidate_list_torch(NQ, ND, V, DEV, seed=5)
+    batch = synthetic.make_candidate_list_torch(NQ, ND, V, DEV, seed=5, maxqlen=Q)
     if kind != "knrm":
         batch = {**batch, "query": batch["query"].clamp(min=0)}
     torch.manual_seed(1)
-    ext = SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32), config={"maxqlen": 4}, pad=0)
+    ext = SimpleNamespace(embeddings=np.zeros((2, 300), dtype=np.float32), config={"maxqlen": Q}, pad=0)
     r = {"knrm": KNRM, "drmm": DRMM, "drmmtks": DRMMTKS, "pacrr": PACRR}[kind]({}, ext)
     m = r.build_model().to(DEV).eval()
     m.embedding = torch.nn.Embedding.from_pretrained(emb, freeze=True)
@@ -2778,7 +2781,7 @@ def test_pacrr_lists_are_bit_identical_to_the_per_pair_kernel(cfg):
     b, off = _lists_batch(len(docs), docs, V, 41)
     b["posdoc"][7] = 0
     b["posdoc"][9, 3] = b["query"][9, 0] if b["query"][9, 0] < 0 else -4
-    r = PACRR(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": 4}, pad=0))
+    r = PACRR(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
     torch.manual_seed(4)
     r.build_model().to(DEV).eval()
     assert r.supports_lists
@@ -2804,11 +2807,15 @@ def test_pacrr_lists_are_bit_identical_to_the_per_pair_kernel(cfg):
     (100, 1, 130, 1500, [9] * 11),                      # one query term; more than 8 lists (the XCD-aware numbering)
     (200, 4, 1000, 2100, [2, 300]),                     # documents longer than the benchmark's; ids beyond one 1024-id block
     (300, 2, 64, 1030, [3] * 70),                       # more lists than one launch group holds (64)
+    (300, 5, 200, 2500, [30, 7, 120]),                  # five query terms: a second block of ONE term (`maxqlen` is a free option)
+    (100, 6, 90, 1200, [11] * 9),                       # six terms, more than 8 lists
+    (300, 8, 800, 3000, [250, 40]),                     # eight terms at the benchmark's document length
+    (50, 7, 33, 600, [1, 2, 3, 50]),                    # seven terms, single-document lists
 ])
 def test_lists_random_geometries(D, Q, L, V, docs):
-    """The list route over the shapes the per-pair sweep covers: embedding widths of 1-5 float4 chunks per lane, 1-4 query terms, short /
-    long documents, fewer and more lists than an XCD group and than a launch group - KNRM against the per-pair kernel to fp32 rounding
-    of its sums, DRMM bit for bit."""
+    """The list route over the shapes the per-pair sweep covers: embedding widths of 1-5 float4 chunks per lane, 1-8 query terms (two
+    blocks of four from the fifth on), short / long documents, fewer and more lists than an XCD group and than a launch group - KNRM
+    against the per-pair kernel to fp32 rounding of its sums, DRMM and DRMM-TKS bit for bit."""
     emb = synthetic.make_embeddings(V, D, seed=D + Q)
     b, off = _lists_batch(len(docs), docs, V, 100 + L, Q=Q, L=L)
     d = {k: _t(v) for k, v in b.items()}
@@ -2825,6 +2832,69 @@ def test_lists_random_geometries(D, Q, L, V, docs):
     r.build_model().to(DEV).eval()
     with torch.no_grad():
         assert torch.equal(r.test_lists(no_oov, off), r.test(no_oov))
+        for hist, gate in (("NH", "IDF"), ("LCH", "TV")):
+            r2 = DRMM({"histType": hist, "gateType": gate}, SimpleNamespace(embeddings=emb))
+            torch.manual_seed(L + 1)
+            r2.build_model().to(DEV).eval()
+            assert torch.equal(r2.test_lists(no_oov, off), r2.test(no_oov)), (hist, gate)
+    from capreolus_amd.reranker import DRMMTKS
+
+    if L >= 10:
+        r = DRMMTKS({"topk": 10}, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
+        torch.manual_seed(L)
+        r.build_model().to(DEV).eval()
+        with torch.no_grad():
+            assert torch.equal(r.test_lists(no_oov, off), r.test(no_oov))
+
+
+@pytest.mark.parametrize("Q", [5, 6, 8])
+def test_lists_with_long_queries_through_predict(Q):
+    """`PytorchTrainer.predict` on a run whose extractor was configured with `maxqlen` > 4 (reference extractor/embedtext.py:28-31): the
+    resident route still scores whole lists (two blocks of four query terms), DRMM's predictions equal the DataLoader route's bit for bit,
+    KNRM's to fp16 rounding of sums that differ by 1e-6; short queries under the long `maxqlen` (pads in block 0, an empty block 1) too."""
+    from capreolus_amd.trainer import PytorchTrainer
+
+    V, L = 2000, 120
+    emb = synthetic.make_embeddings(V, 300, seed=Q)
+    docs = [40, 25, 60]
+    b, off = _lists_batch(len(docs), docs, V, 50 + Q, Q=Q, L=L)
+    b["query"] = np.clip(b["query"], 0, None)
+    b["query"][off[1]:off[2], 2:] = 0          # the second list's query: two terms under maxqlen = Q
+    q2d = {str(k): [f"d{i}" for i in range(off[k], off[k + 1])] for k in range(len(docs))}
+
+    class Sampler(torch.utils.data.IterableDataset):
+        qid_to_docids = q2d
+
+        def __iter__(self):
+            for qid, ds in q2d.items():
+                for d in ds:
+                    i = int(d[1:])
+                    yield {"qid": qid, "posdocid": d, "query": b["query"][i], "posdoc": b["posdoc"][i], "query_idf": b["query_idf"][off[int(qid)]]}
+
+        def __len__(self):
+            return int(off[-1])
+
+        def get_qid_docid_pairs(self):
+            return ((q, d) for q, ds in q2d.items() for d in ds)
+
+    for cls in (KNRM, DRMM):
+        r = cls({}, SimpleNamespace(embeddings=emb))
+        torch.manual_seed(Q)
+        r.build_model().to(DEV).eval()
+        calls = []
+        real = cls.test_resident_lists
+        cls.test_resident_lists = lambda self, *a, _real=real: calls.append(1) or _real(self, *a)
+        try:
+            got = PytorchTrainer({"batch": 32}).predict(r, Sampler())
+        finally:
+            cls.test_resident_lists = real
+        assert calls, "the list route should have taken this run"
+        want = PytorchTrainer({"batch": 32, "resident": False}).predict(r, Sampler())
+        if cls is DRMM:
+            assert got == want
+        else:
+            flat = lambda p: np.array([p[q][d] for q, ds in q2d.items() for d in ds], dtype=np.float64)      # noqa: E731
+            assert np.abs(flat(got) - flat(want)).max() <= 2e-3 * np.abs(flat(want)).max()
 
 
 @pytest.mark.parametrize("model", ["knrm", "drmm"])
