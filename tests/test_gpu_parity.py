@@ -2781,7 +2781,7 @@ def test_pacrr_lists_are_bit_identical_to_the_per_pair_kernel(cfg):
     b, off = _lists_batch(len(docs), docs, V, 41)
     b["posdoc"][7] = 0
     b["posdoc"][9, 3] = b["query"][9, 0] if b["query"][9, 0] < 0 else -4
-    r = PACRR(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
+    r = PACRR(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": 4}, pad=0))
     torch.manual_seed(4)
     r.build_model().to(DEV).eval()
     assert r.supports_lists
