@@ -39,7 +39,9 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
     out = [None]
 
     # whole candidate lists (csrc/lists.hip) where the model takes them, unless asked otherwise or on the uniform-id leg (lists share nothing there)
-    as_lists = bool(getattr(rr, "supports_lists", False)) and not args.per_pair and not uniform and n_queries >= 2
+    # (--force-lists: ConvKNRM's list entry, which exists and is bit-identical but is not the default route - 2 % slower than its per-pair kernel)
+    as_lists = (bool(getattr(rr, "supports_lists", False)) or (getattr(args, "force_lists", False) and hasattr(m, "forward_lists"))) and \
+        not args.per_pair and not uniform and n_queries >= 2
     offsets = np.arange(0, n_pairs + 1, args.docs, dtype=np.int64)
 
     def step(_):

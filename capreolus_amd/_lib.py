@@ -59,6 +59,8 @@ SIGNATURES = {
     "capamd_convknrm_table_bytes": (_i64, [_i64, _i, _i]),
     "capamd_convknrm_pack_tables": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "capamd_convknrm_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "capamd_convknrm_lists_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),
+    "capamd_convknrm_forward_lists": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "capamd_knrm_features": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "capamd_drmm_train_step_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "capamd_drmm_train_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _f, _vp, _vp, _sz, _vp, _vp]),

@@ -1113,6 +1113,43 @@ def convknrm_forward(query, doc, tables, V, maxngram, filters, crossmatch, mu, s
     return out
 
 
+def convknrm_forward_lists(offsets, query, doc, tables, V, maxngram, filters, crossmatch, mu, sigma, w1, b1, w2=None, b2=None, score_tanh=False, out=None,
+                           check=True):
+    """ConvKNRM over whole candidate lists (capamd_convknrm_forward_lists): pairs laid out list after list, `offsets` their n_lists + 1
+    boundaries on the host; the unigram document view once per distinct token of a list.  Scores equal convknrm_forward's bit for bit."""
+    _need_gpu(query, doc, tables, mu, sigma, w1, b1)
+    q, d = _i64(query), _i64(doc)
+    B, Q = q.shape
+    L = d.shape[1]
+    off = _list_offsets(offsets)
+    if int(off[-1]) != B:
+        raise ValueError("the last list offset must be the number of pairs")
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    n_lists = off.size - 1
+    one = int(lib.capamd_convknrm_lists_workspace_bytes(1, int(V), Q, int(maxngram), int(filters)))
+    if one == 0:
+        raise ValueError("capamd_convknrm_forward_lists does not take this geometry")
+    per_list = int(lib.capamd_convknrm_lists_workspace_bytes(2, int(V), Q, int(maxngram), int(filters))) - one
+    in_flight = max(1, min(n_lists, LISTS_WORKSPACE_BUDGET // max(per_list, 1)))
+    nbytes = int(lib.capamd_convknrm_lists_workspace_bytes(in_flight, int(V), Q, int(maxngram), int(filters)))
+    key = (q.device.index, int(torch.cuda.current_stream(q.device).cuda_stream))
+    ws = _list_workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _list_workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    st = status_word(q.device)
+    H = 0 if w2 is None else w1.shape[0]
+    rc = lib.capamd_convknrm_forward_lists(_ptr(q), _ptr(d), ctypes.c_void_p(off.ctypes.data), n_lists, Q, L, _ptr(tables), V, int(maxngram), int(filters),
+                                           int(bool(crossmatch)), _ptr(mu), _ptr(sigma), mu.numel(), _ptr(w1), _ptr(b1), H,
+                                           None if w2 is None else _ptr(w2), None if b2 is None else _ptr(b2), int(bool(score_tanh)), _ptr(out),
+                                           _ptr(st.t), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "capamd_convknrm_forward_lists")
+    if check:
+        st.raise_if_set()
+    return out
+
+
 CLS_MODES = {None: 0, "avg": 1, "max": 2}
 
 

@@ -48,6 +48,26 @@ class ConvKNRM_class(nn.Module):
                                       mu, sigma, lin1.weight.detach().contiguous(), lin1.bias.detach(), w2, b2, score_tanh=self.p["scoretanh"])
         return out.view(-1, 1)
 
+    def forward_lists(self, offsets, query=None, doc=None, idf=None, store=None, pair_q=None, pair_d=None):
+        """[B] scores of pairs laid out list after list (`offsets`: host array of n_lists + 1 boundaries; every list against its first
+        pair's query): the unigram document view once per distinct token of a list (capamd_convknrm_forward_lists).  Equal to `forward`
+        bit for bit.  Ids as [B, Q] / [B, L] rows, or index pairs of a device-resident CandidateStore (the id rows are then gathered on the
+        device: int32 tables -> the int64 rows the kernels read)."""
+        if store is not None:
+            query_sentence, sentence = store.q_table.index_select(0, pair_q.long()).long(), store.d_table.index_select(0, pair_d.long()).long()
+        else:
+            query_sentence, sentence = query, doc
+        w = self.embeddings.weight
+        tables = self._tables.get(w, [c[0].weight for c in self.convs], [c[0].bias for c in self.convs])
+        mu, sigma = self.kernels.stacked()
+        lin1 = self.combine[0]
+        w2 = b2 = None
+        if not self.p["singlefc"]:
+            w2, b2 = self.combine[2].weight.detach().contiguous().view(-1), self.combine[2].bias.detach()
+        return engine.convknrm_forward_lists(offsets, query_sentence, sentence, tables, w.shape[0], self.p["maxngram"], self.p["filters"],
+                                             self.p["crossmatch"], mu, sigma, lin1.weight.detach().contiguous(), lin1.bias.detach(), w2, b2,
+                                             score_tanh=self.p["scoretanh"])
+
 
     def _forward_train(self, sentence, query_sentence):
         """Training step (reference trainer/pytorch.py:96-99 -> ConvKNRM.score).  The trainable convolutions sit IN FRONT of the
@@ -148,6 +168,22 @@ class ConvKNRM(Reranker):
 
     def test(self, d):
         return self.model(d["posdoc"], d["query"], d["query_idf"]).view(-1)
+
+    # Whole candidate lists (capamd_convknrm_forward_lists: the unigram document view once per distinct token of a list) exist, are
+    # bit-identical to the per-pair kernel (the same matrix instructions on the same operands; the n-gram views and the pooling are
+    # the per-pair kernel's) and are NOT what `PytorchTrainer.predict` takes: measured 9.53 M pairs/s against 9.70 M pair by pair on the
+    # benchmark's lists (profiles/r06/convknrm_lists.txt) - the per-pair kernel is bound by its gather, of which the unigram part is a
+    # sixth, and the list's own passes (mark 0.11 ms, the table 0.30 ms) cost what the shorter gather saves (0.45 of 6.6 ms).
+    # `test_lists` / `test_resident_lists` stay callable for callers that want them.
+    supports_lists = False
+    lists_bit_identical = True
+    lists_max_qlen = 8
+
+    def test_lists(self, d, offsets):
+        return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"])
+
+    def test_resident_lists(self, store, pair_q, pair_d, offsets):
+        return self.model.forward_lists(offsets, store=store, pair_q=pair_q, pair_d=pair_d)
 
     def fused_train_step(self, d, optimizer, softmax=False):
         return self.model.fused_train_step(d, optimizer, softmax)

@@ -384,6 +384,21 @@ int capamd_convknrm_forward(const int64_t* q_ids, const int64_t* d_ids, int B, i
                             const float* b1, int H, const float* w2, const float* b2, int score_tanh, float* out, int* status,
                             void* stream);
 
+/* ConvKNRM over whole candidate lists (what PytorchTrainer.predict scores: capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query
+ * lists, sampler/__init__.py:222-233): pairs laid out list after list, list l = pairs list_offsets_host[l] .. list_offsets_host[l + 1] (a
+ * HOST array of n_lists + 1 entries), every list scored against its FIRST pair's query row (a pair with another row sets
+ * CAPAMD_STATUS_LIST_QUERY).  The unigram document view (ConvKNRM.py:46-49 with kernel size 1: a per-token projection) is computed once per
+ * DISTINCT token of a list - normalised, multiplied with the list's maxngram x Q query vectors by the same matrix instructions as the
+ * per-pair kernel - and looked up per position; the n-gram views of sizes 2 .. maxngram stay per position.  Scores equal
+ * capamd_convknrm_forward's bit for bit.  workspace: capamd_convknrm_lists_workspace_bytes(n_lists, V, Q, maxngram, filters) caller-owned
+ * bytes (16-byte aligned; per list in flight a flag byte and maxngram x Q floats - rounded up to four - per vocabulary id: 19.6 MB at V =
+ * 400,001, Q = 4, maxngram = 3; fewer lists are kept in flight when the buffer is smaller). */
+size_t capamd_convknrm_lists_workspace_bytes(int n_lists, int64_t V, int Q, int maxngram, int filters);
+int capamd_convknrm_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int64_t* list_offsets_host, int n_lists, int Q, int L,
+                                  const float* tables, int64_t V, int maxngram, int filters, int crossmatch, const float* mu, const float* sigma,
+                                  int K, const float* w1, const float* b1, int H, const float* w2, const float* b2, int score_tanh, float* out,
+                                  int* status, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- PACRR ---------------------------------------------------------------------------
  * Replaces PACRR_class.forward + PACRRConvMax2dModule.forward, capreolus/reranker/PACRR.py:42-78 (called from PACRR.test
  * :114-118): similarity matrix as in KNRM -> per n-gram size Conv2d(1 -> nfilters, ng x ng) on the zero-padded matrix,

@@ -2687,6 +2687,53 @@ def test_knrm_lists_with_other_kernel_banks(K):
         assert np.abs(lists - pairwise).max() <= 2e-5 * scale, (K, hidden, np.abs(lists - pairwise).max(), scale)
 
 
+@pytest.mark.parametrize("cfg,Q", [({}, 4), ({"crossmatch": False, "singlefc": False, "scoretanh": True}, 4), ({"maxngram": 2, "filters": 64}, 3),
+                                   ({}, 7), ({"maxngram": 1, "filters": 32}, 2)])
+def test_convknrm_lists_are_bit_identical_to_the_per_pair_kernel(cfg, Q):
+    """ConvKNRM over whole lists (capamd_convknrm_forward_lists): the unigram document view computed once per distinct token of a list -
+    the same normalisation, f16 split and matrix instructions as the per-pair kernel's phase B - and looked up per position; the other
+    n-gram views and the pooling unchanged: scores equal capamd_convknrm_forward's bit for bit.  Ragged lists (1 .. 300 documents), pads,
+    an all-pad document, more than 8 lists; ids as rows and through a candidate store; cross-match and not, 1-3 n-gram sizes, a query of
+    seven terms (two blocks of sixteen query vectors)."""
+    from capreolus_amd.feeder import CandidateStore
+    from capreolus_amd.reranker import ConvKNRM
+
+    V, D = 3000, 300
+    emb = synthetic.make_embeddings(V, D, seed=11)
+    docs = [300, 1, 9, 70, 2, 5, 33, 4, 12, 8]
+    b, off = _lists_batch(len(docs), docs, V, 43, Q=Q, L=200)
+    b["query"] = np.clip(b["query"], 0, None)          # (ConvKNRM takes no OOV ids: nn.Embedding would raise)
+    b["posdoc"] = np.clip(b["posdoc"], 0, None)
+    b["posdoc"][7] = 0
+    r = ConvKNRM(cfg, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
+    torch.manual_seed(5)
+    r.build_model().to(DEV).eval()
+    d = {k: _t(v) for k, v in b.items()}
+    with torch.no_grad():
+        pairwise = r.test(d)
+        lists = r.test_lists(d, off)
+        assert torch.isfinite(pairwise).all() and float(pairwise.abs().max()) > 0
+        assert torch.equal(pairwise, lists), float((pairwise - lists).abs().max())
+        # the documents of every list in another order; lists cut in two
+        perm = np.concatenate([off[k] + np.random.RandomState(k).permutation(docs[k]) for k in range(len(docs))])
+        assert torch.equal(r.test_lists({k: v[perm] for k, v in d.items()}, off), pairwise[perm])
+        cuts = np.unique(np.concatenate([off, off[:-1] + np.maximum(1, np.asarray(docs) // 2)]))
+        assert torch.equal(r.test_lists(d, cuts), pairwise)
+        store = CandidateStore(DEV)
+        pq, pd = [], []
+        for l, n in enumerate(docs):
+            for i in range(off[l], off[l] + n):
+                pq.append(store.add_query(f"q{l}", b["query"][off[l]], b["query_idf"][off[l]]))
+                pd.append(store.add_doc(f"d{i}", b["posdoc"][i]))
+        store.finalize()
+        assert torch.equal(r.test_resident_lists(store, _t(np.asarray(pq, np.int32)), _t(np.asarray(pd, np.int32)), off), pairwise)
+        # a list whose pairs bring different query rows is refused, as for the other list entries
+        bad = {k: v.clone() for k, v in d.items()}
+        bad["query"][off[3] + 1, 0] = (bad["query"][off[3] + 1, 0] % (V - 2)) + 1 if bad["query"][off[3] + 1, 0] != 1 else 2
+        with pytest.raises(ValueError):
+            r.test_lists(bad, off)
+
+
 @pytest.mark.parametrize("kind,Q", [("knrm", 4), ("drmm", 4), ("drmmtks", 4), ("pacrr", 4), ("knrm", 8), ("drmm", 6), ("drmmtks", 5), ("knrm", 5)])
 def test_full_size_list_properties(kind, Q):
     """The list route at BASELINE.json's geometry (vocabulary 400,001 x 300, 800-term documents, 16 queries x 1000 candidates): a
