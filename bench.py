@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--docs", type=int, default=1000, help="candidate documents per query")
     ap.add_argument("--qlen", type=int, default=4, help="query terms (the extractor's maxqlen): 4 is BASELINE.json's; up to 8 on the list route")
     ap.add_argument("--launch-docs", type=int, default=0, help="pairs per kernel launch (0 = whole step in one launch)")
+    ap.add_argument("--step-streams", type=int, default=0,
+                    help="list route: consecutive steps (independent batches of candidate lists) go round-robin over this many HIP streams (one call per "
+                         "step; per-stream workspace and score buffer), so that the passes of step i + 1 overlap those of step i; 0 = auto (2 for steps "
+                         "of up to 128 lists, else 1), 1 = strictly serial steps")
     ap.add_argument("--launch-streams", type=int, default=4,
                     help="with --launch-docs: the launches of a step go round-robin over this many HIP streams, so the tail of one candidate "
                          "list (as long as its longest document) overlaps the next list's launch; 1 = one stream, strictly serial launches")
@@ -126,6 +130,7 @@ def main():
                 r_elapsed, _ = rl.run(3, args.steps)
                 rl.check_against_oracle(min(64, rl.n_pairs))
                 rec["resident_int32_route"] = {"value": rl.n_pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps,
+                                               "step_streams": len(rl.step_side) or 1,
                                                "what": "bench.py --resident: the headline's lists as int32 tables + index pairs (capamd_knrm_forward_lists, indexed form)"}
                 del rl
             except Exception as e:  # noqa: BLE001
@@ -141,7 +146,7 @@ def main():
                 _, u_distinct = ul.bytes_requested_per_pair_lists()
                 ul.check_against_oracle(min(64, ul.n_pairs))
                 rec["lists_on_uniform_ids"] = {"value": ul.n_pairs * short / u_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * u_elapsed / short, "steps": short,
-                                               "mean_distinct_terms_per_list": u_distinct,
+                                               "mean_distinct_terms_per_list": u_distinct, "step_streams": len(ul.step_side) or 1,
                                                "what": "bench.py --uniform-ids --force-lists: the whole-list route where lists share nothing (its worst case; the "
                                                        "per-pair kernels - roofline.per_pair_hbm_leg - are what such launches should take)"}
                 del ul

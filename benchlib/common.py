@@ -9,7 +9,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (guides: MI355X_MICROARCH.m
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA")
 KERNEL_VARIANT = {"knrm": "knrm_forward_kernel<5, 1, true, 6, false>", "drmm": "drmm_forward_kernel<5, 1, true, 6, false>"}
-# launches of more than 3072 pairs over a table the cache hierarchy can hold run the persistent streaming kernels (interaction_stream.cuh)
+# launches of more than 3072 pairs over a table the cache hierarchy can hold run the persistent streaming kernels (interaction_stream.h)
 STREAM_VARIANT = {"knrm": "stream_kernel<5, false, KnrmStream>", "drmm": "stream_kernel<5, false, DrmmStream>"}
 
 

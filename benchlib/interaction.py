@@ -45,7 +45,8 @@ class InteractionLeg:
         w = m.embedding.weight
         self.packed = packed = m._packed.get(w)
         self.row_stride = packed.numel() // V
-        self.out = out = torch.empty(self.n_pairs, dtype=torch.float32, device=dev)
+        self.out = torch.empty(self.n_pairs, dtype=torch.float32, device=dev)
+        self.cur_out = self.out        # where launch_one writes (a per-stream buffer when consecutive steps alternate over streams)
         launch = args.launch_docs or self.n_pairs
         self.slices = [(i, min(i + launch, self.n_pairs)) for i in range(0, self.n_pairs, launch)]
         # whole candidate lists (csrc/lists.hip) unless asked otherwise; launches of single lists (38.6 M pairs/s as a list against 48.6 M
@@ -66,18 +67,18 @@ class InteractionLeg:
                 def launch_one(bi, lo, hi):
                     if self.lists:      # the store's lists as lists (index pairs into the int32 tables)
                         engine.knrm_forward_lists(np.arange(0, hi - lo + 1, args.docs), packed, V, D, mu, sigma, w1, b1, store=stores[bi], pair_q=pq[lo:hi],
-                                                  pair_d=pd[lo:hi], out=out[lo:hi], check=False)
+                                                  pair_d=pd[lo:hi], out=self.cur_out[lo:hi], check=False)
                     else:
-                        engine.knrm_forward_indexed(tabs[bi][0], tabs[bi][1], pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+                        engine.knrm_forward_indexed(tabs[bi][0], tabs[bi][1], pq[lo:hi], pd[lo:hi], packed, V, D, mu, sigma, w1, b1, out=self.cur_out[lo:hi], check=False)
             elif self.lists:
                 def launch_one(bi, lo, hi):      # the step's candidate lists (args.docs documents per query) as lists
                     b = self.batches[bi]
                     engine.knrm_forward_lists(np.arange(0, hi - lo + 1, args.docs), packed, V, D, mu, sigma, w1, b1, query=b["query"][lo:hi],
-                                              doc=b["posdoc"][lo:hi], out=out[lo:hi], check=False)
+                                              doc=b["posdoc"][lo:hi], out=self.cur_out[lo:hi], check=False)
             else:
                 def launch_one(bi, lo, hi):
                     b = self.batches[bi]
-                    engine.knrm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], packed, V, D, mu, sigma, w1, b1, out=out[lo:hi], check=False)
+                    engine.knrm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], packed, V, D, mu, sigma, w1, b1, out=self.cur_out[lo:hi], check=False)
         else:
             edges = m._bin_edges(dev)
             gw = m.gates.weight.detach().contiguous().view(-1)
@@ -89,10 +90,10 @@ class InteractionLeg:
                 b = self.batches[bi]
                 if self.lists:
                     engine.drmm_forward_lists(np.arange(0, hi - lo + 1, args.docs), b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
-                                              f2w, f2b, ow, ob, query=b["query"][lo:hi], doc=b["posdoc"][lo:hi], out=out[lo:hi], check=False)
+                                              f2w, f2b, ow, ob, query=b["query"][lo:hi], doc=b["posdoc"][lo:hi], out=self.cur_out[lo:hi], check=False)
                 else:
                     engine.drmm_forward(b["query"][lo:hi], b["posdoc"][lo:hi], b["query_idf"][lo:hi], packed, V, D, edges, "LCH", "IDF", gw, w, f0w, f0b,
-                                        f2w, f2b, ow, ob, out=out[lo:hi], check=False)
+                                        f2w, f2b, ow, ob, out=self.cur_out[lo:hi], check=False)
         self.launch_one = launch_one
         n_side = min(args.launch_streams, len(self.slices)) if len(self.slices) > 1 else 1
         self.side = [torch.cuda.Stream(device=dev) for _ in range(n_side)] if n_side > 1 else []
@@ -103,6 +104,15 @@ class InteractionLeg:
         self.snap = [torch.empty(self.n_pairs, dtype=torch.float32, device=dev) for _ in range(2)] if ctx.use_dist else None
         self.pending = [None, None]
         self.last_batch = 0
+        # --step-streams S: consecutive STEPS (independent batches of candidate lists) go round-robin over S HIP streams, each with its
+        # own score buffer and its own whole-list workspace (engine._lists_workspace is per stream): a step's HBM-bound mark pass runs
+        # under the previous step's VALU-bound pooling pass, and every pass's tail is filled by the other stream's workgroups
+        ns = getattr(args, "step_streams", 1)
+        if ns <= 0:      # auto: calls of up to 128 lists leave tails and fixed passes a second stream fills (64 lists: +9 %, 128: +3-5 %; 250: -1 %)
+            ns = 2 if n_queries <= 128 else 1
+        self.step_side = [torch.cuda.Stream(device=dev) for _ in range(ns)] if ns > 1 and len(self.slices) == 1 and self.lists else []
+        self.step_out = [torch.empty(self.n_pairs, dtype=torch.float32, device=dev) for _ in self.step_side]
+        self.snap_done = [None] * len(self.step_side)      # (multi-GPU: the main stream's snapshot of a buffer, awaited before the buffer is rewritten)
 
     def capture(self):
         """one HIP graph per batch: the step's launches (fork over the side streams, join) replayed with a single host call"""
@@ -120,6 +130,31 @@ class InteractionLeg:
 
     def step(self, i):
         bi = i % len(self.batches)
+        if self.step_side:
+            k = i % len(self.step_side)
+            st = self.step_side[k]
+            if self.snap_done[k] is not None:
+                st.wait_event(self.snap_done[k])
+            with torch.cuda.stream(st):
+                self.cur_out = self.step_out[k]
+                self.launch_one(bi, 0, self.n_pairs)
+                self.cur_out = self.out
+            self.last_side = k
+            if self.ctx.use_dist:      # the step's gather from a snapshot on the main stream; only THIS buffer's next step waits for it
+                main = torch.cuda.current_stream()
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+                j = i & 1
+                if self.pending[j] is not None:
+                    self.pending[j].wait()
+                self.snap[j].copy_(self.step_out[k])
+                self.snap_done[k] = torch.cuda.Event()
+                self.snap_done[k].record(main)
+                self.pending[j] = self.ctx.dist.all_gather_into_tensor(self.gathered[j], self.snap[j], async_op=True)
+                self.last_gather = j
+            self.last_batch = bi
+            return
         if getattr(self, "graphs", None):
             self.graphs[bi].replay()
         else:
@@ -134,6 +169,10 @@ class InteractionLeg:
         self.last_batch = bi
 
     def drain(self):
+        if self.step_side:
+            main = torch.cuda.current_stream()
+            for st in self.step_side:
+                main.wait_stream(st)
         for k in range(2):
             if self.pending[k] is not None:
                 self.pending[k].wait()
@@ -160,7 +199,15 @@ class InteractionLeg:
         from capreolus_amd import engine
 
         self.capture()
-        elapsed, dev_s, self.repeats = repeated_timed_loop(self.ctx, self.step, warmup, steps, self.drain if self.ctx.use_dist else None, repeats)
+        if self.step_side:
+            for st in self.step_side:          # module load / workspace allocation of every stream outside the timed region
+                with torch.cuda.stream(st):
+                    self.launch_one(0, 0, self.n_pairs)
+            torch.cuda.synchronize()
+        elapsed, dev_s, self.repeats = repeated_timed_loop(self.ctx, self.step, warmup, steps, self.drain if (self.ctx.use_dist or self.step_side) else None, repeats)
+        if self.step_side:
+            self.out.copy_(self.step_out[self.last_side])      # (the last step's scores: what the oracle check and the gather check compare)
+            torch.cuda.synchronize()
         engine.status_word(self.ctx.dev).raise_if_set()
         assert torch.isfinite(self.out).all()
         if self.ctx.use_dist:
@@ -379,6 +426,16 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
     nb = max(1, args.batches if model == "knrm" else min(args.batches, 2))      # (a DRMM batch is 250,000 pairs = 1.6 GB of id rows)
     leg = InteractionLeg(args, ctx, model, args.vocab, args.uniform_ids, per_rank_q, nb, 1 + ctx.rank)
     elapsed, dev_s = leg.run(warmup, steps, args.repeats)
+    serial = None
+    if leg.step_side and world == 1:
+        # the same steps strictly one after the other on ONE stream (what the line reported before round 6's step streams): the call's
+        # own duration - the per-pass figures of `roofline` belong to this form
+        sides, leg.step_side = leg.step_side, []
+        s_elapsed, s_dev, s_rep = repeated_timed_loop(ctx, leg.step, 2, steps, None, 3)
+        leg.step_side = sides
+        serial = {"value": leg.n_pairs * steps / s_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * s_elapsed / steps, "call_ms": s_dev * 1e3,
+                  "ms_per_step_min": s_rep["ms_per_step_min"], "ms_per_step_max": s_rep["ms_per_step_max"],
+                  "what": "bench.py --step-streams 1: every step's call waits for the previous one (3 repetitions of the K steps, median)"}
     zero_idf = None
     if model == "drmm" and world == 1 and not args.uniform_ids:
         # configs[2]'s second run: the same lists with the all-zero idf rows EmbedText produces by default
@@ -478,7 +535,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         traffic, traffic_src = None, "not measured in this run (--no-pmc-traffic)"
         if not args.no_pmc_traffic and ctx.rank == 0 and not args.uniform_ids:
             traffic, traffic_src = pmc_traffic(args, model, "lists")
-        roof = lists_roofline(model, headline, roof, n_pairs, dev_s, compulsory, traffic, traffic_src)
+        roof = lists_roofline(model, headline, roof, n_pairs, serial["call_ms"] * 1e-3 if serial else dev_s, compulsory, traffic, traffic_src)
     total_pairs = n_pairs * world
     rec = {
         "metric": "query-doc pairs scored/sec",
@@ -501,6 +558,7 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
                         f"{'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, lognormal doc lengths, "
                         + (f"scored as whole candidate lists ({distinct_per_list:.0f} distinct terms per list), " if leg.lists else "") +
                         f"{launches} launch(es) per step" + (f" round-robin over {len(leg.side)} HIP streams" if leg.side else "") + (", replayed as one captured HIP graph" if leg.graphs else "") +
+                        (f", consecutive steps round-robin over {len(leg.step_side)} HIP streams (step i + 1's passes overlap step i's)" if leg.step_side else "") +
                         f", {len(leg.batches)} distinct batches in rotation"
                         + (", query_idf ~ U(0.5, 8) per query (a second run with all-zero idf rows: zero_idf_run)" if model == "drmm" else ""),
             "pairs_per_step_per_gpu": n_pairs,
@@ -509,6 +567,12 @@ def interaction_record(args, ctx, model, steps, warmup, n_queries, with_cpu):
         "roofline": roof if roof is not None else {"bound": "hbm", "kernel": KERNEL_VARIANT[model], "achieved": None, "peak": HBM_PEAK_GBS,
                                                    "unit": "GB/s", "frac": None, "traffic": None, "headline_leg": headline},
     }
+    if serial is not None:
+        rec["step_streams"] = {"streams": len(leg.step_side), "serial_steps": serial,
+                               "what": "consecutive steps (independent batches of candidate lists) are issued round-robin over this many HIP streams, each "
+                                       "with its own workspace and score buffer: a step's HBM-bound mark pass and the tails of its passes run under the other "
+                                       "stream's sims / pooling passes.  `value` / `ms_per_step` are the K steps' throughput in this form; `roofline` prices "
+                                       "the passes of ONE call as they run alone (serial_steps.call_ms)"}
     if zero_idf is not None:
         rec["zero_idf_run"] = zero_idf
     if ctx.use_dist:

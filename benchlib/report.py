@@ -74,6 +74,9 @@ def compact(rec, full_path):
         out["other_operand_type"] = _pick(rec["other_operand_type"], ("dtype", "value", "ms_per_step", "whole_step_frac", "whole_step_frac_nominal"))
     if isinstance(rec.get("zero_idf_run"), dict):
         out["zero_idf_run"] = _pick(rec["zero_idf_run"], ("value", "unit", "ms_per_step", "steps"))
+    if isinstance(rec.get("step_streams"), dict):
+        out["step_streams"] = {"streams": rec["step_streams"].get("streams"),
+                               "serial_steps": _pick(rec["step_streams"].get("serial_steps") or {}, ("value", "ms_per_step", "call_ms"))}
     if isinstance(rec.get("resident_int32_route"), dict):
         out["resident_int32_route"] = _pick(rec["resident_int32_route"], ("value", "unit", "ms_per_step", "error"))
     if isinstance(rec.get("qlen8_lists"), dict):
@@ -98,6 +101,8 @@ def compact(rec, full_path):
             e["other_operand_type"] = _pick(a["other_operand_type"], ("dtype", "value", "whole_step_frac", "whole_step_frac_nominal"))
         if isinstance(a.get("zero_idf_run"), dict):
             e["zero_idf_run"] = _pick(a["zero_idf_run"], ("value", "ms_per_step"))
+        if isinstance(a.get("step_streams"), dict):
+            e["step_streams"] = a["step_streams"].get("streams")
         also.append(e)
     if also:
         out["also"] = also

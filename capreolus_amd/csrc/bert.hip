@@ -1,19 +1,19 @@
 // BERT-MaxP passage scoring for gfx950: PTBERTMaxP_Class.predict_step (reference
 // capreolus/reranker/ptBERTMaxP.py:67-96) with the transformers BertForSequenceClassification it
 // calls at :82 re-built as hand-written kernels: embedding sum + LayerNorm, 16-bit MFMA GEMMs with
-// fused bias / GELU / QKV epilogues (bert_gemm.cuh), fused exact-softmax attention (bert_attn.cuh),
+// fused bias / GELU / QKV epilogues (bert_gemm.h), fused exact-softmax attention (bert_attn.h),
 // residual + LayerNorm, pooler + classifier, passage pooling.
 //
 // Precision: the activation stream is 16-bit end to end (fp16 by default - the reference's autocast type - or
 // bf16, `compute_dtype` of the model); every accumulation, the residual sums (added in fp32 inside the LayerNorm
 // pass, one rounding), LayerNorm statistics, softmax and the pooler/classifier are fp32.  (A fp32 residual stream
 // was measured to give the same logit error: the error is set by the 16-bit GEMM operands.)
-#include "bert_attn.cuh"
-#include "bert_gemm.cuh"
-#include "bert_gemm_ring16.cuh"
+#include "bert_attn.h"
+#include "bert_gemm.h"
+#include "bert_gemm_ring16.h"
 #include "capreolus_amd.h"
 #include "capamd_profiling.h"
-#include "cedr_tap.cuh"
+#include "cedr_tap.h"
 #include <stdlib.h>
 #include <string.h>
 #include <utility>
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ pre, cons
         ob[4 * h + 2] = (T)((v[i][4 * h + 2] - mean) * rstd * g.z + b.z);
         ob[4 * h + 3] = (T)((v[i][4 * h + 3] - mean) * rstd * g.w + b.w);
       }
-      if (out_cm) *reinterpret_cast<bf16x8*>(xb + cm_offset(tok, c * 8, H)) = ob;   // chunk-major stream (bert_gemm.cuh)
+      if (out_cm) *reinterpret_cast<bf16x8*>(xb + cm_offset(tok, c * 8, H)) = ob;   // chunk-major stream (bert_gemm.h)
       else reinterpret_cast<bf16x8*>(xb + tok * H)[c] = ob;
     }
   }
@@ -377,7 +377,7 @@ bool dims_ok(const capamd_bert_model* m) {
          (m->compute_dtype == 0 || m->compute_dtype == 1) && m->ln_eps >= 0.f && m->pos_pad_id < m->vocab;
 }
 
-// LayerNorm folded into the GEMMs (bert_gemm.cuh) needs every encoder GEMM on the ping-pong kernel: N and K multiples of 256
+// LayerNorm folded into the GEMMs (bert_gemm.h) needs every encoder GEMM on the ping-pong kernel: N and K multiples of 256
 bool fused_capable(int H, int F) { return H % 256 == 0 && F % 256 == 0; }
 // per layer, 16-bit: wqkv [3H,H] | wo [H,H] | w1 [F,H] | w2 [H,F]   (+ wqkv' = wqkv . gamma_in | w1' = w1 . ln1_gamma when fused_capable)
 //   (+ when fused_capable: a chunk-major copy of all six, same order, for the ring kernel)
@@ -411,7 +411,7 @@ int num_cus() {
 template <typename T>
 void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
   if (S == 256) {
-    // two 4-wave workgroups per CU, 64 queries per wave (bert_attn.cuh: attention_s256_kernel); CAPAMD_ATTN=oneshot | persistent
+    // two 4-wave workgroups per CU, 64 queries per wave (bert_attn.h: attention_s256_kernel); CAPAMD_ATTN=oneshot | persistent
     // select the earlier kernels for A/B runs
     static const int which = [] {
       const char* e = getenv("CAPAMD_ATTN");
@@ -439,7 +439,7 @@ void launch_attention(const AttnArgs& at, int S, unsigned nblk, hipStream_t s) {
       hipLaunchKernelGGL((attention_persistent_kernel<T>), dim3(grid), dim3(512), kAttnLds, s, at, (int)nblk);
     }
   } else if (S > 256) {
-    // 384 / 512: keys walked in chunks with the running-maximum softmax (bert_attn.cuh), K and V^T of the passage in LDS
+    // 384 / 512: keys walked in chunks with the running-maximum softmax (bert_attn.h), K and V^T of the passage in LDS
     constexpr int kLds384 = 384 * 128 + 64 * (384 * 2 + 8) + 384 * 4, kLds512 = 512 * 128 + 64 * (512 * 2 + 8) + 512 * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -486,17 +486,17 @@ bool pingpong_shape(int64_t M, int N, int K) {
   static const bool pingpong = [] { const char* e = getenv("CAPAMD_GEMM_KLOOP"); return !(e && e[0] == 'h'); }();
   return pingpong && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
-// Shapes the 4-wave ring kernel takes (bert_gemm_ring.cuh): whole 256 x 256 tiles, at least 16 k-slices (the ring holds 8 and the
+// Shapes the 4-wave ring kernel takes (bert_gemm_ring.h): whole 256 x 256 tiles, at least 16 k-slices (the ring holds 8 and the
 // tile loop has a head and a tail of 8), an even number of them.  CAPAMD_GEMM_RING=0 keeps the 8-wave ping-pong kernel (A/B runs).
 bool ring_shape(int64_t M, int N, int K) {
   return M % 256 == 0 && N % 256 == 0 && K % 32 == 0 && K >= 256 && (size_t)M * K < (1ull << 31) && (size_t)N * K < (1ull << 31);
 }
-int ring_rows() {   // CAPAMD_RING_BM=256: one workgroup per CU with 128 x 128 wave tiles; default 128: two workgroups per CU (see bert_gemm_ring.cuh)
+int ring_rows() {   // CAPAMD_RING_BM=256: one workgroup per CU with 128 x 128 wave tiles; default 128: two workgroups per CU (see bert_gemm_ring.h)
   static const int bm = [] { const char* e = getenv("CAPAMD_RING_BM"); return (e && atoi(e) == 256) ? 256 : 128; }();
   return bm;
 }
 // Which ring kernel each of the encoder's four GEMMs runs on: tile rows (256: one workgroup per CU, 128: two) and, for 256, the MFMA
-// shape (16x16x32, bert_gemm_ring16.cuh, or 32x32x16).  Defaults = what measured fastest inside the encoder at M = 64,000
+// shape (16x16x32, bert_gemm_ring16.h, or 32x32x16).  Defaults = what measured fastest inside the encoder at M = 64,000
 // (profiles/r05/bert_gemm_pick_ab.txt); CAPAMD_GEMM_PICK="qkv=256x16,ffn1=128,oproj=256x32,ffn2=256x32" overrides any of them (A/B runs),
 // CAPAMD_RING_BM every one alike.
 struct GemmPick { int rows, mfma32, mfma16; };   // mfma32: 256 rows on 32x32x16; mfma16: 128 rows on 16x16x32
@@ -566,7 +566,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
       const int rows = g.ring_rows ? g.ring_rows : ring_rows();
       const bool r16 = ring16_enabled() && !g.ring_mfma32 && g.out_cm && g.K % 64 == 0;
       if (rows == 256 && r16) {
-        // one workgroup per CU on 16x16x32 MFMAs (bert_gemm_ring16.cuh)
+        // one workgroup per CU on 16x16x32 MFMAs (bert_gemm_ring16.h)
         using R = GemmRing16<EPI, T, 256>;
         auto k = gemm_ring16_kernel<EPI, T, 256>;
         static bool attr_set = false;
@@ -580,7 +580,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
         gg.res_touch = touch;
         hipLaunchKernelGGL(k, dim3(grid), dim3(R::kThreads), R::kLdsBytes, s, gg);
       } else if (rows == 128 && r16 && g.ring_mfma16 && EPI != kEpiQkv) {
-        // two workgroups per CU on 16x16x32 MFMAs (the 128-row form of bert_gemm_ring16.cuh; no V^T tiles)
+        // two workgroups per CU on 16x16x32 MFMAs (the 128-row form of bert_gemm_ring16.h; no V^T tiles)
         if constexpr (EPI != kEpiQkv) {
           using R = GemmRing16<EPI, T, 128>;
           auto k = gemm_ring16_kernel<EPI, T, 128>;
@@ -872,7 +872,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
     const int64_t* seg_mb = seg + p0 * S;
     // LayerNorm folded into the GEMMs: every encoder GEMM of this microbatch must be a ping-pong shape
     // (a CEDR-KNRM call reads every layer's normalised output: its tap applies the LayerNorm to the operand fragments it loads from
-    // the un-normalised stream, cedr_tap.cuh; CAPAMD_CEDR_FUSED=0 runs it on the path that materialises them instead)
+    // the un-normalised stream, cedr_tap.h; CAPAMD_CEDR_FUSED=0 runs it on the path that materialises them instead)
     const bool fused = (!tap || (cedr_fused_enabled() && S % 32 == 0 && cedr_pool_cm_smem(S, H, tap->A) <= 160 * 1024)) && fused_ln_enabled() &&
                        fused_capable(H, F) && pingpong_shape(M, 3 * H, H) && pingpong_shape(M, H, H) && pingpong_shape(M, F, H) &&
                        pingpong_shape(M, H, F);
@@ -903,7 +903,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
         const float* fl = m->layer_f32 + (int64_t)l * layer_f32_floats(H, F);
         const T *wqkv = wl, *wo = wl + (int64_t)3 * H * H, *w1 = wl + (int64_t)4 * H * H, *w2 = w1 + (int64_t)F * H;
         const T *wqkv_s = w2 + (int64_t)H * F, *w1_s = wqkv_s + (int64_t)3 * H * H;
-        // both operands chunk-major -> the 4-wave ring kernel (bert_gemm_ring.cuh); its weights are the copies behind the row-major ones
+        // both operands chunk-major -> the 4-wave ring kernel (bert_gemm_ring.h); its weights are the copies behind the row-major ones
         const bool ring = ring_enabled() && ring_shape(M, 3 * H, H) && ring_shape(M, H, H) && ring_shape(M, F, H) && ring_shape(M, H, F);
         const int64_t cmo = ring ? layer_rowmajor_elems(H, F) : 0;
         const float *bqkv = fl, *ln1g = fl + 4 * H, *ln2g = fl + 7 * H + F, *ln2b = fl + 8 * H + F;
@@ -1026,7 +1026,7 @@ hipError_t encode_passages(const int64_t* ids, const int64_t* mask, const int64_
       hipLaunchKernelGGL((ln_kernel<2, T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, (const T*)w.pre, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, 0, S, ln1g, ln1b, M, H, (T*)w.xb, status, 0, eps, -1, 0);
       // feed-forward: 768 -> 3072 (GELU) -> 768, residual + LayerNorm
-      const bool cm = chunk_major_enabled() && pingpong_shape(M, F, H) && pingpong_shape(M, H, F);  // mid in the chunk-major layout (bert_gemm.cuh)
+      const bool cm = chunk_major_enabled() && pingpong_shape(M, F, H) && pingpong_shape(M, H, F);  // mid in the chunk-major layout (bert_gemm.h)
       g.A = w.xb; g.W = w1; g.bias = b1; g.N = F; g.K = H; g.out_bf16 = w.mid; g.out_cm = cm;
       Ffn1Timing::begin(s);
       e = launch_gemm<kEpiBiasGeluBf16, T>(g, s);

@@ -15,7 +15,7 @@
 // from the QKV GEMM already transposed per head and is staged through registers into rows padded
 // by 8 bytes (conflict-free ds_read_b64 for 32 lanes reading 32 different d rows).
 #pragma once
-#include "bert_gemm.cuh"
+#include "bert_gemm.h"
 
 namespace capamd {
 
@@ -26,8 +26,8 @@ struct AttnArgs {
   const int64_t* mask;   // [M/S, S] attention mask (1 = attend), rows of the current micro-batch
   void* ctx;             // [M, H]
   int H, heads;
-  int qk_cm;             // Q and K in the chunk-major activation layout (bert_gemm.cuh cm_offset) instead of row-major
-  int ctx_cm;            // ctx written chunk-major (the A operand of the ring GEMM, bert_gemm_ring.cuh) instead of row-major
+  int qk_cm;             // Q and K in the chunk-major activation layout (bert_gemm.h cm_offset) instead of row-major
+  int ctx_cm;            // ctx written chunk-major (the A operand of the ring GEMM, bert_gemm_ring.h) instead of row-major
 };
 
 // where lane (query row `tok`, half) stores its 4 consecutive output dimensions d = 32 dt + 8 g4 + 4 half .. + 3 of head `head`:
@@ -123,7 +123,7 @@ __device__ inline f32x16 scores_init_permuted(const float* madd_t) {   // madd_t
 // The value the partner lane (lane ^ 32) holds: v_permlane32_swap on two copies (x.hi <-> y.lo leaves x = [lo | lo], y = [hi | hi]) and a
 // select - a VALU exchange instead of the ds_bpermute round trip through the LDS pipe `__shfl_xor(v, 32)` compiles to; the softmax has two
 // of them in its serial chain (row maximum, row sum).  (Inline asm with the wait states a VALU-written operand needs before a
-// lane-crossing instruction, as in bert_gemm.cuh: swap32.)
+// lane-crossing instruction, as in bert_gemm.h: swap32.)
 __device__ __forceinline__ float partner32(float v, int half) {
   unsigned x = __builtin_bit_cast(unsigned, v), y = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));

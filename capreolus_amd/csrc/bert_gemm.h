@@ -89,7 +89,7 @@ struct GemmArgs {
   int H, S, heads;      // kEpiQkv geometry (head_dim = 64)
   int ngroup;           // column tiles per scheduling group (divides N / 256; 0 = all of them)
   int a_cm, out_cm;     // A operand / output in the chunk-major activation layout (see cm_offset) instead of row-major
-  int w_cm;             // W chunk-major as well: the 4-wave ring kernel (bert_gemm_ring.cuh; needs a_cm too)
+  int w_cm;             // W chunk-major as well: the 4-wave ring kernel (bert_gemm_ring.h; needs a_cm too)
   // ---- fused LayerNorm (see "LayerNorm folded into the GEMMs" below) ----
   // consumer side: A holds the UN-normalised pre-LayerNorm sums P; with W' = W . gamma packed as the weight matrix,
   //   LN(P) W^T + b  ==  rstd_m (acc - mu_m cs_n) + c_n ,   cs_n = sum_k W'[n][k],  c_n = b_n + sum_k beta_k W[n][k]  (passed as `bias`)
@@ -104,8 +104,8 @@ struct GemmArgs {
   const float* res_gamma;                      // [N]
   float* stat_part;     // [M][N / 64][2]: (sum, sum of squares) of the 64 output columns each wave column writes
   int ring_rows;        // ring kernel: 256 = one workgroup per CU (128 x 128 wave tiles), 128 = two per CU; 0 = the library default
-  int ring_mfma16;      // 128-row ring tile: on 16x16x32 MFMAs (bert_gemm_ring16.cuh, two workgroups per CU) instead of 32x32x16
-  int ring_mfma32;      // 256-row ring tile: stay on 32x32x16 MFMAs (bert_gemm_ring.cuh) instead of 16x16x32 (bert_gemm_ring16.cuh)
+  int ring_mfma16;      // 128-row ring tile: on 16x16x32 MFMAs (bert_gemm_ring16.h, two workgroups per CU) instead of 32x32x16
+  int ring_mfma32;      // 256-row ring tile: stay on 32x32x16 MFMAs (bert_gemm_ring.h) instead of 16x16x32 (bert_gemm_ring16.h)
   int res_touch;        // 16x16x32 ring, kEpiResidStats: touch the tile's residual lines in the first steps of its K loop (A/B switch; default off)
   int ring_stagger;     // ring kernel, two workgroups per CU: blocks of the grid's second half start this many x 64 cycles late
   unsigned long long* dbg;  // optional per-block cycle stamps [blocks][32] (profiling builds of the benches only)

@@ -24,7 +24,7 @@
 //
 // Two shapes of the same kernel:
 //   BM = 256  one workgroup per CU, one wave per SIMD, wave tile 128 x 128 (256 accumulators, in AGPRs), ring of 8 x 16 KiB.  Reads
-//             128 KiB of LDS per K step where the 8-wave ping-pong kernel (bert_gemm.cuh) reads 192 and synchronises once per 16 MFMAs,
+//             128 KiB of LDS per K step where the 8-wave ping-pong kernel (bert_gemm.h) reads 192 and synchronises once per 16 MFMAs,
 //             but nothing overlaps its epilogue, and one wave per SIMD gets through VALU work (GELU!) at about half the rate of two.
 //   BM = 128  TWO workgroups per CU (wave tile 64 x 128, 128 accumulators, ring of 5 x 12 KiB each): the two run unsynchronised, so one
 //             workgroup's epilogue overlaps the other's K loop - the matrix pipe always has a K loop to serve.
@@ -34,7 +34,7 @@
 //
 // Accumulation order per output element is k ascending in slices of 16, exactly as in the ping-pong kernel: identical bits.
 #pragma once
-#include "bert_gemm.cuh"
+#include "bert_gemm.h"
 
 namespace capamd {
 

@@ -1,4 +1,4 @@
-// 256 x 256 tile, four waves, the k-slice ring of bert_gemm_ring.cuh consumed by v_mfma_f32_16x16x32 (round 5).
+// 256 x 256 tile, four waves, the k-slice ring of bert_gemm_ring.h consumed by v_mfma_f32_16x16x32 (round 5).
 //
 // Why another K loop.  Every 32x32x16 kernel of this library lands at the same 0.95-1.1 PFLOP/s on the encoder's shapes whatever its
 // schedule, at clocks between 1.06 and 1.5 GHz (profiles/r05/ring_timeline.txt): the part is power-limited and cycles saved come back as
@@ -9,7 +9,7 @@
 // (profiles/r05/gemm4w5_vs_4w2.txt).  Per flop a 16x16x32 MFMA moves half the accumulator registers of a 32x32x16 one (4 in, 4 out per
 // 16 k-flops against 16 and 16 per 32 k) for twice the operand registers: 0.25 against 0.31 register bytes per flop.
 //
-// Layout.  Operands chunk-major as in bert_gemm_ring.cuh; a ring SLOT is a k-slice of 16 (8 A pieces + 8 B pieces of 1 KiB), a STEP is
+// Layout.  Operands chunk-major as in bert_gemm_ring.h; a ring SLOT is a k-slice of 16 (8 A pieces + 8 B pieces of 1 KiB), a STEP is
 // 32 k = two adjacent slots (the ring's 8 slots = 4 steps).  An operand fragment of a 16-row tile is 16 rows x 32 k: lane (l15 = lane
 // % 16, q = lane / 16) reads row l15 of k-chunk q - chunks 0, 1 in the step's first slot, 2, 3 in its second - one ds_read_b128, the 16
 // lanes of a q 256 contiguous bytes: conflict-free.  A wave owns 128 x 128 = 8 x 8 tiles of 16 x 16, 64 accumulators of 4 registers
@@ -23,14 +23,14 @@
 // arithmetic as in the 32x32x16 ring with a step as the unit: 16 pieces (two steps) may stay in flight at the top of a step, 32 more
 // in the two steps after an epilogue.  The first step of a tile writes the accumulators (C = 0): no zero fill.
 //
-// Epilogues.  The chunk-major ones of bert_gemm.cuh re-derived for the 16 x 16 layout: a lane owns 4 consecutive columns of a row; the
+// Epilogues.  The chunk-major ones of bert_gemm.h re-derived for the 16 x 16 layout: a lane owns 4 consecutive columns of a row; the
 // two lanes that hold the halves of an 8-column chunk are 16 apart, and the two 16-row tiles of a 32-row block sit in the same lanes -
 // v_permlane16_swap on the PACKED registers of tile (i, 2 jp) and (i, 2 jp + 1) leaves lane q even with the whole chunk of row l15 and
 // lane q odd with the whole chunk of row 16 + l15: one 16-byte store per lane, 1 KiB contiguous per instruction.  V^T tiles (QKV): the
 // operand roles swapped (lane <-> n, registers <-> 4 consecutive keys), regrouped through the wave's 4 KiB of LDS into 128-byte row
 // segments as before.
 #pragma once
-#include "bert_gemm_ring.cuh"
+#include "bert_gemm_ring.h"
 
 namespace capamd {
 
@@ -95,7 +95,7 @@ struct GemmRing16 {
     return b;
   }
 
-  // lanes of row 1 / 3 (lanes 16..31, 48..63) of x <-> lanes of row 0 / 2 of y   (wait states by hand, as swap32 in bert_gemm.cuh)
+  // lanes of row 1 / 3 (lanes 16..31, 48..63) of x <-> lanes of row 0 / 2 of y   (wait states by hand, as swap32 in bert_gemm.h)
   static __device__ __forceinline__ void swap16(unsigned& x, unsigned& y) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
   }
@@ -114,7 +114,7 @@ struct GemmRing16 {
       if (n0 >= a.H) { base = static_cast<T*>(a.out_k); nloc -= a.H; }
       else scale = 0.125f;
     }
-    const float es = EPI == kEpiBiasGeluBf16 ? 0.5f : scale;     // folded into the affine form (bert_gemm.cuh: epilogue_cm)
+    const float es = EPI == kEpiBiasGeluBf16 ? 0.5f : scale;     // folded into the affine form (bert_gemm.h: epilogue_cm)
     const bool ln = a.ln_mu != nullptr;
     float2 mr[NJ];
 #pragma unroll
@@ -167,7 +167,7 @@ struct GemmRing16 {
     }
   }
 
-  // ---- epilogue: pre-LayerNorm sum with the residual re-normalised on the fly + row statistics (bert_gemm.cuh: epilogue_cm_resid) ---
+  // ---- epilogue: pre-LayerNorm sum with the residual re-normalised on the fly + row statistics (bert_gemm.h: epilogue_cm_resid) ---
   static __device__ __forceinline__ void epilogue_cm_resid(const GemmArgs& a, int m0, int n0, const Lane& L, f32x4 (&acc)[NI][NJ]) {
     T* base = static_cast<T*>(a.out_bf16);
     const T* rsrc = static_cast<const T*>(a.res_src);

@@ -13,7 +13,7 @@
 // memory (operands are the stored activations: one product, fp32 accumulate; the row norms are accumulated from the same operand
 // loads), similarities into LDS, then one thread per (query row, slice of columns) for the K exponentials.
 #pragma once
-#include "bert_gemm.cuh"
+#include "bert_gemm.h"
 
 namespace capamd {
 
@@ -190,7 +190,7 @@ __device__ __forceinline__ typename Half<T>::x8 cedr_ln8(typename Half<T>::x8 v,
   return o;
 }
 
-// The same tap on the CHUNK-MAJOR activation stream of the fused encoder (cm_offset, bert_gemm.cuh): a 32-row x 16-column MFMA operand
+// The same tap on the CHUNK-MAJOR activation stream of the fused encoder (cm_offset, bert_gemm.h): a 32-row x 16-column MFMA operand
 // fragment is 1 KiB contiguous there, so every operand load of a wave is one fully coalesced instruction (the row-major kernel below
 // touches 64 separate 32-byte sectors per load).  x holds either a normalised hidden state (mr == NULL: the embedding output) or the
 // pre-LayerNorm sums of a layer with the rows' (mu, rstd) in mr and the layer's gamma / beta: the tap then applies the LayerNorm to

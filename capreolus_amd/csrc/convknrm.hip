@@ -24,8 +24,8 @@
 //   C  kernel pooling: every thread owns one (view, query term) row and a slice of the tile's positions; K exp2 per value
 // and a fixed-order reduction, log, query sum and the combine layers at the end.
 #include "capreolus_amd.h"
-#include "interaction.cuh"
-#include "lists.cuh"      // whole candidate lists: geometry, the clear / mark passes (capamd_convknrm_forward_lists below)
+#include "interaction.h"
+#include "lists.h"      // whole candidate lists: geometry, the clear / mark passes (capamd_convknrm_forward_lists below)
 
 using namespace capamd;
 
@@ -242,7 +242,7 @@ __device__ __forceinline__ void ck_store_unit(const float4 (&v)[NF4], int F4, in
   }
 }
 
-// LISTS: a workgroup per (list, document) in the XCD-aware numbering of lists.cuh; the unigram document view is looked up, not computed.
+// LISTS: a workgroup per (list, document) in the XCD-aware numbering of lists.h; the unigram document view is looked up, not computed.
 template <int NF4, bool LISTS>
 __device__ __forceinline__ void convknrm_forward_body(const ConvKnrmArgs& a, int b, const float* ltab_l) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_CK_WAVES) void convknrm_forward_ke
 // ---- whole candidate lists: the unigram document view once per distinct term of a LIST ------------------------------------------------
 //   A document position's three n-gram vectors are 3 KB of gathered projections (6 parts of 512 B); the unigram
 // one - part (1, 0) of the position's own token, 512 B - depends on the token alone, and so do its similarities with the list's G x Q
-// query vectors.  Per list: the shared clear / mark passes of lists.cuh flag the list's distinct tokens; ck_lists_sims_kernel walks
+// query vectors.  Per list: the shared clear / mark passes of lists.h flag the list's distinct tokens; ck_lists_sims_kernel walks
 // them in tiles of 16 - gather the part, L2-normalise, split into f16 hi + lo, the 16 x 16 x F products of phase B (the same
 // instruction sequence on the same operands: bit-identical similarities) - and leaves G * Q floats per token in the list's table; the
 // per-pair kernel then gathers 5 parts per position instead of 6, normalises two views instead of three, runs two thirds of the

@@ -14,8 +14,8 @@
 //   * pad document positions carry +1e7 in the reference (DRMM.py:57) -> they fall in no bin and
 //     are skipped; OOV document terms (id < 0) have sim exactly 0 -> added to bin(0) in closed form.
 #include "capreolus_amd.h"
-#include "interaction.cuh"
-#include "interaction_stream.cuh"
+#include "interaction.h"
+#include "interaction_stream.h"
 #include <stdlib.h>
 
 using namespace capamd;
@@ -57,7 +57,7 @@ struct DrmmArgs {
   int split;
 };
 
-__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce_sum(v); }   // (interaction.cuh: DPP + readlane, no LDS-pipe permutes)
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce_sum(v); }   // (interaction.h: DPP + readlane, no LDS-pipe permutes)
 
 __device__ __forceinline__ int bin_of(float x, const float* edges, int nbins) {
   int bi = (int)floorf((x + 1.f) * (0.5f * (float)nbins));
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
   float* w1lds = reinterpret_cast<float*>(hkey);
   const bool w1_in_lds = a.out && a.L <= kDedupMaxL && a.nodes * NB <= 2 * kHashSlots;   // (longer documents: no hash region in the carve-out)
 
-  // ---- the document's distinct real terms with their multiplicities; OOV count (interaction.cuh) --------
+  // ---- the document's distinct real terms with their multiplicities; OOV count (interaction.h) --------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
   const int n_real = tl.n_unique, n_oov = tl.n_oov;
   if (w1_in_lds)
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kThreads, MINW) void drmm_forward_kernel(DrmmArgs a
 
 
 // =====================================================================================================================================
-// Streaming form (interaction_stream.cuh): persistent five-wave workgroups, the model's part as a policy.
+// Streaming form (interaction_stream.h): persistent five-wave workgroups, the model's part as a policy.
 //   gathering waves: bin every gathered similarity into hist[buf][query term][bin] (LDS atomics, integers: order independent)
 //   list wave:       OOV document terms in closed form, then per query term CH / NH / LCH -> feed-forward net -> gate logit, the softmax
 //                    gate and the output layer (DRMM.py:71-116) - the tail that cost the one-pair-per-workgroup kernel 23 % of its
@@ -370,7 +370,7 @@ int drmm_launch(const IdSource& ids, const float* idf, int B, int Q, int L, cons
   const size_t smem = (size_t)((L + 3) & ~3) * 8 + (size_t)(kQT * kMaxBins + kMaxBins + 2 * kMaxQ + 48) * 4 + dedup_hash_bytes(L) + (size_t)kQT * kMaxNV * 16 * 16;
   hipStream_t s = (hipStream_t)stream;
   (void)hipGetLastError();
-  // Launches that outnumber the workgroups the chip holds run the streaming kernel (interaction_stream.cuh; needs the caller's workspace
+  // Launches that outnumber the workgroups the chip holds run the streaming kernel (interaction_stream.h; needs the caller's workspace
   // word, <= kQT query terms, L <= kDedupMaxL, ids < 2^22).  CAPAMD_DRMM_STREAM (profiling): 0 = never, 2 = whenever the geometry allows.
   static const int stream_mode = [] {
     const char* e = getenv("CAPAMD_DRMM_STREAM");

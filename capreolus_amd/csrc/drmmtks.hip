@@ -10,7 +10,7 @@
 // a wave-wide arg-max over the list heads), together with the closed-form candidates of the terms that were never
 // gathered: n1 ones (OOV exact matches) and n0 zeros (pads and other OOV terms).
 #include "capreolus_amd.h"
-#include "interaction.cuh"
+#include "interaction.h"
 
 using namespace capamd;
 
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_TKS_WAVES) void drmmtks_forward_ke
   PairIds ids = pair_ids(a.ids, a.d64_b && b >= a.split ? b - a.split : b, a.Q, a.L);
   if (a.d64_b && b >= a.split) ids.d64 = a.d64_b + (int64_t)(b - a.split) * a.L;
 
-  // the document's distinct real terms with their multiplicities (interaction.cuh: distinct_terms): a repeated term is gathered once
+  // the document's distinct real terms with their multiplicities (interaction.h: distinct_terms): a repeated term is gathered once
   // and its similarity enters the top-k lists as many times as the document repeats it (at most k copies can matter)
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
   const int n_real = tl.n_unique;

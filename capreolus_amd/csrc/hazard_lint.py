@@ -1,6 +1,6 @@
 """Build-time check of the gfx950 code for the one hazard the assembler cannot see for us.
 
-The ring GEMMs issue their MFMAs as inline assembly (bert_gemm_ring16.cuh: Mfma16, "+a" accumulators) so that the register allocator
+The ring GEMMs issue their MFMAs as inline assembly (bert_gemm_ring16.h: Mfma16, "+a" accumulators) so that the register allocator
 leaves the 256 accumulator registers where they are.  The price: LLVM's hazard recogniser does not look inside an inline-assembly
 block, so it inserts no wait states between such an MFMA and a LATER, compiler-generated instruction that touches the MFMA's result -
 an accumulator it decided to copy or spill (v_accvgpr_read / v_accvgpr_mov) right behind the instruction that is still writing it.

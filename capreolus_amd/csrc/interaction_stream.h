@@ -20,7 +20,7 @@
 //   * a gathering wave that is done with pair i asks for the first row of pair i+1 BEFORE the barrier when the list wave has already
 //     published it (a generation word next to the list): the request then travels under the barrier and the other waves' last rows
 //     instead of starting a cold pipeline after it.  Purely a hint: nothing is consumed before the barrier.
-// The list comes out in the same order (first occurrence) as interaction.cuh: distinct_terms, the gather arithmetic is the same code
+// The list comes out in the same order (first occurrence) as interaction.h: distinct_terms, the gather arithmetic is the same code
 // (rows_dot / sim_from_dots = rows_sim_my): similarities are bit-identical to the one-pair-per-workgroup kernels.
 //
 // A model plugs in as a policy struct M (knrm.hip: KnrmStream, drmm.hip: DrmmStream):
@@ -35,7 +35,7 @@
 //   M::row(a, gs, x, entry, lds, buf, lane16) one gathered row: x = similarity of the lane's query term, entry = id | mult << 22
 //   M::pair_end(a, gs, lds, buf, wave, lane)  per pair: the wave's results into buffer `buf`
 #pragma once
-#include "interaction.cuh"
+#include "interaction.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>

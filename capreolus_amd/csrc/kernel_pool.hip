@@ -17,7 +17,7 @@
 //   d a_q      = sum_j d sim ( b_j / (na nb) - sim a_q / (|a_q| na) )            (na = |a_q| + 1e-9, nb = |b_j| + 1e-9; no gradient
 //   d b_j      = sum_q d sim ( a_q / (na nb) - sim b_j / (|b_j| nb) )             through a masked entry, whose similarity is the constant 0)
 #include "capreolus_amd.h"
-#include "interaction.cuh"
+#include "interaction.h"
 
 using namespace capamd;
 

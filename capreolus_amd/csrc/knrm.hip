@@ -11,7 +11,7 @@
 //                are listed in LDS in order of first occurrence, each with its multiplicity (a document
 //                repeats its frequent terms: 59 % distinct at 300 Zipf-distributed terms; a repeated
 //                term's row is gathered once, its kernel values multiplied by the count -
-//                interaction.cuh: distinct_terms); pads (id == 0) and OOV terms (id < 0)
+//                interaction.h: distinct_terms); pads (id == 0) and OOV terms (id < 0)
 //                are only counted: their similarity is exactly 0 (or exactly 1 for an OOV exact
 //                match, common.py:155-158) so their kernel-pooling contribution is added in
 //                closed form  n0[q]*K_k(0) + n1[q]*K_k(1)   (KNRM.py:50 sums over ALL positions).
@@ -23,8 +23,8 @@
 // HBM/L2 traffic per pair: L*8 B of ids + one packed row per real term; the [B,Q,L] similarity
 // and [B,K,Q,L] kernel tensors of the reference are never materialised.
 #include "capreolus_amd.h"
-#include "interaction.cuh"
-#include "interaction_stream.cuh"
+#include "interaction.h"
+#include "interaction_stream.h"
 #include <stdlib.h>
 
 using namespace capamd;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
   PairIds ids = pair_ids(a.ids, GRAD && a.d64_b && b >= a.split ? b - a.split : b, a.Q, a.L);
   if (GRAD && a.d64_b && b >= a.split) ids.d64 = a.d64_b + (int64_t)(b - a.split) * a.L;
 
-  // ---- phase 1: the document's distinct real terms with their multiplicities (interaction.cuh) ---------
+  // ---- phase 1: the document's distinct real terms with their multiplicities (interaction.h) ---------
   const TermList tl = distinct_terms(ids, a.L, a.V, a.status, tok, mult, hkey, hfirst, wave_cnt);
   const int n_real = CAPAMD_KNRM_ABLATE == 2 ? 0 : tl.n_unique;   // rows to gather (profiling builds: 2 = none)
   const int n_nonreal = a.L - tl.n_real;       // pads + OOV positions (closed form below)
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kThreads, MINW) void knrm_forward_kernel(KnrmArgs a
 
 
 // =====================================================================================================================================
-// Streaming form (interaction_stream.cuh): persistent five-wave workgroups, the model's part as a policy.
+// Streaming form (interaction_stream.h): persistent five-wave workgroups, the model's part as a policy.
 //   gathering waves: kernel sums of a pair in registers, the wave's four groups folded ((g0 + g1) + (g2 + g3)) into partial[buf][wave][16 lanes]
 //   list wave:       the four waves' partials + closed-form pad / OOV terms -> log -> sum over the query terms -> combine (KNRM.py:50-54)
 struct KnrmStream {

@@ -7,7 +7,7 @@
 //  in DESIGN.md section 3.5 / docs/history.md, and were removed in round 6; git history has the code.)
 #pragma once
 #include "capreolus_amd.h"
-#include "interaction.cuh"
+#include "interaction.h"
 #include <stdlib.h>
 #include <type_traits>
 

@@ -1,19 +1,19 @@
 // KNRM / DRMM / DRMM-TKS over whole CANDIDATE LISTS (one query, its first-stage documents) for gfx950 - what PytorchTrainer.predict
 // scores (reference capreolus/trainer/pytorch.py:310-353 over PredSampler's per-query lists, sampler/__init__.py:222-233; RerankTask
-// hands it up to 1000 documents per query, task/rerank.py:22-23).  PACRR's list entry is in pacrr.hip; the shared passes in lists.cuh.
+// hands it up to 1000 documents per query, task/rerank.py:22-23).  PACRR's list entry is in pacrr.hip; the shared passes in lists.h.
 //
-// The per-pair kernels (knrm.hip, drmm.hip, interaction_stream.cuh) gather one packed row per distinct term of every DOCUMENT: 179 rows
+// The per-pair kernels (knrm.hip, drmm.hip, interaction_stream.h) gather one packed row per distinct term of every DOCUMENT: 179 rows
 // = 229 KB per pair on the benchmark's lists, 14.7 GB per 64,000 pairs - and that gather is what they are bound by.  But the similarity
 // of a document term to the query depends on (query, term) only, and the 1000 documents of a list share their vocabulary: a list's
 // 303,000 tokens are ~50,000 distinct terms.  So per list:
 //   1  mark    every document of the list flags its real term ids in a byte map over the vocabulary (plain byte stores: racing writers
-//              write the same value)                                                                                    [lists.cuh]
+//              write the same value)                                                                                    [lists.h]
 //   2  sims    per (list, block of 1024 vocabulary ids): collect the flagged ids and for every one of them gather its packed row
 //              ONCE, the four similarities to the list's query by the SAME arithmetic as the per-pair kernels (rows_dot2_pk /
 //              sim_from_dots: bit-identical values) -> table[id]: the four floats, or DRMM's four histogram bins (a byte each: bin |
 //              exact-match bit) - the binning is done once per distinct term, not once per position.  Workgroups are numbered so
 //              that an XCD works on ONE id block of ALL lists at a time: the lists share most of a block's rows, so the rows come
-//              from that XCD's L2.                                                                                       [lists.cuh]
+//              from that XCD's L2.                                                                                       [lists.h]
 //   3  pool    every document, a WAVE each: its ids are requested together, then their table entries (two memory round trips per
 //              document - the per-pair kernels' chain entry -> row -> tail is one per ROW).  KNRM: a lane per (position, query term), K
 //              exponentials into per-lane sums; DRMM: a lane per position, four integer bin counts; DRMM-TKS: a lane per (position,
@@ -28,7 +28,7 @@
 // 17 B x V (6.8 MB at V = 400,001; 33 B x V for queries of five to eight terms) + 5 KB per block for its query; lists are processed in
 // groups of as many as the workspace holds (<= 256).  Q <= 8 (two blocks of kQT = 4 terms: the reference's `maxqlen` is a free option,
 // extractor/embedtext.py:28-31, and its forwards take any Q: reranker/KNRM.py:39-55, DRMM.py:101-116); other limits as the per-pair entries.
-#include "lists.cuh"
+#include "lists.h"
 #include "capamd_profiling.h"
 #include <vector>
 

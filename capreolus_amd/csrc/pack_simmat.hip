@@ -1,7 +1,7 @@
 // Embedding-table packing and the stand-alone similarity matrix (reference
 // capreolus/reranker/common.py:143-182; create_emb_layer common.py:279-288) for gfx950.
 #include "capreolus_amd.h"
-#include "interaction.cuh"
+#include "interaction.h"
 
 using namespace capamd;
 
@@ -9,7 +9,7 @@ namespace {
 
 // One 16-lane group per table row.  Writes the packed row and its den = |row|_2 + 1e-9f.
 // Sum-of-squares order: lane partial s = fma(v,v,s) over the lane's floats in increasing index,
-// then the same 16-lane tree as the dot product (interaction.cuh).
+// then the same 16-lane tree as the dot product (interaction.h).
 __global__ __launch_bounds__(kThreads) void pack_rows_kernel(const float* __restrict__ emb, int64_t V, int D, int64_t ld,
                                                               float* __restrict__ packed) {
   const int RS = row_stride_for_dim(D);

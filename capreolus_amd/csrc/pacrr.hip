@@ -30,8 +30,8 @@
 //                matrix instructions per 32 positions - and no convolutions further than one 64-position step behind the document's
 //                last term (see pacrr_mfma4_body).  The form above remains for Q = 5.
 #include "capreolus_amd.h"
-#include "interaction.cuh"
-#include "lists.cuh"
+#include "interaction.h"
+#include "lists.h"
 
 using namespace capamd;
 
@@ -138,7 +138,7 @@ __device__ __forceinline__ void pacrr_similarities(const PacrrArgs& a, const Pai
   }
 }
 
-// The same over the pair's DISTINCT terms (interaction.cuh: distinct_terms_positions): a term the document repeats is gathered once and its
+// The same over the pair's DISTINCT terms (interaction.h: distinct_terms_positions): a term the document repeats is gathered once and its
 // similarities are written to every position it occupies.
 template <int NV, int U, typename Put>
 __device__ __forceinline__ void pacrr_similarities_distinct(const PacrrArgs& a, const PairIds& ids, const int* tok, const unsigned short* start,
@@ -440,7 +440,7 @@ __host__ __device__ inline int pacrr_mfma_region0(int L, int n_weights) {
 }
 
 // KM = length of the per-lane candidate lists (>= kmax)
-// `table` != nullptr: the whole-list route (lists.cuh) - the pair's list has its terms' four similarities in table[id] already, and the
+// `table` != nullptr: the whole-list route (lists.h) - the pair's list has its terms' four similarities in table[id] already, and the
 // front end is a lookup per position instead of the distinct-term pass and the gather (same values: the matrix, and with it the score,
 // is bit-identical).
 template <int NV, int KM>
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma4_kern
   pacrr_mfma4_body<NV, KM>(a, blockIdx.x, nullptr);
 }
 
-// whole candidate lists: a workgroup per (list, document) in the XCD-aware numbering of lists.cuh
+// whole candidate lists: a workgroup per (list, document) in the XCD-aware numbering of lists.h
 template <int NV, int KM>
 __global__ __launch_bounds__(kThreads, CAPAMD_PACRR_WAVES) void pacrr_mfma_lists_kernel(PacrrArgs a, ListsArgs la, ListGeom g) {
   int l, doc;
@@ -1084,7 +1084,7 @@ extern "C" int capamd_pacrr_forward(const int64_t* q_ids, const int64_t* d_ids, 
   return hipGetLastError() == hipSuccess ? CAPAMD_OK : CAPAMD_ERR_LAUNCH;
 }
 
-/* PACRR over whole candidate lists (lists.cuh): mark -> sims (every distinct term of a list gathered once) -> the MFMA kernel with a
+/* PACRR over whole candidate lists (lists.h): mark -> sims (every distinct term of a list gathered once) -> the MFMA kernel with a
  * table lookup per position as its front end.  Q <= 4, nfilters <= 32 (the MFMA kernel's geometry); scores bit-identical to
  * capamd_pacrr_forward's. */
 extern "C" int capamd_pacrr_forward_lists(const int64_t* q_ids, const int64_t* d_ids, const int32_t* q_table, const int32_t* d_table,

@@ -300,7 +300,7 @@ class BertEngine:
         for layer in range(m.layers):
             ptrs = [keep[f"bert.encoder.layer.{layer}.{n}"].data_ptr() for n in _LAYER_TENSORS]
             # + the LayerNorm whose output feeds this layer (the previous layer's output LayerNorm; layer 0 reads the
-            # already normalised embeddings): folded into this layer's QKV / O-proj epilogues (bert_gemm.cuh)
+            # already normalised embeddings): folded into this layer's QKV / O-proj epilogues (bert_gemm.h)
             prev = [keep[f"bert.encoder.layer.{layer - 1}.output.LayerNorm.{n}"].data_ptr() for n in ("weight", "bias")] if layer > 0 else [None, None]
             arr = (ctypes.c_void_p * 18)(*(ptrs + prev))
             _lib.check(lib.capamd_bert_pack_layer(ctypes.byref(m), layer, arr, _ptr(blob), _ptr(lf32), _stream()), "capamd_bert_pack_layer")
@@ -490,7 +490,7 @@ _list_workspaces = {}
 # V = 4 M - 64 lists would be 4.3 GB, the 256 a launch group takes 17 GB): fewer lists are kept in flight when it would be exceeded (the library then works through the
 # lists in more, smaller groups).  The per-pair part (4 L + 32 bytes per pair of the call) comes on top.
 LISTS_WORKSPACE_BUDGET = 2 << 30
-LISTS_MAX_QLEN = 8          # query terms a whole-list call takes (csrc/lists.cuh: kListMaxQ; PACRR: 4)
+LISTS_MAX_QLEN = 8          # query terms a whole-list call takes (csrc/lists.h: kListMaxQ; PACRR: 4)
 
 
 def _lists_workspace(device, n_lists, V, n_pairs, L, Q=4):

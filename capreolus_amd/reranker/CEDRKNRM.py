@@ -1,5 +1,5 @@
 """CEDR-KNRM behind the reference plugin surface (capreolus/reranker/CEDRKNRM.py:188-217), scored by the gfx950 BERT encoder of
-ptBERTMaxP plus the kernels in capreolus_amd/csrc/cedr_tap.cuh / cedr.hip through the C ABI.
+ptBERTMaxP plus the kernels in capreolus_amd/csrc/cedr_tap.h / cedr.hip through the C ABI.
 
 The module holds the parameters under the reference's state_dict names (``bert.embeddings.*``, ``bert.encoder.layer.N.*``,
 ``bert.pooler.dense.*``, ``kernels.kernels.{k}.mu|sigma``, ``combine.{0,1}.weight|bias``, ``one``, ``zero``) so checkpoints

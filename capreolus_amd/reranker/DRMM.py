@@ -150,7 +150,7 @@ class DRMM(Reranker):
         return self.model.forward_indexed(store, pair_q, pair_d)
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmm_forward_lists)
-    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.cuh kListMaxQ)
+    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.h kListMaxQ)
     lists_bit_identical = True # (integer bin counts of bit-identical similarities)
 
     def test_lists(self, d, offsets):

@@ -107,7 +107,7 @@ class DRMMTKS(Reranker):
         return batch_size <= 1024 and bool(self.config["freezeemb"])
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_drmmtks_forward_lists)
-    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.cuh kListMaxQ)
+    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.h kListMaxQ)
     lists_bit_identical = True # (top-k selections of bit-identical similarities, fed to the Linear in the same order)
 
     def test_lists(self, d, offsets):

@@ -181,7 +181,7 @@ class KNRM(Reranker):
         return self.model.forward_indexed(store, pair_q, pair_d)
 
     supports_lists = True      # whole candidate lists: every distinct term of a list gathered once (capamd_knrm_forward_lists)
-    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.cuh kListMaxQ)
+    lists_max_qlen = 8         # (two blocks of four query terms: csrc/lists.h kListMaxQ)
 
     def test_lists(self, d, offsets):
         return self.model.forward_lists(offsets, query=d["query"], doc=d["posdoc"])

@@ -40,7 +40,7 @@ class Reranker:
     # `lists_bit_identical`: the list route's scores equal the per-pair route's bit for bit (what PytorchTrainer's `lists` = "exact" asks)
     lists_bit_identical = False
     # `lists_max_qlen`: query terms (the extractor's `maxqlen`) the list route takes - 8 for KNRM / DRMM / DRMM-TKS (two blocks of four
-    # terms, csrc/lists.cuh), 4 for PACRR's MFMA list kernel; longer queries are scored by the per-pair kernels (any length)
+    # terms, csrc/lists.h), 4 for PACRR's MFMA list kernel; longer queries are scored by the per-pair kernels (any length)
     lists_max_qlen = 4
 
     def build_model(self):

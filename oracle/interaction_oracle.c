@@ -14,7 +14,7 @@
  * Each function cites the reference lines (under capreolus/) it restates.
  *
  * Arithmetic order.  The similarity front end (pack, dot, cosine) reproduces, operation for
- * operation, the order documented in capreolus_amd/csrc/interaction.cuh — 16 "lane" partial
+ * operation, the order documented in capreolus_amd/csrc/interaction.h — 16 "lane" partial
  * fma chains combined by a balanced tree — so that GPU and oracle agree BIT FOR BIT on every
  * similarity and therefore exactly on DRMM's integer bin counts.  Everything downstream of the
  * similarities (kernel pooling sums, logs, MLPs) is done here in double precision with libm,

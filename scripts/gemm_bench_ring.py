@@ -1,5 +1,5 @@
 """The four BERT-base encoder GEMM shapes at the benchmark's micro-batch (M = 250 passages x 256 tokens) in ONE session:
-the ring kernel (bert_gemm_ring.cuh; chunk-major operands, 128-row tiles x 2 workgroups per CU and 256-row tiles x 1), the 8-wave
+the ring kernel (bert_gemm_ring.h; chunk-major operands, 128-row tiles x 2 workgroups per CU and 256-row tiles x 1), the 8-wave
 ping-pong kernel, and the vendor library on the same shape (torch.nn.functional.linear -> hipBLASLt, bias only).  Median of 20 timed
 launches after 5 warm-up launches, HIP events around each launch.  `profiles/r03/gemm_bench_vs_hipblaslt.txt` is this script's output."""
 import ctypes

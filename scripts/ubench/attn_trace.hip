@@ -1,11 +1,11 @@
-// Builder-side experiment: the S = 256 attention kernel (bert_attn.cuh: attention_s256_kernel) on its own, with per-phase s_memtime stamps.
+// Builder-side experiment: the S = 256 attention kernel (bert_attn.h: attention_s256_kernel) on its own, with per-phase s_memtime stamps.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icapreolus_amd/csrc -Iinclude scripts/ubench/attn_trace.hip -o scripts/ubench/attn_trace
 #define CAPAMD_ATTN_TRACE 1
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "bert_attn.cuh"
+#include "bert_attn.h"
 using namespace capamd;
 
 __global__ void fill(_Float16* p, size_t n, unsigned seed) {

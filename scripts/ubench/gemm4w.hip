@@ -1,5 +1,5 @@
 // Experiment (not part of the product path): K-loop rate of a 4-wave 256x256x64 tile (one wave per SIMD, 128x128 per wave,
-// 256 accumulator registers, LDS-DMA fill, double-buffered) next to the 8-wave ping-pong kernel of bert_gemm.cuh.
+// 256 accumulator registers, LDS-DMA fill, double-buffered) next to the 8-wave ping-pong kernel of bert_gemm.h.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/ubench/gemm4w.hip -o scripts/ubench/gemm4w && scripts/ubench/gemm4w
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -538,13 +538,13 @@ def test_gemm_at_benchmark_scale(N, K, epi, dt):
     out_cm, A_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(A)
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W), _p(bias), M, N, K, epi | 0x300, None, _p(out_cm), code, _stream()) == 0
     assert torch.equal(_from_cm(out_cm, M, N), out)
-    # weights chunk-major too -> the 4-wave ring kernel (bert_gemm_ring.cuh): same accumulation order, identical bits
+    # weights chunk-major too -> the 4-wave ring kernel (bert_gemm_ring.h): same accumulation order, identical bits
     out_ring, W_cm = torch.empty(M * N, dtype=tdt, device=DEV), _to_cm(W)
     for rows256 in (0, 0x1800):         # the 128-row tile (two workgroups per CU) and the 256-row tile (one) on 32x32x16 MFMAs
         out_ring.zero_()
         assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0x700 | rows256, None, _p(out_ring), code, _stream()) == 0
         assert torch.equal(out_ring, out_cm)
-    # the 256-row tile on 16x16x32 MFMAs (bert_gemm_ring16.cuh, round 5): k accumulated in steps of 32 - the reference's numbers to the
+    # the 256-row tile on 16x16x32 MFMAs (bert_gemm_ring16.h, round 5): k accumulated in steps of 32 - the reference's numbers to the
     # same tolerance, the other kernels' to one unit in the last place
     out_ring.zero_()
     assert _lib.load().capamd_bert_gemm(_p(A_cm), _p(W_cm), _p(bias), M, N, K, epi | 0xF00, None, _p(out_ring), code, _stream()) == 0

@@ -485,7 +485,7 @@ def test_full_size_drmm_properties(full):
 
 
 def _repeated_term_docs(L, V, seed):
-    """Documents that stress the distinct-term pass (interaction.cuh: distinct_terms): one term repeated over the whole document,
+    """Documents that stress the distinct-term pass (interaction.h: distinct_terms): one term repeated over the whole document,
     terms that all land in one hash bucket (longest probe chains), heavy repetition with OOV terms and pads mixed in, no repetition."""
     rng = np.random.default_rng(seed)
     ids = np.arange(1, V, dtype=np.int64)
