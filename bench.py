@@ -127,7 +127,7 @@ def main():
                 a2 = copy.copy(args)
                 a2.resident = True
                 rl = InteractionLeg(a2, ctx, "knrm", args.vocab, False, args.queries or 64, 2, 1 + ctx.rank)
-                r_elapsed, _ = rl.run(3, args.steps)
+                r_elapsed, _ = rl.run(3, args.steps, 3)      # (median of three repetitions: the first one after a leg's set-up runs 5-8 % slower)
                 rl.check_against_oracle(min(64, rl.n_pairs))
                 rec["resident_int32_route"] = {"value": rl.n_pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps,
                                                "step_streams": len(rl.step_side) or 1,
