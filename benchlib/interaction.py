@@ -321,7 +321,7 @@ def pmc_traffic(args, model, route="per_pair_hbm"):
     if exe is None:
         return None, "not measured: rocprofv3 not found"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-roofline-leg",
-             "--no-pmc-traffic", "--batches", "2", "--dim", str(args.dim)]
+             "--no-pmc-traffic", "--batches", "2", "--dim", str(args.dim), "--step-streams", "1"]
     if route == "per_pair_hbm":
         child += ["--uniform-ids", "--vocab", str(args.roofline_vocab)]
 

@@ -44,17 +44,39 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
         not args.per_pair and not uniform and n_queries >= 2
     offsets = np.arange(0, n_pairs + 1, args.docs, dtype=np.int64)
 
-    def step(_):
+    # consecutive steps round-robin over two HIP streams where the step is a call of few lists (benchlib/interaction.py):
+    # per-stream workspace (engine._lists_workspace) and score tensor
+    ns = getattr(args, "step_streams", 1)
+    if ns <= 0:
+        ns = 2 if n_queries <= 128 else 1
+    side = [torch.cuda.Stream(device=dev) for _ in range(ns)] if (ns > 1 and as_lists and not use_dist) else []
+
+    def score():
+        return m.forward_lists(offsets, query=q_all, doc=d_all, idf=idf_all).view(-1) if as_lists else m(d_all, q_all, idf_all).view(-1)
+
+    def step(i):
         with torch.no_grad():
-            out[0] = m.forward_lists(offsets, query=q_all, doc=d_all, idf=idf_all).view(-1) if as_lists else m(d_all, q_all, idf_all).view(-1)
+            if side:
+                with torch.cuda.stream(side[i % len(side)]):
+                    out[0] = score()
+            else:
+                out[0] = score()
         if use_dist:
             dist.all_gather_into_tensor(gathered, out[0])
+
+    def drain():
+        for st in side:
+            torch.cuda.current_stream().wait_stream(st)
 
     with torch.no_grad():
         m(d_all[:8], q_all[:8], idf_all[:8])          # packs the tables and checks the status word once, synchronously
     status = engine.deferred_status(dev)              # the timed calls are queued back to back like the KNRM / DRMM launches
     status.__enter__()                                # (check=False there); the accumulated status bits are raised at the end
-    elapsed, kern_s = timed_loop(ctx, step, warmup, steps)   # one scoring call = the model's kernel + a few tiny torch ops of the mirror
+    for k in range(len(side)):                        # (every stream's workspace and module load outside the timed region)
+        step(k)
+    drain()
+    elapsed, kern_s = timed_loop(ctx, step, warmup, steps, drain if side else None)   # one scoring call = the model's kernel + a few tiny torch ops of the mirror
+    torch.cuda.synchronize()
     assert os.environ.get("CAPAMD_BENCH_NOCHECK") == "1" or torch.isfinite(out[0]).all()   # (the knob: profiling builds that drop a phase of the kernel)
     status.__exit__(None, None, None)
     nonpad = float((d_all > 0).sum().item()) / n_pairs
@@ -80,7 +102,7 @@ def sibling_leg(args, ctx, model, V, uniform, steps, warmup, seed):
         row = G * (G + 1) // 2 * F * 4
     else:
         row = 4 * (m._packed.get(getattr(m, name).weight).numel() // V)
-    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad, as_lists, passes
+    return rr, m, batch, out[0], elapsed, kern_s, row, nonpad, as_lists, passes, len(side) or 1
 
 
 def sibling_oracle(model, m, D, q, d, idf, emb_h):
@@ -120,7 +142,7 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
     Q, L, V, D = 4, 800, args.vocab, args.dim
     n_queries = args.queries or 64
     n_pairs = n_queries * args.docs
-    rr, m, batch, scores, elapsed, kern_s, row, nonpad, as_lists, passes = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
+    rr, m, batch, scores, elapsed, kern_s, row, nonpad, as_lists, passes, n_streams = sibling_leg(args, ctx, model, V, args.uniform_ids, steps, warmup, 1 + rank)
     q_all, d_all, idf_all = batch["query"], batch["posdoc"], batch["query_idf"]
     emb = table(dev, V, D)
     if model == "convknrm":
@@ -180,7 +202,8 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{rr.module_name} inference (SURVEY.md §8f row N4) on the KNRM benchmark's lists: qlen={Q} dlen={L} embed={D} vocab={V}, "
                                f"{args.docs} docs/query x {n_queries} queries per step per GPU, {'uniform' if args.uniform_ids else 'Zipf(1.1)'} term ids, "
-                               + ("scored as whole candidate lists, " if as_lists else "") + "reference default model options",
+                               + ("scored as whole candidate lists, " if as_lists else "")
+                               + (f"consecutive steps round-robin over {n_streams} HIP streams, " if n_streams > 1 else "") + "reference default model options",
                    "pairs_per_step_per_gpu": n_pairs, "parallelism": f"query-sharded x{world}, one all_gather of scores per step" if world > 1 else "single GPU"},
         # `frac`: the HBM-bound leg (uniform ids over the --roofline-vocab table); on the Zipf ids of the headline leg the rate is a cache-level rate
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": hbm["achieved"] if hbm else (requested if args.uniform_ids else None), "peak": HBM_PEAK_GBS,
@@ -194,6 +217,8 @@ def bench_sibling(args, ctx, model=None, steps=None, warmup=None, with_cpu=None,
                              "around the timed steps); algorithmic = all L positions (pads are scored in closed form without a gather)"},
         "oracle_check": {"pairs": min(check_pairs, n_pairs), "max_err_of_scale": oracle_err},
     }
+    if n_streams > 1:
+        rec["step_streams"] = {"streams": n_streams}
     if lists_view is not None:      # the line's roofline = what its timed steps launch; the per-pair kernel's HBM-bound leg as the labelled secondary
         per_pair = rec["roofline"]
         per_pair["what"] = "SECONDARY, not what the timed steps launch: the one-pair-per-workgroup kernel on uniform ids over the --roofline-vocab table"

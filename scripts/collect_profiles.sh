@@ -1,11 +1,11 @@
 #!/bin/bash
 # Copies what scripts/gpu_round.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked).  Usage: collect_profiles.sh r04
 set -eu
-D=profiles/${1:-r05}
+D=profiles/${1:-r06}
 G=gpurun_out
 mkdir -p $D
-for f in default knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_r4mix drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; [ -f $G/bench_full_$f.json ] && cp $G/bench_full_$f.json $D/; done
-for m in knrm knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm cedrknrm train_ConvKNRM train_PACRR; do
+for f in default knrm_serial_steps knrm_b1000 knrm_b1000_serial drmm_b1000 bert bert_skip_padding bert_fp16 bert_one_stream bert_r4mix drmmtks pacrr convknrm cedrknrm cedrknrm_separate_layernorm; do cp $G/bench_$f.json $D/; [ -f $G/bench_full_$f.json ] && cp $G/bench_full_$f.json $D/; done
+for m in knrm knrm_step_streams knrm_roofline_leg drmm drmm_roofline_leg bert default drmmtks pacrr convknrm cedrknrm train_ConvKNRM train_PACRR; do
   f=$(ls $G/prof/$m/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $D/${m}_bench_kernel_stats.csv
 done
 for m in knrm knrm_roofline_leg drmm drmm_roofline_leg; do for c in fetch write tcc; do

@@ -5,7 +5,7 @@ mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 model=$1; shift
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg --no-pmc-traffic --model $model"
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-roofline-leg --no-pmc-traffic --step-streams 1 --model $model"
 for spec in "$@"; do
   name=${spec%%[:@]*}; envs=""; lib=""
   case "$spec" in *@*) lib=${spec##*@};; esac

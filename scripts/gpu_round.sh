@@ -1,6 +1,6 @@
 #!/bin/bash
-# One GPU-box session (round 5): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
-# (scripts/collect_profiles.sh r05 copies what is kept into profiles/r05/).  bench.py prints ONE compact line and writes the whole record
+# One GPU-box session (round 6): parity tests, smoke, the bench lines, rocprofv3 kernel stats + PMC traffic.  Outputs under gpurun_out/
+# (scripts/collect_profiles.sh r06 copies what is kept into profiles/r06/).  bench.py prints ONE compact line and writes the whole record
 # to bench_full.json: both are kept per run (bench_<name>.json = the line, bench_full_<name>.json = the record).
 set -u
 rm -rf gpurun_out/prof gpurun_out/ab_*.json; mkdir -p gpurun_out/prof
@@ -11,6 +11,7 @@ B="python $R/bench.py"
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
 # ---- bench lines -------------------------------------------------------------------------------------------------------
 timeout 600 $B --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_default.json; cp bench_full.json gpurun_out/bench_full_default.json 2>/dev/null
+timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --no-roofline-leg --step-streams 1 2>/dev/null | tail -1 > gpurun_out/bench_knrm_serial_steps.json; cp bench_full.json gpurun_out/bench_full_knrm_serial_steps.json 2>/dev/null
 timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000.json; cp bench_full.json gpurun_out/bench_full_knrm_b1000.json 2>/dev/null
 timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-pmc-traffic --launch-docs 1000 --launch-streams 1 --no-graph 2>/dev/null | tail -1 > gpurun_out/bench_knrm_b1000_serial.json; cp bench_full.json gpurun_out/bench_full_knrm_b1000_serial.json 2>/dev/null
 timeout 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-pmc-traffic --model drmm --launch-docs 1000 2>/dev/null | tail -1 > gpurun_out/bench_drmm_b1000.json; cp bench_full.json gpurun_out/bench_full_drmm_b1000.json 2>/dev/null
@@ -27,7 +28,7 @@ PYTHONPATH=$R timeout 300 python $R/scripts/train_step_bench.py 2>/dev/null | gr
 CAPAMD_CEDR_FUSED=0 PYTHONPATH=$R timeout 300 python $R/scripts/sibling_bench.py --only CEDRKNRM 2>/dev/null | tail -1 > gpurun_out/bench_cedrknrm_separate_layernorm.json; cp bench_full.json gpurun_out/bench_full_cedrknrm_separate_layernorm.json 2>/dev/null; cat gpurun_out/bench_cedrknrm_separate_layernorm.json
 python - <<'PY'
 import json
-for f in ("default", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_r4mix", "drmmtks", "pacrr", "convknrm"):
+for f in ("default", "knrm_serial_steps", "knrm_b1000", "knrm_b1000_serial", "drmm_b1000", "bert", "bert_skip_padding", "bert_fp16", "bert_one_stream", "bert_r4mix", "drmmtks", "pacrr", "convknrm"):
     try:
         r = json.load(open(f"gpurun_out/bench_{f}.json")); ro = r["roofline"]
         print(f"{f:20s} {r['value']:14.1f} {r['unit']}  ms/step {r['ms_per_step']:.3f}  roofline frac {ro.get('frac')}  {ro.get('whole_step_frac_nominal', '')}")
@@ -39,7 +40,8 @@ PY
 # ---- rocprofv3 kernel stats of the same commands (one kernel of interest per run, so that the average is that kernel's) -------
 cd /tmp; P=/tmp/prof; rm -rf $P; mkdir -p $P
 KS="rocprofv3 --kernel-trace --stats --output-format csv"
-timeout 300 $KS -d $P/knrm -o knrm -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-also --no-roofline-leg > /dev/null 2>&1
+timeout 300 $KS -d $P/knrm -o knrm -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-also --no-roofline-leg --step-streams 1 > /dev/null 2>&1      # (serial steps: a kernel's average is its own duration)
+timeout 300 $KS -d $P/knrm_step_streams -o knrm -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-also --no-roofline-leg --no-pass-times > /dev/null 2>&1      # (the default: two step streams - kernels of consecutive steps overlap and stretch)
 timeout 300 $KS -d $P/knrm_roofline_leg -o knrm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-roofline-leg --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
 timeout 300 $KS -d $P/drmm -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm > /dev/null 2>&1
 timeout 300 $KS -d $P/drmm_roofline_leg -o drmm -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-roofline-leg --model drmm --uniform-ids --vocab 4000001 --batches 2 > /dev/null 2>&1
