@@ -403,6 +403,10 @@ __global__ __launch_bounds__(128) void lists_query_kernel(ListsArgs a, ListGeom 
 // back: the lists share most of a block's rows, so the rows come from that XCD's L2.
 // What bounds it: the L2 -> CU gather of the rows (13.9 TB/s; profiles/r06/lists_sims_steps.txt has the round-6 rebuilds around
 // precomputed work lists and persistent workgroups, all slower).
+#ifndef CAPAMD_LISTS_SIMS_BALLAST
+#define CAPAMD_LISTS_SIMS_BALLAST 0     // KiB of dynamic LDS a workgroup of the sims pass is launched with and never uses: caps the pass's workgroups per
+                                        // CU, leaving wave slots and registers to the other step stream's kernels (A/B builds)
+#endif
 template <int NV, bool BINS, int QP>
 __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kernel(ListsArgs a, ListGeom g) {
   __shared__ __attribute__((aligned(16))) float4 qlds[QP][kQT * kMaxNV * 16];
@@ -578,8 +582,8 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
     lists_stamp(s);
     const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
 #define CAPAMD_SIMS_Q(NV, QP_)                                                                                  \
-  if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true, QP_>), sg, dim3(256), 0, s, a, g);                 \
-  else hipLaunchKernelGGL((lists_sims_kernel<NV, false, QP_>), sg, dim3(256), 0, s, a, g)
+  if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true, QP_>), sg, dim3(256), CAPAMD_LISTS_SIMS_BALLAST * 1024, s, a, g);   \
+  else hipLaunchKernelGGL((lists_sims_kernel<NV, false, QP_>), sg, dim3(256), CAPAMD_LISTS_SIMS_BALLAST * 1024, s, a, g)
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl, QP), dim3(128), 0, s, a, g);                              \
   lists_stamp(s);                                                                                               \
