@@ -2894,6 +2894,63 @@ def test_lists_random_geometries(D, Q, L, V, docs):
             assert torch.equal(r.test_lists(no_oov, off), r.test(no_oov))
 
 
+@pytest.mark.parametrize("case", ["same", "disjoint", "odd", "alone", "half"])
+def test_lists_sims_pairs_row_classes(case):
+    """lists_sims2_kernel (round 6: two lists per workgroup, a row both lists flag is gathered once) on lists built class by class: the
+    same vocabulary in both lists of a pair (every row in class "both"), disjoint vocabularies (no shared row: the groups of one wave work
+    for different lists), odd counts in every class (the last row of a class is done twice), a last list without a partner, and a pair of
+    which only ONE list has a two-term query (the two-term form needs both).  DRMM and DRMM-TKS must equal their per-pair kernels bit for
+    bit (the table entries are the per-pair kernels' similarities), KNRM to fp32 rounding of its sums."""
+    from capreolus_amd.reranker import DRMMTKS
+
+    V, D, Q, L = 2300, 300, 4, 60
+    emb = synthetic.make_embeddings(V, D, seed=11)
+    rs = np.random.RandomState({"same": 1, "disjoint": 2, "odd": 3, "alone": 4, "half": 5}[case])
+    n_lists, n_docs = (3 if case == "alone" else 4), 7
+    if case == "same":
+        vocab = [np.arange(1, V)] * n_lists
+    elif case == "disjoint":
+        vocab = [np.arange(1 + k, V, n_lists) for k in range(n_lists)]
+    elif case == "odd":      # per 1024-id block: 3 ids in both lists of a pair, 5 only in the first, 1 only in the second
+        both, first, second = [10, 500, 1023, 1030, 1500, 2047, 2050, 2100, 2299], [1, 2, 3, 4, 5, 1100, 1101, 1102, 1103, 1104, 2200, 2201, 2202, 2203, 2204], [700, 1700, 2250]
+        vocab = [np.array(both + first), np.array(both + second)] * 2
+    else:
+        vocab = [rs.choice(np.arange(1, V), size=400, replace=False) for _ in range(n_lists)]
+    q = np.zeros((n_lists * n_docs, Q), np.int64)
+    d = np.zeros((n_lists * n_docs, L), np.int64)
+    idf = np.zeros((n_lists * n_docs, Q), np.float32)
+    for k in range(n_lists):
+        nq = 2 if (case == "half" and k % 2 == 0) else 1 + (k + 2) % Q
+        qk = np.zeros(Q, np.int64)
+        qk[:nq] = rs.choice(vocab[k], size=nq)
+        ik = np.where(qk != 0, rs.uniform(0.5, 8.0, size=Q), 0.0).astype(np.float32)
+        for j in range(n_docs):
+            n = rs.randint(1, L + 1)
+            q[k * n_docs + j], idf[k * n_docs + j] = qk, ik
+            d[k * n_docs + j, :n] = rs.choice(vocab[k], size=n)
+    if case == "odd":        # every id of the class sets must occur
+        for k in range(n_lists):
+            d[k * n_docs, : len(vocab[k])] = vocab[k]
+    off = np.arange(0, n_lists * n_docs + 1, n_docs).astype(np.int64)
+    t = {"query": _t(q), "posdoc": _t(d), "query_idf": _t(idf)}
+    r = DRMM({}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(2)
+    r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(r.test_lists(t, off), r.test(t))
+    r = DRMMTKS({"topk": 5}, SimpleNamespace(embeddings=emb, config={"maxqlen": Q}, pad=0))
+    torch.manual_seed(2)
+    r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(r.test_lists(t, off), r.test(t))
+    r = KNRM({}, SimpleNamespace(embeddings=emb))
+    torch.manual_seed(2)
+    r.build_model().to(DEV).eval()
+    with torch.no_grad():
+        pairwise, lists = r.test(t).cpu().numpy(), r.test_lists(t, off).cpu().numpy()
+    assert np.abs(lists - pairwise).max() <= 2e-5 * float(np.abs(pairwise).max())
+
+
 @pytest.mark.parametrize("Q", [5, 6, 8])
 def test_lists_with_long_queries_through_predict(Q):
     """`PytorchTrainer.predict` on a run whose extractor was configured with `maxqlen` > 4 (reference extractor/embedtext.py:28-31): the
