@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
   if (lane == 0) wave_cnt[wave] = mine;
   __syncthreads();
   const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-  const int total = c0 + c1 + c2 + c3;
+  const int total = __builtin_amdgcn_readfirstlane(c0 + c1 + c2 + c3);      // (workgroup-uniform: an SGPR)
   if (total == 0) return;
   const int base = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
 #pragma unroll
@@ -488,7 +488,11 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
         float pa[kQT], pb[kQT];
         int qoff = 0;
         asm volatile("" : "+v"(qoff));
-        if (h > 0) {      // the rows as NEW values, whole 128-bit tuples (lists_sims2_kernel has the reason: 170 -> 1xx registers for QP = 2)
+        if (h > 0) {
+          // The rows are handed to the second block's pass as NEW values, as whole 128-bit tuples: hipcc otherwise keeps the {x, x} operand
+          // pairs it built for the first pass's packed fmas alive for the second (170 registers, three waves per SIMD; laundered float by
+          // float every value is copied to an even register for the operand pair: 132) - 86 registers and five waves this way (round 6:
+          // queries of eight terms 68 -> 90 M pairs/s)
 #pragma unroll
           for (int i = 0; i < NV; ++i) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -522,175 +526,13 @@ __global__ __launch_bounds__(256, CAPAMD_LISTS_SIMS_WAVES) void lists_sims_kerne
     else if (half[0]) trips(T{}, F{});
     else trips(F{}, F{});
   }
+  // (measured and not kept, round 6 - profiles/r06/lists_sims_{pairs,lead,ballast}_ab.txt: TWO lists per workgroup, a row both flag loaded once
+  //  (18 % fewer rows through the L1s: the pass 2 % shorter, its fabric reads doubled - twice as many id blocks in flight per XCD); the first
+  //  lists running 2-24 grid rows ahead so that shared rows' first touches are made early (equal); the pass capped at 4 / 3 / 2 workgroups per
+  //  CU under two step streams so that the other stream's passes co-reside (the cap costs what it costs alone))
   // (measured and not kept, rounds 3-5: one row per trip with the NEXT row requested before the current one is used - a software pipeline -
   //  4-5 % slower end to end; FOUR rows per trip 10 % slower; three rows per trip equal; 512 / 2048 ids per workgroup slower; the query
   //  rows in registers 30-70 % slower; the dot products on v_mfma_f32_4x4x1 through an LDS turn 40-60 % slower)
-}
-
-// TWO lists per workgroup (round 6; queries of up to four terms): a workgroup per (pair of lists 2 m, 2 m + 1; block of kSimsIds ids).  The
-// lists of a call share a large part of their vocabulary - on the benchmark's lists a fifth of all (list, term) rows is a row its
-// neighbour list needs too (profiles/r06/lists_sims_pairs.txt) - and what binds the pass is the L2 -> CU gather of the rows: a row both
-// lists flag is loaded ONCE and its similarities to both queries computed from the same registers.  The block's flagged ids are
-// compacted by class - in both lists | only in the first | only in the second -, a 16-lane group takes two rows of one class per trip:
-//   both:  rows_dot2_pk against the first list's image, then against the second's (two table entries per row);
-//   one:   rows_dot2_pk against its list's image - the image, the owned term's id / norm and the table are selected per GROUP, so
-//          groups working for the first and for the second list share a wave.
-// Per (row, list) exactly the arithmetic of lists_sims_kernel (rows_dot2_pk / sim_from_dots): bit-identical tables.
-// Measured (profiles/r06/lists_sims_pairs_ab.txt): a fifth fewer row loads buys 2 % of the pass (287 against 293 us; DRMM's call +1-2 %) -
-// the pass is not bound by the bytes the L1s pull from L2 but by how long a trip's loads take to come back.  Also measured, not kept
-// (lists_sims_lead_ab.txt, lists_sims_ballast_ab.txt): the first pair of lists running 2-24 rows of the grid ahead of the others, so
-// that the first touches of the rows they share are made early (equal or slower); the pass capped at 4 / 3 / 2 workgroups per CU under
-// two step streams, so that the other stream's passes co-reside (the streams' gain stays +9 %, the cap costs what it costs alone).
-#ifndef CAPAMD_LISTS_SIMS_PAIRS
-#define CAPAMD_LISTS_SIMS_PAIRS 1      // 0: one list per workgroup (lists_sims_kernel) for every call (A/B builds)
-#endif
-#ifndef CAPAMD_LISTS_SIMS2_WAVES
-#define CAPAMD_LISTS_SIMS2_WAVES 5     // waves per SIMD the register allocation aims at (96 registers; left alone the kernel lands on 98 - a wave less)
-#endif
-template <int NV, bool BINS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPAMD_LISTS_SIMS2_WAVES, 8))) void lists_sims2_kernel(ListsArgs a, ListGeom g) {
-  constexpr int kImg = kQT * kMaxNV * 16;
-  __shared__ __attribute__((aligned(16))) float4 qlds[2 * kImg];
-  __shared__ int lst[kSimsIds + 4];       // [both | first only (padded to an even count) | second only]: at most kSimsIds + 1 entries
-  __shared__ int wave_cnt[3][4];
-  __shared__ float edges[kMaxBins];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane16 = tid & 15, grp = tid >> 4;
-  const int l0 = 2 * (blockIdx.x >> 3), blk = blockIdx.y * 8 + (blockIdx.x & 7);
-  if ((int64_t)blk * kSimsIds >= a.Vp) return;
-  const bool two = l0 + 1 < a.nl;
-  const int l1 = two ? l0 + 1 : l0;
-  const int id0 = blk * kSimsIds;
-  constexpr int kPer = kSimsIds / 256;
-  static_assert(kPer == 4, "lists_sims2_kernel reads a thread's four flag bytes of each list as one word (kSimsIds = 1024)");
-  const uint32_t fw0 = *reinterpret_cast<const uint32_t*>(a.flags + (int64_t)l0 * a.Vp + id0 + tid * kPer);
-  const uint32_t fw1 = two ? *reinterpret_cast<const uint32_t*>(a.flags + (int64_t)l1 * a.Vp + id0 + tid * kPer) : 0u;
-  for (int i = tid; i < kQT * NV * 16; i += 256) {
-    qlds[i] = a.qimg[(int64_t)l0 * kQueryImage + i];
-    qlds[kImg + i] = a.qimg[(int64_t)l1 * kQueryImage + i];
-  }
-  QueryPass<NV> q0, q1;      // (only den_my / id_my are used)
-  q0.den_my = a.qmeta[l0].den[lane16 & 3];
-  q0.id_my = a.qmeta[l0].id[lane16 & 3];
-  q1.den_my = a.qmeta[l1].den[lane16 & 3];
-  q1.id_my = a.qmeta[l1].id[lane16 & 3];
-  if (BINS && tid < a.nbins) edges[tid] = a.edges[tid];
-  // the flagged ids by class, dense, in LDS: per class and flag byte one ballot, the lane's slot = the set lanes below it
-  int slot[3][kPer], mine[3] = {0, 0, 0};
-  unsigned cls[kPer];
-#pragma unroll
-  for (int c = 0; c < kPer; ++c) cls[c] = (((fw0 >> (8 * c)) & 0xffu) ? 1u : 0u) | (((fw1 >> (8 * c)) & 0xffu) ? 2u : 0u);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned want = k == 0 ? 3u : k == 1 ? 1u : 2u;
-#pragma unroll
-    for (int c = 0; c < kPer; ++c) {
-      const uint64_t set = __ballot(cls[c] == want);
-      slot[k][c] = mine[k] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(set >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)set, 0u));
-      mine[k] += __builtin_popcountll(set);
-    }
-  }
-  if (lane < 3) wave_cnt[lane][wave] = lane == 0 ? mine[0] : lane == 1 ? mine[1] : mine[2];
-  __syncthreads();
-  int n[3], base[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int c0 = wave_cnt[k][0], c1 = wave_cnt[k][1], c2 = wave_cnt[k][2], c3 = wave_cnt[k][3];
-    n[k] = c0 + c1 + c2 + c3;
-    base[k] = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
-  }
-  if (n[0] + n[1] + n[2] == 0) return;
-  const int o1 = n[0], o2 = n[0] + ((n[1] + 1) & ~1);      // where the one-list classes start (the first padded to whole pairs)
-#pragma unroll
-  for (int c = 0; c < kPer; ++c) {
-    const int off = cls[c] == 3u ? base[0] + slot[0][c] : cls[c] == 1u ? o1 + base[1] + slot[1][c] : o2 + base[2] + slot[2][c];
-    if (cls[c]) lst[off] = tid * kPer + c;
-  }
-  __syncthreads();
-  float* tab0 = reinterpret_cast<float*>(a.table + (int64_t)l0 * a.Vp);
-  float* tab1 = reinterpret_cast<float*>(a.table + (int64_t)l1 * a.Vp);
-  uint8_t* tabb0 = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l0 * a.Vp);
-  uint8_t* tabb1 = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(a.table) + (int64_t)l1 * a.Vp);
-  auto put = [&](float* tab, uint8_t* tabb, int id, float sm) {        // lane t < 4 of the group: the similarity of query term t
-    if (lane16 < kQT) {
-      if (BINS) {
-        const unsigned bin = (unsigned)list_bin_of(sm, edges, a.nbins) | ((sm > 0.999f && sm < 1.001f) ? kBinExact : 0u);
-        tabb[(int64_t)id * 4 + lane16] = (uint8_t)bin;
-      } else {
-        tab[(int64_t)id * 4 + lane16] = sm;
-      }
-    }
-  };
-  // (a block needs only the first pair's dot products when query terms 2 and 3 are not real, lists_sims_kernel; here when that holds for BOTH lists)
-  const bool half = CAPAMD_LISTS_SIMS_HALF && a.qmeta[l0].id[2] <= 0 && a.qmeta[l0].id[3] <= 0 && a.qmeta[l1].id[2] <= 0 && a.qmeta[l1].id[3] <= 0;
-  const int P3 = (n[0] + 1) >> 1, P1 = (n[1] + 1) >> 1, P2 = (n[2] + 1) >> 1;
-  auto trips = [&](auto H) {
-    constexpr int NP = decltype(H)::value ? 1 : 2, NT = decltype(H)::value ? 2 : kQT;
-    // rows both lists flag: loaded once, two entries each
-#pragma clang loop unroll(disable)
-    for (int p = grp; p < P3; p += kGroupsPerWG) {
-      const int ida = id0 + lst[2 * p], idb = id0 + lst[2 * p + 1 < n[0] ? 2 * p + 1 : 2 * p];      // (an odd last row is done twice)
-      RowRegs<NV> da, db;
-#ifdef CAPAMD_LISTS_ABL_HOTROWS
-      load_row<NV>(a.packed, 1 + (ida & 15), lane16, da);
-      load_row<NV>(a.packed, 1 + (idb & 15), lane16, db);
-#else
-      load_row<NV>(a.packed, ida, lane16, da);
-      load_row<NV>(a.packed, idb, lane16, db);
-#endif
-      const float dena = row_den<NV>(da), denb = row_den<NV>(db);
-      float pa[kQT], pb[kQT];
-      int qoff = 0;
-      asm volatile("" : "+v"(qoff));
-      rows_dot2_pk<NV, NP>(da, db, qlds + qoff, lane16, pa, pb);
-      put(tab0, tabb0, ida, sim_from_dots<NV, NT>(pa, dena, q0, lane16));
-      put(tab0, tabb0, idb, sim_from_dots<NV, NT>(pb, denb, q0, lane16));
-      // (the rows are handed to the second pass as NEW values: hipcc otherwise keeps the {x, x} operand pairs it built for the first pass's
-      //  packed fmas alive for the second - 132 registers instead of 9x, a wave less per SIMD)
-      // (as whole 128-bit tuples: laundered float by float, every value is copied to an even register for the packed fma's operand pair)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 ta = {da.v[i].x, da.v[i].y, da.v[i].z, da.v[i].w}, tb = {db.v[i].x, db.v[i].y, db.v[i].z, db.v[i].w};
-        asm volatile("" : "+v"(ta), "+v"(tb));
-        da.v[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
-        db.v[i] = make_float4(tb.x, tb.y, tb.z, tb.w);
-      }
-      qoff = kImg;
-      asm volatile("" : "+v"(qoff));
-      rows_dot2_pk<NV, NP>(da, db, qlds + qoff, lane16, pa, pb);
-      put(tab1, tabb1, ida, sim_from_dots<NV, NT>(pa, dena, q1, lane16));
-      put(tab1, tabb1, idb, sim_from_dots<NV, NT>(pb, denb, q1, lane16));
-    }
-    // rows one list flags: the list is the GROUP's (pairs of the first list's rows, then pairs of the second's)
-#pragma clang loop unroll(disable)
-    for (int p = grp; p < P1 + P2; p += kGroupsPerWG) {
-      const bool second = p >= P1;
-      const int pp = second ? p - P1 : p, o = second ? o2 : o1, nn = second ? n[2] : n[1];
-      const int ida = id0 + lst[o + 2 * pp], idb = id0 + lst[o + (2 * pp + 1 < nn ? 2 * pp + 1 : 2 * pp)];
-      RowRegs<NV> da, db;
-#ifdef CAPAMD_LISTS_ABL_HOTROWS
-      load_row<NV>(a.packed, 1 + (ida & 15), lane16, da);
-      load_row<NV>(a.packed, 1 + (idb & 15), lane16, db);
-#else
-      load_row<NV>(a.packed, ida, lane16, da);
-      load_row<NV>(a.packed, idb, lane16, db);
-#endif
-      const float dena = row_den<NV>(da), denb = row_den<NV>(db);
-      float pa[kQT], pb[kQT];
-      int qoff = second ? kImg : 0;
-      asm volatile("" : "+v"(qoff));
-      rows_dot2_pk<NV, NP>(da, db, qlds + qoff, lane16, pa, pb);
-      QueryPass<NV> qs;
-      qs.den_my = second ? q1.den_my : q0.den_my;
-      qs.id_my = second ? q1.id_my : q0.id_my;
-      float* tab = second ? tab1 : tab0;
-      uint8_t* tabb = second ? tabb1 : tabb0;
-      put(tab, tabb, ida, sim_from_dots<NV, NT>(pa, dena, qs, lane16));
-      put(tab, tabb, idb, sim_from_dots<NV, NT>(pb, denb, qs, lane16));
-    }
-  };
-  if (half) trips(std::true_type{});
-  else trips(std::false_type{});
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
@@ -756,19 +598,14 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       else hipLaunchKernelGGL(lists_mark_kernel<false>, list_doc_grid(nl, am.longest), dim3(256), 0, s, am, g);
     }
     lists_stamp(s);
-    const bool pairs = CAPAMD_LISTS_SIMS_PAIRS && nl >= 2 && kSimsIds == 1024;
     const dim3 sg((unsigned)nl * 8, (unsigned)((Vp / kSimsIds + 7) / 8));
-    const dim3 sg2((unsigned)((nl + 1) / 2) * 8, sg.y);      // two lists per workgroup (lists_sims2_kernel)
 #define CAPAMD_SIMS_Q(NV, QP_)                                                                                  \
   if (edges) hipLaunchKernelGGL((lists_sims_kernel<NV, true, QP_>), sg, dim3(256), CAPAMD_LISTS_SIMS_BALLAST * 1024, s, a, g);   \
   else hipLaunchKernelGGL((lists_sims_kernel<NV, false, QP_>), sg, dim3(256), CAPAMD_LISTS_SIMS_BALLAST * 1024, s, a, g)
-#define CAPAMD_SIMS2(NV)                                                                                        \
-  if (edges) hipLaunchKernelGGL((lists_sims2_kernel<NV, true>), sg2, dim3(256), 0, s, a, g);                    \
-  else hipLaunchKernelGGL((lists_sims2_kernel<NV, false>), sg2, dim3(256), 0, s, a, g)
 #define CAPAMD_SIMS(NV)                                                                                         \
   hipLaunchKernelGGL(lists_query_kernel<NV>, dim3(nl, QP), dim3(128), 0, s, a, g);                              \
   lists_stamp(s);                                                                                               \
-  if (QP == 1 && pairs) { CAPAMD_SIMS2(NV); } else if (QP == 1) { CAPAMD_SIMS_Q(NV, 1); } else { CAPAMD_SIMS_Q(NV, 2); }
+  if (QP == 1) { CAPAMD_SIMS_Q(NV, 1); } else { CAPAMD_SIMS_Q(NV, 2); }
     switch (nv_for_dim(D)) {
       case 1: CAPAMD_SIMS(1); break;
       case 2: CAPAMD_SIMS(2); break;
@@ -777,7 +614,6 @@ int lists_run(const IdSource& ids, const int64_t* offsets_host, int n_lists, int
       default: CAPAMD_SIMS(5); break;
     }
 #undef CAPAMD_SIMS
-#undef CAPAMD_SIMS2
 #undef CAPAMD_SIMS_Q
     lists_stamp(s);
     pool(a, g, nl, longest);

@@ -2895,12 +2895,12 @@ def test_lists_random_geometries(D, Q, L, V, docs):
 
 
 @pytest.mark.parametrize("case", ["same", "disjoint", "odd", "alone", "half"])
-def test_lists_sims_pairs_row_classes(case):
-    """lists_sims2_kernel (round 6: two lists per workgroup, a row both lists flag is gathered once) on lists built class by class: the
-    same vocabulary in both lists of a pair (every row in class "both"), disjoint vocabularies (no shared row: the groups of one wave work
-    for different lists), odd counts in every class (the last row of a class is done twice), a last list without a partner, and a pair of
-    which only ONE list has a two-term query (the two-term form needs both).  DRMM and DRMM-TKS must equal their per-pair kernels bit for
-    bit (the table entries are the per-pair kernels' similarities), KNRM to fp32 rounding of its sums."""
+def test_lists_sims_neighbouring_lists_row_classes(case):
+    """The sims pass on neighbouring lists built class by class (written for round 6's two-lists-per-workgroup kernel, which was measured
+    and removed - profiles/r06/lists_sims_pairs_ab.txt; kept for the one-list kernel): the same vocabulary in both lists of a pair,
+    disjoint vocabularies, odd counts of shared / unshared rows per 1024-id block (an odd last row is done twice), an odd number of lists,
+    and neighbouring lists of which only ONE has a two-term query (the two-term form of the dot products).  DRMM and DRMM-TKS must equal
+    their per-pair kernels bit for bit (the table entries are the per-pair kernels' similarities), KNRM to fp32 rounding of its sums."""
     from capreolus_amd.reranker import DRMMTKS
 
     V, D, Q, L = 2300, 300, 4, 60
