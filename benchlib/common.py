@@ -141,21 +141,22 @@ KERNEL_EVAL_PEAK_G = 8529.0
 KERNEL_EVAL_PEAK_SOURCE = ("scripts/ubench/valu_rates.hip, 4-instruction form (fma mul exp add), 16 waves per CU: 8,529 G evaluations/s "
                            "(8,160 at 8 waves per CU, 8,735 at 32; the kernel runs 24): profiles/r05/valu_rates.txt")
 SIMS_PIPE = "valu"             # the pipe the sims pass's dot products run on ("mfma" once they are v_mfma_f32_4x4x1_16b_f32)
-# What binds the sims pass: the L2 -> CU gather of the packed rows.  Every (list, distinct term) pair is one 1280-byte row through the
-# vector L1: 4.0 GB per call on the benchmark's lists, at 13.9 TB/s in round 5's kernel - 0.40 of the L2's 34.5 TB/s peak
-# (MI355X_MICROARCH.md section L2) and 0.90 of the 15.5 TB/s a gather-only kernel reaches on the same kind of request stream (round 3's
-# probe).  Round 6 rebuilt the pass five ways around precomputed work lists (persistent waves / workgroups, ticket
-# queues, cross-ticket prefetch: profiles/r06/lists_sims_steps.txt): every form that kept the tables bit-identical was slower - with every
-# row in L1 the pass takes 211-225 us whatever its structure (4 GB through the vector L1, 8 GB of LDS query reads and 69 M VALU
-# wave-instructions overlap imperfectly), and a software queue widens the window of cells in flight per XCD beyond what its 4 MB L2 holds.
-# The fp32 VALU figure (27.9 TF/s = 0.18 of 157.3) is kept beside it: the arithmetic would allow 51 us if rows were free.
+# What binds the sims pass: the L2 -> CU gather of the packed rows - its LATENCY, not its bytes.  Every (list, distinct term) pair is one
+# 1280-byte row through the vector L1: 4.0 GB per call on the benchmark's lists at 13.4-14.7 TB/s - 0.40 of the L2's 34.5 TB/s peak
+# (MI355X_MICROARCH.md section L2), 0.87-0.95 of the 15.5 TB/s a gather-only kernel reaches on the same kind of request stream (round 3's
+# probe).  Round 6 rebuilt the pass six ways around precomputed work lists (profiles/r06/lists_sims_steps.txt: all
+# slower; with every row in L1 the pass takes 211-225 us whatever its structure), then took bytes away and the time stayed: two lists per
+# workgroup with their shared rows loaded once pull 18 % fewer rows through the L1s for 2 % of the pass's time, and an L2 hit rate of 0.67
+# instead of 0.84 does not show either (lists_sims_pairs_ab.txt).  What the pass waits for is a trip's loads coming back, with five waves per
+# SIMD to cover them.  The fp32 VALU figure (27.9 TF/s = 0.18 of 157.3) is kept beside it: the arithmetic would allow 51 us if rows were free.
 L2_PEAK_GBS = 34500.0            # aggregate of the eight XCDs' L2s (MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s)
 GATHER_CEILING_GBS = 15500.0     # what a gather-only kernel of 1280-byte rows reaches from L2 / Infinity Cache (profiles/r03: stream gather probe)
-SIMS_LIMITER = {"bound": "l2 gather: one 1280-byte packed row per (list, distinct term) through the vector L1; the rows of a call (4.0 GB on the benchmark's "
-                         "lists) over the pass's duration against the L2's 34.5 TB/s, with the gather-only ceiling (15.5 TB/s) beside it",
+SIMS_LIMITER = {"bound": "l2 gather (its latency): one 1280-byte packed row per (list, distinct term) through the vector L1; the rows of a call (4.0 GB on the "
+                         "benchmark's lists) over the pass's duration against the L2's 34.5 TB/s, with the gather-only ceiling (15.5 TB/s) beside it",
                 "valu_issue_utilisation": 0.52, "l2_hit_rate": 0.84,
                 "waves_waiting_over_issuing": 2.9, "packed_fma_share_of_valu_instructions": 0.37,
-                "source": "profiles/r05/pmc_lists_knrm.txt (builder-run counter passes); profiles/r06/lists_sims_steps.txt (the rebuilds and their ablations)"}
+                "source": "profiles/r05/pmc_lists_knrm.txt (builder-run counter passes); profiles/r06/lists_sims_steps.txt, lists_sims_pairs_ab.txt (the rebuilds, "
+                          "their ablations, the byte-saving forms)"}
 
 
 class Ctx1:
