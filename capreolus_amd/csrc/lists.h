@@ -337,6 +337,11 @@ __device__ __forceinline__ DocWalk doc_walk(const ListsArgs& a, int b, const int
 }
 template <int TRIPS, int STRIDE>
 __device__ __forceinline__ void load_pass(const DocWalk& w, int j0, int ps, int (&id)[TRIPS]) {
+#ifdef CAPAMD_POOL_ABL_IDS      // ablation: the pass's ids without a load (what the pooling costs without its id round trips)
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) id[u] = (j0 + u * STRIDE + ps < w.n) ? 1 + ((j0 + u * STRIDE + ps) * 37 + (int)(reinterpret_cast<uintptr_t>(w.row) >> 6)) % 40000 : 0;
+  return;
+#endif
   if (kCompactRows) load_pass_cids<TRIPS, STRIDE>(w.row, j0, ps, w.n, id);
   else load_pass_rows<TRIPS, STRIDE>(w.ids, j0, ps, w.n, w.V, id);
 }
