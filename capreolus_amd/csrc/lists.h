@@ -303,17 +303,21 @@ __device__ __forceinline__ void load_pass_rows(const PairIds& ids, int j0, int p
 }
 
 // the compact ids of one pass of a pooling kernel - TRIPS trips of STRIDE consecutive entries, this lane's slot `ps`; 0 beyond the row's n
+#ifndef CAPAMD_POOL_CID_NT
+#define CAPAMD_POOL_CID_NT 1      // the compact id rows are read once: nontemporal loads (0: plain loads - A/B builds)
+#endif
+__device__ __forceinline__ int cid_load(const int32_t* p) { return CAPAMD_POOL_CID_NT ? __builtin_nontemporal_load(p) : *p; }
 template <int TRIPS, int STRIDE>
 __device__ __forceinline__ void load_pass_cids(const int32_t* row, int j0, int ps, int n, int (&id)[TRIPS]) {
   if (j0 + TRIPS * STRIDE <= n) {
     const int32_t* p = row + j0 + ps;
 #pragma unroll
-    for (int u = 0; u < TRIPS; ++u) id[u] = __builtin_nontemporal_load(p + u * STRIDE);
+    for (int u = 0; u < TRIPS; ++u) id[u] = cid_load(p + u * STRIDE);
   } else {
 #pragma unroll
     for (int u = 0; u < TRIPS; ++u) {
       const int j = j0 + u * STRIDE + ps;
-      id[u] = __builtin_nontemporal_load(row + (j < n ? j : 0));
+      id[u] = cid_load(row + (j < n ? j : 0));
     }
 #pragma unroll
     for (int u = 0; u < TRIPS; ++u) id[u] = (j0 + u * STRIDE + ps < n) ? id[u] : 0;

@@ -80,9 +80,10 @@ struct KnrmPoolArgs {
 // (bank conflicts of 64 random ds_reads: 227 -> 281 us), eight documents per wave (261), a prefetch of the next pass's ids, 4 / 12 / 16
 // trips per pass.
 #ifndef CAPAMD_POOL_TRIPS
-#define CAPAMD_POOL_TRIPS 8
+#define CAPAMD_POOL_TRIPS 6       // 8 until round 6: 163 -> 158 us (5 the same, 7: 163, 3-4: 163-167, 12: 190; profiles/r06/lists_pool_ablation.txt)
 #endif
-constexpr int kWaveTrips = CAPAMD_POOL_TRIPS;      // 128 positions per pass
+constexpr int kWaveTrips = CAPAMD_POOL_TRIPS;      // KNRM: 96 positions per pass (queries of three or four real terms; 192 / 384 with two / one)
+constexpr int kTksTrips = 8;                       // DRMM-TKS's pooling kernel: 128 positions per pass
 
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
@@ -130,8 +131,11 @@ __device__ __forceinline__ void knrm_pool_walk(const DocWalk& dw, int n, int lan
 }
 
 // KK: kernels the loops run over (11 - the model's default bank - or kMaxK, slots beyond K repeating the last kernel)
+#ifndef CAPAMD_POOL_WAVES
+#define CAPAMD_POOL_WAVES 1      // waves per SIMD the KNRM pooling kernel's register allocation aims at (1: whatever it needs - A/B builds)
+#endif
 template <int KK, int QP>
-__global__ __launch_bounds__(256) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAPAMD_POOL_WAVES, 8))) void lists_knrm_pool_kernel(ListsArgs a, ListGeom g, KnrmPoolArgs m) {
   int l, dq;
   if (!list_doc_of(a, l, dq)) return;       // (a.longest counts groups of 4 documents here)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane >> 4, k = lane & 15;
@@ -568,21 +572,21 @@ __global__ __launch_bounds__(256) void lists_tks_pool_kernel(ListsArgs a, ListGe
     float top[KT];
 #pragma unroll
     for (int i = 0; i < KT; ++i) top[i] = -INFINITY;
-    for (int j0 = 0; j0 < n; j0 += 16 * kWaveTrips) {
-      int id[kWaveTrips];
-      load_pass<kWaveTrips, 16>(dw, j0, ps, id);
-      float s[kWaveTrips];
+    for (int j0 = 0; j0 < n; j0 += 16 * kTksTrips) {
+      int id[kTksTrips];
+      load_pass<kTksTrips, 16>(dw, j0, ps, id);
+      float s[kTksTrips];
 #pragma unroll
 #ifdef CAPAMD_POOL_ABL_FOLD      // ablation: every lookup lands in the table's first 16 KB (what the pooling costs without its cache misses)
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * (4 * QP)];
+      for (int u = 0; u < kTksTrips; ++u) s[u] = tab[(int64_t)(id[u] & 1023) * (4 * QP)];
 #else
-      for (int u = 0; u < kWaveTrips; ++u) s[u] = tab[(int64_t)id[u] * (4 * QP)];     // (entry 0 is never written and never used)
+      for (int u = 0; u < kTksTrips; ++u) s[u] = tab[(int64_t)id[u] * (4 * QP)];     // (entry 0 is never written and never used)
 #endif
       // (pinned here: left alone, hipcc sinks each load into the branch that uses it, where it is issued and waited for one trip at a time)
 #pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) asm volatile("" : "+v"(s[u]));
+      for (int u = 0; u < kTksTrips; ++u) asm volatile("" : "+v"(s[u]));
 #pragma unroll
-      for (int u = 0; u < kWaveTrips; ++u) {
+      for (int u = 0; u < kTksTrips; ++u) {
         if (j0 + u * 16 >= n) continue;          // (wave-uniform)
         if (id[u] > 0) sorted_insert<KT>(top, s[u]);
       }

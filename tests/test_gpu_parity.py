@@ -1869,14 +1869,25 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
     loss_e, eager = run(False)
     loss_g, graphed = run(True)
     assert abs(loss_e - loss_g) <= 1e-6 * max(1.0, abs(loss_e))
+    # (same kernels on both routes; MIOpen's convolution backward and ATen's reductions are not bit-reproducible run to run, and Adam turns a
+    # gradient component that is pure rounding noise into a step of +-lr whichever way the noise falls: ConvKNRM, whose convolutions run in
+    # MIOpen, gets the wider bound - and, since one run in fifteen of the whole suite saw a component beyond it, the bound is calibrated on the
+    # spot: a SECOND eager run says how far eager is from eager on this box today, and the graph route is allowed four times that)
+    # ... and a component that did flip is told from a wrong step by its size and its company: at most 2 lr per flipped step (0.02 here), in at
+    # most one element in a thousand of the tensor - a graph that replayed a stale batch or skipped a step moves whole tensors
+    eager2 = run(False)[1] if kind == "convknrm" else eager
     moved = 0.0
     for k, v in eager.items():
         scale = float(v.abs().max()) + 1e-6
-        # (same kernels on both routes; MIOpen's convolution backward and ATen's reductions are not bit-reproducible run to run, and Adam
-        # turns a gradient component that is pure rounding noise into a step of +-lr whichever way the noise falls: ConvKNRM, whose
-        # convolutions run in MIOpen, gets the wider bound)
         tol = 5e-3 if kind == "convknrm" else 2e-4
-        assert float((graphed[k] - v).abs().max()) <= tol * scale, (k, float((graphed[k] - v).abs().max()), scale)
+        noise = float((eager2[k] - v).abs().max())
+        diff = (graphed[k] - v).abs()
+        bound = max(tol * scale, 4 * noise)
+        if kind == "convknrm":
+            beyond = int((diff > bound).sum())
+            assert beyond <= max(1, v.numel() // 1000) and float(diff.max()) <= max(bound, 0.05), (k, beyond, float(diff.max()), scale, noise)
+        else:
+            assert float(diff.max()) <= bound, (k, float(diff.max()), scale, noise)
         moved = max(moved, float((v - torch.as_tensor(np.asarray(c["sd." + k])).reshape(v.shape)).abs().max()) if ("sd." + k) in c else 1.0)
     assert moved > 1e-3          # the five steps did train something
 
