@@ -405,7 +405,9 @@ def lists_roofline(model, headline, hbm_leg, n_pairs, dev_s, compulsory, traffic
                    "loop of the same evaluation) and the top-level keys repeat the longest pass; compulsory_bytes = the id rows once + one packed row per "
                    "distinct term of the STEP (rows that lists share are compulsory once) + the scores; traffic = PMC bytes of ALL the call's kernels.  SURVEY 8(d)'s algorithmic bytes (every "
                    "position x a fp32 row) do not describe this route: it gathers a term once per LIST (roofline.headline_leg.algorithmic_GBps is kept "
-                   "for reference and exceeds the HBM peak)",
+                   "for reference and exceeds the HBM peak).  kernel_ms / passes[].ms are the passes of ONE call running alone (HIP events between them); with the default two "
+                   "step streams the kernels of consecutive steps overlap and stretch, so the rocprofv3 average that agrees with kernel_ms is the one of "
+                   "`bench.py --step-streams 1` (profiles/r06/knrm_bench_kernel_stats.csv; profiles/r06/README.md)",
            "headline_leg": headline}
     if hbm_leg is not None:
         out["per_pair_hbm_leg"] = {k: v for k, v in hbm_leg.items() if k != "headline_leg"}
