@@ -1868,7 +1868,9 @@ def test_graphed_training_steps_equal_eager_steps(kind, name, build):
 
     loss_e, eager = run(False)
     loss_g, graphed = run(True)
-    assert abs(loss_e - loss_g) <= 1e-6 * max(1.0, abs(loss_e))
+    # (the iteration's mean loss: ConvKNRM's follows its parameters, which MIOpen's backward moves by rounding noise from run to run - seen
+    # once in twelve runs of the whole suite: 1.2e-6 apart at a loss of 0.95 - so it gets the bound its parameters get below)
+    assert abs(loss_e - loss_g) <= (5e-5 if kind == "convknrm" else 1e-6) * max(1.0, abs(loss_e)), (loss_e, loss_g)
     # (same kernels on both routes; MIOpen's convolution backward and ATen's reductions are not bit-reproducible run to run, and Adam turns a
     # gradient component that is pure rounding noise into a step of +-lr whichever way the noise falls: ConvKNRM, whose convolutions run in
     # MIOpen, gets the wider bound - and, since one run in fifteen of the whole suite saw a component beyond it, the bound is calibrated on the
