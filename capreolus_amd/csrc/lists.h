@@ -334,7 +334,11 @@ struct DocWalk {
 __device__ __forceinline__ DocWalk doc_walk(const ListsArgs& a, int b, const int32_t* dm) {
   DocWalk w;
   w.ids = pair_ids(a.ids, b, a.Q, a.L);
+#ifdef CAPAMD_POOL_ABL_HOTIDS      // ablation: every document reads one of eight id rows (what the pooling costs when its id rows are cache-hot)
+  w.row = kCompactRows ? a.cid + (int64_t)(b & 7) * a.cid_stride : nullptr;
+#else
   w.row = kCompactRows ? a.cid + (int64_t)b * a.cid_stride : nullptr;
+#endif
   w.n = dm[6];
   w.V = a.V;
   return w;
